@@ -1,0 +1,112 @@
+"""Loader for the HIP library behind the C ABI (evergreen_amd/csrc/libevg_sched.so).
+
+There is NO CPU fallback: if the library is missing or no gfx950 device is usable this raises. The CPU
+oracle under oracle/ is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libevg_sched.so")
+
+EXPORTS = [
+    "evg_create", "evg_destroy", "evg_last_error", "evg_abi_version", "evg_validate_plan_input",
+    "evg_plan_distros", "evg_plan_distros_device", "evg_allocate_hosts", "evg_allocate_hosts_device",
+    "evg_cap_queue_device",
+]
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """dlopens the product library and sets up prototypes. No GPU is touched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError("HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'`). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.evg_create.restype = C.c_void_p
+    lib.evg_create.argtypes = [C.c_int]
+    lib.evg_destroy.argtypes = [C.c_void_p]
+    lib.evg_last_error.restype = C.c_char_p
+    lib.evg_last_error.argtypes = [C.c_void_p]
+    lib.evg_abi_version.restype = C.c_int32
+    lib.evg_validate_plan_input.argtypes = [C.POINTER(abi.PlanInput), C.c_char_p, C.c_int32]
+    lib.evg_plan_distros.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput)]
+    lib.evg_plan_distros_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p]
+    lib.evg_allocate_hosts.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput)]
+    lib.evg_allocate_hosts_device.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_void_p]
+    lib.evg_cap_queue_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+class Context:
+    """evg_ctx wrapper. Implements scheduler.Backend over host numpy buffers, and exposes the
+    device-pointer entry points for resident pools (bench.py, the multi-GPU driver)."""
+
+    def __init__(self, device_ordinal: int = 0):
+        self.lib = load_library()
+        self.h = self.lib.evg_create(device_ordinal)
+        if not self.h:
+            msg = self.lib.evg_last_error(None)
+            raise NativeError("evg_create(%d) failed: %s" % (device_ordinal, msg.decode() if msg else "?"))
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.evg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != abi.EVG_OK:
+            msg = self.lib.evg_last_error(self.h)
+            raise NativeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    # ---- scheduler.Backend -------------------------------------------------------------------
+    def plan(self, batch: abi.PlanBatch, breakdown: bool = True, n_units: bool = True) -> abi.PlanResult:
+        res = abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=n_units)
+        inp = abi.make_plan_input(batch)
+        out = res.c_output()
+        self._check(self.lib.evg_plan_distros(self.h, C.byref(inp), C.byref(out)), "evg_plan_distros")
+        return res
+
+    def allocate(self, batch: abi.PlanBatch, distro_info: np.ndarray, group_info: np.ndarray) -> abi.AllocResult:
+        res = abi.AllocResult.alloc_host(batch.n_distros)
+        inp = abi.make_alloc_input(batch, distro_info, group_info)
+        out = res.c_output()
+        self._check(self.lib.evg_allocate_hosts(self.h, C.byref(inp), C.byref(out)), "evg_allocate_hosts")
+        return res
+
+    # ---- device-resident entry points ----------------------------------------------------------
+    def plan_device(self, inp: abi.PlanInput, out: abi.PlanOutput, stream: Optional[int] = None) -> None:
+        self._check(self.lib.evg_plan_distros_device(self.h, C.byref(inp), C.byref(out), stream),
+                    "evg_plan_distros_device")
+
+    def allocate_device(self, inp: abi.AllocInput, out: abi.AllocOutput, stream: Optional[int] = None) -> None:
+        self._check(self.lib.evg_allocate_hosts_device(self.h, C.byref(inp), C.byref(out), stream),
+                    "evg_allocate_hosts_device")
+
+    def cap_queue_device(self, n_distros: int, task_off: int, order: int, tg_name_key: int, max_scheduled: int,
+                         cut: int, stream: Optional[int] = None) -> None:
+        self._check(self.lib.evg_cap_queue_device(self.h, n_distros, task_off, order, tg_name_key, max_scheduled,
+                                                  cut, stream), "evg_cap_queue_device")

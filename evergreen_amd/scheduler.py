@@ -1,0 +1,607 @@
+"""Host-side mirror of the reference's scheduler interface for the hot path.
+
+The reference is Go; its toolchain is absent here, so this module plays the part of the Go shim in
+Python for tests and tooling (the compiled C++ shim with the same job is evergreen_amd/csrc/host_shim.cpp,
+the cgo stub is in INTEGRATION.md). It keeps the reference's names and argument meaning:
+
+    PrioritizeTasks(d, tasks, opts)            <- scheduler/scheduler.go:28-33   (TaskPlanner shape, :26)
+    GetDistroQueueInfo result types            <- model/task_queue.go:22-78
+    UtilizationBasedHostAllocator(data)        <- scheduler/utilization_based_host_allocator.go:26
+    HostAllocatorData                          <- scheduler/host_allocator.go:17-21
+    capTaskQueueLength                         <- scheduler/task_queue_persister.go:66-83
+
+What it does itself is only what the boundary assigns to the host (SURVEY.md 8b'): resolve expected
+durations (a2), intern strings into dense keys, pack struct-of-arrays columns, call the backend through
+the C ABI, and re-order / stamp the caller's task objects. All arithmetic on the path is done by the
+backend (the HIP library in production; tests may plug the oracle in to check this packing layer).
+
+Times are int Unix-nanoseconds; None is Go's zero time.Time.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import abi
+
+# evergreen constants the host side needs (globals.go)
+PatchVersionRequester = "patch_request"            # globals.go:798
+GithubPRRequester = "github_pull_request"
+GitTagRequester = "git_tag_request"
+RepotrackerVersionRequester = "gitter_request"
+TriggerRequester = "trigger_request"
+AdHocRequester = "ad_hoc"
+GithubMergeRequester = "github_merge_request"
+StepbackTaskActivator = "stepback"
+TaskSucceeded, TaskFailed, TaskUndispatched = "success", "failed", "undispatched"
+AllStatuses = "*"                                  # model/task/task.go:508
+ProjectStorageMethodS3 = "s3"
+ProviderNameEc2Fleet, ProviderNameMock, ProviderNameDocker, ProviderNameStatic = "ec2-fleet", "mock", "docker", "static"
+ProviderSpawnable = (ProviderNameEc2Fleet, ProviderNameMock, ProviderNameDocker)  # globals.go:770-774
+HostAllocatorRoundDown, HostAllocatorRoundUp = "round-down", "round-up"
+HostAllocatorNoFeedback, HostAllocatorWaitsOverThreshFeedback = "no-feedback", "waits-over-thresh-feedback"
+DispatcherVersionRevisedWithDependencies = "revised-with-dependencies"  # globals.go:270
+HostAllocatorUtilization = "utilization"
+
+NS = 1
+SECOND = 10**9
+MINUTE = 60 * SECOND
+HOUR = 60 * MINUTE
+MaxDurationPerDistroHost = 30 * MINUTE             # globals.go:273
+defaultTaskDuration = 10 * MINUTE                  # model/task/task.go:65
+
+
+@dataclass
+class Dependency:                                  # model/task/task.go:442-451
+    TaskId: str
+    Status: str = ""
+    Unattainable: bool = False
+    FinishedAt: Optional[int] = None
+
+
+@dataclass
+class CachedDurationValue:                         # util/cached_value.go:88-94
+    Value: int = 0
+    StdDev: int = 0
+    TTL: int = 0
+    CollectedAt: Optional[int] = None
+
+
+@dataclass
+class Task:                                        # the model/task/task.go:96-369 fields the path reads
+    Id: str = ""
+    DistroId: str = ""
+    Version: str = ""
+    TaskGroup: str = ""
+    BuildVariant: str = ""
+    Project: str = ""
+    TaskGroupOrder: int = 0
+    TaskGroupMaxHosts: int = 0
+    Requester: str = ""
+    Priority: int = 0
+    NumDependents: int = 0
+    GenerateTask: bool = False
+    ActivatedBy: str = ""
+    ActivatedTime: Optional[int] = None
+    IngestTime: Optional[int] = None
+    ScheduledTime: Optional[int] = None
+    DependenciesMetTime: Optional[int] = None
+    StartTime: Optional[int] = None
+    OverrideDependencies: bool = False
+    DependsOn: List[Dependency] = field(default_factory=list)
+    ExpectedDuration: int = 0
+    ExpectedDurationStdDev: int = 0
+    DurationPrediction: CachedDurationValue = field(default_factory=CachedDurationValue)
+    Status: str = ""
+    CachedProjectStorageMethod: str = ""
+    # written by the planner
+    SortingValueBreakdown: Optional[Dict[str, int]] = None
+    WaitSinceDependenciesMet: int = 0
+
+    def GetTaskGroupString(self) -> str:           # task.go:436-438
+        return "%s_%s_%s_%s" % (self.TaskGroup, self.BuildVariant, self.Project, self.Version)
+
+    def Blocked(self) -> bool:                     # task.go:3688-3699
+        if self.OverrideDependencies:
+            return False
+        return any(d.Unattainable for d in self.DependsOn)
+
+    def HasDependenciesMet(self) -> bool:          # task.go:3406-3408
+        return (len(self.DependsOn) == 0 or self.OverrideDependencies
+                or not _is_zero_time(self.DependenciesMetTime))
+
+
+def _is_zero_time(t: Optional[int]) -> bool:       # utility.IsZeroTime: Go zero or the Unix epoch
+    return t is None or t == 0
+
+
+def _ts(t: Optional[int]) -> int:
+    return abi.EVG_TIME_GO_ZERO if t is None else int(t)
+
+
+def fetch_expected_duration(t: Task, now_ns: int) -> Tuple[int, int]:
+    """Task.FetchExpectedDuration (task.go:3532-3629) without the history DB: returns (avg, stddev).
+
+    Fresh prediction -> itself; zero prediction with a stored ExpectedDuration -> backfill; otherwise
+    the refresher's no-history branch: previous average if non-zero else the 10-minute default."""
+    p = t.DurationPrediction
+    if p.Value == 0 and t.ExpectedDuration != 0:
+        return t.ExpectedDuration, t.ExpectedDurationStdDev
+    collected = abi.EVG_TIME_GO_ZERO if p.CollectedAt is None else p.CollectedAt
+    since = min(now_ns - collected, 2**63 - 1)
+    ttl = p.TTL if p.TTL != 0 else 8 * HOUR        # task.go:3533-3535 (predictionTTL, jitter ignored)
+    if since < ttl:                                # CachedDurationValue.Get  cached_value.go:125-129
+        return p.Value, p.StdDev
+    if p.Value == 0:
+        return defaultTaskDuration, 0
+    return p.Value, p.StdDev
+
+
+@dataclass
+class PlannerSettings:                             # model/distro/distro.go:310-326
+    TargetTime: int = 0
+    MergeQueueTargetTime: int = 0
+    GroupVersions: Optional[bool] = None
+    PatchFactor: int = 0
+    PatchTimeInQueueFactor: int = 0
+    CommitQueueFactor: int = 0
+    MainlineTimeInQueueFactor: int = 0
+    ExpectedRuntimeFactor: int = 0
+    GenerateTaskFactor: int = 0
+    NumDependentsFactor: float = 0.0
+    StepbackTaskFactor: int = 0
+
+    def ShouldGroupVersions(self) -> bool:
+        return bool(self.GroupVersions)
+
+
+@dataclass
+class HostAllocatorSettings:                       # model/distro/distro.go:291-304
+    MinimumHosts: int = 0
+    MaximumHosts: int = 0
+    RoundingRule: str = ""
+    FeedbackRule: str = ""
+    FutureHostFraction: float = 0.0
+
+
+@dataclass
+class DispatcherSettings:
+    Version: str = ""
+
+
+@dataclass
+class Distro:
+    Id: str = ""
+    Provider: str = ""
+    Disabled: bool = False
+    PlannerSettings: PlannerSettings = field(default_factory=PlannerSettings)
+    HostAllocatorSettings: HostAllocatorSettings = field(default_factory=HostAllocatorSettings)
+    DispatcherSettings: DispatcherSettings = field(default_factory=DispatcherSettings)
+
+    def IsEphemeral(self) -> bool:                 # distro.go:513-515
+        return self.Provider in ProviderSpawnable
+
+
+@dataclass
+class Host:                                        # the model/host/host.go fields the allocator reads
+    Id: str = ""
+    RunningTask: str = ""
+    RunningTaskGroup: str = ""
+    RunningTaskBuildVariant: str = ""
+    RunningTaskProject: str = ""
+    RunningTaskVersion: str = ""
+    TaskGroupTeardownStartTime: Optional[int] = None
+
+    def IsTearingDown(self) -> bool:               # host.go:220-222
+        return self.TaskGroupTeardownStartTime is not None
+
+    def IsFree(self) -> bool:                      # host.go:215-217
+        return self.RunningTask == "" and not self.IsTearingDown()
+
+    def GetTaskGroupString(self) -> str:           # host.go:668-670
+        return "%s_%s_%s_%s" % (self.RunningTaskGroup, self.RunningTaskBuildVariant,
+                                self.RunningTaskProject, self.RunningTaskVersion)
+
+
+@dataclass
+class TaskGroupInfo:                               # model/task_queue.go:22-45
+    Name: str = ""
+    Count: int = 0
+    CountFree: int = 0
+    CountRequired: int = 0
+    MaxHosts: int = 0
+    ExpectedDuration: int = 0
+    CountDurationOverThreshold: int = 0
+    CountWaitOverThreshold: int = 0
+    CountDepFilledMergeQueueTasks: int = 0
+    DurationOverThreshold: int = 0
+
+
+@dataclass
+class DistroQueueInfo:                             # model/task_queue.go:47-78
+    Length: int = 0
+    LengthWithDependenciesMet: int = 0
+    CountDepFilledMergeQueueTasks: int = 0
+    ExpectedDuration: int = 0
+    MaxDurationThreshold: int = 0
+    PlanCreatedAt: Optional[int] = None
+    CountDurationOverThreshold: int = 0
+    DurationOverThreshold: int = 0
+    CountWaitOverThreshold: int = 0
+    NumQueuedLargeParserProjectTasks: int = 0
+    TaskGroupInfos: List[TaskGroupInfo] = field(default_factory=list)
+    SecondaryQueue: bool = False
+
+
+@dataclass
+class TaskPlannerOptions:                          # scheduler/scheduler.go:18-24
+    ID: str = ""
+    IsSecondaryQueue: bool = False
+    IncludesDependencies: bool = False
+    StartedAt: Optional[int] = None
+    MaxScheduledTasksPerDistro: int = 0
+
+
+@dataclass
+class HostAllocatorData:                           # scheduler/host_allocator.go:17-21
+    Distro: Distro
+    ExistingHosts: List[Host]
+    DistroQueueInfo: DistroQueueInfo
+
+
+class Backend:
+    """What the host layer needs from an implementation of the C ABI."""
+
+    def plan(self, batch: abi.PlanBatch, breakdown: bool = True) -> abi.PlanResult:
+        raise NotImplementedError
+
+    def allocate(self, batch: abi.PlanBatch, distro_info: np.ndarray, group_info: np.ndarray) -> abi.AllocResult:
+        raise NotImplementedError
+
+
+def _req_class(requester: str) -> int:
+    if requester == GithubMergeRequester:
+        return abi.TF_REQ_MERGE
+    if requester in (PatchVersionRequester, GithubPRRequester):
+        return abi.TF_REQ_PATCH
+    return 0
+
+
+def _status_class(status: str) -> int:
+    return 1 if status == TaskSucceeded else 2 if status == TaskFailed else 0
+
+
+def _dep_req(t: Task, dep_task_id: str) -> int:
+    """SatisfiesDependency (task.go:546-561) scans DependsOn and returns at the FIRST entry for that
+    task id whose Status is one it recognises; entries with other strings fall through."""
+    for d in t.DependsOn:
+        if d.TaskId != dep_task_id:
+            continue
+        if d.Status in (TaskSucceeded, ""):
+            return abi.DEP_REQ_SUCCESS
+        if d.Status == TaskFailed:
+            return abi.DEP_REQ_FAILED
+        if d.Status == AllStatuses:
+            return abi.DEP_REQ_ALL
+    return abi.DEP_REQ_NEVER
+
+
+DepLookup = Callable[[str], Optional[Tuple[str, bool]]]  # task id -> (Status, Blocked()) or None if not in DB
+
+
+@dataclass
+class PackedQueues:
+    batch: abi.PlanBatch
+    tasks: List[List[Task]]            # per distro, input order (row = task_off[d] + i)
+    tg_names: List[str]                # tg key -> group string
+    tg_key_of: List[Dict[str, int]]    # per distro: group string -> key
+
+
+def pack_queues(queues: Sequence[Tuple[Distro, Sequence[Task]]], now_ns: int,
+                dep_lookup: Optional[DepLookup] = None,
+                includes_dependencies: Optional[Sequence[bool]] = None) -> PackedQueues:
+    """Interns strings and lays the D (distro, tasks) queues out as the ABI's struct-of-arrays.
+
+    Does what PopulateCaches (setup_funcs.go:18-67) leaves behind -- resolved durations -- plus the
+    string->key interning of SURVEY.md 8b'. Keys are numbered in order of first appearance per distro."""
+    D = len(queues)
+    n = sum(len(ts) for _, ts in queues)
+    cols = {k: np.zeros(n, dt) for k, dt in abi.TASK_COLUMNS.items()}
+    tg_name_key = np.full(n, -1, np.int32)
+    task_off = np.zeros(D + 1, np.int32)
+    tg_off = np.zeros(D + 1, np.int32)
+    ver_off = np.zeros(D + 1, np.int32)
+    distros = np.zeros(D, abi.DISTRO_PARAMS_DTYPE)
+    dep_off = [0]
+    dep_idx: List[int] = []
+    dep_info: List[int] = []
+    dep_fin: List[int] = []
+    tg_names: List[str] = []
+    tg_key_of: List[Dict[str, int]] = []
+    bare_names: Dict[str, int] = {}
+    r = 0
+    n_tg = n_ver = 0
+    for d, (distro, tasks) in enumerate(queues):
+        task_off[d], tg_off[d], ver_off[d] = r, n_tg, n_ver
+        ps = distro.PlannerSettings
+        row = distros[d]
+        row["patch_factor"], row["patch_time_in_queue_factor"] = ps.PatchFactor, ps.PatchTimeInQueueFactor
+        row["commit_queue_factor"] = ps.CommitQueueFactor
+        row["mainline_time_in_queue_factor"] = ps.MainlineTimeInQueueFactor
+        row["expected_runtime_factor"], row["generate_task_factor"] = ps.ExpectedRuntimeFactor, ps.GenerateTaskFactor
+        row["stepback_task_factor"], row["num_dependents_factor"] = ps.StepbackTaskFactor, ps.NumDependentsFactor
+        row["target_time_ns"], row["merge_queue_target_time_ns"] = ps.TargetTime, ps.MergeQueueTargetTime
+        row["group_versions"] = 1 if ps.ShouldGroupVersions() else 0
+        inc = (distro.DispatcherSettings.Version == DispatcherVersionRevisedWithDependencies
+               if includes_dependencies is None else includes_dependencies[d])
+        row["includes_dependencies"] = 1 if inc else 0
+
+        row_of = {t.Id: r + i for i, t in enumerate(tasks)}
+        tgk: Dict[str, int] = {}
+        verk: Dict[str, int] = {}
+        for i, t in enumerate(tasks):
+            x = r + i
+            cols["priority"][x] = t.Priority
+            cols["expected_duration_ns"][x] = fetch_expected_duration(t, now_ns)[0]
+            # planner.go:318-322: ActivatedTime unless IsZero(), else IngestTime unless IsZero()
+            q = t.ActivatedTime if t.ActivatedTime is not None else t.IngestTime
+            cols["queue_ts_ns"][x] = _ts(q)
+            cols["scheduled_ts_ns"][x] = _ts(t.ScheduledTime)
+            cols["deps_met_ts_ns"][x] = _ts(t.DependenciesMetTime)
+            cols["num_dependents"][x] = t.NumDependents
+            cols["task_group_order"][x] = t.TaskGroupOrder
+            cols["task_group_max_hosts"][x] = t.TaskGroupMaxHosts
+            if t.TaskGroup != "":
+                s = t.GetTaskGroupString()
+                if s not in tgk:
+                    tgk[s] = n_tg + len(tgk)
+                    tg_names.append(s)
+                cols["tg_key"][x] = tgk[s]
+                tg_name_key[x] = bare_names.setdefault(t.TaskGroup, len(bare_names))
+            else:
+                cols["tg_key"][x] = -1
+            if t.Version not in verk:
+                verk[t.Version] = n_ver + len(verk)
+            cols["version_key"][x] = verk[t.Version]
+            f = _req_class(t.Requester)
+            f |= abi.TF_GENERATE if t.GenerateTask else 0
+            f |= abi.TF_STEPBACK if t.ActivatedBy == StepbackTaskActivator else 0
+            f |= abi.TF_OVERRIDE_DEPS if t.OverrideDependencies else 0
+            f |= abi.TF_OTHER_DISTRO if t.DistroId != distro.Id else 0
+            f |= abi.TF_S3_STORAGE if t.CachedProjectStorageMethod == ProjectStorageMethodS3 else 0
+            f |= abi.TF_BLOCKED if t.Blocked() else 0
+            f |= _status_class(t.Status) << abi.TF_STATUS_SHIFT
+            cols["flags"][x] = f
+            for dep in t.DependsOn:
+                info = _dep_req(t, dep.TaskId)
+                j = row_of.get(dep.TaskId, -1)
+                if j < 0:
+                    found = dep_lookup(dep.TaskId) if dep_lookup else None
+                    if found is None:
+                        info |= abi.DEP_MISSING
+                    else:
+                        info |= _status_class(found[0]) << abi.DEP_STATE_SHIFT
+                        info |= abi.DEP_BLOCKED if found[1] else 0
+                dep_idx.append(j)
+                dep_info.append(info)
+                dep_fin.append(0 if dep.FinishedAt is None else dep.FinishedAt)
+            dep_off.append(len(dep_idx))
+        tg_key_of.append(tgk)
+        r += len(tasks)
+        n_tg += len(tgk)
+        n_ver += len(verk)
+    task_off[D], tg_off[D], ver_off[D] = r, n_tg, n_ver
+    edges = {"dep_idx": np.asarray(dep_idx, np.int32), "dep_info": np.asarray(dep_info, np.uint8),
+             "dep_finished_ts_ns": np.asarray(dep_fin, np.int64)}
+    batch = abi.PlanBatch(n_distros=D, now_ns=now_ns, cols=cols, dep_off=np.asarray(dep_off, np.int32),
+                          edges=edges, distros=distros, task_off=task_off, tg_off=tg_off, ver_off=ver_off,
+                          tg_name_key=tg_name_key)
+    batch.check()
+    return PackedQueues(batch, [list(ts) for _, ts in queues], tg_names, tg_key_of)
+
+
+def _info_from_rows(packed: PackedQueues, res: abi.PlanResult, d: int) -> DistroQueueInfo:
+    b = packed.batch
+    di = res.distro_info[d]
+    info = DistroQueueInfo(
+        Length=int(di["length"]), LengthWithDependenciesMet=int(di["length_with_dependencies_met"]),
+        CountDepFilledMergeQueueTasks=int(di["count_dep_filled_merge_queue_tasks"]),
+        ExpectedDuration=int(di["expected_duration_ns"]), MaxDurationThreshold=int(di["max_duration_threshold_ns"]),
+        CountDurationOverThreshold=int(di["count_duration_over_threshold"]),
+        DurationOverThreshold=int(di["duration_over_threshold_ns"]),
+        CountWaitOverThreshold=int(di["count_wait_over_threshold"]),
+        NumQueuedLargeParserProjectTasks=int(di["num_queued_large_parser_project_tasks"]),
+        SecondaryQueue=bool(di["secondary_queue"]))
+    rows = [(d, "")] + [(b.n_distros + k, packed.tg_names[k]) for k in range(int(b.tg_off[d]), int(b.tg_off[d + 1]))]
+    for ri, name in rows:
+        g = res.group_info[ri]
+        if not g["present"]:
+            continue
+        info.TaskGroupInfos.append(TaskGroupInfo(
+            Name=name, Count=int(g["count"]), CountFree=int(g["count_free"]), CountRequired=int(g["count_required"]),
+            MaxHosts=int(g["max_hosts"]), ExpectedDuration=int(g["expected_duration_ns"]),
+            CountDurationOverThreshold=int(g["count_duration_over_threshold"]),
+            CountWaitOverThreshold=int(g["count_wait_over_threshold"]),
+            CountDepFilledMergeQueueTasks=int(g["count_dep_filled_merge_queue_tasks"]),
+            DurationOverThreshold=int(g["duration_over_threshold_ns"])))
+    return info
+
+
+def PlanDistros(backend: Backend, queues: Sequence[Tuple[Distro, Sequence[Task]]], now_ns: int,
+                opts: Optional[Sequence[TaskPlannerOptions]] = None,
+                dep_lookup: Optional[DepLookup] = None,
+                includes_dependencies: Optional[Sequence[bool]] = None) -> List[Tuple[List[Task], DistroQueueInfo]]:
+    """Batched form of runTunablePlanner minus persistence (scheduler.go:35-52): for every (distro, tasks)
+    returns (plan, DistroQueueInfo) with plan = the same Task objects re-ordered and stamped.
+    IncludesDependencies is derived from DispatcherSettings.Version as PrioritizeTasks does (:29) unless
+    `includes_dependencies` overrides it (for callers of GetDistroQueueInfo itself)."""
+    packed = pack_queues(queues, now_ns, dep_lookup, includes_dependencies)
+    res = backend.plan(packed.batch, breakdown=True)
+    out = []
+    b = packed.batch
+    names = list(abi.BD)
+    for d in range(b.n_distros):
+        lo, hi = int(b.task_off[d]), int(b.task_off[d + 1])
+        plan = []
+        for p in range(lo, hi):
+            row = int(res.order[p])
+            t = packed.tasks[d][row - lo]
+            t.SortingValueBreakdown = {k: int(res.breakdown[row, abi.BD[k]]) for k in names}
+            t.WaitSinceDependenciesMet = int(res.wait_ns[row])
+            if res.deps_met[row] and _is_zero_time(t.DependenciesMetTime) and t.DependsOn and not t.OverrideDependencies:
+                # Task.setDependenciesMetTime (task.go:690-701), observable through HasDependenciesMet()
+                fin = [x.FinishedAt for x in t.DependsOn if not _is_zero_time(x.FinishedAt) and x.FinishedAt > 0]
+                t.DependenciesMetTime = max(fin) if fin else now_ns
+            plan.append(t)
+        info = _info_from_rows(packed, res, d)
+        if opts is not None:
+            info.SecondaryQueue = opts[d].IsSecondaryQueue      # scheduler.go:45
+            info.PlanCreatedAt = opts[d].StartedAt              # scheduler.go:46
+        out.append((plan, info))
+    return out
+
+
+def PrioritizeTasks(backend: Backend, d: Distro, tasks: Sequence[Task], opts: TaskPlannerOptions,
+                    now_ns: int, dep_lookup: Optional[DepLookup] = None) -> Tuple[List[Task], DistroQueueInfo]:
+    """scheduler.PrioritizeTasks (scheduler.go:28-33) for one distro: a batch of one."""
+    return PlanDistros(backend, [(d, tasks)], now_ns, [opts], dep_lookup)[0]
+
+
+def make_task_planner(backend: Backend, now_ns: int) -> Callable[[Distro, Sequence[Task], TaskPlannerOptions], List[Task]]:
+    """A value of the reference's TaskPlanner type: func(*distro.Distro, []task.Task, TaskPlannerOptions)
+    ([]task.Task, error)  -- scheduler/scheduler.go:26. Errors surface as exceptions."""
+    def planner(d: Distro, tasks: Sequence[Task], opts: TaskPlannerOptions) -> List[Task]:
+        return PrioritizeTasks(backend, d, tasks, opts, now_ns)[0]
+    return planner
+
+
+def capTaskQueueLength(tasks: Sequence[Task], maxScheduledTasks: int) -> List[Task]:
+    """scheduler/task_queue_persister.go:66-83 on already-ordered host objects (the device-side version
+    for the batched path is evg_cap_queue_device)."""
+    if maxScheduledTasks <= 0 or len(tasks) <= maxScheduledTasks:
+        return list(tasks)
+    cut = maxScheduledTasks
+    while cut < len(tasks) and tasks[cut].TaskGroup != "" and tasks[cut].TaskGroup == tasks[cut - 1].TaskGroup:
+        cut += 1
+    return list(tasks[:cut])
+
+
+class AllocatorError(Exception):
+    pass
+
+
+RunningTaskLookup = Callable[[str], Optional[Task]]
+
+
+def pack_hosts(batch: abi.PlanBatch, datas: Sequence[HostAllocatorData], tg_key_of: Sequence[Dict[str, int]],
+               running: Optional[RunningTaskLookup], now_ns: int) -> None:
+    """Fills batch.alloc_params / host_off / hosts from HostAllocatorData rows (one per distro)."""
+    D = len(datas)
+    params = np.zeros(D, abi.ALLOC_PARAMS_DTYPE)
+    host_off = np.zeros(D + 1, np.int32)
+    cols: Dict[str, list] = {k: [] for k in abi.HOST_COLUMNS}
+    for d, data in enumerate(datas):
+        s = data.Distro.HostAllocatorSettings
+        p = params[d]
+        p["future_host_fraction"], p["minimum_hosts"], p["maximum_hosts"] = s.FutureHostFraction, s.MinimumHosts, s.MaximumHosts
+        p["provider"] = 2 if data.Distro.Provider == ProviderNameDocker else 1 if data.Distro.IsEphemeral() else 0
+        p["disabled"] = 1 if data.Distro.Disabled else 0
+        p["round_up"] = 1 if s.RoundingRule == HostAllocatorRoundUp else 0
+        p["feedback_waits_over_thresh"] = 1 if s.FeedbackRule == HostAllocatorWaitsOverThreshFeedback else 0
+        host_off[d] = len(cols["flags"])
+        for h in data.ExistingHosts:
+            f = abi.HF_FREE if h.IsFree() else 0
+            key, start, exp, sd = -1, 0, 0, 0
+            if h.RunningTask != "":
+                f |= abi.HF_RUNNING
+                if h.RunningTaskGroup != "":
+                    key = tg_key_of[d].get(h.GetTaskGroupString(), -2)
+                t = running(h.RunningTask) if running else None
+                if t is not None:
+                    f |= abi.HF_RUNNING_FOUND
+                    exp, sd = fetch_expected_duration(t, now_ns)
+                    start = _ts(t.StartTime)
+            cols["flags"].append(f)
+            cols["tg_key"].append(key)
+            cols["start_ts_ns"].append(start)
+            cols["expected_duration_ns"].append(exp)
+            cols["duration_stddev_ns"].append(sd)
+    host_off[D] = len(cols["flags"])
+    batch.alloc_params, batch.host_off = params, host_off
+    batch.hosts = {k: np.asarray(v, dt) for (k, dt), v in zip(abi.HOST_COLUMNS.items(), cols.values())}
+
+
+def AllocateHosts(backend: Backend, datas: Sequence[HostAllocatorData], now_ns: int,
+                  running: Optional[RunningTaskLookup] = None) -> List[Tuple[int, int, Optional[str]]]:
+    """Batched UtilizationBasedHostAllocator: one HostAllocatorData per distro -> (newHostsNeeded,
+    estimatedFreeHosts, error-or-None). Writes CountFree/CountRequired back into
+    data.DistroQueueInfo.TaskGroupInfos IN PLACE like the reference (...allocator.go:106-109)."""
+    D = len(datas)
+    tg_names: List[str] = []
+    tg_key_of: List[Dict[str, int]] = []
+    tg_off = np.zeros(D + 1, np.int32)
+    for d, data in enumerate(datas):
+        tg_off[d] = len(tg_names)
+        m: Dict[str, int] = {}
+        for gi in data.DistroQueueInfo.TaskGroupInfos:
+            if gi.Name != "" and gi.Name not in m:
+                m[gi.Name] = len(tg_names)
+                tg_names.append(gi.Name)
+        tg_key_of.append(m)
+    tg_off[D] = len(tg_names)
+    G = len(tg_names)
+    distro_info = np.zeros(D, abi.DISTRO_INFO_DTYPE)
+    group_info = np.zeros(D + G, abi.GROUP_INFO_DTYPE)
+    for d, data in enumerate(datas):
+        q = data.DistroQueueInfo
+        distro_info[d]["length"] = q.Length
+        distro_info[d]["length_with_dependencies_met"] = q.LengthWithDependenciesMet
+        distro_info[d]["max_duration_threshold_ns"] = q.MaxDurationThreshold
+        for gi in q.TaskGroupInfos:
+            # groupByTaskGroup builds a name->info map (:228-231): a later duplicate name wins
+            g = group_info[d if gi.Name == "" else D + tg_key_of[d][gi.Name]]
+            g["present"], g["count"], g["max_hosts"] = 1, gi.Count, gi.MaxHosts
+            g["expected_duration_ns"], g["duration_over_threshold_ns"] = gi.ExpectedDuration, gi.DurationOverThreshold
+            g["count_duration_over_threshold"] = gi.CountDurationOverThreshold
+            g["count_wait_over_threshold"] = gi.CountWaitOverThreshold
+            g["count_dep_filled_merge_queue_tasks"] = gi.CountDepFilledMergeQueueTasks
+            g["count_free"], g["count_required"] = gi.CountFree, gi.CountRequired
+    zeros = np.zeros(D + 1, np.int32)
+    batch = abi.PlanBatch(n_distros=D, now_ns=now_ns, cols={k: np.zeros(0, dt) for k, dt in abi.TASK_COLUMNS.items()},
+                          dep_off=np.zeros(1, np.int32), edges={k: np.zeros(0, dt) for k, dt in abi.EDGE_COLUMNS.items()},
+                          distros=np.zeros(D, abi.DISTRO_PARAMS_DTYPE), task_off=zeros, tg_off=tg_off, ver_off=zeros)
+    pack_hosts(batch, datas, tg_key_of, running, now_ns)
+    res = backend.allocate(batch, distro_info, group_info)
+    out = []
+    for d, data in enumerate(datas):
+        st = int(res.status[d])
+        err = None
+        if st == abi.EVG_ALLOC_E_FUTURE_FRACTION:
+            err = "calculating hosts for distro '%s': future host factor cannot be greater than 1" % data.Distro.Id
+        elif st == abi.EVG_ALLOC_E_POOL_SIZE:
+            err = ("calculating hosts for distro '%s': unable to plan hosts for distro %s due to pool size of %d"
+                   % (data.Distro.Id, data.Distro.Id, data.Distro.HostAllocatorSettings.MaximumHosts))
+        for gi in data.DistroQueueInfo.TaskGroupInfos:
+            if gi.Name != "":
+                g = group_info[D + tg_key_of[d][gi.Name]]
+                gi.CountFree, gi.CountRequired = int(g["count_free"]), int(g["count_required"])
+        out.append((int(res.new_hosts[d]), int(res.free_hosts[d]), err))
+    return out
+
+
+def UtilizationBasedHostAllocator(backend: Backend, data: HostAllocatorData, now_ns: int,
+                                  running: Optional[RunningTaskLookup] = None) -> Tuple[int, int]:
+    """A value of the reference's HostAllocator type (scheduler/host_allocator.go:15) for one distro;
+    the `error` return becomes AllocatorError carrying the (0, len(freeHosts)) the reference returns."""
+    n, free, err = AllocateHosts(backend, [data], now_ns, running)[0]
+    if err is not None:
+        e = AllocatorError(err)
+        e.result = (n, free)
+        raise e
+    return n, free
+
+
+def GetHostAllocator(name: str):                   # scheduler/host_allocator.go:23-30
+    return UtilizationBasedHostAllocator

@@ -1,0 +1,327 @@
+/*
+ * evg_sched.h -- C ABI of the MI355X-native Evergreen per-distro scheduling hot path.
+ *
+ * This is the drop-in boundary: a cgo-callable, plain-C surface (pointers
+ * and sizes only, no callbacks, no retained caller memory) that replaces, for MANY distros in one
+ * batched call, the bodies behind the reference's two Go function-value types
+ *
+ *     type TaskPlanner   func(*distro.Distro, []task.Task, TaskPlannerOptions) ([]task.Task, error)
+ *                                                      /root/reference/scheduler/scheduler.go:26
+ *     type HostAllocator func(context.Context, *HostAllocatorData) (int, int, error)
+ *                                                      /root/reference/scheduler/host_allocator.go:15
+ *
+ * Every entry point below cites the reference code it replaces. The Go-side binding a maintainer
+ * would add (cgo stub) is in INTEGRATION.md.
+ *
+ * Layout contract (checked by evg_validate_plan_input; the host shim guarantees it):
+ *   - Tasks are struct-of-arrays rows grouped by distro: rows [task_off[d], task_off[d+1]) belong to
+ *     distro d. "Input index" of a task == its row number; the canonical tie-break uses it.
+ *   - Strings never cross the ABI. Task ids, task-group strings (Task.GetTaskGroupString(),
+ *     model/task/task.go:436-438) and version ids are interned by the caller into dense int32 keys:
+ *       tg_key      : -1 when Task.TaskGroup == "", else in [tg_off[d], tg_off[d+1])
+ *       version_key : in [ver_off[d], ver_off[d+1])
+ *     Keys of one distro are numbered in order of FIRST APPEARANCE in that distro's rows (key k first
+ *     occurs after every key < k has occurred). One string maps to one key per distro.
+ *   - A dependency edge stores the ROW of the dependency when that task is in the SAME distro's
+ *     segment (the planner's cache.Exists(dep.TaskId), scheduler/planner.go:453, and
+ *     GetDistroQueueInfo's depCache, scheduler/scheduler.go:62-65), else -1 plus the resolved state
+ *     of the out-of-queue task (what Task.DependenciesMet fetches from the DB, task.go:649-688).
+ *   - All times are int64 Unix nanoseconds (0 is the Unix epoch == utility.ZeroTime). Go's zero
+ *     time.Time (year 1, Time.IsZero()) is not representable in Unix ns and is encoded as
+ *     EVG_TIME_GO_ZERO (INT64_MIN). Durations are computed like Go's Time.Sub: saturating at
+ *     +/- (2^63-1), so time.Since(<Go zero>) == MaxInt64 exactly as in the reference. `now_ns`
+ *     replaces every time.Since()/time.Now() on the path.
+ */
+#ifndef EVG_SCHED_H
+#define EVG_SCHED_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Go's zero time.Time (Time.IsZero()); sorts before every real time, like in Go. */
+#define EVG_TIME_GO_ZERO INT64_MIN
+
+/* ---- return codes of the entry points ------------------------------------------------------ */
+#define EVG_OK 0
+#define EVG_E_INVALID (-1)  /* NULL / negative size / inconsistent offsets                        */
+#define EVG_E_HIP (-2)      /* HIP runtime or launch failure (message via evg_last_error)         */
+#define EVG_E_NOMEM (-3)    /* device or host allocation failed                                  */
+#define EVG_E_CONTRACT (-4) /* input violates the layout contract above                          */
+#define EVG_E_NODEVICE (-5) /* no gfx950 device / HIP runtime unavailable: there is NO CPU fallback */
+
+/* ---- per-distro allocator status (out_status[d]); mirrors the reference's error returns ----- */
+#define EVG_ALLOC_OK 0
+/* "future host factor cannot be greater than 1"  utilization_based_host_allocator.go:287-289 */
+#define EVG_ALLOC_E_FUTURE_FRACTION 1
+/* "unable to plan hosts for distro %s due to pool size of %d"  ...allocator.go:185-187 */
+#define EVG_ALLOC_E_POOL_SIZE 2
+
+/* ---- task flag bits (evg_task_soa.flags) --------------------------------------------------- */
+#define EVG_TF_REQ_MASK 0x0003u      /* requester class: 0 other (mainline/trigger/ad hoc),
+                                        1 patch  (patch_request | github_pull_request),
+                                        2 merge queue (github_merge_request)
+                                        globals.go:798-804,1224-1242; planner.go:308-312        */
+#define EVG_TF_REQ_PATCH 1u
+#define EVG_TF_REQ_MERGE 2u
+#define EVG_TF_GENERATE 0x0004u      /* Task.GenerateTask                    planner.go:315      */
+#define EVG_TF_STEPBACK 0x0008u      /* Task.ActivatedBy == "stepback"       planner.go:316      */
+#define EVG_TF_OVERRIDE_DEPS 0x0010u /* Task.OverrideDependencies            task.go:3406-3408   */
+#define EVG_TF_OTHER_DISTRO 0x0020u  /* Task.DistroId != d.Id                scheduler.go:89     */
+#define EVG_TF_S3_STORAGE 0x0040u    /* CachedProjectStorageMethod == "s3"   scheduler.go:120    */
+#define EVG_TF_BLOCKED 0x0080u       /* Task.Blocked(): an Unattainable dep and !Override
+                                        task.go:3688-3699 (read when this row is someone's dep) */
+#define EVG_TF_STATUS_SHIFT 8        /* 2 bits, this row's Task.Status as seen by a dependent:
+                                        0 anything else (undispatched, started, ...),
+                                        1 "success", 2 "failed"              task.go:546-561     */
+#define EVG_TF_STATUS_MASK 0x0300u
+
+/* ---- dependency edge byte (evg_task_soa.dep_info) ------------------------------------------ */
+#define EVG_DEP_REQ_MASK 0x03u     /* required status of the edge (task.go:550-557):
+                                      0 "" or "success", 1 "failed", 2 "*" (AllStatuses),
+                                      3 unrecognised string => never satisfied                  */
+#define EVG_DEP_STATE_SHIFT 2      /* for dep_idx == -1 only: status class of the fetched task,  */
+#define EVG_DEP_STATE_MASK 0x0Cu   /*   0 other, 1 "success", 2 "failed"                         */
+#define EVG_DEP_BLOCKED 0x10u      /* for dep_idx == -1 only: fetched task .Blocked()            */
+#define EVG_DEP_MISSING 0x20u      /* for dep_idx == -1 only: not in DB => DependenciesMet errors
+                                      => unmet (scheduler.go:180-186)                           */
+
+/* Number of int64 fields in a task.SortingValueBreakdown row (model/task/task.go:4060-4108). */
+#define EVG_BREAKDOWN_FIELDS 13
+enum evg_breakdown_field {
+  EVG_BD_TASK_GROUP_LENGTH = 0,
+  EVG_BD_TOTAL_VALUE = 1,
+  EVG_BD_PRI_INITIAL = 2,        /* PriorityBreakdown.InitialPriorityImpact */
+  EVG_BD_PRI_TASK_GROUP = 3,     /* PriorityBreakdown.TaskGroupImpact       */
+  EVG_BD_PRI_GENERATOR = 4,      /* PriorityBreakdown.GeneratorTaskImpact   */
+  EVG_BD_PRI_COMMIT_QUEUE = 5,   /* PriorityBreakdown.CommitQueueImpact     */
+  EVG_BD_RANK_COMMIT_QUEUE = 6,  /* RankValueBreakdown.CommitQueueImpact    */
+  EVG_BD_RANK_NUM_DEPENDENTS = 7,
+  EVG_BD_RANK_EST_RUNTIME = 8,
+  EVG_BD_RANK_MAINLINE_WAIT = 9,
+  EVG_BD_RANK_STEPBACK = 10,
+  EVG_BD_RANK_PATCH = 11,
+  EVG_BD_RANK_PATCH_WAIT = 12
+};
+
+/* ---- inputs --------------------------------------------------------------------------------- */
+
+/* The runnable-task pool, struct-of-arrays (SURVEY.md 8b' column map). All arrays have n_tasks
+ * entries unless noted. For the *_device entry points every pointer is a device pointer. */
+typedef struct evg_task_soa {
+  int32_t n_tasks;  /* N */
+  int32_t n_edges;  /* E = dep_off[N] */
+  const int64_t* priority;              /* Task.Priority                planner.go:324-327,400 */
+  const int64_t* expected_duration_ns;  /* resolved FetchExpectedDuration().Average
+                                           planner.go:328,404; scheduler.go:87                */
+  const int64_t* queue_ts_ns;           /* ActivatedTime if !IsZero() else IngestTime if
+                                           !IsZero() else EVG_TIME_GO_ZERO (contributes 0)
+                                                                         planner.go:318-322     */
+  const int64_t* scheduled_ts_ns;       /* Task.ScheduledTime           scheduler.go:137       */
+  const int64_t* deps_met_ts_ns;        /* Task.DependenciesMetTime; utility.IsZeroTime() <=>
+                                           value is 0 or EVG_TIME_GO_ZERO
+                                           task.go:3406-3408; scheduler.go:138-140             */
+  const int32_t* num_dependents;        /* Task.NumDependents           planner.go:329-332,396 */
+  const int32_t* task_group_order;      /* Task.TaskGroupOrder          planner.go:392         */
+  const int32_t* task_group_max_hosts;  /* Task.TaskGroupMaxHosts       scheduler.go:105       */
+  const int32_t* tg_key;                /* interned GetTaskGroupString(), -1 = no task group   */
+  const int32_t* version_key;           /* interned Task.Version        planner.go:439,441     */
+  const uint16_t* flags;                /* EVG_TF_*                                            */
+  const int32_t* dep_off;               /* CSR, N+1 entries: edges of row i are
+                                           [dep_off[i], dep_off[i+1])   Task.DependsOn          */
+  const int32_t* dep_idx;               /* E entries: row of the dependency, or -1             */
+  const uint8_t* dep_info;              /* E entries: EVG_DEP_*                                */
+  const int64_t* dep_finished_ts_ns;    /* E entries or NULL (= all zero): Dependency.FinishedAt,
+                                           read by setDependenciesMetTime  task.go:690-701     */
+} evg_task_soa;
+
+/* Resolved planner settings of one distro. RAW values: the library applies the reference's getters
+ * (<= 0 -> 1, model/distro/distro.go:379-434) and target-time defaults (0 -> 30 min,
+ * distro.go:448-475) itself. */
+typedef struct evg_distro_params {
+  int64_t patch_factor;
+  int64_t patch_time_in_queue_factor;
+  int64_t commit_queue_factor;
+  int64_t mainline_time_in_queue_factor;
+  int64_t expected_runtime_factor;
+  int64_t generate_task_factor;
+  int64_t stepback_task_factor;
+  double num_dependents_factor;
+  int64_t target_time_ns;             /* PlannerSettings.TargetTime; 0 => MaxDurationPerHost() */
+  int64_t merge_queue_target_time_ns; /* PlannerSettings.MergeQueueTargetTime; <= 0 => unused  */
+  int32_t group_versions;             /* PlannerSettings.ShouldGroupVersions()                 */
+  int32_t includes_dependencies;      /* DispatcherSettings.Version ==
+                                         "revised-with-dependencies"   scheduler.go:29          */
+} evg_distro_params;
+
+/* The batch: D distros over one task pool. */
+typedef struct evg_plan_input {
+  int32_t n_distros;                  /* D */
+  int32_t n_task_groups;              /* tg_off[D]  */
+  int32_t n_versions;                 /* ver_off[D] */
+  int32_t reserved;
+  evg_task_soa tasks;
+  const evg_distro_params* distros;   /* D rows */
+  const int32_t* task_off;            /* D+1 */
+  const int32_t* tg_off;              /* D+1 */
+  const int32_t* ver_off;             /* D+1 */
+  int64_t now_ns;
+} evg_plan_input;
+
+/* ---- outputs -------------------------------------------------------------------------------- */
+
+/* model.TaskGroupInfo (model/task_queue.go:22-45) without the name: the row index is the name.
+ * Row d (d < D) is distro d's standalone bucket (Name == ""); row D + k is task-group key k. */
+typedef struct evg_group_info {
+  int64_t expected_duration_ns;
+  int64_t duration_over_threshold_ns;
+  int32_t count;
+  int32_t max_hosts;                /* first-seen-in-QUEUE-order task's TaskGroupMaxHosts
+                                       scheduler.go:103-106                                     */
+  int32_t count_duration_over_threshold;
+  int32_t count_wait_over_threshold;
+  int32_t count_dep_filled_merge_queue_tasks;
+  int32_t present;                  /* 1 iff the reference's TaskGroupInfos would hold this row */
+  int32_t count_free;               /* written by evg_allocate_hosts  ...allocator.go:106-109   */
+  int32_t count_required;           /* written by evg_allocate_hosts                            */
+} evg_group_info;
+
+/* model.DistroQueueInfo (model/task_queue.go:47-78). secondary_queue is the COMPUTED value
+ * (scheduler.go:89-91); runTunablePlanner then overwrites it with opts.IsSecondaryQueue and sets
+ * PlanCreatedAt (scheduler.go:45-46) -- that stays in the Go shim. */
+typedef struct evg_distro_info {
+  int64_t expected_duration_ns;
+  int64_t max_duration_threshold_ns;
+  int64_t duration_over_threshold_ns;
+  int32_t length;
+  int32_t length_with_dependencies_met;
+  int32_t count_dep_filled_merge_queue_tasks;
+  int32_t count_duration_over_threshold;
+  int32_t count_wait_over_threshold;
+  int32_t num_queued_large_parser_project_tasks;
+  int32_t secondary_queue;
+  int32_t n_task_group_infos;       /* len(TaskGroupInfos) */
+} evg_distro_info;
+
+typedef struct evg_plan_output {
+  int32_t* order;          /* N: order[task_off[d] + p] = row of the task at queue position p of
+                              distro d  (TaskPlan.Export, planner.go:462-481)                    */
+  int64_t* breakdown;      /* N x 13 by ROW (task.SortingValueBreakdown stamped at planner.go:475),
+                              or NULL to skip                                                    */
+  uint8_t* deps_met;       /* N by row: checkDependenciesMet result (scheduler.go:70-76); this is
+                              also Task.HasDependenciesMet() after the call (persister :47)      */
+  int64_t* wait_ns;        /* N by row: Task.WaitSinceDependenciesMet (scheduler.go:141), 0 when
+                              the reference leaves it untouched                                  */
+  evg_distro_info* distro_info; /* D */
+  evg_group_info* group_info;   /* D + n_task_groups */
+  int32_t* n_units;        /* D: TaskPlan.Len() after UnitCache.Export dedup (planner.go:73-89),
+                              or NULL to skip                                                    */
+} evg_plan_output;
+
+/* ---- allocator inputs ----------------------------------------------------------------------- */
+
+/* distro.HostAllocatorSettings + the few Distro fields the allocator reads
+ * (utilization_based_host_allocator.go:29,39,51,95,142,162,167). */
+typedef struct evg_alloc_params {
+  double future_host_fraction;
+  int32_t minimum_hosts;
+  int32_t maximum_hosts;
+  int32_t provider;   /* 0 not ephemeral (static, ...), 1 ephemeral (ec2-fleet, mock),
+                         2 docker (ephemeral, exempt from the max-hosts early-out :39)
+                         globals.go:767-774 */
+  int32_t disabled;   /* Distro.Disabled                                                :51 */
+  int32_t round_up;   /* RoundingRule == "round-up"                                     :162 */
+  int32_t feedback_waits_over_thresh; /* FeedbackRule == "waits-over-thresh-feedback"   :167 */
+} evg_alloc_params;
+
+#define EVG_HF_FREE 0x01u         /* Host.IsFree(): RunningTask == "" && !IsTearingDown()
+                                     model/host/host.go:215-222                                 */
+#define EVG_HF_RUNNING 0x02u      /* RunningTask != ""  ...allocator.go:313                     */
+#define EVG_HF_RUNNING_FOUND 0x04u/* the running task was found by task.Find(ByIds) (:322); only
+                                     then do start/exp/stddev contribute a fraction             */
+
+typedef struct evg_host_soa {
+  int32_t n_hosts;
+  int32_t reserved;
+  const uint8_t* flags;            /* EVG_HF_* */
+  const int32_t* tg_key;           /* bucket of groupByTaskGroup (:208-224): -1 = "" ; >= 0 = the
+                                      interned host.GetTaskGroupString() when RunningTask != "" &&
+                                      RunningTaskGroup != "" and that string is a task-group key of
+                                      this distro's queue; -2 = a group string not in the queue   */
+  const int64_t* start_ts_ns;      /* running task StartTime                                :345 */
+  const int64_t* expected_duration_ns; /* running task FetchExpectedDuration().Average      :343 */
+  const int64_t* duration_stddev_ns;   /* running task FetchExpectedDuration().StdDev       :344 */
+} evg_host_soa;
+
+typedef struct evg_alloc_input {
+  int32_t n_distros;
+  int32_t n_task_groups;
+  const evg_alloc_params* params;       /* D */
+  const int32_t* host_off;              /* D+1 */
+  const int32_t* tg_off;                /* D+1 (same as the plan's) */
+  evg_host_soa hosts;
+  const evg_distro_info* distro_info;   /* D, from evg_plan_distros (what the allocator job reads
+                                           back from Mongo, units/host_allocator.go:144)         */
+  evg_group_info* group_info;           /* D + n_task_groups, in/out: count_free/count_required  */
+  int64_t now_ns;
+} evg_alloc_input;
+
+typedef struct evg_alloc_output {
+  int32_t* new_hosts;   /* D: newHostsNeeded      */
+  int32_t* free_hosts;  /* D: estimatedFreeHosts  */
+  int32_t* status;      /* D: EVG_ALLOC_*         */
+} evg_alloc_output;
+
+/* ---- entry points --------------------------------------------------------------------------- */
+
+typedef struct evg_ctx evg_ctx;
+
+/* Creates a planner context bound to HIP device `device_ordinal`. Returns NULL (and sets a message
+ * retrievable with evg_last_error(NULL)) when no gfx950 device is usable: there is deliberately no
+ * CPU fallback. One ctx per goroutine/OS thread, or serialise calls externally; ctxs are independent. */
+evg_ctx* evg_create(int device_ordinal);
+void evg_destroy(evg_ctx* ctx);
+
+/* Last error message of `ctx` (or of the failed evg_create when ctx == NULL). */
+const char* evg_last_error(const evg_ctx* ctx);
+
+/* Library/ABI version: (major << 16) | minor. */
+int32_t evg_abi_version(void);
+
+/* Host-side check of the layout contract; no GPU work. */
+int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len);
+
+/* Plans all D distros: replaces, per distro,
+ *   PrepareTasksForPlanning(ctx, d, tasks).Export(ctx)   scheduler/scheduler.go:43
+ *   GetDistroQueueInfo(ctx, d, plan, opts)               scheduler/scheduler.go:44,57-178
+ * Host pointers in, host pointers out; synchronous; nothing is retained. */
+int evg_plan_distros(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out);
+
+/* Same, but every pointer INSIDE in/out (not the structs themselves) is a device pointer on ctx's
+ * device and the work is enqueued on `hip_stream` (a hipStream_t; NULL = default stream) without a
+ * host sync. The small per-distro tables (distros, task_off, tg_off, ver_off) are device-resident
+ * too. This is what the Go shim uses when the pool is kept resident between 15 s ticks. */
+int evg_plan_distros_device(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out,
+                            void* hip_stream);
+
+/* Replaces UtilizationBasedHostAllocator (scheduler/utilization_based_host_allocator.go:26-129)
+ * for all D distros. Per-distro failures the reference reports as `error` come back in
+ * out->status[d] with new_hosts[d] == 0 and free_hosts[d] == #free hosts (:99-101). */
+int evg_allocate_hosts(evg_ctx* ctx, const evg_alloc_input* in, const evg_alloc_output* out);
+int evg_allocate_hosts_device(evg_ctx* ctx, const evg_alloc_input* in, const evg_alloc_output* out,
+                              void* hip_stream);
+
+/* capTaskQueueLength (scheduler/task_queue_persister.go:66-83) for all D distros: cut[d] = number of
+ * leading queue positions of distro d to persist for limit max_scheduled (<= 0 disables). The
+ * straddling test uses Task.TaskGroup (NOT the 4-part group string): tg_name_key is an interning of
+ * the bare TaskGroup name, -1 for "". Device pointers; enqueued on hip_stream. */
+int evg_cap_queue_device(evg_ctx* ctx, int32_t n_distros, const int32_t* task_off,
+                         const int32_t* order, const int32_t* tg_name_key, int32_t max_scheduled,
+                         int32_t* cut, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVG_SCHED_H */

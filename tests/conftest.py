@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests import oracle_lib
+    return oracle_lib.OracleBackend()
+
+
+@pytest.fixture(scope="session")
+def native_ctx():
+    """The HIP library on cuda:0. GPU tests must run the native path: no fallback."""
+    from evergreen_amd import native
+    ctx = native.Context(0)
+    yield ctx
+    ctx.close()

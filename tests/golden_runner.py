@@ -1,0 +1,195 @@
+"""Runs the transcribed reference known-answer tests (tests/golden_cases.py) against any backend of the C
+ABI: the oracle (CPU tests -- this is how the oracle is pinned) and the HIP library (-m gpu tests)."""
+from __future__ import annotations
+
+import numpy as np
+
+from evergreen_amd import abi
+from evergreen_amd import scheduler as S
+from tests import golden_cases as G
+
+
+def _plan(backend, d, tasks, **kw):
+    return S.PlanDistros(backend, [(d, tasks)], G.NOW, **kw)[0]
+
+
+def check_unit_values(backend):
+    for name, d, tasks, want, line in G.unit_value_cases():
+        plan, _ = _plan(backend, d, tasks)
+        assert len(plan) == len(tasks), name
+        for t in plan:
+            b = t.SortingValueBreakdown
+            assert b["total_value"] == want, "%s (planner_test.go:%d): got %d want %d" % (name, line, b["total_value"], want)
+            assert G.verify_rank_breakdown(b), name
+            assert b["task_group_length"] == len(tasks)
+
+
+def check_grouped_unit(backend):
+    d, tasks = G.grouped_unit_case()
+    plan, _ = _plan(backend, d, tasks)
+    b = plan[0].SortingValueBreakdown
+    assert b["rank_num_dependents"] == 22 and b["pri_initial"] == 100 and b["task_group_length"] == 23
+    assert G.verify_rank_breakdown(b)
+    assert plan[0].Id == "build-debug"  # NumDependents desc inside the unit
+
+
+def check_dependency_first(backend):
+    d, tasks = G.dependency_first_case()
+    plan, _ = _plan(backend, d, tasks)
+    ids = [t.Id for t in plan]
+    assert sorted(ids) == sorted(t.Id for t in tasks)
+    assert ids.index("build-debug") < ids.index("independent-test")
+
+
+def check_task_plan_order(backend):
+    # planner_test.go:406-432 TaskPlan: NoChange / ChangeOrder (units of one task each)
+    plan, _ = _plan(backend, S.Distro(), [S.Task(Id="foo"), S.Task(Id="bar")])
+    assert [t.Id for t in plan] == ["foo", "bar"]
+    plan, _ = _plan(backend, S.Distro(), [S.Task(Id="foo"), S.Task(Id="bar", Priority=10)])
+    assert [t.Id for t in plan] == ["bar", "foo"]
+
+
+def check_task_list(backend):
+    d = S.Distro(PlannerSettings=S.PlannerSettings(GroupVersions=True))
+    for name, tasks, want, line in G.task_list_cases():
+        plan, _ = _plan(backend, d, tasks)
+        assert [t.Id for t in plan] == want, "%s (planner_test.go:%d)" % (name, line)
+
+
+def check_prepare(backend):
+    for name, d, tasks, n_units, line in G.prepare_cases():
+        packed = S.pack_queues([(d, tasks)], G.NOW)
+        res = backend.plan(packed.batch)
+        assert int(res.n_units[0]) == n_units, "%s (planner_test.go:%d): %d units" % (name, line, int(res.n_units[0]))
+        ids = [tasks[int(r)].Id for r in res.order]
+        assert sorted(ids) == sorted(t.Id for t in tasks), name  # no task dropped or duplicated
+        if name == "VersionsAndTaskGroupsGrouped":
+            assert tasks[int(res.order[0])].TaskGroup == "one" and tasks[int(res.order[1])].TaskGroup == "one"
+        if name == "DependenciesGrouped":
+            assert ids[3] == "three" and set(ids[:3]) == {"one", "two", "other"}
+
+
+def check_queue_info(backend):
+    for name, d, tasks, want, line in G.queue_info_cases():
+        _, info = _plan(backend, d, tasks, includes_dependencies=[True])
+        for k, v in want.items():
+            assert getattr(info, k) == v, "%s (scheduler_test.go:%d): %s=%r want %r" % (name, line, k, getattr(info, k), v)
+
+
+def check_distro_alias_order(backend):
+    # distro_alias_test.go:20-59: priorities 200 vs 2000 -> ["one", "other"]
+    tasks = [S.Task(Id="other", DistroId="one", Priority=200, Version="foo"),
+             S.Task(Id="one", DistroId="one", Priority=2000, Version="foo")]
+    plan, info = S.PrioritizeTasks(backend, S.Distro(Id="one"), tasks, S.TaskPlannerOptions(ID="tunable-0"), G.NOW)
+    assert [t.Id for t in plan] == ["one", "other"]
+    assert info.Length == 2 and not info.SecondaryQueue
+    # the same tasks planned for distro "two" are a secondary queue (scheduler.go:89-91)
+    _, info2 = _plan(backend, S.Distro(Id="two"), tasks)
+    assert info2.SecondaryQueue
+
+
+def check_allocator(backend):
+    for name, data, running, want, line in G.allocator_cases():
+        got = S.AllocateHosts(backend, [data], G.NOW, running.get)[0]
+        assert got[2] is None, name
+        assert (got[0], got[1]) == want, "%s (utilization_based_host_allocator_test.go:%d): got %r want %r" % (
+            name, line, got[:2], want)
+    # all of them again as ONE batch (distros are independent)
+    cases = G.allocator_cases()
+    allrun = {}
+    datas = []
+    for i, (name, data, running, want, line) in enumerate(cases):
+        for h in data.ExistingHosts:
+            if h.RunningTask:
+                nid = "%d/%s" % (i, h.RunningTask)
+                if h.RunningTask in running:
+                    allrun[nid] = running[h.RunningTask]
+                h.RunningTask = nid
+        datas.append(data)
+    got = S.AllocateHosts(backend, datas, G.NOW, allrun.get)
+    assert [(g[0], g[1]) for g in got] == [c[3] for c in cases]
+
+
+def check_calc_existing_free(backend):
+    hosts, running, want = G.calc_existing_free_case()
+    # calcExistingFreeHosts(hosts, 1, 30min) seen through evalHostUtilization's second return value
+    d = G.suite_distro(FutureHostFraction=1)
+    data = S.HostAllocatorData(d, hosts, S.DistroQueueInfo(MaxDurationThreshold=S.MaxDurationPerDistroHost))
+    got = S.AllocateHosts(backend, [data], G.NOW, running.get)[0]
+    assert got[1] == want
+
+
+def check_allocator_errors(backend):
+    # futureHostFraction > 1  (...allocator.go:287-289)  and  maxHosts < 1 for a task group (:185-187)
+    d = G.suite_distro(FutureHostFraction=1.5)
+    gi = S.TaskGroupInfo(Name="", Count=1, ExpectedDuration=S.MINUTE)
+    data = S.HostAllocatorData(d, [S.Host(Id="h1")], S.DistroQueueInfo(LengthWithDependenciesMet=1, MaxDurationThreshold=30 * S.MINUTE,
+                                                                       TaskGroupInfos=[gi]))
+    n, free, err = S.AllocateHosts(backend, [data], G.NOW)[0]
+    assert (n, free) == (0, 1) and "future host factor" in err
+    d = G.suite_distro()
+    g0 = S.TaskGroupInfo(Name="g_a_b_c", Count=2, MaxHosts=0, ExpectedDuration=S.MINUTE)
+    data = S.HostAllocatorData(d, [], S.DistroQueueInfo(LengthWithDependenciesMet=2, MaxDurationThreshold=30 * S.MINUTE,
+                                                        TaskGroupInfos=[g0]))
+    n, free, err = S.AllocateHosts(backend, [data], G.NOW)[0]
+    assert (n, free) == (0, 0) and "pool size" in err
+    # the per-distro HostAllocator-shaped wrapper raises
+    try:
+        S.UtilizationBasedHostAllocator(backend, data, G.NOW)
+        raise AssertionError("expected AllocatorError")
+    except S.AllocatorError as e:
+        assert e.result == (0, 0)
+
+
+def check_in_place_group_counts(backend):
+    # TaskGroupInfos[i].CountFree / CountRequired are written in place (...allocator.go:106-109)
+    for name, data, running, want, line in G.allocator_cases():
+        if name != "RealisticScenarioWithTaskGroups":
+            continue
+        S.AllocateHosts(backend, [data], G.NOW, running.get)
+        by = {g.Name: g for g in data.DistroQueueInfo.TaskGroupInfos}
+        g1, g2 = by[G._tg("g1")], by[G._tg("g2")]
+        # g1: 2 long tasks, 2 hosts each half free (15/30, x1) -> free 1; needs 2-1=1 -> min(1, Count 2), 1+2 <= 3
+        assert (g1.CountFree, g1.CountRequired) == (1, 1)
+        # g2: 2 long tasks, 1 host half free -> free 0; needs 2, capped by MaxHosts 1 - 1 existing = 0
+        assert (g2.CountFree, g2.CountRequired) == (0, 0)
+        assert by[""].CountFree == 0 and by[""].CountRequired == 0  # never written for ""
+
+
+def check_fuzz_invariants(backend, seed=1234, iters=200):
+    # host_allocator_fuzzer_test.go:154-172: 0 <= newHosts <= queue length
+    rng = np.random.default_rng(seed)
+    datas, runs = [], {}
+    for i in range(iters):
+        nh = int(rng.integers(0, 40))
+        nq = int(rng.integers(0, 200))
+        durs = rng.integers(1, 60, nq) * S.MINUTE
+        over = durs[durs > 30 * S.MINUTE]
+        hosts = []
+        for h in range(nh):
+            if rng.random() < 0.5:
+                hosts.append(S.Host(Id="h%d" % h))
+            else:
+                tid = "%d-%d" % (i, h)
+                hosts.append(S.Host(Id="h%d" % h, RunningTask=tid))
+                runs[tid] = S.Task(Id=tid, ExpectedDuration=int(rng.integers(1, 60)) * S.MINUTE,
+                                   StartTime=G.NOW - int(rng.integers(0, 60)) * S.MINUTE)
+        gi = S.TaskGroupInfo(Name="", Count=nq, ExpectedDuration=int(durs.sum()), CountDurationOverThreshold=len(over),
+                             DurationOverThreshold=int(over.sum()))
+        dqi = S.DistroQueueInfo(Length=nq, LengthWithDependenciesMet=nq, ExpectedDuration=int(durs.sum()),
+                                MaxDurationThreshold=30 * S.MINUTE, TaskGroupInfos=[gi])
+        datas.append(S.HostAllocatorData(G.suite_distro(MaximumHosts=1000, FutureHostFraction=float(rng.random())), hosts, dqi))
+    got = S.AllocateHosts(backend, datas, G.NOW, runs.get)
+    for (n, free, err), data in zip(got, datas):
+        assert err is None and 0 <= n <= data.DistroQueueInfo.Length
+    return got
+
+
+def check_cap(cap_fn):
+    """cap_fn(batch, order, limit) -> cut[D]"""
+    for name, tasks, limit, want in G.cap_cases():
+        packed = S.pack_queues([(S.Distro(), tasks)], G.NOW)
+        order = np.arange(len(tasks), dtype=np.int32)
+        cut = cap_fn(packed.batch, order, limit)
+        assert int(cut[0]) == want, name
+        assert len(S.capTaskQueueLength(tasks, limit)) == want, name

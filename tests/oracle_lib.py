@@ -1,0 +1,82 @@
+"""ctypes binding of oracle/libevg_oracle.so -- TEST INFRASTRUCTURE (the checker), never the product.
+
+Builds the oracle with `make -C oracle` on first use (g++ only)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from evergreen_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libevg_oracle.so")
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "evg_oracle.cpp")
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+            build()
+        L = C.CDLL(LIB)
+        L.evg_oracle_plan_distros.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput)]
+        L.evg_oracle_plan_distro_range.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_int, C.c_int]
+        L.evg_oracle_allocate_hosts.argtypes = [C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput)]
+        L.evg_oracle_cap_queue.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.evg_oracle_calc_new_hosts_needed.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.evg_oracle_cache_new.restype = C.c_void_p
+        L.evg_oracle_cache_new.argtypes = [C.c_int64]
+        L.evg_oracle_cache_free.argtypes = [C.c_void_p]
+        L.evg_oracle_cache_len.argtypes = [C.c_void_p]
+        L.evg_oracle_cache_add_when.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_int64]
+        L.evg_oracle_cache_create.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int]
+        L.evg_oracle_cache_add_new.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64]
+        L.evg_oracle_cache_exists.argtypes = [C.c_void_p, C.c_int64]
+        L.evg_oracle_cache_unit_priority.restype = C.c_int64
+        L.evg_oracle_cache_unit_priority.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+        L.evg_oracle_cache_export_len.argtypes = [C.c_void_p]
+        L.evg_oracle_cache_unit_value.restype = C.c_int64
+        L.evg_oracle_cache_unit_value.argtypes = [C.c_void_p, C.c_int64]
+        L.evg_oracle_cache_same_id.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        _lib = L
+    return _lib
+
+
+class OracleBackend:
+    """scheduler.Backend over the CPU oracle."""
+
+    def plan(self, batch: abi.PlanBatch, breakdown: bool = True, n_units: bool = True, d_range=None) -> abi.PlanResult:
+        res = abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=n_units)
+        inp = abi.make_plan_input(batch)
+        out = res.c_output()
+        if d_range is None:
+            rc = lib().evg_oracle_plan_distros(C.byref(inp), C.byref(out))
+        else:
+            rc = lib().evg_oracle_plan_distro_range(C.byref(inp), C.byref(out), d_range[0], d_range[1])
+        assert rc == 0, rc
+        return res
+
+    def allocate(self, batch: abi.PlanBatch, distro_info: np.ndarray, group_info: np.ndarray) -> abi.AllocResult:
+        res = abi.AllocResult.alloc_host(batch.n_distros)
+        inp = abi.make_alloc_input(batch, distro_info, group_info)
+        out = res.c_output()
+        rc = lib().evg_oracle_allocate_hosts(C.byref(inp), C.byref(out))
+        assert rc == 0, rc
+        return res
+
+    def cap_queue(self, batch: abi.PlanBatch, order: np.ndarray, max_scheduled: int) -> np.ndarray:
+        cut = np.zeros(batch.n_distros, np.int32)
+        rc = lib().evg_oracle_cap_queue(batch.n_distros, batch.task_off.ctypes.data, order.ctypes.data,
+                                        batch.tg_name_key.ctypes.data, max_scheduled, cut.ctypes.data)
+        assert rc == 0
+        return cut

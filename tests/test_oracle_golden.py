@@ -1,0 +1,151 @@
+"""Pins the CPU oracle against the reference's own known-answer tests, transcribed in
+tests/golden_cases.py. The Go reference cannot be executed here; these vectors are what anchors parity."""
+import ctypes as C
+
+import pytest
+
+from tests import golden_cases as G
+from tests import golden_runner as R
+from tests import oracle_lib
+
+
+def test_unit_total_values(oracle):
+    R.check_unit_values(oracle)
+
+
+def test_grouped_unit_breakdown(oracle):
+    R.check_grouped_unit(oracle)
+
+
+def test_dependency_task_scheduled_first(oracle):
+    R.check_dependency_first(oracle)
+
+
+def test_task_plan_order(oracle):
+    R.check_task_plan_order(oracle)
+
+
+def test_task_list_less(oracle):
+    R.check_task_list(oracle)
+
+
+def test_prepare_tasks_for_planning(oracle):
+    R.check_prepare(oracle)
+
+
+def test_queue_info_merge_queue_target_time(oracle):
+    R.check_queue_info(oracle)
+
+
+def test_distro_alias_order(oracle):
+    R.check_distro_alias_order(oracle)
+
+
+def test_calc_new_hosts_needed():
+    L = oracle_lib.lib()
+    for short, maxd, free, nlong, over, merge, down, want in G.CALC_NEW_HOSTS:
+        assert L.evg_oracle_calc_new_hosts_needed(short, maxd, free, nlong, over, merge, int(down)) == want
+
+
+def test_allocator_end_to_end(oracle):
+    R.check_allocator(oracle)
+
+
+def test_calc_existing_free_hosts(oracle):
+    R.check_calc_existing_free(oracle)
+
+
+def test_allocator_errors(oracle):
+    R.check_allocator_errors(oracle)
+
+
+def test_allocator_in_place_group_counts(oracle):
+    R.check_in_place_group_counts(oracle)
+
+
+def test_allocator_fuzz_invariants(oracle):
+    R.check_fuzz_invariants(oracle)
+
+
+def test_cap_task_queue_length(oracle):
+    R.check_cap(oracle.cap_queue)
+
+
+# ---- planner_test.go:54-196: UnitCache / Unit semantics, through the oracle's handle API ----------------
+@pytest.fixture
+def cache():
+    L = oracle_lib.lib()
+    h = L.evg_oracle_cache_new(G.NOW)
+    yield L, C.c_void_p(h)
+    L.evg_oracle_cache_free(C.c_void_p(h))
+
+
+FOO, BAR, ONE, TWO = 1, 2, 11, 12
+
+
+def test_cache_add_when(cache):
+    L, h = cache
+    assert L.evg_oracle_cache_len(h) == 0                       # Zero :55-58
+    L.evg_oracle_cache_add_when(h, 0, FOO, 0, 0)                # AddWhenNoops :59-63
+    assert L.evg_oracle_cache_len(h) == 0
+    L.evg_oracle_cache_add_when(h, 1, FOO, 0, 0)                # AddWhenAddsNew :64-68
+    assert L.evg_oracle_cache_len(h) == 1
+    for _ in range(4):                                          # AddWhenWithExisting :69-79
+        L.evg_oracle_cache_add_when(h, 1, FOO, 0, 0)
+    assert L.evg_oracle_cache_len(h) == 1
+
+
+def test_cache_add_new_merges(cache):
+    L, h = cache
+    assert L.evg_oracle_cache_add_new(h, FOO, FOO, 0) == 1      # AddNewMergesOntoExisting :80-90
+    assert L.evg_oracle_cache_add_new(h, FOO, BAR, 0) == 2
+    assert L.evg_oracle_cache_len(h) == 1
+
+
+def test_cache_create(cache):
+    L, h = cache
+    assert L.evg_oracle_cache_create(h, FOO, FOO, 0, 0) == 1    # CreateNew :102-108
+    assert L.evg_oracle_cache_exists(h, FOO) == 1 and L.evg_oracle_cache_len(h) == 1
+    assert L.evg_oracle_cache_create(h, FOO, FOO, 0, 0) == 1    # CreateTwice :109-115 (same unit, same task)
+    assert L.evg_oracle_cache_len(h) == 1
+
+
+def test_cache_export(cache):
+    L, h = cache
+    L.evg_oracle_cache_create(h, ONE, ONE, 0, 0)                # ExportSkipsMissingDistroTasks :116-121
+    assert L.evg_oracle_cache_export_len(h) == 0
+
+
+def test_cache_export_propagates_and_dedups(cache):
+    L, h = cache
+    L.evg_oracle_cache_create(h, ONE, ONE, 0, 1)                # ExportPropogatesTasks :122-137
+    L.evg_oracle_cache_create(h, TWO, TWO, 0, 1)
+    assert L.evg_oracle_cache_export_len(h) == 2
+    L2 = oracle_lib.lib()
+    h2 = C.c_void_p(L2.evg_oracle_cache_new(G.NOW))
+    L2.evg_oracle_cache_create(h2, ONE, ONE, 0, 1)              # ExportDeduplicatesMatchingUnitNames :138-145
+    L2.evg_oracle_cache_create(h2, TWO, ONE, 0, 1)
+    assert L2.evg_oracle_cache_export_len(h2) == 1
+    L2.evg_oracle_cache_free(h2)
+
+
+def test_unit_add_overwrites_and_hash(cache):
+    L, h = cache
+    L.evg_oracle_cache_create(h, FOO, FOO, 100, 0)              # AddOverwrites :165-170
+    assert L.evg_oracle_cache_unit_priority(h, FOO, FOO) == 100
+    L.evg_oracle_cache_create(h, FOO, FOO, 200, 0)
+    assert L.evg_oracle_cache_unit_priority(h, FOO, FOO) == 200
+    # HashIgnoresOrder :178-195: same members added in different orders -> same ID
+    for t in (4, 1, 2, 3):
+        L.evg_oracle_cache_create(h, 100, t, 0, 0)
+    for t in (4, 3, 1, 2):
+        L.evg_oracle_cache_create(h, 101, t, 0, 0)
+    assert L.evg_oracle_cache_same_id(h, 100, 101) == 1
+
+
+def test_rank_caches_value(cache):
+    L, h = cache
+    L.evg_oracle_cache_create(h, FOO, FOO, 100, 1)              # RankCachesValue :396-404
+    assert L.evg_oracle_cache_unit_value(h, FOO) == 18080
+    L.evg_oracle_cache_create(h, FOO, BAR, 0, 1)
+    assert L.evg_oracle_cache_unit_value(h, FOO) == 18080
