@@ -1,0 +1,663 @@
+// evg_kernels.hip.h -- gfx950 device code of the per-distro scheduling hot path.
+//
+// One workgroup (1024 threads = 16 wave64) plans ONE distro end to end; a launch covers all D distros
+// (D = 512 in the headline config => 2 workgroups per CU on 256 CUs). Per distro:
+//
+//   P1 slots     task columns -> primary unit slot per task                  (planner.go:431-448)
+//   P2 reduce    every task adds itself to each unit it is a member of: atomics into per-unit
+//                accumulators = the segmented reduce of Unit.info            (planner.go:302-337)
+//   P3 score     one thread per unit: unitInfo.value()                       (planner.go:209-300)
+//   P4 elect     per task: its best unit = the unit it is emitted from by the first-occurrence
+//                dedup of TaskPlan.Export                                    (planner.go:462-481)
+//   P5 sort      bitonic sort of the distro's tasks by (unit key, in-unit task key) == sort.Sort(units)
+//                + per-unit sort.Sort(tasks) + dedup, under the canonical tie-break
+//   P6 info      GetDistroQueueInfo: deps-met per task, per-task-group segmented sums
+//                                                                           (scheduler.go:57-178)
+//
+// Small distros (<= 2048 tasks, <= 2560 unit slots) keep every intermediate in LDS (~146 KiB of the
+// CU's 160 KiB); only input columns are read from global memory and only results are written. Larger
+// distros run the SAME code with the intermediates in a global scratch area (correct, not tuned -- see
+// DESIGN.md). No MFMA anywhere: the path is scan / reduce / sort / gather.
+//
+// fp64 steps (Duration.Minutes()/Hours(), floor, float->int) must match Go bit for bit: compile with
+// -ffp-contract=off; only IEEE division is used.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/evg_sched.h"
+
+namespace evg {
+
+constexpr int kBlock = 1024;          // threads per distro workgroup
+constexpr int kLdsMaxTasks = 2048;    // padded task count (pow2) limit of the LDS path
+constexpr int kLdsMaxSlots = 2560;    // unit-slot limit of the LDS path
+constexpr int kLdsMaxGroups = 1536;   // task-group rows (incl. the standalone row) limit of the LDS path
+
+constexpr int64_t kSecond = 1000000000LL;
+constexpr int64_t kMinute = 60 * kSecond;
+constexpr int64_t kHour = 60 * kMinute;
+constexpr int64_t kMaxDurationPerDistroHost = 30 * kMinute;  // globals.go:273
+
+// unit flag bits, kept in the top byte of the member-count word
+constexpr uint32_t UF_MERGE = 1u << 24, UF_PATCH = 2u << 24, UF_NONGROUP = 4u << 24, UF_GENERATE = 8u << 24,
+                   UF_STEPBACK = 16u << 24, UF_DISTRO = 32u << 24;
+constexpr uint32_t UF_COUNT_MASK = 0x00FFFFFFu;
+
+// LDS carve-up of the small path (bytes)
+constexpr int L_TIQ = 0, L_DUR = L_TIQ + 8 * kLdsMaxSlots, L_MAXPRI = L_DUR + 8 * kLdsMaxSlots,
+              L_VAL = L_MAXPRI + 8 * kLdsMaxSlots, L_CNT = L_VAL + 8 * kLdsMaxSlots, L_MAXND = L_CNT + 4 * kLdsMaxSlots,
+              L_MINROW = L_MAXND + 4 * kLdsMaxSlots, L_ACC_END = L_MINROW + 4 * kLdsMaxSlots;
+constexpr int L_K0 = L_ACC_END, L_K1 = L_K0 + 8 * kLdsMaxTasks, L_IDX = L_K1 + 4 * kLdsMaxTasks,
+              L_PSLOT = L_IDX + 2 * kLdsMaxTasks, L_TFLAGS = L_PSLOT + 2 * kLdsMaxTasks,
+              L_TOTAL = L_TFLAGS + 2 * kLdsMaxTasks;
+// after P4 the accumulator region is dead and is re-used for the sort's task-key columns and, behind
+// them, the task-group accumulators of P6
+constexpr int L_CPRI = 0, L_CDUR = L_CPRI + 8 * kLdsMaxTasks, L_CTGO = L_CDUR + 8 * kLdsMaxTasks,
+              L_CND = L_CTGO + 4 * kLdsMaxTasks, L_G = L_CND + 4 * kLdsMaxTasks;
+static_assert(8 * kLdsMaxSlots <= 8 * kLdsMaxTasks + 4 * kLdsMaxTasks, "hash[] must fit in the k0/k1 area");
+static_assert(L_G + 36 * kLdsMaxGroups <= L_ACC_END, "group accumulators must fit in the dead accumulator area");
+static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
+
+struct PlanArgs {
+  evg_plan_input in;    // device pointers
+  evg_plan_output out;  // device pointers
+  // global scratch for the large-distro path
+  int64_t *w_tiq, *w_dur, *w_maxpri, *w_val;  // [N + n_tg + n_ver] unit slots
+  uint64_t* w_hash;
+  uint32_t* w_cnt;
+  int32_t* w_maxnd;
+  uint32_t* w_minrow;
+  uint32_t* w_pslot;  // [N]
+  int64_t* w_k0;      // [N]
+  uint64_t* w_k1;     // [N]
+  uint32_t* w_idx;    // [2N]
+  uint32_t* w_pos;    // [N]
+  uint32_t *g_cnt, *g_cover, *g_wait, *g_mq, *g_first;  // [D + n_tg]
+  uint64_t *g_dur, *g_dover;
+};
+
+// ---- small helpers ----------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t wrap_add(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+__device__ __forceinline__ int64_t wrap_sub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+__device__ __forceinline__ int64_t wrap_mul(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
+
+// Go's Time.Sub: saturating.
+__device__ __forceinline__ int64_t time_sub(int64_t t, int64_t u) {
+  int64_t d;
+  if (!__builtin_sub_overflow(t, u, &d)) return d;
+  return t < u ? INT64_MIN : INT64_MAX;
+}
+__device__ __forceinline__ bool is_zero_time(int64_t ts) { return ts == 0 || ts == EVG_TIME_GO_ZERO; }
+
+// time.Duration.Minutes()/Hours()
+__device__ __forceinline__ double dur_minutes(int64_t d) {
+  int64_t m = d / kMinute, ns = d % kMinute;
+  return (double)m + (double)ns / (60 * 1e9);
+}
+__device__ __forceinline__ double dur_hours(int64_t d) {
+  int64_t h = d / kHour, ns = d % kHour;
+  return (double)h + (double)ns / (60 * 60 * 1e9);
+}
+
+__device__ __forceinline__ int64_t getter(int64_t v) { return v <= 0 ? 1 : v; }  // distro.go:379-434
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
+  return v;
+}
+
+// distro.go:448-475
+__device__ __forceinline__ int64_t target_time_for_queue(const evg_distro_params& p, bool has_mq) {
+  int64_t tt = p.target_time_ns == 0 ? kMaxDurationPerDistroHost : p.target_time_ns;
+  if (!has_mq || p.merge_queue_target_time_ns <= 0) return tt;
+  return tt < p.merge_queue_target_time_ns ? tt : p.merge_queue_target_time_ns;
+}
+
+// unitInfo.value()  planner.go:209-300. bd == nullptr: only TotalValue.
+__device__ inline int64_t unit_value(const evg_distro_params& p, int64_t n, int64_t tiq, int64_t dur, int64_t maxpri,
+                                     int64_t maxnd, uint32_t fl, int64_t* bd) {
+  const bool in_cq = fl & UF_MERGE, in_patch = fl & UF_PATCH, nongroup = fl & UF_NONGROUP, gen = fl & UF_GENERATE,
+             stepback = fl & UF_STEPBACK;
+  // computePriority :271-300
+  int64_t pri = wrap_add(1, maxpri);
+  int64_t b_init = pri, b_tg = 0, b_gen = 0, b_cq = 0;
+  if (!nongroup) { b_tg = n; pri = wrap_add(pri, n); }
+  if (gen) {
+    int64_t prev = pri, g = getter(p.generate_task_factor);
+    pri = wrap_mul(pri, g);
+    b_gen = wrap_sub(pri, prev);
+    if (!nongroup) { b_tg = wrap_mul(b_tg, g); b_gen = wrap_sub(b_gen, wrap_mul(n, g)); }
+  }
+  if (in_cq) { b_cq = 200; pri = wrap_add(pri, 200); }
+  // computeRankValue :223-265
+  int64_t r_patch = 0, r_patchwait = 0, r_cq = 0, r_main = 0, r_step = 0;
+  if (in_patch) {
+    r_patch = getter(p.patch_factor);
+    r_patchwait = wrap_mul(getter(p.patch_time_in_queue_factor), (int64_t)floor(dur_minutes(tiq) / (double)n));
+  } else if (in_cq) {
+    r_cq = getter(p.commit_queue_factor);
+  } else {
+    int64_t avg = tiq / n;
+    if (avg < 7 * 24 * kHour)
+      r_main = wrap_mul(getter(p.mainline_time_in_queue_factor), (int64_t)dur_hours(wrap_sub(7 * 24 * kHour, avg)));
+    if (stepback) r_step = getter(p.stepback_task_factor);
+  }
+  double ndf = p.num_dependents_factor <= 0 ? 1.0 : p.num_dependents_factor;
+  int64_t r_nd = (int64_t)(ndf * (double)maxnd);
+  int64_t r_rt = wrap_mul(getter(p.expected_runtime_factor), (int64_t)floor(dur_minutes(dur) / (double)n));
+  int64_t rank = 1;
+  rank = wrap_add(rank, r_patch); rank = wrap_add(rank, r_patchwait); rank = wrap_add(rank, r_main);
+  rank = wrap_add(rank, r_cq); rank = wrap_add(rank, r_step); rank = wrap_add(rank, r_nd); rank = wrap_add(rank, r_rt);
+  int64_t total = wrap_add(wrap_mul(pri, rank), n);
+  if (bd) {
+    bd[EVG_BD_TASK_GROUP_LENGTH] = n; bd[EVG_BD_TOTAL_VALUE] = total;
+    bd[EVG_BD_PRI_INITIAL] = b_init; bd[EVG_BD_PRI_TASK_GROUP] = b_tg; bd[EVG_BD_PRI_GENERATOR] = b_gen;
+    bd[EVG_BD_PRI_COMMIT_QUEUE] = b_cq; bd[EVG_BD_RANK_COMMIT_QUEUE] = r_cq; bd[EVG_BD_RANK_NUM_DEPENDENTS] = r_nd;
+    bd[EVG_BD_RANK_EST_RUNTIME] = r_rt; bd[EVG_BD_RANK_MAINLINE_WAIT] = r_main; bd[EVG_BD_RANK_STEPBACK] = r_step;
+    bd[EVG_BD_RANK_PATCH] = r_patch; bd[EVG_BD_RANK_PATCH_WAIT] = r_patchwait;
+  }
+  return total;
+}
+
+// Per-distro uniform state.
+struct DC {
+  int d, D, lo, n, tg_lo, ntg, ver_lo, nver, S, tg_base, ver_base, P;
+  bool gv;
+  int64_t now;
+};
+
+// The intermediates of one distro: pointers into LDS (small path) or global scratch (large path).
+template <bool LDS>
+struct Mem {
+  using idx_t = typename std::conditional<LDS, uint16_t, uint32_t>::type;
+  using k1_t = typename std::conditional<LDS, uint32_t, uint64_t>::type;
+  static constexpr int kShift = LDS ? 16 : 32;
+  int64_t *tiq, *dur, *maxpri, *val;
+  uint32_t* cnt;
+  int32_t* maxnd;
+  uint32_t* minrow;
+  uint64_t* hash;    // LDS: aliases k0/k1 (used before P4 only)
+  idx_t* pslot;
+  uint16_t* tflags;  // LDS only; the large path reads the global column
+  int64_t* k0;
+  k1_t* k1;
+  idx_t* idx;
+  idx_t* pos;        // LDS: aliases pslot (dead after P4)
+  const int64_t *c_pri, *c_dur;  // sort task-key columns: LDS copies, or the global inputs at the distro
+  const int32_t *c_tgo, *c_nd;
+  uint32_t *g_cnt, *g_cover, *g_wait, *g_mq, *g_first;  // group accumulators
+  uint64_t *g_dur, *g_dover;
+  int g0, gk;  // index of the standalone row and of task group 0 in the g_* arrays
+  __device__ __forceinline__ int grow(int tgk_local) const { return tgk_local < 0 ? g0 : gk + tgk_local; }
+};
+
+__device__ __forceinline__ int pslot_of(int i, int tgk, int verk, const DC& c) {
+  if (tgk >= 0) return c.tg_base + (tgk - c.tg_lo);
+  if (c.gv) return c.ver_base + (verk - c.ver_lo);
+  return i;
+}
+
+// Visits the unit slots task i (local) is a member of (planner.go:434-456):
+//   its primary unit (own / task group / version),
+//   the version unit too when it is a task-group task and versions are grouped (:439),
+//   the primary unit of each direct dependency that is in this distro's queue (:451-455).
+// DEDUP: each distinct slot exactly once (Unit.Add is keyed by task id, :131).
+template <bool LDS, bool DEDUP, class F>
+__device__ __forceinline__ void for_each_unit(const Mem<LDS>& m, const DC& c, int i, int tgk, int verk, int e0, int e1,
+                                              const int32_t* __restrict__ dep_idx, F f) {
+  const int t0 = m.pslot[i];
+  f(t0, true);
+  int t1 = -1;
+  if (c.gv && tgk >= 0) { t1 = c.ver_base + (verk - c.ver_lo); f(t1, false); }
+  for (int e = e0; e < e1; e++) {
+    const int j = dep_idx[e] - c.lo;
+    if ((unsigned)j >= (unsigned)c.n) continue;
+    const int s = m.pslot[j];
+    if (s == t0 || s == t1) continue;
+    if (DEDUP) {
+      bool dup = false;
+      for (int e2 = e0; e2 < e; e2++) {
+        const int j2 = dep_idx[e2] - c.lo;
+        if ((unsigned)j2 < (unsigned)c.n && (int)m.pslot[j2] == s) { dup = true; break; }
+      }
+      if (dup) continue;
+    }
+    f(s, false);
+  }
+}
+
+// Strict weak order of the queue: position of task a before task b?
+template <bool LDS>
+__device__ __forceinline__ bool queue_less(const Mem<LDS>& m, uint32_t a, uint32_t b, uint32_t pad) {
+  if (a == pad) return false;
+  if (b == pad) return true;
+  const int64_t va = m.k0[a], vb = m.k0[b];
+  if (va != vb) return va > vb;                      // unit TotalValue desc      planner.go:416-418
+  const auto ka = m.k1[a], kb = m.k1[b];
+  if (ka != kb) return ka < kb;                      // canonical: unit min row asc, unit ordinal asc
+  const int32_t oa = m.c_tgo[a], ob = m.c_tgo[b];    // same unit: TaskList.Less  planner.go:386-405
+  if (oa != ob) return oa < ob;
+  const int32_t na = m.c_nd[a], nb = m.c_nd[b];
+  if (na != nb) return na > nb;
+  const int64_t pa = m.c_pri[a], pb = m.c_pri[b];
+  if (pa != pb) return pa > pb;
+  const int64_t da = m.c_dur[a], db = m.c_dur[b];
+  if (da != db) return da > db;
+  return a < b;                                      // canonical: input row asc
+}
+
+template <bool LDS>
+__device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigned* s_red) {
+  using idx_t = typename Mem<LDS>::idx_t;
+  using k1_t = typename Mem<LDS>::k1_t;
+  const evg_task_soa& t = a.in.tasks;
+  const int d = c.d;
+  const evg_distro_params p = a.in.distros[d];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int lo = c.lo, n = c.n, S = c.S;
+
+  // ---- P0/P1: init accumulators, primary slots ---------------------------------------------------------
+  for (int u = tid; u < S; u += kBlock) {
+    m.tiq[u] = 0; m.dur[u] = 0; m.maxpri[u] = 0; m.cnt[u] = 0; m.maxnd[u] = 0; m.minrow[u] = 0xFFFFFFFFu;
+  }
+  for (int i = tid; i < n; i += kBlock) {
+    const int r = lo + i;
+    m.pslot[i] = (idx_t)pslot_of(i, t.tg_key[r], t.version_key[r], c);
+    if (LDS) m.tflags[i] = t.flags[r];
+  }
+  if (tid < 8) s_red[tid] = 0;
+  __syncthreads();
+
+  // ---- P2: segmented reduce of Unit.info (planner.go:302-337) -------------------------------------------
+  for (int i = tid; i < n; i += kBlock) {
+    const int r = lo + i;
+    const int tgk = t.tg_key[r], verk = t.version_key[r];
+    const uint32_t f = t.flags[r];
+    const int64_t pri = t.priority[r], dur = t.expected_duration_ns[r], qts = t.queue_ts_ns[r];
+    const int32_t nd = t.num_dependents[r];
+    const int64_t tiq = qts == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, qts);
+    const uint32_t rc = f & EVG_TF_REQ_MASK;
+    uint32_t uf = rc == EVG_TF_REQ_MERGE ? UF_MERGE : rc == EVG_TF_REQ_PATCH ? UF_PATCH : 0u;
+    uf |= tgk < 0 ? UF_NONGROUP : 0u;
+    uf |= (f & EVG_TF_GENERATE) ? UF_GENERATE : 0u;
+    uf |= (f & EVG_TF_STEPBACK) ? UF_STEPBACK : 0u;
+    for_each_unit<LDS, true>(m, c, i, tgk, verk, t.dep_off[r], t.dep_off[r + 1], t.dep_idx, [&](int u, bool primary) {
+      if (tiq != 0) atomicAdd((unsigned long long*)&m.tiq[u], (unsigned long long)tiq);
+      atomicAdd((unsigned long long*)&m.dur[u], (unsigned long long)dur);
+      if (pri > 0) atomicMax((long long*)&m.maxpri[u], (long long)pri);
+      if (nd > 0) atomicMax(&m.maxnd[u], nd);
+      atomicAdd(&m.cnt[u], 1u);
+      atomicOr(&m.cnt[u], uf | (primary ? UF_DISTRO : 0u));  // SetDistro only via the primary key (:447)
+      atomicMin(&m.minrow[u], (uint32_t)i);
+    });
+  }
+  __syncthreads();
+
+  // ---- P3: score every unit (planner.go:209-300); units whose distro is nil are dropped (:81) ---------------
+  for (int u = tid; u < S; u += kBlock) {
+    const uint32_t cw = m.cnt[u];
+    const int64_t nu = cw & UF_COUNT_MASK;
+    int64_t v = INT64_MIN;
+    if (nu > 0 && (cw & UF_DISTRO)) v = unit_value(p, nu, m.tiq[u], m.dur[u], m.maxpri[u], m.maxnd[u], cw, nullptr);
+    m.val[u] = v;
+  }
+  __syncthreads();
+
+  // ---- P3b (optional): TaskPlan.Len() after UnitCache.Export's set-equality dedup (planner.go:73-89) --------
+  // Unit identity = (member count, min member, commutative 64-bit hash of the member rows); the reference's
+  // own identity is a hash too (sha1 of the sorted ids, :154-172). Set-equal units share their min member,
+  // so a unit's duplicates are among the units of that one task.
+  if (a.out.n_units) {
+    for (int u = tid; u < S; u += kBlock) m.hash[u] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kBlock) {
+      const int r = lo + i;
+      const uint64_t h = mix64((uint64_t)i);
+      for_each_unit<LDS, true>(m, c, i, t.tg_key[r], t.version_key[r], t.dep_off[r], t.dep_off[r + 1], t.dep_idx,
+                               [&](int u, bool) { atomicAdd((unsigned long long*)&m.hash[u], (unsigned long long)h); });
+    }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int u = tid; u < S; u += kBlock) {
+      if (m.val[u] == INT64_MIN) continue;
+      const int i = (int)m.minrow[u];
+      const int r = lo + i;
+      bool dup = false;
+      const uint64_t hu = m.hash[u];
+      const uint32_t cu = m.cnt[u] & UF_COUNT_MASK;
+      for_each_unit<LDS, false>(m, c, i, t.tg_key[r], t.version_key[r], t.dep_off[r], t.dep_off[r + 1], t.dep_idx,
+                                [&](int w, bool) {
+                                  if (w < u && m.val[w] != INT64_MIN && m.hash[w] == hu &&
+                                      (m.cnt[w] & UF_COUNT_MASK) == cu && m.minrow[w] == (uint32_t)i)
+                                    dup = true;
+                                });
+      mine += dup ? 0u : 1u;
+    }
+    mine = wave_sum(mine);
+    if (lane == 0 && mine) atomicAdd(&s_red[7], mine);
+    __syncthreads();
+    if (tid == 0) a.out.n_units[d] = (int32_t)s_red[7];
+    __syncthreads();  // hash[] aliases k0/k1
+  }
+
+  // ---- P4: elect each task's emitting unit; build its sort key -------------------------------------------
+  for (int i = tid; i < n; i += kBlock) {
+    const int r = lo + i;
+    int best = -1;
+    int64_t bv = INT64_MIN;
+    uint32_t bm = 0;
+    for_each_unit<LDS, false>(m, c, i, t.tg_key[r], t.version_key[r], t.dep_off[r], t.dep_off[r + 1], t.dep_idx,
+                              [&](int u, bool) {
+                                const int64_t v = m.val[u];
+                                if (v == INT64_MIN) return;
+                                const uint32_t mr = m.minrow[u];
+                                if (best < 0 || v > bv || (v == bv && (mr < bm || (mr == bm && u < best)))) {
+                                  best = u; bv = v; bm = mr;
+                                }
+                              });
+    m.k0[i] = bv;
+    m.k1[i] = ((k1_t)bm << Mem<LDS>::kShift) | (k1_t)best;
+    if (a.out.breakdown) {
+      const uint32_t cw = m.cnt[best];
+      unit_value(p, cw & UF_COUNT_MASK, m.tiq[best], m.dur[best], m.maxpri[best], m.maxnd[best], cw,
+                 a.out.breakdown + (size_t)r * EVG_BREAKDOWN_FIELDS);
+    }
+  }
+  __syncthreads();  // accumulators are dead from here on
+
+  const int P = c.P;
+  const uint32_t pad = LDS ? 0xFFFFu : 0xFFFFFFFFu;
+  if (LDS) {
+    int64_t* cp = const_cast<int64_t*>(m.c_pri);
+    int64_t* cd = const_cast<int64_t*>(m.c_dur);
+    int32_t* co = const_cast<int32_t*>(m.c_tgo);
+    int32_t* cn = const_cast<int32_t*>(m.c_nd);
+    for (int i = tid; i < n; i += kBlock) {
+      const int r = lo + i;
+      cp[i] = t.priority[r]; cd[i] = t.expected_duration_ns[r];
+      co[i] = t.task_group_order[r]; cn[i] = t.num_dependents[r];
+    }
+  }
+  for (int i = tid; i < P; i += kBlock) m.idx[i] = i < n ? (idx_t)i : (idx_t)pad;
+  // group accumulators (rows: standalone + ntg)
+  for (int k = tid; k < c.ntg + 1; k += kBlock) {
+    const int g = m.grow(k - 1);
+    m.g_cnt[g] = 0; m.g_cover[g] = 0; m.g_wait[g] = 0; m.g_mq[g] = 0; m.g_first[g] = 0xFFFFFFFFu;
+    m.g_dur[g] = 0; m.g_dover[g] = 0;
+  }
+
+  // ---- P5: bitonic sort of idx[] by queue_less ------------------------------------------------------------
+  int prev_j = 1 << 30;
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (LDS && j <= 64 && prev_j <= 64) {
+        // both this stage and the previous one only touch the 128 elements this wave owns
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        __syncthreads();
+      }
+      prev_j = j;
+      for (int tt = tid; tt < (P >> 1); tt += kBlock) {
+        const int i = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
+        const int x = i | j;
+        const uint32_t ia = m.idx[i], ib = m.idx[x];
+        const bool up = (i & k) == 0;
+        const bool sw = up ? queue_less<LDS>(m, ib, ia, pad) : queue_less<LDS>(m, ia, ib, pad);
+        if (sw) { m.idx[i] = (idx_t)ib; m.idx[x] = (idx_t)ia; }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- queue order out; inverse permutation -------------------------------------------------------------
+  for (int q = tid; q < n; q += kBlock) {
+    const uint32_t i = m.idx[q];
+    a.out.order[lo + q] = lo + (int)i;
+    m.pos[i] = (idx_t)q;
+  }
+
+  // ---- P6: GetDistroQueueInfo (scheduler.go:57-178) --------------------------------------------------------
+  // pass A: checkDependenciesMet per task; does any met merge-queue task exist?
+  const bool incl = p.includes_dependencies != 0;
+  uint32_t any_mq = 0;
+  for (int i = tid; i < n; i += kBlock) {
+    const int r = lo + i;
+    const uint32_t f = t.flags[r];
+    const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
+    const int64_t dmt = t.deps_met_ts_ns[r];
+    bool met = (e1 == e0) || (f & EVG_TF_OVERRIDE_DEPS) || !is_zero_time(dmt);  // HasDependenciesMet task.go:3406
+    int64_t mettime = dmt;
+    if (!met) {
+      bool all = true;
+      for (int e = e0; e < e1; e++) {
+        const int j = t.dep_idx[e] - lo;
+        const uint32_t info = t.dep_info[e];
+        uint32_t st;
+        bool blk;
+        if ((unsigned)j < (unsigned)n) {
+          const uint32_t fj = LDS ? (uint32_t)m.tflags[j] : (uint32_t)t.flags[lo + j];
+          st = (fj & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT;
+          blk = fj & EVG_TF_BLOCKED;
+        } else {
+          if (info & EVG_DEP_MISSING) { all = false; break; }
+          st = (info & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT;
+          blk = info & EVG_DEP_BLOCKED;
+        }
+        const uint32_t req = info & EVG_DEP_REQ_MASK;  // SatisfiesDependency task.go:546-561
+        const bool sat = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
+        if (!sat) { all = false; break; }
+      }
+      if (all) {
+        met = true;  // setDependenciesMetTime task.go:690-701
+        int64_t mt = 0;
+        if (t.dep_finished_ts_ns)
+          for (int e = e0; e < e1; e++) {
+            const int64_t fa = t.dep_finished_ts_ns[e];
+            if (!is_zero_time(fa) && fa > mt) mt = fa;
+          }
+        mettime = is_zero_time(mt) ? c.now : mt;
+      }
+    }
+    a.out.deps_met[r] = met ? 1 : 0;
+    // stash the effective DependenciesMetTime for pass B in wait_ns (overwritten there)
+    a.out.wait_ns[r] = mettime;
+    if (met && (f & EVG_TF_REQ_MASK) == EVG_TF_REQ_MERGE) any_mq = 1;
+  }
+  if (__any(any_mq) && lane == 0) atomicOr(&s_red[0], 1u);
+  __syncthreads();
+  const int64_t T = target_time_for_queue(p, s_red[0] != 0);
+
+  // pass B: segmented sums keyed by task group ("" = row g0). The standalone row takes ~90% of the tasks:
+  // wave-reduce it and issue one atomic per wave; task-group rows take direct atomics.
+  uint32_t n_met = 0, n_mq = 0, n_s3 = 0, sec = 0;
+  const int n_round = (n + kBlock - 1) / kBlock * kBlock;
+  for (int i = tid; i < n_round; i += kBlock) {
+    uint32_t s_cnt = 0, s_cover = 0, s_wait = 0, s_mq = 0;
+    uint64_t s_dur = 0, s_dover = 0;
+    if (i < n) {
+      const int r = lo + i;
+      const uint32_t f = t.flags[r];
+      const int tgk = t.tg_key[r];
+      const bool met = a.out.deps_met[r] != 0;
+      const int64_t mettime = a.out.wait_ns[r];
+      const int64_t dur = t.expected_duration_ns[r];
+      const bool merge = (f & EVG_TF_REQ_MASK) == EVG_TF_REQ_MERGE;
+      const bool count = !incl || met;
+      const bool over = count && dur > T;
+      int64_t wait = 0;
+      bool wait_over = false;
+      if (count && met) {
+        int64_t start = t.scheduled_ts_ns[r];
+        if (mettime > start) start = mettime;  // DependenciesMetTime.After(startTime)
+        wait = time_sub(c.now, start);
+        wait_over = wait > T;
+      }
+      a.out.wait_ns[r] = wait;
+      if (f & EVG_TF_OTHER_DISTRO) sec = 1;
+      if (met) { n_met++; if (merge) n_mq++; if (f & EVG_TF_S3_STORAGE) n_s3++; }
+      const int g = m.grow(tgk < 0 ? -1 : tgk - c.tg_lo);
+      atomicMin(&m.g_first[g], (uint32_t)m.pos[i]);
+      if (tgk < 0) {
+        s_cnt = count; s_dur = count ? (uint64_t)dur : 0; s_cover = over; s_dover = over ? (uint64_t)dur : 0;
+        s_wait = wait_over; s_mq = met && merge;
+      } else {
+        if (count) { atomicAdd(&m.g_cnt[g], 1u); atomicAdd((unsigned long long*)&m.g_dur[g], (unsigned long long)dur); }
+        if (over) { atomicAdd(&m.g_cover[g], 1u); atomicAdd((unsigned long long*)&m.g_dover[g], (unsigned long long)dur); }
+        if (wait_over) atomicAdd(&m.g_wait[g], 1u);
+        if (met && merge) atomicAdd(&m.g_mq[g], 1u);
+      }
+    }
+    s_cnt = wave_sum(s_cnt); s_cover = wave_sum(s_cover); s_wait = wave_sum(s_wait); s_mq = wave_sum(s_mq);
+    s_dur = wave_sum(s_dur); s_dover = wave_sum(s_dover);
+    if (lane == 0) {
+      const int g = m.g0;
+      if (s_cnt) atomicAdd(&m.g_cnt[g], s_cnt);
+      if (s_dur) atomicAdd((unsigned long long*)&m.g_dur[g], (unsigned long long)s_dur);
+      if (s_cover) atomicAdd(&m.g_cover[g], s_cover);
+      if (s_dover) atomicAdd((unsigned long long*)&m.g_dover[g], (unsigned long long)s_dover);
+      if (s_wait) atomicAdd(&m.g_wait[g], s_wait);
+      if (s_mq) atomicAdd(&m.g_mq[g], s_mq);
+    }
+  }
+  n_met = wave_sum(n_met); n_mq = wave_sum(n_mq); n_s3 = wave_sum(n_s3);
+  if (lane == 0) {
+    if (n_met) atomicAdd(&s_red[1], n_met);
+    if (n_mq) atomicAdd(&s_red[2], n_mq);
+    if (n_s3) atomicAdd(&s_red[3], n_s3);
+  }
+  if (__any(sec) && lane == 0) atomicOr(&s_red[4], 1u);
+  __syncthreads();
+
+  // rows out: model.TaskGroupInfo; MaxHosts = first task of the group in QUEUE order (scheduler.go:103-106)
+  uint64_t t_dur = 0, t_dover = 0;
+  uint32_t t_cover = 0, t_wait = 0, t_rows = 0;
+  for (int k = tid; k < c.ntg + 1; k += kBlock) {
+    const int g = m.grow(k - 1);
+    evg_group_info* o = &a.out.group_info[k == 0 ? d : c.D + c.tg_lo + (k - 1)];
+    const uint32_t first = m.g_first[g];
+    const bool present = first != 0xFFFFFFFFu;
+    evg_group_info gi;
+    gi.expected_duration_ns = (int64_t)m.g_dur[g];
+    gi.duration_over_threshold_ns = (int64_t)m.g_dover[g];
+    gi.count = (int32_t)m.g_cnt[g];
+    gi.max_hosts = present ? t.task_group_max_hosts[lo + (int)m.idx[first]] : 0;
+    gi.count_duration_over_threshold = (int32_t)m.g_cover[g];
+    gi.count_wait_over_threshold = (int32_t)m.g_wait[g];
+    gi.count_dep_filled_merge_queue_tasks = (int32_t)m.g_mq[g];
+    gi.present = present ? 1 : 0;
+    gi.count_free = 0;
+    gi.count_required = 0;
+    *o = gi;
+    t_dur += m.g_dur[g]; t_dover += m.g_dover[g]; t_cover += m.g_cover[g]; t_wait += m.g_wait[g];
+    t_rows += present ? 1u : 0u;
+  }
+  t_dur = wave_sum(t_dur); t_dover = wave_sum(t_dover);
+  t_cover = wave_sum(t_cover); t_wait = wave_sum(t_wait); t_rows = wave_sum(t_rows);
+  if (lane == 0) {
+    if (t_cover) atomicAdd(&s_red[5], t_cover);
+    if (t_wait) atomicAdd(&s_red[6], t_wait);
+    if (t_rows) atomicAdd(&s_red[7 + 1], t_rows);
+    // 64-bit totals: two words each
+    atomicAdd((unsigned long long*)&s_red[10], (unsigned long long)t_dur);
+    atomicAdd((unsigned long long*)&s_red[12], (unsigned long long)t_dover);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    evg_distro_info di;
+    di.expected_duration_ns = (int64_t)(*(unsigned long long*)&s_red[10]);
+    di.max_duration_threshold_ns = T;
+    di.duration_over_threshold_ns = (int64_t)(*(unsigned long long*)&s_red[12]);
+    di.length = n;
+    di.length_with_dependencies_met = (int32_t)s_red[1];
+    di.count_dep_filled_merge_queue_tasks = (int32_t)s_red[2];
+    di.count_duration_over_threshold = (int32_t)s_red[5];
+    di.count_wait_over_threshold = (int32_t)s_red[6];
+    di.num_queued_large_parser_project_tasks = (int32_t)s_red[3];
+    di.secondary_queue = (int32_t)s_red[4];
+    di.n_task_group_infos = (int32_t)s_red[8];
+    a.out.distro_info[d] = di;
+  }
+}
+
+// One workgroup per distro.
+__global__ void __launch_bounds__(kBlock) k_plan_distros(const PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(8))) unsigned s_red[16];
+  const int d = blockIdx.x;
+  DC c;
+  c.d = d;
+  c.D = a.in.n_distros;
+  c.lo = a.in.task_off[d];
+  c.n = a.in.task_off[d + 1] - c.lo;
+  c.tg_lo = a.in.tg_off[d];
+  c.ntg = a.in.tg_off[d + 1] - c.tg_lo;
+  c.ver_lo = a.in.ver_off[d];
+  c.nver = a.in.ver_off[d + 1] - c.ver_lo;
+  c.gv = a.in.distros[d].group_versions != 0;
+  c.now = a.in.now_ns;
+  // slot map: !gv: own task units [0,n) then task groups; gv: task groups then versions (no own units)
+  if (c.gv) { c.tg_base = 0; c.ver_base = c.ntg; c.S = c.ntg + c.nver; }
+  else { c.tg_base = c.n; c.ver_base = c.n + c.ntg; c.S = c.n + c.ntg; }
+  int P = 1;
+  while (P < c.n) P <<= 1;
+  c.P = P;
+  if (threadIdx.x < 16) s_red[threadIdx.x] = 0;
+  __syncthreads();
+
+  if (P <= kLdsMaxTasks && c.S <= kLdsMaxSlots && c.ntg + 1 <= kLdsMaxGroups) {
+    Mem<true> m;
+    m.tiq = (int64_t*)(smem + L_TIQ); m.dur = (int64_t*)(smem + L_DUR); m.maxpri = (int64_t*)(smem + L_MAXPRI);
+    m.val = (int64_t*)(smem + L_VAL); m.cnt = (uint32_t*)(smem + L_CNT); m.maxnd = (int32_t*)(smem + L_MAXND);
+    m.minrow = (uint32_t*)(smem + L_MINROW); m.hash = (uint64_t*)(smem + L_K0);
+    m.pslot = (uint16_t*)(smem + L_PSLOT); m.tflags = (uint16_t*)(smem + L_TFLAGS);
+    m.k0 = (int64_t*)(smem + L_K0); m.k1 = (uint32_t*)(smem + L_K1); m.idx = (uint16_t*)(smem + L_IDX);
+    m.pos = (uint16_t*)(smem + L_PSLOT);
+    m.c_pri = (const int64_t*)(smem + L_CPRI); m.c_dur = (const int64_t*)(smem + L_CDUR);
+    m.c_tgo = (const int32_t*)(smem + L_CTGO); m.c_nd = (const int32_t*)(smem + L_CND);
+    unsigned char* g = smem + L_G;
+    m.g_dur = (uint64_t*)g; g += 8 * kLdsMaxGroups;
+    m.g_dover = (uint64_t*)g; g += 8 * kLdsMaxGroups;
+    m.g_cnt = (uint32_t*)g; g += 4 * kLdsMaxGroups;
+    m.g_cover = (uint32_t*)g; g += 4 * kLdsMaxGroups;
+    m.g_wait = (uint32_t*)g; g += 4 * kLdsMaxGroups;
+    m.g_mq = (uint32_t*)g; g += 4 * kLdsMaxGroups;
+    m.g_first = (uint32_t*)g;
+    m.g0 = 0; m.gk = 1;
+    plan_distro<true>(a, c, m, s_red);
+  } else {
+    const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // disjoint slot range of this distro
+    Mem<false> m;
+    m.tiq = a.w_tiq + sb; m.dur = a.w_dur + sb; m.maxpri = a.w_maxpri + sb; m.val = a.w_val + sb;
+    m.cnt = a.w_cnt + sb; m.maxnd = a.w_maxnd + sb; m.minrow = a.w_minrow + sb; m.hash = a.w_hash + sb;
+    m.pslot = a.w_pslot + c.lo; m.tflags = nullptr;
+    m.k0 = a.w_k0 + c.lo; m.k1 = a.w_k1 + c.lo; m.idx = a.w_idx + 2 * (size_t)c.lo; m.pos = a.w_pos + c.lo;
+    const evg_task_soa& t = a.in.tasks;
+    m.c_pri = t.priority + c.lo; m.c_dur = t.expected_duration_ns + c.lo;
+    m.c_tgo = t.task_group_order + c.lo; m.c_nd = t.num_dependents + c.lo;
+    m.g_cnt = a.g_cnt; m.g_cover = a.g_cover; m.g_wait = a.g_wait; m.g_mq = a.g_mq; m.g_first = a.g_first;
+    m.g_dur = a.g_dur; m.g_dover = a.g_dover;
+    m.g0 = d; m.gk = c.D + c.tg_lo;
+    plan_distro<false>(a, c, m, s_red);
+  }
+}
+
+}  // namespace evg

@@ -1,0 +1,532 @@
+// evg_sched.hip -- the C ABI of include/evg_sched.h on top of the gfx950 kernels.
+//
+// gfx950 only, HIP only: there is no CPU path in this library. evg_create() fails when no gfx950 device is
+// usable and every entry point needs a ctx, so a missing GPU is a loud error, never a silent fallback.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared evg_sched.hip -o libevg_sched.so
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "evg_kernels.hip.h"
+
+namespace evg {
+
+// ---- UtilizationBasedHostAllocator: one 256-thread workgroup per distro -------------------------------------
+// (scheduler/utilization_based_host_allocator.go:26-384). Buckets of groupByTaskGroup (:208-245): bucket 0 is
+// "" and bucket 1+k is task group k of the distro. The fp64 sum of getSoonToBeFreeHosts (:373-376) is taken in
+// host order, one lane per bucket, so that it is reproducible.
+constexpr int kAllocBlock = 256;
+
+struct AllocArgs {
+  evg_alloc_input in;
+  evg_alloc_output out;
+  double* w_term;  // [n_hosts] fractional-free term of each running host
+  int32_t *w_new, *w_free, *w_err;  // [D + n_tg] per-bucket results; w_err: -1 not evaluated, 0 ok, >0 EVG_ALLOC_E_*
+};
+
+__global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs a) {
+  __shared__ int s_i[8];  // 0: #free hosts, 1: sum new, 2: sum free, 4: first failing bucket, 5: its error
+  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int D = a.in.n_distros;
+  const evg_alloc_params p = a.in.params[d];
+  const evg_host_soa& h = a.in.hosts;
+  const int h0 = a.in.host_off[d], nh = a.in.host_off[d + 1] - h0;
+  const int tg_lo = a.in.tg_off[d], ntg = a.in.tg_off[d + 1] - tg_lo;
+  const int64_t T = a.in.distro_info[d].max_duration_threshold_ns;
+  const int len_met = a.in.distro_info[d].length_with_dependencies_met;
+  const int64_t now = a.in.now_ns;
+  if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
+  __syncthreads();
+
+  // free hosts of the distro (:33-37) and every running host's fractional-free term (:340-368)
+  uint32_t nfree = 0;
+  for (int i = tid; i < nh; i += kAllocBlock) {
+    const uint32_t f = h.flags[h0 + i];
+    nfree += (f & EVG_HF_FREE) ? 1u : 0u;
+    double term = 0.0;
+    if ((f & EVG_HF_RUNNING) && (f & EVG_HF_RUNNING_FOUND)) {
+      const int64_t exp = h.expected_duration_ns[h0 + i], sd = h.duration_stddev_ns[h0 + i];
+      const int64_t elapsed = time_sub(now, h.start_ts_ns[h0 + i]);
+      const int64_t left = wrap_sub(exp, elapsed);
+      double frac;
+      if (elapsed > kMaxDurationPerDistroHost && sd > 0 && elapsed > wrap_add(exp, wrap_mul(3, sd))) frac = 0;
+      else frac = (double)wrap_sub(T, left) / (double)T;
+      if (frac < 0) frac = 0;
+      if (frac > 1) frac = 1;
+      term = p.future_host_fraction * frac;
+    }
+    a.w_term[h0 + i] = term;
+  }
+  nfree = wave_sum(nfree);
+  if (lane == 0 && nfree) atomicAdd(&s_i[0], (int)nfree);
+  __syncthreads();
+  const int n_free_hosts = s_i[0];
+
+  // early outs (:39-67)
+  if (p.provider != 2 && nh >= p.maximum_hosts) {
+    if (tid == 0) { a.out.new_hosts[d] = 0; a.out.free_hosts[d] = n_free_hosts; a.out.status[d] = EVG_ALLOC_OK; }
+    return;
+  }
+  if (p.disabled) {
+    if (tid == 0) {
+      const int want = p.minimum_hosts - nh;
+      a.out.new_hosts[d] = want > 0 ? want : 0; a.out.free_hosts[d] = n_free_hosts; a.out.status[d] = EVG_ALLOC_OK;
+    }
+    return;
+  }
+
+  // per bucket: evalHostUtilization (:134-205)
+  const bool ephemeral = p.provider != 0;
+  for (int b = tid; b < ntg + 1; b += kAllocBlock) {
+    const int row = b == 0 ? d : D + tg_lo + (b - 1);
+    const evg_group_info gi = a.in.group_info[row];
+    const int want_key = b == 0 ? -1 : tg_lo + (b - 1);
+    int n_hosts_b = 0, n_free_b = 0;
+    double soon = 0.0;
+    for (int i = 0; i < nh; i++) {  // host order: the canonical order of the fp64 sum
+      if (h.tg_key[h0 + i] != want_key) continue;
+      n_hosts_b++;
+      const uint32_t f = h.flags[h0 + i];
+      n_free_b += (f & EVG_HF_FREE) ? 1 : 0;
+      if ((f & EVG_HF_RUNNING) && (f & EVG_HF_RUNNING_FOUND)) soon += a.w_term[h0 + i];
+    }
+    const bool present = gi.present != 0;
+    // "" is evaluated when it exists in taskGroupDatas (hosts or an info row); a named group is skipped when
+    // no task of it is queued (:84-86), which also covers groups that only hosts know about
+    const bool eval = b == 0 ? (n_hosts_b > 0 || present) : (present && gi.count != 0);
+    int n_new = 0, n_free = 0, err = -1;
+    if (eval) {
+      err = 0;
+      const int max_hosts = b == 0 ? p.maximum_hosts : gi.max_hosts;
+      if (ephemeral) {
+        if (p.future_host_fraction > 1) {
+          err = EVG_ALLOC_E_FUTURE_FRACTION;  // calcExistingFreeHosts :287-289
+        } else {
+          const int count = present ? gi.count : 0;
+          const int64_t exp_dur = present ? gi.expected_duration_ns : 0;
+          const int64_t over_dur = present ? gi.duration_over_threshold_ns : 0;
+          const int n_long = present ? gi.count_duration_over_threshold : 0;
+          const int n_overdue = (present && p.feedback_waits_over_thresh) ? gi.count_wait_over_threshold : 0;
+          const int n_mq = present ? gi.count_dep_filled_merge_queue_tasks : 0;
+          const int exp_free = n_free_b + (int)floor(soon);
+          // calcNewHostsNeeded :253-281
+          const double turn = (double)wrap_sub(exp_dur, over_dur) / (double)T;
+          const double need = turn - (double)exp_free + (double)n_long + (double)n_overdue + (double)n_mq;
+          int nn;
+          if (exp_free < 1 && need > 0 && need < 1) {
+            nn = 1;
+          } else {
+            nn = p.round_up ? (int)ceil(need) : (int)floor(need);
+            if (nn < 0) nn = 0;
+          }
+          n_new = nn < count ? nn : count;
+          if (n_new + n_hosts_b > max_hosts) n_new = max_hosts - n_hosts_b;  // isMaxHostsCapacity :382-384
+          if (n_new < 0) n_new = 0;
+          n_free = exp_free;
+          if (max_hosts < 1) { err = EVG_ALLOC_E_POOL_SIZE; n_new = 0; n_free = 0; }  // :185-187
+        }
+      }
+      if (err > 0) atomicMin(&s_i[4], b);
+    }
+    a.w_new[row] = n_new; a.w_free[row] = n_free; a.w_err[row] = err;
+  }
+  __syncthreads();
+  // Canonical map order: "" first, then groups by key. The reference returns at the first failing group (:99-101);
+  // groups visited before it already had CountFree/CountRequired written (:106-109).
+  const int first_err = s_i[4];
+  int t_new = 0, t_free = 0;
+  for (int b = tid; b < ntg + 1; b += kAllocBlock) {
+    const int row = b == 0 ? d : D + tg_lo + (b - 1);
+    const int err = a.w_err[row];
+    if (b == first_err) s_i[5] = err;
+    if (err != 0 || b > first_err) continue;
+    t_new += a.w_new[row];
+    t_free += a.w_free[row];
+    if (b != 0) { a.in.group_info[row].count_free = a.w_free[row]; a.in.group_info[row].count_required = a.w_new[row]; }
+  }
+  if (t_new) atomicAdd(&s_i[1], t_new);
+  if (t_free) atomicAdd(&s_i[2], t_free);
+  __syncthreads();
+  if (tid == 0) {
+    if (first_err != 0x7FFFFFFF) {
+      a.out.new_hosts[d] = 0; a.out.free_hosts[d] = n_free_hosts; a.out.status[d] = s_i[5];
+    } else {
+      int required = s_i[1];
+      if (required + n_free_hosts > len_met) required = len_met - n_free_hosts;  // :113-115
+      if (required < 0) required = 0;
+      int add_min = 0;
+      if (nh + required < p.minimum_hosts) add_min = p.minimum_hosts - (nh + required);  // :121-126
+      a.out.new_hosts[d] = required + add_min; a.out.free_hosts[d] = s_i[2]; a.out.status[d] = EVG_ALLOC_OK;
+    }
+  }
+}
+
+// capTaskQueueLength (scheduler/task_queue_persister.go:66-83): one thread per distro.
+__global__ void k_cap_queue(int D, const int32_t* task_off, const int32_t* order, const int32_t* tg_name_key,
+                            int32_t max_scheduled, int32_t* cut) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  const int lo = task_off[d], len = task_off[d + 1] - lo;
+  if (max_scheduled <= 0 || len <= max_scheduled) { cut[d] = len; return; }
+  int c = max_scheduled;
+  while (c < len) {
+    const int g = tg_name_key[order[lo + c]];
+    if (g < 0 || g != tg_name_key[order[lo + c - 1]]) break;
+    c++;
+  }
+  cut[d] = c;
+}
+
+}  // namespace evg
+
+// =============================================================================================================
+// Host side
+// =============================================================================================================
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct evg_ctx {
+  int device = 0;
+  std::string err;
+  std::mutex mu;
+  hipStream_t stream = nullptr;  // used by the host-pointer entry points
+  // scratch of the large-distro path + allocator
+  std::vector<DevBuf> scratch = std::vector<DevBuf>(32);
+  // staging for the host-pointer entry points
+  std::vector<DevBuf> stage = std::vector<DevBuf>(48);
+  bool lds_attr_set = false;
+};
+
+static thread_local std::string g_create_err;
+
+static int set_err(evg_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_err = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                        \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return set_err((c), e_ == hipErrorOutOfMemory ? EVG_E_NOMEM : EVG_E_HIP, "%s: %s", #expr, \
+                     hipGetErrorString(e_));                                                    \
+  } while (0)
+
+static int ensure(evg_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return EVG_OK;
+  if (b.p) HIP_TRY(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 8 + 256;
+  HIP_TRY(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return EVG_OK;
+}
+
+struct Stager {
+  evg_ctx* c;
+  int slot = 0;
+  int rc = EVG_OK;
+  // uploads `bytes` from host pointer h; returns device pointer (nullptr when h is null / empty)
+  template <class T>
+  T* up(const T* h, size_t count) {
+    if (rc || !h || count == 0) { slot++; return nullptr; }
+    DevBuf& b = c->stage[slot++];
+    rc = ensure(c, b, count * sizeof(T));
+    if (rc) return nullptr;
+    if (hipMemcpyAsync(b.p, h, count * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      rc = set_err(c, EVG_E_HIP, "H2D copy failed");
+      return nullptr;
+    }
+    return (T*)b.p;
+  }
+  template <class T>
+  T* out(size_t count, bool wanted) {
+    if (rc || !wanted || count == 0) { slot++; return nullptr; }
+    DevBuf& b = c->stage[slot++];
+    rc = ensure(c, b, count * sizeof(T));
+    return rc ? nullptr : (T*)b.p;
+  }
+  template <class T>
+  void down(T* h, const T* dptr, size_t count) {
+    if (rc || !h || !dptr || count == 0) return;
+    if (hipMemcpyAsync(h, dptr, count * sizeof(T), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+      rc = set_err(c, EVG_E_HIP, "D2H copy failed");
+  }
+};
+
+extern "C" {
+
+int32_t evg_abi_version(void) { return (1 << 16) | 0; }
+
+const char* evg_last_error(const evg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+evg_ctx* evg_create(int device_ordinal) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_err(nullptr, EVG_E_NODEVICE, "no HIP device (%s); this library has no CPU fallback",
+            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device_ordinal < 0 || device_ordinal >= n) {
+    set_err(nullptr, EVG_E_INVALID, "device ordinal %d out of range [0,%d)", device_ordinal, n);
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) {
+    set_err(nullptr, EVG_E_HIP, "hipGetDeviceProperties failed");
+    return nullptr;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_err(nullptr, EVG_E_NODEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_ordinal,
+            prop.gcnArchName);
+    return nullptr;
+  }
+  evg_ctx* c = new evg_ctx();
+  c->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_err(nullptr, EVG_E_HIP, "cannot create a stream on device %d", device_ordinal);
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+void evg_destroy(evg_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->stage) if (b.p) (void)hipFree(b.p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len) {
+  auto fail = [&](const char* fmt, long a, long b) {
+    if (msg && msg_len > 0) snprintf(msg, msg_len, fmt, a, b);
+    return EVG_E_CONTRACT;
+  };
+  if (!in) return EVG_E_INVALID;
+  const int D = in->n_distros;
+  const evg_task_soa& t = in->tasks;
+  if (D < 0 || t.n_tasks < 0 || t.n_edges < 0) return fail("negative size (%ld, %ld)", D, t.n_tasks);
+  if (D == 0) return EVG_OK;
+  if (!in->task_off || !in->tg_off || !in->ver_off || !in->distros) return EVG_E_INVALID;
+  if (in->task_off[0] != 0 || in->task_off[D] != t.n_tasks) return fail("task_off must span [0, n_tasks] (%ld..%ld)", in->task_off[0], in->task_off[D]);
+  if (in->tg_off[0] != 0 || in->tg_off[D] != in->n_task_groups) return fail("tg_off must span [0, n_task_groups] (%ld..%ld)", in->tg_off[0], in->tg_off[D]);
+  if (in->ver_off[0] != 0 || in->ver_off[D] != in->n_versions) return fail("ver_off must span [0, n_versions] (%ld..%ld)", in->ver_off[0], in->ver_off[D]);
+  if (t.n_tasks && t.dep_off[t.n_tasks] != t.n_edges) return fail("dep_off[N]=%ld != n_edges=%ld", t.dep_off[t.n_tasks], t.n_edges);
+  for (int d = 0; d < D; d++) {
+    const int lo = in->task_off[d], hi = in->task_off[d + 1];
+    if (hi < lo) return fail("task_off not monotone at distro %ld (%ld)", d, hi);
+    if (hi - lo >= (1 << 24)) return fail("distro %ld has %ld tasks; the limit is 2^24-1", d, hi - lo);
+    int next_tg = in->tg_off[d], next_ver = in->ver_off[d];
+    for (int r = lo; r < hi; r++) {
+      const int g = t.tg_key[r], v = t.version_key[r];
+      if (g >= 0) {
+        if (g > next_tg || g < in->tg_off[d]) return fail("row %ld: tg_key %ld is not in first-appearance order", r, g);
+        if (g == next_tg) next_tg++;
+      } else if (g != -1) return fail("row %ld: tg_key %ld (use -1 for no task group)", r, g);
+      if (v > next_ver || v < in->ver_off[d]) return fail("row %ld: version_key %ld is not in first-appearance order", r, v);
+      if (v == next_ver) next_ver++;
+      if (t.dep_off[r + 1] < t.dep_off[r]) return fail("dep_off not monotone at row %ld (%ld)", r, t.dep_off[r + 1]);
+    }
+    if (next_tg != in->tg_off[d + 1]) return fail("distro %ld: tg keys do not fill [tg_off[d], tg_off[d+1]) (%ld)", d, next_tg);
+    if (next_ver != in->ver_off[d + 1]) return fail("distro %ld: version keys do not fill their range (%ld)", d, next_ver);
+  }
+  return EVG_OK;
+}
+
+static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, hipStream_t st) {
+  using namespace evg;
+  if (!c || !in || !out) return EVG_E_INVALID;
+  const int D = in->n_distros;
+  if (D < 0 || in->tasks.n_tasks < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
+  if (D == 0) return EVG_OK;
+  if (!out->order || !out->deps_met || !out->wait_ns || !out->distro_info || !out->group_info)
+    return set_err(c, EVG_E_INVALID, "order, deps_met, wait_ns, distro_info and group_info outputs are required");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t N = (size_t)in->tasks.n_tasks;
+  const size_t Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions + 1;
+  const size_t G = (size_t)D + (size_t)in->n_task_groups;
+  PlanArgs a;
+  a.in = *in;
+  a.out = *out;
+  // scratch of the large-distro path (untouched pages cost nothing; small distros never use it)
+  size_t sz[20] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
+                   4 * (N + 1), 8 * (N + 1), 8 * (N + 1), 8 * (N + 1), 4 * (N + 1),
+                   4 * G, 4 * G, 4 * G, 4 * G, 4 * G, 8 * G, 8 * G};
+  for (int i = 0; i < 20; i++) {
+    int rc = ensure(c, c->scratch[i], sz[i]);
+    if (rc) return rc;
+  }
+  a.w_tiq = (int64_t*)c->scratch[0].p; a.w_dur = (int64_t*)c->scratch[1].p; a.w_maxpri = (int64_t*)c->scratch[2].p;
+  a.w_val = (int64_t*)c->scratch[3].p; a.w_hash = (uint64_t*)c->scratch[4].p; a.w_cnt = (uint32_t*)c->scratch[5].p;
+  a.w_maxnd = (int32_t*)c->scratch[6].p; a.w_minrow = (uint32_t*)c->scratch[7].p; a.w_pslot = (uint32_t*)c->scratch[8].p;
+  a.w_k0 = (int64_t*)c->scratch[9].p; a.w_k1 = (uint64_t*)c->scratch[10].p; a.w_idx = (uint32_t*)c->scratch[11].p;
+  a.w_pos = (uint32_t*)c->scratch[12].p;
+  a.g_cnt = (uint32_t*)c->scratch[13].p; a.g_cover = (uint32_t*)c->scratch[14].p; a.g_wait = (uint32_t*)c->scratch[15].p;
+  a.g_mq = (uint32_t*)c->scratch[16].p; a.g_first = (uint32_t*)c->scratch[17].p; a.g_dur = (uint64_t*)c->scratch[18].p;
+  a.g_dover = (uint64_t*)c->scratch[19].p;
+  if (!c->lds_attr_set) {
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+    c->lds_attr_set = true;
+  }
+  hipLaunchKernelGGL(k_plan_distros, dim3(D), dim3(kBlock), L_TOTAL, st, a);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
+int evg_plan_distros_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, void* hip_stream) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return launch_plan(c, in, out, (hipStream_t)hip_stream);
+}
+
+static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, hipStream_t st) {
+  using namespace evg;
+  if (!c || !in || !out) return EVG_E_INVALID;
+  if (in->n_distros < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
+  if (in->n_distros == 0) return EVG_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  AllocArgs a;
+  a.in = *in;
+  a.out = *out;
+  const size_t G = (size_t)in->n_distros + (size_t)in->n_task_groups;
+  size_t sz[4] = {8 * ((size_t)in->hosts.n_hosts + 1), 4 * G, 4 * G, 4 * G};
+  for (int i = 0; i < 4; i++) {
+    int rc = ensure(c, c->scratch[20 + i], sz[i]);
+    if (rc) return rc;
+  }
+  a.w_term = (double*)c->scratch[20].p;
+  a.w_new = (int32_t*)c->scratch[21].p; a.w_free = (int32_t*)c->scratch[22].p; a.w_err = (int32_t*)c->scratch[23].p;
+  hipLaunchKernelGGL(k_allocate_hosts, dim3(in->n_distros), dim3(kAllocBlock), 0, st, a);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
+int evg_allocate_hosts_device(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, void* hip_stream) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return launch_alloc(c, in, out, (hipStream_t)hip_stream);
+}
+
+int evg_cap_queue_device(evg_ctx* c, int32_t n_distros, const int32_t* task_off, const int32_t* order,
+                         const int32_t* tg_name_key, int32_t max_scheduled, int32_t* cut, void* hip_stream) {
+  if (!c || n_distros < 0) return EVG_E_INVALID;
+  if (n_distros == 0) return EVG_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(evg::k_cap_queue, dim3((n_distros + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, n_distros,
+                     task_off, order, tg_name_key, max_scheduled, cut);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
+// ---- host-pointer entry points: stage in, run, stage out, synchronously ---------------------------------
+
+int evg_plan_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out) {
+  if (!c || !in || !out) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  char msg[256];
+  int rc = evg_validate_plan_input(in, msg, sizeof msg);
+  if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
+  const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, D = in->n_distros, G = D + in->n_task_groups;
+  if (D == 0) return EVG_OK;
+  Stager s{c};
+  evg_plan_input di = *in;
+  const evg_task_soa& t = in->tasks;
+  evg_task_soa& dt = di.tasks;
+  dt.priority = s.up(t.priority, N); dt.expected_duration_ns = s.up(t.expected_duration_ns, N);
+  dt.queue_ts_ns = s.up(t.queue_ts_ns, N); dt.scheduled_ts_ns = s.up(t.scheduled_ts_ns, N);
+  dt.deps_met_ts_ns = s.up(t.deps_met_ts_ns, N); dt.num_dependents = s.up(t.num_dependents, N);
+  dt.task_group_order = s.up(t.task_group_order, N); dt.task_group_max_hosts = s.up(t.task_group_max_hosts, N);
+  dt.tg_key = s.up(t.tg_key, N); dt.version_key = s.up(t.version_key, N); dt.flags = s.up(t.flags, N);
+  dt.dep_off = s.up(t.dep_off, N + 1); dt.dep_idx = s.up(t.dep_idx, E); dt.dep_info = s.up(t.dep_info, E);
+  dt.dep_finished_ts_ns = s.up(t.dep_finished_ts_ns, E);
+  di.distros = s.up(in->distros, D); di.task_off = s.up(in->task_off, D + 1); di.tg_off = s.up(in->tg_off, D + 1);
+  di.ver_off = s.up(in->ver_off, D + 1);
+  evg_plan_output dout;
+  dout.order = s.out<int32_t>(N, true);
+  dout.breakdown = s.out<int64_t>(N * EVG_BREAKDOWN_FIELDS, out->breakdown != nullptr);
+  dout.deps_met = s.out<uint8_t>(N, true);
+  dout.wait_ns = s.out<int64_t>(N, true);
+  dout.distro_info = s.out<evg_distro_info>(D, true);
+  dout.group_info = s.out<evg_group_info>(G, true);
+  dout.n_units = s.out<int32_t>(D, out->n_units != nullptr);
+  if (s.rc) return s.rc;
+  // a zero-task batch still needs valid (non-null) required outputs for the launch check
+  static int32_t dummy;
+  if (N == 0) {
+    // nothing to order; give the kernel harmless pointers
+    DevBuf& b = c->stage[47];
+    rc = ensure(c, b, 64);
+    if (rc) return rc;
+    dout.order = (int32_t*)b.p; dout.deps_met = (uint8_t*)b.p; dout.wait_ns = (int64_t*)b.p;
+    (void)dummy;
+  }
+  rc = launch_plan(c, &di, &dout, c->stream);
+  if (rc) return rc;
+  s.down(out->order, dout.order, N);
+  s.down(out->breakdown, dout.breakdown, N * EVG_BREAKDOWN_FIELDS);
+  s.down(out->deps_met, dout.deps_met, N);
+  s.down(out->wait_ns, dout.wait_ns, N);
+  s.down(out->distro_info, dout.distro_info, D);
+  s.down(out->group_info, dout.group_info, G);
+  s.down(out->n_units, dout.n_units, D);
+  if (s.rc) return s.rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EVG_OK;
+}
+
+int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out) {
+  if (!c || !in || !out) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t D = in->n_distros, G = D + in->n_task_groups, H = in->hosts.n_hosts;
+  if (D == 0) return EVG_OK;
+  if (!in->params || !in->host_off || !in->tg_off || !in->distro_info || !in->group_info || !out->new_hosts ||
+      !out->free_hosts || !out->status)
+    return set_err(c, EVG_E_INVALID, "null allocator argument");
+  Stager s{c};
+  s.slot = 24;
+  evg_alloc_input di = *in;
+  di.params = s.up(in->params, D); di.host_off = s.up(in->host_off, D + 1); di.tg_off = s.up(in->tg_off, D + 1);
+  di.hosts.flags = s.up(in->hosts.flags, H); di.hosts.tg_key = s.up(in->hosts.tg_key, H);
+  di.hosts.start_ts_ns = s.up(in->hosts.start_ts_ns, H);
+  di.hosts.expected_duration_ns = s.up(in->hosts.expected_duration_ns, H);
+  di.hosts.duration_stddev_ns = s.up(in->hosts.duration_stddev_ns, H);
+  di.distro_info = s.up(in->distro_info, D);
+  di.group_info = s.up((const evg_group_info*)in->group_info, G);
+  evg_alloc_output dout;
+  dout.new_hosts = s.out<int32_t>(D, true); dout.free_hosts = s.out<int32_t>(D, true); dout.status = s.out<int32_t>(D, true);
+  if (s.rc) return s.rc;
+  int rc = launch_alloc(c, &di, &dout, c->stream);
+  if (rc) return rc;
+  s.down(out->new_hosts, dout.new_hosts, D); s.down(out->free_hosts, dout.free_hosts, D);
+  s.down(out->status, dout.status, D);
+  s.down(in->group_info, (const evg_group_info*)di.group_info, G);
+  if (s.rc) return s.rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EVG_OK;
+}
+
+}  // extern "C"

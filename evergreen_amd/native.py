@@ -37,6 +37,15 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise NativeError("HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
                           "g.build()'`). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64, and a
+    # process that initialises the system runtime first and torch's second ends up with "No HIP GPUs are
+    # available" in the second one. When torch is installed (it is the designated plumbing for device memory
+    # and streams), import it first so that this library's NEEDED libamdhip64.so.7 resolves to the runtime
+    # already loaded. Without torch (the Go deployment) the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the library itself
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.evg_create.restype = C.c_void_p
     lib.evg_create.argtypes = [C.c_int]

@@ -1,0 +1,70 @@
+"""A task pool kept resident in HBM: torch owns the device memory and the stream (plumbing only), the C ABI's
+*_device entry points do the work. This is the production shape the boundary aims at (SURVEY.md 8b
+"Threading"): upload the pool once per tick, plan all distros in one launch, read back order + infos."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import abi, native
+
+
+class ResidentPool:
+    def __init__(self, ctx: native.Context, batch: abi.PlanBatch, device, breakdown: bool = False, n_units: bool = False):
+        import torch
+        self.torch = torch
+        self.ctx, self.batch, self.device = ctx, batch, device
+        self.t = batch.device_tensors(device)
+        n, D, G = batch.n_tasks, batch.n_distros, batch.n_distros + batch.n_task_groups
+        z = lambda *s, dt: torch.zeros(*s, dtype=dt, device=device)  # noqa: E731
+        self.o_order = z(max(n, 1), dt=torch.int32)
+        self.o_bd = z(max(n, 1) * abi.BREAKDOWN_FIELDS, dt=torch.int64) if breakdown else None
+        self.o_met = z(max(n, 1), dt=torch.uint8)
+        self.o_wait = z(max(n, 1), dt=torch.int64)
+        self.o_di = z(D * abi.DISTRO_INFO_DTYPE.itemsize, dt=torch.uint8)
+        self.o_gi = z(G * abi.GROUP_INFO_DTYPE.itemsize, dt=torch.uint8)
+        self.o_nu = z(D, dt=torch.int32) if n_units else None
+        self.inp = abi.make_plan_input(batch, self.t)
+        self.out = abi.PlanOutput()
+        self.out.order, self.out.deps_met, self.out.wait_ns = self.o_order.data_ptr(), self.o_met.data_ptr(), self.o_wait.data_ptr()
+        self.out.breakdown = self.o_bd.data_ptr() if breakdown else None
+        self.out.distro_info, self.out.group_info = self.o_di.data_ptr(), self.o_gi.data_ptr()
+        self.out.n_units = self.o_nu.data_ptr() if n_units else None
+        self.has_hosts = batch.alloc_params is not None
+        if self.has_hosts:
+            self.o_new, self.o_free, self.o_status = z(D, dt=torch.int32), z(D, dt=torch.int32), z(D, dt=torch.int32)
+            self.ainp = abi.make_alloc_input(batch, self.o_di, self.o_gi, self.t)
+            self.aout = abi.AllocOutput()
+            self.aout.new_hosts, self.aout.free_hosts, self.aout.status = (self.o_new.data_ptr(), self.o_free.data_ptr(),
+                                                                            self.o_status.data_ptr())
+
+    def stream(self) -> int:
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def plan(self, stream: Optional[int] = None) -> None:
+        self.ctx.plan_device(self.inp, self.out, self.stream() if stream is None else stream)
+
+    def allocate(self, stream: Optional[int] = None) -> None:
+        self.ctx.allocate_device(self.ainp, self.aout, self.stream() if stream is None else stream)
+
+    def step(self, stream: Optional[int] = None) -> None:
+        """One pass of the hot path over the resident pool: plan + queue info [+ host allocation]."""
+        s = self.stream() if stream is None else stream
+        self.ctx.plan_device(self.inp, self.out, s)
+        if self.has_hosts:
+            self.ctx.allocate_device(self.ainp, self.aout, s)
+
+    def plan_result(self) -> abi.PlanResult:
+        n = self.batch.n_tasks
+        self.torch.cuda.synchronize(self.device)
+        return abi.PlanResult(
+            order=self.o_order.cpu().numpy()[:n],
+            breakdown=self.o_bd.cpu().numpy().reshape(-1, abi.BREAKDOWN_FIELDS)[:n] if self.o_bd is not None else None,
+            deps_met=self.o_met.cpu().numpy()[:n], wait_ns=self.o_wait.cpu().numpy()[:n],
+            distro_info=self.o_di.cpu().numpy().view(abi.DISTRO_INFO_DTYPE), group_info=self.o_gi.cpu().numpy().view(abi.GROUP_INFO_DTYPE),
+            n_units=self.o_nu.cpu().numpy() if self.o_nu is not None else None)
+
+    def alloc_result(self) -> abi.AllocResult:
+        self.torch.cuda.synchronize(self.device)
+        return abi.AllocResult(self.o_new.cpu().numpy(), self.o_free.cpu().numpy(), self.o_status.cpu().numpy())

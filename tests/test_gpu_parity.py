@@ -1,0 +1,188 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors.
+Everything here is integer / index work: the bar is bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from evergreen_amd import abi, gen
+from evergreen_amd import scheduler as S
+from tests import compare
+from tests import golden_cases as G
+from tests import golden_runner as R
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- the reference's known-answer tests, run on the GPU ------------------------------------------------------
+@pytest.mark.parametrize("check", [
+    R.check_unit_values, R.check_grouped_unit, R.check_dependency_first, R.check_task_plan_order, R.check_task_list,
+    R.check_prepare, R.check_queue_info, R.check_distro_alias_order, R.check_allocator, R.check_calc_existing_free,
+    R.check_allocator_errors, R.check_in_place_group_counts], ids=lambda f: f.__name__)
+def test_reference_golden_vectors(native_ctx, check):
+    check(native_ctx)
+
+
+def test_allocator_fuzz_matches_oracle(native_ctx, oracle):
+    got = R.check_fuzz_invariants(native_ctx)
+    want = R.check_fuzz_invariants(oracle)
+    assert got == want
+
+
+def _cap_gpu(ctx):
+    import torch
+
+    def cap(batch, order, limit):
+        dev = torch.device("cuda:0")
+        t_off = torch.from_numpy(batch.task_off).to(dev)
+        t_ord = torch.from_numpy(order).to(dev)
+        t_key = torch.from_numpy(batch.tg_name_key).to(dev)
+        cut = torch.zeros(batch.n_distros, dtype=torch.int32, device=dev)
+        ctx.cap_queue_device(batch.n_distros, t_off.data_ptr(), t_ord.data_ptr() if order.size else None,
+                             t_key.data_ptr() if order.size else None, limit, cut.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return cut.cpu().numpy()
+    return cap
+
+
+def test_cap_task_queue_length(native_ctx):
+    R.check_cap(_cap_gpu(native_ctx))
+
+
+# ---- synthetic pools: full bit-exact comparison ---------------------------------------------------------------
+def _full_compare(native_ctx, oracle, batch, what):
+    got = native_ctx.plan(batch)
+    want = oracle.plan(batch)
+    compare.assert_plan_equal(got, want, batch, what)
+    compare.queue_properties(batch, got)
+    if batch.alloc_params is not None:
+        a = native_ctx.allocate(batch, got.distro_info, got.group_info)
+        b = oracle.allocate(batch, want.distro_info, want.group_info)
+        compare.assert_alloc_equal(a, b, what)
+        for name in ("count_free", "count_required"):
+            assert np.array_equal(got.group_info[name], want.group_info[name]), what + " " + name
+    return got
+
+
+@pytest.mark.parametrize("num", [1, 2])
+def test_config_small(native_ctx, oracle, num):
+    _full_compare(native_ctx, oracle, gen.generate(gen.config(num)), "config %d" % num)
+
+
+def test_config3_1m_tasks_512_distros(native_ctx, oracle):
+    """BASELINE config 3 at full size. The oracle needs a few seconds for 1M tasks, so the comparison is still
+    the full bit-exact one; the size-independent properties are checked on top."""
+    _full_compare(native_ctx, oracle, gen.generate(gen.config(3)), "config 3")
+
+
+def test_dag_depth8_more_task_groups(native_ctx, oracle):
+    """config 5's shape (DAG depth 8, 20% task-group tasks) at a single-GPU test size."""
+    _full_compare(native_ctx, oracle, gen.generate(gen.config(5, n_tasks=200_000, n_distros=128)), "config 5 shape")
+
+
+def test_skewed_distros_large_path(native_ctx, oracle):
+    """Zipf distro sizes: the head distros exceed the LDS path (2048 tasks) and take the global-scratch path."""
+    b = gen.generate(gen.GenConfig(60_000, 24, gen.SEED_BASE + 31, skew=True))
+    assert int(np.diff(b.task_off).max()) > 4096
+    _full_compare(native_ctx, oracle, b, "skewed")
+
+
+def test_unshuffled_and_no_hosts(native_ctx, oracle):
+    _full_compare(native_ctx, oracle, gen.generate(gen.GenConfig(5_000, 7, 77, shuffle=False, with_hosts=False)), "unshuffled")
+
+
+@pytest.mark.parametrize("n,d", [(0, 1), (0, 3), (1, 1), (2, 2), (3, 5), (64, 1), (65, 1), (129, 2), (2048, 1), (2049, 1)])
+def test_ragged_and_empty(native_ctx, oracle, n, d):
+    """Empty pools, empty distros (d > n), sizes around the wave / workgroup / LDS-path boundaries."""
+    cfg = gen.GenConfig(max(n, 0), d, 900 + n + d)
+    if n < d:  # distro sizes must allow zeros
+        cfg = gen.GenConfig(n, d, 900 + n + d, with_hosts=True)
+    b = gen.generate(cfg)
+    _full_compare(native_ctx, oracle, b, "n=%d d=%d" % (n, d))
+
+
+def test_all_task_group_versions_quirk(native_ctx, oracle):
+    """Versions made only of task-group tasks under GroupVersions: the version unit has no distro and is dropped
+    (planner.go:81,439); every distro groups versions here."""
+    b = gen.generate(gen.GenConfig(20_000, 16, 4242, all_tg_version_fraction=0.3, tg_fraction=0.3))
+    b.distros["group_versions"] = 1
+    _full_compare(native_ctx, oracle, b, "all-tg versions")
+
+
+def test_extreme_values(native_ctx, oracle):
+    """Max priorities, Go-zero times everywhere, zero durations, negative priorities."""
+    b = gen.generate(gen.GenConfig(4_000, 4, 555))
+    n = b.n_tasks
+    rng = np.random.default_rng(5)
+    b.cols["priority"][rng.random(n) < 0.1] = 2**40
+    b.cols["priority"][rng.random(n) < 0.1] = -5
+    b.cols["queue_ts_ns"][rng.random(n) < 0.3] = abi.EVG_TIME_GO_ZERO
+    b.cols["scheduled_ts_ns"][rng.random(n) < 0.3] = abi.EVG_TIME_GO_ZERO
+    b.cols["expected_duration_ns"][rng.random(n) < 0.1] = 0
+    b.cols["num_dependents"][rng.random(n) < 0.05] = 2**31 - 1
+    _full_compare(native_ctx, oracle, b, "extremes")
+
+
+def test_plan_is_deterministic(native_ctx):
+    b = gen.generate(gen.config(2))
+    r1 = native_ctx.plan(b)
+    r2 = native_ctx.plan(b)
+    assert np.array_equal(r1.order, r2.order) and np.array_equal(r1.group_info, r2.group_info)
+
+
+def test_row_permutation_invariance(native_ctx):
+    """Property: the multiset of (TotalValue) stamped per task does not depend on the input row order."""
+    b1 = gen.generate(gen.GenConfig(30_000, 16, 99, shuffle=False, with_hosts=False))
+    b2 = gen.generate(gen.GenConfig(30_000, 16, 99, shuffle=True, with_hosts=False))
+    r1, r2 = native_ctx.plan(b1), native_ctx.plan(b2)
+    for d in range(16):
+        lo, hi = int(b1.task_off[d]), int(b1.task_off[d + 1])
+        assert np.array_equal(np.sort(r1.breakdown[lo:hi, 1]), np.sort(r2.breakdown[lo:hi, 1]))
+    assert np.array_equal(r1.distro_info, r2.distro_info)
+    assert np.array_equal(r1.n_units, r2.n_units)
+
+
+def test_device_resident_entry_points(native_ctx, oracle):
+    """evg_plan_distros_device / evg_allocate_hosts_device on torch-owned device memory and torch's stream."""
+    import torch
+    dev = torch.device("cuda:0")
+    b = gen.generate(gen.config(2))
+    t = b.device_tensors(dev)
+    n, D, Gn = b.n_tasks, b.n_distros, b.n_distros + b.n_task_groups
+    o_order = torch.empty(n, dtype=torch.int32, device=dev)
+    o_bd = torch.empty(n * abi.BREAKDOWN_FIELDS, dtype=torch.int64, device=dev)
+    o_met = torch.empty(n, dtype=torch.uint8, device=dev)
+    o_wait = torch.empty(n, dtype=torch.int64, device=dev)
+    o_di = torch.empty(D * abi.DISTRO_INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    o_gi = torch.empty(Gn * abi.GROUP_INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    o_nu = torch.empty(D, dtype=torch.int32, device=dev)
+    inp = abi.make_plan_input(b, t)
+    out = abi.PlanOutput()
+    out.order, out.breakdown, out.deps_met, out.wait_ns = o_order.data_ptr(), o_bd.data_ptr(), o_met.data_ptr(), o_wait.data_ptr()
+    out.distro_info, out.group_info, out.n_units = o_di.data_ptr(), o_gi.data_ptr(), o_nu.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    native_ctx.plan_device(inp, out, st)
+    ainp = abi.make_alloc_input(b, o_di, o_gi, t)
+    o_new = torch.empty(D, dtype=torch.int32, device=dev)
+    o_free = torch.empty(D, dtype=torch.int32, device=dev)
+    o_st = torch.empty(D, dtype=torch.int32, device=dev)
+    aout = abi.AllocOutput()
+    aout.new_hosts, aout.free_hosts, aout.status = o_new.data_ptr(), o_free.data_ptr(), o_st.data_ptr()
+    native_ctx.allocate_device(ainp, aout, st)
+    torch.cuda.synchronize()
+    want = oracle.plan(b)
+    got = abi.PlanResult(order=o_order.cpu().numpy(), breakdown=o_bd.cpu().numpy().reshape(n, -1), deps_met=o_met.cpu().numpy(),
+                         wait_ns=o_wait.cpu().numpy(), distro_info=o_di.cpu().numpy().view(abi.DISTRO_INFO_DTYPE),
+                         group_info=o_gi.cpu().numpy().view(abi.GROUP_INFO_DTYPE), n_units=o_nu.cpu().numpy())
+    wa = oracle.allocate(b, want.distro_info, want.group_info)
+    compare.assert_plan_equal(got, want, b, "device api")
+    assert np.array_equal(o_new.cpu().numpy(), wa.new_hosts) and np.array_equal(o_free.cpu().numpy(), wa.free_hosts)
+
+
+def test_contract_violation_is_rejected(native_ctx):
+    b = gen.generate(gen.config(1))
+    b.cols["tg_key"][0] = 10**6
+    with pytest.raises(Exception) as e:
+        native_ctx.plan(b)
+    assert "first-appearance" in str(e.value) or "tg_key" in str(e.value)
