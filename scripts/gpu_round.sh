@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the gpurun box from the repo root: GPU parity tests, bench, rocprofv3 kernel stats and PMC passes.
+# Everything lands in gpurun_out/ (merged back by gpurun); summaries worth keeping are copied to profiles/ by hand.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+TAG=${1:-r01}
+mkdir -p $OUT/prof
+cd $R
+echo "== pytest -m gpu" | tee $OUT/pytest_$TAG.log
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee -a $OUT/pytest_$TAG.log
+echo "== bench" | tee $OUT/bench_$TAG.log
+timeout 600 python bench.py --steps 50 --warmup 5 2>&1 | tail -5 | tee -a $OUT/bench_$TAG.log
+cd /tmp && export TMPDIR=/tmp
+echo "== rocprofv3 kernel-trace stats"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof/$TAG-stats -o $TAG -- \
+  python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/prof/$TAG-stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  echo "== rocprofv3 pmc $c"
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/prof/$TAG-pmc-$c -o $TAG -- \
+    python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof/$TAG-pmc-$c.log 2>&1
+done
+find $OUT/prof -name "*.csv" | head -50
+python $R/scripts/summarize_prof.py $OUT/prof $TAG > $OUT/prof/$TAG-summary.txt 2>&1
+cat $OUT/prof/$TAG-summary.txt
