@@ -1,7 +1,10 @@
 // evg_kernels.hip.h -- gfx950 device code of the per-distro scheduling hot path.
 //
-// One workgroup (1024 threads = 16 wave64) plans ONE distro end to end; a launch covers all D distros
-// (D = 512 in the headline config => 2 workgroups per CU on 256 CUs). Per distro:
+// This header holds the shared device helpers (Go-exact time/duration arithmetic, unitInfo.value()) and the
+// GENERIC per-distro path: one workgroup plans one distro with every intermediate in a global scratch area.
+// It handles any distro size and any value range, is correct and deliberately simple, and is only taken by
+// distros that do not fit the LDS path of evg_plan_lds.hip.h (more than 2048 tasks, too many unit slots or
+// task groups, priorities beyond int32). Phases (same in both paths):
 //
 //   P1 slots     task columns -> primary unit slot per task                  (planner.go:431-448)
 //   P2 reduce    every task adds itself to each unit it is a member of: atomics into per-unit
@@ -9,15 +12,12 @@
 //   P3 score     one thread per unit: unitInfo.value()                       (planner.go:209-300)
 //   P4 elect     per task: its best unit = the unit it is emitted from by the first-occurrence
 //                dedup of TaskPlan.Export                                    (planner.go:462-481)
-//   P5 sort      bitonic sort of the distro's tasks by (unit key, in-unit task key) == sort.Sort(units)
+//   P5 sort      sort of the distro's tasks by (unit key, in-unit task key) == sort.Sort(units)
 //                + per-unit sort.Sort(tasks) + dedup, under the canonical tie-break
 //   P6 info      GetDistroQueueInfo: deps-met per task, per-task-group segmented sums
 //                                                                           (scheduler.go:57-178)
 //
-// Small distros (<= 2048 tasks, <= 2560 unit slots) keep every intermediate in LDS (~146 KiB of the
-// CU's 160 KiB); only input columns are read from global memory and only results are written. Larger
-// distros run the SAME code with the intermediates in a global scratch area (correct, not tuned -- see
-// DESIGN.md). No MFMA anywhere: the path is scan / reduce / sort / gather.
+// No MFMA anywhere: the path is scan / reduce / sort / gather.
 //
 // fp64 steps (Duration.Minutes()/Hours(), floor, float->int) must match Go bit for bit: compile with
 // -ffp-contract=off; only IEEE division is used.
@@ -32,10 +32,7 @@
 
 namespace evg {
 
-constexpr int kBlock = 1024;          // threads per distro workgroup
-constexpr int kLdsMaxTasks = 2048;    // padded task count (pow2) limit of the LDS path
-constexpr int kLdsMaxSlots = 2560;    // unit-slot limit of the LDS path
-constexpr int kLdsMaxGroups = 1536;   // task-group rows (incl. the standalone row) limit of the LDS path
+constexpr int kBlock = 512;           // threads per distro workgroup (both paths)
 
 constexpr int64_t kSecond = 1000000000LL;
 constexpr int64_t kMinute = 60 * kSecond;
@@ -46,21 +43,6 @@ constexpr int64_t kMaxDurationPerDistroHost = 30 * kMinute;  // globals.go:273
 constexpr uint32_t UF_MERGE = 1u << 24, UF_PATCH = 2u << 24, UF_NONGROUP = 4u << 24, UF_GENERATE = 8u << 24,
                    UF_STEPBACK = 16u << 24, UF_DISTRO = 32u << 24;
 constexpr uint32_t UF_COUNT_MASK = 0x00FFFFFFu;
-
-// LDS carve-up of the small path (bytes)
-constexpr int L_TIQ = 0, L_DUR = L_TIQ + 8 * kLdsMaxSlots, L_MAXPRI = L_DUR + 8 * kLdsMaxSlots,
-              L_VAL = L_MAXPRI + 8 * kLdsMaxSlots, L_CNT = L_VAL + 8 * kLdsMaxSlots, L_MAXND = L_CNT + 4 * kLdsMaxSlots,
-              L_MINROW = L_MAXND + 4 * kLdsMaxSlots, L_ACC_END = L_MINROW + 4 * kLdsMaxSlots;
-constexpr int L_K0 = L_ACC_END, L_K1 = L_K0 + 8 * kLdsMaxTasks, L_IDX = L_K1 + 4 * kLdsMaxTasks,
-              L_PSLOT = L_IDX + 2 * kLdsMaxTasks, L_TFLAGS = L_PSLOT + 2 * kLdsMaxTasks,
-              L_TOTAL = L_TFLAGS + 2 * kLdsMaxTasks;
-// after P4 the accumulator region is dead and is re-used for the sort's task-key columns and, behind
-// them, the task-group accumulators of P6
-constexpr int L_CPRI = 0, L_CDUR = L_CPRI + 8 * kLdsMaxTasks, L_CTGO = L_CDUR + 8 * kLdsMaxTasks,
-              L_CND = L_CTGO + 4 * kLdsMaxTasks, L_G = L_CND + 4 * kLdsMaxTasks;
-static_assert(8 * kLdsMaxSlots <= 8 * kLdsMaxTasks + 4 * kLdsMaxTasks, "hash[] must fit in the k0/k1 area");
-static_assert(L_G + 36 * kLdsMaxGroups <= L_ACC_END, "group accumulators must fit in the dead accumulator area");
-static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
 
 struct PlanArgs {
   evg_plan_input in;    // device pointers
@@ -78,7 +60,21 @@ struct PlanArgs {
   uint32_t* w_pos;    // [N]
   uint32_t *g_cnt, *g_cover, *g_wait, *g_mq, *g_first;  // [D + n_tg]
   uint64_t *g_dur, *g_dover;
+  int32_t* w_generic;  // [D] 1: the distro was left to k_plan_generic
+#ifdef EVG_PHASE_TIMING
+  unsigned long long* dbg_ts;  // [D][16] s_memtime stamps at the phase boundaries (scripts/phase_timing.py)
+#endif
 };
+
+#ifdef EVG_PHASE_TIMING
+#define EVG_STAMP(k)                                                                                   \
+  do {                                                                                                 \
+    __syncthreads();                                                                                   \
+    if (threadIdx.x == 0 && a.dbg_ts) a.dbg_ts[(size_t)c.d * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define EVG_STAMP(k) do {} while (0)
+#endif
 
 // ---- small helpers ----------------------------------------------------------------------------------
 __device__ __forceinline__ int64_t wrap_add(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
@@ -112,16 +108,67 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// ---- cross-lane exchange without the LDS pipe ----------------------------------------------------------------
+// ds_bpermute (what __shfl_xor compiles to) occupies the CU's LDS pipeline, which the atomics and the staged
+// arrays of this kernel need; DPP modifiers and the gfx950 v_permlane{16,32}_swap run in the VALU instead.
+// lane_xor<M>(v): value of lane (lane ^ M), M in {1,2,4,8,16,32} -- verified lane-exact on MI355X.
+template <int CTRL, int BANK = 0xF>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, BANK, false);
 }
-__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
-  return v;
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+  if constexpr (M == 1) return dpp_mov<0xB1>(v, v);        // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return dpp_mov<0x4E>(v, v);   // quad_perm [2,3,0,1]
+  else if constexpr (M == 4) return dpp_mov<0x114, 0xA>(dpp_mov<0x104, 0x5>(v, v), v);  // row_shl:4 | row_shr:4 by bank
+  else if constexpr (M == 8) return dpp_mov<0x128>(v, v);  // row_ror:8
+  else if constexpr (M == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (__lane_id() & 16) ? r[0] : r[1];
+  } else {
+    static_assert(M == 32, "lane_xor distance");
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (__lane_id() & 32) ? r[0] : r[1];
+  }
 }
+template <int M>
+__device__ __forceinline__ uint64_t lane_xor(uint64_t v) {
+  return ((uint64_t)lane_xor<M>((uint32_t)(v >> 32)) << 32) | lane_xor<M>((uint32_t)v);
+}
+// butterflies inside a 16-lane row (xor 1, xor 2, mirror in 8, mirror in 16), then the four row results
+template <class T, class Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op) {
+  if constexpr (sizeof(T) == 4) {
+    v = op(v, (T)dpp_mov<0xB1>((uint32_t)v, (uint32_t)v));
+    v = op(v, (T)dpp_mov<0x4E>((uint32_t)v, (uint32_t)v));
+    v = op(v, (T)dpp_mov<0x141>((uint32_t)v, (uint32_t)v));  // row_half_mirror
+    v = op(v, (T)dpp_mov<0x140>((uint32_t)v, (uint32_t)v));  // row_mirror
+    const T a = (T)__builtin_amdgcn_readlane((int)v, 0), b = (T)__builtin_amdgcn_readlane((int)v, 16),
+            c = (T)__builtin_amdgcn_readlane((int)v, 32), d = (T)__builtin_amdgcn_readlane((int)v, 48);
+    return op(op(a, b), op(c, d));
+  } else {
+    auto x = [](T w, auto f) {
+      const uint64_t u = (uint64_t)w;
+      return (T)(((uint64_t)f((uint32_t)(u >> 32)) << 32) | f((uint32_t)u));
+    };
+    v = op(v, x(v, [](uint32_t w) { return dpp_mov<0xB1>(w, w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_mov<0x4E>(w, w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_mov<0x141>(w, w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_mov<0x140>(w, w); }));
+    auto rl = [&](int l) {
+      const uint64_t u = (uint64_t)v;
+      return (T)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l) << 32) |
+                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l));
+    };
+    return op(op(rl(0), rl(16)), op(rl(32), rl(48)));
+  }
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return wave_reduce(v, [](uint32_t a, uint32_t b) { return a + b; }); }
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) { return wave_reduce(v, [](uint64_t a, uint64_t b) { return a + b; }); }
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) { return wave_reduce(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) { return wave_reduce(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
+__device__ __forceinline__ uint64_t wave_min(uint64_t v) { return wave_reduce(v, [](uint64_t a, uint64_t b) { return a < b ? a : b; }); }
+__device__ __forceinline__ uint64_t wave_max(uint64_t v) { return wave_reduce(v, [](uint64_t a, uint64_t b) { return a > b ? a : b; }); }
 
 // distro.go:448-475
 __device__ __forceinline__ int64_t target_time_for_queue(const evg_distro_params& p, bool has_mq) {
@@ -179,7 +226,9 @@ __device__ inline int64_t unit_value(const evg_distro_params& p, int64_t n, int6
 // Per-distro uniform state.
 struct DC {
   int d, D, lo, n, tg_lo, ntg, ver_lo, nver, S, tg_base, ver_base, P;
-  bool gv;
+  int eb, ne;  // first dependency edge of the distro in the global CSR; number of edges
+  bool gv;     // PlannerSettings.ShouldGroupVersions()
+  bool eL;     // LDS path: the edges are staged in LDS
   int64_t now;
 };
 
@@ -264,7 +313,7 @@ __device__ __forceinline__ bool queue_less(const Mem<LDS>& m, uint32_t a, uint32
 }
 
 template <bool LDS>
-__device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigned* s_red) {
+__device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigned* s_red) {
   using idx_t = typename Mem<LDS>::idx_t;
   using k1_t = typename Mem<LDS>::k1_t;
   const evg_task_soa& t = a.in.tasks;
@@ -274,6 +323,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
   const int lane = tid & 63;
   const int lo = c.lo, n = c.n, S = c.S;
 
+  EVG_STAMP(0);
   // ---- P0/P1: init accumulators, primary slots ---------------------------------------------------------
   for (int u = tid; u < S; u += kBlock) {
     m.tiq[u] = 0; m.dur[u] = 0; m.maxpri[u] = 0; m.cnt[u] = 0; m.maxnd[u] = 0; m.minrow[u] = 0xFFFFFFFFu;
@@ -286,6 +336,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
   if (tid < 8) s_red[tid] = 0;
   __syncthreads();
 
+  EVG_STAMP(1);
   // ---- P2: segmented reduce of Unit.info (planner.go:302-337) -------------------------------------------
   for (int i = tid; i < n; i += kBlock) {
     const int r = lo + i;
@@ -311,6 +362,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
   }
   __syncthreads();
 
+  EVG_STAMP(2);
   // ---- P3: score every unit (planner.go:209-300); units whose distro is nil are dropped (:81) ---------------
   for (int u = tid; u < S; u += kBlock) {
     const uint32_t cw = m.cnt[u];
@@ -321,6 +373,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
   }
   __syncthreads();
 
+  EVG_STAMP(3);
   // ---- P3b (optional): TaskPlan.Len() after UnitCache.Export's set-equality dedup (planner.go:73-89) --------
   // Unit identity = (member count, min member, commutative 64-bit hash of the member rows); the reference's
   // own identity is a hash too (sha1 of the sorted ids, :154-172). Set-equal units share their min member,
@@ -358,6 +411,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
     __syncthreads();  // hash[] aliases k0/k1
   }
 
+  EVG_STAMP(4);
   // ---- P4: elect each task's emitting unit; build its sort key -------------------------------------------
   for (int i = tid; i < n; i += kBlock) {
     const int r = lo + i;
@@ -383,6 +437,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
   }
   __syncthreads();  // accumulators are dead from here on
 
+  EVG_STAMP(5);
   const int P = c.P;
   const uint32_t pad = LDS ? 0xFFFFu : 0xFFFFFFFFu;
   if (LDS) {
@@ -404,6 +459,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
     m.g_dur[g] = 0; m.g_dover[g] = 0;
   }
 
+  EVG_STAMP(6);
   // ---- P5: bitonic sort of idx[] by queue_less ------------------------------------------------------------
   int prev_j = 1 << 30;
   for (int k = 2; k <= P; k <<= 1) {
@@ -428,6 +484,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
   }
   __syncthreads();
 
+  EVG_STAMP(7);
   // ---- queue order out; inverse permutation -------------------------------------------------------------
   for (int q = tid; q < n; q += kBlock) {
     const uint32_t i = m.idx[q];
@@ -435,6 +492,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
     m.pos[i] = (idx_t)q;
   }
 
+  EVG_STAMP(8);
   // ---- P6: GetDistroQueueInfo (scheduler.go:57-178) --------------------------------------------------------
   // pass A: checkDependenciesMet per task; does any met merge-queue task exist?
   const bool incl = p.includes_dependencies != 0;
@@ -486,6 +544,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
   __syncthreads();
   const int64_t T = target_time_for_queue(p, s_red[0] != 0);
 
+  EVG_STAMP(9);
   // pass B: segmented sums keyed by task group ("" = row g0). The standalone row takes ~90% of the tasks:
   // wave-reduce it and issue one atomic per wave; task-group rows take direct atomics.
   uint32_t n_met = 0, n_mq = 0, n_s3 = 0, sec = 0;
@@ -547,6 +606,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
   if (__any(sec) && lane == 0) atomicOr(&s_red[4], 1u);
   __syncthreads();
 
+  EVG_STAMP(10);
   // rows out: model.TaskGroupInfo; MaxHosts = first task of the group in QUEUE order (scheduler.go:103-106)
   uint64_t t_dur = 0, t_dover = 0;
   uint32_t t_cover = 0, t_wait = 0, t_rows = 0;
@@ -596,68 +656,7 @@ __device__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigne
     di.n_task_group_infos = (int32_t)s_red[8];
     a.out.distro_info[d] = di;
   }
-}
-
-// One workgroup per distro.
-__global__ void __launch_bounds__(kBlock) k_plan_distros(const PlanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ __attribute__((aligned(8))) unsigned s_red[16];
-  const int d = blockIdx.x;
-  DC c;
-  c.d = d;
-  c.D = a.in.n_distros;
-  c.lo = a.in.task_off[d];
-  c.n = a.in.task_off[d + 1] - c.lo;
-  c.tg_lo = a.in.tg_off[d];
-  c.ntg = a.in.tg_off[d + 1] - c.tg_lo;
-  c.ver_lo = a.in.ver_off[d];
-  c.nver = a.in.ver_off[d + 1] - c.ver_lo;
-  c.gv = a.in.distros[d].group_versions != 0;
-  c.now = a.in.now_ns;
-  // slot map: !gv: own task units [0,n) then task groups; gv: task groups then versions (no own units)
-  if (c.gv) { c.tg_base = 0; c.ver_base = c.ntg; c.S = c.ntg + c.nver; }
-  else { c.tg_base = c.n; c.ver_base = c.n + c.ntg; c.S = c.n + c.ntg; }
-  int P = 1;
-  while (P < c.n) P <<= 1;
-  c.P = P;
-  if (threadIdx.x < 16) s_red[threadIdx.x] = 0;
-  __syncthreads();
-
-  if (P <= kLdsMaxTasks && c.S <= kLdsMaxSlots && c.ntg + 1 <= kLdsMaxGroups) {
-    Mem<true> m;
-    m.tiq = (int64_t*)(smem + L_TIQ); m.dur = (int64_t*)(smem + L_DUR); m.maxpri = (int64_t*)(smem + L_MAXPRI);
-    m.val = (int64_t*)(smem + L_VAL); m.cnt = (uint32_t*)(smem + L_CNT); m.maxnd = (int32_t*)(smem + L_MAXND);
-    m.minrow = (uint32_t*)(smem + L_MINROW); m.hash = (uint64_t*)(smem + L_K0);
-    m.pslot = (uint16_t*)(smem + L_PSLOT); m.tflags = (uint16_t*)(smem + L_TFLAGS);
-    m.k0 = (int64_t*)(smem + L_K0); m.k1 = (uint32_t*)(smem + L_K1); m.idx = (uint16_t*)(smem + L_IDX);
-    m.pos = (uint16_t*)(smem + L_PSLOT);
-    m.c_pri = (const int64_t*)(smem + L_CPRI); m.c_dur = (const int64_t*)(smem + L_CDUR);
-    m.c_tgo = (const int32_t*)(smem + L_CTGO); m.c_nd = (const int32_t*)(smem + L_CND);
-    unsigned char* g = smem + L_G;
-    m.g_dur = (uint64_t*)g; g += 8 * kLdsMaxGroups;
-    m.g_dover = (uint64_t*)g; g += 8 * kLdsMaxGroups;
-    m.g_cnt = (uint32_t*)g; g += 4 * kLdsMaxGroups;
-    m.g_cover = (uint32_t*)g; g += 4 * kLdsMaxGroups;
-    m.g_wait = (uint32_t*)g; g += 4 * kLdsMaxGroups;
-    m.g_mq = (uint32_t*)g; g += 4 * kLdsMaxGroups;
-    m.g_first = (uint32_t*)g;
-    m.g0 = 0; m.gk = 1;
-    plan_distro<true>(a, c, m, s_red);
-  } else {
-    const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // disjoint slot range of this distro
-    Mem<false> m;
-    m.tiq = a.w_tiq + sb; m.dur = a.w_dur + sb; m.maxpri = a.w_maxpri + sb; m.val = a.w_val + sb;
-    m.cnt = a.w_cnt + sb; m.maxnd = a.w_maxnd + sb; m.minrow = a.w_minrow + sb; m.hash = a.w_hash + sb;
-    m.pslot = a.w_pslot + c.lo; m.tflags = nullptr;
-    m.k0 = a.w_k0 + c.lo; m.k1 = a.w_k1 + c.lo; m.idx = a.w_idx + 2 * (size_t)c.lo; m.pos = a.w_pos + c.lo;
-    const evg_task_soa& t = a.in.tasks;
-    m.c_pri = t.priority + c.lo; m.c_dur = t.expected_duration_ns + c.lo;
-    m.c_tgo = t.task_group_order + c.lo; m.c_nd = t.num_dependents + c.lo;
-    m.g_cnt = a.g_cnt; m.g_cover = a.g_cover; m.g_wait = a.g_wait; m.g_mq = a.g_mq; m.g_first = a.g_first;
-    m.g_dur = a.g_dur; m.g_dover = a.g_dover;
-    m.g0 = d; m.gk = c.D + c.tg_lo;
-    plan_distro<false>(a, c, m, s_red);
-  }
+  EVG_STAMP(11);
 }
 
 }  // namespace evg

@@ -1,0 +1,889 @@
+// evg_plan_lds.hip.h -- the LDS path of the fused per-distro planner + queue-info kernel (gfx950).
+//
+// One 512-thread workgroup (8 wave64) plans ONE distro end to end; thread t owns tasks 4t..4t+3 of the distro
+// (blocked, so every column is fetched with one 16-byte-per-lane coalesced load and stays in registers).
+// A launch covers all D distros; the lean configuration needs < 80 KiB of LDS, so two workgroups share a CU
+// and the 512 distros of the headline config are all resident at once (256 CUs x 2).
+//
+//   A  load     task columns -> registers; primary unit slot (+ status bits) -> LDS; the distro's dependency
+//               edges (a contiguous CSR range) -> LDS as packed 16-bit records; accumulators zeroed
+//   B  reduce   Unit.info (planner.go:302-337): every task adds itself to each unit it is a member of
+//               (LDS atomics = the segmented reduce)
+//   C  score    unitInfo.value() (planner.go:209-300), one thread per unit slot
+//   D  elect    per task: the unit it is emitted from by TaskPlan.Export's first-occurrence dedup
+//               (planner.go:462-481) = its best unit under (TotalValue desc, canonical tie-break)
+//   E  sort     range-compressed 64-bit keys [maxValue-value | unit min row | unit slot | row], bitonic network
+//               with 4 keys per lane: in-lane, wave-shuffle and (6 of 66 stages) LDS exchange steps
+//   F  in-unit  tasks of one unit are now contiguous; TaskList.Less (planner.go:380-405) order inside each run
+//               by counting, on range-compressed 64-bit in-unit keys
+//   G  info     GetDistroQueueInfo (scheduler.go:57-178): deps-met per task from the LDS edge records,
+//               per-task-group sums by LDS atomics, rows out
+//
+// Anything that does not fit (n > 2048 tasks, > 2176 unit slots, > 1024 task-group rows, |priority| >= 2^31)
+// branches -- uniformly, before any output is written -- to the generic path of evg_kernels.hip.h. Value ranges
+// that do not compress into 64 bits take wider-key variants of E / F inside this path.
+//
+// RICH = the optional outputs (SortingValueBreakdown rows, TaskPlan.Len()) are requested: 34 KiB more LDS
+// (one workgroup per CU); chosen at launch.
+#pragma once
+
+#include "evg_kernels.hip.h"
+
+namespace evg {
+
+constexpr int kE = 4;                // tasks per thread
+constexpr int kN = kBlock * kE;      // 2048 tasks max on this path
+constexpr int kS = 2176;             // unit slots max
+constexpr int kG = 1024;             // task-group rows (incl. the standalone row) max
+constexpr int kEdgeCap = 3072;       // dependency edges staged in LDS (more: read from global)
+
+// ---- LDS map (bytes) ------------------------------------------------------------------------------------
+// region A: unit accumulators, live during B..D
+constexpr int A_TIQ = 0, A_DUR = A_TIQ + 8 * kS, A_MAXPRI = A_DUR + 8 * kS, A_CNT = A_MAXPRI + 4 * kS,
+              A_MAXND = A_CNT + 4 * kS, A_MINROW = A_MAXND + 4 * kS, A_END = A_MINROW + 4 * kS;
+// region B: live for the whole kernel
+constexpr int B_PSLOT = A_END, B_EDGE = B_PSLOT + 2 * kN, B_END = B_EDGE + 2 * kEdgeCap;
+// region R: RICH only
+constexpr int R_VAL = B_END, R_HASH = R_VAL + 8 * kS, R_END = R_HASH + 8 * kS;
+// region A re-used after D:
+constexpr int X_BUF0 = 0, X_BUF1 = 8 * kN, X_IK = 16 * kN, X_IK_END = X_IK + 8 * kN;  // sort exchange, in-unit keys by task
+constexpr int Y_SIK = 0, Y_SSLOT = 8 * kN, Y_SIDX = Y_SSLOT + 2 * kN;                  // by sorted position
+constexpr int Y_SCAN = Y_SIDX + 2 * kN, Y_REN = Y_SCAN + 4 * kBlock;                  // run-start scan, run end by run start
+static_assert(Y_REN + 2 * kN <= X_IK, "run bookkeeping must not overlap the in-unit keys by task");
+constexpr int Y_POS = X_IK_END, Y_FIDX = Y_POS + 2 * kN, Y_END = Y_FIDX + 2 * kN;      // final position by task / task by position
+constexpr int Z_G = 0;                                                                 // group accumulators (36 B per row)
+static_assert(Y_SIDX + 2 * kN <= X_IK, "by-position arrays must not overlap the in-unit keys by task");
+static_assert(Y_END <= A_END && Z_G + 36 * kG <= Y_POS, "region A re-use");
+static_assert(B_END + 256 <= 80 * 1024 - 1024, "lean configuration: two workgroups per CU with allocation-granule slack");
+static_assert(R_END + 256 <= 160 * 1024, "rich configuration");
+static_assert(kS < 4096 && kN <= 2048, "slot ids are 12 bits, rows 11 bits");
+
+constexpr int kLdsLean = B_END, kLdsRich = R_END;
+
+// pslot record: bits 0-11 unit slot, 12-13 status class (EVG_TF_STATUS), 14 Blocked()
+constexpr uint32_t PS_SLOT = 0x0FFFu;
+// edge record: in queue  : bit15 = 0, bits 11-12 required status, bits 0-10 local row of the dependency
+//              otherwise : bit15 = 1, bits 0-5 = dep_info (required status, fetched state, blocked, missing)
+constexpr uint32_t ED_OUT = 0x8000u;
+
+__device__ __forceinline__ uint32_t pack_edge(int j, int n, uint32_t info) {
+  return (unsigned)j < (unsigned)n ? ((info & EVG_DEP_REQ_MASK) << 11) | (uint32_t)j : ED_OUT | (info & 0x3Fu);
+}
+
+// ---- 4-wide column loads: one 16 B (8 B for 16-bit columns) access per lane when the 4 rows exist ------
+template <class T>
+struct __attribute__((packed, aligned(sizeof(T)))) Vec4 {
+  T v[4];
+};
+template <class T>
+__device__ __forceinline__ void load4(const T* __restrict__ p, int i0, int n, T fill, T (&out)[4]) {
+  if (i0 + 3 < n) {
+    const Vec4<T> x = *reinterpret_cast<const Vec4<T>*>(p + i0);
+#pragma unroll
+    for (int e = 0; e < 4; e++) out[e] = x.v[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; e++) out[e] = i0 + e < n ? p[i0 + e] : fill;
+  }
+}
+template <class T>
+__device__ __forceinline__ void store4(T* __restrict__ p, int i0, int n, const T (&v)[4]) {
+  if (i0 + 3 < n) {
+    Vec4<T> x;
+#pragma unroll
+    for (int e = 0; e < 4; e++) x.v[e] = v[e];
+    *reinterpret_cast<Vec4<T>*>(p + i0) = x;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (i0 + e < n) p[i0 + e] = v[e];
+  }
+}
+
+// order-preserving signed -> unsigned
+__device__ __forceinline__ uint32_t ub(int32_t x) { return (uint32_t)x ^ 0x80000000u; }
+__device__ __forceinline__ uint64_t ub(int64_t x) { return (uint64_t)x ^ 0x8000000000000000ull; }
+__device__ __forceinline__ int bits_of(uint64_t x) { return x ? 64 - __builtin_clzll(x) : 0; }
+
+// ---- sort keys -------------------------------------------------------------------------------------------
+struct K128 {
+  uint64_t hi, lo;
+};
+__device__ __forceinline__ bool key_lt(uint64_t a, uint64_t b) { return a < b; }
+__device__ __forceinline__ bool key_lt(const K128& a, const K128& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+// Partner's key at lane distance M. Distances 1..8 are DPP moves in the VALU; 16 and 32 go through ds_bpermute:
+// the sort is VALU-issue bound while the LDS pipe idles, and a v_permlane swap costs two VALU slots plus copies.
+template <int M>
+__device__ __forceinline__ uint32_t word_xor(uint32_t v) {
+  if constexpr (M >= 16) return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((__lane_id() ^ M) << 2), (int)v);
+  else return lane_xor<M>(v);
+}
+template <int M>
+__device__ __forceinline__ uint64_t key_xor(uint64_t v) { return ((uint64_t)word_xor<M>((uint32_t)(v >> 32)) << 32) | word_xor<M>((uint32_t)v); }
+template <int M>
+__device__ __forceinline__ K128 key_xor(const K128& v) { return K128{key_xor<M>(v.hi), key_xor<M>(v.lo)}; }
+// compare-exchange of the lane's 4 keys with lane (lane ^ M): keep the smaller (take_min) or the larger of each pair
+template <int M, class K>
+__device__ __forceinline__ void shuffle_stage(K (&k)[4], bool take_min) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const K o = key_xor<M>(k[e]);
+    const bool lt = key_lt(o, k[e]);
+    if (take_min == lt) k[e] = o;
+  }
+}
+
+template <class K>
+__device__ __forceinline__ void cmpx(K& a, K& b, bool asc) {  // a at the lower position
+  const bool sw = asc ? key_lt(b, a) : key_lt(a, b);
+  if (sw) { const K t = a; a = b; b = t; }
+}
+
+// The same network as bitonic_sort4 below for a compile-time P: fully unrolled, so every stage is straight-line code
+// with its exchange distance resolved at compile time and no scalar dispatch.
+template <int P, class K>
+__device__ __forceinline__ void bitonic_sort4_fixed(K (&k)[4], int tid, K* buf0, K* buf1) {
+  const int p0 = tid * 4;
+  int which = 0;
+#pragma unroll
+  for (int kk = 2; kk <= P; kk <<= 1) {
+    const bool asc_t = (p0 & kk) == 0;  // valid for kk >= 4
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      const bool take_min = ((p0 & j) == 0) == asc_t;
+      if (j >= 256) {
+        K* buf = which ? buf1 : buf0;
+        which ^= 1;
+        if (buf0 == buf1) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; e++) buf[p0 + e] = k[e];
+        __syncthreads();
+        const int q0 = (tid ^ (j >> 2)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const K o = buf[q0 + e];
+          const bool lt = key_lt(o, k[e]);
+          if (take_min == lt) k[e] = o;
+        }
+      } else if (j == 128) shuffle_stage<32>(k, take_min);
+      else if (j == 64) shuffle_stage<16>(k, take_min);
+      else if (j == 32) shuffle_stage<8>(k, take_min);
+      else if (j == 16) shuffle_stage<4>(k, take_min);
+      else if (j == 8) shuffle_stage<2>(k, take_min);
+      else if (j == 4) shuffle_stage<1>(k, take_min);
+      else if (j == 2) { cmpx(k[0], k[2], asc_t); cmpx(k[1], k[3], asc_t); }
+      else if (kk == 2) { cmpx(k[0], k[1], true); cmpx(k[2], k[3], false); }
+      else { cmpx(k[0], k[1], asc_t); cmpx(k[2], k[3], asc_t); }
+    }
+  }
+}
+
+// Bitonic sort of P = 2^m keys (P >= 4; position p = 4*tid + e holds k[e]; positions >= P are ignored) ascending.
+// Stages with partner distance j: j < 4 inside the lane, 4 <= j < 256 by wave shuffles (lane ^ j/4), j >= 256
+// through LDS (buf0/buf1 alternate so that one barrier per stage suffices; buf1 == buf0 is allowed).
+template <class K>
+__device__ __forceinline__ void bitonic_sort4(K (&k)[4], int P, int tid, K* buf0, K* buf1) {
+  const int p0 = tid * 4;
+  int which = 0;
+  for (int kk = 2; kk <= P; kk <<= 1) {
+    const bool asc_t = (p0 & kk) == 0;  // valid for kk >= 4
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j >= 256) {
+        K* buf = which ? buf1 : buf0;
+        which ^= 1;
+        if (buf0 == buf1) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; e++) buf[p0 + e] = k[e];
+        __syncthreads();
+        const int q0 = (tid ^ (j >> 2)) * 4;
+        const bool take_min = ((p0 & j) == 0) == asc_t;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const K o = buf[q0 + e];
+          const bool lt = key_lt(o, k[e]);
+          if (take_min == lt) k[e] = o;
+        }
+      } else if (j >= 4) {
+        const bool take_min = ((p0 & j) == 0) == asc_t;
+        switch (j >> 2) {  // one uniform dispatch per stage; the exchange distance is a compile-time constant inside
+          case 1: shuffle_stage<1>(k, take_min); break;
+          case 2: shuffle_stage<2>(k, take_min); break;
+          case 4: shuffle_stage<4>(k, take_min); break;
+          case 8: shuffle_stage<8>(k, take_min); break;
+          case 16: shuffle_stage<16>(k, take_min); break;
+          default: shuffle_stage<32>(k, take_min); break;
+        }
+      } else if (j == 2) {
+        cmpx(k[0], k[2], asc_t);
+        cmpx(k[1], k[3], asc_t);
+      } else {
+        if (kk == 2) { cmpx(k[0], k[1], true); cmpx(k[2], k[3], false); }
+        else { cmpx(k[0], k[1], asc_t); cmpx(k[2], k[3], asc_t); }
+      }
+    }
+  }
+}
+
+// ---- unit membership -------------------------------------------------------------------------------------
+struct LdsView {
+  int64_t *tiq, *dur, *val;
+  int32_t* maxpri;
+  uint32_t* cnt;
+  int32_t* maxnd;
+  uint32_t* minrow;
+  uint16_t* pslot;
+  uint16_t* edge;
+};
+
+__device__ __forceinline__ uint32_t edge_at(const LdsView& m, const DC& c, const evg_task_soa& t, int x) {
+  if (c.eL) return m.edge[x];
+  return pack_edge(t.dep_idx[c.eb + x] - c.lo, c.n, t.dep_info[c.eb + x]);
+}
+
+// Visits the unit slots a task is a member of (planner.go:434-456): its primary unit t0, the version unit too
+// when it is a task-group task and versions are grouped (:439), and the primary unit of each direct dependency
+// that is in this distro's queue (:451-455). [x0, x1) = the task's local edge range.
+// DEDUP: each distinct slot exactly once (Unit.Add is keyed by task id, :131).
+template <bool DEDUP, class F>
+__device__ __forceinline__ void visit_units(const LdsView& m, const DC& c, const evg_task_soa& t, int t0, bool tg, int verk,
+                                            int x0, int x1, F f, bool skip_primary = false) {
+  if (!skip_primary) f(t0, true);
+  int t1 = -1;
+  if (c.gv && tg) { t1 = c.ver_base + (verk - c.ver_lo); f(t1, false); }
+  for (int x = x0; x < x1; x++) {
+    const uint32_t er = edge_at(m, c, t, x);
+    if (er & ED_OUT) continue;
+    const int s = m.pslot[er & 0x7FFu] & PS_SLOT;
+    if (s == t0 || s == t1) continue;
+    if (DEDUP) {
+      bool dup = false;
+      for (int y = x0; y < x; y++) {
+        const uint32_t e2 = edge_at(m, c, t, y);
+        if (!(e2 & ED_OUT) && (int)(m.pslot[e2 & 0x7FFu] & PS_SLOT) == s) { dup = true; break; }
+      }
+      if (dup) continue;
+    }
+    f(s, false);
+  }
+}
+
+__device__ __forceinline__ uint64_t shl64(uint64_t x, int s) { return s >= 64 ? 0ull : x << s; }
+
+// TaskList.Less (planner.go:386-405) on the global columns, rows ra / rb: is ra strictly before rb, ignoring the
+// final row tie-break?  Returns -1 before, +1 after, 0 tie.
+__device__ __forceinline__ int inunit_cmp(const evg_task_soa& t, int ra, int rb) {
+  const int32_t oa = t.task_group_order[ra], ob = t.task_group_order[rb];
+  if (oa != ob) return oa < ob ? -1 : 1;
+  const int32_t na = t.num_dependents[ra], nb = t.num_dependents[rb];
+  if (na != nb) return na > nb ? -1 : 1;
+  const int64_t pa = t.priority[ra], pb = t.priority[rb];
+  if (pa != pb) return pa > pb ? -1 : 1;
+  const int64_t da = t.expected_duration_ns[ra], db = t.expected_duration_ns[rb];
+  if (da != db) return da > db ? -1 : 1;
+  return 0;
+}
+
+// The LDS path. Returns false (uniformly, before writing any output) when the distro must take the generic path.
+// s_red: 32 zeroed words of static LDS.
+template <bool RICH>
+__device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, unsigned char* smem, unsigned* s_red) {
+  const evg_task_soa& t = a.in.tasks;
+  const int d = c.d, lo = c.lo, n = c.n, S = c.S;
+  const evg_distro_params p = a.in.distros[d];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int i0 = tid * kE;
+
+  LdsView m;
+  m.tiq = (int64_t*)(smem + A_TIQ); m.dur = (int64_t*)(smem + A_DUR); m.maxpri = (int32_t*)(smem + A_MAXPRI);
+  m.cnt = (uint32_t*)(smem + A_CNT); m.maxnd = (int32_t*)(smem + A_MAXND); m.minrow = (uint32_t*)(smem + A_MINROW);
+  m.pslot = (uint16_t*)(smem + B_PSLOT); m.edge = (uint16_t*)(smem + B_EDGE);
+  m.val = RICH ? (int64_t*)(smem + R_VAL) : m.tiq;  // lean: TotalValue overwrites the unit's TimeInQueue sum
+  // s_red words: 0 any met merge-queue task, 1 n_met, 2 n_mq, 3 n_s3, 4 secondary, 5 t_cover, 6 t_wait, 7 n_units,
+  // 8 rows, 10-11 t_dur, 12-13 t_dover; 16-23 four 64-bit range words; 24-29 six 32-bit range words
+  unsigned long long* s_rng = (unsigned long long*)(s_red + 16);  // 0 vmin 1 vmax 2 durmin 3 durmax (biased)
+  uint32_t* s_r32 = s_red + 24;                                   // 0 tgomin 1 tgomax 2 ndmin 3 ndmax 4 primin 5 primax
+
+  // ---- A: load ------------------------------------------------------------------------------------------
+  int32_t tgk[4], verk[4], nd[4], tgo[4];
+  uint16_t fl[4];
+  int64_t pri[4], dur[4], qts[4];
+  load4(t.tg_key + lo, i0, n, (int32_t)-1, tgk);
+  load4(t.version_key + lo, i0, n, (int32_t)c.ver_lo, verk);
+  load4(t.flags + lo, i0, n, (uint16_t)0, fl);
+  load4(t.priority + lo, i0, n, (int64_t)0, pri);
+  load4(t.expected_duration_ns + lo, i0, n, (int64_t)0, dur);
+  load4(t.queue_ts_ns + lo, i0, n, (int64_t)EVG_TIME_GO_ZERO, qts);
+  load4(t.num_dependents + lo, i0, n, (int32_t)0, nd);
+  load4(t.task_group_order + lo, i0, n, (int32_t)0, tgo);
+  int doff[5];  // local edge offsets of the thread's rows; rows past n get empty ranges
+  {
+    int32_t o4[4];
+    load4(t.dep_off + lo, i0, n, (int32_t)0, o4);
+    const int last = i0 + 3 < n ? t.dep_off[lo + i0 + 4] - c.eb : c.ne;
+#pragma unroll
+    for (int e = 0; e < 4; e++) doff[e] = i0 + e < n ? o4[e] - c.eb : last;
+    doff[4] = last;
+  }
+  bool wide_pri = false;
+#pragma unroll
+  for (int e = 0; e < 4; e++) wide_pri |= pri[e] != (int64_t)(int32_t)pri[e];
+  if (__syncthreads_or(wide_pri ? 1 : 0)) return false;  // int32 priority accumulators would not be exact
+
+  // Unit.info contribution of each row (planner.go:302-337)
+  int64_t tiq[4];
+  uint32_t uf[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const uint32_t f = fl[e];
+    tiq[e] = qts[e] == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, qts[e]);
+    const uint32_t rc = f & EVG_TF_REQ_MASK;
+    uf[e] = (rc == EVG_TF_REQ_MERGE ? UF_MERGE : rc == EVG_TF_REQ_PATCH ? UF_PATCH : 0u) | (tgk[e] < 0 ? UF_NONGROUP : 0u) |
+            ((f & EVG_TF_GENERATE) ? UF_GENERATE : 0u) | ((f & EVG_TF_STEPBACK) ? UF_STEPBACK : 0u);
+  }
+  int ps[4];  // primary unit slot
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int i = i0 + e;
+    ps[e] = tgk[e] >= 0 ? c.tg_base + (tgk[e] - c.tg_lo) : c.gv ? c.ver_base + (verk[e] - c.ver_lo) : i;
+    if (i < n) {
+      const uint32_t f = fl[e];
+      m.pslot[i] = (uint16_t)(ps[e] | (((f & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT) << 12) | ((f & EVG_TF_BLOCKED) ? 0x4000u : 0u));
+      if (!c.gv) {
+        // slot i is the unit keyed by task i's own id: only row i is ever its PRIMARY member, so the owner
+        // initialises it with plain stores (empty when i is a task-group task) and phase B only adds dependents
+        const bool own = tgk[e] < 0;
+        m.tiq[i] = own ? tiq[e] : 0;
+        m.dur[i] = own ? dur[e] : 0;
+        m.maxpri[i] = own && pri[e] > 0 ? (int32_t)pri[e] : 0;
+        m.cnt[i] = own ? (1u | uf[e] | UF_DISTRO) : 0u;
+        m.maxnd[i] = own && nd[e] > 0 ? nd[e] : 0;
+        m.minrow[i] = own ? (uint32_t)i : 0xFFFFFFFFu;
+      }
+    }
+  }
+  if (c.eL)
+    for (int x = tid; x < c.ne; x += kBlock) m.edge[x] = (uint16_t)pack_edge(t.dep_idx[c.eb + x] - lo, n, t.dep_info[c.eb + x]);
+  for (int u = (c.gv ? 0 : n) + tid; u < S; u += kBlock) {
+    m.tiq[u] = 0; m.dur[u] = 0; m.maxpri[u] = 0; m.cnt[u] = 0; m.maxnd[u] = 0; m.minrow[u] = 0xFFFFFFFFu;
+  }
+  if (tid < 4) s_rng[tid] = (tid & 1) ? 0ull : ~0ull;
+  if (tid < 6) s_r32[tid] = (tid & 1) ? 0u : ~0u;
+  EVG_STAMP(1);
+  __syncthreads();
+
+  // ---- B: segmented reduce of Unit.info (planner.go:302-337) -------------------------------------------------
+  const int n_own = c.gv ? 0 : n;  // slots below n_own were initialised by their owner (NONGROUP | DISTRO, min row = slot)
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int i = i0 + e;
+    if (i >= n) continue;
+    const int64_t tq = tiq[e], du = dur[e], pr = pri[e];
+    const int32_t ndv = nd[e];
+    const uint32_t ufe = uf[e];
+    visit_units<true>(m, c, t, ps[e], tgk[e] >= 0, verk[e], doff[e], doff[e + 1], [&](int u, bool primary) {
+      const bool owned = u < n_own;
+      if (tq != 0) atomicAdd((unsigned long long*)&m.tiq[u], (unsigned long long)tq);
+      atomicAdd((unsigned long long*)&m.dur[u], (unsigned long long)du);
+      if (pr > 0) atomicMax(&m.maxpri[u], (int32_t)pr);
+      if (ndv > 0) atomicMax(&m.maxnd[u], ndv);
+      atomicAdd(&m.cnt[u], 1u);
+      const uint32_t bits = (owned ? ufe & ~UF_NONGROUP : ufe) | (primary ? UF_DISTRO : 0u);  // SetDistro only via the primary key (:447)
+      if (bits) atomicOr(&m.cnt[u], bits);
+      if (!owned || i < u) atomicMin(&m.minrow[u], (uint32_t)i);
+    }, !c.gv && tgk[e] < 0);
+  }
+  EVG_STAMP(2);
+  __syncthreads();
+
+  // ---- C: score every unit (planner.go:209-300); units whose distro is nil are dropped (:81) -----------------
+  for (int u = tid; u < S; u += kBlock) {
+    const uint32_t cw = m.cnt[u];
+    const int64_t nu = cw & UF_COUNT_MASK;
+    int64_t v = INT64_MIN;
+    if (nu > 0 && (cw & UF_DISTRO)) v = unit_value(p, nu, m.tiq[u], m.dur[u], (int64_t)m.maxpri[u], (int64_t)m.maxnd[u], cw, nullptr);
+    m.val[u] = v;
+  }
+  EVG_STAMP(3);
+  __syncthreads();
+
+  // ---- C' (RICH, optional): TaskPlan.Len() after UnitCache.Export's set-equality dedup (planner.go:73-89) ----
+  // Unit identity = (member count, min member, commutative 64-bit hash of the member rows); the reference's own
+  // identity is a hash too (sha1 of the sorted ids, :154-172). Set-equal units share their min member, so a
+  // unit's duplicates are among the units of that one task.
+  if (RICH && a.out.n_units) {
+    uint64_t* hash = (uint64_t*)(smem + R_HASH);
+    for (int u = tid; u < S; u += kBlock) hash[u] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int i = i0 + e;
+      if (i >= n) continue;
+      const uint64_t h = mix64((uint64_t)i);
+      visit_units<true>(m, c, t, ps[e], tgk[e] >= 0, verk[e], doff[e], doff[e + 1],
+                        [&](int u, bool) { atomicAdd((unsigned long long*)&hash[u], (unsigned long long)h); });
+    }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int u = tid; u < S; u += kBlock) {
+      if (m.val[u] == INT64_MIN) continue;
+      const int i = (int)m.minrow[u];
+      const int r = lo + i;
+      const int tg_i = t.tg_key[r];
+      const int x0 = t.dep_off[r] - c.eb, x1 = t.dep_off[r + 1] - c.eb;
+      bool dup = false;
+      const uint64_t hu = hash[u];
+      const uint32_t cu = m.cnt[u] & UF_COUNT_MASK;
+      visit_units<false>(m, c, t, m.pslot[i] & PS_SLOT, tg_i >= 0, t.version_key[r], x0, x1, [&](int w, bool) {
+        if (w < u && m.val[w] != INT64_MIN && hash[w] == hu && (m.cnt[w] & UF_COUNT_MASK) == cu && m.minrow[w] == (uint32_t)i)
+          dup = true;
+      });
+      mine += dup ? 0u : 1u;
+    }
+    mine = wave_sum(mine);
+    if (lane == 0 && mine) atomicAdd(&s_red[7], mine);
+    __syncthreads();
+    if (tid == 0) a.out.n_units[d] = (int32_t)s_red[7];
+  }
+  EVG_STAMP(4);
+
+  // ---- D: elect each task's emitting unit ------------------------------------------------------------------
+  int64_t bv[4];
+  uint32_t bm[4];
+  int bs[4];
+  uint64_t r_vmin = ~0ull, r_vmax = 0, r_dmin = ~0ull, r_dmax = 0;
+  uint32_t r_tmin = ~0u, r_tmax = 0, r_nmin = ~0u, r_nmax = 0, r_pmin = ~0u, r_pmax = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int i = i0 + e;
+    bv[e] = INT64_MIN; bm[e] = 0; bs[e] = -1;
+    if (i >= n) continue;
+    int best = -1;
+    int64_t bvv = INT64_MIN;
+    uint32_t bmm = 0;
+    visit_units<false>(m, c, t, ps[e], tgk[e] >= 0, verk[e], doff[e], doff[e + 1], [&](int u, bool) {
+      const int64_t v = m.val[u];
+      if (v == INT64_MIN) return;
+      const uint32_t mr = m.minrow[u];
+      if (best < 0 || v > bvv || (v == bvv && (mr < bmm || (mr == bmm && u < best)))) { best = u; bvv = v; bmm = mr; }
+    });
+    bv[e] = bvv; bm[e] = bmm; bs[e] = best;
+    if (RICH && a.out.breakdown) {
+      const uint32_t cw = m.cnt[best];
+      unit_value(p, cw & UF_COUNT_MASK, m.tiq[best], m.dur[best], (int64_t)m.maxpri[best], (int64_t)m.maxnd[best], cw,
+                 a.out.breakdown + (size_t)(lo + i) * EVG_BREAKDOWN_FIELDS);
+    }
+    const uint64_t uv = ub(bvv), ud = ub(dur[e]);
+    const uint32_t ut = ub(tgo[e]), un = ub(nd[e]), up = ub((int32_t)pri[e]);
+    r_vmin = uv < r_vmin ? uv : r_vmin; r_vmax = uv > r_vmax ? uv : r_vmax;
+    r_dmin = ud < r_dmin ? ud : r_dmin; r_dmax = ud > r_dmax ? ud : r_dmax;
+    r_tmin = ut < r_tmin ? ut : r_tmin; r_tmax = ut > r_tmax ? ut : r_tmax;
+    r_nmin = un < r_nmin ? un : r_nmin; r_nmax = un > r_nmax ? un : r_nmax;
+    r_pmin = up < r_pmin ? up : r_pmin; r_pmax = up > r_pmax ? up : r_pmax;
+  }
+  r_vmin = wave_min(r_vmin); r_vmax = wave_max(r_vmax); r_dmin = wave_min(r_dmin); r_dmax = wave_max(r_dmax);
+  r_tmin = wave_min(r_tmin); r_tmax = wave_max(r_tmax); r_nmin = wave_min(r_nmin); r_nmax = wave_max(r_nmax);
+  r_pmin = wave_min(r_pmin); r_pmax = wave_max(r_pmax);
+  if (lane == 0) {
+    atomicMin(&s_rng[0], (unsigned long long)r_vmin); atomicMax(&s_rng[1], (unsigned long long)r_vmax);
+    atomicMin(&s_rng[2], (unsigned long long)r_dmin); atomicMax(&s_rng[3], (unsigned long long)r_dmax);
+    atomicMin(&s_r32[0], r_tmin); atomicMax(&s_r32[1], r_tmax); atomicMin(&s_r32[2], r_nmin); atomicMax(&s_r32[3], r_nmax);
+    atomicMin(&s_r32[4], r_pmin); atomicMax(&s_r32[5], r_pmax);
+  }
+  // the columns of phase G: fetched now, consumed after the sort
+  int64_t sched[4], dmt[4];
+  load4(t.scheduled_ts_ns + lo, i0, n, (int64_t)0, sched);
+  load4(t.deps_met_ts_ns + lo, i0, n, (int64_t)0, dmt);
+  EVG_STAMP(5);
+  __syncthreads();  // accumulators are dead from here on
+
+  // ---- E: keys + sort --------------------------------------------------------------------------------------
+  const int P = c.P < 4 ? 4 : c.P;
+  const uint64_t vmax = n ? s_rng[1] : 0, vspan = n ? s_rng[1] - s_rng[0] : 0;
+  const int vb = bits_of(vspan);
+  // in-unit key  [tgo asc | num_dependents desc | priority desc | expected duration desc]  planner.go:386-405
+  const uint64_t dmax = s_rng[3];
+  const uint32_t tmin = s_r32[0], nmax = s_r32[3], pmax = s_r32[5];
+  const int bt = n ? bits_of((uint64_t)(s_r32[1] - s_r32[0])) : 0, bn = n ? bits_of((uint64_t)(s_r32[3] - s_r32[2])) : 0,
+            bp = n ? bits_of((uint64_t)(s_r32[5] - s_r32[4])) : 0, bd = n ? bits_of(s_rng[3] - s_rng[2]) : 0;
+  const bool ik_ok = bt + bn + bp + bd <= 64;
+  uint64_t* xik = (uint64_t*)(smem + X_IK);
+  if (ik_ok) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int i = i0 + e;
+      if (i >= n) continue;
+      xik[i] = shl64((uint64_t)(ub(tgo[e]) - tmin), bn + bp + bd) | shl64((uint64_t)(nmax - ub(nd[e])), bp + bd) |
+               shl64((uint64_t)(pmax - ub((int32_t)pri[e])), bd) | (dmax - ub(dur[e]));
+    }
+  }
+  uint32_t srt[4];  // after the sort: (unit slot << 11) | local row at sorted position i0+e
+  if (vb + 34 <= 64) {
+    uint64_t k[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int i = i0 + e;
+      k[e] = i < n ? ((vmax - ub(bv[e])) << 34) | ((uint64_t)bm[e] << 23) | ((uint64_t)bs[e] << 11) | (uint64_t)i : ~0ull;
+    }
+    EVG_STAMP(6);
+    if (P == 2048) bitonic_sort4_fixed<2048, uint64_t>(k, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
+    else bitonic_sort4<uint64_t>(k, P, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
+#pragma unroll
+    for (int e = 0; e < 4; e++) srt[e] = (uint32_t)k[e] & 0x7FFFFFu;
+  } else {
+    K128 k[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int i = i0 + e;
+      k[e] = i < n ? K128{vmax - ub(bv[e]), ((uint64_t)bm[e] << 23) | ((uint64_t)bs[e] << 11) | (uint64_t)i} : K128{~0ull, ~0ull};
+    }
+    EVG_STAMP(6);
+    bitonic_sort4<K128>(k, P, tid, (K128*)(smem + X_BUF0), (K128*)(smem + X_BUF0));
+#pragma unroll
+    for (int e = 0; e < 4; e++) srt[e] = (uint32_t)k[e].lo & 0x7FFFFFu;
+  }
+  EVG_STAMP(7);
+  __syncthreads();  // the exchange buffers are re-used below
+
+  // ---- F: order inside each unit (TaskList.Less) --------------------------------------------------------------
+  // After the sort the tasks emitted from one unit are contiguous ("runs"), in row order. Run bounds come from a
+  // max-scan of the run-start positions; the place of a task inside its run is the number of run members that
+  // precede it under TaskList.Less (ties: row order, which is position order inside the run).
+  uint64_t* sik = (uint64_t*)(smem + Y_SIK);
+  uint16_t* sslot = (uint16_t*)(smem + Y_SSLOT);
+  uint16_t* sidx = (uint16_t*)(smem + Y_SIDX);
+  int32_t* scan = (int32_t*)(smem + Y_SCAN);
+  uint16_t* ren = (uint16_t*)(smem + Y_REN);
+  uint16_t* pos = (uint16_t*)(smem + Y_POS);
+  uint16_t* fidx = (uint16_t*)(smem + Y_FIDX);
+  uint64_t myik[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int q = i0 + e;
+    myik[e] = 0;
+    if (q >= n) continue;
+    sslot[q] = (uint16_t)(srt[e] >> 11);
+    sidx[q] = (uint16_t)(srt[e] & 0x7FFu);
+    if (ik_ok) { myik[e] = xik[srt[e] & 0x7FFu]; sik[q] = myik[e]; }
+  }
+  __syncthreads();
+  // run starts: position q starts a run when the slot changes
+  bool brk[4];
+  int st[4], en[4];
+  int lb = -1;  // last run start inside this thread
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int q = i0 + e;
+    const uint32_t prev = e ? srt[e - 1] >> 11 : (q > 0 && q <= n ? (uint32_t)sslot[q - 1] : 0xFFFFu);
+    brk[e] = q < n && (q == 0 || prev != (srt[e] >> 11));
+    if (brk[e]) lb = q;
+  }
+  {  // inclusive max-scan over the wave, then over the 8 waves through LDS
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    int v = lb;
+    v = mx(v, __builtin_amdgcn_update_dpp(-1, v, 0x111, 0xF, 0xF, false));  // row_shr:1
+    v = mx(v, __builtin_amdgcn_update_dpp(-1, v, 0x112, 0xF, 0xF, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(-1, v, 0x114, 0xF, 0xF, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(-1, v, 0x118, 0xF, 0xF, false));
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    v = mx(v, row >= 1 ? r0 : -1); v = mx(v, row >= 2 ? r1 : -1); v = mx(v, row >= 3 ? r2 : -1);
+    scan[tid] = v;
+  }
+  __syncthreads();
+  int incoming = lane ? scan[tid - 1] : -1;  // last run start before this thread's positions
+  for (int w = 0; w < (tid >> 6); w++) { const int x = scan[w * 64 + 63]; incoming = x > incoming ? x : incoming; }
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int q = i0 + e;
+    const int before = e ? st[e - 1] : incoming;
+    st[e] = brk[e] ? q : before;
+    if (brk[e] && q > 0) ren[before] = (uint16_t)q;      // the previous run ends here
+    if (q == n - 1) ren[st[e]] = (uint16_t)n;            // the last run ends at n
+  }
+  __syncthreads();
+  bool multi = false;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int q = i0 + e;
+    if (q < n) { en[e] = ren[st[e]]; multi |= en[e] - st[e] > 1; }
+    else { st[e] = q; en[e] = q; }
+  }
+  int rank[4] = {0, 0, 0, 0};
+  if (multi) {
+    if (ik_ok) {
+      // one sweep over the union of the thread's runs: every fetched key is compared against the thread's 4 keys
+      const int qlo = st[0], qhi = i0 + 3 < n ? en[3] : n;
+      for (int q2 = qlo; q2 < qhi; q2++) {
+        const uint64_t k2 = sik[q2];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const bool in = q2 >= st[e] && q2 < en[e];
+          const bool lt = k2 < myik[e] || (k2 == myik[e] && q2 < i0 + e);
+          rank[e] += in && lt ? 1 : 0;
+        }
+      }
+    } else {  // value ranges too wide to compress into 64 bits: compare the columns themselves
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int q = i0 + e, r = lo + (int)(srt[e] & 0x7FFu);
+        for (int q2 = st[e]; q2 < en[e]; q2++) {
+          const int cmp = inunit_cmp(t, lo + sidx[q2], r);
+          rank[e] += cmp < 0 || (cmp == 0 && q2 < q) ? 1 : 0;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int q = i0 + e;
+    if (q >= n) continue;
+    const int fin = st[e] + rank[e];
+    const int i = (int)(srt[e] & 0x7FFu);
+    pos[i] = (uint16_t)fin;
+    fidx[fin] = (uint16_t)i;
+  }
+  __syncthreads();
+  {
+    int32_t o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) o4[e] = i0 + e < n ? lo + (int)fidx[i0 + e] : 0;
+    store4(a.out.order + lo, i0, n, o4);
+  }
+  EVG_STAMP(8);
+
+  // ---- G: GetDistroQueueInfo (scheduler.go:57-178) -----------------------------------------------------------
+  uint64_t* g_dur = (uint64_t*)(smem + Z_G);
+  uint64_t* g_dover = g_dur + kG;
+  uint32_t* g_cnt = (uint32_t*)(g_dover + kG);
+  uint32_t *g_cover = g_cnt + kG, *g_wait = g_cover + kG, *g_mq = g_wait + kG, *g_first = g_mq + kG;
+  for (int k = tid; k < c.ntg + 1; k += kBlock) {
+    g_cnt[k] = 0; g_cover[k] = 0; g_wait[k] = 0; g_mq[k] = 0; g_first[k] = 0xFFFFFFFFu; g_dur[k] = 0; g_dover[k] = 0;
+  }
+  // pass A: checkDependenciesMet per task; does any met merge-queue task exist?
+  const bool incl = p.includes_dependencies != 0;
+  bool met[4];
+  int64_t mettime[4];
+  bool any_mq = false;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int i = i0 + e;
+    met[e] = false; mettime[e] = 0;
+    if (i >= n) continue;
+    const uint32_t f = fl[e];
+    const int x0 = doff[e], x1 = doff[e + 1];
+    bool mt = (x1 == x0) || (f & EVG_TF_OVERRIDE_DEPS) || !is_zero_time(dmt[e]);  // HasDependenciesMet task.go:3406
+    int64_t mtime = dmt[e];
+    if (!mt) {
+      bool all = true;
+      for (int x = x0; x < x1; x++) {
+        const uint32_t er = edge_at(m, c, t, x);
+        uint32_t st, req;
+        bool blk;
+        if (!(er & ED_OUT)) {
+          const uint32_t pj = m.pslot[er & 0x7FFu];
+          st = (pj >> 12) & 3u; blk = pj & 0x4000u; req = (er >> 11) & 3u;
+        } else {
+          if (er & EVG_DEP_MISSING) { all = false; break; }
+          st = (er & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT; blk = er & EVG_DEP_BLOCKED; req = er & EVG_DEP_REQ_MASK;
+        }
+        const bool sat = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;  // task.go:546-561
+        if (!sat) { all = false; break; }
+      }
+      if (all) {
+        mt = true;  // setDependenciesMetTime task.go:690-701
+        int64_t mx = 0;
+        if (t.dep_finished_ts_ns)
+          for (int x = x0; x < x1; x++) {
+            const int64_t fa = t.dep_finished_ts_ns[c.eb + x];
+            if (!is_zero_time(fa) && fa > mx) mx = fa;
+          }
+        mtime = is_zero_time(mx) ? c.now : mx;
+      }
+    }
+    met[e] = mt; mettime[e] = mtime;
+    if (mt && (f & EVG_TF_REQ_MASK) == EVG_TF_REQ_MERGE) any_mq = true;
+  }
+  {
+    uint8_t m4[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) m4[e] = met[e] ? 1 : 0;
+    store4(a.out.deps_met + lo, i0, n, m4);
+  }
+  EVG_STAMP(9);
+  const bool has_mq = __syncthreads_or(any_mq ? 1 : 0) != 0;  // also orders the zeroing of the group rows
+  const int64_t T = target_time_for_queue(p, has_mq);
+
+  // pass B: segmented sums keyed by task group (row 0 = ""). The standalone row takes ~90% of the tasks: it is
+  // summed in registers and wave-reduced, one atomic per wave; task-group rows take direct LDS atomics.
+  uint32_t n_met = 0, n_mq = 0, n_s3 = 0, sec = 0;
+  uint32_t s_cnt = 0, s_cover = 0, s_wait = 0, s_mq = 0;
+  uint64_t s_dur = 0, s_dover = 0;
+  int64_t wait4[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int i = i0 + e;
+    wait4[e] = 0;
+    if (i >= n) continue;
+    const uint32_t f = fl[e];
+    const bool mt = met[e];
+    const int64_t du = dur[e];
+    const bool merge = (f & EVG_TF_REQ_MASK) == EVG_TF_REQ_MERGE;
+    const bool count = !incl || mt;
+    const bool over = count && du > T;
+    bool wait_over = false;
+    if (count && mt) {
+      int64_t start = sched[e];
+      if (mettime[e] > start) start = mettime[e];  // DependenciesMetTime.After(startTime)
+      wait4[e] = time_sub(c.now, start);
+      wait_over = wait4[e] > T;
+    }
+    if (f & EVG_TF_OTHER_DISTRO) sec = 1;
+    if (mt) { n_met++; if (merge) n_mq++; if (f & EVG_TF_S3_STORAGE) n_s3++; }
+    const int g = tgk[e] < 0 ? 0 : 1 + (tgk[e] - c.tg_lo);
+    atomicMin(&g_first[g], (uint32_t)pos[i]);
+    if (g == 0) {
+      s_cnt += count; s_dur += count ? (uint64_t)du : 0; s_cover += over; s_dover += over ? (uint64_t)du : 0;
+      s_wait += wait_over; s_mq += (mt && merge);
+    } else {
+      if (count) { atomicAdd(&g_cnt[g], 1u); atomicAdd((unsigned long long*)&g_dur[g], (unsigned long long)du); }
+      if (over) { atomicAdd(&g_cover[g], 1u); atomicAdd((unsigned long long*)&g_dover[g], (unsigned long long)du); }
+      if (wait_over) atomicAdd(&g_wait[g], 1u);
+      if (mt && merge) atomicAdd(&g_mq[g], 1u);
+    }
+  }
+  store4(a.out.wait_ns + lo, i0, n, wait4);
+  s_cnt = wave_sum(s_cnt); s_cover = wave_sum(s_cover); s_wait = wave_sum(s_wait); s_mq = wave_sum(s_mq);
+  s_dur = wave_sum(s_dur); s_dover = wave_sum(s_dover);
+  n_met = wave_sum(n_met); n_mq = wave_sum(n_mq); n_s3 = wave_sum(n_s3);
+  if (lane == 0) {
+    if (s_cnt) atomicAdd(&g_cnt[0], s_cnt);
+    if (s_dur) atomicAdd((unsigned long long*)&g_dur[0], (unsigned long long)s_dur);
+    if (s_cover) atomicAdd(&g_cover[0], s_cover);
+    if (s_dover) atomicAdd((unsigned long long*)&g_dover[0], (unsigned long long)s_dover);
+    if (s_wait) atomicAdd(&g_wait[0], s_wait);
+    if (s_mq) atomicAdd(&g_mq[0], s_mq);
+    if (n_met) atomicAdd(&s_red[1], n_met);
+    if (n_mq) atomicAdd(&s_red[2], n_mq);
+    if (n_s3) atomicAdd(&s_red[3], n_s3);
+  }
+  if (__any(sec) && lane == 0) atomicOr(&s_red[4], 1u);
+  EVG_STAMP(10);
+  __syncthreads();
+
+  // rows out: model.TaskGroupInfo; MaxHosts = first task of the group in QUEUE order (scheduler.go:103-106)
+  uint64_t t_dur = 0, t_dover = 0;
+  uint32_t t_cover = 0, t_wait = 0, t_rows = 0;
+  for (int k = tid; k < c.ntg + 1; k += kBlock) {
+    evg_group_info* o = &a.out.group_info[k == 0 ? d : c.D + c.tg_lo + (k - 1)];
+    const uint32_t first = g_first[k];
+    const bool present = first != 0xFFFFFFFFu;
+    evg_group_info gi;
+    gi.expected_duration_ns = (int64_t)g_dur[k];
+    gi.duration_over_threshold_ns = (int64_t)g_dover[k];
+    gi.count = (int32_t)g_cnt[k];
+    gi.max_hosts = present ? t.task_group_max_hosts[lo + (int)fidx[first]] : 0;
+    gi.count_duration_over_threshold = (int32_t)g_cover[k];
+    gi.count_wait_over_threshold = (int32_t)g_wait[k];
+    gi.count_dep_filled_merge_queue_tasks = (int32_t)g_mq[k];
+    gi.present = present ? 1 : 0;
+    gi.count_free = 0;
+    gi.count_required = 0;
+    *o = gi;
+    t_dur += g_dur[k]; t_dover += g_dover[k]; t_cover += g_cover[k]; t_wait += g_wait[k];
+    t_rows += present ? 1u : 0u;
+  }
+  t_dur = wave_sum(t_dur); t_dover = wave_sum(t_dover);
+  t_cover = wave_sum(t_cover); t_wait = wave_sum(t_wait); t_rows = wave_sum(t_rows);
+  if (lane == 0) {
+    if (t_cover) atomicAdd(&s_red[5], t_cover);
+    if (t_wait) atomicAdd(&s_red[6], t_wait);
+    if (t_rows) atomicAdd(&s_red[8], t_rows);
+    atomicAdd((unsigned long long*)&s_red[10], (unsigned long long)t_dur);
+    atomicAdd((unsigned long long*)&s_red[12], (unsigned long long)t_dover);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    evg_distro_info di;
+    di.expected_duration_ns = (int64_t)(*(unsigned long long*)&s_red[10]);
+    di.max_duration_threshold_ns = T;
+    di.duration_over_threshold_ns = (int64_t)(*(unsigned long long*)&s_red[12]);
+    di.length = n;
+    di.length_with_dependencies_met = (int32_t)s_red[1];
+    di.count_dep_filled_merge_queue_tasks = (int32_t)s_red[2];
+    di.count_duration_over_threshold = (int32_t)s_red[5];
+    di.count_wait_over_threshold = (int32_t)s_red[6];
+    di.num_queued_large_parser_project_tasks = (int32_t)s_red[3];
+    di.secondary_queue = (int32_t)s_red[4];
+    di.n_task_group_infos = (int32_t)s_red[8];
+    a.out.distro_info[d] = di;
+  }
+  EVG_STAMP(11);
+  return true;
+}
+
+// Per-distro uniform state from the offset tables.
+__device__ __forceinline__ DC distro_context(const PlanArgs& a, int d) {
+  DC c;
+  c.d = d;
+  c.D = a.in.n_distros;
+  c.lo = a.in.task_off[d];
+  c.n = a.in.task_off[d + 1] - c.lo;
+  c.tg_lo = a.in.tg_off[d];
+  c.ntg = a.in.tg_off[d + 1] - c.tg_lo;
+  c.ver_lo = a.in.ver_off[d];
+  c.nver = a.in.ver_off[d + 1] - c.ver_lo;
+  c.gv = a.in.distros[d].group_versions != 0;
+  c.now = a.in.now_ns;
+  // slot map: !gv: own task units [0,n) then task groups; gv: task groups then versions (no own units)
+  if (c.gv) { c.tg_base = 0; c.ver_base = c.ntg; c.S = c.ntg + c.nver; }
+  else { c.tg_base = c.n; c.ver_base = c.n + c.ntg; c.S = c.n + c.ntg; }
+  int P = 1;
+  while (P < c.n) P <<= 1;
+  c.P = P;
+  c.eb = a.in.tasks.dep_off[c.lo];
+  c.ne = a.in.tasks.dep_off[c.lo + c.n] - c.eb;
+  c.eL = c.ne <= kEdgeCap;
+  return c;
+}
+__device__ __forceinline__ bool fits_lds_path(const DC& c) { return c.n <= kN && c.S <= kS && c.ntg + 1 <= kG; }
+
+// One workgroup per distro: the LDS path. Distros it cannot take are flagged in a.w_generic[d] and left to
+// k_plan_generic, which is enqueued right behind this kernel.
+template <bool RICH>
+__global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
+  const int d = blockIdx.x;
+  const DC c = distro_context(a, d);
+  if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
+  __syncthreads();
+  EVG_STAMP(0);
+  const bool done = fits_lds_path(c) && plan_distro_lds<RICH>(a, c, smem, s_red);
+  if (threadIdx.x == 0) a.w_generic[d] = done ? 0 : 1;
+}
+
+// One workgroup per distro the LDS path left over (none in the headline configuration): every intermediate lives
+// in the global scratch area.
+__global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
+  const int d = blockIdx.x;
+  if (!a.w_generic[d]) return;
+  const DC c = distro_context(a, d);
+  if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // disjoint slot range of this distro
+  Mem<false> m;
+  m.tiq = a.w_tiq + sb; m.dur = a.w_dur + sb; m.maxpri = a.w_maxpri + sb; m.val = a.w_val + sb;
+  m.cnt = a.w_cnt + sb; m.maxnd = a.w_maxnd + sb; m.minrow = a.w_minrow + sb; m.hash = a.w_hash + sb;
+  m.pslot = a.w_pslot + c.lo; m.tflags = nullptr;
+  m.k0 = a.w_k0 + c.lo; m.k1 = a.w_k1 + c.lo; m.idx = a.w_idx + 2 * (size_t)c.lo; m.pos = a.w_pos + c.lo;
+  const evg_task_soa& t = a.in.tasks;
+  m.c_pri = t.priority + c.lo; m.c_dur = t.expected_duration_ns + c.lo;
+  m.c_tgo = t.task_group_order + c.lo; m.c_nd = t.num_dependents + c.lo;
+  m.g_cnt = a.g_cnt; m.g_cover = a.g_cover; m.g_wait = a.g_wait; m.g_mq = a.g_mq; m.g_first = a.g_first;
+  m.g_dur = a.g_dur; m.g_dover = a.g_dover;
+  m.g0 = d; m.gk = c.D + c.tg_lo;
+  plan_distro<false>(a, c, m, s_red);
+}
+
+}  // namespace evg

@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "evg_kernels.hip.h"
+#include "evg_plan_lds.hip.h"
 
 namespace evg {
 
@@ -206,6 +206,9 @@ struct evg_ctx {
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
+#ifdef EVG_PHASE_TIMING
+  unsigned long long* dbg_ts = nullptr;
+#endif
 };
 
 static thread_local std::string g_create_err;
@@ -274,6 +277,11 @@ struct Stager {
 extern "C" {
 
 int32_t evg_abi_version(void) { return (1 << 16) | 0; }
+
+#ifdef EVG_PHASE_TIMING
+// diagnostics build only (scripts/phase_timing.py): device buffer of D x 16 s_memtime stamps
+void evg_dbg_phase_buffer(evg_ctx* c, void* dev_ptr) { c->dbg_ts = (unsigned long long*)dev_ptr; }
+#endif
 
 const char* evg_last_error(const evg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -370,10 +378,10 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   a.in = *in;
   a.out = *out;
   // scratch of the large-distro path (untouched pages cost nothing; small distros never use it)
-  size_t sz[20] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
+  size_t sz[21] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
                    4 * (N + 1), 8 * (N + 1), 8 * (N + 1), 8 * (N + 1), 4 * (N + 1),
-                   4 * G, 4 * G, 4 * G, 4 * G, 4 * G, 8 * G, 8 * G};
-  for (int i = 0; i < 20; i++) {
+                   4 * G, 4 * G, 4 * G, 4 * G, 4 * G, 8 * G, 8 * G, 4 * (size_t)D};
+  for (int i = 0; i < 21; i++) {
     int rc = ensure(c, c->scratch[i], sz[i]);
     if (rc) return rc;
   }
@@ -385,11 +393,21 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   a.g_cnt = (uint32_t*)c->scratch[13].p; a.g_cover = (uint32_t*)c->scratch[14].p; a.g_wait = (uint32_t*)c->scratch[15].p;
   a.g_mq = (uint32_t*)c->scratch[16].p; a.g_first = (uint32_t*)c->scratch[17].p; a.g_dur = (uint64_t*)c->scratch[18].p;
   a.g_dover = (uint64_t*)c->scratch[19].p;
+  a.w_generic = (int32_t*)c->scratch[20].p;
+#ifdef EVG_PHASE_TIMING
+  a.dbg_ts = c->dbg_ts;
+#endif
   if (!c->lds_attr_set) {
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
     c->lds_attr_set = true;
   }
-  hipLaunchKernelGGL(k_plan_distros, dim3(D), dim3(kBlock), L_TOTAL, st, a);
+  // the optional outputs need 34 KiB more LDS per workgroup (one workgroup per CU instead of two)
+  if (out->breakdown || out->n_units) hipLaunchKernelGGL(k_plan_distros<true>, dim3(D), dim3(kBlock), kLdsRich, st, a);
+  else hipLaunchKernelGGL(k_plan_distros<false>, dim3(D), dim3(kBlock), kLdsLean, st, a);
+  HIP_TRY(c, hipGetLastError());
+  // distros the LDS path could not take (flagged on the device); its workgroups exit at once otherwise
+  hipLaunchKernelGGL(k_plan_generic, dim3(D), dim3(kBlock), 0, st, a);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }
@@ -412,11 +430,11 @@ static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_o
   const size_t G = (size_t)in->n_distros + (size_t)in->n_task_groups;
   size_t sz[4] = {8 * ((size_t)in->hosts.n_hosts + 1), 4 * G, 4 * G, 4 * G};
   for (int i = 0; i < 4; i++) {
-    int rc = ensure(c, c->scratch[20 + i], sz[i]);
+    int rc = ensure(c, c->scratch[24 + i], sz[i]);
     if (rc) return rc;
   }
-  a.w_term = (double*)c->scratch[20].p;
-  a.w_new = (int32_t*)c->scratch[21].p; a.w_free = (int32_t*)c->scratch[22].p; a.w_err = (int32_t*)c->scratch[23].p;
+  a.w_term = (double*)c->scratch[24].p;
+  a.w_new = (int32_t*)c->scratch[25].p; a.w_free = (int32_t*)c->scratch[26].p; a.w_err = (int32_t*)c->scratch[27].p;
   hipLaunchKernelGGL(k_allocate_hosts, dim3(in->n_distros), dim3(kAllocBlock), 0, st, a);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;

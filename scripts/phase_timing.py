@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Per-phase cycle breakdown of k_plan_distros (diagnostics build with -DEVG_PHASE_TIMING; GPU box only).
+
+usage: python scripts/phase_timing.py [config#] [n_tasks] [n_distros]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from evergreen_amd import abi, gen, native  # noqa: E402
+
+CSRC = os.path.join(ROOT, "evergreen_amd", "csrc")
+DBG = os.path.join(CSRC, "libevg_sched_dbg.so")
+NAMES = ["A load+slots", "B reduce", "C score", "C' n_units", "D elect+ranges", "E keys", "E sort", "F in-unit+order",
+         "G deps met", "G group sums", "G rows out"]
+
+
+def main():
+    cfgn = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    over = {}
+    if len(sys.argv) > 2:
+        over["n_tasks"] = int(sys.argv[2])
+    if len(sys.argv) > 3:
+        over["n_distros"] = int(sys.argv[3])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                           "-shared", "-DEVG_PHASE_TIMING", os.path.join(CSRC, "evg_sched.hip"), "-o", DBG])
+    native.LIB_PATH = DBG
+    lib = native.load_library()
+    lib.evg_dbg_phase_buffer.argtypes = [C.c_void_p, C.c_void_p]
+    batch = gen.generate(gen.config(cfgn, **over))
+    from evergreen_amd import resident
+    ctx = native.Context(0)
+    dev = torch.device("cuda:0")
+    ts = torch.zeros(batch.n_distros * 16, dtype=torch.int64, device=dev)
+    lib.evg_dbg_phase_buffer(ctx.h, ts.data_ptr())
+    pool = resident.ResidentPool(ctx, batch, dev, breakdown=False, n_units=False)
+    for _ in range(5):
+        pool.plan()
+    torch.cuda.synchronize()
+    t = ts.cpu().numpy().reshape(-1, 16)[:, :12]
+    dt = np.diff(t, axis=1).astype(np.float64)
+    tot = (t[:, 11] - t[:, 0]).astype(np.float64)
+    print("distros %d  tasks/distro mean %.0f   (s_memtime ticks; 100 MHz constant clock => 10 ns per tick)" % (
+        batch.n_distros, batch.n_tasks / batch.n_distros))
+    for k, nm in enumerate(NAMES):
+        print("  %-18s mean %8.1f  p50 %8.1f  max %8.1f   %5.1f%%" % (nm, dt[:, k].mean(), np.median(dt[:, k]), dt[:, k].max(),
+                                                                      100 * dt[:, k].mean() / tot.mean()))
+    print("  %-18s mean %8.1f  p50 %8.1f  max %8.1f" % ("WG total", tot.mean(), np.median(tot), tot.max()))
+    print("  kernel span (first start -> last end): %.1f ticks" % float(t[:, 11].max() - t[:, 0].min()))
+
+
+if __name__ == "__main__":
+    main()
