@@ -19,7 +19,8 @@
 //   G  info     GetDistroQueueInfo (scheduler.go:57-178): deps-met per task from the LDS edge records,
 //               per-task-group sums by LDS atomics, rows out
 //
-// Anything that does not fit (n > 2048 tasks, > 2176 unit slots, > 1024 task-group rows, |priority| >= 2^31)
+// Anything that does not fit (n > 2048 tasks, unit slots + edges beyond the LDS budget, > 1024 task-group rows,
+// |priority| >= 2^31)
 // branches -- uniformly, before any output is written -- to the generic path of evg_kernels.hip.h. Value ranges
 // that do not compress into 64 bits take wider-key variants of E / F inside this path.
 //
@@ -33,18 +34,23 @@ namespace evg {
 
 constexpr int kE = 4;                // tasks per thread
 constexpr int kN = kBlock * kE;      // 2048 tasks max on this path
-constexpr int kS = 2176;             // unit slots max
+constexpr int kS = 2304;             // unit slots max (12-bit slot ids); the LDS budget below is the binding limit
 constexpr int kG = 1024;             // task-group rows (incl. the standalone row) max
-constexpr int kEdgeCap = 3072;       // dependency edges staged in LDS (more: read from global)
 
 // ---- LDS map (bytes) ------------------------------------------------------------------------------------
-// region A: unit accumulators, live during B..D
-constexpr int A_TIQ = 0, A_DUR = A_TIQ + 8 * kS, A_MAXPRI = A_DUR + 8 * kS, A_CNT = A_MAXPRI + 4 * kS,
-              A_MAXND = A_CNT + 4 * kS, A_MINROW = A_MAXND + 4 * kS, A_END = A_MINROW + 4 * kS;
-// region B: live for the whole kernel
-constexpr int B_PSLOT = A_END, B_EDGE = B_PSLOT + 2 * kN, B_END = B_EDGE + 2 * kEdgeCap;
-// region R: RICH only
-constexpr int R_VAL = B_END, R_HASH = R_VAL + 8 * kS, R_END = R_HASH + 8 * kS;
+// The lean configuration is one 79,872-byte block, so that two workgroups fit a CU's 160 KiB whatever the
+// allocation granule:
+//   [0, 32*Sp)            region A: unit accumulators (Sp = unit slots rounded up to even), live during B..D:
+//                         tiq i64[Sp] | dur i64[Sp] | maxpri i32[Sp] | cnt u32[Sp] | maxnd i32[Sp] | minrow u32[Sp]
+//   [0, Y_END)            the same bytes re-used after D (sort exchange buffers, in-unit keys, run bookkeeping,
+//                         final positions, task-group accumulators)
+//   [kLdsLean-4096-2*Ep, kLdsLean-4096)  the distro's dependency edge records u16[Ep] (Ep = edges rounded up to 8)
+//   [kLdsLean-4096, kLdsLean)            pslot u16[2048]
+// A distro takes the LDS path when max(32*Sp, Y_END) + 2*Ep + 4096 <= kLdsLean (e.g. 2021 slots with up to 5.5k
+// edges, or 1600 slots with up to 9.2k edges). RICH appends val i64[kS] | hash u64[kS] behind the lean block.
+constexpr int kLdsLean = 79872;
+constexpr int B_PSLOT = kLdsLean - 2 * kN;
+constexpr int R_VAL = kLdsLean, R_HASH = R_VAL + 8 * kS, kLdsRich = R_HASH + 8 * kS;
 // region A re-used after D:
 constexpr int X_BUF0 = 0, X_BUF1 = 8 * kN, X_IK = 16 * kN, X_IK_END = X_IK + 8 * kN;  // sort exchange, in-unit keys by task
 constexpr int Y_SIK = 0, Y_SSLOT = 8 * kN, Y_SIDX = Y_SSLOT + 2 * kN;                  // by sorted position
@@ -53,18 +59,28 @@ static_assert(Y_REN + 2 * kN <= X_IK, "run bookkeeping must not overlap the in-u
 constexpr int Y_POS = X_IK_END, Y_FIDX = Y_POS + 2 * kN, Y_END = Y_FIDX + 2 * kN;      // final position by task / task by position
 constexpr int Z_G = 0;                                                                 // group accumulators (36 B per row)
 static_assert(Y_SIDX + 2 * kN <= X_IK, "by-position arrays must not overlap the in-unit keys by task");
-static_assert(Y_END <= A_END && Z_G + 36 * kG <= Y_POS, "region A re-use");
-static_assert(B_END + 256 <= 80 * 1024 - 1024, "lean configuration: two workgroups per CU with allocation-granule slack");
-static_assert(R_END + 256 <= 160 * 1024, "rich configuration");
+static_assert(Z_G + 36 * kG <= Y_POS, "region A re-use");
+static_assert(kLdsLean + 512 <= 80 * 1024, "lean configuration: two workgroups per CU");
+static_assert(kLdsRich + 512 <= 160 * 1024, "rich configuration");
 static_assert(kS < 4096 && kN <= 2048, "slot ids are 12 bits, rows 11 bits");
-
-constexpr int kLdsLean = B_END, kLdsRich = R_END;
+__device__ __forceinline__ int lds_pad_slots(int S) { return (S + 1) & ~1; }
+__device__ __forceinline__ int lds_pad_edges(int ne) { return (ne + 7) & ~7; }
+__device__ __forceinline__ bool lds_budget_ok(int S, int ne) {
+  const int a = 32 * lds_pad_slots(S);
+  return (a > Y_END ? a : Y_END) + 2 * lds_pad_edges(ne) <= B_PSLOT;
+}
 
 // pslot record: bits 0-11 unit slot, 12-13 status class (EVG_TF_STATUS), 14 Blocked()
 constexpr uint32_t PS_SLOT = 0x0FFFu;
-// edge record: in queue  : bit15 = 0, bits 11-12 required status, bits 0-10 local row of the dependency
-//              otherwise : bit15 = 1, bits 0-5 = dep_info (required status, fetched state, blocked, missing)
-constexpr uint32_t ED_OUT = 0x8000u;
+// edge record as staged (phase A):  in queue  : bit15 = 0, bits 11-12 required status, bits 0-10 local row of the dependency
+//                                   otherwise : bit15 = 1, bits 0-5 = dep_info (required status, fetched state, blocked, missing)
+// edge record as resolved (phase B, by the thread that owns the depending row):
+//   ED_OUT  the dependency is not in this distro's queue
+//   ER_SAT  the edge is satisfied (Task.SatisfiesDependency, task.go:546-561)
+//   ER_SKIP in queue, but adds no unit membership: the dependency's unit is the row's own primary / version unit
+//           or was already named by an earlier edge of the same row (Unit.Add is keyed by task id, planner.go:131)
+//   bits 0-11: unit slot of the dependency (in queue)
+constexpr uint32_t ED_OUT = 0x8000u, ER_SAT = 0x4000u, ER_SKIP = 0x2000u, ER_SLOT = 0x0FFFu;
 
 __device__ __forceinline__ uint32_t pack_edge(int j, int n, uint32_t info) {
   return (unsigned)j < (unsigned)n ? ((info & EVG_DEP_REQ_MASK) << 11) | (uint32_t)j : ED_OUT | (info & 0x3Fu);
@@ -235,36 +251,20 @@ struct LdsView {
   uint16_t* edge;
 };
 
-__device__ __forceinline__ uint32_t edge_at(const LdsView& m, const DC& c, const evg_task_soa& t, int x) {
-  if (c.eL) return m.edge[x];
-  return pack_edge(t.dep_idx[c.eb + x] - c.lo, c.n, t.dep_info[c.eb + x]);
-}
-
-// Visits the unit slots a task is a member of (planner.go:434-456): its primary unit t0, the version unit too
-// when it is a task-group task and versions are grouped (:439), and the primary unit of each direct dependency
-// that is in this distro's queue (:451-455). [x0, x1) = the task's local edge range.
-// DEDUP: each distinct slot exactly once (Unit.Add is keyed by task id, :131).
-template <bool DEDUP, class F>
-__device__ __forceinline__ void visit_units(const LdsView& m, const DC& c, const evg_task_soa& t, int t0, bool tg, int verk,
-                                            int x0, int x1, F f, bool skip_primary = false) {
-  if (!skip_primary) f(t0, true);
-  int t1 = -1;
-  if (c.gv && tg) { t1 = c.ver_base + (verk - c.ver_lo); f(t1, false); }
+// Visits the unit slots a row is a member of (planner.go:434-456): its primary unit t0, the version unit t1 when it is
+// a task-group task and versions are grouped (:439; -1 otherwise), and the unit of each direct dependency that is in
+// this distro's queue (:451-455) -- each distinct slot once. [x0, x1) = the row's RESOLVED edge records.
+template <class F>
+__device__ __forceinline__ void for_units(const uint16_t* edge, int t0, int t1, int x0, int x1, F f) {
+  f(t0);
+  if (t1 >= 0) f(t1);
   for (int x = x0; x < x1; x++) {
-    const uint32_t er = edge_at(m, c, t, x);
-    if (er & ED_OUT) continue;
-    const int s = m.pslot[er & 0x7FFu] & PS_SLOT;
-    if (s == t0 || s == t1) continue;
-    if (DEDUP) {
-      bool dup = false;
-      for (int y = x0; y < x; y++) {
-        const uint32_t e2 = edge_at(m, c, t, y);
-        if (!(e2 & ED_OUT) && (int)(m.pslot[e2 & 0x7FFu] & PS_SLOT) == s) { dup = true; break; }
-      }
-      if (dup) continue;
-    }
-    f(s, false);
+    const uint32_t er = edge[x];
+    if (!(er & (ED_OUT | ER_SKIP))) f((int)(er & ER_SLOT));
   }
+}
+__device__ __forceinline__ bool dep_satisfied(uint32_t req, uint32_t st, bool blk) {  // task.go:546-561
+  return req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
 }
 
 __device__ __forceinline__ uint64_t shl64(uint64_t x, int s) { return s >= 64 ? 0ull : x << s; }
@@ -294,9 +294,12 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
   const int i0 = tid * kE;
 
   LdsView m;
-  m.tiq = (int64_t*)(smem + A_TIQ); m.dur = (int64_t*)(smem + A_DUR); m.maxpri = (int32_t*)(smem + A_MAXPRI);
-  m.cnt = (uint32_t*)(smem + A_CNT); m.maxnd = (int32_t*)(smem + A_MAXND); m.minrow = (uint32_t*)(smem + A_MINROW);
-  m.pslot = (uint16_t*)(smem + B_PSLOT); m.edge = (uint16_t*)(smem + B_EDGE);
+  {
+    const int Sp = lds_pad_slots(S);
+    m.tiq = (int64_t*)smem; m.dur = m.tiq + Sp; m.maxpri = (int32_t*)(m.dur + Sp);
+    m.cnt = (uint32_t*)(m.maxpri + Sp); m.maxnd = (int32_t*)(m.cnt + Sp); m.minrow = (uint32_t*)(m.maxnd + Sp);
+    m.pslot = (uint16_t*)(smem + B_PSLOT); m.edge = m.pslot - lds_pad_edges(c.ne);
+  }
   m.val = RICH ? (int64_t*)(smem + R_VAL) : m.tiq;  // lean: TotalValue overwrites the unit's TimeInQueue sum
   // s_red words: 0 any met merge-queue task, 1 n_met, 2 n_mq, 3 n_s3, 4 secondary, 5 t_cover, 6 t_wait, 7 n_units,
   // 8 rows, 10-11 t_dur, 12-13 t_dover; 16-23 four 64-bit range words; 24-29 six 32-bit range words
@@ -361,8 +364,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
       }
     }
   }
-  if (c.eL)
-    for (int x = tid; x < c.ne; x += kBlock) m.edge[x] = (uint16_t)pack_edge(t.dep_idx[c.eb + x] - lo, n, t.dep_info[c.eb + x]);
+  for (int x = tid; x < c.ne; x += kBlock) m.edge[x] = (uint16_t)pack_edge(t.dep_idx[c.eb + x] - lo, n, t.dep_info[c.eb + x]);
   for (int u = (c.gv ? 0 : n) + tid; u < S; u += kBlock) {
     m.tiq[u] = 0; m.dur[u] = 0; m.maxpri[u] = 0; m.cnt[u] = 0; m.maxnd[u] = 0; m.minrow[u] = 0xFFFFFFFFu;
   }
@@ -371,26 +373,52 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
   EVG_STAMP(1);
   __syncthreads();
 
-  // ---- B: segmented reduce of Unit.info (planner.go:302-337) -------------------------------------------------
+  // ---- B: resolve the edge records; segmented reduce of Unit.info (planner.go:302-337) -------------------------
   const int n_own = c.gv ? 0 : n;  // slots below n_own were initialised by their owner (NONGROUP | DISTRO, min row = slot)
+  int tv[4];                       // version unit of a task-group row when versions are grouped, else -1
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const int i = i0 + e;
+    tv[e] = c.gv && tgk[e] >= 0 ? c.ver_base + (verk[e] - c.ver_lo) : -1;
     if (i >= n) continue;
-    const int64_t tq = tiq[e], du = dur[e], pr = pri[e];
-    const int32_t ndv = nd[e];
+    const int64_t tq = tiq[e], du = dur[e];
+    const int32_t prv = pri[e] > 0 ? (int32_t)pri[e] : 0, ndv = nd[e] > 0 ? nd[e] : 0;
     const uint32_t ufe = uf[e];
-    visit_units<true>(m, c, t, ps[e], tgk[e] >= 0, verk[e], doff[e], doff[e + 1], [&](int u, bool primary) {
-      const bool owned = u < n_own;
-      if (tq != 0) atomicAdd((unsigned long long*)&m.tiq[u], (unsigned long long)tq);
+    // branch-free: neutral operands instead of skipped atomics
+    auto join = [&](int u, uint32_t bits) {
+      atomicAdd((unsigned long long*)&m.tiq[u], (unsigned long long)tq);
       atomicAdd((unsigned long long*)&m.dur[u], (unsigned long long)du);
-      if (pr > 0) atomicMax(&m.maxpri[u], (int32_t)pr);
-      if (ndv > 0) atomicMax(&m.maxnd[u], ndv);
+      atomicMax(&m.maxpri[u], prv);
+      atomicMax(&m.maxnd[u], ndv);
       atomicAdd(&m.cnt[u], 1u);
-      const uint32_t bits = (owned ? ufe & ~UF_NONGROUP : ufe) | (primary ? UF_DISTRO : 0u);  // SetDistro only via the primary key (:447)
-      if (bits) atomicOr(&m.cnt[u], bits);
-      if (!owned || i < u) atomicMin(&m.minrow[u], (uint32_t)i);
-    }, !c.gv && tgk[e] < 0);
+      atomicOr(&m.cnt[u], bits);
+      atomicMin(&m.minrow[u], (uint32_t)i);
+    };
+    const int t0 = ps[e], t1 = tv[e];
+    if (c.gv || tgk[e] >= 0) join(t0, ufe | UF_DISTRO);  // SetDistro only via the primary key (:447)
+    if (t1 >= 0) join(t1, ufe);
+    const int x0 = doff[e], x1 = doff[e + 1];
+    for (int x = x0; x < x1; x++) {
+      const uint32_t raw = m.edge[x];
+      uint32_t rec;
+      if (raw & ED_OUT) {
+        const bool sat = !(raw & EVG_DEP_MISSING) &&
+                         dep_satisfied(raw & EVG_DEP_REQ_MASK, (raw & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT, raw & EVG_DEP_BLOCKED);
+        rec = ED_OUT | (sat ? ER_SAT : 0u);
+      } else {
+        const uint32_t pj = m.pslot[raw & 0x7FFu];
+        const int sl = (int)(pj & PS_SLOT);
+        const bool sat = dep_satisfied((raw >> 11) & 3u, (pj >> 12) & 3u, pj & 0x4000u);
+        bool skip = sl == t0 || sl == t1;
+        for (int y = x0; y < x; y++) {
+          const uint32_t e2 = m.edge[y];
+          skip |= !(e2 & ED_OUT) && (int)(e2 & ER_SLOT) == sl;
+        }
+        rec = (sat ? ER_SAT : 0u) | (skip ? ER_SKIP : 0u) | (uint32_t)sl;
+        if (!skip) join(sl, sl < n_own ? ufe & ~UF_NONGROUP : ufe);
+      }
+      m.edge[x] = (uint16_t)rec;
+    }
   }
   EVG_STAMP(2);
   __syncthreads();
@@ -419,8 +447,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
       const int i = i0 + e;
       if (i >= n) continue;
       const uint64_t h = mix64((uint64_t)i);
-      visit_units<true>(m, c, t, ps[e], tgk[e] >= 0, verk[e], doff[e], doff[e + 1],
-                        [&](int u, bool) { atomicAdd((unsigned long long*)&hash[u], (unsigned long long)h); });
+      for_units(m.edge, ps[e], tv[e], doff[e], doff[e + 1], [&](int u) { atomicAdd((unsigned long long*)&hash[u], (unsigned long long)h); });
     }
     __syncthreads();
     uint32_t mine = 0;
@@ -433,7 +460,8 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
       bool dup = false;
       const uint64_t hu = hash[u];
       const uint32_t cu = m.cnt[u] & UF_COUNT_MASK;
-      visit_units<false>(m, c, t, m.pslot[i] & PS_SLOT, tg_i >= 0, t.version_key[r], x0, x1, [&](int w, bool) {
+      const int tv_i = c.gv && tg_i >= 0 ? c.ver_base + (t.version_key[r] - c.ver_lo) : -1;
+      for_units(m.edge, m.pslot[i] & PS_SLOT, tv_i, x0, x1, [&](int w) {
         if (w < u && m.val[w] != INT64_MIN && hash[w] == hu && (m.cnt[w] & UF_COUNT_MASK) == cu && m.minrow[w] == (uint32_t)i)
           dup = true;
       });
@@ -457,15 +485,21 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
     const int i = i0 + e;
     bv[e] = INT64_MIN; bm[e] = 0; bs[e] = -1;
     if (i >= n) continue;
-    int best = -1;
-    int64_t bvv = INT64_MIN;
-    uint32_t bmm = 0;
-    visit_units<false>(m, c, t, ps[e], tgk[e] >= 0, verk[e], doff[e], doff[e + 1], [&](int u, bool) {
-      const int64_t v = m.val[u];
-      if (v == INT64_MIN) return;
+    // candidates: every unit the row is a member of; the primary unit is always valid (it got its distro from this row)
+    int best = ps[e];
+    int64_t bvv = m.val[best];
+    uint32_t bmm = m.minrow[best];
+    auto consider = [&](int u) {
+      const int64_t v = m.val[u];  // INT64_MIN for a dropped unit: never better
       const uint32_t mr = m.minrow[u];
-      if (best < 0 || v > bvv || (v == bvv && (mr < bmm || (mr == bmm && u < best)))) { best = u; bvv = v; bmm = mr; }
-    });
+      const bool better = v > bvv || (v == bvv && (mr < bmm || (mr == bmm && u < best)));
+      best = better ? u : best; bvv = better ? v : bvv; bmm = better ? mr : bmm;
+    };
+    if (tv[e] >= 0) consider(tv[e]);
+    for (int x = doff[e]; x < doff[e + 1]; x++) {
+      const uint32_t er = m.edge[x];
+      if (!(er & (ED_OUT | ER_SKIP))) consider((int)(er & ER_SLOT));
+    }
     bv[e] = bvv; bm[e] = bmm; bs[e] = best;
     if (RICH && a.out.breakdown) {
       const uint32_t cw = m.cnt[best];
@@ -675,20 +709,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
     int64_t mtime = dmt[e];
     if (!mt) {
       bool all = true;
-      for (int x = x0; x < x1; x++) {
-        const uint32_t er = edge_at(m, c, t, x);
-        uint32_t st, req;
-        bool blk;
-        if (!(er & ED_OUT)) {
-          const uint32_t pj = m.pslot[er & 0x7FFu];
-          st = (pj >> 12) & 3u; blk = pj & 0x4000u; req = (er >> 11) & 3u;
-        } else {
-          if (er & EVG_DEP_MISSING) { all = false; break; }
-          st = (er & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT; blk = er & EVG_DEP_BLOCKED; req = er & EVG_DEP_REQ_MASK;
-        }
-        const bool sat = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;  // task.go:546-561
-        if (!sat) { all = false; break; }
-      }
+      for (int x = x0; x < x1; x++) all &= (m.edge[x] & ER_SAT) != 0;
       if (all) {
         mt = true;  // setDependenciesMetTime task.go:690-701
         int64_t mx = 0;
@@ -842,10 +863,12 @@ __device__ __forceinline__ DC distro_context(const PlanArgs& a, int d) {
   c.P = P;
   c.eb = a.in.tasks.dep_off[c.lo];
   c.ne = a.in.tasks.dep_off[c.lo + c.n] - c.eb;
-  c.eL = c.ne <= kEdgeCap;
+  c.eL = true;
   return c;
 }
-__device__ __forceinline__ bool fits_lds_path(const DC& c) { return c.n <= kN && c.S <= kS && c.ntg + 1 <= kG; }
+__device__ __forceinline__ bool fits_lds_path(const DC& c) {
+  return c.n <= kN && c.S <= kS && c.ntg + 1 <= kG && c.ne >= 0 && lds_budget_ok(c.S, c.ne);
+}
 
 // One workgroup per distro: the LDS path. Distros it cannot take are flagged in a.w_generic[d] and left to
 // k_plan_generic, which is enqueued right behind this kernel.

@@ -24,6 +24,7 @@ namespace evg {
 // "" and bucket 1+k is task group k of the distro. The fp64 sum of getSoonToBeFreeHosts (:373-376) is taken in
 // host order, one lane per bucket, so that it is reproducible.
 constexpr int kAllocBlock = 256;
+constexpr int kAllocLdsHosts = 2048;  // hosts of one distro staged in LDS (more: the bucket loop reads global memory)
 
 struct AllocArgs {
   evg_alloc_input in;
@@ -34,6 +35,9 @@ struct AllocArgs {
 
 __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs a) {
   __shared__ int s_i[8];  // 0: #free hosts, 1: sum new, 2: sum free, 4: first failing bucket, 5: its error
+  __shared__ double s_term[kAllocLdsHosts];
+  __shared__ int32_t s_key[kAllocLdsHosts];
+  __shared__ uint8_t s_flag[kAllocLdsHosts];
   const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int D = a.in.n_distros;
   const evg_alloc_params p = a.in.params[d];
@@ -46,7 +50,9 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
   if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
   __syncthreads();
 
-  // free hosts of the distro (:33-37) and every running host's fractional-free term (:340-368)
+  // free hosts of the distro (:33-37) and every running host's fractional-free term (:340-368); the host columns
+  // the bucket loop re-reads are staged in LDS when they fit
+  const bool staged = nh <= kAllocLdsHosts;
   uint32_t nfree = 0;
   for (int i = tid; i < nh; i += kAllocBlock) {
     const uint32_t f = h.flags[h0 + i];
@@ -63,7 +69,8 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
       if (frac > 1) frac = 1;
       term = p.future_host_fraction * frac;
     }
-    a.w_term[h0 + i] = term;
+    if (staged) { s_term[i] = term; s_key[i] = h.tg_key[h0 + i]; s_flag[i] = (uint8_t)f; }
+    else a.w_term[h0 + i] = term;
   }
   nfree = wave_sum(nfree);
   if (lane == 0 && nfree) atomicAdd(&s_i[0], (int)nfree);
@@ -91,12 +98,22 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
     const int want_key = b == 0 ? -1 : tg_lo + (b - 1);
     int n_hosts_b = 0, n_free_b = 0;
     double soon = 0.0;
-    for (int i = 0; i < nh; i++) {  // host order: the canonical order of the fp64 sum
-      if (h.tg_key[h0 + i] != want_key) continue;
-      n_hosts_b++;
-      const uint32_t f = h.flags[h0 + i];
-      n_free_b += (f & EVG_HF_FREE) ? 1 : 0;
-      if ((f & EVG_HF_RUNNING) && (f & EVG_HF_RUNNING_FOUND)) soon += a.w_term[h0 + i];
+    if (staged) {
+      for (int i = 0; i < nh; i++) {  // host order: the canonical order of the fp64 sum
+        if (s_key[i] != want_key) continue;
+        n_hosts_b++;
+        const uint32_t f = s_flag[i];
+        n_free_b += (f & EVG_HF_FREE) ? 1 : 0;
+        if ((f & EVG_HF_RUNNING) && (f & EVG_HF_RUNNING_FOUND)) soon += s_term[i];
+      }
+    } else {
+      for (int i = 0; i < nh; i++) {
+        if (h.tg_key[h0 + i] != want_key) continue;
+        n_hosts_b++;
+        const uint32_t f = h.flags[h0 + i];
+        n_free_b += (f & EVG_HF_FREE) ? 1 : 0;
+        if ((f & EVG_HF_RUNNING) && (f & EVG_HF_RUNNING_FOUND)) soon += a.w_term[h0 + i];
+      }
     }
     const bool present = gi.present != 0;
     // "" is evaluated when it exists in taskGroupDatas (hosts or an info row); a named group is skipped when
