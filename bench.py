@@ -124,7 +124,7 @@ def main():
     for _ in range(args.warmup):
         pool.step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()          # HIP events on the stream the kernels are launched on (torch's current stream)
@@ -132,9 +132,11 @@ def main():
         ev[k][1].record()
         if pool.has_hosts:
             pool.allocate()
+        ev[k][2].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    plan_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    plan_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / max(args.steps, 1)
+    alloc_ms = sum(b.elapsed_time(c) for _, b, c in ev) / max(args.steps, 1)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     ntask = torch.tensor([float(batch.n_tasks)], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -173,7 +175,7 @@ def main():
                 traffic = None
         line["roofline"] = {"bound": "hbm", "kernel": "k_plan_distros", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                            "algorithmic_bytes_per_launch": abytes, "kernel_ms": plan_ms,
+                            "algorithmic_bytes_per_launch": abytes, "kernel_ms": plan_ms, "allocator_ms": alloc_ms,
                             "bytes_per_task": abytes / max(batch.n_tasks, 1)}
         if world == 1 and not args.no_cpu_baseline:
             want, want_alloc, t1, tn, nt = cpu_baseline(batch, os.cpu_count() or 1)

@@ -645,16 +645,62 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
   int rank[4] = {0, 0, 0, 0};
   if (multi) {
     if (ik_ok) {
-      // one sweep over the union of the thread's runs: every fetched key is compared against the thread's 4 keys
-      const int qlo = st[0], qhi = i0 + 3 < n ? en[3] : n;
-      for (int q2 = qlo; q2 < qhi; q2++) {
-        const uint64_t k2 = sik[q2];
+      // The thread's positions are consecutive, so the members of one run inside the thread are consecutive too.
+      // Per distinct run: (1) positions before the thread's members precede on key <=, (2) positions after them on
+      // key <, (3) the members among themselves in registers. Keys of elements outside the run are masked so that
+      // the inner loops are one compare + one add-with-carry per element.
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        if (i0 + g >= n || (g && st[g] == st[g - 1]) || en[g] - st[g] <= 1) continue;  // g opens a run inside the thread
+        const int rs = st[g], re = en[g];
+        uint64_t khi[4], klo[4];
+        int last = g;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const bool in = q2 >= st[e] && q2 < en[e];
-          const bool lt = k2 < myik[e] || (k2 == myik[e] && q2 < i0 + e);
-          rank[e] += in && lt ? 1 : 0;
+          const bool in = e >= g && st[e] == rs && i0 + e < n;
+          khi[e] = in ? myik[e] : ~0ull;  // never "greater than the other key"
+          klo[e] = in ? myik[e] : 0ull;   // never "less than ..."
+          last = in ? e : last;
         }
+        const int a0 = i0 + g, a1 = i0 + last + 1;  // the thread's members of the run: positions [a0, a1)
+        int gt[4] = {0, 0, 0, 0};
+        {  // earlier positions precede unless their key is greater; 4 independent LDS reads per trip
+          int q2 = rs;
+          for (; q2 + 4 <= a0; q2 += 4) {
+            const uint64_t k0 = sik[q2], k1 = sik[q2 + 1], k2 = sik[q2 + 2], k3 = sik[q2 + 3];
+#pragma unroll
+            for (int e = 0; e < 4; e++) gt[e] += (khi[e] < k0 ? 1 : 0) + (khi[e] < k1 ? 1 : 0) + (khi[e] < k2 ? 1 : 0) + (khi[e] < k3 ? 1 : 0);
+          }
+          for (; q2 < a0; q2++) {
+            const uint64_t k0 = sik[q2];
+#pragma unroll
+            for (int e = 0; e < 4; e++) gt[e] += khi[e] < k0 ? 1 : 0;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) rank[e] += (e >= g && e <= last) ? (a0 - rs) - gt[e] : 0;
+        {  // later positions precede only when their key is smaller
+          int q2 = a1;
+          for (; q2 + 4 <= re; q2 += 4) {
+            const uint64_t k0 = sik[q2], k1 = sik[q2 + 1], k2 = sik[q2 + 2], k3 = sik[q2 + 3];
+#pragma unroll
+            for (int e = 0; e < 4; e++) rank[e] += (k0 < klo[e] ? 1 : 0) + (k1 < klo[e] ? 1 : 0) + (k2 < klo[e] ? 1 : 0) + (k3 < klo[e] ? 1 : 0);
+          }
+          for (; q2 < re; q2++) {
+            const uint64_t k0 = sik[q2];
+#pragma unroll
+            for (int e = 0; e < 4; e++) rank[e] += k0 < klo[e] ? 1 : 0;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+          for (int f = e + 1; f < 4; f++) {
+            const bool both = e >= g && f <= last;
+            const bool f_first = myik[f] < myik[e];  // ties: the earlier position (row order) stays first
+            rank[e] += both && f_first ? 1 : 0;
+            rank[f] += both && !f_first ? 1 : 0;
+          }
       }
     } else {  // value ranges too wide to compress into 64 bits: compare the columns themselves
 #pragma unroll

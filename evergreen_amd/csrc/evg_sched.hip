@@ -31,7 +31,15 @@ struct AllocArgs {
   evg_alloc_output out;
   double* w_term;  // [n_hosts] fractional-free term of each running host
   int32_t *w_new, *w_free, *w_err;  // [D + n_tg] per-bucket results; w_err: -1 not evaluated, 0 ok, >0 EVG_ALLOC_E_*
+#ifdef EVG_PHASE_TIMING
+  unsigned long long* dbg_ts;
+#endif
 };
+#ifdef EVG_PHASE_TIMING
+#define ALLOC_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0 && a.dbg_ts) a.dbg_ts[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ALLOC_STAMP(k) do {} while (0)
+#endif
 
 __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs a) {
   __shared__ int s_i[8];  // 0: #free hosts, 1: sum new, 2: sum free, 4: first failing bucket, 5: its error
@@ -47,6 +55,7 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
   const int64_t T = a.in.distro_info[d].max_duration_threshold_ns;
   const int len_met = a.in.distro_info[d].length_with_dependencies_met;
   const int64_t now = a.in.now_ns;
+  ALLOC_STAMP(0);
   if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
   __syncthreads();
 
@@ -72,6 +81,7 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
     if (staged) { s_term[i] = term; s_key[i] = h.tg_key[h0 + i]; s_flag[i] = (uint8_t)f; }
     else a.w_term[h0 + i] = term;
   }
+  ALLOC_STAMP(1);
   nfree = wave_sum(nfree);
   if (lane == 0 && nfree) atomicAdd(&s_i[0], (int)nfree);
   __syncthreads();
@@ -90,6 +100,7 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
     return;
   }
 
+  ALLOC_STAMP(2);
   // per bucket: evalHostUtilization (:134-205)
   const bool ephemeral = p.provider != 0;
   for (int b = tid; b < ntg + 1; b += kAllocBlock) {
@@ -99,13 +110,18 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
     int n_hosts_b = 0, n_free_b = 0;
     double soon = 0.0;
     if (staged) {
-      for (int i = 0; i < nh; i++) {  // host order: the canonical order of the fp64 sum
-        if (s_key[i] != want_key) continue;
-        n_hosts_b++;
+      // host order is the canonical order of the fp64 sum. Branch-free: a host of another bucket adds +0.0, which
+      // leaves a non-negative partial sum unchanged bit for bit; 4 independent LDS reads per trip.
+      auto take = [&](int i) {
+        const bool in = s_key[i] == want_key;
         const uint32_t f = s_flag[i];
-        n_free_b += (f & EVG_HF_FREE) ? 1 : 0;
-        if ((f & EVG_HF_RUNNING) && (f & EVG_HF_RUNNING_FOUND)) soon += s_term[i];
-      }
+        n_hosts_b += in ? 1 : 0;
+        n_free_b += in && (f & EVG_HF_FREE) ? 1 : 0;
+        soon += in ? s_term[i] : 0.0;  // s_term is 0.0 unless the host runs a found task
+      };
+      int i = 0;
+      for (; i + 4 <= nh; i += 4) { take(i); take(i + 1); take(i + 2); take(i + 3); }
+      for (; i < nh; i++) take(i);
     } else {
       for (int i = 0; i < nh; i++) {
         if (h.tg_key[h0 + i] != want_key) continue;
@@ -156,6 +172,7 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
     a.w_new[row] = n_new; a.w_free[row] = n_free; a.w_err[row] = err;
   }
   __syncthreads();
+  ALLOC_STAMP(3);
   // Canonical map order: "" first, then groups by key. The reference returns at the first failing group (:99-101);
   // groups visited before it already had CountFree/CountRequired written (:106-109).
   const int first_err = s_i[4];
@@ -169,6 +186,7 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
     t_free += a.w_free[row];
     if (b != 0) { a.in.group_info[row].count_free = a.w_free[row]; a.in.group_info[row].count_required = a.w_new[row]; }
   }
+  ALLOC_STAMP(4);
   if (t_new) atomicAdd(&s_i[1], t_new);
   if (t_free) atomicAdd(&s_i[2], t_free);
   __syncthreads();
@@ -184,6 +202,7 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
       a.out.new_hosts[d] = required + add_min; a.out.free_hosts[d] = s_i[2]; a.out.status[d] = EVG_ALLOC_OK;
     }
   }
+  ALLOC_STAMP(5);
 }
 
 // capTaskQueueLength (scheduler/task_queue_persister.go:66-83): one thread per distro.
@@ -225,6 +244,7 @@ struct evg_ctx {
   bool lds_attr_set = false;
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts = nullptr;
+  unsigned long long* dbg_ts_alloc = nullptr;
 #endif
 };
 
@@ -298,6 +318,7 @@ int32_t evg_abi_version(void) { return (1 << 16) | 0; }
 #ifdef EVG_PHASE_TIMING
 // diagnostics build only (scripts/phase_timing.py): device buffer of D x 16 s_memtime stamps
 void evg_dbg_phase_buffer(evg_ctx* c, void* dev_ptr) { c->dbg_ts = (unsigned long long*)dev_ptr; }
+void evg_dbg_alloc_phase_buffer(evg_ctx* c, void* dev_ptr) { c->dbg_ts_alloc = (unsigned long long*)dev_ptr; }
 #endif
 
 const char* evg_last_error(const evg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -452,6 +473,9 @@ static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_o
   }
   a.w_term = (double*)c->scratch[24].p;
   a.w_new = (int32_t*)c->scratch[25].p; a.w_free = (int32_t*)c->scratch[26].p; a.w_err = (int32_t*)c->scratch[27].p;
+#ifdef EVG_PHASE_TIMING
+  a.dbg_ts = c->dbg_ts_alloc;
+#endif
   hipLaunchKernelGGL(k_allocate_hosts, dim3(in->n_distros), dim3(kAllocBlock), 0, st, a);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;

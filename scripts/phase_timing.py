@@ -51,7 +51,19 @@ def main():
         print("  %-18s mean %8.1f  p50 %8.1f  max %8.1f   %5.1f%%" % (nm, dt[:, k].mean(), np.median(dt[:, k]), dt[:, k].max(),
                                                                       100 * dt[:, k].mean() / tot.mean()))
     print("  %-18s mean %8.1f  p50 %8.1f  max %8.1f" % ("WG total", tot.mean(), np.median(tot), tot.max()))
-    print("  kernel span (first start -> last end): %.1f ticks" % float(t[:, 11].max() - t[:, 0].min()))
+    if pool.has_hosts:
+        ts2 = torch.zeros(batch.n_distros * 16, dtype=torch.int64, device=dev)
+        lib.evg_dbg_alloc_phase_buffer.argtypes = [C.c_void_p, C.c_void_p]
+        lib.evg_dbg_alloc_phase_buffer(ctx.h, ts2.data_ptr())
+        for _ in range(3):
+            pool.allocate()
+        torch.cuda.synchronize()
+        t2 = ts2.cpu().numpy().reshape(-1, 16)[:, :6]
+        ok = t2[:, 5] > 0
+        d2 = np.diff(t2[ok], axis=1).astype(np.float64)
+        print("allocator (distros that run the bucket loop: %d)" % int(ok.sum()))
+        for k, nm in enumerate(["init", "host loop", "nfree+early outs", "bucket loop", "write back"]):
+            print("  %-18s mean %8.1f  max %8.1f" % (nm, d2[:, k].mean(), d2[:, k].max()))
 
 
 if __name__ == "__main__":

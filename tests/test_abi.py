@@ -1,0 +1,107 @@
+"""CPU-side checks of the drop-in boundary: the HIP library loads without a GPU, exports exactly the entry points
+include/evg_sched.h declares, the ctypes / numpy mirrors in evergreen_amd/abi.py match the C layout byte for byte,
+the host-side contract check works, and -- with no GPU -- the product refuses to run instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "evg_sched.h")
+
+from evergreen_amd import abi, gen, native  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(native.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    return native.load_library()
+
+
+def _declared_entry_points():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(evg_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_entry_point(lib):
+    names = _declared_entry_points()
+    assert set(names) == set(native.EXPORTS), (names, native.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), "libevg_sched.so does not export %s" % n
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof from the real header (gcc) against the ctypes structs and numpy dtypes."""
+    structs = {"evg_task_soa": abi.TaskSoa, "evg_plan_input": abi.PlanInput, "evg_plan_output": abi.PlanOutput,
+               "evg_host_soa": abi.HostSoa, "evg_alloc_input": abi.AllocInput, "evg_alloc_output": abi.AllocOutput}
+    dtypes = {"evg_distro_params": abi.DISTRO_PARAMS_DTYPE, "evg_group_info": abi.GROUP_INFO_DTYPE,
+              "evg_distro_info": abi.DISTRO_INFO_DTYPE, "evg_alloc_params": abi.ALLOC_PARAMS_DTYPE}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "evg_sched.h"', "int main(void) {"]
+    for s, ct in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (s, s))
+        for f, _ in ct._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (s, f, s, f))
+    for s, dt in dtypes.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (s, s))
+        for f in dt.names:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (s, f, s, f))
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for s, ct in structs.items():
+        assert int(got[s]) == C.sizeof(ct), s
+        for f, _ in ct._fields_:
+            assert int(got["%s.%s" % (s, f)]) == getattr(ct, f).offset, (s, f)
+    for s, dt in dtypes.items():
+        assert int(got[s]) == dt.itemsize, s
+        for f in dt.names:
+            assert int(got["%s.%s" % (s, f)]) == dt.fields[f][1], (s, f)
+
+
+def test_validate_plan_input_on_host(lib):
+    b = gen.generate(gen.config(1))
+    inp = abi.make_plan_input(b)
+    msg = C.create_string_buffer(256)
+    assert lib.evg_validate_plan_input(C.byref(inp), msg, 256) == abi.EVG_OK
+    b.cols["version_key"][5] = 10**6
+    inp = abi.make_plan_input(b)
+    assert lib.evg_validate_plan_input(C.byref(inp), msg, 256) == abi.EVG_E_CONTRACT
+    assert b"version_key" in msg.value
+    b = gen.generate(gen.config(1))
+    b.task_off[-1] -= 1
+    inp = abi.make_plan_input(b)
+    assert lib.evg_validate_plan_input(C.byref(inp), msg, 256) == abi.EVG_E_CONTRACT
+
+
+def test_abi_version(lib):
+    assert lib.evg_abi_version() >> 16 == 1
+
+
+def test_no_gpu_means_no_context_and_no_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(native.NativeError) as e:
+        native.Context(0)
+    assert "no CPU fallback" in str(e.value) or "no HIP device" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under evergreen_amd/ may load, link or mention it."""
+    pkg = os.path.join(ROOT, "evergreen_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "libevg_oracle" not in text and "oracle_lib" not in text and "evg_oracle_" not in text, f
