@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--tasks", type=int, default=0, help="override the task count (parity/debug runs only)")
     ap.add_argument("--distros", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", action="store_true", help="time the single-launch entry point evg_plan_allocate_device instead of "
+                    "evg_plan_distros_device + evg_allocate_hosts_device (the reference's two jobs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -122,16 +124,20 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        pool.step()
+        pool.step(fused=args.fused)
     barrier()
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()          # HIP events on the stream the kernels are launched on (torch's current stream)
-        pool.plan()
-        ev[k][1].record()
-        if pool.has_hosts:
-            pool.allocate()
+        if not args.fused:
+            pool.plan()
+            ev[k][1].record()
+            if pool.has_hosts:
+                pool.allocate()
+        else:
+            pool.step(fused=True)  # one launch: every distro's planner workgroup ends with its host-allocator pass
+            ev[k][1].record()
         ev[k][2].record()
     barrier()
     elapsed = time.perf_counter() - t0

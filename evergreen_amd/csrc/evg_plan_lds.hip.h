@@ -28,6 +28,7 @@
 // (one workgroup per CU); chosen at launch.
 #pragma once
 
+#include "evg_alloc.hip.h"
 #include "evg_kernels.hip.h"
 
 namespace evg {
@@ -285,8 +286,11 @@ __device__ __forceinline__ int inunit_cmp(const evg_task_soa& t, int ra, int rb)
 
 // The LDS path. Returns false (uniformly, before writing any output) when the distro must take the generic path.
 // s_red: 32 zeroed words of static LDS.
-template <bool RICH>
-__device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, unsigned char* smem, unsigned* s_red) {
+// FUSED: the distro's UtilizationBasedHostAllocator pass (q) runs as the tail of the same workgroup: its host rows are
+// fetched before the sort, so their latency hides behind the planner's compute, and the queue info it consumes never
+// leaves the CU.
+template <bool RICH, bool FUSED>
+__device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocArgs& q, const DC& c, unsigned char* smem, unsigned* s_red) {
   const evg_task_soa& t = a.in.tasks;
   const int d = c.d, lo = c.lo, n = c.n, S = c.S;
   const evg_distro_params p = a.in.distros[d];
@@ -326,6 +330,29 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
 #pragma unroll
     for (int e = 0; e < 4; e++) doff[e] = i0 + e < n ? o4[e] - c.eb : last;
     doff[4] = last;
+  }
+  // FUSED: the distro's host rows are fetched with the task columns, reduced to what does not depend on the target
+  // time ({time left, bucket key, flags}) and parked in the LDS bytes between the unit accumulators / re-use area and
+  // the edge records, where nothing else ever lives: their latency is paid together with phase A's and no register is
+  // held for them. Too many hosts for that gap: they are fetched in the tail instead.
+  int fh0 = 0, fnh = 0;
+  bool fpre = false;
+  evg_alloc_params ap{};
+  struct HostPre { int64_t left; int32_t key; uint32_t flags; };  // flags: EVG_HF_* | bit 8 counted | bit 9 overrun
+  const int park_off = 32 * lds_pad_slots(S) > Y_END ? 32 * lds_pad_slots(S) : Y_END;
+  HostPre* hpre = (HostPre*)(smem + park_off);
+  if (FUSED) {
+    ap = q.in.params[d];
+    fh0 = q.in.host_off[d];
+    fnh = q.in.host_off[d + 1] - fh0;
+    fpre = park_off + 16 * fnh <= (int)((unsigned char*)m.edge - smem);
+    if (fpre)
+      for (int i = tid; i < fnh; i += kBlock) {
+        const uint32_t f = q.in.hosts.flags[fh0 + i];
+        const HostLeft hl = host_left(c.now, f, q.in.hosts.start_ts_ns[fh0 + i], q.in.hosts.expected_duration_ns[fh0 + i],
+                                      q.in.hosts.duration_stddev_ns[fh0 + i]);
+        hpre[i] = HostPre{hl.left, q.in.hosts.tg_key[fh0 + i], f | (hl.counted ? 0x100u : 0u) | (hl.overrun ? 0x200u : 0u)};
+      }
   }
   bool wide_pri = false;
 #pragma unroll
@@ -885,6 +912,43 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const DC& c, 
     a.out.distro_info[d] = di;
   }
   EVG_STAMP(11);
+  if (FUSED) {
+    // ---- H: UtilizationBasedHostAllocator for this distro (evg_alloc.hip.h) ----------------------------------
+    const int len_met = (int)s_red[1];
+    __syncthreads();  // group rows are in global memory (same CU: visible after the barrier); region A and s_red are free
+    const int lds_room = (int)((unsigned char*)m.edge - smem);
+    const int nb = c.ntg + 1;
+    HostStage hs;
+    hs.n_hosts = (int*)smem;  // the group accumulators are dead
+    hs.n_free = hs.n_hosts + nb;
+    hs.rec = fpre ? (HostRec*)hpre : (HostRec*)(hs.n_free + nb + (nb & 1));
+    hs.staged = fpre || 8 * (nb + 1) + 16 * fnh <= lds_room;
+    int* s_i = (int*)s_red;
+    if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
+    if (hs.staged)
+      for (int b = tid; b < nb; b += kBlock) { hs.n_hosts[b] = 0; hs.n_free[b] = 0; }
+    __syncthreads();
+    uint32_t nfree = 0;
+    for (int i = tid; i < fnh; i += kBlock) {
+      uint32_t f;
+      int32_t key;
+      HostLeft hl;
+      if (fpre) {  // parked before the sort; the record is converted in place (same 16 bytes)
+        const HostPre hp = hpre[i];
+        f = hp.flags & 0xFFu; key = hp.key;
+        hl = HostLeft{hp.left, (hp.flags & 0x100u) != 0, (hp.flags & 0x200u) != 0};
+      } else {
+        f = q.in.hosts.flags[fh0 + i];
+        key = q.in.hosts.tg_key[fh0 + i];
+        hl = host_left(c.now, f, q.in.hosts.start_ts_ns[fh0 + i], q.in.hosts.expected_duration_ns[fh0 + i], q.in.hosts.duration_stddev_ns[fh0 + i]);
+      }
+      nfree += (f & EVG_HF_FREE) ? 1u : 0u;
+      stage_host(hs, q, fh0, i, f, key, host_term(ap.future_host_fraction, T, hl), c.tg_lo, c.ntg);
+    }
+    __syncthreads();
+    allocate_distro<kBlock>(q, d, ap, fh0, fnh, c.tg_lo, c.ntg, T, len_met, nfree, hs, s_i);
+    EVG_STAMP(12);
+  }
   return true;
 }
 
@@ -927,19 +991,32 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const Pla
   if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
   __syncthreads();
   EVG_STAMP(0);
-  const bool done = fits_lds_path(c) && plan_distro_lds<RICH>(a, c, smem, s_red);
+  const AllocArgs none{};
+  const bool done = fits_lds_path(c) && plan_distro_lds<RICH, false>(a, none, c, smem, s_red);
   if (threadIdx.x == 0) a.w_generic[d] = done ? 0 : 1;
 }
 
-// One workgroup per distro the LDS path left over (none in the headline configuration): every intermediate lives
-// in the global scratch area.
-__global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a) {
+// The batched tick in one launch: plan every distro AND run its host allocator (evg_plan_allocate_device).
+struct FusedArgs {
+  PlanArgs p;
+  AllocArgs q;  // q.in.distro_info / q.in.group_info alias p.out.distro_info / p.out.group_info
+};
+template <bool RICH>
+__global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const FusedArgs f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
   const int d = blockIdx.x;
-  if (!a.w_generic[d]) return;
-  const DC c = distro_context(a, d);
+  const DC c = distro_context(f.p, d);
   if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
   __syncthreads();
+  const PlanArgs& a = f.p;
+  EVG_STAMP(0);
+  const bool done = fits_lds_path(c) && plan_distro_lds<RICH, true>(f.p, f.q, c, smem, s_red);
+  if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
+}
+
+__device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c, unsigned* s_red) {
+  const int d = c.d;
   const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // disjoint slot range of this distro
   Mem<false> m;
   m.tiq = a.w_tiq + sb; m.dur = a.w_dur + sb; m.maxpri = a.w_maxpri + sb; m.val = a.w_val + sb;
@@ -953,6 +1030,62 @@ __global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a) {
   m.g_dur = a.g_dur; m.g_dover = a.g_dover;
   m.g0 = d; m.gk = c.D + c.tg_lo;
   plan_distro<false>(a, c, m, s_red);
+}
+
+// One workgroup per distro the LDS path left over (none in the headline configuration): every intermediate lives
+// in the global scratch area.
+// Launched with a FIXED small grid (kGenericGrid workgroups striding over the distros): when no distro is flagged --
+// the normal case -- the launch costs a quarter of a one-workgroup-per-distro grid.
+constexpr int kGenericGrid = 128;
+__global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
+  for (int d = blockIdx.x; d < a.in.n_distros; d += gridDim.x) {
+    if (!a.w_generic[d]) continue;
+    const DC c = distro_context(a, d);
+    __syncthreads();
+    if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
+    __syncthreads();
+    plan_generic_body(a, c, s_red);
+  }
+}
+
+// The same for the fused entry point: plan, then allocate hosts, for the distros the fused LDS kernel left over.
+__global__ void __launch_bounds__(kBlock) k_plan_allocate_generic(const FusedArgs f) {
+  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
+  __shared__ HostRec s_rec[kAllocLdsHosts];
+  __shared__ int s_cnt[2 * kAllocLdsBuckets];
+  const int tid = threadIdx.x;
+  for (int d = blockIdx.x; d < f.p.in.n_distros; d += gridDim.x) {
+  if (!f.p.w_generic[d]) continue;
+  const DC c = distro_context(f.p, d);
+  __syncthreads();
+  if (tid < 32) s_red[tid] = 0;
+  __syncthreads();
+  plan_generic_body(f.p, c, s_red);
+  __syncthreads();  // the distro's info rows are in global memory, written by this workgroup
+  const AllocArgs& a = f.q;
+  const evg_alloc_params p = a.in.params[d];
+  const evg_host_soa& h = a.in.hosts;
+  const int h0 = a.in.host_off[d], nh = a.in.host_off[d + 1] - h0;
+  const int64_t T = a.in.distro_info[d].max_duration_threshold_ns;
+  const int len_met = a.in.distro_info[d].length_with_dependencies_met;
+  int* s_i = (int*)s_red;
+  if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
+  HostStage hs{s_rec, s_cnt, s_cnt + kAllocLdsBuckets, nh <= kAllocLdsHosts && c.ntg + 1 <= kAllocLdsBuckets};
+  if (hs.staged)
+    for (int b = tid; b < c.ntg + 1; b += kBlock) { hs.n_hosts[b] = 0; hs.n_free[b] = 0; }
+  __syncthreads();
+  uint32_t nfree = 0;
+  for (int i = tid; i < nh; i += kBlock) {
+    const uint32_t fl = h.flags[h0 + i];
+    nfree += (fl & EVG_HF_FREE) ? 1u : 0u;
+    const double term = host_term(p.future_host_fraction, T, host_left(a.in.now_ns, fl, h.start_ts_ns[h0 + i], h.expected_duration_ns[h0 + i],
+                                                                       h.duration_stddev_ns[h0 + i]));
+    stage_host(hs, a, h0, i, fl, hs.staged ? h.tg_key[h0 + i] : 0, term, c.tg_lo, c.ntg);
+  }
+  __syncthreads();
+  allocate_distro<kBlock>(a, d, p, h0, nh, c.tg_lo, c.ntg, T, len_met, nfree, hs, s_i);
+  }
 }
 
 }  // namespace evg

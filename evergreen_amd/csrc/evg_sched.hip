@@ -15,39 +15,18 @@
 #include <string>
 #include <vector>
 
+#include "evg_alloc.hip.h"
 #include "evg_plan_lds.hip.h"
 
 namespace evg {
 
-// ---- UtilizationBasedHostAllocator: one 256-thread workgroup per distro -------------------------------------
-// (scheduler/utilization_based_host_allocator.go:26-384). Buckets of groupByTaskGroup (:208-245): bucket 0 is
-// "" and bucket 1+k is task group k of the distro. The fp64 sum of getSoonToBeFreeHosts (:373-376) is taken in
-// host order, one lane per bucket, so that it is reproducible.
-constexpr int kAllocBlock = 256;
-constexpr int kAllocLdsHosts = 2048;  // hosts of one distro staged in LDS (more: the bucket loop reads global memory)
-
-struct AllocArgs {
-  evg_alloc_input in;
-  evg_alloc_output out;
-  double* w_term;  // [n_hosts] fractional-free term of each running host
-  int32_t *w_new, *w_free, *w_err;  // [D + n_tg] per-bucket results; w_err: -1 not evaluated, 0 ok, >0 EVG_ALLOC_E_*
-#ifdef EVG_PHASE_TIMING
-  unsigned long long* dbg_ts;
-#endif
-};
-#ifdef EVG_PHASE_TIMING
-#define ALLOC_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0 && a.dbg_ts) a.dbg_ts[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define ALLOC_STAMP(k) do {} while (0)
-#endif
-
+// Standalone UtilizationBasedHostAllocator: one 256-thread workgroup per distro (what the reference's separate
+// host-allocator job maps to; the batched tick uses the fused kernel of evg_plan_lds.hip.h instead).
 __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs a) {
   __shared__ int s_i[8];  // 0: #free hosts, 1: sum new, 2: sum free, 4: first failing bucket, 5: its error
-  __shared__ double s_term[kAllocLdsHosts];
-  __shared__ int32_t s_key[kAllocLdsHosts];
-  __shared__ uint8_t s_flag[kAllocLdsHosts];
-  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int D = a.in.n_distros;
+  __shared__ HostRec s_rec[kAllocLdsHosts];
+  __shared__ int s_cnt[2 * kAllocLdsBuckets];
+  const int d = blockIdx.x, tid = threadIdx.x;
   const evg_alloc_params p = a.in.params[d];
   const evg_host_soa& h = a.in.hosts;
   const int h0 = a.in.host_off[d], nh = a.in.host_off[d + 1] - h0;
@@ -57,151 +36,23 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
   const int64_t now = a.in.now_ns;
   ALLOC_STAMP(0);
   if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
-  __syncthreads();
-
   // free hosts of the distro (:33-37) and every running host's fractional-free term (:340-368); the host columns
   // the bucket loop re-reads are staged in LDS when they fit
-  const bool staged = nh <= kAllocLdsHosts;
+  HostStage hs{s_rec, s_cnt, s_cnt + kAllocLdsBuckets, nh <= kAllocLdsHosts && ntg + 1 <= kAllocLdsBuckets};
+  if (hs.staged)
+    for (int b = tid; b < ntg + 1; b += kAllocBlock) { hs.n_hosts[b] = 0; hs.n_free[b] = 0; }
+  __syncthreads();
   uint32_t nfree = 0;
   for (int i = tid; i < nh; i += kAllocBlock) {
     const uint32_t f = h.flags[h0 + i];
     nfree += (f & EVG_HF_FREE) ? 1u : 0u;
-    double term = 0.0;
-    if ((f & EVG_HF_RUNNING) && (f & EVG_HF_RUNNING_FOUND)) {
-      const int64_t exp = h.expected_duration_ns[h0 + i], sd = h.duration_stddev_ns[h0 + i];
-      const int64_t elapsed = time_sub(now, h.start_ts_ns[h0 + i]);
-      const int64_t left = wrap_sub(exp, elapsed);
-      double frac;
-      if (elapsed > kMaxDurationPerDistroHost && sd > 0 && elapsed > wrap_add(exp, wrap_mul(3, sd))) frac = 0;
-      else frac = (double)wrap_sub(T, left) / (double)T;
-      if (frac < 0) frac = 0;
-      if (frac > 1) frac = 1;
-      term = p.future_host_fraction * frac;
-    }
-    if (staged) { s_term[i] = term; s_key[i] = h.tg_key[h0 + i]; s_flag[i] = (uint8_t)f; }
-    else a.w_term[h0 + i] = term;
+    const double term = host_term(p.future_host_fraction, T, host_left(now, f, h.start_ts_ns[h0 + i], h.expected_duration_ns[h0 + i],
+                                                                       h.duration_stddev_ns[h0 + i]));
+    stage_host(hs, a, h0, i, f, hs.staged ? h.tg_key[h0 + i] : 0, term, tg_lo, ntg);
   }
+  __syncthreads();
   ALLOC_STAMP(1);
-  nfree = wave_sum(nfree);
-  if (lane == 0 && nfree) atomicAdd(&s_i[0], (int)nfree);
-  __syncthreads();
-  const int n_free_hosts = s_i[0];
-
-  // early outs (:39-67)
-  if (p.provider != 2 && nh >= p.maximum_hosts) {
-    if (tid == 0) { a.out.new_hosts[d] = 0; a.out.free_hosts[d] = n_free_hosts; a.out.status[d] = EVG_ALLOC_OK; }
-    return;
-  }
-  if (p.disabled) {
-    if (tid == 0) {
-      const int want = p.minimum_hosts - nh;
-      a.out.new_hosts[d] = want > 0 ? want : 0; a.out.free_hosts[d] = n_free_hosts; a.out.status[d] = EVG_ALLOC_OK;
-    }
-    return;
-  }
-
-  ALLOC_STAMP(2);
-  // per bucket: evalHostUtilization (:134-205)
-  const bool ephemeral = p.provider != 0;
-  for (int b = tid; b < ntg + 1; b += kAllocBlock) {
-    const int row = b == 0 ? d : D + tg_lo + (b - 1);
-    const evg_group_info gi = a.in.group_info[row];
-    const int want_key = b == 0 ? -1 : tg_lo + (b - 1);
-    int n_hosts_b = 0, n_free_b = 0;
-    double soon = 0.0;
-    if (staged) {
-      // host order is the canonical order of the fp64 sum. Branch-free: a host of another bucket adds +0.0, which
-      // leaves a non-negative partial sum unchanged bit for bit; 4 independent LDS reads per trip.
-      auto take = [&](int i) {
-        const bool in = s_key[i] == want_key;
-        const uint32_t f = s_flag[i];
-        n_hosts_b += in ? 1 : 0;
-        n_free_b += in && (f & EVG_HF_FREE) ? 1 : 0;
-        soon += in ? s_term[i] : 0.0;  // s_term is 0.0 unless the host runs a found task
-      };
-      int i = 0;
-      for (; i + 4 <= nh; i += 4) { take(i); take(i + 1); take(i + 2); take(i + 3); }
-      for (; i < nh; i++) take(i);
-    } else {
-      for (int i = 0; i < nh; i++) {
-        if (h.tg_key[h0 + i] != want_key) continue;
-        n_hosts_b++;
-        const uint32_t f = h.flags[h0 + i];
-        n_free_b += (f & EVG_HF_FREE) ? 1 : 0;
-        if ((f & EVG_HF_RUNNING) && (f & EVG_HF_RUNNING_FOUND)) soon += a.w_term[h0 + i];
-      }
-    }
-    const bool present = gi.present != 0;
-    // "" is evaluated when it exists in taskGroupDatas (hosts or an info row); a named group is skipped when
-    // no task of it is queued (:84-86), which also covers groups that only hosts know about
-    const bool eval = b == 0 ? (n_hosts_b > 0 || present) : (present && gi.count != 0);
-    int n_new = 0, n_free = 0, err = -1;
-    if (eval) {
-      err = 0;
-      const int max_hosts = b == 0 ? p.maximum_hosts : gi.max_hosts;
-      if (ephemeral) {
-        if (p.future_host_fraction > 1) {
-          err = EVG_ALLOC_E_FUTURE_FRACTION;  // calcExistingFreeHosts :287-289
-        } else {
-          const int count = present ? gi.count : 0;
-          const int64_t exp_dur = present ? gi.expected_duration_ns : 0;
-          const int64_t over_dur = present ? gi.duration_over_threshold_ns : 0;
-          const int n_long = present ? gi.count_duration_over_threshold : 0;
-          const int n_overdue = (present && p.feedback_waits_over_thresh) ? gi.count_wait_over_threshold : 0;
-          const int n_mq = present ? gi.count_dep_filled_merge_queue_tasks : 0;
-          const int exp_free = n_free_b + (int)floor(soon);
-          // calcNewHostsNeeded :253-281
-          const double turn = (double)wrap_sub(exp_dur, over_dur) / (double)T;
-          const double need = turn - (double)exp_free + (double)n_long + (double)n_overdue + (double)n_mq;
-          int nn;
-          if (exp_free < 1 && need > 0 && need < 1) {
-            nn = 1;
-          } else {
-            nn = p.round_up ? (int)ceil(need) : (int)floor(need);
-            if (nn < 0) nn = 0;
-          }
-          n_new = nn < count ? nn : count;
-          if (n_new + n_hosts_b > max_hosts) n_new = max_hosts - n_hosts_b;  // isMaxHostsCapacity :382-384
-          if (n_new < 0) n_new = 0;
-          n_free = exp_free;
-          if (max_hosts < 1) { err = EVG_ALLOC_E_POOL_SIZE; n_new = 0; n_free = 0; }  // :185-187
-        }
-      }
-      if (err > 0) atomicMin(&s_i[4], b);
-    }
-    a.w_new[row] = n_new; a.w_free[row] = n_free; a.w_err[row] = err;
-  }
-  __syncthreads();
-  ALLOC_STAMP(3);
-  // Canonical map order: "" first, then groups by key. The reference returns at the first failing group (:99-101);
-  // groups visited before it already had CountFree/CountRequired written (:106-109).
-  const int first_err = s_i[4];
-  int t_new = 0, t_free = 0;
-  for (int b = tid; b < ntg + 1; b += kAllocBlock) {
-    const int row = b == 0 ? d : D + tg_lo + (b - 1);
-    const int err = a.w_err[row];
-    if (b == first_err) s_i[5] = err;
-    if (err != 0 || b > first_err) continue;
-    t_new += a.w_new[row];
-    t_free += a.w_free[row];
-    if (b != 0) { a.in.group_info[row].count_free = a.w_free[row]; a.in.group_info[row].count_required = a.w_new[row]; }
-  }
-  ALLOC_STAMP(4);
-  if (t_new) atomicAdd(&s_i[1], t_new);
-  if (t_free) atomicAdd(&s_i[2], t_free);
-  __syncthreads();
-  if (tid == 0) {
-    if (first_err != 0x7FFFFFFF) {
-      a.out.new_hosts[d] = 0; a.out.free_hosts[d] = n_free_hosts; a.out.status[d] = s_i[5];
-    } else {
-      int required = s_i[1];
-      if (required + n_free_hosts > len_met) required = len_met - n_free_hosts;  // :113-115
-      if (required < 0) required = 0;
-      int add_min = 0;
-      if (nh + required < p.minimum_hosts) add_min = p.minimum_hosts - (nh + required);  // :121-126
-      a.out.new_hosts[d] = required + add_min; a.out.free_hosts[d] = s_i[2]; a.out.status[d] = EVG_ALLOC_OK;
-    }
-  }
+  allocate_distro<kAllocBlock>(a, d, p, h0, nh, tg_lo, ntg, T, len_met, nfree, hs, s_i);
   ALLOC_STAMP(5);
 }
 
@@ -400,7 +251,8 @@ int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len
   return EVG_OK;
 }
 
-static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, hipStream_t st) {
+// Fills the kernel argument block of the planner (scratch of the generic path included).
+static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, evg::PlanArgs* pa) {
   using namespace evg;
   if (!c || !in || !out) return EVG_E_INVALID;
   const int D = in->n_distros;
@@ -412,7 +264,7 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   const size_t N = (size_t)in->tasks.n_tasks;
   const size_t Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions + 1;
   const size_t G = (size_t)D + (size_t)in->n_task_groups;
-  PlanArgs a;
+  PlanArgs& a = *pa;
   a.in = *in;
   a.out = *out;
   // scratch of the large-distro path (untouched pages cost nothing; small distros never use it)
@@ -438,31 +290,20 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   if (!c->lds_attr_set) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
     c->lds_attr_set = true;
   }
-  // the optional outputs need 34 KiB more LDS per workgroup (one workgroup per CU instead of two)
-  if (out->breakdown || out->n_units) hipLaunchKernelGGL(k_plan_distros<true>, dim3(D), dim3(kBlock), kLdsRich, st, a);
-  else hipLaunchKernelGGL(k_plan_distros<false>, dim3(D), dim3(kBlock), kLdsLean, st, a);
-  HIP_TRY(c, hipGetLastError());
-  // distros the LDS path could not take (flagged on the device); its workgroups exit at once otherwise
-  hipLaunchKernelGGL(k_plan_generic, dim3(D), dim3(kBlock), 0, st, a);
-  HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }
 
-int evg_plan_distros_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, void* hip_stream) {
-  if (!c) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
-  return launch_plan(c, in, out, (hipStream_t)hip_stream);
-}
-
-static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, hipStream_t st) {
+static int prepare_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, evg::AllocArgs* qa) {
   using namespace evg;
   if (!c || !in || !out) return EVG_E_INVALID;
   if (in->n_distros < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
   if (in->n_distros == 0) return EVG_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  AllocArgs a;
+  AllocArgs& a = *qa;
   a.in = *in;
   a.out = *out;
   const size_t G = (size_t)in->n_distros + (size_t)in->n_task_groups;
@@ -476,6 +317,36 @@ static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_o
 #ifdef EVG_PHASE_TIMING
   a.dbg_ts = c->dbg_ts_alloc;
 #endif
+  return EVG_OK;
+}
+
+static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, hipStream_t st) {
+  using namespace evg;
+  PlanArgs a;
+  int rc = prepare_plan(c, in, out, &a);
+  if (rc || in->n_distros == 0) return rc;
+  const int D = in->n_distros;
+  // the optional outputs need 36 KiB more LDS per workgroup (one workgroup per CU instead of two)
+  if (out->breakdown || out->n_units) hipLaunchKernelGGL(k_plan_distros<true>, dim3(D), dim3(kBlock), kLdsRich, st, a);
+  else hipLaunchKernelGGL(k_plan_distros<false>, dim3(D), dim3(kBlock), kLdsLean, st, a);
+  HIP_TRY(c, hipGetLastError());
+  // distros the LDS path could not take (flagged on the device); its workgroups exit at once otherwise
+  hipLaunchKernelGGL(k_plan_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), 0, st, a);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
+int evg_plan_distros_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, void* hip_stream) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return launch_plan(c, in, out, (hipStream_t)hip_stream);
+}
+
+static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, hipStream_t st) {
+  using namespace evg;
+  AllocArgs a;
+  int rc = prepare_alloc(c, in, out, &a);
+  if (rc || in->n_distros == 0) return rc;
   hipLaunchKernelGGL(k_allocate_hosts, dim3(in->n_distros), dim3(kAllocBlock), 0, st, a);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
@@ -485,6 +356,33 @@ int evg_allocate_hosts_device(evg_ctx* c, const evg_alloc_input* in, const evg_a
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return launch_alloc(c, in, out, (hipStream_t)hip_stream);
+}
+
+int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const evg_alloc_input* ain,
+                             const evg_alloc_output* aout, void* hip_stream) {
+  using namespace evg;
+  if (!c || !in || !out || !ain || !aout) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (ain->n_distros != in->n_distros || ain->n_task_groups != in->n_task_groups)
+    return set_err(c, EVG_E_INVALID, "plan and allocator inputs describe different batches");
+  FusedArgs f;
+  int rc = prepare_plan(c, in, out, &f.p);
+  if (rc || in->n_distros == 0) return rc;
+  evg_alloc_input ai = *ain;
+  ai.distro_info = out->distro_info;  // the allocator consumes what the planner of the same launch produced
+  ai.group_info = out->group_info;
+  ai.tg_off = in->tg_off;
+  ai.now_ns = in->now_ns;
+  rc = prepare_alloc(c, &ai, aout, &f.q);
+  if (rc) return rc;
+  const int D = in->n_distros;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (out->breakdown || out->n_units) hipLaunchKernelGGL(k_plan_allocate<true>, dim3(D), dim3(kBlock), kLdsRich, st, f);
+  else hipLaunchKernelGGL(k_plan_allocate<false>, dim3(D), dim3(kBlock), kLdsLean, st, f);
+  HIP_TRY(c, hipGetLastError());
+  hipLaunchKernelGGL(k_plan_allocate_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), 0, st, f);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
 }
 
 int evg_cap_queue_device(evg_ctx* c, int32_t n_distros, const int32_t* task_off, const int32_t* order,

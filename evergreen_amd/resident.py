@@ -48,9 +48,13 @@ class ResidentPool:
     def allocate(self, stream: Optional[int] = None) -> None:
         self.ctx.allocate_device(self.ainp, self.aout, self.stream() if stream is None else stream)
 
-    def step(self, stream: Optional[int] = None) -> None:
-        """One pass of the hot path over the resident pool: plan + queue info [+ host allocation]."""
+    def step(self, stream: Optional[int] = None, fused: bool = True) -> None:
+        """One pass of the hot path over the resident pool: plan + queue info [+ host allocation]. `fused` uses the
+        single-launch entry point (evg_plan_allocate_device); otherwise the two separate calls."""
         s = self.stream() if stream is None else stream
+        if self.has_hosts and fused:
+            self.ctx.plan_allocate_device(self.inp, self.out, self.ainp, self.aout, s)
+            return
         self.ctx.plan_device(self.inp, self.out, s)
         if self.has_hosts:
             self.ctx.allocate_device(self.ainp, self.aout, s)

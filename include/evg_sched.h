@@ -313,6 +313,16 @@ int evg_allocate_hosts(evg_ctx* ctx, const evg_alloc_input* in, const evg_alloc_
 int evg_allocate_hosts_device(evg_ctx* ctx, const evg_alloc_input* in, const evg_alloc_output* out,
                               void* hip_stream);
 
+/* The batched tick in one launch: evg_plan_distros_device followed by evg_allocate_hosts_device for the same batch,
+ * fused -- every distro's planning workgroup finishes with that distro's UtilizationBasedHostAllocator pass, so the
+ * queue info never round-trips through a second kernel and the host rows are fetched behind the planner's compute.
+ * `ain->distro_info`, `ain->group_info`, `ain->tg_off` and `ain->now_ns` are ignored: the allocator consumes
+ * out->distro_info / out->group_info of this very call (what units/host_allocator.go:144 reads back from the
+ * task_queues document the planner persisted) and writes count_free / count_required into out->group_info.
+ * Results are identical to the two separate calls. Device pointers; enqueued on hip_stream. */
+int evg_plan_allocate_device(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out,
+                             const evg_alloc_input* ain, const evg_alloc_output* aout, void* hip_stream);
+
 /* capTaskQueueLength (scheduler/task_queue_persister.go:66-83) for all D distros: cut[d] = number of
  * leading queue positions of distro d to persist for limit max_scheduled (<= 0 disables). The
  * straddling test uses Task.TaskGroup (NOT the 4-part group string): tg_name_key is an interning of

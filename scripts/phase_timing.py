@@ -39,9 +39,23 @@ def main():
     ts = torch.zeros(batch.n_distros * 16, dtype=torch.int64, device=dev)
     lib.evg_dbg_phase_buffer(ctx.h, ts.data_ptr())
     pool = resident.ResidentPool(ctx, batch, dev, breakdown=False, n_units=False)
+    fused = os.environ.get("FUSED", "0") == "1" and pool.has_hosts
+    ts2 = torch.zeros(batch.n_distros * 16, dtype=torch.int64, device=dev)
+    lib.evg_dbg_alloc_phase_buffer.argtypes = [C.c_void_p, C.c_void_p]
+    lib.evg_dbg_alloc_phase_buffer(ctx.h, ts2.data_ptr())
     for _ in range(5):
-        pool.plan()
+        pool.step(fused=True) if fused else pool.plan()
     torch.cuda.synchronize()
+    if fused:
+        tt = ts.cpu().numpy().reshape(-1, 16)
+        okf = tt[:, 12] > 0
+        print("fused tail H (allocator) mean %.1f max %.1f cycles over %d distros" % (
+            (tt[okf, 12] - tt[okf, 11]).mean(), (tt[okf, 12] - tt[okf, 11]).max(), int(okf.sum())))
+        t2 = ts2.cpu().numpy().reshape(-1, 16)
+        ok2 = okf & (t2[:, 7] > 0) & (t2[:, 2] > 0)
+        print("  tail: staging (plan stamp 11 -> alloc entry) %.1f | nfree+early outs %.1f | bucket loop %.1f | write back %.1f | final %.1f" % (
+            (t2[ok2, 6] - tt[ok2, 11]).mean(), (t2[ok2, 2] - t2[ok2, 6]).mean(), (t2[ok2, 3] - t2[ok2, 2]).mean(),
+            (t2[ok2, 4] - t2[ok2, 3]).mean(), (t2[ok2, 7] - t2[ok2, 4]).mean()))
     t = ts.cpu().numpy().reshape(-1, 16)[:, :12]
     dt = np.diff(t, axis=1).astype(np.float64)
     tot = (t[:, 11] - t[:, 0]).astype(np.float64)
@@ -51,10 +65,7 @@ def main():
         print("  %-18s mean %8.1f  p50 %8.1f  max %8.1f   %5.1f%%" % (nm, dt[:, k].mean(), np.median(dt[:, k]), dt[:, k].max(),
                                                                       100 * dt[:, k].mean() / tot.mean()))
     print("  %-18s mean %8.1f  p50 %8.1f  max %8.1f" % ("WG total", tot.mean(), np.median(tot), tot.max()))
-    if pool.has_hosts:
-        ts2 = torch.zeros(batch.n_distros * 16, dtype=torch.int64, device=dev)
-        lib.evg_dbg_alloc_phase_buffer.argtypes = [C.c_void_p, C.c_void_p]
-        lib.evg_dbg_alloc_phase_buffer(ctx.h, ts2.data_ptr())
+    if pool.has_hosts and not fused:
         for _ in range(3):
             pool.allocate()
         torch.cuda.synchronize()

@@ -186,3 +186,31 @@ def test_contract_violation_is_rejected(native_ctx):
     with pytest.raises(Exception) as e:
         native_ctx.plan(b)
     assert "first-appearance" in str(e.value) or "tg_key" in str(e.value)
+
+
+@pytest.mark.parametrize("make", [lambda: gen.generate(gen.config(2)),
+                                  lambda: gen.generate(gen.GenConfig(60_000, 24, gen.SEED_BASE + 31, skew=True)),
+                                  lambda: gen.generate(gen.GenConfig(3_000, 40, 321))], ids=["config2", "skewed-generic", "small"])
+@pytest.mark.parametrize("rich", [False, True], ids=["lean", "rich"])
+def test_fused_plan_allocate_entry_point(native_ctx, oracle, make, rich):
+    """evg_plan_allocate_device (one launch: planner + host allocator per distro) == the two separate calls == oracle."""
+    import torch
+    from evergreen_amd import resident
+    b = make()
+    pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=rich, n_units=rich)
+    pool.step(fused=True)
+    got, got_alloc = pool.plan_result(), pool.alloc_result()
+    want = oracle.plan(b)
+    want_alloc = oracle.allocate(b, want.distro_info, want.group_info)
+    if not rich:
+        want.breakdown, want.n_units = None, None
+    compare.assert_plan_equal(got, want, b, "fused")
+    compare.assert_alloc_equal(got_alloc, want_alloc, "fused")
+    for name in ("count_free", "count_required"):
+        assert np.array_equal(got.group_info[name], want.group_info[name]), name
+    # and the unfused pair of calls on the same pool gives the same bytes
+    pool2 = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=rich, n_units=rich)
+    pool2.step(fused=False)
+    g2, a2 = pool2.plan_result(), pool2.alloc_result()
+    assert np.array_equal(g2.order, got.order) and np.array_equal(g2.group_info, got.group_info)
+    assert np.array_equal(a2.new_hosts, got_alloc.new_hosts) and np.array_equal(a2.free_hosts, got_alloc.free_hosts)
