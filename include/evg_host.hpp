@@ -1,0 +1,545 @@
+// evg_host.hpp -- host side of the drop-in boundary, in C++17.
+//
+// The reference is Go and there is no Go toolchain in this image, so the compiled host layer that sits between the
+// reference's scheduler interface and the C ABI (include/evg_sched.h) is written in C++: same names, argument meaning
+// and error behaviour as the Go code it stands in for, so that tests/cpp/test_host_shim.cpp reads like
+// scheduler/planner_test.go and scheduler/utilization_based_host_allocator_test.go. The cgo version a maintainer of
+// evergreen would add is in INTEGRATION.md; evergreen_amd/scheduler.py is the same layer in Python.
+//
+//   evergreen::PrioritizeTasks(backend, d, tasks, opts, now)          scheduler/scheduler.go:28-52
+//   evergreen::TaskPlanner / evergreen::HostAllocator                 scheduler/scheduler.go:26, host_allocator.go:15
+//   evergreen::UtilizationBasedHostAllocator(backend, data, now, ..)  scheduler/utilization_based_host_allocator.go:26
+//   evergreen::GetHostAllocator(name)                                 scheduler/host_allocator.go:23-30
+//   evergreen::capTaskQueueLength(tasks, max)                         scheduler/task_queue_persister.go:66-83
+//
+// What this layer does itself is only what the boundary assigns to the host (SURVEY.md 8b'): resolve expected durations
+// (PopulateCaches' no-DB branches), intern strings into dense keys, pack struct-of-arrays columns, call the backend
+// through the C ABI, re-order and stamp the caller's task values. Every number on the path comes from the backend:
+// the HIP library (HipBackend: dlopen of libevg_sched.so, no CPU fallback) in production.
+//
+// Times are int64 Unix nanoseconds; kGoZeroTime (== EVG_TIME_GO_ZERO) is Go's zero time.Time.
+#pragma once
+
+#include <dlfcn.h>
+
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "evg_sched.h"
+
+namespace evergreen {
+
+using Time = int64_t;
+using Duration = int64_t;
+constexpr Time kGoZeroTime = EVG_TIME_GO_ZERO;
+constexpr Duration Second = 1000000000LL, Minute = 60 * Second, Hour = 60 * Minute;
+constexpr Duration MaxDurationPerDistroHost = 30 * Minute;  // globals.go:273
+constexpr Duration defaultTaskDuration = 10 * Minute;       // model/task/task.go:65
+
+// globals.go constants the host side needs
+inline const std::string PatchVersionRequester = "patch_request", GithubPRRequester = "github_pull_request",
+                         RepotrackerVersionRequester = "gitter_request", GithubMergeRequester = "github_merge_request",
+                         StepbackTaskActivator = "stepback", TaskSucceeded = "success", TaskFailed = "failed",
+                         TaskUndispatched = "undispatched", AllStatuses = "*", ProjectStorageMethodS3 = "s3",
+                         ProviderNameEc2Fleet = "ec2-fleet", ProviderNameMock = "mock", ProviderNameDocker = "docker",
+                         ProviderNameStatic = "static", HostAllocatorRoundUp = "round-up",
+                         HostAllocatorWaitsOverThreshFeedback = "waits-over-thresh-feedback",
+                         DispatcherVersionRevisedWithDependencies = "revised-with-dependencies";
+
+inline bool IsZeroTime(Time t) { return t == kGoZeroTime || t == 0; }  // utility.IsZeroTime: Go zero or the Unix epoch
+
+struct Dependency {  // model/task/task.go:442-451
+  std::string TaskId, Status;
+  bool Unattainable = false;
+  Time FinishedAt = kGoZeroTime;
+};
+struct CachedDurationValue {  // util/cached_value.go:88-94
+  Duration Value = 0, StdDev = 0, TTL = 0;
+  Time CollectedAt = kGoZeroTime;
+};
+struct SortingValueBreakdown {  // model/task/task.go:4060-4108; field order == enum evg_breakdown_field
+  int64_t TaskGroupLength = 0, TotalValue = 0;
+  struct { int64_t InitialPriorityImpact = 0, TaskGroupImpact = 0, GeneratorTaskImpact = 0, CommitQueueImpact = 0; } PriorityBreakdown;
+  struct {
+    int64_t CommitQueueImpact = 0, NumDependentsImpact = 0, EstimatedRuntimeImpact = 0, MainlineWaitTimeImpact = 0,
+            StepbackImpact = 0, PatchImpact = 0, PatchWaitTimeImpact = 0;
+  } RankValueBreakdown;
+};
+struct Task {  // the model/task/task.go:96-369 fields the path reads
+  std::string Id, DistroId, Version, TaskGroup, BuildVariant, Project, Requester, ActivatedBy, Status, CachedProjectStorageMethod;
+  int TaskGroupOrder = 0, TaskGroupMaxHosts = 0, NumDependents = 0;
+  int64_t Priority = 0;
+  bool GenerateTask = false, OverrideDependencies = false;
+  Time ActivatedTime = kGoZeroTime, IngestTime = kGoZeroTime, ScheduledTime = kGoZeroTime, DependenciesMetTime = kGoZeroTime,
+       StartTime = kGoZeroTime;
+  std::vector<Dependency> DependsOn;
+  Duration ExpectedDuration = 0, ExpectedDurationStdDev = 0;
+  CachedDurationValue DurationPrediction;
+  // written by the planner
+  evergreen::SortingValueBreakdown SortingValueBreakdown;
+  Duration WaitSinceDependenciesMet = 0;
+
+  std::string GetTaskGroupString() const { return TaskGroup + "_" + BuildVariant + "_" + Project + "_" + Version; }  // task.go:436-438
+  bool Blocked() const {                                                                                          // task.go:3688-3699
+    if (OverrideDependencies) return false;
+    for (const auto& d : DependsOn)
+      if (d.Unattainable) return true;
+    return false;
+  }
+  bool HasDependenciesMet() const { return DependsOn.empty() || OverrideDependencies || !IsZeroTime(DependenciesMetTime); }  // :3406
+};
+
+// Task.FetchExpectedDuration (task.go:3532-3629) without the history DB: (average, stddev).
+inline std::pair<Duration, Duration> FetchExpectedDuration(const Task& t, Time now) {
+  const auto& p = t.DurationPrediction;
+  if (p.Value == 0 && t.ExpectedDuration != 0) return {t.ExpectedDuration, t.ExpectedDurationStdDev};
+  int64_t since;
+  if (__builtin_sub_overflow(now, p.CollectedAt, &since)) since = INT64_MAX;
+  const Duration ttl = p.TTL != 0 ? p.TTL : 8 * Hour;
+  if (since < ttl) return {p.Value, p.StdDev};  // CachedDurationValue.Get cached_value.go:125-129
+  if (p.Value == 0) return {defaultTaskDuration, 0};
+  return {p.Value, p.StdDev};
+}
+
+struct PlannerSettings {  // model/distro/distro.go:310-326 (RAW values; the library applies the getters)
+  Duration TargetTime = 0, MergeQueueTargetTime = 0;
+  bool GroupVersions = false;
+  int64_t PatchFactor = 0, PatchTimeInQueueFactor = 0, CommitQueueFactor = 0, MainlineTimeInQueueFactor = 0,
+          ExpectedRuntimeFactor = 0, GenerateTaskFactor = 0, StepbackTaskFactor = 0;
+  double NumDependentsFactor = 0;
+  bool ShouldGroupVersions() const { return GroupVersions; }
+};
+struct HostAllocatorSettings {  // model/distro/distro.go:291-304
+  int MinimumHosts = 0, MaximumHosts = 0;
+  std::string RoundingRule, FeedbackRule;
+  double FutureHostFraction = 0;
+};
+struct Distro {
+  std::string Id, Provider;
+  bool Disabled = false;
+  evergreen::PlannerSettings PlannerSettings;
+  evergreen::HostAllocatorSettings HostAllocatorSettings;
+  struct { std::string Version; } DispatcherSettings;
+  bool IsEphemeral() const { return Provider == ProviderNameEc2Fleet || Provider == ProviderNameMock || Provider == ProviderNameDocker; }  // distro.go:513
+};
+struct Host {  // the model/host/host.go fields the allocator reads
+  std::string Id, RunningTask, RunningTaskGroup, RunningTaskBuildVariant, RunningTaskProject, RunningTaskVersion;
+  Time TaskGroupTeardownStartTime = kGoZeroTime;
+  bool IsTearingDown() const { return TaskGroupTeardownStartTime != kGoZeroTime; }  // host.go:220-222
+  bool IsFree() const { return RunningTask.empty() && !IsTearingDown(); }           // host.go:215-217
+  std::string GetTaskGroupString() const {                                          // host.go:668-670
+    return RunningTaskGroup + "_" + RunningTaskBuildVariant + "_" + RunningTaskProject + "_" + RunningTaskVersion;
+  }
+};
+struct TaskGroupInfo {  // model/task_queue.go:22-45
+  std::string Name;
+  int Count = 0, CountFree = 0, CountRequired = 0, MaxHosts = 0;
+  Duration ExpectedDuration = 0;
+  int CountDurationOverThreshold = 0, CountWaitOverThreshold = 0, CountDepFilledMergeQueueTasks = 0;
+  Duration DurationOverThreshold = 0;
+};
+struct DistroQueueInfo {  // model/task_queue.go:47-78
+  int Length = 0, LengthWithDependenciesMet = 0, CountDepFilledMergeQueueTasks = 0;
+  Duration ExpectedDuration = 0, MaxDurationThreshold = 0;
+  Time PlanCreatedAt = kGoZeroTime;
+  int CountDurationOverThreshold = 0;
+  Duration DurationOverThreshold = 0;
+  int CountWaitOverThreshold = 0, NumQueuedLargeParserProjectTasks = 0;
+  std::vector<TaskGroupInfo> TaskGroupInfos;
+  bool SecondaryQueue = false;
+};
+struct TaskPlannerOptions {  // scheduler/scheduler.go:18-24
+  std::string ID;
+  bool IsSecondaryQueue = false, IncludesDependencies = false;
+  Time StartedAt = kGoZeroTime;
+  int MaxScheduledTasksPerDistro = 0;
+};
+struct HostAllocatorData {  // scheduler/host_allocator.go:17-21
+  evergreen::Distro Distro;
+  std::vector<Host> ExistingHosts;
+  evergreen::DistroQueueInfo DistroQueueInfo;
+};
+
+// ---- the backend: the two batched calls of the C ABI -----------------------------------------------------
+struct Backend {
+  std::function<int(const evg_plan_input*, const evg_plan_output*)> plan;
+  std::function<int(const evg_alloc_input*, const evg_alloc_output*)> allocate;
+  std::function<std::string()> last_error;
+  std::shared_ptr<void> keep;  // whatever must outlive the calls (library handle, context)
+};
+
+// The product backend: libevg_sched.so on a gfx950 device. Throws when the library or the device is missing --
+// there is no CPU fallback.
+inline Backend HipBackend(const std::string& lib_path, int device = 0) {
+  void* h = dlopen(lib_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!h) throw std::runtime_error(std::string("cannot load the HIP library: ") + dlerror());
+  auto create = reinterpret_cast<evg_ctx* (*)(int)>(dlsym(h, "evg_create"));
+  auto destroy = reinterpret_cast<void (*)(evg_ctx*)>(dlsym(h, "evg_destroy"));
+  auto lasterr = reinterpret_cast<const char* (*)(const evg_ctx*)>(dlsym(h, "evg_last_error"));
+  auto plan = reinterpret_cast<int (*)(evg_ctx*, const evg_plan_input*, const evg_plan_output*)>(dlsym(h, "evg_plan_distros"));
+  auto alloc = reinterpret_cast<int (*)(evg_ctx*, const evg_alloc_input*, const evg_alloc_output*)>(dlsym(h, "evg_allocate_hosts"));
+  if (!create || !destroy || !lasterr || !plan || !alloc) throw std::runtime_error("libevg_sched.so lacks an entry point of evg_sched.h");
+  evg_ctx* ctx = create(device);
+  if (!ctx) throw std::runtime_error(std::string("evg_create failed: ") + lasterr(nullptr));
+  std::shared_ptr<void> keep(ctx, [destroy](void* p) { destroy(static_cast<evg_ctx*>(p)); });
+  Backend b;
+  b.keep = keep;
+  b.plan = [ctx, plan](const evg_plan_input* in, const evg_plan_output* out) { return plan(ctx, in, out); };
+  b.allocate = [ctx, alloc](const evg_alloc_input* in, const evg_alloc_output* out) { return alloc(ctx, in, out); };
+  b.last_error = [ctx, lasterr]() { return std::string(lasterr(ctx)); };
+  return b;
+}
+
+// ---- packing ------------------------------------------------------------------------------------------------
+namespace detail {
+inline uint32_t req_class(const std::string& r) {
+  if (r == GithubMergeRequester) return EVG_TF_REQ_MERGE;
+  if (r == PatchVersionRequester || r == GithubPRRequester) return EVG_TF_REQ_PATCH;
+  return 0;
+}
+inline uint32_t status_class(const std::string& s) { return s == TaskSucceeded ? 1u : s == TaskFailed ? 2u : 0u; }
+// SatisfiesDependency (task.go:546-561) returns at the FIRST DependsOn entry for that id whose Status it recognises.
+inline uint8_t dep_required(const Task& t, const std::string& id) {
+  for (const auto& d : t.DependsOn) {
+    if (d.TaskId != id) continue;
+    if (d.Status == TaskSucceeded || d.Status.empty()) return 0;
+    if (d.Status == TaskFailed) return 1;
+    if (d.Status == AllStatuses) return 2;
+  }
+  return 3;
+}
+}  // namespace detail
+
+// task id -> (Status, Blocked()) of a dependency that is not in the queue, or nullopt when it is not in the DB
+using DepLookup = std::function<std::optional<std::pair<std::string, bool>>(const std::string&)>;
+using RunningTaskLookup = std::function<const Task*(const std::string&)>;
+
+struct PackedQueues {
+  std::vector<int64_t> priority, expected_duration, queue_ts, scheduled_ts, deps_met_ts, dep_finished;
+  std::vector<int32_t> num_dependents, tg_order, tg_max_hosts, tg_key, version_key, dep_off, dep_idx, task_off, tg_off, ver_off;
+  std::vector<uint16_t> flags;
+  std::vector<uint8_t> dep_info;
+  std::vector<evg_distro_params> distros;
+  std::vector<std::string> tg_names;                              // tg key -> group string
+  std::vector<std::unordered_map<std::string, int32_t>> tg_key_of;  // per distro
+  Time now = 0;
+
+  evg_plan_input input() const {
+    evg_plan_input in{};
+    in.n_distros = (int32_t)distros.size();
+    in.n_task_groups = tg_off.back();
+    in.n_versions = ver_off.back();
+    in.tasks.n_tasks = (int32_t)priority.size();
+    in.tasks.n_edges = (int32_t)dep_idx.size();
+    in.tasks.priority = priority.data(); in.tasks.expected_duration_ns = expected_duration.data();
+    in.tasks.queue_ts_ns = queue_ts.data(); in.tasks.scheduled_ts_ns = scheduled_ts.data();
+    in.tasks.deps_met_ts_ns = deps_met_ts.data(); in.tasks.num_dependents = num_dependents.data();
+    in.tasks.task_group_order = tg_order.data(); in.tasks.task_group_max_hosts = tg_max_hosts.data();
+    in.tasks.tg_key = tg_key.data(); in.tasks.version_key = version_key.data(); in.tasks.flags = flags.data();
+    in.tasks.dep_off = dep_off.data(); in.tasks.dep_idx = dep_idx.data(); in.tasks.dep_info = dep_info.data();
+    in.tasks.dep_finished_ts_ns = dep_finished.data();
+    in.distros = distros.data(); in.task_off = task_off.data(); in.tg_off = tg_off.data(); in.ver_off = ver_off.data();
+    in.now_ns = now;
+    return in;
+  }
+};
+
+// Interns strings and lays the D (distro, tasks) queues out as the ABI's struct-of-arrays: what PopulateCaches
+// (setup_funcs.go:18-67) leaves behind -- resolved durations -- plus the string -> key interning of SURVEY.md 8b'.
+inline PackedQueues pack_queues(const std::vector<std::pair<const Distro*, const std::vector<Task>*>>& queues, Time now,
+                                const DepLookup& lookup = nullptr, const std::vector<bool>* includes_dependencies = nullptr) {
+  PackedQueues p;
+  p.now = now;
+  p.dep_off.push_back(0);
+  int32_t n_tg = 0, n_ver = 0, row = 0;
+  for (size_t di = 0; di < queues.size(); di++) {
+    const Distro& d = *queues[di].first;
+    const std::vector<Task>& tasks = *queues[di].second;
+    p.task_off.push_back(row); p.tg_off.push_back(n_tg); p.ver_off.push_back(n_ver);
+    const auto& ps = d.PlannerSettings;
+    evg_distro_params dp{};
+    dp.patch_factor = ps.PatchFactor; dp.patch_time_in_queue_factor = ps.PatchTimeInQueueFactor;
+    dp.commit_queue_factor = ps.CommitQueueFactor; dp.mainline_time_in_queue_factor = ps.MainlineTimeInQueueFactor;
+    dp.expected_runtime_factor = ps.ExpectedRuntimeFactor; dp.generate_task_factor = ps.GenerateTaskFactor;
+    dp.stepback_task_factor = ps.StepbackTaskFactor; dp.num_dependents_factor = ps.NumDependentsFactor;
+    dp.target_time_ns = ps.TargetTime; dp.merge_queue_target_time_ns = ps.MergeQueueTargetTime;
+    dp.group_versions = ps.ShouldGroupVersions() ? 1 : 0;
+    dp.includes_dependencies = includes_dependencies ? ((*includes_dependencies)[di] ? 1 : 0)
+                                                     : (d.DispatcherSettings.Version == DispatcherVersionRevisedWithDependencies ? 1 : 0);  // scheduler.go:29
+    p.distros.push_back(dp);
+    std::unordered_map<std::string, int32_t> row_of, tgk, verk;
+    for (size_t i = 0; i < tasks.size(); i++) row_of[tasks[i].Id] = row + (int32_t)i;  // later duplicates win, like a Go map
+    for (const Task& t : tasks) {
+      p.priority.push_back(t.Priority);
+      p.expected_duration.push_back(FetchExpectedDuration(t, now).first);
+      const Time q = t.ActivatedTime != kGoZeroTime ? t.ActivatedTime : t.IngestTime;  // planner.go:318-322
+      p.queue_ts.push_back(q);
+      p.scheduled_ts.push_back(t.ScheduledTime);
+      p.deps_met_ts.push_back(t.DependenciesMetTime);
+      p.num_dependents.push_back(t.NumDependents);
+      p.tg_order.push_back(t.TaskGroupOrder);
+      p.tg_max_hosts.push_back(t.TaskGroupMaxHosts);
+      if (!t.TaskGroup.empty()) {
+        const std::string s = t.GetTaskGroupString();
+        auto it = tgk.find(s);
+        if (it == tgk.end()) { it = tgk.emplace(s, n_tg + (int32_t)tgk.size()).first; p.tg_names.push_back(s); }
+        p.tg_key.push_back(it->second);
+      } else {
+        p.tg_key.push_back(-1);
+      }
+      auto iv = verk.find(t.Version);
+      if (iv == verk.end()) iv = verk.emplace(t.Version, n_ver + (int32_t)verk.size()).first;
+      p.version_key.push_back(iv->second);
+      uint32_t f = detail::req_class(t.Requester);
+      if (t.GenerateTask) f |= EVG_TF_GENERATE;
+      if (t.ActivatedBy == StepbackTaskActivator) f |= EVG_TF_STEPBACK;
+      if (t.OverrideDependencies) f |= EVG_TF_OVERRIDE_DEPS;
+      if (t.DistroId != d.Id) f |= EVG_TF_OTHER_DISTRO;
+      if (t.CachedProjectStorageMethod == ProjectStorageMethodS3) f |= EVG_TF_S3_STORAGE;
+      if (t.Blocked()) f |= EVG_TF_BLOCKED;
+      f |= detail::status_class(t.Status) << EVG_TF_STATUS_SHIFT;
+      p.flags.push_back((uint16_t)f);
+      for (const auto& dep : t.DependsOn) {
+        uint8_t info = detail::dep_required(t, dep.TaskId);
+        int32_t j = -1;
+        auto ir = row_of.find(dep.TaskId);
+        if (ir != row_of.end()) {
+          j = ir->second;
+        } else {
+          const auto found = lookup ? lookup(dep.TaskId) : std::nullopt;
+          if (!found) info |= EVG_DEP_MISSING;
+          else info |= (uint8_t)(detail::status_class(found->first) << EVG_DEP_STATE_SHIFT) | (found->second ? EVG_DEP_BLOCKED : 0);
+        }
+        p.dep_idx.push_back(j);
+        p.dep_info.push_back(info);
+        p.dep_finished.push_back(dep.FinishedAt == kGoZeroTime ? 0 : dep.FinishedAt);
+      }
+      p.dep_off.push_back((int32_t)p.dep_idx.size());
+    }
+    p.tg_key_of.push_back(tgk);
+    row += (int32_t)tasks.size();
+    n_tg += (int32_t)tgk.size();
+    n_ver += (int32_t)verk.size();
+  }
+  p.task_off.push_back(row); p.tg_off.push_back(n_tg); p.ver_off.push_back(n_ver);
+  return p;
+}
+
+struct PlanError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// Batched runTunablePlanner minus persistence (scheduler.go:35-52): per (distro, tasks) the plan -- the SAME task values
+// re-ordered and stamped -- and the DistroQueueInfo. n_units (TaskPlan.Len()) is returned for the tests that pin it.
+struct PlannedQueue {
+  std::vector<Task> plan;
+  DistroQueueInfo info;
+  int n_units = 0;
+};
+inline std::vector<PlannedQueue> PlanDistros(const Backend& be, const std::vector<std::pair<const Distro*, const std::vector<Task>*>>& queues,
+                                             Time now, const std::vector<TaskPlannerOptions>* opts = nullptr, const DepLookup& lookup = nullptr,
+                                             const std::vector<bool>* includes_dependencies = nullptr) {
+  const PackedQueues p = pack_queues(queues, now, lookup, includes_dependencies);
+  const size_t n = p.priority.size(), D = queues.size(), G = D + (size_t)p.tg_off.back();
+  std::vector<int32_t> order(n + 1), n_units(D + 1);
+  std::vector<int64_t> breakdown((n + 1) * EVG_BREAKDOWN_FIELDS), wait(n + 1);
+  std::vector<uint8_t> met(n + 1);
+  std::vector<evg_distro_info> di(D + 1);
+  std::vector<evg_group_info> gi(G + 1);
+  const evg_plan_input in = p.input();
+  evg_plan_output out{order.data(), breakdown.data(), met.data(), wait.data(), di.data(), gi.data(), n_units.data()};
+  const int rc = be.plan(&in, &out);
+  if (rc != EVG_OK) throw PlanError("evg_plan_distros failed (" + std::to_string(rc) + "): " + (be.last_error ? be.last_error() : ""));
+  std::vector<PlannedQueue> res(D);
+  for (size_t d = 0; d < D; d++) {
+    const int lo = p.task_off[d], hi = p.task_off[d + 1];
+    const std::vector<Task>& src = *queues[d].second;
+    PlannedQueue& pq = res[d];
+    pq.n_units = n_units[d];
+    for (int q = lo; q < hi; q++) {
+      const int r = order[q];
+      Task t = src[r - lo];  // the same task value, re-ordered (planner_test.go:493,507,525)
+      const int64_t* b = &breakdown[(size_t)r * EVG_BREAKDOWN_FIELDS];
+      auto& sb = t.SortingValueBreakdown;  // stamped at planner.go:475
+      sb.TaskGroupLength = b[EVG_BD_TASK_GROUP_LENGTH]; sb.TotalValue = b[EVG_BD_TOTAL_VALUE];
+      sb.PriorityBreakdown.InitialPriorityImpact = b[EVG_BD_PRI_INITIAL]; sb.PriorityBreakdown.TaskGroupImpact = b[EVG_BD_PRI_TASK_GROUP];
+      sb.PriorityBreakdown.GeneratorTaskImpact = b[EVG_BD_PRI_GENERATOR]; sb.PriorityBreakdown.CommitQueueImpact = b[EVG_BD_PRI_COMMIT_QUEUE];
+      sb.RankValueBreakdown.CommitQueueImpact = b[EVG_BD_RANK_COMMIT_QUEUE]; sb.RankValueBreakdown.NumDependentsImpact = b[EVG_BD_RANK_NUM_DEPENDENTS];
+      sb.RankValueBreakdown.EstimatedRuntimeImpact = b[EVG_BD_RANK_EST_RUNTIME]; sb.RankValueBreakdown.MainlineWaitTimeImpact = b[EVG_BD_RANK_MAINLINE_WAIT];
+      sb.RankValueBreakdown.StepbackImpact = b[EVG_BD_RANK_STEPBACK]; sb.RankValueBreakdown.PatchImpact = b[EVG_BD_RANK_PATCH];
+      sb.RankValueBreakdown.PatchWaitTimeImpact = b[EVG_BD_RANK_PATCH_WAIT];
+      t.ExpectedDuration = p.expected_duration[r];        // scheduler.go:125
+      t.WaitSinceDependenciesMet = wait[r];               // scheduler.go:141
+      if (met[r] && IsZeroTime(t.DependenciesMetTime) && !t.DependsOn.empty() && !t.OverrideDependencies) {
+        Time mx = 0;  // Task.setDependenciesMetTime task.go:690-701
+        for (const auto& x : t.DependsOn)
+          if (!IsZeroTime(x.FinishedAt) && x.FinishedAt > mx) mx = x.FinishedAt;
+        t.DependenciesMetTime = mx ? mx : now;
+      }
+      pq.plan.push_back(std::move(t));
+    }
+    const evg_distro_info& i = di[d];
+    DistroQueueInfo& info = pq.info;
+    info.Length = i.length; info.LengthWithDependenciesMet = i.length_with_dependencies_met;
+    info.CountDepFilledMergeQueueTasks = i.count_dep_filled_merge_queue_tasks; info.ExpectedDuration = i.expected_duration_ns;
+    info.MaxDurationThreshold = i.max_duration_threshold_ns; info.CountDurationOverThreshold = i.count_duration_over_threshold;
+    info.DurationOverThreshold = i.duration_over_threshold_ns; info.CountWaitOverThreshold = i.count_wait_over_threshold;
+    info.NumQueuedLargeParserProjectTasks = i.num_queued_large_parser_project_tasks; info.SecondaryQueue = i.secondary_queue != 0;
+    auto add_row = [&](const evg_group_info& g, const std::string& name) {
+      if (!g.present) return;
+      TaskGroupInfo tg;
+      tg.Name = name; tg.Count = g.count; tg.CountFree = g.count_free; tg.CountRequired = g.count_required; tg.MaxHosts = g.max_hosts;
+      tg.ExpectedDuration = g.expected_duration_ns; tg.CountDurationOverThreshold = g.count_duration_over_threshold;
+      tg.CountWaitOverThreshold = g.count_wait_over_threshold; tg.CountDepFilledMergeQueueTasks = g.count_dep_filled_merge_queue_tasks;
+      tg.DurationOverThreshold = g.duration_over_threshold_ns;
+      info.TaskGroupInfos.push_back(tg);
+    };
+    add_row(gi[d], "");
+    for (int k = p.tg_off[d]; k < p.tg_off[d + 1]; k++) add_row(gi[D + k], p.tg_names[k]);
+    if (opts) {
+      info.SecondaryQueue = (*opts)[d].IsSecondaryQueue;  // scheduler.go:45
+      info.PlanCreatedAt = (*opts)[d].StartedAt;          // scheduler.go:46
+    }
+  }
+  return res;
+}
+
+// scheduler.PrioritizeTasks (scheduler.go:28-33) for one distro: a batch of one.
+inline PlannedQueue PrioritizeTasks(const Backend& be, const Distro& d, const std::vector<Task>& tasks, const TaskPlannerOptions& opts, Time now,
+                                    const DepLookup& lookup = nullptr) {
+  std::vector<TaskPlannerOptions> o{opts};
+  return PlanDistros(be, {{&d, &tasks}}, now, &o, lookup)[0];
+}
+
+// A value of the reference's TaskPlanner type: func(*distro.Distro, []task.Task, TaskPlannerOptions) ([]task.Task, error);
+// the error return is an exception.
+using TaskPlanner = std::function<std::vector<Task>(const Distro&, const std::vector<Task>&, const TaskPlannerOptions&)>;
+inline TaskPlanner MakeTaskPlanner(Backend be, Time now) {
+  return [be, now](const Distro& d, const std::vector<Task>& tasks, const TaskPlannerOptions& o) { return PrioritizeTasks(be, d, tasks, o, now).plan; };
+}
+
+// scheduler/task_queue_persister.go:66-83
+inline std::vector<Task> capTaskQueueLength(const std::vector<Task>& tasks, int maxScheduledTasks) {
+  if (maxScheduledTasks <= 0 || (int)tasks.size() <= maxScheduledTasks) return tasks;
+  size_t cut = (size_t)maxScheduledTasks;
+  while (cut < tasks.size() && !tasks[cut].TaskGroup.empty() && tasks[cut].TaskGroup == tasks[cut - 1].TaskGroup) cut++;
+  return std::vector<Task>(tasks.begin(), tasks.begin() + (long)cut);
+}
+
+// ---- host allocator -------------------------------------------------------------------------------------------
+struct AllocatorResult {
+  int newHostsNeeded = 0, estimatedFreeHosts = 0;
+  std::string err;  // empty == nil
+};
+
+// Batched UtilizationBasedHostAllocator: one HostAllocatorData per distro. Writes CountFree / CountRequired back into
+// data.DistroQueueInfo.TaskGroupInfos IN PLACE like the reference (utilization_based_host_allocator.go:106-109).
+inline std::vector<AllocatorResult> AllocateHosts(const Backend& be, std::vector<HostAllocatorData*>& datas, Time now,
+                                                  const RunningTaskLookup& running = nullptr) {
+  const size_t D = datas.size();
+  std::vector<int32_t> tg_off(D + 1, 0), host_off(D + 1, 0);
+  std::vector<std::unordered_map<std::string, int32_t>> key_of(D);
+  int32_t n_tg = 0;
+  for (size_t d = 0; d < D; d++) {
+    tg_off[d] = n_tg;
+    for (const auto& g : datas[d]->DistroQueueInfo.TaskGroupInfos)
+      if (!g.Name.empty() && !key_of[d].count(g.Name)) key_of[d][g.Name] = n_tg++;
+  }
+  tg_off[D] = n_tg;
+  std::vector<evg_distro_info> di(D + 1);
+  std::vector<evg_group_info> gi(D + (size_t)n_tg + 1);
+  std::vector<evg_alloc_params> params(D + 1);
+  std::vector<uint8_t> hflags;
+  std::vector<int32_t> hkey;
+  std::vector<int64_t> hstart, hexp, hsd;
+  for (size_t d = 0; d < D; d++) {
+    const HostAllocatorData& data = *datas[d];
+    const auto& q = data.DistroQueueInfo;
+    di[d].length = q.Length; di[d].length_with_dependencies_met = q.LengthWithDependenciesMet;
+    di[d].max_duration_threshold_ns = q.MaxDurationThreshold;
+    for (const auto& g : q.TaskGroupInfos) {  // groupByTaskGroup builds a name -> info map (:228-231): a later duplicate wins
+      evg_group_info& r = gi[g.Name.empty() ? d : D + (size_t)key_of[d][g.Name]];
+      r.present = 1; r.count = g.Count; r.max_hosts = g.MaxHosts; r.expected_duration_ns = g.ExpectedDuration;
+      r.duration_over_threshold_ns = g.DurationOverThreshold; r.count_duration_over_threshold = g.CountDurationOverThreshold;
+      r.count_wait_over_threshold = g.CountWaitOverThreshold; r.count_dep_filled_merge_queue_tasks = g.CountDepFilledMergeQueueTasks;
+      r.count_free = g.CountFree; r.count_required = g.CountRequired;
+    }
+    const auto& s = data.Distro.HostAllocatorSettings;
+    evg_alloc_params& ap = params[d];
+    ap.future_host_fraction = s.FutureHostFraction; ap.minimum_hosts = s.MinimumHosts; ap.maximum_hosts = s.MaximumHosts;
+    ap.provider = data.Distro.Provider == ProviderNameDocker ? 2 : data.Distro.IsEphemeral() ? 1 : 0;
+    ap.disabled = data.Distro.Disabled ? 1 : 0;
+    ap.round_up = s.RoundingRule == HostAllocatorRoundUp ? 1 : 0;
+    ap.feedback_waits_over_thresh = s.FeedbackRule == HostAllocatorWaitsOverThreshFeedback ? 1 : 0;
+    host_off[d] = (int32_t)hflags.size();
+    for (const Host& h : data.ExistingHosts) {
+      uint8_t f = h.IsFree() ? EVG_HF_FREE : 0;
+      int32_t key = -1;
+      int64_t start = 0, exp = 0, sd = 0;
+      if (!h.RunningTask.empty()) {
+        f |= EVG_HF_RUNNING;
+        if (!h.RunningTaskGroup.empty()) {
+          auto it = key_of[d].find(h.GetTaskGroupString());
+          key = it == key_of[d].end() ? -2 : it->second;
+        }
+        const Task* t = running ? running(h.RunningTask) : nullptr;
+        if (t) {
+          f |= EVG_HF_RUNNING_FOUND;
+          std::tie(exp, sd) = FetchExpectedDuration(*t, now);
+          start = t->StartTime;
+        }
+      }
+      hflags.push_back(f); hkey.push_back(key); hstart.push_back(start); hexp.push_back(exp); hsd.push_back(sd);
+    }
+  }
+  host_off[D] = (int32_t)hflags.size();
+  hflags.push_back(0); hkey.push_back(0); hstart.push_back(0); hexp.push_back(0); hsd.push_back(0);  // non-null when empty
+  evg_alloc_input in{};
+  in.n_distros = (int32_t)D; in.n_task_groups = n_tg; in.params = params.data(); in.host_off = host_off.data(); in.tg_off = tg_off.data();
+  in.hosts.n_hosts = host_off[D]; in.hosts.flags = hflags.data(); in.hosts.tg_key = hkey.data(); in.hosts.start_ts_ns = hstart.data();
+  in.hosts.expected_duration_ns = hexp.data(); in.hosts.duration_stddev_ns = hsd.data();
+  in.distro_info = di.data(); in.group_info = gi.data(); in.now_ns = now;
+  std::vector<int32_t> nh(D + 1), nf(D + 1), st(D + 1);
+  evg_alloc_output out{nh.data(), nf.data(), st.data()};
+  const int rc = be.allocate(&in, &out);
+  if (rc != EVG_OK) throw PlanError("evg_allocate_hosts failed (" + std::to_string(rc) + "): " + (be.last_error ? be.last_error() : ""));
+  std::vector<AllocatorResult> res(D);
+  for (size_t d = 0; d < D; d++) {
+    HostAllocatorData& data = *datas[d];
+    res[d].newHostsNeeded = nh[d]; res[d].estimatedFreeHosts = nf[d];
+    if (st[d] == EVG_ALLOC_E_FUTURE_FRACTION)
+      res[d].err = "calculating hosts for distro '" + data.Distro.Id + "': future host factor cannot be greater than 1";
+    else if (st[d] == EVG_ALLOC_E_POOL_SIZE)
+      res[d].err = "calculating hosts for distro '" + data.Distro.Id + "': unable to plan hosts for distro " + data.Distro.Id +
+                   " due to pool size of " + std::to_string(data.Distro.HostAllocatorSettings.MaximumHosts);
+    for (auto& g : data.DistroQueueInfo.TaskGroupInfos)
+      if (!g.Name.empty()) {
+        const evg_group_info& r = gi[D + (size_t)key_of[d][g.Name]];
+        g.CountFree = r.count_free; g.CountRequired = r.count_required;
+      }
+  }
+  return res;
+}
+
+struct AllocatorError : std::runtime_error {
+  int newHostsNeeded, estimatedFreeHosts;  // what the reference returns next to the error (:99-101)
+  AllocatorError(const std::string& m, int n, int f) : std::runtime_error(m), newHostsNeeded(n), estimatedFreeHosts(f) {}
+};
+// A value of the reference's HostAllocator type (scheduler/host_allocator.go:15) for one distro.
+inline std::pair<int, int> UtilizationBasedHostAllocator(const Backend& be, HostAllocatorData& data, Time now, const RunningTaskLookup& running = nullptr) {
+  std::vector<HostAllocatorData*> one{&data};
+  const AllocatorResult r = AllocateHosts(be, one, now, running)[0];
+  if (!r.err.empty()) throw AllocatorError(r.err, r.newHostsNeeded, r.estimatedFreeHosts);
+  return {r.newHostsNeeded, r.estimatedFreeHosts};
+}
+using HostAllocator = std::function<std::pair<int, int>(const Backend&, HostAllocatorData&, Time, const RunningTaskLookup&)>;
+inline HostAllocator GetHostAllocator(const std::string& /*name*/) { return UtilizationBasedHostAllocator; }  // host_allocator.go:23-30
+
+}  // namespace evergreen

@@ -1,0 +1,197 @@
+// test_host_shim.cpp -- the reference's known-answer tests run through the C++ host layer (include/evg_host.hpp).
+//
+//   test_host_shim oracle <path to oracle/libevg_oracle.so>      CPU: checks the host layer itself (packing, interning,
+//                                                                 re-ordering, in-place write-back, error strings)
+//   test_host_shim hip    <path to libevg_sched.so>              MI355X: the product path, end to end
+//
+// The cases are generated from tests/golden_cases.py (transcribed from /root/reference/scheduler/*_test.go) into
+// golden_cases.inc; the check_* functions below mirror what the Go tests assert.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+
+#include "evg_host.hpp"
+
+using namespace evergreen;
+
+static int g_checks = 0, g_fail = 0;
+#define EXPECT(cond, ...)                                  \
+  do {                                                     \
+    g_checks++;                                            \
+    if (!(cond)) {                                         \
+      g_fail++;                                            \
+      std::fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+      std::fprintf(stderr, __VA_ARGS__);                   \
+      std::fprintf(stderr, "\n");                          \
+    }                                                      \
+  } while (0)
+
+// tests only: the CPU oracle behind the same two calls (oracle/ is test infrastructure, never part of the product)
+static Backend OracleBackend(const std::string& path) {
+  void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!h) throw std::runtime_error(std::string("cannot load the oracle: ") + dlerror());
+  auto plan = reinterpret_cast<int (*)(const evg_plan_input*, const evg_plan_output*)>(dlsym(h, "evg_oracle_plan_distros"));
+  auto alloc = reinterpret_cast<int (*)(const evg_alloc_input*, const evg_alloc_output*)>(dlsym(h, "evg_oracle_allocate_hosts"));
+  if (!plan || !alloc) throw std::runtime_error("oracle entry points missing");
+  Backend b;
+  b.plan = plan;
+  b.allocate = alloc;
+  b.last_error = [] { return std::string("oracle"); };
+  return b;
+}
+
+static const Time NOW_FWD = 0;  // (NOW is defined by the generated file)
+
+// planner_test.go:561-574 verifyRankBreakdown
+static bool verify_rank_breakdown(const SortingValueBreakdown& b) {
+  const auto& r = b.RankValueBreakdown;
+  const auto& p = b.PriorityBreakdown;
+  const int64_t rank = r.StepbackImpact + r.PatchImpact + r.PatchWaitTimeImpact + r.MainlineWaitTimeImpact + r.EstimatedRuntimeImpact +
+                       r.NumDependentsImpact + r.CommitQueueImpact;
+  const int64_t pri = p.InitialPriorityImpact + p.CommitQueueImpact + p.GeneratorTaskImpact + p.TaskGroupImpact;
+  return pri + b.TaskGroupLength + rank * pri == b.TotalValue;
+}
+
+static void check_unit_value(const Backend& be, const char* name, int line, const Distro& d, const std::vector<Task>& tasks, int64_t want);
+static void check_task_list(const Backend& be, const char* name, int line, const std::vector<Task>& tasks, std::vector<std::string> want);
+static void check_prepare(const Backend& be, const char* name, int line, const Distro& d, const std::vector<Task>& tasks, int n_units);
+static void check_queue_info(const Backend& be, const char* name, int line, const Distro& d, const std::vector<Task>& tasks,
+                             std::vector<std::pair<std::string, int64_t>> want);
+static void check_allocator(const Backend& be, const char* name, int line, HostAllocatorData& data, const std::map<std::string, Task>& running,
+                            int want_hosts, int want_free);
+static void check_cap(const char* name, const std::vector<Task>& tasks, int limit, int want);
+
+#include "golden_cases.inc"
+
+static void check_unit_value(const Backend& be, const char* name, int line, const Distro& d, const std::vector<Task>& tasks, int64_t want) {
+  const PlannedQueue pq = PrioritizeTasks(be, d, tasks, TaskPlannerOptions{}, NOW);
+  EXPECT(pq.plan.size() == tasks.size(), "%s: %zu tasks planned", name, pq.plan.size());
+  for (const Task& t : pq.plan) {
+    EXPECT(t.SortingValueBreakdown.TotalValue == want, "%s (planner_test.go:%d): TotalValue %lld, the reference asserts %lld", name, line,
+           (long long)t.SortingValueBreakdown.TotalValue, (long long)want);
+    EXPECT(verify_rank_breakdown(t.SortingValueBreakdown), "%s: breakdown identity", name);
+    EXPECT(t.SortingValueBreakdown.TaskGroupLength == (int64_t)tasks.size(), "%s: unit length", name);
+  }
+}
+
+static void check_task_list(const Backend& be, const char* name, int line, const std::vector<Task>& tasks, std::vector<std::string> want) {
+  Distro d;
+  d.PlannerSettings.GroupVersions = true;
+  const PlannedQueue pq = PrioritizeTasks(be, d, tasks, TaskPlannerOptions{}, NOW);
+  std::vector<std::string> ids;
+  for (const Task& t : pq.plan) ids.push_back(t.Id);
+  EXPECT(ids == want, "%s (planner_test.go:%d): order differs", name, line);
+}
+
+static void check_prepare(const Backend& be, const char* name, int line, const Distro& d, const std::vector<Task>& tasks, int n_units) {
+  const PlannedQueue pq = PrioritizeTasks(be, d, tasks, TaskPlannerOptions{}, NOW);
+  EXPECT(pq.n_units == n_units, "%s (planner_test.go:%d): %d units, the reference asserts %d", name, line, pq.n_units, n_units);
+  std::multiset<std::string> a, b;
+  for (const Task& t : pq.plan) a.insert(t.Id);
+  for (const Task& t : tasks) b.insert(t.Id);
+  EXPECT(a == b, "%s: a task was dropped or duplicated", name);
+}
+
+static void check_queue_info(const Backend& be, const char* name, int line, const Distro& d, const std::vector<Task>& tasks,
+                             std::vector<std::pair<std::string, int64_t>> want) {
+  std::vector<bool> inc{true};
+  const PlannedQueue pq = PlanDistros(be, {{&d, &tasks}}, NOW, nullptr, nullptr, &inc)[0];
+  for (const auto& kv : want) {
+    int64_t got = -1;
+    if (kv.first == "MaxDurationThreshold") got = pq.info.MaxDurationThreshold;
+    else if (kv.first == "CountDepFilledMergeQueueTasks") got = pq.info.CountDepFilledMergeQueueTasks;
+    else if (kv.first == "CountDurationOverThreshold") got = pq.info.CountDurationOverThreshold;
+    else if (kv.first == "DurationOverThreshold") got = pq.info.DurationOverThreshold;
+    else if (kv.first == "LengthWithDependenciesMet") got = pq.info.LengthWithDependenciesMet;
+    EXPECT(got == kv.second, "%s (scheduler_test.go:%d): %s = %lld, the reference asserts %lld", name, line, kv.first.c_str(), (long long)got,
+           (long long)kv.second);
+  }
+}
+
+static void check_allocator(const Backend& be, const char* name, int line, HostAllocatorData& data, const std::map<std::string, Task>& running,
+                            int want_hosts, int want_free) {
+  auto look = [&](const std::string& id) -> const Task* {
+    auto it = running.find(id);
+    return it == running.end() ? nullptr : &it->second;
+  };
+  const HostAllocator allocator = GetHostAllocator("utilization");
+  const auto got = allocator(be, data, NOW, look);
+  EXPECT(got.first == want_hosts && got.second == want_free, "%s (utilization_based_host_allocator_test.go:%d): (%d, %d), the reference asserts (%d, %d)",
+         name, line, got.first, got.second, want_hosts, want_free);
+}
+
+static void check_cap(const char* name, const std::vector<Task>& tasks, int limit, int want) {
+  EXPECT((int)capTaskQueueLength(tasks, limit).size() == want, "%s: capTaskQueueLength", name);
+}
+
+static void run_error_cases(const Backend& be) {
+  // futureHostFraction > 1 (utilization_based_host_allocator.go:287-289) and a task group with MaxHosts < 1 (:185-187)
+  HostAllocatorData data;
+  data.Distro.Id = "testDistro"; data.Distro.Provider = ProviderNameEc2Fleet;
+  data.Distro.HostAllocatorSettings.MaximumHosts = 50; data.Distro.HostAllocatorSettings.FutureHostFraction = 1.5;
+  data.ExistingHosts.push_back(Host{});
+  data.ExistingHosts[0].Id = "h1";
+  TaskGroupInfo gi; gi.Count = 1; gi.ExpectedDuration = Minute;
+  data.DistroQueueInfo.LengthWithDependenciesMet = 1; data.DistroQueueInfo.MaxDurationThreshold = 30 * Minute;
+  data.DistroQueueInfo.TaskGroupInfos.push_back(gi);
+  try {
+    UtilizationBasedHostAllocator(be, data, NOW);
+    EXPECT(false, "expected an AllocatorError for FutureHostFraction 1.5");
+  } catch (const AllocatorError& e) {
+    EXPECT(std::string(e.what()).find("future host factor cannot be greater than 1") != std::string::npos, "error text: %s", e.what());
+    EXPECT(e.newHostsNeeded == 0 && e.estimatedFreeHosts == 1, "error tuple (%d, %d)", e.newHostsNeeded, e.estimatedFreeHosts);
+  }
+  HostAllocatorData d2;
+  d2.Distro.Id = "testDistro"; d2.Distro.Provider = ProviderNameEc2Fleet; d2.Distro.HostAllocatorSettings.MaximumHosts = 50;
+  d2.Distro.HostAllocatorSettings.FutureHostFraction = 0.5;
+  TaskGroupInfo g0; g0.Name = "g_a_b_c"; g0.Count = 2; g0.MaxHosts = 0; g0.ExpectedDuration = Minute;
+  d2.DistroQueueInfo.LengthWithDependenciesMet = 2; d2.DistroQueueInfo.MaxDurationThreshold = 30 * Minute;
+  d2.DistroQueueInfo.TaskGroupInfos.push_back(g0);
+  try {
+    UtilizationBasedHostAllocator(be, d2, NOW);
+    EXPECT(false, "expected an AllocatorError for MaxHosts 0");
+  } catch (const AllocatorError& e) {
+    EXPECT(std::string(e.what()).find("due to pool size of") != std::string::npos, "error text: %s", e.what());
+  }
+}
+
+static void run_planner_behaviour(const Backend& be) {
+  // planner_test.go:406-432 TaskPlan: NoChange / ChangeOrder
+  std::vector<Task> ts(2);
+  ts[0].Id = "foo"; ts[1].Id = "bar";
+  const TaskPlanner planner = MakeTaskPlanner(be, NOW);  // a value of the reference's TaskPlanner type
+  auto plan = planner(Distro{}, ts, TaskPlannerOptions{});
+  EXPECT(plan[0].Id == "foo" && plan[1].Id == "bar", "NoChange");
+  ts[1].Priority = 10;
+  plan = planner(Distro{}, ts, TaskPlannerOptions{});
+  EXPECT(plan[0].Id == "bar" && plan[1].Id == "foo", "ChangeOrder");
+  // runTunablePlanner overwrites SecondaryQueue / PlanCreatedAt from the options (scheduler.go:45-46)
+  TaskPlannerOptions o; o.IsSecondaryQueue = true; o.StartedAt = NOW - 5;
+  const PlannedQueue pq = PrioritizeTasks(be, Distro{}, ts, o, NOW);
+  EXPECT(pq.info.SecondaryQueue && pq.info.PlanCreatedAt == NOW - 5 && pq.info.Length == 2, "options copied into the queue info");
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: %s oracle|hip <library path>\n", argv[0]);
+    return 2;
+  }
+  (void)NOW_FWD;
+  try {
+    const Backend be = std::string(argv[1]) == "hip" ? HipBackend(argv[2]) : OracleBackend(argv[2]);
+    run_unit_value_cases(be);
+    run_task_list_cases(be);
+    run_prepare_cases(be);
+    run_queue_info_cases(be);
+    run_allocator_cases(be);
+    run_cap_cases();
+    run_error_cases(be);
+    run_planner_behaviour(be);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 1;
+  }
+  std::printf("%s backend: %d checks, %d failed\n", argv[1], g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}
