@@ -66,6 +66,17 @@ class AllocInput(C.Structure):
                 ("group_info", _p), ("now_ns", C.c_int64)]
 
 
+class QueueItems(C.Structure):
+    _fields_ = [("cut", _p), ("item_off", _p), ("row", _p), ("expected_duration_ns", _p), ("priority", _p),
+                ("group_max_hosts", _p), ("group_index", _p), ("n_dependencies", _p), ("dependencies_met", _p),
+                ("breakdown", _p)]
+
+
+TASK_QUEUE_SAVE_LIMIT = 10000
+QUEUE_ITEM_COLUMNS = {"row": np.int32, "expected_duration_ns": np.int64, "priority": np.int64, "group_max_hosts": np.int32,
+                      "group_index": np.int32, "n_dependencies": np.int32, "dependencies_met": np.uint8}
+
+
 class AllocOutput(C.Structure):
     _fields_ = [("new_hosts", _p), ("free_hosts", _p), ("status", _p)]
 
@@ -285,3 +296,31 @@ def make_alloc_input(batch: PlanBatch, distro_info, group_info, arrays=None) -> 
     inp.distro_info = _ptr(distro_info)
     inp.group_info = _ptr(group_info)
     return inp
+
+
+@dataclass
+class QueueItemsResult:
+    """evg_queue_items on the host: the persisted queues of all distros, struct-of-arrays."""
+    cut: np.ndarray
+    item_off: np.ndarray
+    cols: Dict[str, np.ndarray]
+    breakdown: Optional[np.ndarray]
+
+    @staticmethod
+    def alloc_host(batch: PlanBatch, breakdown=True) -> "QueueItemsResult":
+        n, d = batch.n_tasks, batch.n_distros
+        return QueueItemsResult(cut=np.zeros(d, np.int32), item_off=np.zeros(d + 1, np.int32),
+                                cols={k: np.zeros(n, dt) for k, dt in QUEUE_ITEM_COLUMNS.items()},
+                                breakdown=np.zeros((n, BREAKDOWN_FIELDS), np.int64) if breakdown else None)
+
+    def c_struct(self) -> QueueItems:
+        q = QueueItems()
+        q.cut, q.item_off, q.breakdown = _ptr(self.cut), _ptr(self.item_off), _ptr(self.breakdown)
+        for k in QUEUE_ITEM_COLUMNS:
+            setattr(q, k, _ptr(self.cols[k]))
+        return q
+
+    def trimmed(self) -> "QueueItemsResult":
+        m = int(self.item_off[-1])
+        return QueueItemsResult(self.cut, self.item_off, {k: v[:m] for k, v in self.cols.items()},
+                                None if self.breakdown is None else self.breakdown[:m])

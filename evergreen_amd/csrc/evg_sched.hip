@@ -72,6 +72,73 @@ __global__ void k_cap_queue(int D, const int32_t* task_off, const int32_t* order
   cut[d] = c;
 }
 
+// ---- PersistTaskQueue's queue materialisation (task_queue_persister.go:17-62, task_queue.go:269-275) ----------
+// k_queue_offsets: one workgroup; cut[d] per distro (capTaskQueueLength), persisted = min(cut, 10000), exclusive scan.
+__global__ void __launch_bounds__(1024) k_queue_offsets(int D, const int32_t* task_off, const int32_t* order, const int32_t* tg_name_key,
+                                                        int32_t max_scheduled, int32_t* cut, int32_t* item_off) {
+  __shared__ int s_part[1024];
+  const int tid = threadIdx.x;
+  const int per = (D + 1023) / 1024;  // distros per thread, consecutive
+  int sum = 0;
+  for (int k = 0; k < per; k++) {
+    const int d = tid * per + k;
+    if (d >= D) break;
+    const int lo = task_off[d], len = task_off[d + 1] - lo;
+    int c = len;
+    if (max_scheduled > 0 && len > max_scheduled) {
+      c = max_scheduled;
+      while (c < len) {
+        const int g = tg_name_key[order[lo + c]];
+        if (g < 0 || g != tg_name_key[order[lo + c - 1]]) break;
+        c++;
+      }
+    }
+    cut[d] = c;
+    sum += c < EVG_TASK_QUEUE_SAVE_LIMIT ? c : EVG_TASK_QUEUE_SAVE_LIMIT;
+  }
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+    const int v = tid >= o ? s_part[tid - o] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - sum;
+  for (int k = 0; k < per; k++) {
+    const int d = tid * per + k;
+    if (d >= D) break;
+    item_off[d] = run;
+    const int c = cut[d];
+    run += c < EVG_TASK_QUEUE_SAVE_LIMIT ? c : EVG_TASK_QUEUE_SAVE_LIMIT;
+    if (d == D - 1) item_off[D] = run;
+  }
+}
+
+// k_queue_items: blockIdx.y = distro, one thread per persisted queue position: a gather by `order`.
+__global__ void __launch_bounds__(256) k_queue_items(const evg_plan_input in, const evg_plan_output plan, const evg_queue_items it) {
+  const int d = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int n = it.item_off[d + 1] - it.item_off[d];
+  if (p >= n) return;
+  const int r = plan.order[in.task_off[d] + p];
+  const int o = it.item_off[d] + p;
+  const evg_task_soa& t = in.tasks;
+  it.row[o] = r;
+  it.expected_duration_ns[o] = t.expected_duration_ns[r];
+  it.priority[o] = t.priority[r];
+  it.group_max_hosts[o] = t.task_group_max_hosts[r];
+  it.group_index[o] = t.task_group_order[r];
+  it.n_dependencies[o] = t.dep_off[r + 1] - t.dep_off[r];
+  it.dependencies_met[o] = plan.deps_met[r];
+  if (it.breakdown) {
+    const int64_t* src = plan.breakdown + (size_t)r * EVG_BREAKDOWN_FIELDS;
+    int64_t* dst = it.breakdown + (size_t)o * EVG_BREAKDOWN_FIELDS;
+#pragma unroll
+    for (int k = 0; k < EVG_BREAKDOWN_FIELDS; k++) dst[k] = src[k];
+  }
+}
+
 }  // namespace evg
 
 // =============================================================================================================
@@ -393,6 +460,28 @@ int evg_cap_queue_device(evg_ctx* c, int32_t n_distros, const int32_t* task_off,
   HIP_TRY(c, hipSetDevice(c->device));
   hipLaunchKernelGGL(evg::k_cap_queue, dim3((n_distros + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, n_distros,
                      task_off, order, tg_name_key, max_scheduled, cut);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
+int evg_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* plan, const int32_t* tg_name_key,
+                                 int32_t max_scheduled, const evg_queue_items* items, void* hip_stream) {
+  if (!c || !in || !plan || !items) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  const int D = in->n_distros;
+  if (D < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
+  if (D == 0) return EVG_OK;
+  if (!items->cut || !items->item_off || !items->row || !items->expected_duration_ns || !items->priority || !items->group_max_hosts ||
+      !items->group_index || !items->n_dependencies || !items->dependencies_met || !plan->order || !plan->deps_met)
+    return set_err(c, EVG_E_INVALID, "null queue-item output");
+  if (items->breakdown && !plan->breakdown) return set_err(c, EVG_E_INVALID, "item breakdowns need the plan's breakdown output");
+  if (in->tasks.n_tasks > 0 && !tg_name_key) return set_err(c, EVG_E_INVALID, "tg_name_key is required");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  hipLaunchKernelGGL(evg::k_queue_offsets, dim3(1), dim3(1024), 0, st, D, in->task_off, plan->order, tg_name_key, max_scheduled, items->cut,
+                     items->item_off);
+  HIP_TRY(c, hipGetLastError());
+  hipLaunchKernelGGL(evg::k_queue_items, dim3((EVG_TASK_QUEUE_SAVE_LIMIT + 255) / 256, D), dim3(256), 0, st, *in, *plan, *items);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }

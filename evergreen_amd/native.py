@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libevg_sched.so")
 EXPORTS = [
     "evg_create", "evg_destroy", "evg_last_error", "evg_abi_version", "evg_validate_plan_input",
     "evg_plan_distros", "evg_plan_distros_device", "evg_allocate_hosts", "evg_allocate_hosts_device",
-    "evg_cap_queue_device", "evg_plan_allocate_device",
+    "evg_cap_queue_device", "evg_plan_allocate_device", "evg_materialize_queue_device",
 ]
 
 _lib = None
@@ -60,6 +60,8 @@ def load_library() -> C.CDLL:
     lib.evg_allocate_hosts_device.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_void_p]
     lib.evg_plan_allocate_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput),
                                              C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_void_p]
+    lib.evg_materialize_queue_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p, C.c_int32,
+                                                 C.POINTER(abi.QueueItems), C.c_void_p]
     lib.evg_cap_queue_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p]
     _lib = lib
@@ -121,6 +123,11 @@ class Context:
                              stream: Optional[int] = None) -> None:
         self._check(self.lib.evg_plan_allocate_device(self.h, C.byref(inp), C.byref(out), C.byref(ainp), C.byref(aout), stream),
                     "evg_plan_allocate_device")
+
+    def materialize_queue_device(self, inp: abi.PlanInput, out: abi.PlanOutput, tg_name_key: int, max_scheduled: int,
+                                 items: abi.QueueItems, stream: Optional[int] = None) -> None:
+        self._check(self.lib.evg_materialize_queue_device(self.h, C.byref(inp), C.byref(out), tg_name_key, max_scheduled,
+                                                          C.byref(items), stream), "evg_materialize_queue_device")
 
     def cap_queue_device(self, n_distros: int, task_off: int, order: int, tg_name_key: int, max_scheduled: int,
                          cut: int, stream: Optional[int] = None) -> None:

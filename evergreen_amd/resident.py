@@ -59,6 +59,32 @@ class ResidentPool:
         if self.has_hosts:
             self.ctx.allocate_device(self.ainp, self.aout, s)
 
+    def materialize_queue(self, max_scheduled: int, stream: Optional[int] = None) -> abi.QueueItemsResult:
+        """PersistTaskQueue's item list for every distro (cap + 10,000 truncation + gather by queue order), on the
+        device, from the plan that is resident in this pool. Returns host copies."""
+        torch = self.torch
+        b, dev = self.batch, self.device
+        n, D = max(b.n_tasks, 1), b.n_distros
+        if not hasattr(self, "_qi"):
+            tmap = {np.int32: torch.int32, np.int64: torch.int64, np.uint8: torch.uint8}
+            self._qi = {k: torch.zeros(n, dtype=tmap[dt], device=dev) for k, dt in abi.QUEUE_ITEM_COLUMNS.items()}
+            self._qi["cut"] = torch.zeros(D, dtype=torch.int32, device=dev)
+            self._qi["item_off"] = torch.zeros(D + 1, dtype=torch.int32, device=dev)
+            if self.o_bd is not None:
+                self._qi["breakdown"] = torch.zeros(n * abi.BREAKDOWN_FIELDS, dtype=torch.int64, device=dev)
+        q = abi.QueueItems()
+        for k, v in self._qi.items():
+            setattr(q, k, v.data_ptr())
+        if self.o_bd is None:
+            q.breakdown = None
+        self.ctx.materialize_queue_device(self.inp, self.out, self.t["tg_name_key"].data_ptr(), max_scheduled, q,
+                                          self.stream() if stream is None else stream)
+        torch.cuda.synchronize(dev)
+        res = abi.QueueItemsResult(cut=self._qi["cut"].cpu().numpy(), item_off=self._qi["item_off"].cpu().numpy(),
+                                   cols={k: self._qi[k].cpu().numpy() for k in abi.QUEUE_ITEM_COLUMNS},
+                                   breakdown=self._qi["breakdown"].cpu().numpy().reshape(-1, abi.BREAKDOWN_FIELDS) if self.o_bd is not None else None)
+        return res.trimmed()
+
     def plan_result(self) -> abi.PlanResult:
         n = self.batch.n_tasks
         self.torch.cuda.synchronize(self.device)

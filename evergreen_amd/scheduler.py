@@ -449,6 +449,7 @@ def PlanDistros(backend: Backend, queues: Sequence[Tuple[Distro, Sequence[Task]]
             row = int(res.order[p])
             t = packed.tasks[d][row - lo]
             t.SortingValueBreakdown = {k: int(res.breakdown[row, abi.BD[k]]) for k in names}
+            t.ExpectedDuration = int(packed.batch.cols["expected_duration_ns"][row])   # scheduler.go:125
             t.WaitSinceDependenciesMet = int(res.wait_ns[row])
             if res.deps_met[row] and _is_zero_time(t.DependenciesMetTime) and t.DependsOn and not t.OverrideDependencies:
                 # Task.setDependenciesMetTime (task.go:690-701), observable through HasDependenciesMet()
@@ -486,6 +487,37 @@ def capTaskQueueLength(tasks: Sequence[Task], maxScheduledTasks: int) -> List[Ta
     while cut < len(tasks) and tasks[cut].TaskGroup != "" and tasks[cut].TaskGroup == tasks[cut - 1].TaskGroup:
         cut += 1
     return list(tasks[:cut])
+
+
+@dataclass
+class TaskQueueItem:                               # model/task_queue.go:181-205 (the fields the path fills)
+    Id: str = ""
+    Group: str = ""
+    GroupMaxHosts: int = 0
+    GroupIndex: int = 0
+    Version: str = ""
+    BuildVariant: str = ""
+    Requester: str = ""
+    Project: str = ""
+    ExpectedDuration: int = 0
+    Priority: int = 0
+    SortingValueBreakdown: Optional[Dict[str, int]] = None
+    Dependencies: List[str] = field(default_factory=list)
+    DependenciesMet: bool = False
+    ActivatedBy: str = ""
+
+
+def BuildTaskQueue(tasks: Sequence[Task], maxScheduledTasks: int) -> List[TaskQueueItem]:
+    """What PersistTaskQueue hands to TaskQueue.Save (task_queue_persister.go:17-52, task_queue.go:269-272), from an
+    already planned task list: cap, build the items, truncate to 10,000. Host-object form; the batched device form is
+    evg_materialize_queue_device."""
+    out = []
+    for t in capTaskQueueLength(tasks, maxScheduledTasks):
+        out.append(TaskQueueItem(Id=t.Id, Group=t.TaskGroup, GroupMaxHosts=t.TaskGroupMaxHosts, GroupIndex=t.TaskGroupOrder, Version=t.Version,
+                                 BuildVariant=t.BuildVariant, Requester=t.Requester, Project=t.Project, ExpectedDuration=t.ExpectedDuration,
+                                 Priority=t.Priority, SortingValueBreakdown=t.SortingValueBreakdown, Dependencies=[d.TaskId for d in t.DependsOn],
+                                 DependenciesMet=t.HasDependenciesMet(), ActivatedBy=t.ActivatedBy))
+    return out[:abi.TASK_QUEUE_SAVE_LIMIT]
 
 
 class AllocatorError(Exception):

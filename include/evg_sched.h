@@ -331,6 +331,35 @@ int evg_cap_queue_device(evg_ctx* ctx, int32_t n_distros, const int32_t* task_of
                          const int32_t* order, const int32_t* tg_name_key, int32_t max_scheduled,
                          int32_t* cut, void* hip_stream);
 
+/* ---- PersistTaskQueue's queue materialisation -------------------------------------------------
+ * scheduler/task_queue_persister.go:17-62 + model/task_queue.go:181-205,269-275: cap the plan with capTaskQueueLength
+ * (task-group-aware cut), truncate to the 10,000-item limit of TaskQueue.Save, and build one model.TaskQueueItem per
+ * persisted queue position. Strings never cross the ABI, so an item carries the ROW of its task (the shim fills
+ * Id / DisplayName / BuildVariant / Revision / Project / Requester / Version / ActivatedBy / Group and the
+ * Dependencies id list from its own task slice) plus every numeric field of the item. Struct-of-arrays output,
+ * items of distro d at [item_off[d], item_off[d+1]) in queue order; each array must hold n_tasks entries. */
+#define EVG_TASK_QUEUE_SAVE_LIMIT 10000 /* model/task_queue.go:270-272 */
+typedef struct evg_queue_items {
+  int32_t* cut;                 /* D:   capTaskQueueLength result (tasks marked scheduled, persister :57)   */
+  int32_t* item_off;            /* D+1: persisted items per distro, prefix sums: min(cut, 10000)            */
+  int32_t* row;                 /* task row of the item (-> Id and the other strings)                       */
+  int64_t* expected_duration_ns;/* TaskQueueItem.ExpectedDuration (Task.ExpectedDuration set at scheduler.go:125) */
+  int64_t* priority;            /* TaskQueueItem.Priority                                                   */
+  int32_t* group_max_hosts;     /* TaskQueueItem.GroupMaxHosts                                              */
+  int32_t* group_index;         /* TaskQueueItem.GroupIndex  (Task.TaskGroupOrder)                          */
+  int32_t* n_dependencies;      /* len(TaskQueueItem.Dependencies) == len(Task.DependsOn)                   */
+  uint8_t* dependencies_met;    /* TaskQueueItem.DependenciesMet == Task.HasDependenciesMet() after planning */
+  int64_t* breakdown;           /* items x 13: TaskQueueItem.SortingValueBreakdown, or NULL to skip
+                                   (requires the plan's breakdown output)                                   */
+} evg_queue_items;
+
+/* `in` / `plan` are the inputs and outputs of a finished evg_plan_distros_device call on the same stream; tg_name_key
+ * is the interning of the bare Task.TaskGroup name (-1 for ""), as for evg_cap_queue_device. max_scheduled <= 0
+ * disables the cap (the 10,000 limit still applies). Device pointers; enqueued on hip_stream. */
+int evg_materialize_queue_device(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* plan,
+                                 const int32_t* tg_name_key, int32_t max_scheduled, const evg_queue_items* items,
+                                 void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1021,6 +1021,35 @@ int evg_oracle_cap_queue(int32_t n_distros, const int32_t* task_off, const int32
   return EVG_OK;
 }
 
+// PersistTaskQueue's item list  task_queue_persister.go:17-62 (+ TaskQueue.Save's 10,000 truncation, task_queue.go:269-272):
+// walks each distro's plan in queue order exactly like the reference's loop over `tasks`.
+int evg_oracle_materialize_queue(const evg_plan_input* in, const evg_plan_output* plan, const int32_t* tg_name_key,
+                                 int32_t max_scheduled, const evg_queue_items* it) {
+  const int D = in->n_distros;
+  evg_oracle_cap_queue(D, in->task_off, plan->order, tg_name_key, max_scheduled, it->cut);
+  int o = 0;
+  for (int d = 0; d < D; d++) {
+    it->item_off[d] = o;
+    int keep = it->cut[d];                                   // tasks = capTaskQueueLength(...)
+    if (keep > EVG_TASK_QUEUE_SAVE_LIMIT) keep = EVG_TASK_QUEUE_SAVE_LIMIT;  // tq.Queue = tq.Queue[:10000]
+    for (int p = 0; p < keep; p++, o++) {
+      const int r = plan->order[in->task_off[d] + p];
+      it->row[o] = r;
+      it->expected_duration_ns[o] = in->tasks.expected_duration_ns[r];
+      it->priority[o] = in->tasks.priority[r];
+      it->group_max_hosts[o] = in->tasks.task_group_max_hosts[r];
+      it->group_index[o] = in->tasks.task_group_order[r];
+      it->n_dependencies[o] = in->tasks.dep_off[r + 1] - in->tasks.dep_off[r];
+      it->dependencies_met[o] = plan->deps_met[r];
+      if (it->breakdown)
+        for (int k = 0; k < EVG_BREAKDOWN_FIELDS; k++)
+          it->breakdown[(size_t)o * EVG_BREAKDOWN_FIELDS + k] = plan->breakdown[(size_t)r * EVG_BREAKDOWN_FIELDS + k];
+    }
+  }
+  it->item_off[D] = o;
+  return EVG_OK;
+}
+
 // Direct access to calcNewHostsNeeded for its 9 known-answer vectors
 // (utilization_based_host_allocator_test.go:160-170).
 int evg_oracle_calc_new_hosts_needed(int64_t total_short_ns, int64_t max_duration_ns, int expected_free,

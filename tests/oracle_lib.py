@@ -33,6 +33,8 @@ def lib() -> C.CDLL:
         L.evg_oracle_plan_distro_range.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_int, C.c_int]
         L.evg_oracle_allocate_hosts.argtypes = [C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput)]
         L.evg_oracle_cap_queue.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.evg_oracle_materialize_queue.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p, C.c_int32,
+                                                   C.POINTER(abi.QueueItems)]
         L.evg_oracle_calc_new_hosts_needed.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.evg_oracle_cache_new.restype = C.c_void_p
         L.evg_oracle_cache_new.argtypes = [C.c_int64]
@@ -73,6 +75,14 @@ class OracleBackend:
         rc = lib().evg_oracle_allocate_hosts(C.byref(inp), C.byref(out))
         assert rc == 0, rc
         return res
+
+    def materialize_queue(self, batch: abi.PlanBatch, plan: abi.PlanResult, max_scheduled: int, breakdown: bool = True) -> abi.QueueItemsResult:
+        res = abi.QueueItemsResult.alloc_host(batch, breakdown=breakdown and plan.breakdown is not None)
+        inp, out, q = abi.make_plan_input(batch), plan.c_output(), res.c_struct()
+        rc = lib().evg_oracle_materialize_queue(C.byref(inp), C.byref(out), batch.tg_name_key.ctypes.data if batch.n_tasks else None,
+                                                max_scheduled, C.byref(q))
+        assert rc == 0
+        return res.trimmed()
 
     def cap_queue(self, batch: abi.PlanBatch, order: np.ndarray, max_scheduled: int) -> np.ndarray:
         cut = np.zeros(batch.n_distros, np.int32)
