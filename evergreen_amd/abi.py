@@ -107,6 +107,11 @@ ALLOC_PARAMS_DTYPE = np.dtype([
     ("provider", "<i4"), ("disabled", "<i4"), ("round_up", "<i4"),
     ("feedback_waits_over_thresh", "<i4")], align=True)
 
+REPORT_PARAMS_DTYPE = np.dtype([("n_up_hosts", "<i4"), ("minimum_hosts", "<i4"), ("drawdown_allowed", "<i4"), ("reserved", "<i4")], align=True)
+ALLOC_REPORT_DTYPE = np.dtype([("time_to_empty_ns", "<i8"), ("time_to_empty_no_spawns_ns", "<i8"), ("host_queue_ratio", "<f4"),
+                               ("no_spawns_ratio", "<f4"), ("hosts_avail", "<i4"), ("drawdown", "<i4"), ("new_cap_target", "<i4"),
+                               ("killable_hosts", "<i4")], align=True)
+assert REPORT_PARAMS_DTYPE.itemsize == 16 and ALLOC_REPORT_DTYPE.itemsize == 40
 assert DISTRO_PARAMS_DTYPE.itemsize == 88
 assert GROUP_INFO_DTYPE.itemsize == 48
 assert DISTRO_INFO_DTYPE.itemsize == 56

@@ -139,6 +139,60 @@ __global__ void __launch_bounds__(256) k_queue_items(const evg_plan_input in, co
   }
 }
 
+// ---- the host-allocator job's report math (units/host_allocator.go:250-334,393-424): one wave per distro --------
+__global__ void __launch_bounds__(64) k_allocator_report(int D, const int32_t* tg_off, const evg_distro_info* distro_info,
+                                                         const evg_group_info* group_info, const int32_t* hosts_spawned,
+                                                         const int32_t* free_hosts, const evg_report_params* params, evg_alloc_report* report) {
+  const int d = blockIdx.x, lane = threadIdx.x;
+  const int g0 = tg_off[d], g1 = tg_off[d + 1];
+  // sums over the NAMED task groups of the distro (:268-277)
+  uint32_t overdue = 0, n_over = 0, n_free = 0, n_req = 0;
+  uint64_t dur_over = 0, dur = 0;
+  for (int k = g0 + lane; k < g1; k += 64) {
+    const evg_group_info g = group_info[D + k];
+    if (!g.present) continue;
+    overdue += (uint32_t)g.count_wait_over_threshold; n_over += (uint32_t)g.count_duration_over_threshold;
+    dur_over += (uint64_t)g.duration_over_threshold_ns; dur += (uint64_t)g.expected_duration_ns;
+    n_free += (uint32_t)g.count_free; n_req += (uint32_t)g.count_required;
+  }
+  n_over = wave_sum(n_over); n_free = wave_sum(n_free); n_req = wave_sum(n_req);
+  dur_over = wave_sum(dur_over); dur = wave_sum(dur);
+  (void)overdue;
+  if (lane != 0) return;
+  const evg_distro_info di = distro_info[d];
+  const evg_report_params p = params[d];
+  const int64_t corrected_expected = wrap_sub(di.expected_duration_ns, (int64_t)dur);                 // :280
+  const int64_t corrected_over = wrap_sub(di.duration_over_threshold_ns, (int64_t)dur_over);          // :282
+  const int64_t scheduled = wrap_sub(corrected_expected, corrected_over);                             // :284
+  const int over_no_tg = di.count_duration_over_threshold - (int)n_over;                              // :286
+  const int corrected_spawned = hosts_spawned[d] - (int)n_req;                                        // :289
+  const int hosts_avail = (free_hosts[d] - (int)n_free) + corrected_spawned - over_no_tg;             // :291
+  const int64_t kMaxPossible = 2532000LL * kHour;                                                     // :305
+  int64_t tte = 0, tte_ns = 0;
+  if (scheduled > 0) {
+    const int avail_ns = hosts_avail - corrected_spawned;
+    if (hosts_avail <= 0) { tte = kMaxPossible; tte_ns = kMaxPossible; }
+    else if (avail_ns <= 0) { tte = scheduled / hosts_avail; tte_ns = kMaxPossible; }
+    else { tte = scheduled / hosts_avail; tte_ns = scheduled / avail_ns; }
+  }
+  evg_alloc_report r;
+  r.time_to_empty_ns = tte;
+  r.time_to_empty_no_spawns_ns = tte_ns;
+  r.host_queue_ratio = (float)tte / (float)di.max_duration_threshold_ns;                              // :319 float32 / float32
+  r.no_spawns_ratio = (float)tte_ns / (float)di.max_duration_threshold_ns;                            // :321
+  r.hosts_avail = hosts_avail;
+  r.drawdown = 0; r.new_cap_target = 0; r.killable_hosts = 0;
+  if (p.drawdown_allowed && r.host_queue_ratio < 0.25f && p.n_up_hosts > 0) {                         // :327
+    int killable, target = 0;                                                                          // :393-404
+    if (r.host_queue_ratio == 0.0f) killable = p.n_up_hosts;
+    else { killable = (int)((float)p.n_up_hosts * (1.0f - r.host_queue_ratio)); target = p.n_up_hosts - killable; }
+    if (target < p.minimum_hosts) target = p.minimum_hosts;
+    r.killable_hosts = killable;
+    if (killable > 0) { r.drawdown = 1; r.new_cap_target = target; }                                   // :407
+  }
+  report[d] = r;
+}
+
 }  // namespace evg
 
 // =============================================================================================================
@@ -482,6 +536,21 @@ int evg_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, const evg
                      items->item_off);
   HIP_TRY(c, hipGetLastError());
   hipLaunchKernelGGL(evg::k_queue_items, dim3((EVG_TASK_QUEUE_SAVE_LIMIT + 255) / 256, D), dim3(256), 0, st, *in, *plan, *items);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
+int evg_allocator_report_device(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
+                                const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
+                                const evg_report_params* params, evg_alloc_report* report, void* hip_stream) {
+  if (!c || n_distros < 0) return EVG_E_INVALID;
+  if (n_distros == 0) return EVG_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!tg_off || !distro_info || !group_info || !hosts_spawned || !free_hosts || !params || !report)
+    return set_err(c, EVG_E_INVALID, "null allocator-report argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(evg::k_allocator_report, dim3(n_distros), dim3(64), 0, (hipStream_t)hip_stream, n_distros, tg_off, distro_info,
+                     group_info, hosts_spawned, free_hosts, params, report);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }

@@ -520,6 +520,70 @@ def BuildTaskQueue(tasks: Sequence[Task], maxScheduledTasks: int) -> List[TaskQu
     return out[:abi.TASK_QUEUE_SAVE_LIMIT]
 
 
+@dataclass
+class AllocatorReport:                             # what units/host_allocator.go:250-334,393-424 computes after the allocator
+    timeToEmpty: int = 0
+    timeToEmptyNoSpawns: int = 0
+    hostQueueRatio: float = 0.0
+    noSpawnsRatio: float = 0.0
+    hostsAvail: int = 0
+    drawdown: bool = False
+    NewCapTarget: int = 0
+    killableHosts: int = 0
+
+
+def HostAllocatorReport(info: DistroQueueInfo, hostsSpawned: int, nHostsFree: int, numUpHosts: int, minimumHosts: int,
+                        drawdownAllowed: bool) -> AllocatorReport:
+    """Host-object restatement of the allocator job's report math (units/host_allocator.go:250-334) and of
+    setTargetAndTerminate (:393-424); float32 steps via numpy.float32. The batched device form is
+    evg_allocator_report_device."""
+    f32 = np.float32
+    freeTG = reqTG = overTG = 0
+    durOverTG = durTG = 0
+    for g in info.TaskGroupInfos:
+        if g.Name != "":
+            overTG += g.CountDurationOverThreshold
+            durOverTG += g.DurationOverThreshold
+            durTG += g.ExpectedDuration
+            freeTG += g.CountFree
+            reqTG += g.CountRequired
+    scheduled = (info.ExpectedDuration - durTG) - (info.DurationOverThreshold - durOverTG)
+    overNoTG = info.CountDurationOverThreshold - overTG
+    correctedSpawned = hostsSpawned - reqTG
+    hostsAvail = (nHostsFree - freeTG) + correctedSpawned - overNoTG
+    maxD = 2532000 * HOUR
+    tte = tteNS = 0
+    if scheduled > 0:
+        noSpawns = hostsAvail - correctedSpawned
+        if hostsAvail <= 0:
+            tte = tteNS = maxD
+        elif noSpawns <= 0:
+            tte, tteNS = int(scheduled / hostsAvail) if False else _go_div(scheduled, hostsAvail), maxD
+        else:
+            tte, tteNS = _go_div(scheduled, hostsAvail), _go_div(scheduled, noSpawns)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = f32(tte) / f32(info.MaxDurationThreshold)
+        ratioNS = f32(tteNS) / f32(info.MaxDurationThreshold)
+    rep = AllocatorReport(tte, tteNS, float(ratio), float(ratioNS), hostsAvail)
+    if drawdownAllowed and ratio < f32(0.25) and numUpHosts > 0:
+        target = 0
+        if ratio == 0:
+            killable = numUpHosts
+        else:
+            killable = int(f32(numUpHosts) * (f32(1) - ratio))
+            target = numUpHosts - killable
+        target = max(target, minimumHosts)
+        rep.killableHosts = killable
+        if killable > 0:
+            rep.drawdown, rep.NewCapTarget = True, target
+    return rep
+
+
+def _go_div(a: int, b: int) -> int:                # Go's integer division truncates toward zero
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
 class AllocatorError(Exception):
     pass
 

@@ -360,6 +360,36 @@ int evg_materialize_queue_device(evg_ctx* ctx, const evg_plan_input* in, const e
                                  const int32_t* tg_name_key, int32_t max_scheduled, const evg_queue_items* items,
                                  void* hip_stream);
 
+/* ---- the host-allocator job's report math ------------------------------------------------------
+ * units/host_allocator.go:250-334 (time-to-empty of the standalone queue on the hosts expected to be available,
+ * with and without the hosts just spawned; its ratio to MaxDurationThreshold) and :393-424 (setTargetAndTerminate:
+ * how many up hosts can be drawn down and the new capacity target). Closed forms per distro over the
+ * DistroQueueInfo / TaskGroupInfo rows the planner and the allocator produced. float32 steps are IEEE single like Go's. */
+typedef struct evg_report_params {
+  int32_t n_up_hosts;        /* len(upHosts)                                              host_allocator.go:161 */
+  int32_t minimum_hosts;     /* HostAllocatorSettings.MinimumHosts                                         :403 */
+  int32_t drawdown_allowed;  /* HostsOverallocatedRule == terminate && provider spawnable && !hourly billing
+                                                                                                   :327-333     */
+  int32_t reserved;
+} evg_report_params;
+
+typedef struct evg_alloc_report {
+  int64_t time_to_empty_ns;            /* timeToEmpty            :294-316 */
+  int64_t time_to_empty_no_spawns_ns;  /* timeToEmptyNoSpawns             */
+  float host_queue_ratio;              /* hostQueueRatio         :319     */
+  float no_spawns_ratio;               /* noSpawnsRatio          :321     */
+  int32_t hosts_avail;                 /* hostsAvail             :291     */
+  int32_t drawdown;                    /* 1 iff setTargetAndTerminate enqueues a drawdown job (:327-333, :407) */
+  int32_t new_cap_target;              /* DrawdownInfo.NewCapTarget (:399-404); 0 when drawdown == 0 */
+  int32_t killable_hosts;              /* :396-398; 0 when the ratio test of :327 fails */
+} evg_alloc_report;
+
+/* hosts_spawned[d] = len(hostsSpawned) (normally new_hosts[d] of evg_allocate_hosts); free_hosts[d] = nHostsFree;
+ * group_info carries count_free / count_required from the allocator. Device pointers; enqueued on hip_stream. */
+int evg_allocator_report_device(evg_ctx* ctx, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
+                                const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
+                                const evg_report_params* params, evg_alloc_report* report, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

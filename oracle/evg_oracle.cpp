@@ -1050,6 +1050,63 @@ int evg_oracle_materialize_queue(const evg_plan_input* in, const evg_plan_output
   return EVG_OK;
 }
 
+// The host-allocator job's report math  units/host_allocator.go:250-334 and setTargetAndTerminate :393-424.
+int evg_oracle_allocator_report(int32_t D, const int32_t* tg_off, const evg_distro_info* distro_info, const evg_group_info* group_info,
+                                const int32_t* hosts_spawned, const int32_t* free_hosts, const evg_report_params* params,
+                                evg_alloc_report* report) {
+  for (int d = 0; d < D; d++) {
+    int totalOverdueInTaskGroups = 0, countDurationOverThresholdInTaskGroups = 0, freeInTaskGroups = 0, requiredInTaskGroups = 0;
+    Duration durationOverThresholdInTaskGroups = 0, expectedDurationInTaskGroups = 0;
+    for (int k = tg_off[d]; k < tg_off[d + 1]; k++) {  // for _, info := range TaskGroupInfos { if info.Name != "" {...} }
+      const evg_group_info& info = group_info[D + k];
+      if (!info.present) continue;
+      totalOverdueInTaskGroups += info.count_wait_over_threshold;
+      countDurationOverThresholdInTaskGroups += info.count_duration_over_threshold;
+      durationOverThresholdInTaskGroups = wrap_add(durationOverThresholdInTaskGroups, info.duration_over_threshold_ns);
+      expectedDurationInTaskGroups = wrap_add(expectedDurationInTaskGroups, info.expected_duration_ns);
+      freeInTaskGroups += info.count_free;
+      requiredInTaskGroups += info.count_required;
+    }
+    (void)totalOverdueInTaskGroups;
+    const evg_distro_info& q = distro_info[d];
+    const Duration correctedExpectedDuration = wrap_sub(q.expected_duration_ns, expectedDurationInTaskGroups);
+    const Duration correctedDurationOverThreshold = wrap_sub(q.duration_over_threshold_ns, durationOverThresholdInTaskGroups);
+    const Duration scheduledDuration = wrap_sub(correctedExpectedDuration, correctedDurationOverThreshold);
+    const int durationOverThreshNoTaskGroups = q.count_duration_over_threshold - countDurationOverThresholdInTaskGroups;
+    const int correctedHostsSpawned = hosts_spawned[d] - requiredInTaskGroups;
+    const int hostsAvail = (free_hosts[d] - freeInTaskGroups) + correctedHostsSpawned - durationOverThreshNoTaskGroups;
+    Duration timeToEmpty = 0, timeToEmptyNoSpawns = 0;
+    if (scheduledDuration > 0) {
+      const int64_t maxPossibleHours = 2532000;
+      const int hostsAvailNoSpawns = hostsAvail - correctedHostsSpawned;
+      if (hostsAvail <= 0) {
+        timeToEmpty = maxPossibleHours * kHour; timeToEmptyNoSpawns = maxPossibleHours * kHour;
+      } else if (hostsAvailNoSpawns <= 0) {
+        timeToEmpty = scheduledDuration / hostsAvail; timeToEmptyNoSpawns = maxPossibleHours * kHour;
+      } else {
+        timeToEmpty = scheduledDuration / hostsAvail; timeToEmptyNoSpawns = scheduledDuration / hostsAvailNoSpawns;
+      }
+    }
+    evg_alloc_report r;
+    r.time_to_empty_ns = timeToEmpty; r.time_to_empty_no_spawns_ns = timeToEmptyNoSpawns;
+    r.host_queue_ratio = (float)timeToEmpty / (float)q.max_duration_threshold_ns;
+    r.no_spawns_ratio = (float)timeToEmptyNoSpawns / (float)q.max_duration_threshold_ns;
+    r.hosts_avail = hostsAvail; r.drawdown = 0; r.new_cap_target = 0; r.killable_hosts = 0;
+    const float lowRatioThresh = 0.25f;
+    const evg_report_params& p = params[d];
+    if (p.drawdown_allowed && r.host_queue_ratio < lowRatioThresh && p.n_up_hosts > 0) {
+      int killableHosts = 0, newCapTarget = 0;  // setTargetAndTerminate
+      if (r.host_queue_ratio == 0) killableHosts = p.n_up_hosts;
+      else { killableHosts = (int)((float)p.n_up_hosts * (1 - r.host_queue_ratio)); newCapTarget = p.n_up_hosts - killableHosts; }
+      if (newCapTarget < p.minimum_hosts) newCapTarget = p.minimum_hosts;
+      r.killable_hosts = killableHosts;
+      if (killableHosts > 0) { r.drawdown = 1; r.new_cap_target = newCapTarget; }
+    }
+    report[d] = r;
+  }
+  return EVG_OK;
+}
+
 // Direct access to calcNewHostsNeeded for its 9 known-answer vectors
 // (utilization_based_host_allocator_test.go:160-170).
 int evg_oracle_calc_new_hosts_needed(int64_t total_short_ns, int64_t max_duration_ns, int expected_free,

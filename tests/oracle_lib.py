@@ -35,6 +35,7 @@ def lib() -> C.CDLL:
         L.evg_oracle_cap_queue.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.evg_oracle_materialize_queue.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p, C.c_int32,
                                                    C.POINTER(abi.QueueItems)]
+        L.evg_oracle_allocator_report.argtypes = [C.c_int32] + [C.c_void_p] * 7
         L.evg_oracle_calc_new_hosts_needed.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.evg_oracle_cache_new.restype = C.c_void_p
         L.evg_oracle_cache_new.argtypes = [C.c_int64]
@@ -83,6 +84,13 @@ class OracleBackend:
                                                 max_scheduled, C.byref(q))
         assert rc == 0
         return res.trimmed()
+
+    def allocator_report(self, n_distros, tg_off, distro_info, group_info, hosts_spawned, free_hosts, params) -> np.ndarray:
+        rep = np.zeros(n_distros, abi.ALLOC_REPORT_DTYPE)
+        rc = lib().evg_oracle_allocator_report(n_distros, tg_off.ctypes.data, distro_info.ctypes.data, group_info.ctypes.data,
+                                               hosts_spawned.ctypes.data, free_hosts.ctypes.data, params.ctypes.data, rep.ctypes.data)
+        assert rc == 0
+        return rep
 
     def cap_queue(self, batch: abi.PlanBatch, order: np.ndarray, max_scheduled: int) -> np.ndarray:
         cut = np.zeros(batch.n_distros, np.int32)

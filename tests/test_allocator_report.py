@@ -1,0 +1,105 @@
+"""the host-allocator job's report math (units/host_allocator.go:250-334, setTargetAndTerminate :393-424).
+CPU: the oracle against the host-object restatement (scheduler.HostAllocatorReport) on the allocator's own golden
+scenarios and on a synthetic pool. GPU: evg_allocator_report_device against the oracle, bit for bit (incl. float32)."""
+import numpy as np
+import pytest
+
+from evergreen_amd import abi, gen
+from evergreen_amd import scheduler as S
+from tests import golden_cases as G
+
+
+def _random_rows(seed, D=600):
+    """Random DistroQueueInfo / TaskGroupInfo rows covering every branch of the report math: nothing short queued,
+    no hosts available, no hosts without the spawned ones, ordinary; ratios on both sides of the 0.25 drawdown line."""
+    rng = np.random.default_rng(seed)
+    ntg = rng.integers(0, 6, D)
+    tg_off = np.zeros(D + 1, np.int32)
+    tg_off[1:] = np.cumsum(ntg)
+    G_ = int(tg_off[-1])
+    di = np.zeros(D, abi.DISTRO_INFO_DTYPE)
+    gi = np.zeros(D + G_, abi.GROUP_INFO_DTYPE)
+    gi["present"][D:] = rng.random(G_) < 0.9
+    gi["expected_duration_ns"][D:] = rng.integers(0, 3 * S.HOUR, G_)
+    gi["duration_over_threshold_ns"][D:] = (gi["expected_duration_ns"][D:] * rng.random(G_)).astype(np.int64)
+    gi["count_duration_over_threshold"][D:] = rng.integers(0, 4, G_)
+    gi["count_free"][D:] = rng.integers(0, 3, G_)
+    gi["count_required"][D:] = rng.integers(0, 3, G_)
+    for d in range(D):
+        rows = gi[D + tg_off[d]:D + tg_off[d + 1]]
+        rows = rows[rows["present"] != 0]
+        di["expected_duration_ns"][d] = int(rows["expected_duration_ns"].sum()) + int(rng.integers(0, 40)) * 17 * S.MINUTE * int(rng.random() < 0.8)
+        di["duration_over_threshold_ns"][d] = int(rows["duration_over_threshold_ns"].sum()) + int(rng.integers(0, 3)) * 45 * S.MINUTE
+        di["count_duration_over_threshold"][d] = int(rows["count_duration_over_threshold"].sum()) + int(rng.integers(0, 3))
+    di["max_duration_threshold_ns"] = rng.choice([30 * S.MINUTE, 5 * S.MINUTE, S.HOUR], D)
+    spawned = rng.integers(0, 12, D).astype(np.int32)
+    free = rng.integers(0, 40, D).astype(np.int32)
+    params = np.zeros(D, abi.REPORT_PARAMS_DTYPE)
+    params["n_up_hosts"] = rng.integers(0, 60, D)
+    params["minimum_hosts"] = rng.integers(0, 5, D)
+    params["drawdown_allowed"] = rng.random(D) < 0.7
+    return tg_off, di, gi, spawned, free, params
+
+
+def test_oracle_report_matches_host_object_restatement(oracle):
+    tg_off, di_rows, gi, spawned, free, params = _random_rows(3)
+    D = len(di_rows)
+    rep = oracle.allocator_report(D, tg_off, di_rows, gi, spawned, free, params)
+    seen = {"drawdown": 0, "max": 0, "zero": 0, "nospawn_max": 0, "normal": 0}
+    for d in range(D):
+        di = di_rows[d]
+        info = S.DistroQueueInfo(ExpectedDuration=int(di["expected_duration_ns"]), DurationOverThreshold=int(di["duration_over_threshold_ns"]),
+                                 CountDurationOverThreshold=int(di["count_duration_over_threshold"]),
+                                 MaxDurationThreshold=int(di["max_duration_threshold_ns"]))
+        for k in range(int(tg_off[d]), int(tg_off[d + 1])):
+            g = gi[D + k]
+            if g["present"]:
+                info.TaskGroupInfos.append(S.TaskGroupInfo(Name="g%d" % k, CountFree=int(g["count_free"]), CountRequired=int(g["count_required"]),
+                                                           ExpectedDuration=int(g["expected_duration_ns"]),
+                                                           CountDurationOverThreshold=int(g["count_duration_over_threshold"]),
+                                                           DurationOverThreshold=int(g["duration_over_threshold_ns"])))
+        want = S.HostAllocatorReport(info, int(spawned[d]), int(free[d]), int(params[d]["n_up_hosts"]),
+                                     int(params[d]["minimum_hosts"]), bool(params[d]["drawdown_allowed"]))
+        r = rep[d]
+        assert int(r["time_to_empty_ns"]) == want.timeToEmpty and int(r["time_to_empty_no_spawns_ns"]) == want.timeToEmptyNoSpawns, d
+        assert np.float32(r["host_queue_ratio"]) == np.float32(want.hostQueueRatio) and np.float32(r["no_spawns_ratio"]) == np.float32(want.noSpawnsRatio)
+        assert int(r["hosts_avail"]) == want.hostsAvail
+        assert (bool(r["drawdown"]), int(r["new_cap_target"]), int(r["killable_hosts"])) == (want.drawdown, want.NewCapTarget, want.killableHosts)
+        mx = 2532000 * S.HOUR
+        seen["drawdown"] += int(r["drawdown"])
+        seen["max"] += int(r["time_to_empty_ns"] == mx)
+        seen["zero"] += int(r["time_to_empty_ns"] == 0)
+        seen["nospawn_max"] += int(r["time_to_empty_no_spawns_ns"] == mx and r["time_to_empty_ns"] != mx)
+        seen["normal"] += int(0 < r["time_to_empty_no_spawns_ns"] < mx)
+    assert all(v > 0 for v in seen.values()), seen
+
+
+def test_report_on_the_allocators_golden_scenarios(oracle):
+    """The reference's allocator scenarios, pushed through allocate + report: time-to-empty is non-negative, zero when
+    nothing short is queued, and the 'no spawns' estimate is never faster than the one with the spawned hosts."""
+    for name, data, running, want, line in G.allocator_cases():
+        n, free, err = S.AllocateHosts(oracle, [data], G.NOW, running.get)[0]
+        r = S.HostAllocatorReport(data.DistroQueueInfo, n, free, len(data.ExistingHosts), data.Distro.HostAllocatorSettings.MinimumHosts, True)
+        assert r.timeToEmpty >= 0 and r.timeToEmptyNoSpawns >= r.timeToEmpty, name
+        q = data.DistroQueueInfo
+        short = (q.ExpectedDuration - sum(g.ExpectedDuration for g in q.TaskGroupInfos if g.Name)) - (
+            q.DurationOverThreshold - sum(g.DurationOverThreshold for g in q.TaskGroupInfos if g.Name))
+        if short <= 0:
+            assert r.timeToEmpty == 0 and (q.MaxDurationThreshold == 0 or r.hostQueueRatio == 0), name  # 0/0 is NaN in Go too
+
+
+@pytest.mark.gpu
+def test_hip_report_matches_oracle(native_ctx, oracle):
+    import torch
+    tg_off, di_rows, gi, spawned, free, params = _random_rows(4, D=2000)
+    want = oracle.allocator_report(len(di_rows), tg_off, di_rows, gi, spawned, free, params)
+    n_distros = len(di_rows)
+    dev = torch.device("cuda:0")
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a.view(np.uint8) if a.dtype.fields else a)).to(dev)  # noqa: E731
+    t = [up(tg_off), up(di_rows), up(gi), up(spawned), up(free), up(params)]
+    out = torch.zeros(n_distros * abi.ALLOC_REPORT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    native_ctx.allocator_report_device(n_distros, *[x.data_ptr() for x in t], out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(abi.ALLOC_REPORT_DTYPE)
+    for name in abi.ALLOC_REPORT_DTYPE.names:
+        assert np.array_equal(got[name], want[name], equal_nan=got[name].dtype.kind == "f"), name
