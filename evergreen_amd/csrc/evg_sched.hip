@@ -139,6 +139,66 @@ __global__ void __launch_bounds__(256) k_queue_items(const evg_plan_input in, co
   }
 }
 
+// ---- the task finder's dependency filter (scheduler/task_finder.go:40-116): one 256-thread workgroup per distro ----
+// Task.DependenciesMet per row (same edge semantics as the planner's phase G), then an order-preserving compaction of
+// the kept rows by ballot prefix counts.
+__global__ void __launch_bounds__(256) k_filter_runnable(const evg_plan_input in, const uint8_t* dispatchable, uint8_t* deps_met,
+                                                         uint8_t* keep, int32_t* runnable_row, int32_t* runnable_count) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = in.task_off[d], n = in.task_off[d + 1] - lo;
+  const bool check = in.distros[d].includes_dependencies == 0;  // task_finder.go:56,85
+  const evg_task_soa& t = in.tasks;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    bool k = false;
+    if (i < n) {
+      const int r = lo + i;
+      const uint32_t f = t.flags[r];
+      const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
+      bool met = true;
+      if (check) {
+        met = (e1 == e0) || (f & EVG_TF_OVERRIDE_DEPS) || !is_zero_time(t.deps_met_ts_ns[r]);  // HasDependenciesMet task.go:3406
+        if (!met) {
+          met = true;
+          for (int e = e0; e < e1 && met; e++) {
+            const int j = t.dep_idx[e];
+            const uint32_t info = t.dep_info[e];
+            uint32_t st;
+            bool blk;
+            if (j >= lo && j < lo + n) {
+              const uint32_t fj = t.flags[j];
+              st = (fj & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT; blk = fj & EVG_TF_BLOCKED;
+            } else {
+              if (info & EVG_DEP_MISSING) { met = false; break; }
+              st = (info & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT; blk = info & EVG_DEP_BLOCKED;
+            }
+            const uint32_t req = info & EVG_DEP_REQ_MASK;
+            met = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
+          }
+        }
+      }
+      k = dispatchable[r] != 0 && met;
+      deps_met[r] = met ? 1 : 0;
+      keep[r] = k ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(k);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    if (k) runnable_row[lo + off + before] = lo + i;
+    __syncthreads();
+    if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (tid == 0) runnable_count[d] = s_base;
+}
+
 // ---- the host-allocator job's report math (units/host_allocator.go:250-334,393-424): one wave per distro --------
 __global__ void __launch_bounds__(64) k_allocator_report(int D, const int32_t* tg_off, const evg_distro_info* distro_info,
                                                          const evg_group_info* group_info, const int32_t* hosts_spawned,
@@ -536,6 +596,21 @@ int evg_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, const evg
                      items->item_off);
   HIP_TRY(c, hipGetLastError());
   hipLaunchKernelGGL(evg::k_queue_items, dim3((EVG_TASK_QUEUE_SAVE_LIMIT + 255) / 256, D), dim3(256), 0, st, *in, *plan, *items);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
+int evg_filter_runnable_device(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
+                               int32_t* runnable_row, int32_t* runnable_count, void* hip_stream) {
+  if (!c || !in) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (in->n_distros < 0 || in->tasks.n_tasks < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
+  if (in->n_distros == 0) return EVG_OK;
+  if (!runnable_count || (in->tasks.n_tasks > 0 && (!dispatchable || !deps_met || !keep || !runnable_row)))
+    return set_err(c, EVG_E_INVALID, "null finder-filter argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(evg::k_filter_runnable, dim3(in->n_distros), dim3(256), 0, (hipStream_t)hip_stream, *in, dispatchable, deps_met, keep,
+                     runnable_row, runnable_count);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }

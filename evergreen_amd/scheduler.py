@@ -520,6 +520,41 @@ def BuildTaskQueue(tasks: Sequence[Task], maxScheduledTasks: int) -> List[TaskQu
     return out[:abi.TASK_QUEUE_SAVE_LIMIT]
 
 
+def FindRunnableTasks(d: Distro, undispatched: Sequence[Task], can_dispatch: Callable[[Task], bool],
+                      dep_lookup: Optional[DepLookup] = None) -> List[Task]:
+    """Host-object restatement of LegacyFindRunnableTasks' filter (scheduler/task_finder.go:40-116) after the DB queries:
+    `undispatched` is what task.FindHostSchedulable returned, `can_dispatch` folds the project-ref checks (:59-84),
+    `dep_lookup` stands for getDependencyTaskCache's batched fetch of dependencies outside the list (:289-320)."""
+    cache = {t.Id: t for t in undispatched}
+    check = d.DispatcherSettings.Version != DispatcherVersionRevisedWithDependencies
+    out = []
+    for t in undispatched:
+        if not can_dispatch(t):
+            continue
+        if check and not t.HasDependenciesMet():
+            ok = True
+            for dep in t.DependsOn:
+                if dep.TaskId in cache:
+                    other = cache[dep.TaskId]
+                    status, blocked = other.Status, other.Blocked()
+                else:
+                    found = dep_lookup(dep.TaskId) if dep_lookup else None
+                    if found is None:
+                        ok = False                 # DependenciesMet returns an error: "skipping" (:86-99)
+                        break
+                    status, blocked = found
+                req = _dep_req(t, dep.TaskId)      # SatisfiesDependency scans DependsOn for that id (task.go:546-561)
+                sat = (status == TaskSucceeded if req == abi.DEP_REQ_SUCCESS else status == TaskFailed if req == abi.DEP_REQ_FAILED
+                       else (status in (TaskSucceeded, TaskFailed) or blocked) if req == abi.DEP_REQ_ALL else False)
+                if not sat:
+                    ok = False
+                    break
+            if not ok:
+                continue
+        out.append(t)
+    return out
+
+
 @dataclass
 class AllocatorReport:                             # what units/host_allocator.go:250-334,393-424 computes after the allocator
     timeToEmpty: int = 0

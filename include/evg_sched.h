@@ -360,6 +360,19 @@ int evg_materialize_queue_device(evg_ctx* ctx, const evg_plan_input* in, const e
                                  const int32_t* tg_name_key, int32_t max_scheduled, const evg_queue_items* items,
                                  void* hip_stream);
 
+/* ---- the task finder's dependency filter -------------------------------------------------------
+ * scheduler/task_finder.go:40-116 (LegacyFindRunnableTasks): of the undispatched tasks of each distro keep, in input
+ * order, those whose project may dispatch them (dispatchable[row], decided on the host: ProjectCanDispatchTask and
+ * the distro's ValidProjects, :59-84) and -- unless the distro's dispatcher is "revised-with-dependencies"
+ * (evg_distro_params.includes_dependencies) -- whose dependencies are met (Task.DependenciesMet, task.go:649-688, with
+ * getDependencyTaskCache's statuses in flags / dep_info; a dependency missing from the DB is an error => skipped, :86-99).
+ * The Mongo queries (task.FindHostSchedulable, the project-ref cache) stay on the host. `in` is the candidate pool in
+ * the planner's own layout. Outputs: deps_met[N] (what DependenciesMet returned; 1 when the check is not performed),
+ * keep[N], runnable_count[D] and runnable_row[N] = the kept rows of distro d, in input order, at
+ * [task_off[d], task_off[d] + runnable_count[d]). Device pointers; enqueued on hip_stream. */
+int evg_filter_runnable_device(evg_ctx* ctx, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met,
+                               uint8_t* keep, int32_t* runnable_row, int32_t* runnable_count, void* hip_stream);
+
 /* ---- the host-allocator job's report math ------------------------------------------------------
  * units/host_allocator.go:250-334 (time-to-empty of the standalone queue on the hosts expected to be available,
  * with and without the hosts just spawned; its ratio to MaxDurationThreshold) and :393-424 (setTargetAndTerminate:

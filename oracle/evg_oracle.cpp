@@ -1050,6 +1050,49 @@ int evg_oracle_materialize_queue(const evg_plan_input* in, const evg_plan_output
   return EVG_OK;
 }
 
+// LegacyFindRunnableTasks' filter  scheduler/task_finder.go:40-116: walks each distro's undispatched tasks in order and keeps
+// the ones whose project may dispatch them and (unless the dispatcher is revised-with-dependencies) whose dependencies are met.
+int evg_oracle_filter_runnable(const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
+                               int32_t* runnable_row, int32_t* runnable_count) {
+  const evg_task_soa& t = in->tasks;
+  for (int d = 0; d < in->n_distros; d++) {
+    const int lo = in->task_off[d], hi = in->task_off[d + 1];
+    const bool check = in->distros[d].includes_dependencies == 0;  // d.DispatcherSettings.Version != revised-with-dependencies
+    int kept = 0;
+    for (int r = lo; r < hi; r++) {
+      bool met = true;
+      if (check) {
+        // t.DependenciesMet(ctx, dependencyCaches)  task.go:649-688
+        const bool has = t.dep_off[r + 1] == t.dep_off[r] || (t.flags[r] & EVG_TF_OVERRIDE_DEPS) || !is_zero_time(t.deps_met_ts_ns[r]);
+        if (!has) {
+          for (int e = t.dep_off[r]; e < t.dep_off[r + 1] && met; e++) {
+            const int j = t.dep_idx[e];
+            const uint8_t info = t.dep_info[e];
+            unsigned st;
+            bool blk;
+            if (j >= lo && j < hi) {  // cache[t.Id] = t for every undispatched task  task_finder.go:295-297
+              st = (t.flags[j] & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT;
+              blk = (t.flags[j] & EVG_TF_BLOCKED) != 0;
+            } else {
+              if (info & EVG_DEP_MISSING) { met = false; break; }  // error => "skipping"  :86-99
+              st = (info & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT;
+              blk = (info & EVG_DEP_BLOCKED) != 0;
+            }
+            const unsigned req = info & EVG_DEP_REQ_MASK;  // SatisfiesDependency task.go:546-561
+            met = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
+          }
+        }
+      }
+      const bool k = dispatchable[r] != 0 && met;
+      deps_met[r] = met ? 1 : 0;
+      keep[r] = k ? 1 : 0;
+      if (k) runnable_row[lo + kept++] = r;  // runnableTasks = append(runnableTasks, t)
+    }
+    runnable_count[d] = kept;
+  }
+  return EVG_OK;
+}
+
 // The host-allocator job's report math  units/host_allocator.go:250-334 and setTargetAndTerminate :393-424.
 int evg_oracle_allocator_report(int32_t D, const int32_t* tg_off, const evg_distro_info* distro_info, const evg_group_info* group_info,
                                 const int32_t* hosts_spawned, const int32_t* free_hosts, const evg_report_params* params,

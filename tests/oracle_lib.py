@@ -35,6 +35,7 @@ def lib() -> C.CDLL:
         L.evg_oracle_cap_queue.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.evg_oracle_materialize_queue.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p, C.c_int32,
                                                    C.POINTER(abi.QueueItems)]
+        L.evg_oracle_filter_runnable.argtypes = [C.POINTER(abi.PlanInput)] + [C.c_void_p] * 5
         L.evg_oracle_allocator_report.argtypes = [C.c_int32] + [C.c_void_p] * 7
         L.evg_oracle_calc_new_hosts_needed.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.evg_oracle_cache_new.restype = C.c_void_p
@@ -84,6 +85,16 @@ class OracleBackend:
                                                 max_scheduled, C.byref(q))
         assert rc == 0
         return res.trimmed()
+
+    def filter_runnable(self, batch: abi.PlanBatch, dispatchable: np.ndarray):
+        n, D = batch.n_tasks, batch.n_distros
+        met, keep = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+        rows, cnt = np.full(max(n, 1), -1, np.int32), np.zeros(D, np.int32)
+        inp = abi.make_plan_input(batch)
+        disp = np.ascontiguousarray(dispatchable, np.uint8) if n else np.zeros(1, np.uint8)
+        rc = lib().evg_oracle_filter_runnable(C.byref(inp), disp.ctypes.data, met.ctypes.data, keep.ctypes.data, rows.ctypes.data, cnt.ctypes.data)
+        assert rc == 0
+        return met[:n], keep[:n], rows[:n], cnt
 
     def allocator_report(self, n_distros, tg_off, distro_info, group_info, hosts_spawned, free_hosts, params) -> np.ndarray:
         rep = np.zeros(n_distros, abi.ALLOC_REPORT_DTYPE)

@@ -1,0 +1,100 @@
+"""the task finder's dependency filter (scheduler/task_finder.go:40-116, Task.DependenciesMet
+task.go:649-688). CPU: the oracle's batched filter against the host-object restatement (scheduler.FindRunnableTasks).
+GPU: evg_filter_runnable_device against the oracle (keep flags, deps-met flags, order-preserving compaction)."""
+import numpy as np
+import pytest
+
+from evergreen_amd import abi, gen
+from evergreen_amd import scheduler as S
+from tests import golden_cases as G
+
+NOW = G.NOW
+
+
+def _object_queues(seed):
+    rng = np.random.default_rng(seed)
+    outside = {}
+    for k in range(40):
+        outside["out-%d" % k] = (str(rng.choice([S.TaskSucceeded, S.TaskFailed, "started", S.TaskUndispatched])), bool(rng.random() < 0.2))
+    queues = []
+    for d in range(4):
+        tasks = []
+        for i in range(150 + 11 * d):
+            t = S.Task(Id="d%d-t%d" % (d, i), DistroId="distro%d" % d, Project="p%d" % int(rng.integers(0, 3)),
+                       Status=str(rng.choice([S.TaskUndispatched, S.TaskUndispatched, S.TaskSucceeded, S.TaskFailed])))
+            for _ in range(int(rng.integers(0, 4))):
+                if rng.random() < 0.5 and i > 0:
+                    dep_id = "d%d-t%d" % (d, int(rng.integers(0, i)))
+                elif rng.random() < 0.9:
+                    dep_id = "out-%d" % int(rng.integers(0, 40))
+                else:
+                    dep_id = "missing-%d" % int(rng.integers(0, 5))
+                t.DependsOn.append(S.Dependency(dep_id, str(rng.choice([S.TaskSucceeded, "", S.TaskFailed, S.AllStatuses, "weird"])),
+                                                Unattainable=bool(rng.random() < 0.1)))
+            if rng.random() < 0.1:
+                t.OverrideDependencies = True
+            if rng.random() < 0.1:
+                t.DependenciesMetTime = NOW - S.MINUTE
+            tasks.append(t)
+        dist = S.Distro(Id="distro%d" % d, DispatcherSettings=S.DispatcherSettings(
+            Version=S.DispatcherVersionRevisedWithDependencies if d == 3 else ""))
+        queues.append((dist, tasks))
+    return queues, outside
+
+
+def test_oracle_filter_matches_host_object_restatement(oracle):
+    queues, outside = _object_queues(21)
+    can = lambda t: t.Project != "p2"  # noqa: E731  (a project with dispatching disabled)
+    packed = S.pack_queues(queues, NOW, outside.get)
+    b = packed.batch
+    disp = np.asarray([1 if can(t) else 0 for _, ts in queues for t in ts], np.uint8)
+    met, keep, rows, cnt = oracle.filter_runnable(b, disp)
+    for d, (dist, tasks) in enumerate(queues):
+        want = S.FindRunnableTasks(dist, tasks, can, outside.get)
+        lo = int(b.task_off[d])
+        got = [tasks[int(r) - lo].Id for r in rows[lo:lo + int(cnt[d])]]
+        assert got == [t.Id for t in want], d
+        assert int(keep[lo:int(b.task_off[d + 1])].sum()) == len(want)
+    assert 0 < int(cnt.sum()) < b.n_tasks
+    assert int(cnt[3]) == int(disp[int(b.task_off[3]):].sum())  # revised-with-dependencies: no dependency check
+
+
+def _random_dispatchable(b, seed):
+    return (np.random.default_rng(seed).random(b.n_tasks) < 0.9).astype(np.uint8)
+
+
+def test_oracle_filter_agrees_with_planner_deps_met(oracle):
+    """Same predicate as GetDistroQueueInfo's checkDependenciesMet (scheduler.go:180-187): where the finder checks, its
+    deps-met flags equal the planner's."""
+    b = gen.generate(gen.GenConfig(20_000, 12, 5, with_hosts=False))
+    met, keep, rows, cnt = oracle.filter_runnable(b, np.ones(b.n_tasks, np.uint8))
+    plan = oracle.plan(b, breakdown=False, n_units=False)
+    checked = np.repeat(b.distros["includes_dependencies"] == 0, np.diff(b.task_off))
+    assert np.array_equal(met[checked], plan.deps_met[checked]) and np.all(met[~checked] == 1)
+    assert np.array_equal(cnt, np.add.reduceat(keep.astype(np.int64), b.task_off[:-1]).astype(np.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("make", [lambda: gen.generate(gen.config(2)), lambda: gen.generate(gen.GenConfig(60_000, 24, gen.SEED_BASE + 31, skew=True)),
+                                  lambda: gen.generate(gen.GenConfig(2, 4, 1))], ids=["config2", "skewed", "tiny"])
+def test_hip_filter_matches_oracle(native_ctx, oracle, make):
+    import torch
+    b = make()
+    disp = _random_dispatchable(b, 9)
+    want_met, want_keep, want_rows, want_cnt = oracle.filter_runnable(b, disp)
+    dev = torch.device("cuda:0")
+    t = b.device_tensors(dev)
+    inp = abi.make_plan_input(b, t)
+    n = max(b.n_tasks, 1)
+    d_disp = torch.from_numpy(np.ascontiguousarray(disp) if b.n_tasks else np.zeros(1, np.uint8)).to(dev)
+    o_met, o_keep = torch.zeros(n, dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+    o_rows, o_cnt = torch.full((n,), -1, dtype=torch.int32, device=dev), torch.zeros(b.n_distros, dtype=torch.int32, device=dev)
+    native_ctx.filter_runnable_device(inp, d_disp.data_ptr(), o_met.data_ptr(), o_keep.data_ptr(), o_rows.data_ptr(), o_cnt.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_cnt.cpu().numpy(), want_cnt)
+    assert np.array_equal(o_met.cpu().numpy()[:b.n_tasks], want_met) and np.array_equal(o_keep.cpu().numpy()[:b.n_tasks], want_keep)
+    got_rows = o_rows.cpu().numpy()[:b.n_tasks]
+    for d in range(b.n_distros):
+        lo = int(b.task_off[d])
+        assert np.array_equal(got_rows[lo:lo + int(want_cnt[d])], want_rows[lo:lo + int(want_cnt[d])]), d
