@@ -550,7 +550,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
   uint32_t n_met = 0, n_mq = 0, n_s3 = 0, sec = 0;
   const int n_round = (n + kBlock - 1) / kBlock * kBlock;
   for (int i = tid; i < n_round; i += kBlock) {
-    uint32_t s_cnt = 0, s_cover = 0, s_wait = 0, s_mq = 0;
+    uint32_t s_cnt = 0, s_cover = 0, s_wait = 0, s_mq = 0, s_first = 0xFFFFFFFFu;
     uint64_t s_dur = 0, s_dover = 0;
     if (i < n) {
       const int r = lo + i;
@@ -574,7 +574,8 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
       if (f & EVG_TF_OTHER_DISTRO) sec = 1;
       if (met) { n_met++; if (merge) n_mq++; if (f & EVG_TF_S3_STORAGE) n_s3++; }
       const int g = m.grow(tgk < 0 ? -1 : tgk - c.tg_lo);
-      atomicMin(&m.g_first[g], (uint32_t)m.pos[i]);
+      if (tgk < 0) s_first = (uint32_t)m.pos[i];  // standalone row: reduced per wave below (one contended word otherwise)
+      else atomicMin(&m.g_first[g], (uint32_t)m.pos[i]);
       if (tgk < 0) {
         s_cnt = count; s_dur = count ? (uint64_t)dur : 0; s_cover = over; s_dover = over ? (uint64_t)dur : 0;
         s_wait = wait_over; s_mq = met && merge;
@@ -587,8 +588,10 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
     }
     s_cnt = wave_sum(s_cnt); s_cover = wave_sum(s_cover); s_wait = wave_sum(s_wait); s_mq = wave_sum(s_mq);
     s_dur = wave_sum(s_dur); s_dover = wave_sum(s_dover);
+    s_first = wave_min(s_first);
     if (lane == 0) {
       const int g = m.g0;
+      if (s_first != 0xFFFFFFFFu) atomicMin(&m.g_first[g], s_first);
       if (s_cnt) atomicAdd(&m.g_cnt[g], s_cnt);
       if (s_dur) atomicAdd((unsigned long long*)&m.g_dur[g], (unsigned long long)s_dur);
       if (s_cover) atomicAdd(&m.g_cover[g], s_cover);

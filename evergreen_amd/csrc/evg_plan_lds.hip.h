@@ -267,6 +267,19 @@ __device__ __forceinline__ void for_units(const uint16_t* edge, int t0, int t1, 
 __device__ __forceinline__ bool dep_satisfied(uint32_t req, uint32_t st, bool blk) {  // task.go:546-561
   return req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
 }
+// The same predicate as a 32-entry bit table indexed by  req | status << 2 | blocked << 4  (one shift instead of a
+// branch tree in the per-edge loop); checked against dep_satisfied at compile time.
+constexpr uint32_t dep_sat_table() {
+  uint32_t t = 0;
+  for (uint32_t blk = 0; blk < 2; blk++)
+    for (uint32_t st = 0; st < 4; st++)
+      for (uint32_t req = 0; req < 4; req++) {
+        const bool sat = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk != 0) : false;
+        if (sat) t |= 1u << (req | (st << 2) | (blk << 4));
+      }
+  return t;
+}
+constexpr uint32_t kDepSatTable = dep_sat_table();
 
 __device__ __forceinline__ uint64_t shl64(uint64_t x, int s) { return s >= 64 ? 0ull : x << s; }
 
@@ -426,24 +439,22 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     if (t1 >= 0) join(t1, ufe);
     const int x0 = doff[e], x1 = doff[e + 1];
     for (int x = x0; x < x1; x++) {
+      // branch-free: an out-of-queue edge reads pslot[0] and ignores it
       const uint32_t raw = m.edge[x];
-      uint32_t rec;
-      if (raw & ED_OUT) {
-        const bool sat = !(raw & EVG_DEP_MISSING) &&
-                         dep_satisfied(raw & EVG_DEP_REQ_MASK, (raw & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT, raw & EVG_DEP_BLOCKED);
-        rec = ED_OUT | (sat ? ER_SAT : 0u);
-      } else {
-        const uint32_t pj = m.pslot[raw & 0x7FFu];
-        const int sl = (int)(pj & PS_SLOT);
-        const bool sat = dep_satisfied((raw >> 11) & 3u, (pj >> 12) & 3u, pj & 0x4000u);
-        bool skip = sl == t0 || sl == t1;
-        for (int y = x0; y < x; y++) {
-          const uint32_t e2 = m.edge[y];
-          skip |= !(e2 & ED_OUT) && (int)(e2 & ER_SLOT) == sl;
-        }
-        rec = (sat ? ER_SAT : 0u) | (skip ? ER_SKIP : 0u) | (uint32_t)sl;
-        if (!skip) join(sl, sl < n_own ? ufe & ~UF_NONGROUP : ufe);
+      const bool out = (raw & ED_OUT) != 0;
+      const uint32_t pj = m.pslot[out ? 0u : raw & 0x7FFu];
+      const int sl = (int)(pj & PS_SLOT);
+      const uint32_t req = out ? raw & EVG_DEP_REQ_MASK : (raw >> 11) & 3u;
+      const uint32_t st = out ? (raw & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT : (pj >> 12) & 3u;
+      const uint32_t blk = out ? (raw >> 4) & 1u : (pj >> 14) & 1u;
+      const bool sat = ((kDepSatTable >> (req | (st << 2) | (blk << 4))) & 1u) != 0 && !(out && (raw & EVG_DEP_MISSING));
+      bool skip = out || sl == t0 || sl == t1;
+      for (int y = x0; y < x; y++) {
+        const uint32_t e2 = m.edge[y];
+        skip |= !(e2 & ED_OUT) && (int)(e2 & ER_SLOT) == sl;
       }
+      const uint32_t rec = out ? (ED_OUT | (sat ? ER_SAT : 0u)) : ((sat ? ER_SAT : 0u) | (skip ? ER_SKIP : 0u) | (uint32_t)sl);
+      if (!skip) join(sl, sl < n_own ? ufe & ~UF_NONGROUP : ufe);
       m.edge[x] = (uint16_t)rec;
     }
   }
