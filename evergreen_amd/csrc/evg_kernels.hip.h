@@ -61,6 +61,7 @@ struct PlanArgs {
   uint32_t *g_cnt, *g_cover, *g_wait, *g_mq, *g_first;  // [D + n_tg]
   uint64_t *g_dur, *g_dover;
   int32_t* w_generic;  // [D] 1: the distro was left to k_plan_generic
+  void* w_key;         // [2N + 4096] 128-bit sort keys of the generic path (K128)
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts;  // [D][16] s_memtime stamps at the phase boundaries (scripts/phase_timing.py)
 #endif
@@ -176,6 +177,12 @@ __device__ __forceinline__ int64_t target_time_for_queue(const evg_distro_params
   if (!has_mq || p.merge_queue_target_time_ns <= 0) return tt;
   return tt < p.merge_queue_target_time_ns ? tt : p.merge_queue_target_time_ns;
 }
+
+}  // namespace evg
+
+#include "evg_sort.hip.h"
+
+namespace evg {
 
 // unitInfo.value()  planner.go:209-300. bd == nullptr: only TotalValue.
 __device__ inline int64_t unit_value(const evg_distro_params& p, int64_t n, int64_t tiq, int64_t dur, int64_t maxpri,
@@ -313,7 +320,7 @@ __device__ __forceinline__ bool queue_less(const Mem<LDS>& m, uint32_t a, uint32
 }
 
 template <bool LDS>
-__device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigned* s_red) {
+__device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigned* s_red, K128* sort_buf = nullptr) {
   using idx_t = typename Mem<LDS>::idx_t;
   using k1_t = typename Mem<LDS>::k1_t;
   const evg_task_soa& t = a.in.tasks;
@@ -460,9 +467,103 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
   }
 
   EVG_STAMP(6);
+  // ---- P5 (fast form, generic path): two tiled sorts of packed 128-bit keys ------------------------------------------
+  // (1) by [maxValue - value | unit min row | unit slot | row]: the tasks emitted from one unit become contiguous;
+  // (2) by [run start | TaskList.Less key | row]: order inside each unit. Needs the value range of the distro to fit
+  // 55 bits and the TaskList.Less ranges to fit 64 bits; otherwise the comparator sort below runs instead.
+  bool sorted_fast = false;
+  if (!LDS && sort_buf && a.w_key && P >= 2048) {
+    unsigned long long* r64 = (unsigned long long*)(s_red + 16);  // vmin vmax dmin dmax pmin pmax
+    uint32_t* r32 = s_red + 28;                                   // tmin tmax nmin nmax
+    __syncthreads();
+    if (tid < 6) r64[tid] = (tid & 1) ? 0ull : ~0ull;
+    if (tid < 4) r32[tid] = (tid & 1) ? 0u : ~0u;
+    __syncthreads();
+    uint64_t vmin = ~0ull, vmax = 0, dmin = ~0ull, dmax = 0, pmin = ~0ull, pmax = 0;
+    uint32_t tmin = ~0u, tmax = 0, nmin = ~0u, nmax = 0;
+    for (int i = tid; i < n; i += kBlock) {
+      const int r = lo + i;
+      const uint64_t uv = ub(m.k0[i]), ud = ub(t.expected_duration_ns[r]), up = ub(t.priority[r]);
+      const uint32_t ut = ub(t.task_group_order[r]), un = ub(t.num_dependents[r]);
+      vmin = uv < vmin ? uv : vmin; vmax = uv > vmax ? uv : vmax; dmin = ud < dmin ? ud : dmin; dmax = ud > dmax ? ud : dmax;
+      pmin = up < pmin ? up : pmin; pmax = up > pmax ? up : pmax; tmin = ut < tmin ? ut : tmin; tmax = ut > tmax ? ut : tmax;
+      nmin = un < nmin ? un : nmin; nmax = un > nmax ? un : nmax;
+    }
+    vmin = wave_min(vmin); vmax = wave_max(vmax); dmin = wave_min(dmin); dmax = wave_max(dmax); pmin = wave_min(pmin); pmax = wave_max(pmax);
+    tmin = wave_min(tmin); tmax = wave_max(tmax); nmin = wave_min(nmin); nmax = wave_max(nmax);
+    if (lane == 0) {
+      atomicMin(&r64[0], (unsigned long long)vmin); atomicMax(&r64[1], (unsigned long long)vmax);
+      atomicMin(&r64[2], (unsigned long long)dmin); atomicMax(&r64[3], (unsigned long long)dmax);
+      atomicMin(&r64[4], (unsigned long long)pmin); atomicMax(&r64[5], (unsigned long long)pmax);
+      atomicMin(&r32[0], tmin); atomicMax(&r32[1], tmax); atomicMin(&r32[2], nmin); atomicMax(&r32[3], nmax);
+    }
+    __syncthreads();
+    vmax = r64[1]; dmax = r64[3]; pmax = r64[5]; tmin = r32[0]; nmax = r32[3];
+    const int vb = bits_of(r64[1] - r64[0]);
+    const int bt = bits_of((uint64_t)(r32[1] - r32[0])), bn = bits_of((uint64_t)(r32[3] - r32[2])), bp = bits_of(r64[5] - r64[4]),
+              bd = bits_of(r64[3] - r64[2]);
+    if (vb <= 55 && bt + bn + bp + bd <= 64) {
+      K128* keys = (K128*)a.w_key + 2 * (size_t)lo;  // P <= 2n keys per distro (n >= 1025 here)
+      // ---- sort 1 ----
+      for (int i = tid; i < P; i += kBlock) {
+        K128 k{~0ull, ~0ull};
+        if (i < n) {
+          const uint64_t vc = vmax - ub(m.k0[i]), mr = (uint64_t)(m.k1[i] >> 32), sl = (uint64_t)(m.k1[i] & 0xFFFFFFFFu);
+          k.hi = (vc << 9) | (mr >> 15);                               // [value : vb <= 55][min row, upper 9 of 24 bits]
+          k.lo = ((mr & 0x7FFFu) << 49) | (sl << 24) | (uint64_t)i;    // [min row, lower 15][slot : 25][row : 24]
+        }
+        keys[i] = k;
+      }
+      __syncthreads();
+      tiled_sort_k128(keys, P, sort_buf);
+      // ---- run starts: chunked max-scan of the positions where the slot changes ----
+      const int per = (n + kBlock - 1) / kBlock;
+      const int q0 = tid * per < n ? tid * per : n, q1 = q0 + per < n ? q0 + per : n;
+      auto slot_at = [&](int q) { return (uint32_t)((keys[q].lo >> 24) & 0x1FFFFFFu); };
+      const uint32_t prev0 = q0 > 0 && q0 < n ? slot_at(q0 - 1) : 0xFFFFFFFFu;
+      int lastb = -1;
+      {
+        uint32_t prev = prev0;
+        for (int q = q0; q < q1; q++) { const uint32_t sl = slot_at(q); if (q == 0 || sl != prev) lastb = q; prev = sl; }
+      }
+      int* scan = (int*)sort_buf;
+      __syncthreads();
+      scan[tid] = lastb;
+      __syncthreads();
+      for (int o = 1; o < kBlock; o <<= 1) {
+        const int v = tid >= o ? scan[tid - o] : -1;
+        __syncthreads();
+        if (v > scan[tid]) scan[tid] = v;
+        __syncthreads();
+      }
+      int run = tid ? scan[tid - 1] : -1;  // last run start before this chunk
+      __syncthreads();
+      // ---- keys of sort 2, in place ----
+      {
+        uint32_t prev = prev0;
+        for (int q = q0; q < q1; q++) {
+          const K128 k = keys[q];
+          const uint32_t sl = (uint32_t)((k.lo >> 24) & 0x1FFFFFFu);
+          const int i = (int)(k.lo & 0xFFFFFFu);
+          if (q == 0 || sl != prev) run = q;
+          prev = sl;
+          const int r = lo + i;
+          const uint64_t ik = shl64((uint64_t)(ub(t.task_group_order[r]) - tmin), bn + bp + bd) |
+                              shl64((uint64_t)(nmax - ub(t.num_dependents[r])), bp + bd) | shl64(pmax - ub(t.priority[r]), bd) |
+                              (dmax - ub(t.expected_duration_ns[r]));
+          keys[q] = K128{((uint64_t)run << 40) | (ik >> 24), (ik << 40) | (uint64_t)i};  // [run start : 24][key : 64][row : 24]
+        }
+      }
+      __syncthreads();
+      tiled_sort_k128(keys, P, sort_buf);
+      for (int q = tid; q < n; q += kBlock) m.idx[q] = (idx_t)(keys[q].lo & 0xFFFFFFu);
+      __syncthreads();
+      sorted_fast = true;
+    }
+  }
   // ---- P5: bitonic sort of idx[] by queue_less ------------------------------------------------------------
   int prev_j = 1 << 30;
-  for (int k = 2; k <= P; k <<= 1) {
+  for (int k = 2; k <= (sorted_fast ? 0 : P); k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       if (LDS && j <= 64 && prev_j <= 64) {
         // both this stage and the previous one only touch the 128 elements this wave owns

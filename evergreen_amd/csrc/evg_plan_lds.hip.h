@@ -117,130 +117,6 @@ __device__ __forceinline__ void store4(T* __restrict__ p, int i0, int n, const T
   }
 }
 
-// order-preserving signed -> unsigned
-__device__ __forceinline__ uint32_t ub(int32_t x) { return (uint32_t)x ^ 0x80000000u; }
-__device__ __forceinline__ uint64_t ub(int64_t x) { return (uint64_t)x ^ 0x8000000000000000ull; }
-__device__ __forceinline__ int bits_of(uint64_t x) { return x ? 64 - __builtin_clzll(x) : 0; }
-
-// ---- sort keys -------------------------------------------------------------------------------------------
-struct K128 {
-  uint64_t hi, lo;
-};
-__device__ __forceinline__ bool key_lt(uint64_t a, uint64_t b) { return a < b; }
-__device__ __forceinline__ bool key_lt(const K128& a, const K128& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
-// Partner's key at lane distance M. Distances 1..8 are DPP moves in the VALU; 16 and 32 go through ds_bpermute:
-// the sort is VALU-issue bound while the LDS pipe idles, and a v_permlane swap costs two VALU slots plus copies.
-template <int M>
-__device__ __forceinline__ uint32_t word_xor(uint32_t v) {
-  if constexpr (M >= 16) return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((__lane_id() ^ M) << 2), (int)v);
-  else return lane_xor<M>(v);
-}
-template <int M>
-__device__ __forceinline__ uint64_t key_xor(uint64_t v) { return ((uint64_t)word_xor<M>((uint32_t)(v >> 32)) << 32) | word_xor<M>((uint32_t)v); }
-template <int M>
-__device__ __forceinline__ K128 key_xor(const K128& v) { return K128{key_xor<M>(v.hi), key_xor<M>(v.lo)}; }
-// compare-exchange of the lane's 4 keys with lane (lane ^ M): keep the smaller (take_min) or the larger of each pair
-template <int M, class K>
-__device__ __forceinline__ void shuffle_stage(K (&k)[4], bool take_min) {
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const K o = key_xor<M>(k[e]);
-    const bool lt = key_lt(o, k[e]);
-    if (take_min == lt) k[e] = o;
-  }
-}
-
-template <class K>
-__device__ __forceinline__ void cmpx(K& a, K& b, bool asc) {  // a at the lower position
-  const bool sw = asc ? key_lt(b, a) : key_lt(a, b);
-  if (sw) { const K t = a; a = b; b = t; }
-}
-
-// The same network as bitonic_sort4 below for a compile-time P: fully unrolled, so every stage is straight-line code
-// with its exchange distance resolved at compile time and no scalar dispatch.
-template <int P, class K>
-__device__ __forceinline__ void bitonic_sort4_fixed(K (&k)[4], int tid, K* buf0, K* buf1) {
-  const int p0 = tid * 4;
-  int which = 0;
-#pragma unroll
-  for (int kk = 2; kk <= P; kk <<= 1) {
-    const bool asc_t = (p0 & kk) == 0;  // valid for kk >= 4
-#pragma unroll
-    for (int j = kk >> 1; j > 0; j >>= 1) {
-      const bool take_min = ((p0 & j) == 0) == asc_t;
-      if (j >= 256) {
-        K* buf = which ? buf1 : buf0;
-        which ^= 1;
-        if (buf0 == buf1) __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; e++) buf[p0 + e] = k[e];
-        __syncthreads();
-        const int q0 = (tid ^ (j >> 2)) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const K o = buf[q0 + e];
-          const bool lt = key_lt(o, k[e]);
-          if (take_min == lt) k[e] = o;
-        }
-      } else if (j == 128) shuffle_stage<32>(k, take_min);
-      else if (j == 64) shuffle_stage<16>(k, take_min);
-      else if (j == 32) shuffle_stage<8>(k, take_min);
-      else if (j == 16) shuffle_stage<4>(k, take_min);
-      else if (j == 8) shuffle_stage<2>(k, take_min);
-      else if (j == 4) shuffle_stage<1>(k, take_min);
-      else if (j == 2) { cmpx(k[0], k[2], asc_t); cmpx(k[1], k[3], asc_t); }
-      else if (kk == 2) { cmpx(k[0], k[1], true); cmpx(k[2], k[3], false); }
-      else { cmpx(k[0], k[1], asc_t); cmpx(k[2], k[3], asc_t); }
-    }
-  }
-}
-
-// Bitonic sort of P = 2^m keys (P >= 4; position p = 4*tid + e holds k[e]; positions >= P are ignored) ascending.
-// Stages with partner distance j: j < 4 inside the lane, 4 <= j < 256 by wave shuffles (lane ^ j/4), j >= 256
-// through LDS (buf0/buf1 alternate so that one barrier per stage suffices; buf1 == buf0 is allowed).
-template <class K>
-__device__ __forceinline__ void bitonic_sort4(K (&k)[4], int P, int tid, K* buf0, K* buf1) {
-  const int p0 = tid * 4;
-  int which = 0;
-  for (int kk = 2; kk <= P; kk <<= 1) {
-    const bool asc_t = (p0 & kk) == 0;  // valid for kk >= 4
-    for (int j = kk >> 1; j > 0; j >>= 1) {
-      if (j >= 256) {
-        K* buf = which ? buf1 : buf0;
-        which ^= 1;
-        if (buf0 == buf1) __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; e++) buf[p0 + e] = k[e];
-        __syncthreads();
-        const int q0 = (tid ^ (j >> 2)) * 4;
-        const bool take_min = ((p0 & j) == 0) == asc_t;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const K o = buf[q0 + e];
-          const bool lt = key_lt(o, k[e]);
-          if (take_min == lt) k[e] = o;
-        }
-      } else if (j >= 4) {
-        const bool take_min = ((p0 & j) == 0) == asc_t;
-        switch (j >> 2) {  // one uniform dispatch per stage; the exchange distance is a compile-time constant inside
-          case 1: shuffle_stage<1>(k, take_min); break;
-          case 2: shuffle_stage<2>(k, take_min); break;
-          case 4: shuffle_stage<4>(k, take_min); break;
-          case 8: shuffle_stage<8>(k, take_min); break;
-          case 16: shuffle_stage<16>(k, take_min); break;
-          default: shuffle_stage<32>(k, take_min); break;
-        }
-      } else if (j == 2) {
-        cmpx(k[0], k[2], asc_t);
-        cmpx(k[1], k[3], asc_t);
-      } else {
-        if (kk == 2) { cmpx(k[0], k[1], true); cmpx(k[2], k[3], false); }
-        else { cmpx(k[0], k[1], asc_t); cmpx(k[2], k[3], asc_t); }
-      }
-    }
-  }
-}
-
 // ---- unit membership -------------------------------------------------------------------------------------
 struct LdsView {
   int64_t *tiq, *dur, *val;
@@ -281,7 +157,6 @@ constexpr uint32_t dep_sat_table() {
 }
 constexpr uint32_t kDepSatTable = dep_sat_table();
 
-__device__ __forceinline__ uint64_t shl64(uint64_t x, int s) { return s >= 64 ? 0ull : x << s; }
 
 // TaskList.Less (planner.go:386-405) on the global columns, rows ra / rb: is ra strictly before rb, ignoring the
 // final row tie-break?  Returns -1 before, +1 after, 0 tie.
@@ -1026,7 +901,7 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const Fu
   if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
 }
 
-__device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c, unsigned* s_red) {
+__device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c, unsigned* s_red, K128* sort_buf) {
   const int d = c.d;
   const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // disjoint slot range of this distro
   Mem<false> m;
@@ -1040,7 +915,7 @@ __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c
   m.g_cnt = a.g_cnt; m.g_cover = a.g_cover; m.g_wait = a.g_wait; m.g_mq = a.g_mq; m.g_first = a.g_first;
   m.g_dur = a.g_dur; m.g_dover = a.g_dover;
   m.g0 = d; m.gk = c.D + c.tg_lo;
-  plan_distro<false>(a, c, m, s_red);
+  plan_distro<false>(a, c, m, s_red, sort_buf);
 }
 
 // One workgroup per distro the LDS path left over (none in the headline configuration): every intermediate lives
@@ -1048,7 +923,9 @@ __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c
 // Launched with a FIXED small grid (kGenericGrid workgroups striding over the distros): when no distro is flagged --
 // the normal case -- the launch costs a quarter of a one-workgroup-per-distro grid.
 constexpr int kGenericGrid = 128;
+constexpr int kGenericLds = 2048 * 16;  // one tile of 128-bit keys
 __global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
   for (int d = blockIdx.x; d < a.in.n_distros; d += gridDim.x) {
     if (!a.w_generic[d]) continue;
@@ -1056,12 +933,13 @@ __global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a) {
     __syncthreads();
     if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
     __syncthreads();
-    plan_generic_body(a, c, s_red);
+    plan_generic_body(a, c, s_red, (K128*)gsm);
   }
 }
 
 // The same for the fused entry point: plan, then allocate hosts, for the distros the fused LDS kernel left over.
 __global__ void __launch_bounds__(kBlock) k_plan_allocate_generic(const FusedArgs f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
   __shared__ HostRec s_rec[kAllocLdsHosts];
   __shared__ int s_cnt[2 * kAllocLdsBuckets];
@@ -1072,7 +950,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_allocate_generic(const FusedArg
   __syncthreads();
   if (tid < 32) s_red[tid] = 0;
   __syncthreads();
-  plan_generic_body(f.p, c, s_red);
+  plan_generic_body(f.p, c, s_red, (K128*)gsm);
   __syncthreads();  // the distro's info rows are in global memory, written by this workgroup
   const AllocArgs& a = f.q;
   const evg_alloc_params p = a.in.params[d];

@@ -449,10 +449,10 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.in = *in;
   a.out = *out;
   // scratch of the large-distro path (untouched pages cost nothing; small distros never use it)
-  size_t sz[21] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
+  size_t sz[22] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
                    4 * (N + 1), 8 * (N + 1), 8 * (N + 1), 8 * (N + 1), 4 * (N + 1),
-                   4 * G, 4 * G, 4 * G, 4 * G, 4 * G, 8 * G, 8 * G, 4 * (size_t)D};
-  for (int i = 0; i < 21; i++) {
+                   4 * G, 4 * G, 4 * G, 4 * G, 4 * G, 8 * G, 8 * G, 4 * (size_t)D, 16 * (2 * N + 4096)};
+  for (int i = 0; i < 22; i++) {
     int rc = ensure(c, c->scratch[i], sz[i]);
     if (rc) return rc;
   }
@@ -465,6 +465,7 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.g_mq = (uint32_t*)c->scratch[16].p; a.g_first = (uint32_t*)c->scratch[17].p; a.g_dur = (uint64_t*)c->scratch[18].p;
   a.g_dover = (uint64_t*)c->scratch[19].p;
   a.w_generic = (int32_t*)c->scratch[20].p;
+  a.w_key = c->scratch[21].p;
 #ifdef EVG_PHASE_TIMING
   a.dbg_ts = c->dbg_ts;
 #endif
@@ -512,7 +513,7 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   else hipLaunchKernelGGL(k_plan_distros<false>, dim3(D), dim3(kBlock), kLdsLean, st, a);
   HIP_TRY(c, hipGetLastError());
   // distros the LDS path could not take (flagged on the device); its workgroups exit at once otherwise
-  hipLaunchKernelGGL(k_plan_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL(k_plan_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), kGenericLds, st, a);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }
@@ -561,7 +562,7 @@ int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_pla
   if (out->breakdown || out->n_units) hipLaunchKernelGGL(k_plan_allocate<true>, dim3(D), dim3(kBlock), kLdsRich, st, f);
   else hipLaunchKernelGGL(k_plan_allocate<false>, dim3(D), dim3(kBlock), kLdsLean, st, f);
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(k_plan_allocate_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), 0, st, f);
+  hipLaunchKernelGGL(k_plan_allocate_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), kGenericLds, st, f);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }

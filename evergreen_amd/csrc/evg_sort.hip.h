@@ -1,0 +1,205 @@
+// evg_sort.hip.h -- sorting networks of the planner kernels (gfx950): 4 keys per lane, 512-thread workgroups.
+// Compare-exchange partners at distance 1-2 are in the lane, 4-32 come by DPP (VALU), 64-128 by ds_bpermute, 256 and up
+// through LDS (inside a 2048-key tile) or global memory (between tiles, generic path only).
+#pragma once
+
+namespace evg {
+
+// order-preserving signed -> unsigned
+__device__ __forceinline__ uint32_t ub(int32_t x) { return (uint32_t)x ^ 0x80000000u; }
+__device__ __forceinline__ uint64_t ub(int64_t x) { return (uint64_t)x ^ 0x8000000000000000ull; }
+__device__ __forceinline__ int bits_of(uint64_t x) { return x ? 64 - __builtin_clzll(x) : 0; }
+__device__ __forceinline__ uint64_t shl64(uint64_t x, int s) { return s >= 64 ? 0ull : x << s; }
+
+// ---- sort keys -------------------------------------------------------------------------------------------
+struct K128 {
+  uint64_t hi, lo;
+};
+__device__ __forceinline__ bool key_lt(uint64_t a, uint64_t b) { return a < b; }
+__device__ __forceinline__ bool key_lt(const K128& a, const K128& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+// Partner's key at lane distance M. Distances 1..8 are DPP moves in the VALU; 16 and 32 go through ds_bpermute:
+// the sort is VALU-issue bound while the LDS pipe idles, and a v_permlane swap costs two VALU slots plus copies.
+template <int M>
+__device__ __forceinline__ uint32_t word_xor(uint32_t v) {
+  if constexpr (M >= 16) return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((__lane_id() ^ M) << 2), (int)v);
+  else return lane_xor<M>(v);
+}
+template <int M>
+__device__ __forceinline__ uint64_t key_xor(uint64_t v) { return ((uint64_t)word_xor<M>((uint32_t)(v >> 32)) << 32) | word_xor<M>((uint32_t)v); }
+template <int M>
+__device__ __forceinline__ K128 key_xor(const K128& v) { return K128{key_xor<M>(v.hi), key_xor<M>(v.lo)}; }
+// compare-exchange of the lane's 4 keys with lane (lane ^ M): keep the smaller (take_min) or the larger of each pair
+template <int M, class K>
+__device__ __forceinline__ void shuffle_stage(K (&k)[4], bool take_min) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const K o = key_xor<M>(k[e]);
+    const bool lt = key_lt(o, k[e]);
+    if (take_min == lt) k[e] = o;
+  }
+}
+
+template <class K>
+__device__ __forceinline__ void cmpx(K& a, K& b, bool asc) {  // a at the lower position
+  const bool sw = asc ? key_lt(b, a) : key_lt(a, b);
+  if (sw) { const K t = a; a = b; b = t; }
+}
+
+// The same network as bitonic_sort4 below for a compile-time P: fully unrolled, so every stage is straight-line code
+// with its exchange distance resolved at compile time and no scalar dispatch.
+// p_base: global position of the tile's first key (directions of the last merges depend on it when the tile is part of a
+// larger network; 0 for a stand-alone sort).
+template <int P, class K>
+__device__ __forceinline__ void bitonic_sort4_fixed(K (&k)[4], int tid, K* buf0, K* buf1, int p_base = 0) {
+  const int p0 = tid * 4;
+  int which = 0;
+#pragma unroll
+  for (int kk = 2; kk <= P; kk <<= 1) {
+    const bool asc_t = ((p_base + p0) & kk) == 0;  // valid for kk >= 4
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      const bool take_min = ((p0 & j) == 0) == asc_t;
+      if (j >= 256) {
+        K* buf = which ? buf1 : buf0;
+        which ^= 1;
+        if (buf0 == buf1) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; e++) buf[p0 + e] = k[e];
+        __syncthreads();
+        const int q0 = (tid ^ (j >> 2)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const K o = buf[q0 + e];
+          const bool lt = key_lt(o, k[e]);
+          if (take_min == lt) k[e] = o;
+        }
+      } else if (j == 128) shuffle_stage<32>(k, take_min);
+      else if (j == 64) shuffle_stage<16>(k, take_min);
+      else if (j == 32) shuffle_stage<8>(k, take_min);
+      else if (j == 16) shuffle_stage<4>(k, take_min);
+      else if (j == 8) shuffle_stage<2>(k, take_min);
+      else if (j == 4) shuffle_stage<1>(k, take_min);
+      else if (j == 2) { cmpx(k[0], k[2], asc_t); cmpx(k[1], k[3], asc_t); }
+      else if (kk == 2) { cmpx(k[0], k[1], true); cmpx(k[2], k[3], false); }
+      else { cmpx(k[0], k[1], asc_t); cmpx(k[2], k[3], asc_t); }
+    }
+  }
+}
+
+// The in-tile half of one merge of a larger network: stages j = P/2 .. 1 of the merge whose direction for this whole
+// tile is `asc` (the tile lies inside one 2^m-aligned block of the merge). Same stage kinds as above.
+template <int P, class K>
+__device__ __forceinline__ void bitonic_merge4_fixed(K (&k)[4], int tid, K* buf, bool asc) {
+  const int p0 = tid * 4;
+#pragma unroll
+  for (int j = P >> 1; j > 0; j >>= 1) {
+    const bool take_min = ((p0 & j) == 0) == asc;
+    if (j >= 256) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 4; e++) buf[p0 + e] = k[e];
+      __syncthreads();
+      const int q0 = (tid ^ (j >> 2)) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const K o = buf[q0 + e];
+        const bool lt = key_lt(o, k[e]);
+        if (take_min == lt) k[e] = o;
+      }
+    } else if (j == 128) shuffle_stage<32>(k, take_min);
+    else if (j == 64) shuffle_stage<16>(k, take_min);
+    else if (j == 32) shuffle_stage<8>(k, take_min);
+    else if (j == 16) shuffle_stage<4>(k, take_min);
+    else if (j == 8) shuffle_stage<2>(k, take_min);
+    else if (j == 4) shuffle_stage<1>(k, take_min);
+    else if (j == 2) { cmpx(k[0], k[2], asc); cmpx(k[1], k[3], asc); }
+    else { cmpx(k[0], k[1], asc); cmpx(k[2], k[3], asc); }
+  }
+}
+
+// Sort of P = 2^m (P >= 2048) 128-bit keys in GLOBAL memory by one 512-thread workgroup, ascending: the bitonic network
+// split into 2048-key tiles. Stages with partner distance < 2048 run inside a tile on the register / DPP / LDS network
+// above (one load and one store of the tile per merge); only the log2(P/2048) * (log2(P/2048) + 1) / 2 stages with
+// distance >= 2048 touch global memory pairwise. buf: 2048 keys of LDS.
+__device__ __forceinline__ void tiled_sort_k128(K128* keys, int P, K128* buf) {
+  constexpr int TILE = 2048;
+  const int tid = threadIdx.x;
+  for (int base = 0; base < P; base += TILE) {
+    K128 k[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) k[e] = keys[base + tid * 4 + e];
+    bitonic_sort4_fixed<TILE, K128>(k, tid, buf, buf, base);
+#pragma unroll
+    for (int e = 0; e < 4; e++) keys[base + tid * 4 + e] = k[e];
+  }
+  for (int kk = 2 * TILE; kk <= P; kk <<= 1) {
+    for (int j = kk >> 1; j >= TILE; j >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (P >> 1); t += kBlock) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int x = i | j;
+        const K128 a = keys[i], b = keys[x];
+        const bool asc = (i & kk) == 0;
+        if (key_lt(b, a) == asc) { keys[i] = b; keys[x] = a; }
+      }
+    }
+    __syncthreads();
+    for (int base = 0; base < P; base += TILE) {
+      K128 k[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) k[e] = keys[base + tid * 4 + e];
+      bitonic_merge4_fixed<TILE, K128>(k, tid, buf, (base & kk) == 0);
+#pragma unroll
+      for (int e = 0; e < 4; e++) keys[base + tid * 4 + e] = k[e];
+    }
+  }
+  __syncthreads();
+}
+
+// Bitonic sort of P = 2^m keys (P >= 4; position p = 4*tid + e holds k[e]; positions >= P are ignored) ascending.
+// Stages with partner distance j: j < 4 inside the lane, 4 <= j < 256 by wave shuffles (lane ^ j/4), j >= 256
+// through LDS (buf0/buf1 alternate so that one barrier per stage suffices; buf1 == buf0 is allowed).
+template <class K>
+__device__ __forceinline__ void bitonic_sort4(K (&k)[4], int P, int tid, K* buf0, K* buf1) {
+  const int p0 = tid * 4;
+  int which = 0;
+  for (int kk = 2; kk <= P; kk <<= 1) {
+    const bool asc_t = (p0 & kk) == 0;  // valid for kk >= 4
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j >= 256) {
+        K* buf = which ? buf1 : buf0;
+        which ^= 1;
+        if (buf0 == buf1) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; e++) buf[p0 + e] = k[e];
+        __syncthreads();
+        const int q0 = (tid ^ (j >> 2)) * 4;
+        const bool take_min = ((p0 & j) == 0) == asc_t;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const K o = buf[q0 + e];
+          const bool lt = key_lt(o, k[e]);
+          if (take_min == lt) k[e] = o;
+        }
+      } else if (j >= 4) {
+        const bool take_min = ((p0 & j) == 0) == asc_t;
+        switch (j >> 2) {  // one uniform dispatch per stage; the exchange distance is a compile-time constant inside
+          case 1: shuffle_stage<1>(k, take_min); break;
+          case 2: shuffle_stage<2>(k, take_min); break;
+          case 4: shuffle_stage<4>(k, take_min); break;
+          case 8: shuffle_stage<8>(k, take_min); break;
+          case 16: shuffle_stage<16>(k, take_min); break;
+          default: shuffle_stage<32>(k, take_min); break;
+        }
+      } else if (j == 2) {
+        cmpx(k[0], k[2], asc_t);
+        cmpx(k[1], k[3], asc_t);
+      } else {
+        if (kk == 2) { cmpx(k[0], k[1], true); cmpx(k[2], k[3], false); }
+        else { cmpx(k[0], k[1], asc_t); cmpx(k[2], k[3], asc_t); }
+      }
+    }
+  }
+}
+
+}  // namespace evg

@@ -214,3 +214,18 @@ def test_fused_plan_allocate_entry_point(native_ctx, oracle, make, rich):
     g2, a2 = pool2.plan_result(), pool2.alloc_result()
     assert np.array_equal(g2.order, got.order) and np.array_equal(g2.group_info, got.group_info)
     assert np.array_equal(a2.new_hosts, got_alloc.new_hosts) and np.array_equal(a2.free_hosts, got_alloc.free_hosts)
+
+
+def test_big_distros_generic_fast_sort(native_ctx, oracle):
+    """Distros beyond the LDS path (config 5's shape: 19.5k tasks each, DAG depth 8, 20% task-group tasks) take the generic
+    kernel with the tiled two-pass 128-bit-key sort."""
+    b = gen.generate(gen.config(5, n_tasks=80_000, n_distros=4))
+    assert int(np.diff(b.task_off).min()) > 2048
+    _full_compare(native_ctx, oracle, b, "config 5 shape, big distros")
+
+
+def test_big_distro_wide_value_range_falls_back(native_ctx, oracle):
+    """A value range beyond 55 bits cannot be packed: the comparator sort of the generic path runs instead."""
+    b = gen.generate(gen.GenConfig(9_000, 2, 808, with_hosts=False))
+    b.cols["priority"][::7] = 2**58
+    _full_compare(native_ctx, oracle, b, "wide values, big distro")
