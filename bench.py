@@ -167,7 +167,7 @@ def main():
         }
         # roofline of the dominant kernel (k_plan_distros), from the HIP events of the timed region
         nu_pool = resident.ResidentPool(ctx, batch, dev, breakdown=True, n_units=True)
-        nu_pool.step()
+        nu_pool.step(fused=args.fused)
         got = nu_pool.plan_result()
         got_alloc = nu_pool.alloc_result() if nu_pool.has_hosts else None
         abytes, e_in = algorithmic_bytes(batch, int(got.n_units.sum()))

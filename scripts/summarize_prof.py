@@ -46,6 +46,11 @@ def main():
             v["hbm_bytes_per_launch_corrected"] = (2 * rd + wr) * 1024
             print("## %s: raw %.2f MB, corrected (2x read) %.2f MB per launch" % (
                 k[:50], v["hbm_bytes_per_launch_raw"] / 1e6, v["hbm_bytes_per_launch_corrected"] / 1e6))
+    # what bench.py reports as roofline.traffic: HBM bytes per launch of the planner kernel (lean instantiation)
+    for k, v in out.get("pmc", {}).items():
+        if "k_plan_distros<false>" in k and "hbm_bytes_per_launch_corrected" in v:
+            out["k_plan_distros_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch_corrected"]
+            out["k_plan_distros_hbm_bytes_per_launch_raw"] = v["hbm_bytes_per_launch_raw"]
     json.dump(out, open(os.path.join(d, tag + "-pmc.json"), "w"), indent=1)
 
 
