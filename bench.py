@@ -51,12 +51,14 @@ def cpu_baseline(batch, want_threads):
     res = abi.PlanResult.alloc_host(batch, breakdown=False, n_units=True)
     inp, out = abi.make_plan_input(batch), res.c_output()
     D = batch.n_distros
-    # single thread: plan + allocate over the whole pool
-    t0 = time.perf_counter()
-    lib.evg_oracle_plan_distros(C.byref(inp), C.byref(out))
-    alloc = o.allocate(batch, res.distro_info, res.group_info) if batch.alloc_params is not None else None
-    t1 = time.perf_counter() - t0
-    # all cores
+    # single thread: plan + allocate over the whole pool, best of 3
+    t1 = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        lib.evg_oracle_plan_distros(C.byref(inp), C.byref(out))
+        alloc = o.allocate(batch, res.distro_info, res.group_info) if batch.alloc_params is not None else None
+        t1 = min(t1, time.perf_counter() - t0)
+    # all cores, best of 5
     nt = max(1, min(want_threads, D))
     bounds = [D * i // nt for i in range(nt + 1)]
     res2 = abi.PlanResult.alloc_host(batch, breakdown=False, n_units=True)
@@ -64,13 +66,15 @@ def cpu_baseline(batch, want_threads):
 
     def work(i):
         lib.evg_oracle_plan_distro_range(C.byref(inp), C.byref(out2), bounds[i], bounds[i + 1])
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    if batch.alloc_params is not None:
-        o.allocate(batch, res2.distro_info, res2.group_info)
-    tn = time.perf_counter() - t0
+    tn = float("inf")
+    for _ in range(5):
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if batch.alloc_params is not None:
+            o.allocate(batch, res2.distro_info, res2.group_info)
+        tn = min(tn, time.perf_counter() - t0)
     assert np.array_equal(res.order, res2.order)
     return res, alloc, t1, tn, nt
 
@@ -195,9 +199,9 @@ def main():
             line["cpu_baseline"] = {
                 "value": batch.n_tasks / tn, "unit": "tasks/s", "cores": nt, "kind": "port",
                 "single_thread_value": batch.n_tasks / t1,
-                "sample": "the whole workload once (%d tasks x %d distros): C++ oracle, a port of the Go algorithm (the Go "
-                          "reference cannot be built here: no Go toolchain); %d worker threads, one distro range each "
-                          "(%.2f s), and one thread (%.2f s)" % (batch.n_tasks, batch.n_distros, nt, tn, t1)}
+                "sample": "the whole workload (%d tasks x %d distros), best of 5 passes with %d worker threads, one distro range each "
+                          "(%.2f s per pass), and best of 3 passes on one thread (%.2f s per pass): C++ oracle, a port of the Go "
+                          "algorithm (the Go reference cannot be built here: no Go toolchain)" % (batch.n_tasks, batch.n_distros, nt, tn, t1)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
