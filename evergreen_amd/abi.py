@@ -46,7 +46,7 @@ class TaskSoa(C.Structure):
 
 class PlanInput(C.Structure):
     _fields_ = [("n_distros", C.c_int32), ("n_task_groups", C.c_int32), ("n_versions", C.c_int32),
-                ("reserved", C.c_int32), ("tasks", TaskSoa), ("distros", _p), ("task_off", _p),
+                ("max_distro_tasks", C.c_int32), ("tasks", TaskSoa), ("distros", _p), ("task_off", _p),
                 ("tg_off", _p), ("ver_off", _p), ("now_ns", C.c_int64)]
 
 
@@ -228,6 +228,7 @@ def make_plan_input(batch: PlanBatch, arrays=None) -> PlanInput:
     inp.n_task_groups = batch.n_task_groups
     inp.n_versions = batch.n_versions
     inp.now_ns = batch.now_ns
+    inp.max_distro_tasks = int(np.diff(batch.task_off).max()) if batch.n_distros else 0
     ts = inp.tasks
     ts.n_tasks, ts.n_edges = batch.n_tasks, batch.n_edges
     for k in TASK_COLUMNS:

@@ -44,6 +44,14 @@ constexpr uint32_t UF_MERGE = 1u << 24, UF_PATCH = 2u << 24, UF_NONGROUP = 4u <<
                    UF_STEPBACK = 16u << 24, UF_DISTRO = 32u << 24;
 constexpr uint32_t UF_COUNT_MASK = 0x00FFFFFFu;
 
+// What the staged generic pipeline (pre -> sort -> mid -> sort -> post) keeps per distro between its kernels.
+struct GState {
+  unsigned long long vmax, dmax, pmax;  // biased range tops of the elected values / durations / priorities
+  uint32_t tmin, nmax;                  // biased task-group-order minimum, num-dependents maximum
+  int32_t bn, bp, bd;                   // bit widths of the TaskList.Less key fields below the group order
+  int32_t fast;                         // 1: packed-key sorts are in flight for this distro; 0: already finished
+};
+
 struct PlanArgs {
   evg_plan_input in;    // device pointers
   evg_plan_output out;  // device pointers
@@ -62,6 +70,9 @@ struct PlanArgs {
   uint64_t *g_dur, *g_dover;
   int32_t* w_generic;  // [D] 1: the distro was left to k_plan_generic
   void* w_key;         // [2N + 4096] 128-bit sort keys of the generic path (K128)
+  struct GState* w_gstate;  // [D] per-distro state handed between the kernels of the generic pipeline
+  int32_t* w_tiles;    // [2 * max_tiles] (distro, tile) of every 2048-key tile the pipeline's sort kernels work on
+  int32_t* w_ntiles;   // [1] number of registered tiles (zeroed by the LDS-path kernel of the same call)
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts;  // [D][16] s_memtime stamps at the phase boundaries (scripts/phase_timing.py)
 #endif
@@ -319,7 +330,56 @@ __device__ __forceinline__ bool queue_less(const Mem<LDS>& m, uint32_t a, uint32
   return a < b;                                      // canonical: input row asc
 }
 
-template <bool LDS>
+// Between the two sorts of the generic path: the keys are sorted by [value | unit min row | slot | row], so the tasks
+// emitted from one unit are contiguous. Finds every position's run start (chunked max-scan of the positions where the
+// slot changes; scan = kBlock ints of LDS) and rewrites the keys in place as [run start : 24][TaskList.Less key : 64][row : 24].
+__device__ __forceinline__ void second_sort_keys(K128* keys, int n, int lo, const evg_task_soa& t, uint32_t tmin, uint32_t nmax,
+                                                 uint64_t pmax, uint64_t dmax, int bn, int bp, int bd, int* scan) {
+  const int tid = threadIdx.x;
+  // ---- run starts: chunked max-scan of the positions where the slot changes ----
+  const int per = (n + kBlock - 1) / kBlock;
+  const int q0 = tid * per < n ? tid * per : n, q1 = q0 + per < n ? q0 + per : n;
+  auto slot_at = [&](int q) { return (uint32_t)((keys[q].lo >> 24) & 0x1FFFFFFu); };
+  const uint32_t prev0 = q0 > 0 && q0 < n ? slot_at(q0 - 1) : 0xFFFFFFFFu;
+  int lastb = -1;
+  {
+    uint32_t prev = prev0;
+    for (int q = q0; q < q1; q++) { const uint32_t sl = slot_at(q); if (q == 0 || sl != prev) lastb = q; prev = sl; }
+  }
+  __syncthreads();
+  scan[tid] = lastb;
+  __syncthreads();
+  for (int o = 1; o < kBlock; o <<= 1) {
+    const int v = tid >= o ? scan[tid - o] : -1;
+    __syncthreads();
+    if (v > scan[tid]) scan[tid] = v;
+    __syncthreads();
+  }
+  int run = tid ? scan[tid - 1] : -1;  // last run start before this chunk
+  __syncthreads();
+  // ---- keys of sort 2, in place ----
+  {
+    uint32_t prev = prev0;
+    for (int q = q0; q < q1; q++) {
+      const K128 k = keys[q];
+      const uint32_t sl = (uint32_t)((k.lo >> 24) & 0x1FFFFFFu);
+      const int i = (int)(k.lo & 0xFFFFFFu);
+      if (q == 0 || sl != prev) run = q;
+      prev = sl;
+      const int r = lo + i;
+      const uint64_t ik = shl64((uint64_t)(ub(t.task_group_order[r]) - tmin), bn + bp + bd) |
+                          shl64((uint64_t)(nmax - ub(t.num_dependents[r])), bp + bd) | shl64(pmax - ub(t.priority[r]), bd) |
+                          (dmax - ub(t.expected_duration_ns[r]));
+      keys[q] = K128{((uint64_t)run << 40) | (ik >> 24), (ik << 40) | (uint64_t)i};  // [run start : 24][key : 64][row : 24]
+    }
+  }
+}
+
+// STAGE selects the part of the distro's plan this call runs: 0 everything (one workgroup from start to end);
+// 1 "pre": up to the packed keys of the first sort, which the pipeline's sort kernels then spread over all CUs (a distro
+// whose ranges do not pack is finished here by the comparator sort); 3 "post": from the sorted keys to the end.
+// (Stage 2, the run scan between the two sorts, is generic_mid below.)
+template <bool LDS, int STAGE = 0>
 __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigned* s_red, K128* sort_buf = nullptr) {
   using idx_t = typename Mem<LDS>::idx_t;
   using k1_t = typename Mem<LDS>::k1_t;
@@ -331,6 +391,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
   const int lo = c.lo, n = c.n, S = c.S;
 
   EVG_STAMP(0);
+  if (STAGE != 3) {
   // ---- P0/P1: init accumulators, primary slots ---------------------------------------------------------
   for (int u = tid; u < S; u += kBlock) {
     m.tiq[u] = 0; m.dur[u] = 0; m.maxpri[u] = 0; m.cnt[u] = 0; m.maxnd[u] = 0; m.minrow[u] = 0xFFFFFFFFu;
@@ -443,6 +504,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
     }
   }
   __syncthreads();  // accumulators are dead from here on
+  }  // STAGE != 3
 
   EVG_STAMP(5);
   const int P = c.P;
@@ -458,9 +520,10 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
       co[i] = t.task_group_order[r]; cn[i] = t.num_dependents[r];
     }
   }
-  for (int i = tid; i < P; i += kBlock) m.idx[i] = i < n ? (idx_t)i : (idx_t)pad;
+  if (STAGE != 3)
+    for (int i = tid; i < P; i += kBlock) m.idx[i] = i < n ? (idx_t)i : (idx_t)pad;
   // group accumulators (rows: standalone + ntg)
-  for (int k = tid; k < c.ntg + 1; k += kBlock) {
+  for (int k = tid; STAGE != 3 && k < c.ntg + 1; k += kBlock) {
     const int g = m.grow(k - 1);
     m.g_cnt[g] = 0; m.g_cover[g] = 0; m.g_wait[g] = 0; m.g_mq[g] = 0; m.g_first[g] = 0xFFFFFFFFu;
     m.g_dur[g] = 0; m.g_dover[g] = 0;
@@ -472,7 +535,15 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
   // (2) by [run start | TaskList.Less key | row]: order inside each unit. Needs the value range of the distro to fit
   // 55 bits and the TaskList.Less ranges to fit 64 bits; otherwise the comparator sort below runs instead.
   bool sorted_fast = false;
-  if (!LDS && sort_buf && a.w_key && P >= 2048) {
+  if (STAGE == 3) {
+    if (!a.w_gstate[d].fast) return;  // finished by the pre kernel
+    const K128* keys = (const K128*)a.w_key + 2 * (size_t)lo;
+    for (int q = tid; q < n; q += kBlock) m.idx[q] = (idx_t)(keys[q].lo & 0xFFFFFFu);
+    __syncthreads();
+    sorted_fast = true;
+  }
+  if (STAGE == 1 && tid == 0) a.w_gstate[d].fast = 0;
+  if (STAGE != 3 && !LDS && sort_buf && a.w_key && P >= 2048) {
     unsigned long long* r64 = (unsigned long long*)(s_red + 16);  // vmin vmax dmin dmax pmin pmax
     uint32_t* r32 = s_red + 28;                                   // tmin tmax nmin nmax
     __syncthreads();
@@ -514,46 +585,20 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
         }
         keys[i] = k;
       }
+      if (STAGE == 1) {  // hand the distro's tiles to the sort kernels
+        if (tid == 0) {
+          GState g;
+          g.vmax = vmax; g.dmax = dmax; g.pmax = pmax; g.tmin = tmin; g.nmax = nmax; g.bn = bn; g.bp = bp; g.bd = bd; g.fast = 1;
+          a.w_gstate[d] = g;
+          const int nt = P >> 11;
+          const int base = atomicAdd(a.w_ntiles, nt);
+          for (int k = 0; k < nt; k++) { a.w_tiles[2 * (base + k)] = d; a.w_tiles[2 * (base + k) + 1] = k; }
+        }
+        return;
+      }
       __syncthreads();
       tiled_sort_k128(keys, P, sort_buf);
-      // ---- run starts: chunked max-scan of the positions where the slot changes ----
-      const int per = (n + kBlock - 1) / kBlock;
-      const int q0 = tid * per < n ? tid * per : n, q1 = q0 + per < n ? q0 + per : n;
-      auto slot_at = [&](int q) { return (uint32_t)((keys[q].lo >> 24) & 0x1FFFFFFu); };
-      const uint32_t prev0 = q0 > 0 && q0 < n ? slot_at(q0 - 1) : 0xFFFFFFFFu;
-      int lastb = -1;
-      {
-        uint32_t prev = prev0;
-        for (int q = q0; q < q1; q++) { const uint32_t sl = slot_at(q); if (q == 0 || sl != prev) lastb = q; prev = sl; }
-      }
-      int* scan = (int*)sort_buf;
-      __syncthreads();
-      scan[tid] = lastb;
-      __syncthreads();
-      for (int o = 1; o < kBlock; o <<= 1) {
-        const int v = tid >= o ? scan[tid - o] : -1;
-        __syncthreads();
-        if (v > scan[tid]) scan[tid] = v;
-        __syncthreads();
-      }
-      int run = tid ? scan[tid - 1] : -1;  // last run start before this chunk
-      __syncthreads();
-      // ---- keys of sort 2, in place ----
-      {
-        uint32_t prev = prev0;
-        for (int q = q0; q < q1; q++) {
-          const K128 k = keys[q];
-          const uint32_t sl = (uint32_t)((k.lo >> 24) & 0x1FFFFFFu);
-          const int i = (int)(k.lo & 0xFFFFFFu);
-          if (q == 0 || sl != prev) run = q;
-          prev = sl;
-          const int r = lo + i;
-          const uint64_t ik = shl64((uint64_t)(ub(t.task_group_order[r]) - tmin), bn + bp + bd) |
-                              shl64((uint64_t)(nmax - ub(t.num_dependents[r])), bp + bd) | shl64(pmax - ub(t.priority[r]), bd) |
-                              (dmax - ub(t.expected_duration_ns[r]));
-          keys[q] = K128{((uint64_t)run << 40) | (ik >> 24), (ik << 40) | (uint64_t)i};  // [run start : 24][key : 64][row : 24]
-        }
-      }
+      second_sort_keys(keys, n, lo, t, tmin, nmax, pmax, dmax, bn, bp, bd, (int*)sort_buf);
       __syncthreads();
       tiled_sort_k128(keys, P, sort_buf);
       for (int q = tid; q < n; q += kBlock) m.idx[q] = (idx_t)(keys[q].lo & 0xFFFFFFu);

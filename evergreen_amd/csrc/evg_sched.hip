@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -449,10 +450,11 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.in = *in;
   a.out = *out;
   // scratch of the large-distro path (untouched pages cost nothing; small distros never use it)
-  size_t sz[22] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
+  size_t sz[24] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
                    4 * (N + 1), 8 * (N + 1), 8 * (N + 1), 8 * (N + 1), 4 * (N + 1),
-                   4 * G, 4 * G, 4 * G, 4 * G, 4 * G, 8 * G, 8 * G, 4 * (size_t)D, 16 * (2 * N + 4096)};
-  for (int i = 0; i < 22; i++) {
+                   4 * G, 4 * G, 4 * G, 4 * G, 4 * G, 8 * G, 8 * G, 4 * (size_t)D, 16 * (2 * N + 4096),
+                   sizeof(GState) * (size_t)D, 8 * (2 * N / 2048 + (size_t)D + 8)};
+  for (int i = 0; i < 24; i++) {
     int rc = ensure(c, c->scratch[i], sz[i]);
     if (rc) return rc;
   }
@@ -466,6 +468,9 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.g_dover = (uint64_t*)c->scratch[19].p;
   a.w_generic = (int32_t*)c->scratch[20].p;
   a.w_key = c->scratch[21].p;
+  a.w_gstate = (GState*)c->scratch[22].p;
+  a.w_tiles = (int32_t*)c->scratch[23].p;
+  a.w_ntiles = a.w_tiles + 2 * (2 * N / 2048 + (size_t)D + 4);
 #ifdef EVG_PHASE_TIMING
   a.dbg_ts = c->dbg_ts;
 #endif
@@ -502,6 +507,39 @@ static int prepare_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_
   return EVG_OK;
 }
 
+// The generic path behind the LDS kernel. evg_plan_input.max_distro_tasks (0 = unknown) tells how large a distro can
+// be: with every distro <= 2048 tasks only data-dependent fallbacks can be flagged and one kernel finishes them; otherwise
+// the staged pipeline spreads the packed-key sorts of the large distros over all CUs. The launches are unconditional
+// (nothing is read back); kernels of stages that have no work exit at once.
+static int launch_generic(evg_ctx* c, const evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st) {
+  using namespace evg;
+  const int D = in->n_distros;
+  const dim3 gg(D < kGenericGrid ? D : kGenericGrid), bb(kBlock);
+  const long long hint = in->max_distro_tasks > 0 ? in->max_distro_tasks : in->tasks.n_tasks;
+  if (hint <= 2048) {
+    hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a);
+    HIP_TRY(c, hipGetLastError());
+    return EVG_OK;
+  }
+  long long pmax = 2048;
+  while (pmax < hint) pmax <<= 1;
+  const int max_tiles = (int)(2 * (size_t)in->tasks.n_tasks / 2048 + (size_t)D + 4);
+  auto sort_all = [&]() {
+    hipLaunchKernelGGL(k_gsort_tiles<0>, dim3(max_tiles), bb, kGenericLds, st, a, 0);
+    for (long long kk = 4096; kk <= pmax; kk <<= 1) {
+      for (long long j = kk >> 1; j >= 2048; j >>= 1) hipLaunchKernelGGL(k_gsort_global, dim3(max_tiles), bb, 0, st, a, (int)kk, (int)j);
+      hipLaunchKernelGGL(k_gsort_tiles<1>, dim3(max_tiles), bb, kGenericLds, st, a, (int)kk);
+    }
+  };
+  hipLaunchKernelGGL(k_generic_stage<1>, gg, bb, kGenericLds, st, a);
+  sort_all();
+  hipLaunchKernelGGL(k_generic_stage<2>, gg, bb, kGenericLds, st, a);
+  sort_all();
+  hipLaunchKernelGGL(k_generic_stage<3>, gg, bb, kGenericLds, st, a);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
 static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, hipStream_t st) {
   using namespace evg;
   PlanArgs a;
@@ -512,10 +550,8 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   if (out->breakdown || out->n_units) hipLaunchKernelGGL(k_plan_distros<true>, dim3(D), dim3(kBlock), kLdsRich, st, a);
   else hipLaunchKernelGGL(k_plan_distros<false>, dim3(D), dim3(kBlock), kLdsLean, st, a);
   HIP_TRY(c, hipGetLastError());
-  // distros the LDS path could not take (flagged on the device); its workgroups exit at once otherwise
-  hipLaunchKernelGGL(k_plan_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), kGenericLds, st, a);
-  HIP_TRY(c, hipGetLastError());
-  return EVG_OK;
+  // distros the LDS path could not take (flagged on the device); the workgroups exit at once otherwise
+  return launch_generic(c, a, in, st);
 }
 
 int evg_plan_distros_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, void* hip_stream) {
@@ -644,6 +680,8 @@ int evg_plan_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output
   if (D == 0) return EVG_OK;
   Stager s{c};
   evg_plan_input di = *in;
+  if (di.max_distro_tasks <= 0)  // the offsets are host memory here: fill the launch hint in
+    for (size_t d = 0; d < D; d++) di.max_distro_tasks = std::max(di.max_distro_tasks, in->task_off[d + 1] - in->task_off[d]);
   const evg_task_soa& t = in->tasks;
   evg_task_soa& dt = di.tasks;
   dt.priority = s.up(t.priority, N); dt.expected_duration_ns = s.up(t.expected_duration_ns, N);

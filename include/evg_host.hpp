@@ -22,6 +22,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <functional>
 #include <map>
@@ -249,6 +250,7 @@ struct PackedQueues {
     in.tasks.dep_finished_ts_ns = dep_finished.data();
     in.distros = distros.data(); in.task_off = task_off.data(); in.tg_off = tg_off.data(); in.ver_off = ver_off.data();
     in.now_ns = now;
+    for (size_t d = 0; d + 1 < task_off.size(); d++) in.max_distro_tasks = std::max(in.max_distro_tasks, task_off[d + 1] - task_off[d]);
     return in;
   }
 };

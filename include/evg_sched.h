@@ -161,7 +161,8 @@ typedef struct evg_plan_input {
   int32_t n_distros;                  /* D */
   int32_t n_task_groups;              /* tg_off[D]  */
   int32_t n_versions;                 /* ver_off[D] */
-  int32_t reserved;
+  int32_t max_distro_tasks;           /* max over d of task_off[d+1]-task_off[d], or 0 = unknown (a hint: it only
+                                         selects how the generic path is launched, never what is computed)     */
   evg_task_soa tasks;
   const evg_distro_params* distros;   /* D rows */
   const int32_t* task_off;            /* D+1 */
