@@ -41,3 +41,17 @@ def test_cpp_host_layer_with_hip_backend():
     out = subprocess.run([_build(), "hip", native.LIB_PATH], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failed" in out.stdout
+
+
+def test_cpp_host_layer_and_oracle_under_sanitizers(tmp_path):
+    """The reference's CI has a race-detector variant (go test -race, makefile:63-68); the closest equivalent for the C++
+    pieces that run on the host: AddressSanitizer + UndefinedBehaviorSanitizer builds of the host layer and of the oracle,
+    driven through all the known-answer cases."""
+    exe, lib = str(tmp_path / "shim_asan"), str(tmp_path / "liboracle_asan.so")
+    flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-std=c++17"]
+    subprocess.check_call(["g++"] + flags + ["-I", os.path.join(ROOT, "include"), os.path.join(CPP, "test_host_shim.cpp"), "-o", exe, "-ldl"])
+    subprocess.check_call(["g++"] + flags + ["-fPIC", "-shared", "-ffp-contract=off", os.path.join(ROOT, "oracle", "evg_oracle.cpp"), "-o", lib])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([exe, "oracle", lib], capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and "0 failed" in out.stdout, out.stdout + out.stderr
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr
