@@ -250,24 +250,22 @@ struct DC {
   int64_t now;
 };
 
-// The intermediates of one distro: pointers into LDS (small path) or global scratch (large path).
-template <bool LDS>
+// The intermediates of one distro on the generic path: pointers into the global scratch area.
 struct Mem {
-  using idx_t = typename std::conditional<LDS, uint16_t, uint32_t>::type;
-  using k1_t = typename std::conditional<LDS, uint32_t, uint64_t>::type;
-  static constexpr int kShift = LDS ? 16 : 32;
+  using idx_t = uint32_t;
+  using k1_t = uint64_t;
+  static constexpr int kShift = 32;
   int64_t *tiq, *dur, *maxpri, *val;
   uint32_t* cnt;
   int32_t* maxnd;
   uint32_t* minrow;
-  uint64_t* hash;    // LDS: aliases k0/k1 (used before P4 only)
+  uint64_t* hash;
   idx_t* pslot;
-  uint16_t* tflags;  // LDS only; the large path reads the global column
-  int64_t* k0;
-  k1_t* k1;
-  idx_t* idx;
-  idx_t* pos;        // LDS: aliases pslot (dead after P4)
-  const int64_t *c_pri, *c_dur;  // sort task-key columns: LDS copies, or the global inputs at the distro
+  int64_t* k0;       // elected unit's TotalValue per task
+  k1_t* k1;          // (unit min row << 32) | unit slot per task
+  idx_t* idx;        // task at each queue position (2n entries: padded to a power of two for the comparator sort)
+  idx_t* pos;        // queue position of each task
+  const int64_t *c_pri, *c_dur;  // TaskList.Less columns of the distro (the global inputs)
   const int32_t *c_tgo, *c_nd;
   uint32_t *g_cnt, *g_cover, *g_wait, *g_mq, *g_first;  // group accumulators
   uint64_t *g_dur, *g_dover;
@@ -286,8 +284,8 @@ __device__ __forceinline__ int pslot_of(int i, int tgk, int verk, const DC& c) {
 //   the version unit too when it is a task-group task and versions are grouped (:439),
 //   the primary unit of each direct dependency that is in this distro's queue (:451-455).
 // DEDUP: each distinct slot exactly once (Unit.Add is keyed by task id, :131).
-template <bool LDS, bool DEDUP, class F>
-__device__ __forceinline__ void for_each_unit(const Mem<LDS>& m, const DC& c, int i, int tgk, int verk, int e0, int e1,
+template <bool DEDUP, class F>
+__device__ __forceinline__ void for_each_unit(const Mem& m, const DC& c, int i, int tgk, int verk, int e0, int e1,
                                               const int32_t* __restrict__ dep_idx, F f) {
   const int t0 = m.pslot[i];
   f(t0, true);
@@ -311,8 +309,7 @@ __device__ __forceinline__ void for_each_unit(const Mem<LDS>& m, const DC& c, in
 }
 
 // Strict weak order of the queue: position of task a before task b?
-template <bool LDS>
-__device__ __forceinline__ bool queue_less(const Mem<LDS>& m, uint32_t a, uint32_t b, uint32_t pad) {
+__device__ __forceinline__ bool queue_less(const Mem& m, uint32_t a, uint32_t b, uint32_t pad) {
   if (a == pad) return false;
   if (b == pad) return true;
   const int64_t va = m.k0[a], vb = m.k0[b];
@@ -379,10 +376,10 @@ __device__ __forceinline__ void second_sort_keys(K128* keys, int n, int lo, cons
 // 1 "pre": up to the packed keys of the first sort, which the pipeline's sort kernels then spread over all CUs (a distro
 // whose ranges do not pack is finished here by the comparator sort); 3 "post": from the sorted keys to the end.
 // (Stage 2, the run scan between the two sorts, is generic_mid below.)
-template <bool LDS, int STAGE = 0>
-__device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<LDS>& m, unsigned* s_red, K128* sort_buf = nullptr) {
-  using idx_t = typename Mem<LDS>::idx_t;
-  using k1_t = typename Mem<LDS>::k1_t;
+template <int STAGE = 0>
+__device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem& m, unsigned* s_red, K128* sort_buf = nullptr) {
+  using idx_t = Mem::idx_t;
+  using k1_t = Mem::k1_t;
   const evg_task_soa& t = a.in.tasks;
   const int d = c.d;
   const evg_distro_params p = a.in.distros[d];
@@ -399,7 +396,6 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
   for (int i = tid; i < n; i += kBlock) {
     const int r = lo + i;
     m.pslot[i] = (idx_t)pslot_of(i, t.tg_key[r], t.version_key[r], c);
-    if (LDS) m.tflags[i] = t.flags[r];
   }
   if (tid < 8) s_red[tid] = 0;
   __syncthreads();
@@ -418,7 +414,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
     uf |= tgk < 0 ? UF_NONGROUP : 0u;
     uf |= (f & EVG_TF_GENERATE) ? UF_GENERATE : 0u;
     uf |= (f & EVG_TF_STEPBACK) ? UF_STEPBACK : 0u;
-    for_each_unit<LDS, true>(m, c, i, tgk, verk, t.dep_off[r], t.dep_off[r + 1], t.dep_idx, [&](int u, bool primary) {
+    for_each_unit<true>(m, c, i, tgk, verk, t.dep_off[r], t.dep_off[r + 1], t.dep_idx, [&](int u, bool primary) {
       if (tiq != 0) atomicAdd((unsigned long long*)&m.tiq[u], (unsigned long long)tiq);
       atomicAdd((unsigned long long*)&m.dur[u], (unsigned long long)dur);
       if (pri > 0) atomicMax((long long*)&m.maxpri[u], (long long)pri);
@@ -452,7 +448,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
     for (int i = tid; i < n; i += kBlock) {
       const int r = lo + i;
       const uint64_t h = mix64((uint64_t)i);
-      for_each_unit<LDS, true>(m, c, i, t.tg_key[r], t.version_key[r], t.dep_off[r], t.dep_off[r + 1], t.dep_idx,
+      for_each_unit<true>(m, c, i, t.tg_key[r], t.version_key[r], t.dep_off[r], t.dep_off[r + 1], t.dep_idx,
                                [&](int u, bool) { atomicAdd((unsigned long long*)&m.hash[u], (unsigned long long)h); });
     }
     __syncthreads();
@@ -464,7 +460,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
       bool dup = false;
       const uint64_t hu = m.hash[u];
       const uint32_t cu = m.cnt[u] & UF_COUNT_MASK;
-      for_each_unit<LDS, false>(m, c, i, t.tg_key[r], t.version_key[r], t.dep_off[r], t.dep_off[r + 1], t.dep_idx,
+      for_each_unit<false>(m, c, i, t.tg_key[r], t.version_key[r], t.dep_off[r], t.dep_off[r + 1], t.dep_idx,
                                 [&](int w, bool) {
                                   if (w < u && m.val[w] != INT64_MIN && m.hash[w] == hu &&
                                       (m.cnt[w] & UF_COUNT_MASK) == cu && m.minrow[w] == (uint32_t)i)
@@ -486,7 +482,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
     int best = -1;
     int64_t bv = INT64_MIN;
     uint32_t bm = 0;
-    for_each_unit<LDS, false>(m, c, i, t.tg_key[r], t.version_key[r], t.dep_off[r], t.dep_off[r + 1], t.dep_idx,
+    for_each_unit<false>(m, c, i, t.tg_key[r], t.version_key[r], t.dep_off[r], t.dep_off[r + 1], t.dep_idx,
                               [&](int u, bool) {
                                 const int64_t v = m.val[u];
                                 if (v == INT64_MIN) return;
@@ -496,7 +492,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
                                 }
                               });
     m.k0[i] = bv;
-    m.k1[i] = ((k1_t)bm << Mem<LDS>::kShift) | (k1_t)best;
+    m.k1[i] = ((k1_t)bm << Mem::kShift) | (k1_t)best;
     if (a.out.breakdown) {
       const uint32_t cw = m.cnt[best];
       unit_value(p, cw & UF_COUNT_MASK, m.tiq[best], m.dur[best], m.maxpri[best], m.maxnd[best], cw,
@@ -508,18 +504,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
 
   EVG_STAMP(5);
   const int P = c.P;
-  const uint32_t pad = LDS ? 0xFFFFu : 0xFFFFFFFFu;
-  if (LDS) {
-    int64_t* cp = const_cast<int64_t*>(m.c_pri);
-    int64_t* cd = const_cast<int64_t*>(m.c_dur);
-    int32_t* co = const_cast<int32_t*>(m.c_tgo);
-    int32_t* cn = const_cast<int32_t*>(m.c_nd);
-    for (int i = tid; i < n; i += kBlock) {
-      const int r = lo + i;
-      cp[i] = t.priority[r]; cd[i] = t.expected_duration_ns[r];
-      co[i] = t.task_group_order[r]; cn[i] = t.num_dependents[r];
-    }
-  }
+  const uint32_t pad = 0xFFFFFFFFu;
   if (STAGE != 3)
     for (int i = tid; i < P; i += kBlock) m.idx[i] = i < n ? (idx_t)i : (idx_t)pad;
   // group accumulators (rows: standalone + ntg)
@@ -543,7 +528,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
     sorted_fast = true;
   }
   if (STAGE == 1 && tid == 0) a.w_gstate[d].fast = 0;
-  if (STAGE != 3 && !LDS && sort_buf && a.w_key && P >= 2048) {
+  if (STAGE != 3 && sort_buf && a.w_key && P >= 2048) {
     unsigned long long* r64 = (unsigned long long*)(s_red + 16);  // vmin vmax dmin dmax pmin pmax
     uint32_t* r32 = s_red + 28;                                   // tmin tmax nmin nmax
     __syncthreads();
@@ -607,23 +592,15 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
     }
   }
   // ---- P5: bitonic sort of idx[] by queue_less ------------------------------------------------------------
-  int prev_j = 1 << 30;
   for (int k = 2; k <= (sorted_fast ? 0 : P); k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      if (LDS && j <= 64 && prev_j <= 64) {
-        // both this stage and the previous one only touch the 128 elements this wave owns
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-      } else {
-        __syncthreads();
-      }
-      prev_j = j;
+      __syncthreads();
       for (int tt = tid; tt < (P >> 1); tt += kBlock) {
         const int i = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
         const int x = i | j;
         const uint32_t ia = m.idx[i], ib = m.idx[x];
         const bool up = (i & k) == 0;
-        const bool sw = up ? queue_less<LDS>(m, ib, ia, pad) : queue_less<LDS>(m, ia, ib, pad);
+        const bool sw = up ? queue_less(m, ib, ia, pad) : queue_less(m, ia, ib, pad);
         if (sw) { m.idx[i] = (idx_t)ib; m.idx[x] = (idx_t)ia; }
       }
     }
@@ -658,7 +635,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem<
         uint32_t st;
         bool blk;
         if ((unsigned)j < (unsigned)n) {
-          const uint32_t fj = LDS ? (uint32_t)m.tflags[j] : (uint32_t)t.flags[lo + j];
+          const uint32_t fj = (uint32_t)t.flags[lo + j];
           st = (fj & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT;
           blk = fj & EVG_TF_BLOCKED;
         } else {

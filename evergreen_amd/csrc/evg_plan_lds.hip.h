@@ -907,10 +907,10 @@ template <int STAGE = 0>
 __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c, unsigned* s_red, K128* sort_buf) {
   const int d = c.d;
   const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // disjoint slot range of this distro
-  Mem<false> m;
+  Mem m;
   m.tiq = a.w_tiq + sb; m.dur = a.w_dur + sb; m.maxpri = a.w_maxpri + sb; m.val = a.w_val + sb;
   m.cnt = a.w_cnt + sb; m.maxnd = a.w_maxnd + sb; m.minrow = a.w_minrow + sb; m.hash = a.w_hash + sb;
-  m.pslot = a.w_pslot + c.lo; m.tflags = nullptr;
+  m.pslot = a.w_pslot + c.lo;
   m.k0 = a.w_k0 + c.lo; m.k1 = a.w_k1 + c.lo; m.idx = a.w_idx + 2 * (size_t)c.lo; m.pos = a.w_pos + c.lo;
   const evg_task_soa& t = a.in.tasks;
   m.c_pri = t.priority + c.lo; m.c_dur = t.expected_duration_ns + c.lo;
@@ -918,7 +918,7 @@ __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c
   m.g_cnt = a.g_cnt; m.g_cover = a.g_cover; m.g_wait = a.g_wait; m.g_mq = a.g_mq; m.g_first = a.g_first;
   m.g_dur = a.g_dur; m.g_dover = a.g_dover;
   m.g0 = d; m.gk = c.D + c.tg_lo;
-  plan_distro<false, STAGE>(a, c, m, s_red, sort_buf);
+  plan_distro<STAGE>(a, c, m, s_red, sort_buf);
 }
 
 // One workgroup per distro the LDS path left over (none in the headline configuration): every intermediate lives
