@@ -44,12 +44,13 @@ constexpr uint32_t UF_MERGE = 1u << 24, UF_PATCH = 2u << 24, UF_NONGROUP = 4u <<
                    UF_STEPBACK = 16u << 24, UF_DISTRO = 32u << 24;
 constexpr uint32_t UF_COUNT_MASK = 0x00FFFFFFu;
 
-// What the staged generic pipeline (pre -> sort -> mid -> sort -> post) keeps per distro between its kernels.
+// What the generic pipelines (pre -> sort -> mid -> sort -> post) keep per distro between their kernels.
 struct GState {
-  unsigned long long vmax, dmax, pmax;  // biased range tops of the elected values / durations / priorities
-  uint32_t tmin, nmax;                  // biased task-group-order minimum, num-dependents maximum
-  int32_t bn, bp, bd;                   // bit widths of the TaskList.Less key fields below the group order
-  int32_t fast;                         // 1: packed-key sorts are in flight for this distro; 0: already finished
+  unsigned long long vmin, vmax, dmin, dmax, pmin, pmax;  // biased ranges of the elected values / durations / priorities
+  uint32_t tmin, tmax, nmin, nmax;                        // biased ranges of task-group order / num dependents
+  int32_t bn, bp, bd;                                     // bit widths of the TaskList.Less key fields below the group order
+  int32_t fast;                                           // 1: packed-key sorts are in flight for this distro
+  uint32_t any_mq, n_met, n_mq, n_s3, sec, pad;           // flat pipeline: GetDistroQueueInfo's per-distro flags / counters
 };
 
 struct PlanArgs {
@@ -572,7 +573,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem&
       }
       if (STAGE == 1) {  // hand the distro's tiles to the sort kernels
         if (tid == 0) {
-          GState g;
+          GState g{};
           g.vmax = vmax; g.dmax = dmax; g.pmax = pmax; g.tmin = tmin; g.nmax = nmax; g.bn = bn; g.bp = bp; g.bd = bd; g.fast = 1;
           a.w_gstate[d] = g;
           const int nt = P >> 11;

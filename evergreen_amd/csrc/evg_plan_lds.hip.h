@@ -927,11 +927,13 @@ __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c
 // the normal case -- the launch costs a quarter of a one-workgroup-per-distro grid.
 constexpr int kGenericGrid = 128;
 constexpr int kGenericLds = 2048 * 16;  // one tile of 128-bit keys
-__global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a) {
+// skip_flat: the flat pipeline (evg_generic_flat.hip.h) ran first and finished the large distros whose keys packed.
+__global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a, int skip_flat) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
   for (int d = blockIdx.x; d < a.in.n_distros; d += gridDim.x) {
     if (!a.w_generic[d]) continue;
+    if (skip_flat && a.in.task_off[d + 1] - a.in.task_off[d] > 1024 && a.w_gstate[d].fast) continue;
     const DC c = distro_context(a, d);
     __syncthreads();
     if (threadIdx.x < 32) s_red[threadIdx.x] = 0;

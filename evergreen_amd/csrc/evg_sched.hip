@@ -18,6 +18,7 @@
 
 #include "evg_alloc.hip.h"
 #include "evg_plan_lds.hip.h"
+#include "evg_generic_flat.hip.h"
 
 namespace evg {
 
@@ -517,7 +518,7 @@ static int launch_generic(evg_ctx* c, const evg::PlanArgs& a, const evg_plan_inp
   const dim3 gg(D < kGenericGrid ? D : kGenericGrid), bb(kBlock);
   const long long hint = in->max_distro_tasks > 0 ? in->max_distro_tasks : in->tasks.n_tasks;
   if (hint <= 2048) {
-    hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a);
+    hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 0);
     HIP_TRY(c, hipGetLastError());
     return EVG_OK;
   }
@@ -531,11 +532,34 @@ static int launch_generic(evg_ctx* c, const evg::PlanArgs& a, const evg_plan_inp
       hipLaunchKernelGGL(k_gsort_tiles<1>, dim3(max_tiles), bb, kGenericLds, st, a, (int)kk);
     }
   };
-  hipLaunchKernelGGL(k_generic_stage<1>, gg, bb, kGenericLds, st, a);
+  if (a.out.n_units) {
+    // TaskPlan.Len() needs the set-equality pass of the one-workgroup form: staged per-distro pipeline
+    hipLaunchKernelGGL(k_generic_stage<1>, gg, bb, kGenericLds, st, a);
+    sort_all();
+    hipLaunchKernelGGL(k_generic_stage<2>, gg, bb, kGenericLds, st, a);
+    sort_all();
+    hipLaunchKernelGGL(k_generic_stage<3>, gg, bb, kGenericLds, st, a);
+    HIP_TRY(c, hipGetLastError());
+    return EVG_OK;
+  }
+  // flat pipeline: every phase of the large flagged distros over the whole chip
+  const size_t N = (size_t)in->tasks.n_tasks, Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions;
+  auto blocks = [](size_t n) { return dim3((unsigned)((n + kFlatBlock - 1) / kFlatBlock)); };
+  const dim3 fb(kFlatBlock);
+  hipLaunchKernelGGL(k_flat_init, dim3(1024), fb, 0, st, a);
+  hipLaunchKernelGGL(k_flat_reduce, blocks(N), fb, 0, st, a);
+  hipLaunchKernelGGL(k_flat_score, blocks(Stot), fb, 0, st, a);
+  hipLaunchKernelGGL(k_flat_elect, blocks(N), fb, 0, st, a);
+  hipLaunchKernelGGL(k_flat_keys, blocks(2 * N), fb, 0, st, a);
   sort_all();
   hipLaunchKernelGGL(k_generic_stage<2>, gg, bb, kGenericLds, st, a);
   sort_all();
-  hipLaunchKernelGGL(k_generic_stage<3>, gg, bb, kGenericLds, st, a);
+  hipLaunchKernelGGL(k_flat_order, blocks(N), fb, 0, st, a);
+  hipLaunchKernelGGL(k_flat_deps_met, blocks(N), fb, 0, st, a);
+  hipLaunchKernelGGL(k_flat_sums, blocks(N), fb, 0, st, a);
+  hipLaunchKernelGGL(k_flat_rows, gg, fb, 0, st, a);
+  // flagged distros that are small, or whose ranges did not pack
+  hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 1);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }
