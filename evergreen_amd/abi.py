@@ -73,6 +73,13 @@ class QueueItems(C.Structure):
 
 
 TASK_QUEUE_SAVE_LIMIT = 10000
+
+
+class DispatchOrder(C.Structure):
+    _fields_ = [("sorted", _p), ("n_sorted", _p), ("n_cycles", _p), ("group_items", _p), ("group_start", _p), ("group_count", _p)]
+
+
+DISPATCH_ORDER_ARRAYS = ("sorted", "n_sorted", "n_cycles", "group_items", "group_start", "group_count")
 QUEUE_ITEM_COLUMNS = {"row": np.int32, "expected_duration_ns": np.int64, "priority": np.int64, "group_max_hosts": np.int32,
                       "group_index": np.int32, "n_dependencies": np.int32, "dependencies_met": np.uint8}
 
@@ -330,3 +337,35 @@ class QueueItemsResult:
         m = int(self.item_off[-1])
         return QueueItemsResult(self.cut, self.item_off, {k: v[:m] for k, v in self.cols.items()},
                                 None if self.breakdown is None else self.breakdown[:m])
+
+
+@dataclass
+class DispatchOrderResult:
+    """evg_dispatch_order on the host: every distro's dispatcher order (d.sorted as queue indexes, -1 = nil entry) at
+    item_off[d], and the task-group units (queue indexes, stable-sorted by GroupIndex) per tg_key."""
+    sorted: np.ndarray
+    n_sorted: np.ndarray
+    n_cycles: np.ndarray
+    group_items: np.ndarray
+    group_start: np.ndarray
+    group_count: np.ndarray
+
+    @staticmethod
+    def alloc_host(batch: PlanBatch) -> "DispatchOrderResult":
+        n, d, g = max(batch.n_tasks, 1), batch.n_distros, max(int(batch.tg_off[-1]) if batch.n_distros else 0, 1)
+        return DispatchOrderResult(np.full(n, -2, np.int32), np.zeros(max(d, 1), np.int32), np.zeros(max(d, 1), np.int32),
+                                   np.full(n, -2, np.int32), np.zeros(g, np.int32), np.zeros(g, np.int32))
+
+    def c_struct(self) -> DispatchOrder:
+        o = DispatchOrder()
+        for k in DISPATCH_ORDER_ARRAYS:
+            setattr(o, k, _ptr(getattr(self, k)))
+        return o
+
+    def distro_sorted(self, item_off: np.ndarray, d: int) -> np.ndarray:
+        lo = int(item_off[d])
+        return self.sorted[lo:lo + int(self.n_sorted[d])]
+
+    def group_tasks(self, g: int) -> np.ndarray:
+        lo = int(self.group_start[g])
+        return self.group_items[lo:lo + int(self.group_count[g])]

@@ -19,6 +19,7 @@
 #include "evg_alloc.hip.h"
 #include "evg_plan_lds.hip.h"
 #include "evg_generic_flat.hip.h"
+#include "evg_dispatch.hip.h"
 
 namespace evg {
 
@@ -272,7 +273,7 @@ struct evg_ctx {
   std::mutex mu;
   hipStream_t stream = nullptr;  // used by the host-pointer entry points
   // scratch of the large-distro path + allocator
-  std::vector<DevBuf> scratch = std::vector<DevBuf>(32);
+  std::vector<DevBuf> scratch = std::vector<DevBuf>(32);  // 0-23 planner, 24-27 allocator, 28 dispatcher
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
@@ -672,6 +673,36 @@ int evg_filter_runnable_device(evg_ctx* c, const evg_plan_input* in, const uint8
   HIP_TRY(c, hipSetDevice(c->device));
   hipLaunchKernelGGL(evg::k_filter_runnable, dim3(in->n_distros), dim3(256), 0, (hipStream_t)hip_stream, *in, dispatchable, deps_met, keep,
                      runnable_row, runnable_count);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
+int evg_dispatch_order_device(evg_ctx* c, const evg_plan_input* in, const int32_t* item_off, const int32_t* item_row,
+                              const evg_dispatch_order* out, void* hip_stream) {
+  if (!c || !in || !out) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (in->n_distros < 0 || in->tasks.n_tasks < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
+  if (in->n_distros == 0) return EVG_OK;
+  const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, G = in->n_task_groups;
+  if (!item_off || !out->n_sorted || !out->n_cycles || (G > 0 && (!out->group_start || !out->group_count)) ||
+      (N > 0 && (!item_row || !out->sorted || !out->group_items)))
+    return set_err(c, EVG_E_INVALID, "null dispatch-order argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  constexpr int kItemArrays = 17;
+  const size_t words = (1 + kItemArrays) * (N + 64) + 2 * (E + 64) + (G + 64);
+  int rc = ensure(c, c->scratch[28], words * sizeof(int32_t));
+  if (rc) return rc;
+  evg::DispatchArgs a{};
+  a.in = *in; a.item_off = item_off; a.item_row = item_row; a.out = *out;
+  int32_t* w = (int32_t*)c->scratch[28].p;
+  auto take = [&](size_t n) { int32_t* p = w; w += n + 64; return p; };
+  a.pos = take(N);
+  int32_t** item_arrays[kItemArrays] = {&a.cnt, &a.beg, &a.cur, &a.top, &a.bcnt, &a.bbeg, &a.m, &a.fbeg, &a.tmp, &a.own, &a.idx, &a.low,
+                                        &a.onstk, &a.cstk, &a.sstk, &a.gtmp, &a.llist};
+  for (auto pp : item_arrays) *pp = take(N);
+  a.adj = take(E); a.adj2 = take(E);
+  a.gcur = take(G);
+  hipLaunchKernelGGL(evg::k_dispatch_order, dim3(in->n_distros), dim3(evg::kDBlock), 0, (hipStream_t)hip_stream, a);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }

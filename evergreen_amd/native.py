@@ -20,7 +20,7 @@ EXPORTS = [
     "evg_create", "evg_destroy", "evg_last_error", "evg_abi_version", "evg_validate_plan_input",
     "evg_plan_distros", "evg_plan_distros_device", "evg_allocate_hosts", "evg_allocate_hosts_device",
     "evg_cap_queue_device", "evg_plan_allocate_device", "evg_materialize_queue_device",
-    "evg_allocator_report_device", "evg_filter_runnable_device",
+    "evg_allocator_report_device", "evg_filter_runnable_device", "evg_dispatch_order_device",
 ]
 
 _lib = None
@@ -65,6 +65,8 @@ def load_library() -> C.CDLL:
                                                  C.POINTER(abi.QueueItems), C.c_void_p]
     lib.evg_allocator_report_device.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8
     lib.evg_filter_runnable_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput)] + [C.c_void_p] * 6
+    lib.evg_dispatch_order_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.c_void_p, C.c_void_p, C.POINTER(abi.DispatchOrder),
+                                              C.c_void_p]
     lib.evg_cap_queue_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p]
     _lib = lib
@@ -141,6 +143,11 @@ class Context:
                                runnable_count: int, stream: Optional[int] = None) -> None:
         self._check(self.lib.evg_filter_runnable_device(self.h, C.byref(inp), dispatchable, deps_met, keep, runnable_row, runnable_count,
                                                         stream), "evg_filter_runnable_device")
+
+    def dispatch_order_device(self, inp: abi.PlanInput, item_off: int, item_row: int, out: abi.DispatchOrder,
+                              stream: Optional[int] = None) -> None:
+        self._check(self.lib.evg_dispatch_order_device(self.h, C.byref(inp), item_off, item_row, C.byref(out), stream),
+                    "evg_dispatch_order_device")
 
     def cap_queue_device(self, n_distros: int, task_off: int, order: int, tg_name_key: int, max_scheduled: int,
                          cut: int, stream: Optional[int] = None) -> None:

@@ -85,6 +85,26 @@ class ResidentPool:
                                    breakdown=self._qi["breakdown"].cpu().numpy().reshape(-1, abi.BREAKDOWN_FIELDS) if self.o_bd is not None else None)
         return res.trimmed()
 
+    def dispatch_order(self, stream: Optional[int] = None, sync: bool = True) -> Optional[abi.DispatchOrderResult]:
+        """The DAG dispatcher's rebuild for every distro over the queues materialize_queue left on the device
+        (evg_dispatch_order_device). Returns host copies (None with sync=False)."""
+        torch = self.torch
+        b, dev = self.batch, self.device
+        assert hasattr(self, "_qi"), "materialize_queue first: the dispatcher is built from the persisted queue"
+        if not hasattr(self, "_do"):
+            n, D, g = max(b.n_tasks, 1), max(b.n_distros, 1), max(int(b.tg_off[-1]) if b.n_distros else 0, 1)
+            sizes = {"sorted": n, "n_sorted": D, "n_cycles": D, "group_items": n, "group_start": g, "group_count": g}
+            self._do = {k: torch.zeros(sizes[k], dtype=torch.int32, device=dev) for k in abi.DISPATCH_ORDER_ARRAYS}
+        o = abi.DispatchOrder()
+        for k, v in self._do.items():
+            setattr(o, k, v.data_ptr())
+        self.ctx.dispatch_order_device(self.inp, self._qi["item_off"].data_ptr(), self._qi["row"].data_ptr(), o,
+                                       self.stream() if stream is None else stream)
+        if not sync:
+            return None
+        torch.cuda.synchronize(dev)
+        return abi.DispatchOrderResult(**{k: self._do[k].cpu().numpy() for k in abi.DISPATCH_ORDER_ARRAYS})
+
     def plan_result(self) -> abi.PlanResult:
         n = self.batch.n_tasks
         self.torch.cuda.synchronize(self.device)

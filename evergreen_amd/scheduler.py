@@ -520,6 +520,100 @@ def BuildTaskQueue(tasks: Sequence[Task], maxScheduledTasks: int) -> List[TaskQu
     return out[:abi.TASK_QUEUE_SAVE_LIMIT]
 
 
+def compositeGroupID(group: str, variant: str, project: str, version: str) -> str:   # task_queue_service_dependency.go:695-697
+    return "%s_%s_%s_%s" % (group, variant, project, version)
+
+
+def _sort_stabilized(n: int, from_: Dict[int, List[int]]) -> Tuple[List[Optional[int]], int]:
+    """gonum.org/v1/gonum v0.17.0 graph/topo SortStabilized with order = ascending node (node == queueIndex,
+    task_queue_service_dependency.go:207-216): Tarjan's search over the nodes in descending order, successors in
+    descending order; components in reverse order of completion; a component of more than one node becomes one None.
+    Host-object form (explicit stack instead of recursion); returns (sorted, number of unorderable components)."""
+    index_of, low, on_stack, stack, sccs, counter = {}, {}, set(), [], [], 0
+    for root in range(n - 1, -1, -1):
+        if root in index_of:
+            continue
+        frames = []
+
+        def enter(v):
+            nonlocal counter
+            counter += 1
+            index_of[v] = low[v] = counter
+            stack.append(v)
+            on_stack.add(v)
+            frames.append((v, iter(sorted(set(from_.get(v, ())), reverse=True))))
+
+        enter(root)
+        while frames:
+            v, it = frames[-1]
+            w = next(it, None)
+            if w is None:
+                frames.pop()
+                if frames:
+                    u = frames[-1][0]
+                    low[u] = min(low[u], low[v])
+                if low[v] == index_of[v]:
+                    comp = []
+                    while True:
+                        x = stack.pop()
+                        on_stack.discard(x)
+                        comp.append(x)
+                        if x == v:
+                            break
+                    sccs.append(comp)
+            elif w not in index_of:
+                enter(w)
+            elif w in on_stack:
+                low[v] = min(low[v], index_of[w])
+    out = [c[0] if len(c) == 1 else None for c in sccs]
+    out.reverse()
+    return out, sum(1 for c in sccs if len(c) != 1)
+
+
+@dataclass
+class schedulableUnit:                             # model/task_queue_service.go (the fields rebuild fills)
+    id: str = ""
+    group: str = ""
+    project: str = ""
+    version: str = ""
+    variant: str = ""
+    maxHosts: int = 0
+    tasks: List[TaskQueueItem] = field(default_factory=list)
+
+
+class basicCachedDAGDispatcherImpl:
+    """The part of model/task_queue_service_dependency.go the batched evg_dispatch_order_device computes: rebuild
+    (:153-250). `sorted` holds the items in dispatcher order (None = the nil entry of a dependency cycle); `taskGroups`
+    maps compositeGroupID -> schedulableUnit with its tasks stable-sorted by GroupIndex. FindNextTask (DB reads, host
+    state, locking) is the caller's."""
+
+    def __init__(self, distroID: str = ""):
+        self.distroID = distroID
+        self.sorted: List[Optional[TaskQueueItem]] = []
+        self.taskGroups: Dict[str, schedulableUnit] = {}
+        self.cycles = 0
+
+    def rebuild(self, items: Sequence[TaskQueueItem]) -> None:
+        itemNodeMap = {it.Id: i for i, it in enumerate(items)}             # addItem, queueIndex = i   :161-164
+        self.taskGroups = {}
+        for it in items:                                                   # :166-188
+            if it.Group != "":
+                gid = compositeGroupID(it.Group, it.BuildVariant, it.Project, it.Version)
+                su = self.taskGroups.get(gid)
+                if su is None:
+                    su = self.taskGroups[gid] = schedulableUnit(gid, it.Group, it.Project, it.Version, it.BuildVariant, it.GroupMaxHosts)
+                su.tasks.append(it)
+        for su in self.taskGroups.values():                                # sort.SliceStable by GroupIndex   :190-195
+            su.tasks.sort(key=lambda x: x.GroupIndex)
+        from_: Dict[int, List[int]] = {}
+        for i, it in enumerate(items):                                     # addEdge(dependency, item.Id)   :197-204
+            for dep in it.Dependencies:
+                if dep in itemNodeMap:                                     # no node for the dependency: no edge   :125-128
+                    from_.setdefault(itemNodeMap[dep], []).append(i)
+        order, self.cycles = _sort_stabilized(len(items), from_)
+        self.sorted = [None if q is None else items[q] for q in order]
+
+
 def FindRunnableTasks(d: Distro, undispatched: Sequence[Task], can_dispatch: Callable[[Task], bool],
                       dep_lookup: Optional[DepLookup] = None) -> List[Task]:
     """Host-object restatement of LegacyFindRunnableTasks' filter (scheduler/task_finder.go:40-116) after the DB queries:

@@ -374,6 +374,34 @@ int evg_materialize_queue_device(evg_ctx* ctx, const evg_plan_input* in, const e
 int evg_filter_runnable_device(evg_ctx* ctx, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met,
                                uint8_t* keep, int32_t* runnable_row, int32_t* runnable_count, void* hip_stream);
 
+/* ---- the DAG dispatcher's rebuild --------------------------------------------------------------
+ * model/task_queue_service_dependency.go:153-250 (basicCachedDAGDispatcherImpl.rebuild): one node per persisted
+ * TaskQueueItem (queueIndex = position in the distro's queue, :161-164), one line dependency -> dependent for every
+ * entry of item.Dependencies that is itself in the queue (addEdge :119-150; others are skipped), then
+ * topo.SortStabilized(graph, order by queueIndex) (:205-217, gonum.org/v1/gonum v0.17.0 graph/topo: Tarjan's SCC
+ * search over the nodes in DESCENDING queueIndex, successors in descending queueIndex, the components in reverse
+ * order of completion; a component of more than one node -- a dependency cycle -- leaves ONE nil entry), and the
+ * schedulableUnit of every task group: its items in queue order, stable-sorted by GroupIndex (:166-195).
+ *
+ * Inputs: `in` = the planner's batch (dependency CSR, tg_key = the composite group id, task_group_order = GroupIndex)
+ * and the persisted queues evg_materialize_queue_device produced (item_off[D+1], item_row[]). Outputs, all indexed
+ * like the items (distro d at item_off[d]):
+ *   sorted[item_off[d] + k], k < n_sorted[d] : d.sorted -- the queue index of the k-th node, -1 for a nil entry
+ *   n_cycles[d]                              : len(topo.Unorderable)
+ *   group_items[group_start[g] + k], k < group_count[g] : d.taskGroups[g].tasks as queue indexes, g = tg_key
+ * Device pointers; enqueued on hip_stream. */
+typedef struct evg_dispatch_order {
+  int32_t* sorted;      /* n_tasks */
+  int32_t* n_sorted;    /* D */
+  int32_t* n_cycles;    /* D */
+  int32_t* group_items; /* n_tasks */
+  int32_t* group_start; /* n_task_groups: absolute index into group_items */
+  int32_t* group_count; /* n_task_groups */
+} evg_dispatch_order;
+
+int evg_dispatch_order_device(evg_ctx* ctx, const evg_plan_input* in, const int32_t* item_off, const int32_t* item_row,
+                              const evg_dispatch_order* out, void* hip_stream);
+
 /* ---- the host-allocator job's report math ------------------------------------------------------
  * units/host_allocator.go:250-334 (time-to-empty of the standalone queue on the hosts expected to be available,
  * with and without the hosts just spawned; its ratio to MaxDurationThreshold) and :393-424 (setTargetAndTerminate:

@@ -1203,3 +1203,98 @@ int evg_oracle_cache_same_id(void* h, int64_t key_a, int64_t key_b) {
 }
 
 }  // extern "C"
+
+// ---- basicCachedDAGDispatcherImpl.rebuild  model/task_queue_service_dependency.go:153-250 -------------------
+// The order comes from gonum.org/v1/gonum v0.17.0 (go.mod:62), which is NOT under /root/reference: graph/topo's
+// SortStabilized + tarjanSCCstabilized are restated here from the published algorithm and pinned against the reference's
+// own TestConstructor vector (model/task_queue_service_test.go:529-657, tests/golden/dispatcher_vectors.json).
+namespace {
+struct Tarjan {  // gonum graph/topo/tarjan.go: type tarjan
+  const std::vector<std::vector<int>>& succ;  // successors of every node, already ordered
+  std::vector<int> indexTable, lowLink;
+  std::vector<char> onStack;
+  std::vector<int> stack;
+  int index = 0;
+  std::vector<std::vector<int>> sccs;
+  explicit Tarjan(const std::vector<std::vector<int>>& s) : succ(s), indexTable(s.size(), 0), lowLink(s.size(), 0), onStack(s.size(), 0) {}
+  void strongconnect(int v) {
+    index++;  // "Set the depth index for v to the smallest unused index."
+    indexTable[v] = index;
+    lowLink[v] = index;
+    stack.push_back(v);
+    onStack[v] = 1;
+    for (int w : succ[v]) {
+      if (indexTable[w] == 0) {  // successor not yet visited: recurse
+        strongconnect(w);
+        lowLink[v] = std::min(lowLink[v], lowLink[w]);
+      } else if (onStack[w]) {   // successor is in the current SCC
+        lowLink[v] = std::min(lowLink[v], indexTable[w]);
+      }
+    }
+    if (lowLink[v] == indexTable[v]) {  // v is a root node: pop the stack and generate an SCC
+      std::vector<int> scc;
+      for (;;) {
+        const int w = stack.back();
+        stack.pop_back();
+        onStack[w] = 0;
+        scc.push_back(w);
+        if (w == v) break;
+      }
+      sccs.push_back(scc);
+    }
+  }
+};
+}  // namespace
+
+extern "C" int evg_oracle_dispatch_order(const evg_plan_input* in, const int32_t* item_off, const int32_t* item_row, const evg_dispatch_order* out) {
+  const evg_task_soa& t = in->tasks;
+  for (int g = 0; g < in->n_task_groups; g++) { out->group_start[g] = 0; out->group_count[g] = 0; }
+  for (int d = 0; d < in->n_distros; d++) {
+    const int i0 = item_off[d], n = item_off[d + 1] - i0;
+    // addItem for every item; items[i].queueIndex = i   :161-164. Node IDs are handed out in queue order, so node == queueIndex.
+    std::unordered_map<int, int> itemNodeMap;  // task row (stands for TaskQueueItem.Id) -> node
+    for (int q = 0; q < n; q++) itemNodeMap[item_row[i0 + q]] = q;
+    // d.taskGroups: items of one composite group id in queue order, then sort.SliceStable by GroupIndex   :166-195
+    std::map<int, std::vector<int>> taskGroups;
+    for (int q = 0; q < n; q++) {
+      const int g = t.tg_key[item_row[i0 + q]];
+      if (g >= 0) taskGroups[g].push_back(q);
+    }
+    int gpos = i0;
+    for (auto& kv : taskGroups) {
+      std::stable_sort(kv.second.begin(), kv.second.end(),
+                       [&](int a, int b) { return t.task_group_order[item_row[i0 + a]] < t.task_group_order[item_row[i0 + b]]; });
+      out->group_start[kv.first] = gpos;
+      out->group_count[kv.first] = (int)kv.second.size();
+      for (int q : kv.second) out->group_items[gpos++] = q;
+    }
+    // addEdge(dependency, item.Id) for every dependency that has a node   :197-204, :119-150. g.From(id) is a set of nodes.
+    std::vector<std::vector<int>> from(n);
+    for (int q = 0; q < n; q++) {
+      const int r = item_row[i0 + q];
+      for (int e = t.dep_off[r]; e < t.dep_off[r + 1]; e++) {
+        auto it = itemNodeMap.find(t.dep_idx[e]);
+        if (it == itemNodeMap.end()) continue;  // "The depend_on <from> task is not in the DAG so we don't need an edge."
+        std::vector<int>& f = from[it->second];
+        if (std::find(f.begin(), f.end(), q) == f.end()) f.push_back(q);
+      }
+    }
+    // tarjanSCCstabilized: order(nodes); Reverse(nodes); succ = order(From(id)); Reverse   (order = by queueIndex, :207-216)
+    for (auto& f : from) { std::sort(f.begin(), f.end()); std::reverse(f.begin(), f.end()); }
+    Tarjan tj(from);
+    for (int v = n - 1; v >= 0; v--)
+      if (tj.indexTable[v] == 0) tj.strongconnect(v);
+    // SortStabilized: a component of one node is that node, anything else a nil entry and an Unorderable; Reverse(sorted)
+    std::vector<int> sorted;
+    int cycles = 0;
+    for (const auto& s : tj.sccs) {
+      if (s.size() != 1) { cycles++; sorted.push_back(-1); continue; }
+      sorted.push_back(s[0]);
+    }
+    std::reverse(sorted.begin(), sorted.end());
+    for (size_t k = 0; k < sorted.size(); k++) out->sorted[i0 + k] = sorted[k];
+    out->n_sorted[d] = (int)sorted.size();
+    out->n_cycles[d] = cycles;
+  }
+  return EVG_OK;
+}

@@ -36,6 +36,7 @@ def lib() -> C.CDLL:
         L.evg_oracle_materialize_queue.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p, C.c_int32,
                                                    C.POINTER(abi.QueueItems)]
         L.evg_oracle_filter_runnable.argtypes = [C.POINTER(abi.PlanInput)] + [C.c_void_p] * 5
+        L.evg_oracle_dispatch_order.argtypes = [C.POINTER(abi.PlanInput), C.c_void_p, C.c_void_p, C.POINTER(abi.DispatchOrder)]
         L.evg_oracle_allocator_report.argtypes = [C.c_int32] + [C.c_void_p] * 7
         L.evg_oracle_calc_new_hosts_needed.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.evg_oracle_cache_new.restype = C.c_void_p
@@ -95,6 +96,15 @@ class OracleBackend:
         rc = lib().evg_oracle_filter_runnable(C.byref(inp), disp.ctypes.data, met.ctypes.data, keep.ctypes.data, rows.ctypes.data, cnt.ctypes.data)
         assert rc == 0
         return met[:n], keep[:n], rows[:n], cnt
+
+    def dispatch_order(self, batch: abi.PlanBatch, item_off: np.ndarray, item_row: np.ndarray) -> abi.DispatchOrderResult:
+        res = abi.DispatchOrderResult.alloc_host(batch)
+        inp, o = abi.make_plan_input(batch), res.c_struct()
+        off = np.ascontiguousarray(item_off, np.int32)
+        row = np.ascontiguousarray(item_row, np.int32) if len(item_row) else np.zeros(1, np.int32)
+        rc = lib().evg_oracle_dispatch_order(C.byref(inp), off.ctypes.data, row.ctypes.data, C.byref(o))
+        assert rc == 0
+        return res
 
     def allocator_report(self, n_distros, tg_off, distro_info, group_info, hosts_spawned, free_hosts, params) -> np.ndarray:
         rep = np.zeros(n_distros, abi.ALLOC_REPORT_DTYPE)
