@@ -346,6 +346,26 @@ struct Stager {
   }
 };
 
+// Uploads the planner's batch (stage slots 0..18); returns the device-side view.
+static evg_plan_input stage_plan_input(Stager& s, const evg_plan_input* in) {
+  const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, D = in->n_distros;
+  evg_plan_input di = *in;
+  if (di.max_distro_tasks <= 0)  // the offsets are host memory here: fill the launch hint in
+    for (size_t d = 0; d < D; d++) di.max_distro_tasks = std::max(di.max_distro_tasks, in->task_off[d + 1] - in->task_off[d]);
+  const evg_task_soa& t = in->tasks;
+  evg_task_soa& dt = di.tasks;
+  dt.priority = s.up(t.priority, N); dt.expected_duration_ns = s.up(t.expected_duration_ns, N);
+  dt.queue_ts_ns = s.up(t.queue_ts_ns, N); dt.scheduled_ts_ns = s.up(t.scheduled_ts_ns, N);
+  dt.deps_met_ts_ns = s.up(t.deps_met_ts_ns, N); dt.num_dependents = s.up(t.num_dependents, N);
+  dt.task_group_order = s.up(t.task_group_order, N); dt.task_group_max_hosts = s.up(t.task_group_max_hosts, N);
+  dt.tg_key = s.up(t.tg_key, N); dt.version_key = s.up(t.version_key, N); dt.flags = s.up(t.flags, N);
+  dt.dep_off = s.up(t.dep_off, N + 1); dt.dep_idx = s.up(t.dep_idx, E); dt.dep_info = s.up(t.dep_info, E);
+  dt.dep_finished_ts_ns = s.up(t.dep_finished_ts_ns, E);
+  di.distros = s.up(in->distros, D); di.task_off = s.up(in->task_off, D + 1); di.tg_off = s.up(in->tg_off, D + 1);
+  di.ver_off = s.up(in->ver_off, D + 1);
+  return di;
+}
+
 extern "C" {
 
 int32_t evg_abi_version(void) { return (1 << 16) | 0; }
@@ -640,10 +660,9 @@ int evg_cap_queue_device(evg_ctx* c, int32_t n_distros, const int32_t* task_off,
   return EVG_OK;
 }
 
-int evg_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* plan, const int32_t* tg_name_key,
+static int do_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* plan, const int32_t* tg_name_key,
                                  int32_t max_scheduled, const evg_queue_items* items, void* hip_stream) {
   if (!c || !in || !plan || !items) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
   const int D = in->n_distros;
   if (D < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
   if (D == 0) return EVG_OK;
@@ -662,10 +681,9 @@ int evg_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, const evg
   return EVG_OK;
 }
 
-int evg_filter_runnable_device(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
+static int do_filter_runnable_device(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
                                int32_t* runnable_row, int32_t* runnable_count, void* hip_stream) {
   if (!c || !in) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
   if (in->n_distros < 0 || in->tasks.n_tasks < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
   if (in->n_distros == 0) return EVG_OK;
   if (!runnable_count || (in->tasks.n_tasks > 0 && (!dispatchable || !deps_met || !keep || !runnable_row)))
@@ -677,10 +695,9 @@ int evg_filter_runnable_device(evg_ctx* c, const evg_plan_input* in, const uint8
   return EVG_OK;
 }
 
-int evg_dispatch_order_device(evg_ctx* c, const evg_plan_input* in, const int32_t* item_off, const int32_t* item_row,
+static int do_dispatch_order_device(evg_ctx* c, const evg_plan_input* in, const int32_t* item_off, const int32_t* item_row,
                               const evg_dispatch_order* out, void* hip_stream) {
   if (!c || !in || !out) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
   if (in->n_distros < 0 || in->tasks.n_tasks < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
   if (in->n_distros == 0) return EVG_OK;
   const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, G = in->n_task_groups;
@@ -707,12 +724,11 @@ int evg_dispatch_order_device(evg_ctx* c, const evg_plan_input* in, const int32_
   return EVG_OK;
 }
 
-int evg_allocator_report_device(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
+static int do_allocator_report_device(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
                                 const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
                                 const evg_report_params* params, evg_alloc_report* report, void* hip_stream) {
   if (!c || n_distros < 0) return EVG_E_INVALID;
   if (n_distros == 0) return EVG_OK;
-  std::lock_guard<std::mutex> lk(c->mu);
   if (!tg_off || !distro_info || !group_info || !hosts_spawned || !free_hosts || !params || !report)
     return set_err(c, EVG_E_INVALID, "null allocator-report argument");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -722,32 +738,53 @@ int evg_allocator_report_device(evg_ctx* c, int32_t n_distros, const int32_t* tg
   return EVG_OK;
 }
 
+// ---- the device-pointer entry points of the SURVEY 8f rows: lock, then the bodies above ----------------------
+
+int evg_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* plan, const int32_t* tg_name_key,
+                                 int32_t max_scheduled, const evg_queue_items* items, void* hip_stream) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return do_materialize_queue_device(c, in, plan, tg_name_key, max_scheduled, items, hip_stream);
+}
+
+int evg_filter_runnable_device(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
+                               int32_t* runnable_row, int32_t* runnable_count, void* hip_stream) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return do_filter_runnable_device(c, in, dispatchable, deps_met, keep, runnable_row, runnable_count, hip_stream);
+}
+
+int evg_dispatch_order_device(evg_ctx* c, const evg_plan_input* in, const int32_t* item_off, const int32_t* item_row,
+                              const evg_dispatch_order* out, void* hip_stream) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return do_dispatch_order_device(c, in, item_off, item_row, out, hip_stream);
+}
+
+int evg_allocator_report_device(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
+                                const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
+                                const evg_report_params* params, evg_alloc_report* report, void* hip_stream) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return do_allocator_report_device(c, n_distros, tg_off, distro_info, group_info, hosts_spawned, free_hosts, params, report, hip_stream);
+}
+
 // ---- host-pointer entry points: stage in, run, stage out, synchronously ---------------------------------
 
-int evg_plan_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out) {
-  if (!c || !in || !out) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
+// evg_plan_distros and evg_schedule_distros: upload once, plan, optionally build the persisted queues and the dispatcher
+// order from the plan that is still on the device, download.
+static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const int32_t* tg_name_key,
+                         int32_t max_scheduled, const evg_queue_items* items, const evg_dispatch_order* disp) {
   HIP_TRY(c, hipSetDevice(c->device));
   char msg[256];
   int rc = evg_validate_plan_input(in, msg, sizeof msg);
   if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
-  const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, D = in->n_distros, G = D + in->n_task_groups;
+  const size_t N = in->tasks.n_tasks, D = in->n_distros, G = D + in->n_task_groups, TG = in->n_task_groups;
   if (D == 0) return EVG_OK;
+  if (disp && !items) return set_err(c, EVG_E_INVALID, "the dispatcher order is built from the persisted queues: items is required");
+  if (items && items->breakdown && !out->breakdown) return set_err(c, EVG_E_INVALID, "item breakdowns need the plan's breakdown output");
   Stager s{c};
-  evg_plan_input di = *in;
-  if (di.max_distro_tasks <= 0)  // the offsets are host memory here: fill the launch hint in
-    for (size_t d = 0; d < D; d++) di.max_distro_tasks = std::max(di.max_distro_tasks, in->task_off[d + 1] - in->task_off[d]);
-  const evg_task_soa& t = in->tasks;
-  evg_task_soa& dt = di.tasks;
-  dt.priority = s.up(t.priority, N); dt.expected_duration_ns = s.up(t.expected_duration_ns, N);
-  dt.queue_ts_ns = s.up(t.queue_ts_ns, N); dt.scheduled_ts_ns = s.up(t.scheduled_ts_ns, N);
-  dt.deps_met_ts_ns = s.up(t.deps_met_ts_ns, N); dt.num_dependents = s.up(t.num_dependents, N);
-  dt.task_group_order = s.up(t.task_group_order, N); dt.task_group_max_hosts = s.up(t.task_group_max_hosts, N);
-  dt.tg_key = s.up(t.tg_key, N); dt.version_key = s.up(t.version_key, N); dt.flags = s.up(t.flags, N);
-  dt.dep_off = s.up(t.dep_off, N + 1); dt.dep_idx = s.up(t.dep_idx, E); dt.dep_info = s.up(t.dep_info, E);
-  dt.dep_finished_ts_ns = s.up(t.dep_finished_ts_ns, E);
-  di.distros = s.up(in->distros, D); di.task_off = s.up(in->task_off, D + 1); di.tg_off = s.up(in->tg_off, D + 1);
-  di.ver_off = s.up(in->ver_off, D + 1);
+  evg_plan_input di = stage_plan_input(s, in);
   evg_plan_output dout;
   dout.order = s.out<int32_t>(N, true);
   dout.breakdown = s.out<int64_t>(N * EVG_BREAKDOWN_FIELDS, out->breakdown != nullptr);
@@ -756,19 +793,45 @@ int evg_plan_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output
   dout.distro_info = s.out<evg_distro_info>(D, true);
   dout.group_info = s.out<evg_group_info>(G, true);
   dout.n_units = s.out<int32_t>(D, out->n_units != nullptr);
+  const int32_t* d_name = items ? s.up(tg_name_key, N) : (s.slot++, nullptr);
+  evg_queue_items qi{};
+  if (items) {
+    qi.cut = s.out<int32_t>(D, true); qi.item_off = s.out<int32_t>(D + 1, true); qi.row = s.out<int32_t>(N, true);
+    qi.expected_duration_ns = s.out<int64_t>(N, true); qi.priority = s.out<int64_t>(N, true);
+    qi.group_max_hosts = s.out<int32_t>(N, true); qi.group_index = s.out<int32_t>(N, true);
+    qi.n_dependencies = s.out<int32_t>(N, true); qi.dependencies_met = s.out<uint8_t>(N, true);
+    qi.breakdown = s.out<int64_t>(N * EVG_BREAKDOWN_FIELDS, items->breakdown != nullptr);
+  } else {
+    s.slot += 10;
+  }
+  evg_dispatch_order od{};
+  if (disp) {
+    od.sorted = s.out<int32_t>(N, true); od.n_sorted = s.out<int32_t>(D, true); od.n_cycles = s.out<int32_t>(D, true);
+    od.group_items = s.out<int32_t>(N, true); od.group_start = s.out<int32_t>(TG, true); od.group_count = s.out<int32_t>(TG, true);
+  }
   if (s.rc) return s.rc;
-  // a zero-task batch still needs valid (non-null) required outputs for the launch check
-  static int32_t dummy;
-  if (N == 0) {
-    // nothing to order; give the kernel harmless pointers
+  if (N == 0) {  // nothing to order or persist; the kernels still want non-null required pointers
     DevBuf& b = c->stage[47];
     rc = ensure(c, b, 64);
     if (rc) return rc;
     dout.order = (int32_t*)b.p; dout.deps_met = (uint8_t*)b.p; dout.wait_ns = (int64_t*)b.p;
-    (void)dummy;
+    if (items) {
+      d_name = (const int32_t*)b.p;
+      qi.row = (int32_t*)b.p; qi.expected_duration_ns = (int64_t*)b.p; qi.priority = (int64_t*)b.p; qi.group_max_hosts = (int32_t*)b.p;
+      qi.group_index = (int32_t*)b.p; qi.n_dependencies = (int32_t*)b.p; qi.dependencies_met = (uint8_t*)b.p;
+    }
   }
   rc = launch_plan(c, &di, &dout, c->stream);
   if (rc) return rc;
+  if (items) {
+    if (N > 0 && !tg_name_key) return set_err(c, EVG_E_INVALID, "tg_name_key is required");
+    rc = do_materialize_queue_device(c, &di, &dout, d_name, max_scheduled, &qi, c->stream);
+    if (rc) return rc;
+  }
+  if (disp) {
+    rc = do_dispatch_order_device(c, &di, qi.item_off, qi.row, &od, c->stream);
+    if (rc) return rc;
+  }
   s.down(out->order, dout.order, N);
   s.down(out->breakdown, dout.breakdown, N * EVG_BREAKDOWN_FIELDS);
   s.down(out->deps_met, dout.deps_met, N);
@@ -776,6 +839,97 @@ int evg_plan_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output
   s.down(out->distro_info, dout.distro_info, D);
   s.down(out->group_info, dout.group_info, G);
   s.down(out->n_units, dout.n_units, D);
+  if (items) {
+    s.down(items->cut, qi.cut, D); s.down(items->item_off, qi.item_off, D + 1); s.down(items->row, qi.row, N);
+    s.down(items->expected_duration_ns, qi.expected_duration_ns, N); s.down(items->priority, qi.priority, N);
+    s.down(items->group_max_hosts, qi.group_max_hosts, N); s.down(items->group_index, qi.group_index, N);
+    s.down(items->n_dependencies, qi.n_dependencies, N); s.down(items->dependencies_met, qi.dependencies_met, N);
+    s.down(items->breakdown, qi.breakdown, N * EVG_BREAKDOWN_FIELDS);
+  }
+  if (disp) {
+    s.down(disp->sorted, od.sorted, N); s.down(disp->n_sorted, od.n_sorted, D); s.down(disp->n_cycles, od.n_cycles, D);
+    s.down(disp->group_items, od.group_items, N); s.down(disp->group_start, od.group_start, TG);
+    s.down(disp->group_count, od.group_count, TG);
+  }
+  if (s.rc) return s.rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EVG_OK;
+}
+
+int evg_plan_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out) {
+  if (!c || !in || !out) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return schedule_host(c, in, out, nullptr, 0, nullptr, nullptr);
+}
+
+int evg_schedule_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const int32_t* tg_name_key,
+                         int32_t max_scheduled, const evg_queue_items* items, const evg_dispatch_order* dispatch) {
+  if (!c || !in || !out) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (items && (!items->cut || !items->item_off || (in->tasks.n_tasks > 0 && (!items->row || !items->expected_duration_ns ||
+      !items->priority || !items->group_max_hosts || !items->group_index || !items->n_dependencies || !items->dependencies_met))))
+    return set_err(c, EVG_E_INVALID, "null queue-item output");
+  if (dispatch && (!dispatch->n_sorted || !dispatch->n_cycles || (in->n_task_groups > 0 && (!dispatch->group_start || !dispatch->group_count)) ||
+                   (in->tasks.n_tasks > 0 && (!dispatch->sorted || !dispatch->group_items))))
+    return set_err(c, EVG_E_INVALID, "null dispatch-order output");
+  return schedule_host(c, in, out, tg_name_key, max_scheduled, items, dispatch);
+}
+
+int evg_filter_runnable(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
+                        int32_t* runnable_row, int32_t* runnable_count) {
+  if (!c || !in) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  char msg[256];
+  int rc = evg_validate_plan_input(in, msg, sizeof msg);
+  if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
+  const size_t N = in->tasks.n_tasks, D = in->n_distros;
+  if (D == 0) return EVG_OK;
+  if (!runnable_count || (N > 0 && (!dispatchable || !deps_met || !keep || !runnable_row))) return set_err(c, EVG_E_INVALID, "null finder-filter argument");
+  Stager s{c};
+  evg_plan_input di = stage_plan_input(s, in);
+  const uint8_t* d_disp = s.up(dispatchable, N);
+  uint8_t* d_met = s.out<uint8_t>(N, true);
+  uint8_t* d_keep = s.out<uint8_t>(N, true);
+  int32_t* d_row = s.out<int32_t>(N, true);
+  int32_t* d_cnt = s.out<int32_t>(D, true);
+  if (s.rc) return s.rc;
+  if (N == 0) {
+    DevBuf& b = c->stage[47];
+    rc = ensure(c, b, 64);
+    if (rc) return rc;
+    d_disp = (const uint8_t*)b.p; d_met = (uint8_t*)b.p; d_keep = (uint8_t*)b.p; d_row = (int32_t*)b.p;
+  }
+  rc = do_filter_runnable_device(c, &di, d_disp, d_met, d_keep, d_row, d_cnt, c->stream);
+  if (rc) return rc;
+  s.down(deps_met, d_met, N); s.down(keep, d_keep, N); s.down(runnable_row, d_row, N); s.down(runnable_count, d_cnt, D);
+  if (s.rc) return s.rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EVG_OK;
+}
+
+int evg_allocator_report(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
+                         const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
+                         const evg_report_params* params, evg_alloc_report* report) {
+  if (!c || n_distros < 0) return EVG_E_INVALID;
+  if (n_distros == 0) return EVG_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!tg_off || !distro_info || !group_info || !hosts_spawned || !free_hosts || !params || !report)
+    return set_err(c, EVG_E_INVALID, "null allocator-report argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t D = n_distros, G = D + (size_t)tg_off[D];
+  Stager s{c};
+  const int32_t* d_off = s.up(tg_off, D + 1);
+  const evg_distro_info* d_di = s.up(distro_info, D);
+  const evg_group_info* d_gi = s.up(group_info, G);
+  const int32_t* d_sp = s.up(hosts_spawned, D);
+  const int32_t* d_fr = s.up(free_hosts, D);
+  const evg_report_params* d_pa = s.up(params, D);
+  evg_alloc_report* d_rep = s.out<evg_alloc_report>(D, true);
+  if (s.rc) return s.rc;
+  int rc = do_allocator_report_device(c, n_distros, d_off, d_di, d_gi, d_sp, d_fr, d_pa, d_rep, c->stream);
+  if (rc) return rc;
+  s.down(report, d_rep, D);
   if (s.rc) return s.rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return EVG_OK;

@@ -21,6 +21,7 @@ EXPORTS = [
     "evg_plan_distros", "evg_plan_distros_device", "evg_allocate_hosts", "evg_allocate_hosts_device",
     "evg_cap_queue_device", "evg_plan_allocate_device", "evg_materialize_queue_device",
     "evg_allocator_report_device", "evg_filter_runnable_device", "evg_dispatch_order_device",
+    "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report",
 ]
 
 _lib = None
@@ -67,6 +68,10 @@ def load_library() -> C.CDLL:
     lib.evg_filter_runnable_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput)] + [C.c_void_p] * 6
     lib.evg_dispatch_order_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.c_void_p, C.c_void_p, C.POINTER(abi.DispatchOrder),
                                               C.c_void_p]
+    lib.evg_schedule_distros.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p, C.c_int32,
+                                         C.POINTER(abi.QueueItems), C.POINTER(abi.DispatchOrder)]
+    lib.evg_filter_runnable.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput)] + [C.c_void_p] * 5
+    lib.evg_allocator_report.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
     lib.evg_cap_queue_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p]
     _lib = lib
@@ -114,6 +119,35 @@ class Context:
         out = res.c_output()
         self._check(self.lib.evg_allocate_hosts(self.h, C.byref(inp), C.byref(out)), "evg_allocate_hosts")
         return res
+
+    def schedule(self, batch: abi.PlanBatch, max_scheduled: int = 0, breakdown: bool = True, n_units: bool = True, dispatch: bool = True):
+        """evg_schedule_distros: plan + the persisted queues (+ the dispatcher's order) in one host-pointer call.
+        Returns (PlanResult, QueueItemsResult, DispatchOrderResult or None)."""
+        res = abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=n_units)
+        items = abi.QueueItemsResult.alloc_host(batch, breakdown=breakdown)
+        order = abi.DispatchOrderResult.alloc_host(batch) if dispatch else None
+        inp, out, q = abi.make_plan_input(batch), res.c_output(), items.c_struct()
+        o = order.c_struct() if dispatch else None
+        self._check(self.lib.evg_schedule_distros(self.h, C.byref(inp), C.byref(out), abi._ptr(batch.tg_name_key), max_scheduled,
+                                                  C.byref(q), C.byref(o) if dispatch else None), "evg_schedule_distros")
+        return res, items.trimmed(), order
+
+    def filter_runnable(self, batch: abi.PlanBatch, dispatchable: np.ndarray):
+        n, D = batch.n_tasks, batch.n_distros
+        met, keep = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+        rows, cnt = np.full(max(n, 1), -1, np.int32), np.zeros(max(D, 1), np.int32)
+        disp = np.ascontiguousarray(dispatchable, np.uint8) if n else np.zeros(1, np.uint8)
+        inp = abi.make_plan_input(batch)
+        self._check(self.lib.evg_filter_runnable(self.h, C.byref(inp), disp.ctypes.data, met.ctypes.data, keep.ctypes.data, rows.ctypes.data,
+                                                 cnt.ctypes.data), "evg_filter_runnable")
+        return met[:n], keep[:n], rows[:n], cnt[:D]
+
+    def allocator_report(self, n_distros, tg_off, distro_info, group_info, hosts_spawned, free_hosts, params) -> np.ndarray:
+        rep = np.zeros(n_distros, abi.ALLOC_REPORT_DTYPE)
+        self._check(self.lib.evg_allocator_report(self.h, n_distros, tg_off.ctypes.data, distro_info.ctypes.data, group_info.ctypes.data,
+                                                  hosts_spawned.ctypes.data, free_hosts.ctypes.data, params.ctypes.data, rep.ctypes.data),
+                    "evg_allocator_report")
+        return rep
 
     # ---- device-resident entry points ----------------------------------------------------------
     def plan_device(self, inp: abi.PlanInput, out: abi.PlanOutput, stream: Optional[int] = None) -> None:

@@ -402,6 +402,18 @@ typedef struct evg_dispatch_order {
 int evg_dispatch_order_device(evg_ctx* ctx, const evg_plan_input* in, const int32_t* item_off, const int32_t* item_row,
                               const evg_dispatch_order* out, void* hip_stream);
 
+/* ---- the scheduler job end to end, host pointers ---------------------------------------------------------------
+ * What a cgo shim calls once per tick for all D distros: evg_plan_distros, then -- from the plan that is still on the
+ * device, so nothing is uploaded twice -- PersistTaskQueue's item lists (items != NULL; evg_materialize_queue_device)
+ * and the DAG dispatcher's order for those queues (dispatch != NULL, requires items; evg_dispatch_order_device).
+ * Every pointer is host memory; synchronous. Results are identical to the separate calls. */
+int evg_schedule_distros(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out, const int32_t* tg_name_key,
+                         int32_t max_scheduled, const evg_queue_items* items, const evg_dispatch_order* dispatch);
+
+/* Host-pointer forms of evg_filter_runnable_device and evg_allocator_report_device (stage in, run, stage out). */
+int evg_filter_runnable(evg_ctx* ctx, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
+                        int32_t* runnable_row, int32_t* runnable_count);
+
 /* ---- the host-allocator job's report math ------------------------------------------------------
  * units/host_allocator.go:250-334 (time-to-empty of the standalone queue on the hosts expected to be available,
  * with and without the hosts just spawned; its ratio to MaxDurationThreshold) and :393-424 (setTargetAndTerminate:
@@ -431,6 +443,9 @@ typedef struct evg_alloc_report {
 int evg_allocator_report_device(evg_ctx* ctx, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
                                 const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
                                 const evg_report_params* params, evg_alloc_report* report, void* hip_stream);
+int evg_allocator_report(evg_ctx* ctx, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
+                         const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
+                         const evg_report_params* params, evg_alloc_report* report);
 
 #ifdef __cplusplus
 }

@@ -103,3 +103,13 @@ def test_hip_report_matches_oracle(native_ctx, oracle):
     got = out.cpu().numpy().view(abi.ALLOC_REPORT_DTYPE)
     for name in abi.ALLOC_REPORT_DTYPE.names:
         assert np.array_equal(got[name], want[name], equal_nan=got[name].dtype.kind == "f"), name
+
+
+@pytest.mark.gpu
+def test_hip_report_host_pointer_form(native_ctx, oracle):
+    """evg_allocator_report: the same closed forms from host memory (what a cgo shim calls)."""
+    tg_off, di_rows, gi, spawned, free, params = _random_rows(11, D=300)
+    want = oracle.allocator_report(len(di_rows), tg_off, di_rows, gi, spawned, free, params)
+    got = native_ctx.allocator_report(len(di_rows), tg_off, di_rows, gi, spawned, free, params)
+    for name in abi.ALLOC_REPORT_DTYPE.names:
+        assert np.array_equal(got[name], want[name], equal_nan=got[name].dtype.kind == "f"), name

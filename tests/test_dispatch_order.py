@@ -184,3 +184,21 @@ def test_hip_matches_oracle_after_planning(native_ctx, oracle, make, limit):
     assert int(want.n_cycles.sum()) == 0
     for d in range(b.n_distros):   # a permutation of the queue, dependencies first
         assert np.array_equal(np.sort(got.distro_sorted(items.item_off, d)), np.arange(items.item_off[d + 1] - items.item_off[d]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limit", [0, 40])
+def test_hip_schedule_distros_host_pointers(native_ctx, oracle, limit):
+    """evg_schedule_distros (what a cgo shim calls): plan + persisted queues + dispatcher order from host memory in one call."""
+    for b in (gen.generate(gen.config(1)), gen.generate(gen.GenConfig(3, 5, 9)), gen.generate(gen.GenConfig(0, 3, 1))):
+        res, items, order = native_ctx.schedule(b, limit)
+        want = oracle.plan(b)
+        assert np.array_equal(res.order, want.order) and np.array_equal(res.breakdown, want.breakdown)
+        assert np.array_equal(res.distro_info, want.distro_info) and np.array_equal(res.n_units, want.n_units)
+        witems = oracle.materialize_queue(b, want, limit)
+        assert np.array_equal(items.item_off, witems.item_off) and np.array_equal(items.cut, witems.cut)
+        for k in abi.QUEUE_ITEM_COLUMNS:
+            assert np.array_equal(items.cols[k], witems.cols[k]), k
+        assert np.array_equal(items.breakdown, witems.breakdown)
+        worder = oracle.dispatch_order(b, witems.item_off, witems.cols["row"])
+        _assert_same(order, worder, witems.item_off, b.n_distros, int(b.tg_off[-1]))

@@ -98,3 +98,16 @@ def test_hip_filter_matches_oracle(native_ctx, oracle, make):
     for d in range(b.n_distros):
         lo = int(b.task_off[d])
         assert np.array_equal(got_rows[lo:lo + int(want_cnt[d])], want_rows[lo:lo + int(want_cnt[d])]), d
+
+
+@pytest.mark.gpu
+def test_hip_filter_host_pointer_form(native_ctx, oracle):
+    """evg_filter_runnable: the same filter from host memory (what a cgo shim calls)."""
+    for b in (gen.generate(gen.config(1)), gen.generate(gen.GenConfig(2, 4, 1)), gen.generate(gen.GenConfig(0, 3, 1))):
+        disp = _random_dispatchable(b, 4)
+        want_met, want_keep, want_rows, want_cnt = oracle.filter_runnable(b, disp)
+        met, keep, rows, cnt = native_ctx.filter_runnable(b, disp)
+        assert np.array_equal(cnt, want_cnt) and np.array_equal(met, want_met) and np.array_equal(keep, want_keep)
+        for d in range(b.n_distros):
+            lo = int(b.task_off[d])
+            assert np.array_equal(rows[lo:lo + int(want_cnt[d])], want_rows[lo:lo + int(want_cnt[d])]), d
