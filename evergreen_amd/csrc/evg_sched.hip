@@ -875,6 +875,52 @@ int evg_schedule_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
   return schedule_host(c, in, out, tg_name_key, max_scheduled, items, dispatch);
 }
 
+int evg_rebuild_dispatchers(evg_ctx* c, int32_t n_distros, const int32_t* item_off, const int32_t* dep_off, const int32_t* dep_idx,
+                       const int32_t* group_key, const int32_t* tg_off, const int32_t* group_index, const evg_dispatch_order* out) {
+  if (!c || !out || n_distros < 0) return EVG_E_INVALID;
+  if (n_distros == 0) return EVG_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!item_off || !tg_off) return set_err(c, EVG_E_INVALID, "null dispatch-order argument");
+  const size_t D = n_distros, N = (size_t)item_off[D], TG = (size_t)tg_off[D];
+  if (item_off[0] != 0 || tg_off[0] != 0) return set_err(c, EVG_E_CONTRACT, "item_off / tg_off must start at 0");
+  for (size_t d = 0; d < D; d++)
+    if (item_off[d + 1] < item_off[d] || tg_off[d + 1] < tg_off[d]) return set_err(c, EVG_E_CONTRACT, "offsets of distro %zu decrease", d);
+  if (N > 0 && (!dep_off || !group_key || !group_index || !out->sorted || !out->group_items)) return set_err(c, EVG_E_INVALID, "null dispatch-order argument");
+  if (!out->n_sorted || !out->n_cycles || (TG > 0 && (!out->group_start || !out->group_count))) return set_err(c, EVG_E_INVALID, "null dispatch-order output");
+  const size_t E = N ? (size_t)dep_off[N] : 0;
+  if (N > 0 && dep_off[0] != 0) return set_err(c, EVG_E_CONTRACT, "dep_off must start at 0");
+  if (E > 0 && !dep_idx) return set_err(c, EVG_E_INVALID, "null dep_idx");
+  for (size_t d = 0; d < D; d++)  // the kernel indexes per-group words with the key: it must lie in the distro's own range
+    for (int32_t i = item_off[d]; i < item_off[d + 1]; i++) {
+      if (dep_off[i + 1] < dep_off[i]) return set_err(c, EVG_E_CONTRACT, "dep_off decreases at item %d", i);
+      if (group_key[i] >= 0 && (group_key[i] < tg_off[d] || group_key[i] >= tg_off[d + 1]))
+        return set_err(c, EVG_E_CONTRACT, "group_key of item %d is outside its distro's range", i);
+    }
+  HIP_TRY(c, hipSetDevice(c->device));
+  Stager s{c};
+  evg_plan_input di{};
+  di.n_distros = n_distros; di.n_task_groups = (int32_t)TG;
+  di.tasks.n_tasks = (int32_t)N; di.tasks.n_edges = (int32_t)E;
+  di.task_off = s.up(item_off, D + 1); di.tg_off = s.up(tg_off, D + 1);
+  di.tasks.dep_off = s.up(dep_off, N + 1); di.tasks.dep_idx = s.up(dep_idx, E);
+  di.tasks.tg_key = s.up(group_key, N); di.tasks.task_group_order = s.up(group_index, N);
+  std::vector<int32_t> iota(N);
+  for (size_t i = 0; i < N; i++) iota[i] = (int32_t)i;  // the items ARE the rows here
+  const int32_t* d_row = s.up(iota.data(), N);
+  evg_dispatch_order od{};
+  od.sorted = s.out<int32_t>(N, true); od.n_sorted = s.out<int32_t>(D, true); od.n_cycles = s.out<int32_t>(D, true);
+  od.group_items = s.out<int32_t>(N, true); od.group_start = s.out<int32_t>(TG, true); od.group_count = s.out<int32_t>(TG, true);
+  if (s.rc) return s.rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // iota is a local: its copy must have left before it goes away
+  int rc = do_dispatch_order_device(c, &di, di.task_off, d_row, &od, c->stream);
+  if (rc) return rc;
+  s.down(out->sorted, od.sorted, N); s.down(out->n_sorted, od.n_sorted, D); s.down(out->n_cycles, od.n_cycles, D);
+  s.down(out->group_items, od.group_items, N); s.down(out->group_start, od.group_start, TG); s.down(out->group_count, od.group_count, TG);
+  if (s.rc) return s.rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EVG_OK;
+}
+
 int evg_filter_runnable(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
                         int32_t* runnable_row, int32_t* runnable_count) {
   if (!c || !in) return EVG_E_INVALID;

@@ -21,7 +21,7 @@ EXPORTS = [
     "evg_plan_distros", "evg_plan_distros_device", "evg_allocate_hosts", "evg_allocate_hosts_device",
     "evg_cap_queue_device", "evg_plan_allocate_device", "evg_materialize_queue_device",
     "evg_allocator_report_device", "evg_filter_runnable_device", "evg_dispatch_order_device",
-    "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report",
+    "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
 ]
 
 _lib = None
@@ -70,6 +70,7 @@ def load_library() -> C.CDLL:
                                               C.c_void_p]
     lib.evg_schedule_distros.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p, C.c_int32,
                                          C.POINTER(abi.QueueItems), C.POINTER(abi.DispatchOrder)]
+    lib.evg_rebuild_dispatchers.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 6 + [C.POINTER(abi.DispatchOrder)]
     lib.evg_filter_runnable.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput)] + [C.c_void_p] * 5
     lib.evg_allocator_report.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
     lib.evg_cap_queue_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
@@ -131,6 +132,15 @@ class Context:
         self._check(self.lib.evg_schedule_distros(self.h, C.byref(inp), C.byref(out), abi._ptr(batch.tg_name_key), max_scheduled,
                                                   C.byref(q), C.byref(o) if dispatch else None), "evg_schedule_distros")
         return res, items.trimmed(), order
+
+    def dispatch_order(self, batch: abi.PlanBatch) -> abi.DispatchOrderResult:
+        """evg_rebuild_dispatchers with the batch's rows standing for the persisted items (queue order == row order)."""
+        res = abi.DispatchOrderResult.alloc_host(batch)
+        o = res.c_struct()
+        self._check(self.lib.evg_rebuild_dispatchers(self.h, batch.n_distros, abi._ptr(batch.task_off), abi._ptr(batch.dep_off), abi._ptr(batch.edges["dep_idx"]),
+                                                abi._ptr(batch.cols["tg_key"]), abi._ptr(batch.tg_off), abi._ptr(batch.cols["task_group_order"]),
+                                                C.byref(o)), "evg_rebuild_dispatchers")
+        return res
 
     def filter_runnable(self, batch: abi.PlanBatch, dispatchable: np.ndarray):
         n, D = batch.n_tasks, batch.n_distros

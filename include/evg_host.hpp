@@ -174,6 +174,9 @@ struct HostAllocatorData {  // scheduler/host_allocator.go:17-21
 struct Backend {
   std::function<int(const evg_plan_input*, const evg_plan_output*)> plan;
   std::function<int(const evg_alloc_input*, const evg_alloc_output*)> allocate;
+  // evg_rebuild_dispatchers: (D, item_off, dep_off, dep_idx, group_key, tg_off, group_index, out)
+  std::function<int(int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const evg_dispatch_order*)>
+      rebuild;
   std::function<std::string()> last_error;
   std::shared_ptr<void> keep;  // whatever must outlive the calls (library handle, context)
 };
@@ -188,7 +191,9 @@ inline Backend HipBackend(const std::string& lib_path, int device = 0) {
   auto lasterr = reinterpret_cast<const char* (*)(const evg_ctx*)>(dlsym(h, "evg_last_error"));
   auto plan = reinterpret_cast<int (*)(evg_ctx*, const evg_plan_input*, const evg_plan_output*)>(dlsym(h, "evg_plan_distros"));
   auto alloc = reinterpret_cast<int (*)(evg_ctx*, const evg_alloc_input*, const evg_alloc_output*)>(dlsym(h, "evg_allocate_hosts"));
-  if (!create || !destroy || !lasterr || !plan || !alloc) throw std::runtime_error("libevg_sched.so lacks an entry point of evg_sched.h");
+  auto rebuild = reinterpret_cast<int (*)(evg_ctx*, int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
+                                          const evg_dispatch_order*)>(dlsym(h, "evg_rebuild_dispatchers"));
+  if (!create || !destroy || !lasterr || !plan || !alloc || !rebuild) throw std::runtime_error("libevg_sched.so lacks an entry point of evg_sched.h");
   evg_ctx* ctx = create(device);
   if (!ctx) throw std::runtime_error(std::string("evg_create failed: ") + lasterr(nullptr));
   std::shared_ptr<void> keep(ctx, [destroy](void* p) { destroy(static_cast<evg_ctx*>(p)); });
@@ -196,6 +201,8 @@ inline Backend HipBackend(const std::string& lib_path, int device = 0) {
   b.keep = keep;
   b.plan = [ctx, plan](const evg_plan_input* in, const evg_plan_output* out) { return plan(ctx, in, out); };
   b.allocate = [ctx, alloc](const evg_alloc_input* in, const evg_alloc_output* out) { return alloc(ctx, in, out); };
+  b.rebuild = [ctx, rebuild](int32_t D, const int32_t* io, const int32_t* dof, const int32_t* dix, const int32_t* gk, const int32_t* tgo, const int32_t* gi,
+                              const evg_dispatch_order* o) { return rebuild(ctx, D, io, dof, dix, gk, tgo, gi, o); };
   b.last_error = [ctx, lasterr]() { return std::string(lasterr(ctx)); };
   return b;
 }
@@ -436,6 +443,111 @@ inline std::vector<Task> capTaskQueueLength(const std::vector<Task>& tasks, int 
 }
 
 // ---- host allocator -------------------------------------------------------------------------------------------
+// ---- the persisted queue and the DAG dispatcher built from it -------------------------
+struct TaskQueueItem {  // model/task_queue.go:181-205 (the fields the path fills)
+  std::string Id, Group, Version, BuildVariant, Requester, Project, ActivatedBy;
+  int GroupMaxHosts = 0, GroupIndex = 0;
+  Duration ExpectedDuration = 0;
+  int64_t Priority = 0;
+  evergreen::SortingValueBreakdown SortingValueBreakdown;
+  std::vector<std::string> Dependencies;
+  bool DependenciesMet = false;
+};
+
+constexpr size_t kTaskQueueSaveLimit = EVG_TASK_QUEUE_SAVE_LIMIT;  // model/task_queue.go:270-272
+
+// What PersistTaskQueue hands to TaskQueue.Save (task_queue_persister.go:17-52, task_queue.go:269-272) from an already
+// planned task list: cap, build the items, truncate to 10,000. Host-object form of evg_materialize_queue_device.
+inline std::vector<TaskQueueItem> BuildTaskQueue(const std::vector<Task>& plan, int maxScheduledTasks) {
+  std::vector<TaskQueueItem> out;
+  for (const Task& t : capTaskQueueLength(plan, maxScheduledTasks)) {
+    if (out.size() == kTaskQueueSaveLimit) break;
+    TaskQueueItem it;
+    it.Id = t.Id; it.Group = t.TaskGroup; it.GroupMaxHosts = t.TaskGroupMaxHosts; it.GroupIndex = t.TaskGroupOrder; it.Version = t.Version;
+    it.BuildVariant = t.BuildVariant; it.Requester = t.Requester; it.Project = t.Project; it.ExpectedDuration = t.ExpectedDuration;
+    it.Priority = t.Priority; it.SortingValueBreakdown = t.SortingValueBreakdown; it.DependenciesMet = t.HasDependenciesMet();
+    it.ActivatedBy = t.ActivatedBy;
+    for (const auto& d : t.DependsOn) it.Dependencies.push_back(d.TaskId);
+    out.push_back(std::move(it));
+  }
+  return out;
+}
+
+inline std::string compositeGroupID(const std::string& group, const std::string& variant, const std::string& project, const std::string& version) {
+  return group + "_" + variant + "_" + project + "_" + version;  // task_queue_service_dependency.go:695-697
+}
+
+struct schedulableUnit {  // model/task_queue_service.go (the fields rebuild fills)
+  std::string id, group, project, version, variant;
+  int maxHosts = 0;
+  std::vector<TaskQueueItem> tasks;
+};
+
+// What basicCachedDAGDispatcherImpl.rebuild (task_queue_service_dependency.go:153-250) leaves behind: `sorted` are
+// positions in the queue the dispatcher was built from, -1 for the nil entry of a dependency cycle.
+struct DAGDispatcherState {
+  std::vector<int> sorted;
+  std::map<std::string, schedulableUnit> taskGroups;
+  int cycles = 0;  // len(topo.Unorderable)
+};
+
+// rebuild(items) for D persisted queues in one call of the backend (evg_rebuild_dispatchers).
+inline std::vector<DAGDispatcherState> RebuildDispatchers(const Backend& be, const std::vector<const std::vector<TaskQueueItem>*>& queues) {
+  const size_t D = queues.size();
+  std::vector<int32_t> item_off{0}, tg_off{0}, dep_off{0}, dep_idx, group_key, group_index;
+  std::vector<std::vector<std::string>> group_ids(D);
+  for (size_t d = 0; d < D; d++) {
+    const std::vector<TaskQueueItem>& items = *queues[d];
+    const int32_t base = item_off.back();
+    std::unordered_map<std::string, int32_t> node_of, key_of;
+    for (size_t i = 0; i < items.size(); i++) node_of[items[i].Id] = base + (int32_t)i;  // itemNodeMap   :118-123
+    for (const TaskQueueItem& it : items) {
+      int32_t k = -1;
+      if (!it.Group.empty()) {
+        const std::string id = compositeGroupID(it.Group, it.BuildVariant, it.Project, it.Version);
+        auto f = key_of.find(id);
+        if (f == key_of.end()) { f = key_of.emplace(id, tg_off.back() + (int32_t)key_of.size()).first; group_ids[d].push_back(id); }
+        k = f->second;
+      }
+      group_key.push_back(k);
+      group_index.push_back(it.GroupIndex);
+      for (const std::string& dep : it.Dependencies) {
+        auto f = node_of.find(dep);
+        dep_idx.push_back(f == node_of.end() ? -1 : f->second);  // no node for the dependency: no edge   :125-128
+      }
+      dep_off.push_back((int32_t)dep_idx.size());
+    }
+    item_off.push_back(base + (int32_t)items.size());
+    tg_off.push_back(tg_off.back() + (int32_t)key_of.size());
+  }
+  const size_t n = (size_t)item_off.back(), TG = (size_t)tg_off.back();
+  std::vector<int32_t> sorted(n + 1), n_sorted(D + 1), n_cycles(D + 1), gitems(n + 1), gstart(TG + 1), gcount(TG + 1);
+  dep_idx.push_back(-1); group_key.push_back(-1); group_index.push_back(0);  // non-null when empty
+  evg_dispatch_order out{sorted.data(), n_sorted.data(), n_cycles.data(), gitems.data(), gstart.data(), gcount.data()};
+  const int rc = be.rebuild((int32_t)D, item_off.data(), dep_off.data(), dep_idx.data(), group_key.data(), tg_off.data(), group_index.data(), &out);
+  if (rc != EVG_OK) throw std::runtime_error("evg_rebuild_dispatchers failed (" + std::to_string(rc) + "): " + (be.last_error ? be.last_error() : ""));
+  std::vector<DAGDispatcherState> res(D);
+  for (size_t d = 0; d < D; d++) {
+    const std::vector<TaskQueueItem>& items = *queues[d];
+    DAGDispatcherState& st = res[d];
+    st.cycles = n_cycles[d];
+    st.sorted.assign(sorted.begin() + item_off[d], sorted.begin() + item_off[d] + n_sorted[d]);
+    for (int32_t k = tg_off[d]; k < tg_off[d + 1]; k++) {
+      schedulableUnit su;
+      su.id = group_ids[d][(size_t)(k - tg_off[d])];
+      for (int32_t x = 0; x < gcount[k]; x++) su.tasks.push_back(items[(size_t)gitems[gstart[k] + x]]);
+      int32_t first_q = INT32_MAX;  // the unit's fields come from the group's first item in QUEUE order   :172-181
+      for (int32_t x = 0; x < gcount[k]; x++) first_q = std::min(first_q, gitems[gstart[k] + x]);
+      if (first_q != INT32_MAX) {
+        const TaskQueueItem& f = items[(size_t)first_q];
+        su.group = f.Group; su.project = f.Project; su.version = f.Version; su.variant = f.BuildVariant; su.maxHosts = f.GroupMaxHosts;
+      }
+      st.taskGroups.emplace(su.id, std::move(su));
+    }
+  }
+  return res;
+}
+
 struct AllocatorResult {
   int newHostsNeeded = 0, estimatedFreeHosts = 0;
   std::string err;  // empty == nil

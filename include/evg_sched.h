@@ -402,6 +402,15 @@ typedef struct evg_dispatch_order {
 int evg_dispatch_order_device(evg_ctx* ctx, const evg_plan_input* in, const int32_t* item_off, const int32_t* item_row,
                               const evg_dispatch_order* out, void* hip_stream);
 
+/* Host-pointer form for basicCachedDAGDispatcherImpl.rebuild(items) itself -- the dispatcher rebuilds from the persisted
+ * TaskQueue document (Refresh, task_queue_service_dependency.go:74-93), not inside the scheduler job, so it takes the
+ * items alone: items of distro d at [item_off[d], item_off[d+1]) in queue order; item i's Dependencies as the absolute
+ * item indexes dep_idx[dep_off[i] .. dep_off[i+1]) (-1 or an item of another distro = not in this queue: no edge);
+ * group_key[i] = -1 for Group == "" else a dense interning of compositeGroupID(Group, BuildVariant, Project, Version)
+ * (:695-697) in [tg_off[d], tg_off[d+1]); group_index[i] = GroupIndex. Outputs as evg_dispatch_order_device. Synchronous. */
+int evg_rebuild_dispatchers(evg_ctx* ctx, int32_t n_distros, const int32_t* item_off, const int32_t* dep_off, const int32_t* dep_idx,
+                       const int32_t* group_key, const int32_t* tg_off, const int32_t* group_index, const evg_dispatch_order* out);
+
 /* ---- the scheduler job end to end, host pointers ---------------------------------------------------------------
  * What a cgo shim calls once per tick for all D distros: evg_plan_distros, then -- from the plan that is still on the
  * device, so nothing is uploaded twice -- PersistTaskQueue's item lists (items != NULL; evg_materialize_queue_device)

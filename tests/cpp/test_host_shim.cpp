@@ -33,10 +33,21 @@ static Backend OracleBackend(const std::string& path) {
   if (!h) throw std::runtime_error(std::string("cannot load the oracle: ") + dlerror());
   auto plan = reinterpret_cast<int (*)(const evg_plan_input*, const evg_plan_output*)>(dlsym(h, "evg_oracle_plan_distros"));
   auto alloc = reinterpret_cast<int (*)(const evg_alloc_input*, const evg_alloc_output*)>(dlsym(h, "evg_oracle_allocate_hosts"));
-  if (!plan || !alloc) throw std::runtime_error("oracle entry points missing");
+  auto disp = reinterpret_cast<int (*)(const evg_plan_input*, const int32_t*, const int32_t*, const evg_dispatch_order*)>(dlsym(h, "evg_oracle_dispatch_order"));
+  if (!plan || !alloc || !disp) throw std::runtime_error("oracle entry points missing");
   Backend b;
   b.plan = plan;
   b.allocate = alloc;
+  b.rebuild = [disp](int32_t D, const int32_t* item_off, const int32_t* dep_off, const int32_t* dep_idx, const int32_t* group_key, const int32_t* tg_off,
+                     const int32_t* group_index, const evg_dispatch_order* out) {
+    evg_plan_input in{};  // the oracle reads the items through the planner's batch layout; the items are the rows
+    in.n_distros = D; in.n_task_groups = tg_off[D]; in.task_off = item_off; in.tg_off = tg_off;
+    in.tasks.n_tasks = item_off[D]; in.tasks.n_edges = dep_off[item_off[D]];
+    in.tasks.dep_off = dep_off; in.tasks.dep_idx = dep_idx; in.tasks.tg_key = group_key; in.tasks.task_group_order = group_index;
+    std::vector<int32_t> row((size_t)item_off[D] + 1);
+    for (size_t i = 0; i < row.size(); i++) row[i] = (int32_t)i;
+    return disp(&in, item_off, row.data(), out);
+  };
   b.last_error = [] { return std::string("oracle"); };
   return b;
 }
@@ -61,6 +72,9 @@ static void check_queue_info(const Backend& be, const char* name, int line, cons
 static void check_allocator(const Backend& be, const char* name, int line, HostAllocatorData& data, const std::map<std::string, Task>& running,
                             int want_hosts, int want_free);
 static void check_cap(const char* name, const std::vector<Task>& tasks, int limit, int want);
+static void check_dispatcher(const Backend& be, const char* name, const std::vector<TaskQueueItem>& items, std::vector<std::string> want_sorted,
+                             int want_cycles, std::map<std::string, int> want_groups);
+static void check_group_order(const Backend& be, const char* name, const std::vector<TaskQueueItem>& items, std::vector<std::string> want);
 
 #include "golden_cases.inc"
 
@@ -156,6 +170,65 @@ static void run_error_cases(const Backend& be) {
   }
 }
 
+// model/task_queue_service_test.go: rebuild(items), then d.sorted / d.taskGroups. A second, empty queue rides along so the
+// batched call is exercised with more than one distro.
+static void check_dispatcher(const Backend& be, const char* name, const std::vector<TaskQueueItem>& items, std::vector<std::string> want_sorted,
+                             int want_cycles, std::map<std::string, int> want_groups) {
+  const std::vector<TaskQueueItem> none;
+  const auto st = RebuildDispatchers(be, {&none, &items});
+  EXPECT(st[0].sorted.empty() && st[0].taskGroups.empty(), "%s: the empty queue", name);
+  const DAGDispatcherState& d = st[1];
+  EXPECT(d.cycles == want_cycles, "%s: %d cycles, want %d", name, d.cycles, want_cycles);
+  EXPECT(d.sorted.size() == want_sorted.size(), "%s: len(sorted) = %zu, want %zu", name, d.sorted.size(), want_sorted.size());
+  for (size_t k = 0; k < d.sorted.size() && k < want_sorted.size(); k++) {
+    const std::string got = d.sorted[k] < 0 ? std::string() : items[(size_t)d.sorted[k]].Id;
+    EXPECT(got == want_sorted[k], "%s: sorted[%zu] = '%s', want '%s'", name, k, got.c_str(), want_sorted[k].c_str());
+  }
+  if (!want_groups.empty()) {
+    EXPECT(d.taskGroups.size() == want_groups.size(), "%s: %zu task groups", name, d.taskGroups.size());
+    for (const auto& kv : want_groups) {
+      auto it = d.taskGroups.find(kv.first);
+      EXPECT(it != d.taskGroups.end() && (int)it->second.tasks.size() == kv.second, "%s: group %s", name, kv.first.c_str());
+    }
+  }
+}
+
+static void check_group_order(const Backend& be, const char* name, const std::vector<TaskQueueItem>& items, std::vector<std::string> want) {
+  const auto st = RebuildDispatchers(be, {&items});
+  EXPECT(st[0].taskGroups.size() == 1, "%s: one unit", name);
+  if (st[0].taskGroups.empty()) return;
+  const schedulableUnit& su = st[0].taskGroups.begin()->second;
+  EXPECT(su.maxHosts == items[0].GroupMaxHosts && su.group == items[0].Group, "%s: unit fields", name);
+  EXPECT(su.tasks.size() == want.size(), "%s: %zu tasks", name, su.tasks.size());
+  for (size_t k = 0; k < su.tasks.size() && k < want.size(); k++)
+    EXPECT(su.tasks[k].Id == want[k], "%s: tasks[%zu] = %s, want %s", name, k, su.tasks[k].Id.c_str(), want[k].c_str());
+}
+
+// BuildTaskQueue over a planned list: the item fields, the cap and the dependency ids (task_queue_persister.go:17-52)
+static void run_queue_item_behaviour(const Backend& be) {
+  std::vector<Task> ts(3);
+  ts[0].Id = "a"; ts[1].Id = "b"; ts[2].Id = "c";
+  ts[1].Priority = 7; ts[1].TaskGroup = "tg"; ts[1].TaskGroupOrder = 2; ts[1].TaskGroupMaxHosts = 1; ts[1].Version = "v"; ts[1].BuildVariant = "bv";
+  ts[2].DependsOn.push_back(Dependency{}); ts[2].DependsOn[0].TaskId = "a";
+  const PlannedQueue pq = PrioritizeTasks(be, Distro{}, ts, TaskPlannerOptions{}, NOW);
+  const auto items = BuildTaskQueue(pq.plan, 0);
+  EXPECT(items.size() == 3 && items[0].Id == "b" && items[0].Group == "tg" && items[0].GroupIndex == 2 && items[0].GroupMaxHosts == 1 && items[0].Priority == 7,
+         "BuildTaskQueue: first item");
+  for (const auto& it : items)
+    if (it.Id == "c") EXPECT(it.Dependencies.size() == 1 && it.Dependencies[0] == "a" && !it.DependenciesMet, "BuildTaskQueue: dependencies of c");
+  EXPECT(items[0].SortingValueBreakdown.TotalValue == pq.plan[0].SortingValueBreakdown.TotalValue && items[0].SortingValueBreakdown.TotalValue > 0,
+         "BuildTaskQueue: breakdown carried over");
+  EXPECT(BuildTaskQueue(pq.plan, 1).size() == 1, "BuildTaskQueue: cap");
+  // ... and the dispatcher built from that queue: a before c
+  const auto st = RebuildDispatchers(be, {&items});
+  size_t pa = 9, pc = 9;
+  for (size_t k = 0; k < st[0].sorted.size(); k++) {
+    if (items[(size_t)st[0].sorted[k]].Id == "a") pa = k;
+    if (items[(size_t)st[0].sorted[k]].Id == "c") pc = k;
+  }
+  EXPECT(st[0].sorted.size() == 3 && pa < pc, "dispatcher over the built queue: dependency first");
+}
+
 static void run_planner_behaviour(const Backend& be) {
   // planner_test.go:406-432 TaskPlan: NoChange / ChangeOrder
   std::vector<Task> ts(2);
@@ -188,6 +261,8 @@ int main(int argc, char** argv) {
     run_cap_cases();
     run_error_cases(be);
     run_planner_behaviour(be);
+    run_dispatcher_cases(be);
+    run_queue_item_behaviour(be);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 1;

@@ -202,3 +202,17 @@ def test_hip_schedule_distros_host_pointers(native_ctx, oracle, limit):
         assert np.array_equal(items.breakdown, witems.breakdown)
         worder = oracle.dispatch_order(b, witems.item_off, witems.cols["row"])
         _assert_same(order, worder, witems.item_off, b.n_distros, int(b.tg_off[-1]))
+
+
+@pytest.mark.gpu
+def test_hip_rebuild_host_pointer_form(native_ctx, oracle):
+    """evg_rebuild_dispatchers: rebuild(items) from host memory -- the reference's vectors and random graphs with cycles."""
+    rng = np.random.default_rng(3)
+    queues = [_items(VEC["constructor"]["items"]), _items(VEC["single_host_group_ordering"]["items"]), _items(VEC["self_edge"]["items"]),
+              _items(VEC["dependency_cycle"]["items"]), [], _random_queue(rng, 20, 300, True), _random_queue(rng, 21, 700, False)]
+    packed, want = _oracle_rebuild(oracle, queues)
+    b = packed.batch
+    got = native_ctx.dispatch_order(b)
+    _assert_same(got, want, b.task_off, b.n_distros, int(b.tg_off[-1]))
+    assert [queues[0][int(q)].Id for q in got.distro_sorted(b.task_off, 0)] == VEC["constructor"]["sorted"]
+    assert [queues[1][int(q)].Id for q in got.group_tasks(int(b.tg_off[1]))] == VEC["single_host_group_ordering"]["group_tasks"]
