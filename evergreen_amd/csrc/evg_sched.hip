@@ -118,27 +118,43 @@ __global__ void __launch_bounds__(1024) k_queue_offsets(int D, const int32_t* ta
   }
 }
 
-// k_queue_items: blockIdx.y = distro, one thread per persisted queue position: a gather by `order`.
-__global__ void __launch_bounds__(256) k_queue_items(const evg_plan_input in, const evg_plan_output plan, const evg_queue_items it) {
-  const int d = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const int n = it.item_off[d + 1] - it.item_off[d];
-  if (p >= n) return;
-  const int r = plan.order[in.task_off[d] + p];
-  const int o = it.item_off[d] + p;
+// k_queue_items: one workgroup per distro. A gather by `order` costs one L2 request per item and column; a distro of up to
+// 2048 rows instead reads its columns ONCE, coalesced, into LDS (29 B per row) and permutes there, so both the reads and the
+// writes are whole lines. Larger distros gather straight from memory.
+constexpr int kQiRows = 2048;
+__global__ void __launch_bounds__(512) k_queue_items(const evg_plan_input in, const evg_plan_output plan, const evg_queue_items it) {
+  __shared__ int64_t s_dur[kQiRows], s_pri[kQiRows];
+  __shared__ int32_t s_gmh[kQiRows], s_gix[kQiRows], s_ndp[kQiRows];
+  __shared__ uint8_t s_met[kQiRows];
+  const int d = blockIdx.x, tid = threadIdx.x;
+  const int lo = in.task_off[d], rows = in.task_off[d + 1] - lo;
+  const int o0 = it.item_off[d], n = it.item_off[d + 1] - o0;
+  if (n <= 0) return;
   const evg_task_soa& t = in.tasks;
-  it.row[o] = r;
-  it.expected_duration_ns[o] = t.expected_duration_ns[r];
-  it.priority[o] = t.priority[r];
-  it.group_max_hosts[o] = t.task_group_max_hosts[r];
-  it.group_index[o] = t.task_group_order[r];
-  it.n_dependencies[o] = t.dep_off[r + 1] - t.dep_off[r];
-  it.dependencies_met[o] = plan.deps_met[r];
-  if (it.breakdown) {
-    const int64_t* src = plan.breakdown + (size_t)r * EVG_BREAKDOWN_FIELDS;
-    int64_t* dst = it.breakdown + (size_t)o * EVG_BREAKDOWN_FIELDS;
+  const bool staged = rows <= kQiRows;
+  if (staged) {
+    for (int i = tid; i < rows; i += 512) {
+      const int r = lo + i;
+      s_dur[i] = t.expected_duration_ns[r]; s_pri[i] = t.priority[r]; s_gmh[i] = t.task_group_max_hosts[r];
+      s_gix[i] = t.task_group_order[r]; s_ndp[i] = t.dep_off[r + 1] - t.dep_off[r]; s_met[i] = plan.deps_met[r];
+    }
+    __syncthreads();
+  }
+  for (int p = tid; p < n; p += 512) {
+    const int r = plan.order[lo + p], o = o0 + p, i = r - lo;
+    it.row[o] = r;
+    it.expected_duration_ns[o] = staged ? s_dur[i] : t.expected_duration_ns[r];
+    it.priority[o] = staged ? s_pri[i] : t.priority[r];
+    it.group_max_hosts[o] = staged ? s_gmh[i] : t.task_group_max_hosts[r];
+    it.group_index[o] = staged ? s_gix[i] : t.task_group_order[r];
+    it.n_dependencies[o] = staged ? s_ndp[i] : t.dep_off[r + 1] - t.dep_off[r];
+    it.dependencies_met[o] = staged ? s_met[i] : plan.deps_met[r];
+    if (it.breakdown) {
+      const int64_t* src = plan.breakdown + (size_t)r * EVG_BREAKDOWN_FIELDS;
+      int64_t* dst = it.breakdown + (size_t)o * EVG_BREAKDOWN_FIELDS;
 #pragma unroll
-    for (int k = 0; k < EVG_BREAKDOWN_FIELDS; k++) dst[k] = src[k];
+      for (int k = 0; k < EVG_BREAKDOWN_FIELDS; k++) dst[k] = src[k];
+    }
   }
 }
 
@@ -676,7 +692,7 @@ static int do_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, con
   hipLaunchKernelGGL(evg::k_queue_offsets, dim3(1), dim3(1024), 0, st, D, in->task_off, plan->order, tg_name_key, max_scheduled, items->cut,
                      items->item_off);
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(evg::k_queue_items, dim3((EVG_TASK_QUEUE_SAVE_LIMIT + 255) / 256, D), dim3(256), 0, st, *in, *plan, *items);
+  hipLaunchKernelGGL(evg::k_queue_items, dim3(D), dim3(512), 0, st, *in, *plan, *items);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }
