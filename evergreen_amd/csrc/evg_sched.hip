@@ -293,6 +293,7 @@ struct evg_ctx {
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
+  bool dispatch_attr_set = false;
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts = nullptr;
   unsigned long long* dbg_ts_alloc = nullptr;
@@ -721,7 +722,7 @@ static int do_dispatch_order_device(evg_ctx* c, const evg_plan_input* in, const 
       (N > 0 && (!item_row || !out->sorted || !out->group_items)))
     return set_err(c, EVG_E_INVALID, "null dispatch-order argument");
   HIP_TRY(c, hipSetDevice(c->device));
-  constexpr int kItemArrays = 17;
+  constexpr int kItemArrays = 16;
   const size_t words = (1 + kItemArrays) * (N + 64) + 2 * (E + 64) + (G + 64);
   int rc = ensure(c, c->scratch[28], words * sizeof(int32_t));
   if (rc) return rc;
@@ -731,11 +732,20 @@ static int do_dispatch_order_device(evg_ctx* c, const evg_plan_input* in, const 
   auto take = [&](size_t n) { int32_t* p = w; w += n + 64; return p; };
   a.pos = take(N);
   int32_t** item_arrays[kItemArrays] = {&a.cnt, &a.beg, &a.cur, &a.top, &a.bcnt, &a.bbeg, &a.m, &a.fbeg, &a.tmp, &a.own, &a.idx, &a.low,
-                                        &a.onstk, &a.cstk, &a.sstk, &a.gtmp, &a.llist};
+                                        &a.cstk, &a.sstk, &a.gtmp, &a.llist};
   for (auto pp : item_arrays) *pp = take(N);
   a.adj = take(E); a.adj2 = take(E);
   a.gcur = take(G);
-  hipLaunchKernelGGL(evg::k_dispatch_order, dim3(in->n_distros), dim3(evg::kDBlock), 0, (hipStream_t)hip_stream, a);
+  // LDS arena capacity from the launch hint (0 = unknown: the 4096 arena; queues beyond it use the global scratch)
+  const int hint = in->max_distro_tasks > 0 ? in->max_distro_tasks : 4096;
+  const int cap = hint <= 2048 ? 2048 : 4096;
+  const size_t lds = (size_t)evg::kArenaBytesPerItem * cap;
+  if (!c->dispatch_attr_set) {
+    HIP_TRY(c, hipFuncSetAttribute((const void*)evg::k_dispatch_order, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   evg::kArenaBytesPerItem * 4096));
+    c->dispatch_attr_set = true;
+  }
+  hipLaunchKernelGGL(evg::k_dispatch_order, dim3(in->n_distros), dim3(evg::kDBlock), lds, (hipStream_t)hip_stream, a, cap);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }
