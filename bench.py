@@ -183,9 +183,12 @@ def main():
                 traffic = json.load(open(pmc)).get("k_plan_distros_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # kernel_ms is the event interval around evg_plan_distros_device: k_plan_distros plus the (empty, ~4 us) k_plan_generic
+        # launch queued behind it, so `achieved` is a few per cent BELOW what rocprofv3's per-kernel average gives.
         line["roofline"] = {"bound": "hbm", "kernel": "k_plan_distros", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                             "algorithmic_bytes_per_launch": abytes, "kernel_ms": plan_ms, "allocator_ms": alloc_ms,
+                            "kernel_ms_scope": "HIP events around evg_plan_distros_device = k_plan_distros + the empty k_plan_generic launch behind it",
                             "bytes_per_task": abytes / max(batch.n_tasks, 1)}
         if world == 1 and not args.no_cpu_baseline:
             want, want_alloc, t1, tn, nt = cpu_baseline(batch, os.cpu_count() or 1)
