@@ -229,3 +229,25 @@ def test_big_distro_wide_value_range_falls_back(native_ctx, oracle):
     b = gen.generate(gen.GenConfig(9_000, 2, 808, with_hosts=False))
     b.cols["priority"][::7] = 2**58
     _full_compare(native_ctx, oracle, b, "wide values, big distro")
+
+
+@pytest.mark.gpu
+def test_planner_fuzz_matches_oracle(native_ctx, oracle):
+    """Many small random pools across the generator's knobs (sizes around the tile / wave / LDS-path boundaries, DAG depth,
+    task-group share, grouped versions, skewed sizes): plan + allocate, bit-exact against the oracle."""
+    rng = np.random.default_rng(20260923)
+    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 511, 513, 1023, 1025, 2047, 2048, 2049, 2300, 3000, 4097]
+    for it in range(40):
+        d = int(rng.integers(1, 7))
+        n = int(rng.choice(sizes)) * d + int(rng.integers(0, d))
+        cfg = gen.GenConfig(n, d, gen.SEED_BASE + 900 + it, dag_depth=int(rng.integers(1, 10)), tg_fraction=float(rng.choice([0.0, 0.1, 0.5, 1.0])),
+                            skew=bool(rng.random() < 0.3 and n >= 64 * d), shuffle=bool(rng.random() < 0.8),
+                            all_tg_version_fraction=float(rng.choice([0.0, 0.01, 0.5])),
+                            includes_dependencies_fraction=float(rng.choice([0.0, 0.75, 1.0])))
+        b = gen.generate(cfg)
+        got = native_ctx.plan(b)
+        want = oracle.plan(b)
+        compare.assert_plan_equal(got, want, b, "fuzz %d %r" % (it, cfg))
+        ga = native_ctx.allocate(b, got.distro_info, got.group_info)
+        wa = oracle.allocate(b, want.distro_info, want.group_info)
+        assert np.array_equal(ga.new_hosts, wa.new_hosts) and np.array_equal(ga.free_hosts, wa.free_hosts) and np.array_equal(ga.status, wa.status), it
