@@ -11,6 +11,9 @@ sort, dedup), GetDistroQueueInfo, and UtilizationBasedHostAllocator -- the BASEL
 
 Multi-GPU: distros are independent (one amboy job per distro in the reference), so every rank plans its OWN
 pool of the same shape with no data-path collective ("scaling": "weak"); value = all ranks' tasks / max time.
+`value` is the one-batch-at-a-time rate (each step waits for nothing but the stream order), which is what the `roofline`
+block describes. At N=1 the line also carries `pipelined`: the sustained rate with --in-flight (3) independent pools
+ticking on their own streams -- batches in flight fill each other's load / compute phases and the launch gaps.
 The CPU baseline (rank 0, N=1 only) is the C++ oracle -- a port of the Go algorithm, NOT the Go binary, which
 cannot be built here -- timed on this box's host cores.
 """
@@ -79,6 +82,33 @@ def cpu_baseline(batch, want_threads):
     return res, alloc, t1, tn, nt
 
 
+def pipelined_rate(batch, ctx, pool, dev, in_flight, steps, native, resident, torch):
+    """Sustained rate with `in_flight` independent pools (own context, scratch and outputs) ticking on their own HIP streams:
+    the workgroups of one launch are phase-locked (all load, then all compute); batches in flight fill each other's
+    bandwidth-bound and compute-bound phases, the kernel tails and the dispatch gaps. Reported next to `value`, which stays
+    the one-batch-at-a-time figure the roofline block describes."""
+    pools = [pool] + [resident.ResidentPool(native.Context(dev.index or 0), batch, dev, breakdown=False, n_units=False) for _ in range(in_flight - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in pools]
+    torch.cuda.synchronize(dev)
+    for p, st in zip(pools, streams):
+        p.plan(st.cuda_stream)
+        if p.has_hosts:
+            p.allocate(st.cuda_stream)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        p, st = pools[k % in_flight], streams[k % in_flight]
+        p.plan(st.cuda_stream)
+        if p.has_hosts:
+            p.allocate(st.cuda_stream)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / max(steps, 1)
+    ok = all(bool(torch.equal(p.o_order, pools[0].o_order)) for p in pools[1:])  # same batch: every pool must hold the same plan
+    return {"in_flight": in_flight, "value": batch.n_tasks / dt, "unit": "tasks/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "plans_identical": ok,
+            "what": "%d pools of the same workload, each on its own HIP stream with its own context / scratch / outputs, ticks issued round-robin" % in_flight}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +118,8 @@ def main():
     ap.add_argument("--tasks", type=int, default=0, help="override the task count (parity/debug runs only)")
     ap.add_argument("--distros", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=3, help="also report the sustained rate with this many independent pools in flight "
+                                                             "on their own streams (the `pipelined` object; 1 = skip)")
     ap.add_argument("--fused", action="store_true", help="time the single-launch entry point evg_plan_allocate_device instead of "
                     "evg_plan_distros_device + evg_allocate_hosts_device (the reference's two jobs)")
     args = ap.parse_args()
@@ -205,6 +237,8 @@ def main():
                 "sample": "the whole workload (%d tasks x %d distros), best of 5 passes with %d worker threads, one distro range each "
                           "(%.2f s per pass), and best of 3 passes on one thread (%.2f s per pass): C++ oracle, a port of the Go "
                           "algorithm (the Go reference cannot be built here: no Go toolchain)" % (batch.n_tasks, batch.n_distros, nt, tn, t1)}
+        if world == 1 and args.in_flight > 1:
+            line["pipelined"] = pipelined_rate(batch, ctx, pool, dev, args.in_flight, args.steps, native, resident, torch)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
