@@ -931,6 +931,10 @@ constexpr int kGenericLds = 2048 * 16;  // one tile of 128-bit keys
 __global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a, int skip_flat) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
+  // Almost always nothing is flagged: find that out with ONE round trip (independent loads) instead of one per distro.
+  int any = 0;
+  for (int d = blockIdx.x; d < a.in.n_distros; d += gridDim.x) any |= a.w_generic[d];
+  if (!any) return;
   for (int d = blockIdx.x; d < a.in.n_distros; d += gridDim.x) {
     if (!a.w_generic[d]) continue;
     if (skip_flat && a.in.task_off[d + 1] - a.in.task_off[d] > 1024 && a.w_gstate[d].fast) continue;
