@@ -65,6 +65,15 @@ def main():
         print("  %-18s mean %8.1f  p50 %8.1f  max %8.1f   %5.1f%%" % (nm, dt[:, k].mean(), np.median(dt[:, k]), dt[:, k].max(),
                                                                       100 * dt[:, k].mean() / tot.mean()))
     print("  %-18s mean %8.1f  p50 %8.1f  max %8.1f" % ("WG total", tot.mean(), np.median(tot), tot.max()))
+    # the kernel lasts as long as its slowest workgroup: what do the slow ones look like?
+    gv = batch.distros["group_versions"]
+    nver, ntg = np.diff(batch.ver_off), np.diff(batch.tg_off)
+    ne = batch.dep_off[batch.task_off[1:]] - batch.dep_off[batch.task_off[:-1]]
+    print("  grouped-version distros: %d of %d; WG total mean %.0f (gv) vs %.0f (others)" % (
+        int((gv != 0).sum()), len(gv), tot[gv != 0].mean() if (gv != 0).any() else 0, tot[gv == 0].mean()))
+    for d in np.argsort(-tot)[:8]:
+        print("  slow d=%3d total %7.0f gv=%d n=%d ver=%d tg=%d edges=%d | " % (d, tot[d], gv[d], batch.task_off[d + 1] - batch.task_off[d], nver[d], ntg[d], ne[d]) +
+              " ".join("%s %.0f" % (nm.split()[0], dt[d, k]) for k, nm in enumerate(NAMES)))
     if pool.has_hosts and not fused:
         for _ in range(3):
             pool.allocate()
