@@ -558,42 +558,41 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   int rank[4] = {0, 0, 0, 0};
   if (multi) {
     if (ik_ok) {
-      // The thread's positions are consecutive, so the members of one run inside the thread are consecutive too.
-      // Per distinct run: (1) positions before the thread's members precede on key <=, (2) positions after them on
-      // key <, (3) the members among themselves in registers. Keys of elements outside the run are masked so that
-      // the inner loops are one compare + one add-with-carry per element.
+      // The thread's positions are consecutive. Positions BEFORE them can only belong to the run of its first position,
+      // positions AFTER them only to the run of its last one, and every run in between lies inside the thread. So, for all
+      // lanes at once: (1) one loop over the earlier part of the first run -- those precede on key <=; (2) one loop over the
+      // later part of the last run -- those precede on key <; (3) the thread's own members among themselves in registers.
+      // Keys of positions outside the run are masked so that the inner loops are one compare + one add-with-carry per
+      // element. (One pair of loops per lane, whatever the number of run boundaries inside a wave.)
+      int nv = 0;  // the thread's valid positions: [i0, i0 + nv)
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        if (i0 + g >= n || (g && st[g] == st[g - 1]) || en[g] - st[g] <= 1) continue;  // g opens a run inside the thread
-        const int rs = st[g], re = en[g];
+      for (int e = 0; e < 4; e++) nv += i0 + e < n ? 1 : 0;
+      if (nv > 0) {
+        const int rs = st[0], le = nv - 1, re = en[le];
         uint64_t khi[4], klo[4];
-        int last = g;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const bool in = e >= g && st[e] == rs && i0 + e < n;
-          khi[e] = in ? myik[e] : ~0ull;  // never "greater than the other key"
-          klo[e] = in ? myik[e] : 0ull;   // never "less than ..."
-          last = in ? e : last;
+          khi[e] = e < nv && st[e] == rs ? myik[e] : ~0ull;       // never "greater than the other key"
+          klo[e] = e < nv && st[e] == st[le] ? myik[e] : 0ull;   // never "less than ..."
         }
-        const int a0 = i0 + g, a1 = i0 + last + 1;  // the thread's members of the run: positions [a0, a1)
         int gt[4] = {0, 0, 0, 0};
         {  // earlier positions precede unless their key is greater; 4 independent LDS reads per trip
           int q2 = rs;
-          for (; q2 + 4 <= a0; q2 += 4) {
+          for (; q2 + 4 <= i0; q2 += 4) {
             const uint64_t k0 = sik[q2], k1 = sik[q2 + 1], k2 = sik[q2 + 2], k3 = sik[q2 + 3];
 #pragma unroll
             for (int e = 0; e < 4; e++) gt[e] += (khi[e] < k0 ? 1 : 0) + (khi[e] < k1 ? 1 : 0) + (khi[e] < k2 ? 1 : 0) + (khi[e] < k3 ? 1 : 0);
           }
-          for (; q2 < a0; q2++) {
+          for (; q2 < i0; q2++) {
             const uint64_t k0 = sik[q2];
 #pragma unroll
             for (int e = 0; e < 4; e++) gt[e] += khi[e] < k0 ? 1 : 0;
           }
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++) rank[e] += (e >= g && e <= last) ? (a0 - rs) - gt[e] : 0;
+        for (int e = 0; e < 4; e++) rank[e] += (e < nv && st[e] == rs) ? (i0 - rs) - gt[e] : 0;
         {  // later positions precede only when their key is smaller
-          int q2 = a1;
+          int q2 = i0 + nv;
           for (; q2 + 4 <= re; q2 += 4) {
             const uint64_t k0 = sik[q2], k1 = sik[q2 + 1], k2 = sik[q2 + 2], k3 = sik[q2 + 3];
 #pragma unroll
@@ -609,7 +608,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
         for (int e = 0; e < 4; e++)
 #pragma unroll
           for (int f = e + 1; f < 4; f++) {
-            const bool both = e >= g && f <= last;
+            const bool both = f < nv && st[e] == st[f];
             const bool f_first = myik[f] < myik[e];  // ties: the earlier position (row order) stays first
             rank[e] += both && f_first ? 1 : 0;
             rank[f] += both && !f_first ? 1 : 0;

@@ -14,7 +14,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libevg_sched.so")
+LIB_PATH = os.environ.get("EVG_SCHED_LIB") or os.path.join(_HERE, "csrc", "libevg_sched.so")  # the override is for A/B runs of two builds
 
 EXPORTS = [
     "evg_create", "evg_destroy", "evg_last_error", "evg_abi_version", "evg_validate_plan_input",
