@@ -7,18 +7,22 @@ OUT=$R/gpurun_out
 TAG=${1:-r01}
 mkdir -p $OUT/prof
 cd $R
+if [ -z "${PROFILE_ONLY:-}" ]; then
 echo "== pytest -m gpu" | tee $OUT/pytest_$TAG.log
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee -a $OUT/pytest_$TAG.log
 echo "== bench" | tee $OUT/bench_$TAG.log
 timeout 600 python bench.py --steps 50 --warmup 5 2>&1 | tail -5 | tee -a $OUT/bench_$TAG.log
+fi
+# the profiled runs keep ONE batch in flight: with several, concurrent launches stretch each other's durations and the
+# per-kernel averages no longer describe a launch on its own (bench.py's roofline block is the one-at-a-time figure too)
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 kernel-trace stats"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof/$TAG-stats -o $TAG -- \
-  python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/prof/$TAG-stats.log 2>&1
+  python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --in-flight 1 > $OUT/prof/$TAG-stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprofv3 pmc $c"
   timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/prof/$TAG-pmc-$c -o $TAG -- \
-    python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof/$TAG-pmc-$c.log 2>&1
+    python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --in-flight 1 > $OUT/prof/$TAG-pmc-$c.log 2>&1
 done
 find $OUT/prof -name "*.csv" | head -50
 python $R/scripts/summarize_prof.py $OUT/prof $TAG > $OUT/prof/$TAG-summary.txt 2>&1

@@ -71,7 +71,20 @@ def main():
     ne = batch.dep_off[batch.task_off[1:]] - batch.dep_off[batch.task_off[:-1]]
     print("  grouped-version distros: %d of %d; WG total mean %.0f (gv) vs %.0f (others)" % (
         int((gv != 0).sum()), len(gv), tot[gv != 0].mean() if (gv != 0).any() else 0, tot[gv == 0].mean()))
+    fl = batch.cols["flags"].astype(np.int64)
+    req = fl & 3
+    degs = np.diff(batch.dep_off)
+
+    def shape(d):
+        lo, hi = batch.task_off[d], batch.task_off[d + 1]
+        return "patch %.2f merge %.2f tg %.2f maxdeps %d pri>0 %.2f" % (np.mean(req[lo:hi] == 1), np.mean(req[lo:hi] == 2),
+                                                                       np.mean(batch.cols["tg_key"][lo:hi] >= 0), degs[lo:hi].max(),
+                                                                       np.mean(batch.cols["priority"][lo:hi] > 0))
+    ng = np.nonzero(gv == 0)[0]
+    for d in ng[np.argsort(tot[ng])[:3]]:
+        print("  fast d=%3d total %7.0f | B %.0f C %.0f D %.0f F %.0f | %s" % (d, tot[d], dt[d, 1], dt[d, 2], dt[d, 4], dt[d, 7], shape(d)))
     for d in np.argsort(-tot)[:8]:
+        print("       d=%3d %s" % (d, shape(d)))
         print("  slow d=%3d total %7.0f gv=%d n=%d ver=%d tg=%d edges=%d | " % (d, tot[d], gv[d], batch.task_off[d + 1] - batch.task_off[d], nver[d], ntg[d], ne[d]) +
               " ".join("%s %.0f" % (nm.split()[0], dt[d, k]) for k, nm in enumerate(NAMES)))
     if pool.has_hosts and not fused:
