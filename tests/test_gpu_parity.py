@@ -224,6 +224,23 @@ def test_big_distros_generic_fast_sort(native_ctx, oracle):
     _full_compare(native_ctx, oracle, b, "config 5 shape, big distros")
 
 
+def test_config5_per_gpu_share(native_ctx, oracle):
+    """BASELINE config 5 at full size is 10M tasks x 512 distros over 8 GPUs: one GPU's share, 1.25M tasks x 64 distros of
+    19.5k tasks (DAG depth 8, 20% task-group tasks), through the device-resident entry points -- the flat large-distro
+    pipeline -- plan + allocate bit-exact against the oracle."""
+    import torch
+    from evergreen_amd import resident
+    b = gen.generate(gen.config(5, n_tasks=1_250_000, n_distros=64))
+    pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=False, n_units=False)
+    pool.step(fused=False)
+    got, got_alloc = pool.plan_result(), pool.alloc_result()
+    want = oracle.plan(b, breakdown=False, n_units=False)
+    want.breakdown, want.n_units = None, None
+    want_alloc = oracle.allocate(b, want.distro_info, want.group_info)
+    compare.assert_plan_equal(got, want, b, "config 5 share")
+    compare.assert_alloc_equal(got_alloc, want_alloc, "config 5 share")
+
+
 def test_big_distro_wide_value_range_falls_back(native_ctx, oracle):
     """A value range beyond 55 bits cannot be packed: the comparator sort of the generic path runs instead."""
     b = gen.generate(gen.GenConfig(9_000, 2, 808, with_hosts=False))
