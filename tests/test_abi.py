@@ -41,9 +41,11 @@ def test_library_exports_every_declared_entry_point(lib):
 def test_struct_layouts_match_the_header(tmp_path):
     """sizeof / offsetof from the real header (gcc) against the ctypes structs and numpy dtypes."""
     structs = {"evg_task_soa": abi.TaskSoa, "evg_plan_input": abi.PlanInput, "evg_plan_output": abi.PlanOutput,
-               "evg_host_soa": abi.HostSoa, "evg_alloc_input": abi.AllocInput, "evg_alloc_output": abi.AllocOutput}
+               "evg_host_soa": abi.HostSoa, "evg_alloc_input": abi.AllocInput, "evg_alloc_output": abi.AllocOutput,
+               "evg_queue_items": abi.QueueItems, "evg_dispatch_order": abi.DispatchOrder}
     dtypes = {"evg_distro_params": abi.DISTRO_PARAMS_DTYPE, "evg_group_info": abi.GROUP_INFO_DTYPE,
-              "evg_distro_info": abi.DISTRO_INFO_DTYPE, "evg_alloc_params": abi.ALLOC_PARAMS_DTYPE}
+              "evg_distro_info": abi.DISTRO_INFO_DTYPE, "evg_alloc_params": abi.ALLOC_PARAMS_DTYPE,
+              "evg_report_params": abi.REPORT_PARAMS_DTYPE, "evg_alloc_report": abi.ALLOC_REPORT_DTYPE}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "evg_sched.h"', "int main(void) {"]
     for s, ct in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (s, s))
