@@ -89,6 +89,18 @@ struct PlanArgs {
 #define EVG_STAMP(k) do {} while (0)
 #endif
 
+// Two workgroups share a CU and the SQ issues oldest-wave-first, so the workgroup dispatched second gets what the first
+// leaves over and finishes ~30 % later -- and a launch lasts as long as its slowest workgroup. Wave priority that FALLS as
+// a workgroup advances (step k of its phases -> priority 3 - k mod 4) hands the issue slots to whichever of the two is
+// behind: they cross the phases almost in lock step and finish together.
+#define EVG_PRIO(step) __builtin_amdgcn_s_setprio(3 - ((step) & 3))
+// steps base + e for the unrolled e = 0..3 (the builtin wants a literal)
+#define EVG_PRIO4(base, e)                                                                  \
+  do {                                                                                      \
+    if ((e) == 0) EVG_PRIO(base); else if ((e) == 1) EVG_PRIO((base) + 1);                  \
+    else if ((e) == 2) EVG_PRIO((base) + 2); else EVG_PRIO((base) + 3);                     \
+  } while (0)
+
 // ---- small helpers ----------------------------------------------------------------------------------
 __device__ __forceinline__ int64_t wrap_add(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
 __device__ __forceinline__ int64_t wrap_sub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }

@@ -198,6 +198,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   unsigned long long* s_rng = (unsigned long long*)(s_red + 16);  // 0 vmin 1 vmax 2 durmin 3 durmax (biased)
   uint32_t* s_r32 = s_red + 24;                                   // 0 tgomin 1 tgomax 2 ndmin 3 ndmax 4 primin 5 primax
 
+  EVG_PRIO(0);
   // ---- A: load ------------------------------------------------------------------------------------------
   int32_t tgk[4], verk[4], nd[4], tgo[4];
   uint16_t fl[4];
@@ -293,6 +294,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   int tv[4];                       // version unit of a task-group row when versions are grouped, else -1
 #pragma unroll
   for (int e = 0; e < 4; e++) {
+    EVG_PRIO4(1, e);
     const int i = i0 + e;
     tv[e] = c.gv && tgk[e] >= 0 ? c.ver_base + (verk[e] - c.ver_lo) : -1;
     if (i >= n) continue;
@@ -334,6 +336,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     }
   }
   EVG_STAMP(2);
+  EVG_PRIO(5);
   __syncthreads();
 
   // ---- C: score every unit (planner.go:209-300); units whose distro is nil are dropped (:81) -----------------
@@ -395,6 +398,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   uint32_t r_tmin = ~0u, r_tmax = 0, r_nmin = ~0u, r_nmax = 0, r_pmin = ~0u, r_pmax = 0;
 #pragma unroll
   for (int e = 0; e < 4; e++) {
+    EVG_PRIO4(6, e);
     const int i = i0 + e;
     bv[e] = INT64_MIN; bm[e] = 0; bs[e] = -1;
     if (i >= n) continue;
@@ -441,6 +445,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   load4(t.scheduled_ts_ns + lo, i0, n, (int64_t)0, sched);
   load4(t.deps_met_ts_ns + lo, i0, n, (int64_t)0, dmt);
   EVG_STAMP(5);
+  EVG_PRIO(10);
   __syncthreads();  // accumulators are dead from here on
 
   // ---- E: keys + sort --------------------------------------------------------------------------------------
@@ -472,7 +477,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       k[e] = i < n ? ((vmax - ub(bv[e])) << 34) | ((uint64_t)bm[e] << 23) | ((uint64_t)bs[e] << 11) | (uint64_t)i : ~0ull;
     }
     EVG_STAMP(6);
-    if (P == 2048) bitonic_sort4_fixed<2048, uint64_t>(k, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
+    if (P == 2048) bitonic_sort4_fixed<2048, uint64_t, 11>(k, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
     else bitonic_sort4<uint64_t>(k, P, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
 #pragma unroll
     for (int e = 0; e < 4; e++) srt[e] = (uint32_t)k[e] & 0x7FFFFFu;
@@ -489,6 +494,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     for (int e = 0; e < 4; e++) srt[e] = (uint32_t)k[e].lo & 0x7FFFFFu;
   }
   EVG_STAMP(7);
+  EVG_PRIO(15);
   __syncthreads();  // the exchange buffers are re-used below
 
   // ---- F: order inside each unit (TaskList.Less) --------------------------------------------------------------
@@ -642,6 +648,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     store4(a.out.order + lo, i0, n, o4);
   }
   EVG_STAMP(8);
+  EVG_PRIO(16);
 
   // ---- G: GetDistroQueueInfo (scheduler.go:57-178) -----------------------------------------------------------
   uint64_t* g_dur = (uint64_t*)(smem + Z_G);
@@ -689,6 +696,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     store4(a.out.deps_met + lo, i0, n, m4);
   }
   EVG_STAMP(9);
+  EVG_PRIO(17);
   const bool has_mq = __syncthreads_or(any_mq ? 1 : 0) != 0;  // also orders the zeroing of the group rows
   const int64_t T = target_time_for_queue(p, has_mq);
 
@@ -747,6 +755,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   }
   if (__any(sec) && lane == 0) atomicOr(&s_red[4], 1u);
   EVG_STAMP(10);
+  EVG_PRIO(18);
   __syncthreads();
 
   // rows out: model.TaskGroupInfo; MaxHosts = first task of the group in QUEUE order (scheduler.go:103-106)

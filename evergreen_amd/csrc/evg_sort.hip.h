@@ -49,12 +49,20 @@ __device__ __forceinline__ void cmpx(K& a, K& b, bool asc) {  // a at the lower 
 // with its exchange distance resolved at compile time and no scalar dispatch.
 // p_base: global position of the tile's first key (directions of the last merges depend on it when the tile is part of a
 // larger network; 0 for a stand-alone sort).
-template <int P, class K>
+// PRIO_STEP >= 0: the planner's falling wave priority (EVG_PRIO) takes four more steps inside the sort, one per merge of
+// 256 keys and up (the last four merges are two thirds of the network).
+template <int P, class K, int PRIO_STEP = -1>
 __device__ __forceinline__ void bitonic_sort4_fixed(K (&k)[4], int tid, K* buf0, K* buf1, int p_base = 0) {
   const int p0 = tid * 4;
   int which = 0;
 #pragma unroll
   for (int kk = 2; kk <= P; kk <<= 1) {
+    if constexpr (PRIO_STEP >= 0) {
+      if (kk == P / 8) EVG_PRIO(PRIO_STEP);
+      else if (kk == P / 4) EVG_PRIO(PRIO_STEP + 1);
+      else if (kk == P / 2) EVG_PRIO(PRIO_STEP + 2);
+      else if (kk == P) EVG_PRIO(PRIO_STEP + 3);
+    }
     const bool asc_t = ((p_base + p0) & kk) == 0;  // valid for kk >= 4
 #pragma unroll
     for (int j = kk >> 1; j > 0; j >>= 1) {

@@ -80,6 +80,9 @@ def main():
         return "patch %.2f merge %.2f tg %.2f maxdeps %d pri>0 %.2f" % (np.mean(req[lo:hi] == 1), np.mean(req[lo:hi] == 2),
                                                                        np.mean(batch.cols["tg_key"][lo:hi] >= 0), degs[lo:hi].max(),
                                                                        np.mean(batch.cols["priority"][lo:hi] > 0))
+    print("  WG total by distro id (mean of 32 consecutive ids):", " ".join("%.0f" % tot[k:k + 32].mean() for k in range(0, len(tot), 32)))
+    print("  phase B+C by distro id (mean of 32 consecutive ids):", " ".join("%.0f" % (dt[k:k + 32, 1] + dt[k:k + 32, 2]).mean() for k in range(0, len(tot), 32)))
+    print("  start skew (first stamp - earliest first stamp), mean of 32 ids:", " ".join("%.0f" % (t[k:k + 32, 0] - t[:, 0].min()).mean() for k in range(0, len(tot), 32)))
     ng = np.nonzero(gv == 0)[0]
     for d in ng[np.argsort(tot[ng])[:3]]:
         print("  fast d=%3d total %7.0f | B %.0f C %.0f D %.0f F %.0f | %s" % (d, tot[d], dt[d, 1], dt[d, 2], dt[d, 4], dt[d, 7], shape(d)))
