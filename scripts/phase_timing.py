@@ -94,12 +94,13 @@ def main():
         for _ in range(3):
             pool.allocate()
         torch.cuda.synchronize()
-        t2 = ts2.cpu().numpy().reshape(-1, 16)[:, :6]
-        ok = t2[:, 5] > 0
-        d2 = np.diff(t2[ok], axis=1).astype(np.float64)
+        t2 = ts2.cpu().numpy().reshape(-1, 16).astype(np.float64)
+        ok = (t2[:, 7] > 0) & (t2[:, 3] > 0)   # distros that ran the bucket loop to the end
         print("allocator (distros that run the bucket loop: %d)" % int(ok.sum()))
-        for k, nm in enumerate(["init", "host loop", "nfree+early outs", "bucket loop", "write back"]):
-            print("  %-18s mean %8.1f  max %8.1f" % (nm, d2[:, k].mean(), d2[:, k].max()))
+        for nm, a0, a1 in [("params + host pass", 0, 1), ("free-host count + early outs", 6, 2), ("bucket loop", 2, 3), ("totals", 3, 4),
+                           ("write back", 4, 7), ("whole workgroup", 0, 7)]:
+            dd = t2[ok, a1] - t2[ok, a0]
+            print("  %-30s mean %8.1f  max %8.1f" % (nm, dd.mean(), dd.max()))
 
 
 if __name__ == "__main__":

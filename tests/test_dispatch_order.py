@@ -216,3 +216,16 @@ def test_hip_rebuild_host_pointer_form(native_ctx, oracle):
     _assert_same(got, want, b.task_off, b.n_distros, int(b.tg_off[-1]))
     assert [queues[0][int(q)].Id for q in got.distro_sorted(b.task_off, 0)] == VEC["constructor"]["sorted"]
     assert [queues[1][int(q)].Id for q in got.group_tasks(int(b.tg_off[1]))] == VEC["single_host_group_ordering"]["group_tasks"]
+
+
+@pytest.mark.gpu
+def test_hip_rebuild_large_queues_with_cycles(native_ctx, oracle):
+    """Queues beyond the LDS arena (4096 items) up to the 10,000 of TaskQueue.Save, with cycles, hubs and absent dependencies:
+    the same kernel on the global scratch."""
+    rng = np.random.default_rng(8)
+    queues = [_random_queue(rng, 30, 5000, True), _random_queue(rng, 31, 9000, False), _random_queue(rng, 32, 4097, True), _random_queue(rng, 33, 10, False)]
+    packed, want = _oracle_rebuild(oracle, queues)
+    b = packed.batch
+    got = native_ctx.dispatch_order(b)
+    _assert_same(got, want, b.task_off, b.n_distros, int(b.tg_off[-1]))
+    assert int(want.n_cycles.sum()) > 0
