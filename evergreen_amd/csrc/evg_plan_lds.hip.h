@@ -703,7 +703,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // pass B: segmented sums keyed by task group (row 0 = ""). The standalone row takes ~90% of the tasks: it is
   // summed in registers and wave-reduced, one atomic per wave; task-group rows take direct LDS atomics.
   uint32_t n_met = 0, n_mq = 0, n_s3 = 0, sec = 0;
-  uint32_t s_cnt = 0, s_cover = 0, s_wait = 0, s_mq = 0;
+  uint32_t s_cnt = 0, s_cover = 0, s_wait = 0, s_mq = 0, s_first = 0xFFFFFFFFu;
   uint64_t s_dur = 0, s_dover = 0;
   int64_t wait4[4];
 #pragma unroll
@@ -727,11 +727,13 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     if (f & EVG_TF_OTHER_DISTRO) sec = 1;
     if (mt) { n_met++; if (merge) n_mq++; if (f & EVG_TF_S3_STORAGE) n_s3++; }
     const int g = tgk[e] < 0 ? 0 : 1 + (tgk[e] - c.tg_lo);
-    atomicMin(&g_first[g], (uint32_t)pos[i]);
+    const uint32_t qp = (uint32_t)pos[i];
     if (g == 0) {
+      s_first = qp < s_first ? qp : s_first;
       s_cnt += count; s_dur += count ? (uint64_t)du : 0; s_cover += over; s_dover += over ? (uint64_t)du : 0;
       s_wait += wait_over; s_mq += (mt && merge);
     } else {
+      atomicMin(&g_first[g], qp);
       if (count) { atomicAdd(&g_cnt[g], 1u); atomicAdd((unsigned long long*)&g_dur[g], (unsigned long long)du); }
       if (over) { atomicAdd(&g_cover[g], 1u); atomicAdd((unsigned long long*)&g_dover[g], (unsigned long long)du); }
       if (wait_over) atomicAdd(&g_wait[g], 1u);
@@ -742,7 +744,9 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   s_cnt = wave_sum(s_cnt); s_cover = wave_sum(s_cover); s_wait = wave_sum(s_wait); s_mq = wave_sum(s_mq);
   s_dur = wave_sum(s_dur); s_dover = wave_sum(s_dover);
   n_met = wave_sum(n_met); n_mq = wave_sum(n_mq); n_s3 = wave_sum(n_s3);
+  s_first = wave_min(s_first);
   if (lane == 0) {
+    if (s_first != 0xFFFFFFFFu) atomicMin(&g_first[0], s_first);
     if (s_cnt) atomicAdd(&g_cnt[0], s_cnt);
     if (s_dur) atomicAdd((unsigned long long*)&g_dur[0], (unsigned long long)s_dur);
     if (s_cover) atomicAdd(&g_cover[0], s_cover);
