@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(kFlatBlock) k_flat_sums(const PlanArgs a) {
   if (on) {
     const evg_task_soa& t = a.in.tasks;
     const evg_distro_params p = a.in.distros[d];
-    const int lo = a.in.task_off[d], tg_lo = a.in.tg_off[d];
+    const int tg_lo = a.in.tg_off[d];
     const int64_t T = target_time_for_queue(p, a.w_gstate[d].any_mq != 0);
     const bool incl = p.includes_dependencies != 0;
     const uint32_t f = t.flags[r];

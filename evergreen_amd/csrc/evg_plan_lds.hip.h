@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const Fu
   const DC c = distro_context(f.p, d);
   if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
   __syncthreads();
-  const PlanArgs& a = f.p;
+  [[maybe_unused]] const PlanArgs& a = f.p;  // EVG_STAMP's
   EVG_STAMP(0);
   const bool done = fits_lds_path(c) && plan_distro_lds<RICH, true>(f.p, f.q, c, smem, s_red);
   if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
