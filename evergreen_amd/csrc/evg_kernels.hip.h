@@ -141,12 +141,19 @@ template <int CTRL, int BANK = 0xF>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, BANK, false);
 }
+// A DPP move whose every enabled lane has a valid source (or whose other lanes are overwritten next): the previous
+// content of the destination is irrelevant, so none is named -- with an `old` operand the compiler first copies it into
+// the destination, one extra VALU move per DPP.
+template <int CTRL, int BANK = 0xF>
+__device__ __forceinline__ uint32_t dpp_perm(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, BANK, false);
+}
 template <int M>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
-  if constexpr (M == 1) return dpp_mov<0xB1>(v, v);        // quad_perm [1,0,3,2]
-  else if constexpr (M == 2) return dpp_mov<0x4E>(v, v);   // quad_perm [2,3,0,1]
-  else if constexpr (M == 4) return dpp_mov<0x114, 0xA>(dpp_mov<0x104, 0x5>(v, v), v);  // row_shl:4 | row_shr:4 by bank
-  else if constexpr (M == 8) return dpp_mov<0x128>(v, v);  // row_ror:8
+  if constexpr (M == 1) return dpp_perm<0xB1>(v);        // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return dpp_perm<0x4E>(v);   // quad_perm [2,3,0,1]
+  else if constexpr (M == 4) return dpp_mov<0x114, 0xA>(dpp_perm<0x104, 0x5>(v), v);  // row_shl:4 | row_shr:4 by bank
+  else if constexpr (M == 8) return dpp_perm<0x128>(v);  // row_ror:8
   else if constexpr (M == 16) {
     const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
     return (__lane_id() & 16) ? r[0] : r[1];
@@ -164,10 +171,10 @@ __device__ __forceinline__ uint64_t lane_xor(uint64_t v) {
 template <class T, class Op>
 __device__ __forceinline__ T wave_reduce(T v, Op op) {
   if constexpr (sizeof(T) == 4) {
-    v = op(v, (T)dpp_mov<0xB1>((uint32_t)v, (uint32_t)v));
-    v = op(v, (T)dpp_mov<0x4E>((uint32_t)v, (uint32_t)v));
-    v = op(v, (T)dpp_mov<0x141>((uint32_t)v, (uint32_t)v));  // row_half_mirror
-    v = op(v, (T)dpp_mov<0x140>((uint32_t)v, (uint32_t)v));  // row_mirror
+    v = op(v, (T)dpp_perm<0xB1>((uint32_t)v));
+    v = op(v, (T)dpp_perm<0x4E>((uint32_t)v));
+    v = op(v, (T)dpp_perm<0x141>((uint32_t)v));  // row_half_mirror
+    v = op(v, (T)dpp_perm<0x140>((uint32_t)v));  // row_mirror
     const T a = (T)__builtin_amdgcn_readlane((int)v, 0), b = (T)__builtin_amdgcn_readlane((int)v, 16),
             c = (T)__builtin_amdgcn_readlane((int)v, 32), d = (T)__builtin_amdgcn_readlane((int)v, 48);
     return op(op(a, b), op(c, d));
@@ -176,10 +183,10 @@ __device__ __forceinline__ T wave_reduce(T v, Op op) {
       const uint64_t u = (uint64_t)w;
       return (T)(((uint64_t)f((uint32_t)(u >> 32)) << 32) | f((uint32_t)u));
     };
-    v = op(v, x(v, [](uint32_t w) { return dpp_mov<0xB1>(w, w); }));
-    v = op(v, x(v, [](uint32_t w) { return dpp_mov<0x4E>(w, w); }));
-    v = op(v, x(v, [](uint32_t w) { return dpp_mov<0x141>(w, w); }));
-    v = op(v, x(v, [](uint32_t w) { return dpp_mov<0x140>(w, w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_perm<0xB1>(w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_perm<0x4E>(w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_perm<0x141>(w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_perm<0x140>(w); }));
     auto rl = [&](int l) {
       const uint64_t u = (uint64_t)v;
       return (T)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l) << 32) |
