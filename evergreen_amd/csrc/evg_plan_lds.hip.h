@@ -181,7 +181,6 @@ template <bool RICH, bool FUSED>
 __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocArgs& q, const DC& c, unsigned char* smem, unsigned* s_red) {
   const evg_task_soa& t = a.in.tasks;
   const int d = c.d, lo = c.lo, n = c.n, S = c.S;
-  const evg_distro_params p = a.in.distros[d];
   const int tid = threadIdx.x, lane = tid & 63;
   const int i0 = tid * kE;
 
@@ -339,6 +338,11 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   EVG_PRIO(5);
   __syncthreads();
 
+  // The distro's planner settings are 22 SGPRs and nothing before this point reads them: fetched here, behind an index
+  // the compiler cannot see through, they stay out of the register file while phases A and B are short of SGPRs.
+  int late0;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(late0));
+  const evg_distro_params p = a.in.distros[d + late0];
   // ---- C: score every unit (planner.go:209-300); units whose distro is nil are dropped (:81) -----------------
   for (int u = tid; u < S; u += kBlock) {
     const uint32_t cw = m.cnt[u];
