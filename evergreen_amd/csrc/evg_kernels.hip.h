@@ -89,6 +89,21 @@ struct PlanArgs {
 #define EVG_STAMP(k) do {} while (0)
 #endif
 
+// Kernel arguments the late phases need, fetched late. The compiler loads the whole argument block at the top of a kernel
+// and keeps it in SGPRs; the planner has ~30 pointers in there and spills SGPRs into VGPR lanes (v_writelane / v_readlane
+// on the VALU it is bound by). EVG_LATE_ARG reads one field of the FIRST kernel argument (a PlanArgs) from the kernarg
+// segment with a scalar load whose offset carries an opaque zero (EVG_OPAQUE_ZERO, defined where the late phase starts),
+// so the load cannot be hoisted above that point -- and, unlike a volatile asm load, the scheduler stays free around it.
+#define EVG_OPAQUE_ZERO(z) \
+  int z;                   \
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z))
+template <class T>
+__device__ __forceinline__ T late_kernarg(int off) {
+  typedef const __attribute__((address_space(4))) char* kptr;
+  return *reinterpret_cast<const __attribute__((address_space(4))) T*>((kptr)__builtin_amdgcn_kernarg_segment_ptr() + off);
+}
+#define EVG_LATE_ARG(T, field, z) late_kernarg<T>((int)offsetof(PlanArgs, field) + (z))
+
 // Two workgroups share a CU and the SQ issues oldest-wave-first, so the workgroup dispatched second gets what the first
 // leaves over and finishes ~30 % later -- and a launch lasts as long as its slowest workgroup. Wave priority that FALLS as
 // a workgroup advances (step k of its phases -> priority 3 - k mod 4) hands the issue slots to whichever of the two is

@@ -340,8 +340,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
 
   // The distro's planner settings are 22 SGPRs and nothing before this point reads them: fetched here, behind an index
   // the compiler cannot see through, they stay out of the register file while phases A and B are short of SGPRs.
-  int late0;
-  asm volatile("s_mov_b32 %0, 0" : "=s"(late0));
+  EVG_OPAQUE_ZERO(late0);
   const evg_distro_params p = a.in.distros[d + late0];
   // ---- C: score every unit (planner.go:209-300); units whose distro is nil are dropped (:81) -----------------
   for (int u = tid; u < S; u += kBlock) {
@@ -446,8 +445,9 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   }
   // the columns of phase G: fetched now, consumed after the sort
   int64_t sched[4], dmt[4];
-  load4(t.scheduled_ts_ns + lo, i0, n, (int64_t)0, sched);
-  load4(t.deps_met_ts_ns + lo, i0, n, (int64_t)0, dmt);
+  EVG_OPAQUE_ZERO(late1);
+  load4(EVG_LATE_ARG(const int64_t*, in.tasks.scheduled_ts_ns, late1) + lo, i0, n, (int64_t)0, sched);
+  load4(EVG_LATE_ARG(const int64_t*, in.tasks.deps_met_ts_ns, late1) + lo, i0, n, (int64_t)0, dmt);
   EVG_STAMP(5);
   EVG_PRIO(10);
   __syncthreads();  // accumulators are dead from here on
@@ -649,12 +649,14 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     int32_t o4[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) o4[e] = i0 + e < n ? lo + (int)fidx[i0 + e] : 0;
-    store4(a.out.order + lo, i0, n, o4);
+    EVG_OPAQUE_ZERO(late2);
+    store4(EVG_LATE_ARG(int32_t*, out.order, late2) + lo, i0, n, o4);
   }
   EVG_STAMP(8);
   EVG_PRIO(16);
 
   // ---- G: GetDistroQueueInfo (scheduler.go:57-178) -----------------------------------------------------------
+  EVG_OPAQUE_ZERO(late3);
   uint64_t* g_dur = (uint64_t*)(smem + Z_G);
   uint64_t* g_dover = g_dur + kG;
   uint32_t* g_cnt = (uint32_t*)(g_dover + kG);
@@ -697,7 +699,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     uint8_t m4[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) m4[e] = met[e] ? 1 : 0;
-    store4(a.out.deps_met + lo, i0, n, m4);
+    store4(EVG_LATE_ARG(uint8_t*, out.deps_met, late3) + lo, i0, n, m4);
   }
   EVG_STAMP(9);
   EVG_PRIO(17);
@@ -744,7 +746,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       if (mt && merge) atomicAdd(&g_mq[g], 1u);
     }
   }
-  store4(a.out.wait_ns + lo, i0, n, wait4);
+  store4(EVG_LATE_ARG(int64_t*, out.wait_ns, late3) + lo, i0, n, wait4);
   s_cnt = wave_sum(s_cnt); s_cover = wave_sum(s_cover); s_wait = wave_sum(s_wait); s_mq = wave_sum(s_mq);
   s_dur = wave_sum(s_dur); s_dover = wave_sum(s_dover);
   n_met = wave_sum(n_met); n_mq = wave_sum(n_mq); n_s3 = wave_sum(n_s3);
@@ -767,17 +769,19 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   __syncthreads();
 
   // rows out: model.TaskGroupInfo; MaxHosts = first task of the group in QUEUE order (scheduler.go:103-106)
+  evg_group_info* out_group_info = EVG_LATE_ARG(evg_group_info*, out.group_info, late3);
+  const int32_t* tg_max_hosts = EVG_LATE_ARG(const int32_t*, in.tasks.task_group_max_hosts, late3);
   uint64_t t_dur = 0, t_dover = 0;
   uint32_t t_cover = 0, t_wait = 0, t_rows = 0;
   for (int k = tid; k < c.ntg + 1; k += kBlock) {
-    evg_group_info* o = &a.out.group_info[k == 0 ? d : c.D + c.tg_lo + (k - 1)];
+    evg_group_info* o = &out_group_info[k == 0 ? d : c.D + c.tg_lo + (k - 1)];
     const uint32_t first = g_first[k];
     const bool present = first != 0xFFFFFFFFu;
     evg_group_info gi;
     gi.expected_duration_ns = (int64_t)g_dur[k];
     gi.duration_over_threshold_ns = (int64_t)g_dover[k];
     gi.count = (int32_t)g_cnt[k];
-    gi.max_hosts = present ? t.task_group_max_hosts[lo + (int)fidx[first]] : 0;
+    gi.max_hosts = present ? tg_max_hosts[lo + (int)fidx[first]] : 0;
     gi.count_duration_over_threshold = (int32_t)g_cover[k];
     gi.count_wait_over_threshold = (int32_t)g_wait[k];
     gi.count_dep_filled_merge_queue_tasks = (int32_t)g_mq[k];
@@ -811,7 +815,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     di.num_queued_large_parser_project_tasks = (int32_t)s_red[3];
     di.secondary_queue = (int32_t)s_red[4];
     di.n_task_group_infos = (int32_t)s_red[8];
-    a.out.distro_info[d] = di;
+    EVG_LATE_ARG(evg_distro_info*, out.distro_info, late3)[d] = di;
   }
   EVG_STAMP(11);
   if (FUSED) {
