@@ -314,6 +314,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     if (c.gv || tgk[e] >= 0) join(t0, ufe | UF_DISTRO);  // SetDistro only via the primary key (:447)
     if (t1 >= 0) join(t1, ufe);
     const int x0 = doff[e], x1 = doff[e + 1];
+    uint64_t recent = ~0ull;
     for (int x = x0; x < x1; x++) {
       // branch-free: an out-of-queue edge reads pslot[0] and ignores it
       const uint32_t raw = m.edge[x];
@@ -325,10 +326,17 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       const uint32_t blk = out ? (raw >> 4) & 1u : (pj >> 14) & 1u;
       const bool sat = ((kDepSatTable >> (req | (st << 2) | (blk << 4))) & 1u) != 0 && !(out && (raw & EVG_DEP_MISSING));
       bool skip = out || sl == t0 || sl == t1;
-      for (int y = x0; y < x; y++) {
+      // already named by an earlier edge of this row? The last four in-queue edges ride in a register (16 bits each,
+      // 0xFFFF = none; a slot is 12 bits); only a row with more than four dependencies re-reads its older records.
+      const uint32_t s16 = (uint32_t)sl;
+      skip |= (uint32_t)(recent & 0xFFFFu) == s16 || (uint32_t)((recent >> 16) & 0xFFFFu) == s16 ||
+              (uint32_t)((recent >> 32) & 0xFFFFu) == s16 || (uint32_t)(recent >> 48) == s16;
+#pragma clang loop vectorize(disable) unroll(disable)
+      for (int y = x0; y < x - 4; y++) {
         const uint32_t e2 = m.edge[y];
         skip |= !(e2 & ED_OUT) && (int)(e2 & ER_SLOT) == sl;
       }
+      recent = (recent << 16) | (out ? 0xFFFFu : s16);
       const uint32_t rec = out ? (ED_OUT | (sat ? ER_SAT : 0u)) : ((sat ? ER_SAT : 0u) | (skip ? ER_SKIP : 0u) | (uint32_t)sl);
       if (!skip) join(sl, sl < n_own ? ufe & ~UF_NONGROUP : ufe);
       m.edge[x] = (uint16_t)rec;

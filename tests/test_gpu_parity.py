@@ -11,6 +11,8 @@ from tests import compare
 from tests import golden_cases as G
 from tests import golden_runner as R
 
+NOW = G.NOW
+
 pytestmark = pytest.mark.gpu
 
 
@@ -268,3 +270,30 @@ def test_planner_fuzz_matches_oracle(native_ctx, oracle):
         ga = native_ctx.allocate(b, got.distro_info, got.group_info)
         wa = oracle.allocate(b, want.distro_info, want.group_info)
         assert np.array_equal(ga.new_hosts, wa.new_hosts) and np.array_equal(ga.free_hosts, wa.free_hosts) and np.array_equal(ga.status, wa.status), it
+
+
+def test_many_dependencies_per_task(native_ctx, oracle):
+    """Rows with up to nine dependencies, several of them in ONE task group (= one unit named repeatedly) and spread so that
+    the repeat is more than four edges back: the membership dedup beyond the four-edge register window."""
+    rng = np.random.default_rng(4242)
+    queues = []
+    for d in range(3):
+        tasks = []
+        for i in range(400):
+            t = S.Task(Id="d%d-t%d" % (d, i), DistroId="distro%d" % d, Version="v%d" % (i // 40), BuildVariant="bv", Project="p",
+                       Requester=[S.RepotrackerVersionRequester, S.PatchVersionRequester][int(rng.integers(0, 2))],
+                       Priority=int(rng.integers(0, 3)), NumDependents=int(rng.integers(0, 5)),
+                       ExpectedDuration=int(rng.integers(1, 50)) * S.MINUTE, ActivatedTime=NOW - int(rng.integers(1, 10**5)) * S.SECOND)
+            if i % 10 < 4:
+                t.TaskGroup, t.TaskGroupOrder, t.TaskGroupMaxHosts = "tg%d" % (i // 10), i % 10 + 1, 1
+            if i >= 60 and i % 3 == 0:
+                g = int(rng.integers(0, i // 10 - 1))                       # a whole earlier task group: four edges into one unit ...
+                deps = ["d%d-t%d" % (d, 10 * g + k) for k in range(4)]
+                deps[2:2] = ["d%d-t%d" % (d, int(rng.integers(0, i))) for _ in range(int(rng.integers(1, 5)))]  # ... split by other edges
+                deps.append(deps[0])                                         # and the very first dependency again at the end
+                t.DependsOn = [S.Dependency(x, S.TaskSucceeded) for x in deps]
+            tasks.append(t)
+        queues.append((S.Distro(Id="distro%d" % d, PlannerSettings=S.PlannerSettings(GroupVersions=(d == 2))), tasks))
+    b = S.pack_queues(queues, NOW).batch
+    assert int(np.diff(b.dep_off).max()) >= 8
+    _full_compare(native_ctx, oracle, b, "many dependencies per task")
