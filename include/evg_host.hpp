@@ -177,6 +177,12 @@ struct Backend {
   // evg_rebuild_dispatchers: (D, item_off, dep_off, dep_idx, group_key, tg_off, group_index, out)
   std::function<int(int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const evg_dispatch_order*)>
       rebuild;
+  // evg_filter_runnable: (in, dispatchable, deps_met, keep, runnable_row, runnable_count)
+  std::function<int(const evg_plan_input*, const uint8_t*, uint8_t*, uint8_t*, int32_t*, int32_t*)> filter;
+  // evg_allocator_report: (D, tg_off, distro_info, group_info, hosts_spawned, free_hosts, params, report)
+  std::function<int(int32_t, const int32_t*, const evg_distro_info*, const evg_group_info*, const int32_t*, const int32_t*, const evg_report_params*,
+                    evg_alloc_report*)>
+      report;
   std::function<std::string()> last_error;
   std::shared_ptr<void> keep;  // whatever must outlive the calls (library handle, context)
 };
@@ -193,7 +199,10 @@ inline Backend HipBackend(const std::string& lib_path, int device = 0) {
   auto alloc = reinterpret_cast<int (*)(evg_ctx*, const evg_alloc_input*, const evg_alloc_output*)>(dlsym(h, "evg_allocate_hosts"));
   auto rebuild = reinterpret_cast<int (*)(evg_ctx*, int32_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                                           const evg_dispatch_order*)>(dlsym(h, "evg_rebuild_dispatchers"));
-  if (!create || !destroy || !lasterr || !plan || !alloc || !rebuild) throw std::runtime_error("libevg_sched.so lacks an entry point of evg_sched.h");
+  auto filter = reinterpret_cast<int (*)(evg_ctx*, const evg_plan_input*, const uint8_t*, uint8_t*, uint8_t*, int32_t*, int32_t*)>(dlsym(h, "evg_filter_runnable"));
+  auto report = reinterpret_cast<int (*)(evg_ctx*, int32_t, const int32_t*, const evg_distro_info*, const evg_group_info*, const int32_t*, const int32_t*,
+                                         const evg_report_params*, evg_alloc_report*)>(dlsym(h, "evg_allocator_report"));
+  if (!create || !destroy || !lasterr || !plan || !alloc || !rebuild || !filter || !report) throw std::runtime_error("libevg_sched.so lacks an entry point of evg_sched.h");
   evg_ctx* ctx = create(device);
   if (!ctx) throw std::runtime_error(std::string("evg_create failed: ") + lasterr(nullptr));
   std::shared_ptr<void> keep(ctx, [destroy](void* p) { destroy(static_cast<evg_ctx*>(p)); });
@@ -203,6 +212,11 @@ inline Backend HipBackend(const std::string& lib_path, int device = 0) {
   b.allocate = [ctx, alloc](const evg_alloc_input* in, const evg_alloc_output* out) { return alloc(ctx, in, out); };
   b.rebuild = [ctx, rebuild](int32_t D, const int32_t* io, const int32_t* dof, const int32_t* dix, const int32_t* gk, const int32_t* tgo, const int32_t* gi,
                               const evg_dispatch_order* o) { return rebuild(ctx, D, io, dof, dix, gk, tgo, gi, o); };
+  b.filter = [ctx, filter](const evg_plan_input* in, const uint8_t* disp, uint8_t* met, uint8_t* keep, int32_t* rows, int32_t* cnt) {
+    return filter(ctx, in, disp, met, keep, rows, cnt);
+  };
+  b.report = [ctx, report](int32_t D, const int32_t* tgo, const evg_distro_info* di, const evg_group_info* gi, const int32_t* sp, const int32_t* fr,
+                           const evg_report_params* pa, evg_alloc_report* rep) { return report(ctx, D, tgo, di, gi, sp, fr, pa, rep); };
   b.last_error = [ctx, lasterr]() { return std::string(lasterr(ctx)); };
   return b;
 }
@@ -546,6 +560,70 @@ inline std::vector<DAGDispatcherState> RebuildDispatchers(const Backend& be, con
     }
   }
   return res;
+}
+
+// ---- the task finder's filter -------------------------------------------------------------------
+// LegacyFindRunnableTasks (scheduler/task_finder.go:40-116) after its DB queries: `undispatched` is what
+// task.FindHostSchedulable returned for the distro, canDispatch folds the project-ref checks (:59-84), `lookup` stands
+// for getDependencyTaskCache's fetch of the dependencies outside the list (:289-320). Kept tasks, in input order.
+inline std::vector<Task> FindRunnableTasks(const Backend& be, const Distro& d, const std::vector<Task>& undispatched,
+                                           const std::function<bool(const Task&)>& canDispatch, const DepLookup& lookup = nullptr) {
+  const PackedQueues p = pack_queues({{&d, &undispatched}}, 0, lookup);
+  const size_t n = undispatched.size();
+  std::vector<uint8_t> disp(n + 1), met(n + 1), keep(n + 1);
+  std::vector<int32_t> rows(n + 1), cnt(2);
+  for (size_t i = 0; i < n; i++) disp[i] = canDispatch(undispatched[i]) ? 1 : 0;
+  const evg_plan_input in = p.input();
+  const int rc = be.filter(&in, disp.data(), met.data(), keep.data(), rows.data(), cnt.data());
+  if (rc != EVG_OK) throw PlanError("evg_filter_runnable failed (" + std::to_string(rc) + "): " + (be.last_error ? be.last_error() : ""));
+  std::vector<Task> out;
+  for (int k = 0; k < cnt[0]; k++) out.push_back(undispatched[(size_t)rows[(size_t)k]]);
+  return out;
+}
+
+// ---- the host-allocator job's report -------------------------------------------------------------
+struct AllocatorReport {  // what units/host_allocator.go:250-334,393-424 computes after the allocator returned
+  Duration timeToEmpty = 0, timeToEmptyNoSpawns = 0;
+  float hostQueueRatio = 0, noSpawnsRatio = 0;
+  int hostsAvail = 0;
+  bool drawdown = false;
+  int NewCapTarget = 0, killableHosts = 0;
+};
+inline AllocatorReport HostAllocatorReport(const Backend& be, const DistroQueueInfo& q, int hostsSpawned, int nHostsFree, int numUpHosts,
+                                           int minimumHosts, bool drawdownAllowed) {
+  std::vector<evg_group_info> gi(1);
+  std::unordered_map<std::string, size_t> row_of;
+  for (const auto& g : q.TaskGroupInfos) {  // a later duplicate of a name wins, like the reference's name -> info map
+    size_t r = 0;
+    if (!g.Name.empty()) {
+      auto it = row_of.find(g.Name);
+      if (it == row_of.end()) { it = row_of.emplace(g.Name, gi.size()).first; gi.emplace_back(); }
+      r = it->second;
+    }
+    evg_group_info& x = gi[r];
+    x = evg_group_info{};
+    x.present = 1; x.count = g.Count; x.max_hosts = g.MaxHosts; x.expected_duration_ns = g.ExpectedDuration;
+    x.duration_over_threshold_ns = g.DurationOverThreshold; x.count_duration_over_threshold = g.CountDurationOverThreshold;
+    x.count_wait_over_threshold = g.CountWaitOverThreshold; x.count_dep_filled_merge_queue_tasks = g.CountDepFilledMergeQueueTasks;
+    x.count_free = g.CountFree; x.count_required = g.CountRequired;
+  }
+  evg_distro_info di{};
+  di.expected_duration_ns = q.ExpectedDuration; di.max_duration_threshold_ns = q.MaxDurationThreshold;
+  di.duration_over_threshold_ns = q.DurationOverThreshold; di.length = q.Length; di.length_with_dependencies_met = q.LengthWithDependenciesMet;
+  di.count_dep_filled_merge_queue_tasks = q.CountDepFilledMergeQueueTasks; di.count_duration_over_threshold = q.CountDurationOverThreshold;
+  di.count_wait_over_threshold = q.CountWaitOverThreshold; di.num_queued_large_parser_project_tasks = q.NumQueuedLargeParserProjectTasks;
+  di.secondary_queue = q.SecondaryQueue ? 1 : 0; di.n_task_group_infos = (int32_t)q.TaskGroupInfos.size();
+  const int32_t tg_off[2] = {0, (int32_t)gi.size() - 1}, spawned = hostsSpawned, free_hosts = nHostsFree;
+  evg_report_params pa{};
+  pa.n_up_hosts = numUpHosts; pa.minimum_hosts = minimumHosts; pa.drawdown_allowed = drawdownAllowed ? 1 : 0;
+  evg_alloc_report rep{};
+  const int rc = be.report(1, tg_off, &di, gi.data(), &spawned, &free_hosts, &pa, &rep);
+  if (rc != EVG_OK) throw PlanError("evg_allocator_report failed (" + std::to_string(rc) + "): " + (be.last_error ? be.last_error() : ""));
+  AllocatorReport r;
+  r.timeToEmpty = rep.time_to_empty_ns; r.timeToEmptyNoSpawns = rep.time_to_empty_no_spawns_ns; r.hostQueueRatio = rep.host_queue_ratio;
+  r.noSpawnsRatio = rep.no_spawns_ratio; r.hostsAvail = rep.hosts_avail; r.drawdown = rep.drawdown != 0; r.NewCapTarget = rep.new_cap_target;
+  r.killableHosts = rep.killable_hosts;
+  return r;
 }
 
 struct AllocatorResult {

@@ -7,6 +7,7 @@
 // The cases are generated from tests/golden_cases.py (transcribed from /root/reference/scheduler/*_test.go) into
 // golden_cases.inc; the check_* functions below mirror what the Go tests assert.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <set>
@@ -34,10 +35,15 @@ static Backend OracleBackend(const std::string& path) {
   auto plan = reinterpret_cast<int (*)(const evg_plan_input*, const evg_plan_output*)>(dlsym(h, "evg_oracle_plan_distros"));
   auto alloc = reinterpret_cast<int (*)(const evg_alloc_input*, const evg_alloc_output*)>(dlsym(h, "evg_oracle_allocate_hosts"));
   auto disp = reinterpret_cast<int (*)(const evg_plan_input*, const int32_t*, const int32_t*, const evg_dispatch_order*)>(dlsym(h, "evg_oracle_dispatch_order"));
-  if (!plan || !alloc || !disp) throw std::runtime_error("oracle entry points missing");
+  auto filt = reinterpret_cast<int (*)(const evg_plan_input*, const uint8_t*, uint8_t*, uint8_t*, int32_t*, int32_t*)>(dlsym(h, "evg_oracle_filter_runnable"));
+  auto rept = reinterpret_cast<int (*)(int32_t, const int32_t*, const evg_distro_info*, const evg_group_info*, const int32_t*, const int32_t*,
+                                       const evg_report_params*, evg_alloc_report*)>(dlsym(h, "evg_oracle_allocator_report"));
+  if (!plan || !alloc || !disp || !filt || !rept) throw std::runtime_error("oracle entry points missing");
   Backend b;
   b.plan = plan;
   b.allocate = alloc;
+  b.filter = filt;
+  b.report = rept;
   b.rebuild = [disp](int32_t D, const int32_t* item_off, const int32_t* dep_off, const int32_t* dep_idx, const int32_t* group_key, const int32_t* tg_off,
                      const int32_t* group_index, const evg_dispatch_order* out) {
     evg_plan_input in{};  // the oracle reads the items through the planner's batch layout; the items are the rows
@@ -75,6 +81,8 @@ static void check_cap(const char* name, const std::vector<Task>& tasks, int limi
 static void check_dispatcher(const Backend& be, const char* name, const std::vector<TaskQueueItem>& items, std::vector<std::string> want_sorted,
                              int want_cycles, std::map<std::string, int> want_groups);
 static void check_group_order(const Backend& be, const char* name, const std::vector<TaskQueueItem>& items, std::vector<std::string> want);
+static void check_report(const Backend& be, const char* name, const DistroQueueInfo& q, int spawned, int nfree, int up, int minimum, bool allowed,
+                         int64_t tte, int64_t tte_ns, float ratio, float ratio_ns, int avail, bool drawdown, int target, int killable);
 
 #include "golden_cases.inc"
 
@@ -229,6 +237,45 @@ static void run_queue_item_behaviour(const Backend& be) {
   EXPECT(st[0].sorted.size() == 3 && pa < pc, "dispatcher over the built queue: dependency first");
 }
 
+static void check_report(const Backend& be, const char* name, const DistroQueueInfo& q, int spawned, int nfree, int up, int minimum, bool allowed,
+                         int64_t tte, int64_t tte_ns, float ratio, float ratio_ns, int avail, bool drawdown, int target, int killable) {
+  const AllocatorReport r = HostAllocatorReport(be, q, spawned, nfree, up, minimum, allowed);
+  auto same = [](float a, float b) { return a == b || (a != a && b != b); };  // NaN == NaN here (0/0 when the threshold is 0)
+  EXPECT(r.timeToEmpty == tte && r.timeToEmptyNoSpawns == tte_ns, "%s: time to empty %lld / %lld, want %lld / %lld", name, (long long)r.timeToEmpty,
+         (long long)r.timeToEmptyNoSpawns, (long long)tte, (long long)tte_ns);
+  EXPECT(same(r.hostQueueRatio, ratio) && same(r.noSpawnsRatio, ratio_ns), "%s: ratios %g / %g, want %g / %g", name, r.hostQueueRatio, r.noSpawnsRatio,
+         ratio, ratio_ns);
+  EXPECT(r.hostsAvail == avail, "%s: hostsAvail %d, want %d", name, r.hostsAvail, avail);
+  EXPECT(r.drawdown == drawdown && r.NewCapTarget == target && r.killableHosts == killable, "%s: drawdown %d target %d killable %d, want %d %d %d", name,
+         (int)r.drawdown, r.NewCapTarget, r.killableHosts, (int)drawdown, target, killable);
+}
+
+// TestTasksWithUnsatisfiedDependenciesNeverReturned  scheduler/task_finder_test.go:159-191 (SetupTest :70-97)
+static void run_finder_cases(const Backend& be) {
+  std::vector<Task> ts(5);
+  for (int i = 0; i < 5; i++) { ts[(size_t)i].Id = "t" + std::to_string(i); ts[(size_t)i].Project = "exists"; ts[(size_t)i].Status = TaskUndispatched; }
+  auto dep = [](const char* id, const std::string& status) { Dependency d; d.TaskId = id; d.Status = status; return d; };
+  ts[0].DependsOn = {dep("td1", TaskFailed)};                               // matching dependency: runnable
+  ts[1].DependsOn = {dep("td1", TaskSucceeded)};                            // not matching: not runnable
+  ts[2].DependsOn = {dep("td2", AllStatuses), dep("td1", AllStatuses)};     // td2 is blocked and the status is "*": runnable
+  ts[3].DependsOn = {dep("td1", AllStatuses)};                              // "*" matches any finished status: runnable
+  const DepLookup lookup = [](const std::string& id) -> std::optional<std::pair<std::string, bool>> {
+    if (id == "td1") return std::make_pair(TaskFailed, false);
+    if (id == "td2") return std::make_pair(TaskUndispatched, true);          // undispatched, with an unattainable dependency: Blocked()
+    return std::nullopt;
+  };
+  const auto got = FindRunnableTasks(be, Distro{}, ts, [](const Task&) { return true; }, lookup);
+  std::string ids;
+  for (const auto& t : got) ids += t.Id + " ";
+  EXPECT(ids == "t0 t2 t3 t4 ", "FindRunnableTasks: got '%s'", ids.c_str());
+  // a project that may not dispatch (ProjectCanDispatchTask false, task_finder.go:59-84) drops its tasks whatever their dependencies
+  const auto got2 = FindRunnableTasks(be, Distro{}, ts, [](const Task& t) { return t.Id != "t4"; }, lookup);
+  EXPECT(got2.size() == 3 && got2.back().Id == "t3", "FindRunnableTasks: dispatching disabled for t4");
+  // revised-with-dependencies dispatcher: the dependency check is the dispatcher's, every dispatchable task is kept (:56,85)
+  Distro dd; dd.DispatcherSettings.Version = DispatcherVersionRevisedWithDependencies;
+  EXPECT(FindRunnableTasks(be, dd, ts, [](const Task&) { return true; }, lookup).size() == 5, "FindRunnableTasks: revised-with-dependencies");
+}
+
 static void run_planner_behaviour(const Backend& be) {
   // planner_test.go:406-432 TaskPlan: NoChange / ChangeOrder
   std::vector<Task> ts(2);
@@ -263,6 +310,8 @@ int main(int argc, char** argv) {
     run_planner_behaviour(be);
     run_dispatcher_cases(be);
     run_queue_item_behaviour(be);
+    run_finder_cases(be);
+    run_report_cases(be);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 1;

@@ -111,3 +111,34 @@ def test_hip_filter_host_pointer_form(native_ctx, oracle):
         for d in range(b.n_distros):
             lo = int(b.task_off[d])
             assert np.array_equal(rows[lo:lo + int(want_cnt[d])], want_rows[lo:lo + int(want_cnt[d])]), d
+
+
+def _reference_unsatisfied_dependencies_case():
+    """TestTasksWithUnsatisfiedDependenciesNeverReturned (scheduler/task_finder_test.go:159-191, SetupTest :70-97): td1 has
+    FAILED; td2 is undispatched and blocked (an unattainable dependency of its own). t0 wants td1 failed: runnable. t1 wants
+    td1 succeeded: not runnable. t2 wants "*" of td2 (blocked counts) and "*" of td1: runnable. t3 wants "*" of td1:
+    runnable. t4 has no dependencies. (t5, priority -1, never leaves the DB query.) Expected: t0, t2, t3, t4."""
+    tasks = [S.Task(Id="t%d" % i, DistroId="d", Project="exists", Status=S.TaskUndispatched) for i in range(5)]
+    tasks[0].DependsOn = [S.Dependency("td1", S.TaskFailed)]
+    tasks[1].DependsOn = [S.Dependency("td1", S.TaskSucceeded)]
+    tasks[2].DependsOn = [S.Dependency("td2", S.AllStatuses), S.Dependency("td1", S.AllStatuses)]
+    tasks[3].DependsOn = [S.Dependency("td1", S.AllStatuses)]
+    outside = {"td1": (S.TaskFailed, False), "td2": (S.TaskUndispatched, True)}
+    return S.Distro(Id="d"), tasks, outside, ["t0", "t2", "t3", "t4"]
+
+
+def test_reference_unsatisfied_dependencies_vector(oracle):
+    dist, tasks, outside, want = _reference_unsatisfied_dependencies_case()
+    assert [t.Id for t in S.FindRunnableTasks(dist, tasks, lambda t: True, outside.get)] == want
+    b = S.pack_queues([(dist, tasks)], NOW, outside.get).batch
+    met, keep, rows, cnt = oracle.filter_runnable(b, np.ones(b.n_tasks, np.uint8))
+    assert [tasks[int(r)].Id for r in rows[:int(cnt[0])]] == want
+    assert met.tolist() == [1, 0, 1, 1, 1]
+
+
+@pytest.mark.gpu
+def test_hip_reference_unsatisfied_dependencies_vector(native_ctx):
+    dist, tasks, outside, want = _reference_unsatisfied_dependencies_case()
+    b = S.pack_queues([(dist, tasks)], NOW, outside.get).batch
+    met, keep, rows, cnt = native_ctx.filter_runnable(b, np.ones(b.n_tasks, np.uint8))
+    assert [tasks[int(r)].Id for r in rows[:int(cnt[0])]] == want and met.tolist() == [1, 0, 1, 1, 1]
