@@ -182,6 +182,36 @@ template <int M>
 __device__ __forceinline__ uint64_t lane_xor(uint64_t v) {
   return ((uint64_t)lane_xor<M>((uint32_t)(v >> 32)) << 32) | lane_xor<M>((uint32_t)v);
 }
+// The reduction over each 16-lane ROW only (four DPP butterflies, every lane of the row ends up with the row's result).
+// Where the result goes into an LDS accumulator anyway, the four row leaders (lanes 0, 16, 32, 48) issue the atomic
+// themselves: that saves wave_reduce's four v_readlane and the scalar combine per value.
+template <class T, class Op>
+__device__ __forceinline__ T row_reduce(T v, Op op) {
+  if constexpr (sizeof(T) == 4) {
+    v = op(v, (T)dpp_perm<0xB1>((uint32_t)v));
+    v = op(v, (T)dpp_perm<0x4E>((uint32_t)v));
+    v = op(v, (T)dpp_perm<0x141>((uint32_t)v));
+    v = op(v, (T)dpp_perm<0x140>((uint32_t)v));
+    return v;
+  } else {
+    auto x = [](T w, auto f) {
+      const uint64_t u = (uint64_t)w;
+      return (T)(((uint64_t)f((uint32_t)(u >> 32)) << 32) | f((uint32_t)u));
+    };
+    v = op(v, x(v, [](uint32_t w) { return dpp_perm<0xB1>(w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_perm<0x4E>(w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_perm<0x141>(w); }));
+    v = op(v, x(v, [](uint32_t w) { return dpp_perm<0x140>(w); }));
+    return v;
+  }
+}
+__device__ __forceinline__ uint32_t row_sum(uint32_t v) { return row_reduce(v, [](uint32_t a, uint32_t b) { return a + b; }); }
+__device__ __forceinline__ uint64_t row_sum(uint64_t v) { return row_reduce(v, [](uint64_t a, uint64_t b) { return a + b; }); }
+__device__ __forceinline__ uint32_t row_min(uint32_t v) { return row_reduce(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
+__device__ __forceinline__ uint32_t row_max(uint32_t v) { return row_reduce(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
+__device__ __forceinline__ uint64_t row_min(uint64_t v) { return row_reduce(v, [](uint64_t a, uint64_t b) { return a < b ? a : b; }); }
+__device__ __forceinline__ uint64_t row_max(uint64_t v) { return row_reduce(v, [](uint64_t a, uint64_t b) { return a > b ? a : b; }); }
+
 // butterflies inside a 16-lane row (xor 1, xor 2, mirror in 8, mirror in 16), then the four row results
 template <class T, class Op>
 __device__ __forceinline__ T wave_reduce(T v, Op op) {

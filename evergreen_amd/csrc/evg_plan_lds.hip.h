@@ -442,10 +442,10 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     r_nmin = un < r_nmin ? un : r_nmin; r_nmax = un > r_nmax ? un : r_nmax;
     r_pmin = up < r_pmin ? up : r_pmin; r_pmax = up > r_pmax ? up : r_pmax;
   }
-  r_vmin = wave_min(r_vmin); r_vmax = wave_max(r_vmax); r_dmin = wave_min(r_dmin); r_dmax = wave_max(r_dmax);
-  r_tmin = wave_min(r_tmin); r_tmax = wave_max(r_tmax); r_nmin = wave_min(r_nmin); r_nmax = wave_max(r_nmax);
-  r_pmin = wave_min(r_pmin); r_pmax = wave_max(r_pmax);
-  if (lane == 0) {
+  r_vmin = row_min(r_vmin); r_vmax = row_max(r_vmax); r_dmin = row_min(r_dmin); r_dmax = row_max(r_dmax);
+  r_tmin = row_min(r_tmin); r_tmax = row_max(r_tmax); r_nmin = row_min(r_nmin); r_nmax = row_max(r_nmax);
+  r_pmin = row_min(r_pmin); r_pmax = row_max(r_pmax);
+  if ((lane & 15) == 0) {  // the four row leaders
     atomicMin(&s_rng[0], (unsigned long long)r_vmin); atomicMax(&s_rng[1], (unsigned long long)r_vmax);
     atomicMin(&s_rng[2], (unsigned long long)r_dmin); atomicMax(&s_rng[3], (unsigned long long)r_dmax);
     atomicMin(&s_r32[0], r_tmin); atomicMax(&s_r32[1], r_tmax); atomicMin(&s_r32[2], r_nmin); atomicMax(&s_r32[3], r_nmax);
@@ -755,11 +755,11 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     }
   }
   store4(EVG_LATE_ARG(int64_t*, out.wait_ns, late3) + lo, i0, n, wait4);
-  s_cnt = wave_sum(s_cnt); s_cover = wave_sum(s_cover); s_wait = wave_sum(s_wait); s_mq = wave_sum(s_mq);
-  s_dur = wave_sum(s_dur); s_dover = wave_sum(s_dover);
-  n_met = wave_sum(n_met); n_mq = wave_sum(n_mq); n_s3 = wave_sum(n_s3);
-  s_first = wave_min(s_first);
-  if (lane == 0) {
+  s_cnt = row_sum(s_cnt); s_cover = row_sum(s_cover); s_wait = row_sum(s_wait); s_mq = row_sum(s_mq);
+  s_dur = row_sum(s_dur); s_dover = row_sum(s_dover);
+  n_met = row_sum(n_met); n_mq = row_sum(n_mq); n_s3 = row_sum(n_s3);
+  s_first = row_min(s_first);
+  if ((lane & 15) == 0) {  // the four row leaders
     if (s_first != 0xFFFFFFFFu) atomicMin(&g_first[0], s_first);
     if (s_cnt) atomicAdd(&g_cnt[0], s_cnt);
     if (s_dur) atomicAdd((unsigned long long*)&g_dur[0], (unsigned long long)s_dur);
@@ -800,9 +800,9 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     t_dur += g_dur[k]; t_dover += g_dover[k]; t_cover += g_cover[k]; t_wait += g_wait[k];
     t_rows += present ? 1u : 0u;
   }
-  t_dur = wave_sum(t_dur); t_dover = wave_sum(t_dover);
-  t_cover = wave_sum(t_cover); t_wait = wave_sum(t_wait); t_rows = wave_sum(t_rows);
-  if (lane == 0) {
+  t_dur = row_sum(t_dur); t_dover = row_sum(t_dover);
+  t_cover = row_sum(t_cover); t_wait = row_sum(t_wait); t_rows = row_sum(t_rows);
+  if ((lane & 15) == 0) {
     if (t_cover) atomicAdd(&s_red[5], t_cover);
     if (t_wait) atomicAdd(&s_red[6], t_wait);
     if (t_rows) atomicAdd(&s_red[8], t_rows);
