@@ -41,7 +41,8 @@ __device__ __forceinline__ void shuffle_stage(K (&k)[4], bool take_min) {
 
 template <class K>
 __device__ __forceinline__ void cmpx(K& a, K& b, bool asc) {  // a at the lower position
-  const bool sw = asc ? key_lt(b, a) : key_lt(a, b);
+  // one compare: for a != b, a < b is !(b < a); equal keys are the same bits, so swapping them is harmless
+  const bool sw = key_lt(b, a) == asc;
   if (sw) { const K t = a; a = b; b = t; }
 }
 
