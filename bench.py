@@ -238,7 +238,10 @@ def main():
                           "(%.2f s per pass), and best of 3 passes on one thread (%.2f s per pass): C++ oracle, a port of the Go "
                           "algorithm (the Go reference cannot be built here: no Go toolchain)" % (batch.n_tasks, batch.n_distros, nt, tn, t1)}
         if world == 1 and args.in_flight > 1:
-            line["pipelined"] = pipelined_rate(batch, ctx, pool, dev, args.in_flight, args.steps, native, resident, torch)
+            try:
+                line["pipelined"] = pipelined_rate(batch, ctx, pool, dev, args.in_flight, args.steps, native, resident, torch)
+            except Exception as e:  # the extra measurement must never cost the headline line
+                line["pipelined"] = {"in_flight": args.in_flight, "error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
