@@ -229,3 +229,29 @@ def test_hip_rebuild_large_queues_with_cycles(native_ctx, oracle):
     got = native_ctx.dispatch_order(b)
     _assert_same(got, want, b.task_off, b.n_distros, int(b.tg_off[-1]))
     assert int(want.n_cycles.sum()) > 0
+
+
+def test_oracle_matches_host_object_restatement_property(oracle):
+    """Hypothesis: arbitrary small dependency graphs (self-edges, multi-edges, cycles, dangling ids, groups with equal
+    GroupIndex) -- the oracle's rebuild equals the host-object restatement's."""
+    from hypothesis import given, settings, strategies as st
+
+    @st.composite
+    def queue(draw):
+        n = draw(st.integers(0, 14))
+        items = []
+        for i in range(n):
+            it = S.TaskQueueItem(Id="t%d" % i, BuildVariant="bv", Version="v", Project="p")
+            if draw(st.booleans()) and draw(st.booleans()):
+                it.Group, it.GroupIndex = "g%d" % draw(st.integers(0, 2)), draw(st.integers(0, 2))
+            it.Dependencies = ["t%d" % j for j in draw(st.lists(st.integers(0, n + 1), max_size=4))]   # n, n+1: not in the queue
+            items.append(it)
+        return items
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.lists(queue(), min_size=1, max_size=3))
+    def run(queues):
+        packed, res = _oracle_rebuild(oracle, queues)
+        _check_against_object(packed, res, queues)
+
+    run()
