@@ -1,21 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- scheduled tasks/sec of the per-distro scheduling hot path on MI355X.
 
-One "step" = one full pass of the hot path over one resident pool: plan all D distros (units, scores, rank
-sort, dedup), GetDistroQueueInfo, and UtilizationBasedHostAllocator -- the BASELINE.json metric
-"scheduled tasks/sec at 1M tasks x 512 distros". Inputs are resident in HBM when the timed region starts.
+One "step" = one full tick of the hot path over ONE pool: plan all D distros (units, scores, rank sort, dedup),
+GetDistroQueueInfo and UtilizationBasedHostAllocator -- the BASELINE.json metric "scheduled tasks/sec at 1M tasks x 512
+distros". Inputs are resident in HBM when the timed region starts (rank 0's HBM for N > 1).
 
   python bench.py --gpus 1 --steps 50 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: distros are independent (one amboy job per distro in the reference), so every rank plans its OWN
-pool of the same shape with no data-path collective ("scaling": "weak"); value = all ranks' tasks / max time.
-`value` is the one-batch-at-a-time rate (each step waits for nothing but the stream order), which is what the `roofline`
-block describes. At N=1 the line also carries `pipelined`: the sustained rate with --in-flight (3) independent pools
-ticking on their own streams -- batches in flight fill each other's load / compute phases and the launch gaps.
-The CPU baseline (rank 0, N=1 only) is the C++ oracle -- a port of the Go algorithm, NOT the Go binary, which
-cannot be built here -- timed on this box's host cores.
+N = 1: BASELINE config 3 (1M tasks x 512 distros, one GPU). N > 1: BASELINE config 4 = the SAME 1M x 512 pool sharded over
+the N ranks (evergreen_amd/multi.py): the timed tick is ONE RCCL broadcast of the packed pool buffer from rank 0, each
+rank's plan + host allocation of its contiguous distro range in place, and ONE grouped gather of the result slices back
+to rank 0 ("scaling": "strong" -- total work is fixed). The line carries the kernel-only rate (no collectives) next to
+it, the phases under the reference's names (scheduler/wrapper.go:121-123 "planning-distro", units/host_allocator.go:200
+"host-allocation"), and at N = 1: the roofline block of the dominant kernel, the CPU baseline (the C++ oracle, a port of
+the Go algorithm -- the Go reference cannot be built here), the PCIe-inclusive host-pointer rate (`end_to_end`), the
+skewed config-3 variant (`skewed`), BASELINE config 5's per-GPU share (`config5_share`) and the rate with several
+batches in flight (`pipelined`). `--weak` keeps round 1's mode (an independent pool per rank, no collective).
 """
 import argparse
 import json
@@ -29,65 +31,83 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+METRIC = "scheduled tasks/sec at 1M tasks x 512 distros; queue-order match vs ref"
 
 
-def algorithmic_bytes(batch, n_units_total):
-    """SURVEY.md 8(d) accounting for the fused plan + queue-info kernel, per launch.
+def algorithmic_bytes(batch, n_units_total, d0=0, d1=None):
+    """SURVEY.md 8(d) accounting for the fused plan + queue-info kernel, per launch, distros [d0, d1).
     planner: 33 B/task of columns + 4 B per unit membership (lower bound m=1) + 4 B queue slot, 8 B per unit;
     queue info: 29 B/task + 5 B per in-queue dependency edge; the 13 B/task both halves read (expected
     duration, task-group id, flags) are counted once."""
-    import numpy as np
-    n = batch.n_tasks
-    e_in = int((batch.edges["dep_idx"] >= 0).sum())
+    d1 = batch.n_distros if d1 is None else d1
+    r0, r1 = int(batch.task_off[d0]), int(batch.task_off[d1])
+    e0, e1 = int(batch.dep_off[r0]), int(batch.dep_off[r1])
+    n = r1 - r0
+    e_in = int((batch.edges["dep_idx"][e0:e1] >= 0).sum())
     return n * (33 + 4 + 4 + 29 - 13) + 8 * int(n_units_total) + 5 * e_in, e_in
 
 
-def cpu_baseline(batch, want_threads):
-    """Times the oracle (oracle/libevg_oracle.so) on the SAME pool: one distro range per worker thread (ctypes
-    drops the GIL), mirroring "one amboy job per distro" on the host cores; plus a single-thread pass."""
-    import numpy as np
+def oracle_threads(batch, want_threads, reps=5):
+    """The oracle over the whole pool with one distro range per worker thread (ctypes drops the GIL): "one amboy job per
+    distro" on the host cores. Returns (PlanResult, AllocResult, best seconds, threads)."""
+    import ctypes as C
     from evergreen_amd import abi
     from tests import oracle_lib
-    o = oracle_lib.OracleBackend()
-    lib = oracle_lib.lib()
-    import ctypes as C
-    res = abi.PlanResult.alloc_host(batch, breakdown=False, n_units=True)
-    inp, out = abi.make_plan_input(batch), res.c_output()
+    o, lib = oracle_lib.OracleBackend(), oracle_lib.lib()
     D = batch.n_distros
-    # single thread: plan + allocate over the whole pool, best of 3
-    t1 = float("inf")
-    for _ in range(3):
-        t0 = time.perf_counter()
-        lib.evg_oracle_plan_distros(C.byref(inp), C.byref(out))
-        alloc = o.allocate(batch, res.distro_info, res.group_info) if batch.alloc_params is not None else None
-        t1 = min(t1, time.perf_counter() - t0)
-    # all cores, best of 5
     nt = max(1, min(want_threads, D))
     bounds = [D * i // nt for i in range(nt + 1)]
-    res2 = abi.PlanResult.alloc_host(batch, breakdown=False, n_units=True)
-    out2 = res2.c_output()
+    inp = abi.make_plan_input(batch)
+    res = abi.PlanResult.alloc_host(batch, breakdown=False, n_units=True)
+    out = res.c_output()
 
     def work(i):
-        lib.evg_oracle_plan_distro_range(C.byref(inp), C.byref(out2), bounds[i], bounds[i + 1])
-    tn = float("inf")
-    for _ in range(5):
+        lib.evg_oracle_plan_distro_range(C.byref(inp), C.byref(out), bounds[i], bounds[i + 1])
+    best, alloc = float("inf"), None
+    for _ in range(reps):
         t0 = time.perf_counter()
         th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
         [t.start() for t in th]
         [t.join() for t in th]
         if batch.alloc_params is not None:
-            o.allocate(batch, res2.distro_info, res2.group_info)
-        tn = min(tn, time.perf_counter() - t0)
-    assert np.array_equal(res.order, res2.order)
+            alloc = o.allocate(batch, res.distro_info, res.group_info)
+        best = min(best, time.perf_counter() - t0)
+    return res, alloc, best, nt
+
+
+def cpu_baseline(batch, want_threads):
+    """Times the oracle (oracle/libevg_oracle.so) on the SAME pool: all host cores, plus a single-thread pass."""
+    import ctypes as C
+    from evergreen_amd import abi
+    from tests import oracle_lib
+    o, lib = oracle_lib.OracleBackend(), oracle_lib.lib()
+    res1 = abi.PlanResult.alloc_host(batch, breakdown=False, n_units=True)
+    inp, out = abi.make_plan_input(batch), res1.c_output()
+    t1 = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        lib.evg_oracle_plan_distros(C.byref(inp), C.byref(out))
+        if batch.alloc_params is not None:
+            o.allocate(batch, res1.distro_info, res1.group_info)
+        t1 = min(t1, time.perf_counter() - t0)
+    res, alloc, tn, nt = oracle_threads(batch, want_threads)
+    import numpy as np
+    assert np.array_equal(res.order, res1.order)
     return res, alloc, t1, tn, nt
 
 
-def pipelined_rate(batch, ctx, pool, dev, in_flight, steps, native, resident, torch):
+def order_match(batch, got, want):
+    import numpy as np
+    return float(np.mean([np.array_equal(got.order[batch.task_off[d]:batch.task_off[d + 1]], want.order[batch.task_off[d]:batch.task_off[d + 1]])
+                          for d in range(batch.n_distros)])) if batch.n_distros else 1.0
+
+
+def pipelined_rate(batch, dev, in_flight, steps, native, resident, torch):
     """Sustained rate with `in_flight` independent pools (own context, scratch and outputs) ticking on their own HIP streams:
     the workgroups of one launch are phase-locked (all load, then all compute); batches in flight fill each other's
     bandwidth-bound and compute-bound phases, the kernel tails and the dispatch gaps. Reported next to `value`, which stays
     the one-batch-at-a-time figure the roofline block describes."""
-    pools = [pool] + [resident.ResidentPool(native.Context(dev.index or 0), batch, dev, breakdown=False, n_units=False) for _ in range(in_flight - 1)]
+    pools = [resident.ResidentPool(native.Context(dev.index or 0), batch, dev, breakdown=False, n_units=False) for _ in range(in_flight)]
     streams = [torch.cuda.Stream(device=dev) for _ in pools]
     torch.cuda.synchronize(dev)
     for p, st in zip(pools, streams):
@@ -104,29 +124,86 @@ def pipelined_rate(batch, ctx, pool, dev, in_flight, steps, native, resident, to
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / max(steps, 1)
     ok = all(bool(torch.equal(p.o_order, pools[0].o_order)) for p in pools[1:])  # same batch: every pool must hold the same plan
+    for p in pools:
+        p.ctx.close()
     return {"in_flight": in_flight, "value": batch.n_tasks / dt, "unit": "tasks/s", "ms_per_step": dt * 1e3, "steps": steps,
             "plans_identical": ok,
             "what": "%d pools of the same workload, each on its own HIP stream with its own context / scratch / outputs, ticks issued round-robin" % in_flight}
 
 
+def resident_rate(batch, dev, native, resident, torch, steps=10, warmup=2):
+    """ms per tick (plan + allocate, device-resident, one batch at a time) of `batch` + the device results."""
+    ctx = native.Context(dev.index or 0)
+    pool = resident.ResidentPool(ctx, batch, dev, breakdown=False, n_units=False)
+    for _ in range(warmup):
+        pool.step(fused=False)
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b, c in ev:
+        a.record()
+        pool.plan()
+        b.record()
+        if pool.has_hosts:
+            pool.allocate()
+        c.record()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    plan_ms = sorted(a.elapsed_time(b) for a, b, _ in ev)[len(ev) // 2]
+    alloc_ms = sorted(b.elapsed_time(c) for _, b, c in ev)[len(ev) // 2]
+    got, got_alloc = pool.plan_result(), (pool.alloc_result() if pool.has_hosts else None)
+    ctx.close()
+    return dt * 1e3, plan_ms, alloc_ms, got, got_alloc
+
+
+def extra_workload(name, cfg, what, dev, native, resident, torch, gen, np):
+    """A second workload reported next to the headline (the skewed config-3 variant; config 5's per-GPU share): its
+    device-resident rate, its own roofline figure, and parity against the oracle in the same run."""
+    from tests import compare
+    batch = gen.generate(cfg)
+    ms, plan_ms, alloc_ms, got, got_alloc = resident_rate(batch, dev, native, resident, torch)
+    want, want_alloc, tn, nt = oracle_threads(batch, os.cpu_count() or 1, reps=1)
+    n_units = int(want.n_units.sum())
+    want.n_units = None
+    parity = True
+    try:
+        compare.assert_plan_equal(got, want, batch, name)
+        if got_alloc is not None:
+            compare.assert_alloc_equal(got_alloc, want_alloc, name)
+        compare.reference_validity(batch, got)
+    except AssertionError as e:
+        parity = str(e)[:300]
+    abytes, _ = algorithmic_bytes(batch, n_units)
+    sizes = np.diff(batch.task_off)
+    achieved = abytes / (plan_ms * 1e-3) / 1e9
+    return {"workload": what, "tasks": batch.n_tasks, "distros": batch.n_distros, "largest_distro": int(sizes.max()),
+            "distros_over_2048_tasks": int((sizes > 2048).sum()), "tasks_on_the_large_distro_path": int(sizes[sizes > 2048].sum()),
+            "value": batch.n_tasks / (ms * 1e-3), "unit": "tasks/s", "ms_per_step": ms, "planning-distro_ms": plan_ms,
+            "host-allocation_ms": alloc_ms, "parity_vs_oracle": parity, "queue_order_match": order_match(batch, got, want),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": abytes, "kernel_ms": plan_ms,
+                         "kernel_ms_scope": "HIP events around evg_plan_distros_device: every kernel of the plan (LDS path + large-distro pipeline)"},
+            "cpu_oracle_threads_s": tn, "cpu_threads": nt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=3, help="BASELINE config number (3 = 1M tasks x 512 distros)")
+    ap.add_argument("--config", type=int, default=0, help="BASELINE config number (default: 3 at N=1, 4 = the same pool sharded at N>1)")
     ap.add_argument("--tasks", type=int, default=0, help="override the task count (parity/debug runs only)")
     ap.add_argument("--distros", type=int, default=0)
+    ap.add_argument("--weak", action="store_true", help="round 1's mode: every rank plans its OWN pool, no collective (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / skewed / config5_share / pipelined (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=3, help="also report the sustained rate with this many independent pools in flight "
                                                              "on their own streams (the `pipelined` object; 1 = skip)")
-    ap.add_argument("--fused", action="store_true", help="time the single-launch entry point evg_plan_allocate_device instead of "
-                    "evg_plan_distros_device + evg_allocate_hosts_device (the reference's two jobs)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
-    from evergreen_amd import gen, native, resident
+    from evergreen_amd import gen, multi, native, resident
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,16 +220,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    cfg_num = args.config or (3 if world == 1 else 4)
     over = {}
     if args.tasks:
         over["n_tasks"] = args.tasks
     if args.distros:
         over["n_distros"] = args.distros
-    cfg = gen.config(args.config, **over)
-    cfg.seed = cfg.seed + 1000 * rank  # every rank plans its own distros
-    batch = gen.generate(cfg)
+    cfg = gen.config(cfg_num, **over)
+    if args.weak:
+        cfg.seed = cfg.seed + 1000 * rank  # every rank plans its own pool
+    have_batch = args.weak or rank == 0
+    batch = gen.generate(cfg) if have_batch else None
     ctx = native.Context(local_rank)
-    pool = resident.ResidentPool(ctx, batch, dev, breakdown=False, n_units=False)
+    # One code path for every N: the packed pool buffer + range entry points (a range of all distros at N = 1 / --weak).
+    pool = multi.ShardedPool(ctx, dev, collective=not args.weak)
+    pool.setup(multi.pack_pool(batch) if have_batch else None)
 
     def barrier():
         if dist is not None:
@@ -160,88 +242,167 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        pool.step(fused=args.fused)
+        pool.tick()
+    # ---- the timed region: EXACTLY `steps` ticks between barriers, nothing else on the stream ------------------------
     barrier()
-    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()          # HIP events on the stream the kernels are launched on (torch's current stream)
-        if not args.fused:
-            pool.plan()
-            ev[k][1].record()
-            if pool.has_hosts:
-                pool.allocate()
-        else:
-            pool.step(fused=True)  # one launch: every distro's planner workgroup ends with its host-allocator pass
-            ev[k][1].record()
-        ev[k][2].record()
+        pool.tick()                # broadcast -> plan -> allocate -> gather
     barrier()
     elapsed = time.perf_counter() - t0
-    plan_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / max(args.steps, 1)
-    alloc_ms = sum(b.elapsed_time(c) for _, b, c in ev) / max(args.steps, 1)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ntask = torch.tensor([float(batch.n_tasks)], dtype=torch.float64, device=dev)
+
+    # ---- the same ticks again with HIP events between the phases (on the stream the kernels are launched on: torch's
+    # current stream). An event record costs a few microseconds of stream time at these step lengths (a step is ~70 us), so
+    # the per-phase and per-kernel intervals come from this second pass and `value` from the clean one above. -----------
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(5)) for _ in range(args.steps)]
+    barrier()
+    for k in range(args.steps):
+        e = ev[k]
+        e[0].record()
+        pool.broadcast()
+        e[1].record()
+        pool.plan()
+        e[2].record()
+        pool.allocate()
+        e[3].record()
+        pool.gather()
+        e[4].record()
+    barrier()
+
+    # kernel-only: the ticks without the two collectives
+    barrier()
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        pool.plan()
+        pool.allocate()
+    barrier()
+    elapsed_k = time.perf_counter() - t1
+
+    my_tasks = float(pool.layout.N if args.weak else 0)
+    red = torch.tensor([elapsed, elapsed_k, my_tasks], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ntask, op=dist.ReduceOp.SUM)
-    elapsed = float(tmax.item())
-    total_tasks = float(ntask.item())
+        mx = red.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = red.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, elapsed_k, sum_tasks = float(mx[0]), float(mx[1]), float(sm[2])
+    else:
+        sum_tasks = my_tasks
+    total_tasks = sum_tasks if args.weak else float(pool.layout.N)
 
     if rank == 0:
+        def med(i, j):
+            xs = sorted(e[i].elapsed_time(e[j]) for e in ev)
+            return xs[len(xs) // 2], xs[0], sum(xs) / len(xs)
+        bc_ms, plan_ms, alloc_ms, ga_ms = med(0, 1), med(1, 2), med(2, 3), med(3, 4)
+        step_ev = med(0, 4)
         ms_per_step = elapsed / args.steps * 1e3
         value = total_tasks * args.steps / elapsed
+        d0, d1 = pool.my_range
+        lay = pool.layout
+        if args.weak:
+            workload = "BASELINE config %d per GPU (weak scaling, an independent pool per rank): %d tasks x %d distros" % (cfg_num, lay.N, lay.D)
+            par = "%d independent pool(s), no data-path collective" % world
+        elif world == 1:
+            workload = "BASELINE config 3: %d tasks x %d distros on 1 MI355X" % (lay.N, lay.D)
+            par = "1 rank"
+        else:
+            workload = "BASELINE config 4: %d tasks x %d distros over %d ranks" % (lay.N, lay.D, world)
+            par = "distros sharded over %d ranks by prefix-sum balancing; 1 RCCL broadcast of the packed pool (%d bytes) + 1 grouped gather of the result slices per tick" % (world, lay.total_bytes)
         line = {
-            "metric": "scheduled tasks/sec at 1M tasks x 512 distros; queue-order match vs ref",
-            "value": value, "unit": "tasks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": METRIC, "value": value, "unit": "tasks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
-            "config": {"workload": "BASELINE config %d per GPU: %d tasks x %d distros, tunable planner + GetDistroQueueInfo + "
-                                   "UtilizationBasedHostAllocator (%d hosts), SplitMix64 seed 0x%X" % (
-                                       args.config, batch.n_tasks, batch.n_distros, batch.n_hosts, cfg.seed),
-                       "tasks_per_gpu": batch.n_tasks, "distros_per_gpu": batch.n_distros, "dep_edges": batch.n_edges,
-                       "task_groups": batch.n_task_groups, "parallelism": "distros sharded, %d rank(s), no data-path collective" % world},
+            "config": {"workload": workload + ", tunable planner + GetDistroQueueInfo + UtilizationBasedHostAllocator (%d hosts), SplitMix64 seed 0x%X" % (lay.H, cfg.seed),
+                       "tasks": lay.N, "distros": lay.D, "dep_edges": lay.E, "task_groups": lay.TG, "hosts": lay.H, "parallelism": par,
+                       "rank0_distro_range": [d0, d1]},
+            "timed_region": "`steps` ticks of broadcast -> plan -> allocate -> gather (the collectives are no-ops at 1 rank), wall clock between "
+                            "barrier + synchronize on both sides, max over ranks; the HIP-event figures below come from a second pass of the same "
+                            "ticks with events between the phases (an event record costs microseconds of stream time at these step lengths)",
+            "step_ms_hip_events_rank0": {"median": step_ev[0], "min": step_ev[1], "mean": step_ev[2]},
+            "phases_ms": {"pool-broadcast": bc_ms[0], "planning-distro": plan_ms[0], "host-allocation": alloc_ms[0], "queue-gather": ga_ms[0],
+                          "what": "rank 0, median over the timed steps' HIP events; planning-distro / host-allocation are the reference's phase names "
+                                  "(scheduler/wrapper.go:121-123, units/host_allocator.go:200)"},
+            "kernel_only": {"value": total_tasks * args.steps / elapsed_k, "unit": "tasks/s", "ms_per_step": elapsed_k / args.steps * 1e3,
+                            "what": "the same steps without the broadcast and the gather (every rank plans + allocates its range), max over ranks"},
         }
-        # roofline of the dominant kernel (k_plan_distros), from the HIP events of the timed region
-        nu_pool = resident.ResidentPool(ctx, batch, dev, breakdown=True, n_units=True)
-        nu_pool.step(fused=args.fused)
-        got = nu_pool.plan_result()
-        got_alloc = nu_pool.alloc_result() if nu_pool.has_hosts else None
-        abytes, e_in = algorithmic_bytes(batch, int(got.n_units.sum()))
-        achieved = abytes / (plan_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        # roofline of the dominant kernel (k_plan_distros) over rank 0's distro range, from the HIP events of the timed region
+        try:
+            full = ctx.plan(batch, breakdown=True, n_units=True)  # host-pointer call: n_units + breakdown for the checks below
+            abytes, e_in = algorithmic_bytes(batch, int(full.n_units[d0:d1].sum()), d0, d1)
+            achieved = abytes / (plan_ms[0] * 1e-3) / 1e9
+            traffic, traffic_source = None, None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc) and world == 1:
+                try:
+                    j = json.load(open(pmc))
+                    traffic = j.get("k_plan_distros_hbm_bytes_per_launch")
+                    traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this workload, NOT measured in this run)" % j.get("source", "pmc_latest.json")
+                except Exception:
+                    traffic = None
+            line["roofline"] = {"bound": "hbm", "kernel": "k_plan_distros", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                                "algorithmic_bytes_per_launch": abytes, "kernel_ms": plan_ms[0], "kernel_ms_min": plan_ms[1], "kernel_ms_mean": plan_ms[2],
+                                "allocator_ms": alloc_ms[0],
+                                "kernel_ms_scope": "median HIP-event interval around the plan entry point = k_plan_distros + the (empty) large-distro check behind it",
+                                "bytes_per_task": abytes / max(int(batch.task_off[d1] - batch.task_off[d0]), 1)}
+            got, got_alloc = pool.plan_result(), pool.alloc_result()
+        except Exception as e:
+            line["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            got = got_alloc = full = None
+        if got is not None and not args.no_cpu_baseline:
             try:
-                traffic = json.load(open(pmc)).get("k_plan_distros_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # kernel_ms is the event interval around evg_plan_distros_device: k_plan_distros plus the (empty, ~4 us) k_plan_generic
-        # launch queued behind it, so `achieved` is a few per cent BELOW what rocprofv3's per-kernel average gives.
-        line["roofline"] = {"bound": "hbm", "kernel": "k_plan_distros", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                            "algorithmic_bytes_per_launch": abytes, "kernel_ms": plan_ms, "allocator_ms": alloc_ms,
-                            "kernel_ms_scope": "HIP events around evg_plan_distros_device = k_plan_distros + the empty k_plan_generic launch behind it",
-                            "bytes_per_task": abytes / max(batch.n_tasks, 1)}
-        if world == 1 and not args.no_cpu_baseline:
-            want, want_alloc, t1, tn, nt = cpu_baseline(batch, os.cpu_count() or 1)
-            match = float(np.mean([np.array_equal(got.order[batch.task_off[d]:batch.task_off[d + 1]],
-                                                  want.order[batch.task_off[d]:batch.task_off[d + 1]])
-                                   for d in range(batch.n_distros)]))
-            hosts_match = bool(got_alloc is None or (np.array_equal(got_alloc.new_hosts, want_alloc.new_hosts) and
-                                                     np.array_equal(got_alloc.free_hosts, want_alloc.free_hosts)))
-            line["queue_order_match"] = match
-            line["host_counts_match"] = hosts_match
-            line["cpu_baseline"] = {
-                "value": batch.n_tasks / tn, "unit": "tasks/s", "cores": nt, "kind": "port",
-                "single_thread_value": batch.n_tasks / t1,
-                "sample": "the whole workload (%d tasks x %d distros), best of 5 passes with %d worker threads, one distro range each "
-                          "(%.2f s per pass), and best of 3 passes on one thread (%.2f s per pass): C++ oracle, a port of the Go "
-                          "algorithm (the Go reference cannot be built here: no Go toolchain)" % (batch.n_tasks, batch.n_distros, nt, tn, t1)}
-        if world == 1 and args.in_flight > 1:
-            try:
-                line["pipelined"] = pipelined_rate(batch, ctx, pool, dev, args.in_flight, args.steps, native, resident, torch)
-            except Exception as e:  # the extra measurement must never cost the headline line
-                line["pipelined"] = {"in_flight": args.in_flight, "error": "%s: %s" % (type(e).__name__, e)}
+                from tests import compare
+                want, want_alloc, t1s, tn, nt = cpu_baseline(batch, os.cpu_count() or 1)
+                line["queue_order_match"] = order_match(batch, got, want)
+                line["host_counts_match"] = bool(got_alloc is None or (np.array_equal(got_alloc.new_hosts, want_alloc.new_hosts) and
+                                                                       np.array_equal(got_alloc.free_hosts, want_alloc.free_hosts)))
+                try:  # the order the Go code could emit, checked independently of the oracle
+                    full.order[:] = got.order
+                    compare.reference_validity(batch, full)
+                    line["reference_validity"] = True
+                except AssertionError as e:
+                    line["reference_validity"] = str(e)[:300]
+                if world == 1:
+                    line["cpu_baseline"] = {
+                        "value": batch.n_tasks / tn, "unit": "tasks/s", "cores": nt, "kind": "port",
+                        "single_thread_value": batch.n_tasks / t1s,
+                        "sample": "the whole workload (%d tasks x %d distros), best of 5 passes with %d worker threads, one distro range each "
+                                  "(%.2f s per pass), and best of 3 passes on one thread (%.2f s per pass): C++ oracle, a port of the Go "
+                                  "algorithm (the Go reference cannot be built here: no Go toolchain)" % (batch.n_tasks, batch.n_distros, nt, tn, t1s)}
+            except Exception as e:
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.weak and not args.no_extras:
+            def guarded(key, fn):
+                try:
+                    line[key] = fn()
+                except Exception as e:  # an extra measurement must never cost the headline line
+                    line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+            def end_to_end():
+                # host pointers in, host pointers out: what INTEGRATION.md's planBatch binds to (PCIe both ways inside)
+                ts = []
+                for _ in range(5):
+                    t = time.perf_counter()
+                    r = ctx.plan(batch, breakdown=False, n_units=False)
+                    ctx.allocate(batch, r.distro_info, r.group_info)
+                    ts.append(time.perf_counter() - t)
+                ts.sort()
+                b_in = sum(v.nbytes for v in batch.cols.values()) + batch.dep_off.nbytes + sum(v.nbytes for v in batch.edges.values()) + \
+                    sum(v.nbytes for v in batch.hosts.values())
+                b_out = r.order.nbytes + r.deps_met.nbytes + r.wait_ns.nbytes + r.distro_info.nbytes + r.group_info.nbytes
+                return {"value": batch.n_tasks / ts[len(ts) // 2], "unit": "tasks/s", "ms_per_call": ts[len(ts) // 2] * 1e3, "ms_min": ts[0] * 1e3,
+                        "bytes_in": b_in, "bytes_out": b_out, "identical_to_resident": bool(np.array_equal(r.order, got.order)),
+                        "what": "evg_plan_distros + evg_allocate_hosts on host numpy buffers: H2D of every column, the kernels, D2H of the outputs"}
+            guarded("end_to_end", end_to_end)
+            guarded("skewed", lambda: extra_workload("skewed", gen.config(3, skew=True), "BASELINE config 3, skewed variant: Zipf(s=1) distro sizes "
+                                                     "truncated to [64, 65536]", dev, native, resident, torch, gen, np))
+            guarded("config5_share", lambda: extra_workload("config5", gen.config(5, n_tasks=1_250_000, n_distros=64),
+                                                            "BASELINE config 5's per-GPU share: 10M tasks x 512 distros over 8 GPUs = 1.25M tasks x 64 "
+                                                            "distros of ~19.5k tasks, DAG depth 8, 20% task-group tasks (large-distro path)",
+                                                            dev, native, resident, torch, gen, np))
+            if args.in_flight > 1:
+                guarded("pipelined", lambda: pipelined_rate(batch, dev, args.in_flight, min(args.steps, 60), native, resident, torch))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

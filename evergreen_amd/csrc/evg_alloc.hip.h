@@ -17,6 +17,7 @@ struct AllocArgs {
   evg_alloc_output out;
   double* w_term;  // [n_hosts] fractional-free term of each running host
   int32_t *w_new, *w_free, *w_err;  // [D + n_tg] per-bucket results; w_err: -1 not evaluated, 0 ok, >0 EVG_ALLOC_E_*
+  int32_t d0;  // first distro of this call (evg_allocate_host_range_device; else 0): workgroup b allocates distro d0 + b
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts;
 #endif

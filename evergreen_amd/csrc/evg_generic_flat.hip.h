@@ -35,7 +35,7 @@ __device__ __forceinline__ int distro_of_slot(const PlanArgs& a, int D, long lon
   return lo;
 }
 __device__ __forceinline__ bool flat_distro(const PlanArgs& a, int d) {
-  return a.w_generic[d] != 0 && a.in.task_off[d + 1] - a.in.task_off[d] > 1024;
+  return d >= a.d0 && d < a.d1 && a.w_generic[d] != 0 && a.in.task_off[d + 1] - a.in.task_off[d] > 1024;
 }
 
 __device__ __forceinline__ DC flat_context(const PlanArgs& a, int d) {  // distro_context without the edge-range loads
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(kFlatBlock) k_flat_sums(const PlanArgs a) {
 __global__ void __launch_bounds__(kFlatBlock) k_flat_rows(const PlanArgs a) {
   __shared__ unsigned s_red[16];
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int d = blockIdx.x; d < a.in.n_distros; d += gridDim.x) {
+  for (int d = a.d0 + blockIdx.x; d < a.d1; d += gridDim.x) {
     if (!flat_distro(a, d) || !a.w_gstate[d].fast) continue;
     const DC c = flat_context(a, d);
     const evg_task_soa& t = a.in.tasks;

@@ -74,6 +74,8 @@ struct PlanArgs {
   struct GState* w_gstate;  // [D] per-distro state handed between the kernels of the generic pipeline
   int32_t* w_tiles;    // [2 * max_tiles] (distro, tile) of every 2048-key tile the pipeline's sort kernels work on
   int32_t* w_ntiles;   // [1] number of registered tiles (zeroed by the LDS-path kernel of the same call)
+  int32_t d0, d1;      // the distros this call plans: [d0, d1) of the batch (evg_plan_distro_range_device; else 0, D).
+                       // Outputs keep the FULL batch's row / info-row numbering.
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts;  // [D][16] s_memtime stamps at the phase boundaries (scripts/phase_timing.py)
 #endif

@@ -900,7 +900,7 @@ template <bool RICH>
 __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
-  const int d = blockIdx.x;
+  const int d = a.d0 + blockIdx.x;
   const DC c = distro_context(a, d);
   if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
   __syncthreads();
@@ -961,9 +961,9 @@ __global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a, int s
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
   // Almost always nothing is flagged: find that out with ONE round trip (independent loads) instead of one per distro.
   int any = 0;
-  for (int d = blockIdx.x; d < a.in.n_distros; d += gridDim.x) any |= a.w_generic[d];
+  for (int d = a.d0 + blockIdx.x; d < a.d1; d += gridDim.x) any |= a.w_generic[d];
   if (!any) return;
-  for (int d = blockIdx.x; d < a.in.n_distros; d += gridDim.x) {
+  for (int d = a.d0 + blockIdx.x; d < a.d1; d += gridDim.x) {
     if (!a.w_generic[d]) continue;
     if (skip_flat && a.in.task_off[d + 1] - a.in.task_off[d] > 1024 && a.w_gstate[d].fast) continue;
     const DC c = distro_context(a, d);
@@ -983,7 +983,7 @@ template <int STAGE>
 __global__ void __launch_bounds__(kBlock) k_generic_stage(const PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
-  for (int d = blockIdx.x; d < a.in.n_distros; d += gridDim.x) {
+  for (int d = a.d0 + blockIdx.x; d < a.d1; d += gridDim.x) {
     if (!a.w_generic[d]) continue;
     const DC c = distro_context(a, d);
     __syncthreads();

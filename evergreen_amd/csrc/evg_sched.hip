@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
   __shared__ int s_i[8];  // 0: #free hosts, 1: sum new, 2: sum free, 4: first failing bucket, 5: its error
   __shared__ HostRec s_rec[kAllocLdsHosts];
   __shared__ int s_cnt[2 * kAllocLdsBuckets];
-  const int d = blockIdx.x, tid = threadIdx.x;
+  const int d = a.d0 + blockIdx.x, tid = threadIdx.x;
   const evg_alloc_params p = a.in.params[d];
   const evg_host_soa& h = a.in.hosts;
   const int h0 = a.in.host_off[d], nh = a.in.host_off[d + 1] - h0;
@@ -385,7 +385,7 @@ static evg_plan_input stage_plan_input(Stager& s, const evg_plan_input* in) {
 
 extern "C" {
 
-int32_t evg_abi_version(void) { return (1 << 16) | 0; }
+int32_t evg_abi_version(void) { return (1 << 16) | 1; }
 
 #ifdef EVG_PHASE_TIMING
 // diagnostics build only (scripts/phase_timing.py): device buffer of D x 16 s_memtime stamps
@@ -488,6 +488,8 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   PlanArgs& a = *pa;
   a.in = *in;
   a.out = *out;
+  a.d0 = 0;
+  a.d1 = D;
   // scratch of the large-distro path (untouched pages cost nothing; small distros never use it)
   size_t sz[24] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
                    4 * (N + 1), 8 * (N + 1), 8 * (N + 1), 8 * (N + 1), 4 * (N + 1),
@@ -532,6 +534,7 @@ static int prepare_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_
   AllocArgs& a = *qa;
   a.in = *in;
   a.out = *out;
+  a.d0 = 0;
   const size_t G = (size_t)in->n_distros + (size_t)in->n_task_groups;
   size_t sz[4] = {8 * ((size_t)in->hosts.n_hosts + 1), 4 * G, 4 * G, 4 * G};
   for (int i = 0; i < 4; i++) {
@@ -602,12 +605,19 @@ static int launch_generic(evg_ctx* c, const evg::PlanArgs& a, const evg_plan_inp
   return EVG_OK;
 }
 
-static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, hipStream_t st) {
+// Plans distros [d_begin, d_end) of the batch (d_end < 0: all). Outputs keep the full batch's numbering.
+static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, hipStream_t st, int d_begin = 0, int d_end = -1) {
   using namespace evg;
   PlanArgs a;
   int rc = prepare_plan(c, in, out, &a);
   if (rc || in->n_distros == 0) return rc;
-  const int D = in->n_distros;
+  if (d_end >= 0) {
+    if (d_begin < 0 || d_end < d_begin || d_end > in->n_distros) return set_err(c, EVG_E_INVALID, "distro range [%d, %d) outside [0, %d)", d_begin, d_end, in->n_distros);
+    a.d0 = d_begin;
+    a.d1 = d_end;
+    if (d_begin == d_end) return EVG_OK;
+  }
+  const int D = a.d1 - a.d0;
   // the optional outputs need 36 KiB more LDS per workgroup (one workgroup per CU instead of two)
   if (out->breakdown || out->n_units) hipLaunchKernelGGL(k_plan_distros<true>, dim3(D), dim3(kBlock), kLdsRich, st, a);
   else hipLaunchKernelGGL(k_plan_distros<false>, dim3(D), dim3(kBlock), kLdsLean, st, a);
@@ -622,12 +632,19 @@ int evg_plan_distros_device(evg_ctx* c, const evg_plan_input* in, const evg_plan
   return launch_plan(c, in, out, (hipStream_t)hip_stream);
 }
 
-static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, hipStream_t st) {
+static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, hipStream_t st, int d_begin = 0, int d_end = -1) {
   using namespace evg;
   AllocArgs a;
   int rc = prepare_alloc(c, in, out, &a);
   if (rc || in->n_distros == 0) return rc;
-  hipLaunchKernelGGL(k_allocate_hosts, dim3(in->n_distros), dim3(kAllocBlock), 0, st, a);
+  int nd = in->n_distros;
+  if (d_end >= 0) {
+    if (d_begin < 0 || d_end < d_begin || d_end > in->n_distros) return set_err(c, EVG_E_INVALID, "distro range [%d, %d) outside [0, %d)", d_begin, d_end, in->n_distros);
+    a.d0 = d_begin;
+    nd = d_end - d_begin;
+    if (nd == 0) return EVG_OK;
+  }
+  hipLaunchKernelGGL(k_allocate_hosts, dim3(nd), dim3(kAllocBlock), 0, st, a);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }
@@ -636,6 +653,20 @@ int evg_allocate_hosts_device(evg_ctx* c, const evg_alloc_input* in, const evg_a
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return launch_alloc(c, in, out, (hipStream_t)hip_stream);
+}
+
+int evg_plan_distro_range_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, int32_t d_begin, int32_t d_end,
+                                 void* hip_stream) {
+  if (!c || d_end < 0) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return launch_plan(c, in, out, (hipStream_t)hip_stream, d_begin, d_end);
+}
+
+int evg_allocate_host_range_device(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, int32_t d_begin, int32_t d_end,
+                                   void* hip_stream) {
+  if (!c || d_end < 0) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return launch_alloc(c, in, out, (hipStream_t)hip_stream, d_begin, d_end);
 }
 
 int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const evg_alloc_input* ain,

@@ -1,214 +1,309 @@
-"""Multi-GPU driver of the hot path: distros are independent (the reference runs one amboy job per distro,
-units/crons.go:325-330), so ranks own disjoint sets of distros and the data path needs NO collective.
+"""Multi-GPU driver of the hot path (BASELINE config 4): ONE pool, distros sharded across the ranks.
 
-What does move, over RCCL/xGMI on a GPU box (backend "nccl") or gloo in the CPU tests:
-  * optionally ONE broadcast of the packed pool from rank 0 (north_star: "a single RCCL broadcast of the shared
-    runnable-task pool") -- `broadcast_batch`; a deployment whose ranks read their own distros skips it;
-  * ONE gather of each rank's queue order + info rows back to rank 0 -- `gather_results`.
+Distros are independent -- the reference runs one amboy job per distro (units/crons.go:303-332) -- so the only data
+that moves between GPUs is what north_star names:
 
-One process per GPU; the caller initialises torch.distributed. Nothing here computes: planning goes through a
-scheduler.Backend (the HIP library on GPUs; tests plug the oracle in to check the sharding / re-basing logic).
+  * ONE broadcast of the shared runnable-task pool from rank 0: the whole batch (every SoA column, the CSR, the
+    per-distro tables, the allocator's host columns) lives in ONE packed device buffer whose layout (`PoolLayout`) is a
+    256-byte header plus 256-byte-aligned sections, so the collective is a single `broadcast` of one byte tensor and the
+    kernels read the columns in place through typed views -- nothing is unpacked, copied or re-uploaded;
+  * every rank plans a CONTIGUOUS range of distros chosen by prefix-sum balancing of the task counts
+    (`balanced_ranges`) with evg_plan_distro_range_device / evg_allocate_host_range_device, which keep the full batch's
+    numbering, so a rank's results are contiguous slices of full-size output arrays;
+  * ONE gather of those slices (queue order 4 B/task, deps-met 1 B, wait 8 B, the info rows and the host counts) to
+    rank 0: a single group of point-to-point sends/receives (what RCCL's own ncclGather is, rccl.h:745) that lands each
+    slice directly at its final offset in rank 0's arrays -- no staging buffer, no unpack.
+
+One process per GPU; the caller initialises torch.distributed (backend "nccl" == RCCL on a GPU box, "gloo" in the CPU
+tests). torch is plumbing here: it owns the device buffer and issues the collectives. Nothing in this file computes a
+plan: planning goes through a range backend -- `native.Context` (the HIP library) on GPUs; the CPU tests plug the oracle
+in to check the sharding logic with world size 2.
 """
 from __future__ import annotations
 
-import io
-from typing import List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from . import abi
 
-
-def partition_distros(task_counts: Sequence[int], world: int) -> List[np.ndarray]:
-    """Greedy LPT: heaviest distro first onto the least-loaded rank. Returns, per rank, the sorted
-    distro ids it owns. Deterministic, so every rank computes the same partition without communicating."""
-    order = sorted(range(len(task_counts)), key=lambda d: (-int(task_counts[d]), d))
-    load = [0] * world
-    own: List[List[int]] = [[] for _ in range(world)]
-    for d in order:
-        r = min(range(world), key=lambda k: (load[k], k))
-        own[r].append(d)
-        load[r] += int(task_counts[d])
-    return [np.asarray(sorted(o), np.int64) for o in own]
+ALIGN = 256
+MAGIC = 0x45564750_4F4F4C31  # "EVGPOOL1"
+HEADER_WORDS = 32            # int64 words = 256 bytes
+# header words
+H_MAGIC, H_TOTAL, H_NOW, H_D, H_N, H_E, H_TG, H_VER, H_H, H_HAS_HOSTS, H_HAS_NAME, H_MAX_DISTRO = range(12)
 
 
-def select_distros(batch: abi.PlanBatch, ids: Sequence[int]) -> abi.PlanBatch:
-    """The sub-batch holding distros `ids` (in that order): rows, edges, hosts sliced; row indices of in-queue
-    dependencies and the task-group / version keys re-based so that the result obeys the layout contract."""
-    ids = [int(d) for d in ids]
-    D = len(ids)
-    t_off, g_off, v_off = batch.task_off, batch.tg_off, batch.ver_off
-    rows = [np.arange(t_off[d], t_off[d + 1]) for d in ids]
-    row_idx = np.concatenate(rows) if rows else np.zeros(0, np.int64)
-    new_task_off = np.zeros(D + 1, np.int32)
-    new_tg_off = np.zeros(D + 1, np.int32)
-    new_ver_off = np.zeros(D + 1, np.int32)
-    for k, d in enumerate(ids):
-        new_task_off[k + 1] = new_task_off[k] + (t_off[d + 1] - t_off[d])
-        new_tg_off[k + 1] = new_tg_off[k] + (g_off[d + 1] - g_off[d])
-        new_ver_off[k + 1] = new_ver_off[k] + (v_off[d + 1] - v_off[d])
-    cols = {k: np.ascontiguousarray(v[row_idx]) for k, v in batch.cols.items()}
-    # re-base keys and dependency rows distro by distro
-    e_lo = batch.dep_off[:-1][row_idx].astype(np.int64)
-    e_hi = batch.dep_off[1:][row_idx].astype(np.int64)
-    cnt = e_hi - e_lo
-    dep_off = np.zeros(len(row_idx) + 1, np.int32)
-    np.cumsum(cnt, out=dep_off[1:])
-    edge_idx = np.concatenate([np.arange(a, b) for a, b in zip(e_lo, e_hi)]) if len(row_idx) and cnt.sum() else np.zeros(0, np.int64)
-    edges = {k: np.ascontiguousarray(v[edge_idx]) for k, v in batch.edges.items()}
-    for k, d in enumerate(ids):
-        lo, hi = int(new_task_off[k]), int(new_task_off[k + 1])
-        tg = cols["tg_key"][lo:hi]
-        tg[tg >= 0] += int(new_tg_off[k]) - int(g_off[d])
-        cols["version_key"][lo:hi] += int(new_ver_off[k]) - int(v_off[d])
-        elo, ehi = int(dep_off[lo]), int(dep_off[hi])
-        di = edges["dep_idx"][elo:ehi]
-        di[di >= 0] += lo - int(t_off[d])
-    sub = abi.PlanBatch(n_distros=D, now_ns=batch.now_ns, cols=cols, dep_off=dep_off, edges=edges,
-                        distros=np.ascontiguousarray(batch.distros[ids]), task_off=new_task_off, tg_off=new_tg_off,
-                        ver_off=new_ver_off,
-                        tg_name_key=None if batch.tg_name_key is None else np.ascontiguousarray(batch.tg_name_key[row_idx]))
+def balanced_ranges(task_off: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """Contiguous distro ranges [d0, d1) per rank with ~N/world tasks each: boundary r is the distro boundary whose
+    prefix sum is nearest to r*N/world (a distro is never split). Deterministic: every rank computes the same table."""
+    off = np.asarray(task_off, np.int64)
+    D, N = len(off) - 1, int(off[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = r * N / world
+        k = int(np.searchsorted(off, target, side="left"))
+        k = min(max(k, 0), D)
+        if k > 0 and abs(off[k - 1] - target) <= abs(off[k] - target):
+            k -= 1
+        cuts.append(min(max(k, cuts[-1]), D))
+    cuts.append(D)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+class PoolLayout:
+    """Byte layout of the packed pool: header, then each section at the next multiple of 256 bytes, in a fixed order.
+    A pure function of the sizes in the header, so every rank derives the same offsets from the broadcast header."""
+
+    def __init__(self, n_distros: int, n_tasks: int, n_edges: int, n_task_groups: int, n_versions: int, n_hosts: int,
+                 has_hosts: bool, has_name_key: bool, now_ns: int = 0, max_distro_tasks: int = 0):
+        self.D, self.N, self.E, self.TG, self.V, self.H = n_distros, n_tasks, n_edges, n_task_groups, n_versions, n_hosts
+        self.has_hosts, self.has_name_key, self.now_ns, self.max_distro_tasks = has_hosts, has_name_key, now_ns, max_distro_tasks
+        D, N, E, H = self.D, self.N, self.E, self.H
+        sec: List[Tuple[str, np.dtype, int]] = []
+        for k, dt in abi.TASK_COLUMNS.items():
+            sec.append((k, np.dtype(dt), N))
+        sec.append(("dep_off", np.dtype(np.int32), N + 1))
+        for k, dt in abi.EDGE_COLUMNS.items():
+            sec.append((k, np.dtype(dt), E))
+        sec.append(("distros", np.dtype(np.uint8), D * abi.DISTRO_PARAMS_DTYPE.itemsize))
+        for k in ("task_off", "tg_off", "ver_off"):
+            sec.append((k, np.dtype(np.int32), D + 1))
+        if has_name_key:
+            sec.append(("tg_name_key", np.dtype(np.int32), N))
+        if has_hosts:
+            sec.append(("alloc_params", np.dtype(np.uint8), D * abi.ALLOC_PARAMS_DTYPE.itemsize))
+            sec.append(("host_off", np.dtype(np.int32), D + 1))
+            for k, dt in abi.HOST_COLUMNS.items():
+                sec.append(("host_" + k, np.dtype(dt), H))
+        self.sections: Dict[str, Tuple[int, np.dtype, int]] = {}
+        pos = HEADER_WORDS * 8
+        for name, dt, count in sec:
+            pos = (pos + ALIGN - 1) // ALIGN * ALIGN
+            self.sections[name] = (pos, dt, count)
+            pos += dt.itemsize * count
+        self.total_bytes = (pos + ALIGN - 1) // ALIGN * ALIGN
+
+    def header(self) -> np.ndarray:
+        h = np.zeros(HEADER_WORDS, np.int64)
+        h[H_MAGIC], h[H_TOTAL], h[H_NOW] = MAGIC, self.total_bytes, self.now_ns
+        h[H_D], h[H_N], h[H_E], h[H_TG], h[H_VER], h[H_H] = self.D, self.N, self.E, self.TG, self.V, self.H
+        h[H_HAS_HOSTS], h[H_HAS_NAME], h[H_MAX_DISTRO] = int(self.has_hosts), int(self.has_name_key), self.max_distro_tasks
+        return h
+
+    @staticmethod
+    def from_header(h: np.ndarray) -> "PoolLayout":
+        h = np.asarray(h, np.int64)
+        if int(h[H_MAGIC]) != MAGIC:
+            raise ValueError("packed pool: bad magic %x" % int(h[H_MAGIC]))
+        lay = PoolLayout(int(h[H_D]), int(h[H_N]), int(h[H_E]), int(h[H_TG]), int(h[H_VER]), int(h[H_H]), bool(h[H_HAS_HOSTS]),
+                         bool(h[H_HAS_NAME]), int(h[H_NOW]), int(h[H_MAX_DISTRO]))
+        if lay.total_bytes != int(h[H_TOTAL]):
+            raise ValueError("packed pool: header sizes do not add up (%d vs %d bytes)" % (lay.total_bytes, int(h[H_TOTAL])))
+        return lay
+
+
+def pack_pool(batch: abi.PlanBatch) -> np.ndarray:
+    """The batch as ONE host byte buffer in PoolLayout order (what a shim writes its columns into, pinned, once per tick)."""
+    lay = PoolLayout(batch.n_distros, batch.n_tasks, batch.n_edges, batch.n_task_groups, batch.n_versions, batch.n_hosts,
+                     batch.alloc_params is not None, batch.tg_name_key is not None, batch.now_ns,
+                     int(np.diff(batch.task_off).max()) if batch.n_distros else 0)
+    buf = np.zeros(lay.total_bytes, np.uint8)
+    buf[:HEADER_WORDS * 8] = lay.header().view(np.uint8)
+    src: Dict[str, np.ndarray] = dict(batch.cols)
+    src["dep_off"] = batch.dep_off
+    src.update(batch.edges)
+    src["distros"] = batch.distros.view(np.uint8)
+    src.update(task_off=batch.task_off, tg_off=batch.tg_off, ver_off=batch.ver_off)
+    if batch.tg_name_key is not None:
+        src["tg_name_key"] = batch.tg_name_key
     if batch.alloc_params is not None:
-        h_off = batch.host_off
-        hrows = [np.arange(h_off[d], h_off[d + 1]) for d in ids]
-        hidx = np.concatenate(hrows) if hrows else np.zeros(0, np.int64)
-        new_h_off = np.zeros(D + 1, np.int32)
-        for k, d in enumerate(ids):
-            new_h_off[k + 1] = new_h_off[k] + (h_off[d + 1] - h_off[d])
-        sub.alloc_params = np.ascontiguousarray(batch.alloc_params[ids])
-        sub.host_off = new_h_off
-        sub.hosts = {k: np.ascontiguousarray(v[hidx]) for k, v in batch.hosts.items()}
-        for k, d in enumerate(ids):
-            hk = sub.hosts["tg_key"][int(new_h_off[k]):int(new_h_off[k + 1])]
-            hk[hk >= 0] += int(new_tg_off[k]) - int(g_off[d])
-    sub.check()
-    return sub
+        src["alloc_params"] = batch.alloc_params.view(np.uint8)
+        src["host_off"] = batch.host_off
+        src.update({"host_" + k: v for k, v in batch.hosts.items()})
+    for name, (pos, dt, count) in lay.sections.items():
+        a = np.ascontiguousarray(src[name]).view(np.uint8).reshape(-1)
+        assert a.size == dt.itemsize * count, (name, a.size, dt.itemsize * count)
+        buf[pos:pos + a.size] = a
+    return buf
 
 
-def _pack(obj) -> np.ndarray:
-    buf = io.BytesIO()
-    np.savez(buf, **obj)
-    return np.frombuffer(buf.getvalue(), np.uint8).copy()
+class _Meta:
+    """The sizes abi.make_plan_input / make_alloc_input read from a PlanBatch, taken from the pool header instead."""
+
+    def __init__(self, lay: PoolLayout, task_off: np.ndarray):
+        self.n_distros, self.n_tasks, self.n_edges = lay.D, lay.N, lay.E
+        self.n_task_groups, self.n_versions, self.n_hosts, self.now_ns = lay.TG, lay.V, lay.H, lay.now_ns
+        self.task_off = task_off
+        self.alloc_params = True if lay.has_hosts else None
 
 
-def _unpack(raw: np.ndarray):
-    return dict(np.load(io.BytesIO(raw.tobytes()), allow_pickle=False))
+_TORCH_DT = None
 
 
-def _device_of(group_backend: str, local_device):
+def _torch_dtype(dt: np.dtype):
+    global _TORCH_DT
     import torch
-    return local_device if group_backend == "nccl" else torch.device("cpu")
+    if _TORCH_DT is None:
+        _TORCH_DT = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32, np.dtype(np.uint8): torch.uint8,
+                     np.dtype(np.uint16): torch.int16}  # only the bytes matter for the flag column
+    return _TORCH_DT[np.dtype(dt)]
 
 
-def broadcast_batch(batch: Optional[abi.PlanBatch], src: int = 0, device=None) -> abi.PlanBatch:
-    """ONE broadcast of the whole pool from rank `src`: every array of the batch packed into one byte tensor."""
-    import torch
-    import torch.distributed as dist
-    dev = _device_of(dist.get_backend(), device)
-    if dist.get_rank() == src:
-        d = {"c_" + k: v for k, v in batch.cols.items()}
-        d.update({"e_" + k: v for k, v in batch.edges.items()})
-        d.update(dep_off=batch.dep_off, distros=batch.distros.view(np.uint8), task_off=batch.task_off, tg_off=batch.tg_off,
-                 ver_off=batch.ver_off, meta=np.asarray([batch.n_distros, batch.now_ns], np.int64))
-        if batch.alloc_params is not None:
-            d.update(alloc_params=batch.alloc_params.view(np.uint8), host_off=batch.host_off)
-            d.update({"h_" + k: v for k, v in batch.hosts.items()})
-        if batch.tg_name_key is not None:
-            d["tg_name_key"] = batch.tg_name_key
-        raw = _pack(d)
-        size = torch.tensor([raw.size], dtype=torch.int64, device=dev)
-    else:
-        raw, size = None, torch.zeros(1, dtype=torch.int64, device=dev)
-    dist.broadcast(size, src)
-    payload = torch.from_numpy(raw).to(dev) if raw is not None else torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
-    dist.broadcast(payload, src)                      # the single data-path collective on the way in
-    if dist.get_rank() == src:
-        return batch
-    d = _unpack(payload.cpu().numpy())
-    out = abi.PlanBatch(n_distros=int(d["meta"][0]), now_ns=int(d["meta"][1]),
-                        cols={k[2:]: v for k, v in d.items() if k.startswith("c_")}, dep_off=d["dep_off"],
-                        edges={k[2:]: v for k, v in d.items() if k.startswith("e_")},
-                        distros=d["distros"].view(abi.DISTRO_PARAMS_DTYPE), task_off=d["task_off"], tg_off=d["tg_off"],
-                        ver_off=d["ver_off"], tg_name_key=d.get("tg_name_key"))
-    if "alloc_params" in d:
-        out.alloc_params = d["alloc_params"].view(abi.ALLOC_PARAMS_DTYPE)
-        out.host_off = d["host_off"]
-        out.hosts = {k[2:]: v for k, v in d.items() if k.startswith("h_")}
-    out.check()
-    return out
+class ShardedPool:
+    """One rank's side of the sharded tick: broadcast -> plan my distro range -> allocate -> gather to rank `dst`.
+
+    backend: plan_range_device(inp, out, d0, d1, stream) / allocate_range_device(ainp, aout, d0, d1, stream) over the
+    C-ABI structs (native.Context; the CPU tests pass an oracle-backed object with the same two methods)."""
+
+    def __init__(self, backend, device, src: int = 0, dst: int = 0, breakdown: bool = False, group=None, collective: bool = True):
+        import torch
+        self.torch, self.backend, self.device, self.src, self.dst, self.breakdown, self.group = torch, backend, device, src, dst, breakdown, group
+        self.dist = None
+        try:
+            import torch.distributed as dist
+            if collective and dist.is_available() and dist.is_initialized():
+                self.dist = dist  # collective=False: a stand-alone pool even inside a process group (bench.py --weak)
+        except Exception:  # pragma: no cover
+            self.dist = None
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        self.buf = None
+        self.layout: Optional[PoolLayout] = None
+
+    # ---- setup (untimed): agree on the buffer size, place the pool, build the views and the argument blocks ----------
+    def setup(self, packed: Optional[np.ndarray]) -> None:
+        """`packed` (pack_pool's buffer) on rank `src`, None elsewhere. Broadcasts the 256-byte header so that every rank
+        can size its buffer, then the pool itself once; later ticks call broadcast() alone (the sizes of a pool change
+        slowly: a tick whose pool outgrows the buffer calls setup again)."""
+        torch, dev = self.torch, self.device
+        hdr = torch.zeros(HEADER_WORDS, dtype=torch.int64, device=dev)
+        if self.rank == self.src:
+            hdr.copy_(torch.from_numpy(np.ascontiguousarray(packed[:HEADER_WORDS * 8]).view(np.int64)))
+        if self.dist and self.world > 1:
+            self.dist.broadcast(hdr, self.src, group=self.group)
+        self.layout = lay = PoolLayout.from_header(hdr.cpu().numpy())
+        self.buf = torch.zeros(lay.total_bytes, dtype=torch.uint8, device=dev)
+        if self.rank == self.src:
+            self.load(packed)
+        self.broadcast()
+        self._sync()
+        v = self.views = {name: self.buf[pos:pos + dt.itemsize * count].view(_torch_dtype(dt))
+                          for name, (pos, dt, count) in lay.sections.items()}
+        # the per-distro tables on the host (3 x (D+1) ints): ranges and slice bounds are computed from them
+        self.task_off = v["task_off"].cpu().numpy().astype(np.int64)
+        self.tg_off = v["tg_off"].cpu().numpy().astype(np.int64)
+        self.ranges = balanced_ranges(self.task_off, self.world)
+        D, N, G = lay.D, lay.N, lay.D + lay.TG
+        z = lambda n, dt: torch.zeros(max(int(n), 1), dtype=dt, device=dev)  # noqa: E731
+        self.o_order, self.o_met, self.o_wait = z(N, torch.int32), z(N, torch.uint8), z(N, torch.int64)
+        self.o_bd = z(N * abi.BREAKDOWN_FIELDS, torch.int64) if self.breakdown else None
+        self.o_di = z(D * abi.DISTRO_INFO_DTYPE.itemsize, torch.uint8)
+        self.o_gi = z(G * abi.GROUP_INFO_DTYPE.itemsize, torch.uint8)
+        meta = _Meta(lay, self.task_off)
+        self.inp = abi.make_plan_input(meta, v)
+        self.out = abi.PlanOutput()
+        self.out.order, self.out.deps_met, self.out.wait_ns = self.o_order.data_ptr(), self.o_met.data_ptr(), self.o_wait.data_ptr()
+        self.out.breakdown = self.o_bd.data_ptr() if self.breakdown else None
+        self.out.distro_info, self.out.group_info, self.out.n_units = self.o_di.data_ptr(), self.o_gi.data_ptr(), None
+        self.has_hosts = lay.has_hosts
+        if self.has_hosts:
+            self.o_alloc = z(3 * D, torch.int32)  # new_hosts | free_hosts | status
+            hv = {"alloc_params": v["alloc_params"], "host_off": v["host_off"], "tg_off": v["tg_off"]}
+            hv.update({k: v[k] for k in v if k.startswith("host_")})
+            self.ainp = abi.make_alloc_input(_HostMeta(meta), self.o_di, self.o_gi, hv)
+            self.aout = abi.AllocOutput()
+            base, isz = self.o_alloc.data_ptr(), 4
+            self.aout.new_hosts, self.aout.free_hosts, self.aout.status = base, base + isz * D, base + 2 * isz * D
+
+    def load(self, packed: np.ndarray) -> None:
+        """Rank `src`: the tick's pool into the device buffer (one H2D copy of the packed bytes)."""
+        self.buf[:packed.size].copy_(self.torch.from_numpy(packed), non_blocking=True)
+
+    def _sync(self) -> None:
+        if self.device.type == "cuda":
+            self.torch.cuda.synchronize(self.device)
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+
+    # ---- the tick ------------------------------------------------------------------------------------------------
+    def broadcast(self) -> None:
+        """THE data-path collective on the way in: one broadcast of the packed pool buffer."""
+        if self.dist and self.world > 1:
+            self.dist.broadcast(self.buf, self.src, group=self.group)
+
+    @property
+    def my_range(self) -> Tuple[int, int]:
+        return self.ranges[self.rank]
+
+    def plan(self) -> None:
+        d0, d1 = self.my_range
+        self.backend.plan_range_device(self.inp, self.out, d0, d1, self._stream())
+
+    def allocate(self) -> None:
+        if self.has_hosts:
+            d0, d1 = self.my_range
+            self.backend.allocate_range_device(self.ainp, self.aout, d0, d1, self._stream())
+
+    def _slices(self, r: int):
+        """The contiguous slices of the full-size outputs that rank r's distro range fills."""
+        lay = self.layout
+        d0, d1 = self.ranges[r]
+        r0, r1 = int(self.task_off[d0]), int(self.task_off[d1])
+        g0, g1 = lay.D + int(self.tg_off[d0]), lay.D + int(self.tg_off[d1])
+        di, gi = abi.DISTRO_INFO_DTYPE.itemsize, abi.GROUP_INFO_DTYPE.itemsize
+        s = [self.o_order[r0:r1], self.o_met[r0:r1], self.o_wait[r0:r1], self.o_di[d0 * di:d1 * di],
+             self.o_gi[d0 * gi:d1 * gi], self.o_gi[g0 * gi:g1 * gi]]
+        if self.o_bd is not None:
+            s.append(self.o_bd[r0 * abi.BREAKDOWN_FIELDS:r1 * abi.BREAKDOWN_FIELDS])
+        if self.has_hosts:
+            D = lay.D
+            s += [self.o_alloc[k * D + d0:k * D + d1] for k in range(3)]
+        return [t for t in s if t.numel() > 0]
+
+    def gather(self) -> None:
+        """THE data-path collective on the way out: every rank's result slices to rank `dst`, one group of
+        point-to-point operations, each slice received at its final place in dst's full-size arrays."""
+        if not (self.dist and self.world > 1):
+            return
+        dist, ops = self.dist, []
+        if self.rank == self.dst:
+            for r in range(self.world):
+                if r != self.dst:
+                    ops += [dist.P2POp(dist.irecv, t, r, group=self.group) for t in self._slices(r)]
+        else:
+            ops = [dist.P2POp(dist.isend, t, self.dst, group=self.group) for t in self._slices(self.rank)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def tick(self) -> None:
+        self.broadcast()
+        self.plan()
+        self.allocate()
+        self.gather()
+
+    # ---- results (rank dst holds every distro's after gather) --------------------------------------------------------
+    def plan_result(self) -> abi.PlanResult:
+        self._sync()
+        n = self.layout.N
+        return abi.PlanResult(order=self.o_order.cpu().numpy()[:n],
+                              breakdown=self.o_bd.cpu().numpy().reshape(-1, abi.BREAKDOWN_FIELDS)[:n] if self.o_bd is not None else None,
+                              deps_met=self.o_met.cpu().numpy()[:n], wait_ns=self.o_wait.cpu().numpy()[:n],
+                              distro_info=self.o_di.cpu().numpy().view(abi.DISTRO_INFO_DTYPE),
+                              group_info=self.o_gi.cpu().numpy().view(abi.GROUP_INFO_DTYPE), n_units=None)
+
+    def alloc_result(self) -> Optional[abi.AllocResult]:
+        if not self.has_hosts:
+            return None
+        self._sync()
+        a = self.o_alloc.cpu().numpy().reshape(3, -1)
+        return abi.AllocResult(a[0].copy(), a[1].copy(), a[2].copy())
 
 
-class ShardedResult:
-    """What rank 0 holds after the gather: results in the FULL batch's row / key numbering."""
+class _HostMeta:
+    """abi.make_alloc_input reads batch.n_hosts / n_distros / n_task_groups / now_ns only when `arrays` is given."""
 
-    def __init__(self, plan: abi.PlanResult, alloc: Optional[abi.AllocResult]):
-        self.plan, self.alloc = plan, alloc
-
-
-def plan_sharded(backend, batch: abi.PlanBatch, device=None, breakdown: bool = True, dst: int = 0) -> Optional[ShardedResult]:
-    """Every rank plans (and allocates hosts for) its own distros of `batch`; rank `dst` returns the assembled
-    result, the others None. `batch` must be identical on all ranks (see broadcast_batch)."""
-    import torch
-    import torch.distributed as dist
-    rank, world = dist.get_rank(), dist.get_world_size()
-    parts = partition_distros(np.diff(batch.task_off), world)
-    mine = parts[rank]
-    sub = select_distros(batch, mine)
-    res = backend.plan(sub, breakdown=breakdown)
-    alloc = backend.allocate(sub, res.distro_info, res.group_info) if batch.alloc_params is not None else None
-    # global numbering: rows of `order` back to the full batch's rows
-    order = res.order.astype(np.int64)
-    for k, d in enumerate(mine):
-        lo, hi = int(sub.task_off[k]), int(sub.task_off[k + 1])
-        order[lo:hi] += int(batch.task_off[d]) - lo
-    payload = {"ids": mine, "order": order.astype(np.int32), "deps_met": res.deps_met, "wait_ns": res.wait_ns,
-               "distro_info": res.distro_info.view(np.uint8), "group_info": res.group_info.view(np.uint8)}
-    if res.breakdown is not None:
-        payload["breakdown"] = res.breakdown
-    if res.n_units is not None:
-        payload["n_units"] = res.n_units
-    if alloc is not None:
-        payload.update(new_hosts=alloc.new_hosts, free_hosts=alloc.free_hosts, status=alloc.status)
-    raw = _pack(payload)
-    dev = _device_of(dist.get_backend(), device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([raw.size], dtype=torch.int64, device=dev))
-    cap = int(max(int(s.item()) for s in sizes))
-    mine_t = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    mine_t[:raw.size] = torch.from_numpy(raw).to(dev)
-    bufs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
-    if dist.get_backend() == "nccl":                     # RCCL has no gather primitive in torch: all_gather it
-        bufs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-        dist.all_gather(bufs, mine_t)
-    else:
-        dist.gather(mine_t, bufs, dst=dst)               # the single data-path collective on the way out
-    if rank != dst:
-        return None
-    full = abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=True)
-    D = batch.n_distros
-    full_alloc = abi.AllocResult.alloc_host(D) if batch.alloc_params is not None else None
-    for r in range(world):
-        p = _unpack(bufs[r].cpu().numpy()[:int(sizes[r].item())])
-        ids = p["ids"]
-        sub_r = select_distros(batch, ids)              # offsets of that rank's numbering
-        di = p["distro_info"].view(abi.DISTRO_INFO_DTYPE)
-        gi = p["group_info"].view(abi.GROUP_INFO_DTYPE)
-        for k, d in enumerate(ids):
-            d = int(d)
-            lo, hi = int(sub_r.task_off[k]), int(sub_r.task_off[k + 1])
-            glo = int(batch.task_off[d])
-            full.order[glo:glo + hi - lo] = p["order"][lo:hi]
-            full.deps_met[glo:glo + hi - lo] = p["deps_met"][lo:hi]
-            full.wait_ns[glo:glo + hi - lo] = p["wait_ns"][lo:hi]
-            if breakdown:
-                full.breakdown[glo:glo + hi - lo] = p["breakdown"][lo:hi]
-            full.distro_info[d] = di[k]
-            full.group_info[d] = gi[k]
-            g0, g1 = int(sub_r.tg_off[k]), int(sub_r.tg_off[k + 1])
-            full.group_info[D + int(batch.tg_off[d]):D + int(batch.tg_off[d + 1])] = gi[len(ids) + g0:len(ids) + g1]
-            if "n_units" in p:
-                full.n_units[d] = p["n_units"][k]
-            if full_alloc is not None:
-                full_alloc.new_hosts[d], full_alloc.free_hosts[d], full_alloc.status[d] = (
-                    p["new_hosts"][k], p["free_hosts"][k], p["status"][k])
-    return ShardedResult(full, full_alloc)
+    def __init__(self, m: _Meta):
+        self.n_distros, self.n_task_groups, self.now_ns, self.n_hosts = m.n_distros, m.n_task_groups, m.now_ns, m.n_hosts

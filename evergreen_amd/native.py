@@ -22,6 +22,7 @@ EXPORTS = [
     "evg_cap_queue_device", "evg_plan_allocate_device", "evg_materialize_queue_device",
     "evg_allocator_report_device", "evg_filter_runnable_device", "evg_dispatch_order_device",
     "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
+    "evg_plan_distro_range_device", "evg_allocate_host_range_device",
 ]
 
 _lib = None
@@ -58,6 +59,8 @@ def load_library() -> C.CDLL:
     lib.evg_validate_plan_input.argtypes = [C.POINTER(abi.PlanInput), C.c_char_p, C.c_int32]
     lib.evg_plan_distros.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput)]
     lib.evg_plan_distros_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p]
+    lib.evg_plan_distro_range_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_int32, C.c_int32, C.c_void_p]
+    lib.evg_allocate_host_range_device.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_int32, C.c_int32, C.c_void_p]
     lib.evg_allocate_hosts.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput)]
     lib.evg_allocate_hosts_device.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_void_p]
     lib.evg_plan_allocate_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput),
@@ -167,6 +170,15 @@ class Context:
     def allocate_device(self, inp: abi.AllocInput, out: abi.AllocOutput, stream: Optional[int] = None) -> None:
         self._check(self.lib.evg_allocate_hosts_device(self.h, C.byref(inp), C.byref(out), stream),
                     "evg_allocate_hosts_device")
+
+    def plan_range_device(self, inp: abi.PlanInput, out: abi.PlanOutput, d_begin: int, d_end: int, stream: Optional[int] = None) -> None:
+        """Distros [d_begin, d_end) of a batch that is resident as a whole (the multi-GPU shard of one rank)."""
+        self._check(self.lib.evg_plan_distro_range_device(self.h, C.byref(inp), C.byref(out), d_begin, d_end, stream),
+                    "evg_plan_distro_range_device")
+
+    def allocate_range_device(self, inp: abi.AllocInput, out: abi.AllocOutput, d_begin: int, d_end: int, stream: Optional[int] = None) -> None:
+        self._check(self.lib.evg_allocate_host_range_device(self.h, C.byref(inp), C.byref(out), d_begin, d_end, stream),
+                    "evg_allocate_host_range_device")
 
     def plan_allocate_device(self, inp: abi.PlanInput, out: abi.PlanOutput, ainp: abi.AllocInput, aout: abi.AllocOutput,
                              stream: Optional[int] = None) -> None:

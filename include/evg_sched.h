@@ -281,7 +281,8 @@ typedef struct evg_ctx evg_ctx;
 
 /* Creates a planner context bound to HIP device `device_ordinal`. Returns NULL (and sets a message
  * retrievable with evg_last_error(NULL)) when no gfx950 device is usable: there is deliberately no
- * CPU fallback. One ctx per goroutine/OS thread, or serialise calls externally; ctxs are independent. */
+ * CPU fallback. One ctx per goroutine/OS thread, or serialise calls externally; ctxs are independent. One ctx per batch in
+ * flight: see the stream-ordering rule at the *_device prototypes. */
 evg_ctx* evg_create(int device_ordinal);
 void evg_destroy(evg_ctx* ctx);
 
@@ -306,6 +307,19 @@ int evg_plan_distros(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_outp
  * too. This is what the Go shim uses when the pool is kept resident between 15 s ticks. */
 int evg_plan_distros_device(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out,
                             void* hip_stream);
+/* Rule for EVERY *_device entry point: a context owns one set of device scratch (generic-path flags, sort keys, tile
+ * lists, allocator bucket words), so the calls made on one context must be stream-ordered with respect to each other --
+ * one stream per context, or events between streams. Batches that are in flight concurrently need one context each
+ * (contexts are cheap: scratch is allocated on first use). `_device` callers must run evg_validate_plan_input on their
+ * host copy of the batch: the device paths cannot validate. */
+
+/* Multi-GPU form (one amboy job per distro, units/crons.go:303-332 => shard by distro): plans only distros
+ * [d_begin, d_end) of the batch that `in` describes. The WHOLE batch is resident on this device (north_star: one RCCL
+ * broadcast of the shared pool); every output keeps the full batch's numbering -- order[task_off[d] + p], info row d,
+ * group row D + key -- so a rank's results are contiguous slices of the full-size output arrays and the gather to rank 0
+ * is a set of slice copies. Rows outside the range are not touched. ABI 1.1. */
+int evg_plan_distro_range_device(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out, int32_t d_begin,
+                                 int32_t d_end, void* hip_stream);
 
 /* Replaces UtilizationBasedHostAllocator (scheduler/utilization_based_host_allocator.go:26-129)
  * for all D distros. Per-distro failures the reference reports as `error` come back in
@@ -313,6 +327,9 @@ int evg_plan_distros_device(evg_ctx* ctx, const evg_plan_input* in, const evg_pl
 int evg_allocate_hosts(evg_ctx* ctx, const evg_alloc_input* in, const evg_alloc_output* out);
 int evg_allocate_hosts_device(evg_ctx* ctx, const evg_alloc_input* in, const evg_alloc_output* out,
                               void* hip_stream);
+/* The allocator for distros [d_begin, d_end) of the batch only (see evg_plan_distro_range_device). ABI 1.1. */
+int evg_allocate_host_range_device(evg_ctx* ctx, const evg_alloc_input* in, const evg_alloc_output* out,
+                                   int32_t d_begin, int32_t d_end, void* hip_stream);
 
 /* The batched tick in one launch: evg_plan_distros_device followed by evg_allocate_hosts_device for the same batch,
  * fused -- every distro's planning workgroup finishes with that distro's UtilizationBasedHostAllocator pass, so the

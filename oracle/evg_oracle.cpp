@@ -968,9 +968,14 @@ int evg_oracle_plan_distro_range(const evg_plan_input* in, const evg_plan_output
   return EVG_OK;
 }
 
-int evg_oracle_allocate_hosts(const evg_alloc_input* in, const evg_alloc_output* out) {
+// Distros [d_lo, d_hi) only (d_hi < 0: all): the allocator job is per distro too (units/host_allocator.go:56-62).
+int evg_oracle_allocate_host_range(const evg_alloc_input* in, const evg_alloc_output* out, int d_lo, int d_hi);
+int evg_oracle_allocate_hosts(const evg_alloc_input* in, const evg_alloc_output* out) { return evg_oracle_allocate_host_range(in, out, 0, -1); }
+int evg_oracle_allocate_host_range(const evg_alloc_input* in, const evg_alloc_output* out, int d_lo, int d_hi) {
   if (!in || !out) return EVG_E_INVALID;
-  for (int d = 0; d < in->n_distros; d++) {
+  if (d_hi < 0) d_hi = in->n_distros;
+  if (d_lo < 0 || d_hi > in->n_distros) return EVG_E_INVALID;
+  for (int d = d_lo; d < d_hi; d++) {
     AllocDistro distro;
     distro.p = in->params[d];
     std::vector<Host> hosts;

@@ -56,3 +56,10 @@ def queue_properties(batch, res):
         ok = ~((b[:, 3] != 0) & ((b[:, 4] != 0) | (b[:, 3] != b[:, 0])))
         assert np.array_equal((pri + b[:, 0] + rank * pri)[ok], b[ok, 1])
     assert np.array_equal(res.distro_info["length"], np.diff(batch.task_off))
+
+
+def reference_validity(batch, res):
+    """does `res` hold an order the Go code could emit? Checked from the inputs and the outputs alone
+    (the oracle is not consulted). See tests/ref_validity.py for the full checker; this is its entry point."""
+    from tests import ref_validity
+    ref_validity.check(batch, res)

@@ -32,6 +32,7 @@ def lib() -> C.CDLL:
         L.evg_oracle_plan_distros.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput)]
         L.evg_oracle_plan_distro_range.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_int, C.c_int]
         L.evg_oracle_allocate_hosts.argtypes = [C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput)]
+        L.evg_oracle_allocate_host_range.argtypes = [C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_int, C.c_int]
         L.evg_oracle_cap_queue.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.evg_oracle_materialize_queue.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p, C.c_int32,
                                                    C.POINTER(abi.QueueItems)]
@@ -55,6 +56,19 @@ def lib() -> C.CDLL:
         L.evg_oracle_cache_same_id.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
         _lib = L
     return _lib
+
+
+class OracleRangeBackend:
+    """The two range entry points of the multi-GPU driver (evergreen_amd/multi.py) over the oracle: lets the CPU tests run
+    the sharding / broadcast / gather logic with gloo and host tensors. Test infrastructure only."""
+
+    def plan_range_device(self, inp, out, d_begin, d_end, stream=None):
+        rc = lib().evg_oracle_plan_distro_range(C.byref(inp), C.byref(out), d_begin, d_end)
+        assert rc == 0, rc
+
+    def allocate_range_device(self, inp, out, d_begin, d_end, stream=None):
+        rc = lib().evg_oracle_allocate_host_range(C.byref(inp), C.byref(out), d_begin, d_end)
+        assert rc == 0, rc
 
 
 class OracleBackend:
