@@ -44,15 +44,6 @@ constexpr uint32_t UF_MERGE = 1u << 24, UF_PATCH = 2u << 24, UF_NONGROUP = 4u <<
                    UF_STEPBACK = 16u << 24, UF_DISTRO = 32u << 24;
 constexpr uint32_t UF_COUNT_MASK = 0x00FFFFFFu;
 
-// What the generic pipelines (pre -> sort -> mid -> sort -> post) keep per distro between their kernels.
-struct GState {
-  unsigned long long vmin, vmax, dmin, dmax, pmin, pmax;  // biased ranges of the elected values / durations / priorities
-  uint32_t tmin, tmax, nmin, nmax;                        // biased ranges of task-group order / num dependents
-  int32_t bn, bp, bd;                                     // bit widths of the TaskList.Less key fields below the group order
-  int32_t fast;                                           // 1: packed-key sorts are in flight for this distro
-  uint32_t any_mq, n_met, n_mq, n_s3, sec, pad;           // flat pipeline: GetDistroQueueInfo's per-distro flags / counters
-};
-
 struct PlanArgs {
   evg_plan_input in;    // device pointers
   evg_plan_output out;  // device pointers
@@ -71,9 +62,15 @@ struct PlanArgs {
   uint64_t *g_dur, *g_dover;
   int32_t* w_generic;  // [D] 1: the distro was left to k_plan_generic
   void* w_key;         // [2N + 4096] 128-bit sort keys of the generic path (K128)
-  struct GState* w_gstate;  // [D] per-distro state handed between the kernels of the generic pipeline
-  int32_t* w_tiles;    // [2 * max_tiles] (distro, tile) of every 2048-key tile the pipeline's sort kernels work on
-  int32_t* w_ntiles;   // [1] number of registered tiles (zeroed by the LDS-path kernel of the same call)
+  // the many-workgroups-per-distro path for large distros (evg_tiled.hip.h)
+  struct TState* w_ts;         // [D]
+  int32_t *w_rtile, *w_stile;  // (distro, tile) of every row tile / slot tile
+  int32_t* w_ntile;            // [2] their numbers
+  void* w_bucket;              // int2 (offset, count) per (row tile, slot tile) pair
+  void* w_rec;                 // [2N + E] membership records (TRec)
+  int32_t* w_eslot;            // [E] unit slot a dependency edge adds a membership to, or -1
+  void *w_keyA, *w_keyB;       // 192-bit sort keys, ping-pong
+  unsigned long long* w_gfirst;  // [D + n_tg] (first queue position << 32) | TaskGroupMaxHosts of that task
   int32_t d0, d1;      // the distros this call plans: [d0, d1) of the batch (evg_plan_distro_range_device; else 0, D).
                        // Outputs keep the FULL batch's row / info-row numbering.
 #ifdef EVG_PHASE_TIMING
@@ -439,11 +436,7 @@ __device__ __forceinline__ void second_sort_keys(K128* keys, int n, int lo, cons
   }
 }
 
-// STAGE selects the part of the distro's plan this call runs: 0 everything (one workgroup from start to end);
-// 1 "pre": up to the packed keys of the first sort, which the pipeline's sort kernels then spread over all CUs (a distro
-// whose ranges do not pack is finished here by the comparator sort); 3 "post": from the sorted keys to the end.
-// (Stage 2, the run scan between the two sorts, is generic_mid below.)
-template <int STAGE = 0>
+// One workgroup plans the distro from start to end.
 __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem& m, unsigned* s_red, K128* sort_buf = nullptr) {
   using idx_t = Mem::idx_t;
   using k1_t = Mem::k1_t;
@@ -455,7 +448,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem&
   const int lo = c.lo, n = c.n, S = c.S;
 
   EVG_STAMP(0);
-  if (STAGE != 3) {
+  {
   // ---- P0/P1: init accumulators, primary slots ---------------------------------------------------------
   for (int u = tid; u < S; u += kBlock) {
     m.tiq[u] = 0; m.dur[u] = 0; m.maxpri[u] = 0; m.cnt[u] = 0; m.maxnd[u] = 0; m.minrow[u] = 0xFFFFFFFFu;
@@ -567,15 +560,14 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem&
     }
   }
   __syncthreads();  // accumulators are dead from here on
-  }  // STAGE != 3
+  }
 
   EVG_STAMP(5);
   const int P = c.P;
   const uint32_t pad = 0xFFFFFFFFu;
-  if (STAGE != 3)
-    for (int i = tid; i < P; i += kBlock) m.idx[i] = i < n ? (idx_t)i : (idx_t)pad;
+  for (int i = tid; i < P; i += kBlock) m.idx[i] = i < n ? (idx_t)i : (idx_t)pad;
   // group accumulators (rows: standalone + ntg)
-  for (int k = tid; STAGE != 3 && k < c.ntg + 1; k += kBlock) {
+  for (int k = tid; k < c.ntg + 1; k += kBlock) {
     const int g = m.grow(k - 1);
     m.g_cnt[g] = 0; m.g_cover[g] = 0; m.g_wait[g] = 0; m.g_mq[g] = 0; m.g_first[g] = 0xFFFFFFFFu;
     m.g_dur[g] = 0; m.g_dover[g] = 0;
@@ -587,15 +579,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem&
   // (2) by [run start | TaskList.Less key | row]: order inside each unit. Needs the value range of the distro to fit
   // 55 bits and the TaskList.Less ranges to fit 64 bits; otherwise the comparator sort below runs instead.
   bool sorted_fast = false;
-  if (STAGE == 3) {
-    if (!a.w_gstate[d].fast) return;  // finished by the pre kernel
-    const K128* keys = (const K128*)a.w_key + 2 * (size_t)lo;
-    for (int q = tid; q < n; q += kBlock) m.idx[q] = (idx_t)(keys[q].lo & 0xFFFFFFu);
-    __syncthreads();
-    sorted_fast = true;
-  }
-  if (STAGE == 1 && tid == 0) a.w_gstate[d].fast = 0;
-  if (STAGE != 3 && sort_buf && a.w_key && P >= 2048) {
+  if (sort_buf && a.w_key && P >= 2048) {
     unsigned long long* r64 = (unsigned long long*)(s_red + 16);  // vmin vmax dmin dmax pmin pmax
     uint32_t* r32 = s_red + 28;                                   // tmin tmax nmin nmax
     __syncthreads();
@@ -636,17 +620,6 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem&
           k.lo = ((mr & 0x7FFFu) << 49) | (sl << 24) | (uint64_t)i;    // [min row, lower 15][slot : 25][row : 24]
         }
         keys[i] = k;
-      }
-      if (STAGE == 1) {  // hand the distro's tiles to the sort kernels
-        if (tid == 0) {
-          GState g{};
-          g.vmax = vmax; g.dmax = dmax; g.pmax = pmax; g.tmin = tmin; g.nmax = nmax; g.bn = bn; g.bp = bp; g.bd = bd; g.fast = 1;
-          a.w_gstate[d] = g;
-          const int nt = P >> 11;
-          const int base = atomicAdd(a.w_ntiles, nt);
-          for (int k = 0; k < nt; k++) { a.w_tiles[2 * (base + k)] = d; a.w_tiles[2 * (base + k) + 1] = k; }
-        }
-        return;
       }
       __syncthreads();
       tiled_sort_k128(keys, P, sort_buf);

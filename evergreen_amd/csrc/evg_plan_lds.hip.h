@@ -30,6 +30,7 @@
 
 #include "evg_alloc.hip.h"
 #include "evg_kernels.hip.h"
+#include "evg_tiled.hip.h"
 
 namespace evg {
 
@@ -908,7 +909,6 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const Pla
   const AllocArgs none{};
   const bool done = fits_lds_path(c) && plan_distro_lds<RICH, false>(a, none, c, smem, s_red);
   if (threadIdx.x == 0) a.w_generic[d] = done ? 0 : 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *a.w_ntiles = 0;  // consumed by the generic pipeline enqueued behind this kernel
 }
 
 // The batched tick in one launch: plan every distro AND run its host allocator (evg_plan_allocate_device).
@@ -928,10 +928,8 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const Fu
   EVG_STAMP(0);
   const bool done = fits_lds_path(c) && plan_distro_lds<RICH, true>(f.p, f.q, c, smem, s_red);
   if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *f.p.w_ntiles = 0;
 }
 
-template <int STAGE = 0>
 __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c, unsigned* s_red, K128* sort_buf) {
   const int d = c.d;
   const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // disjoint slot range of this distro
@@ -946,7 +944,7 @@ __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c
   m.g_cnt = a.g_cnt; m.g_cover = a.g_cover; m.g_wait = a.g_wait; m.g_mq = a.g_mq; m.g_first = a.g_first;
   m.g_dur = a.g_dur; m.g_dover = a.g_dover;
   m.g0 = d; m.gk = c.D + c.tg_lo;
-  plan_distro<STAGE>(a, c, m, s_red, sort_buf);
+  plan_distro(a, c, m, s_red, sort_buf);
 }
 
 // One workgroup per distro the LDS path left over (none in the headline configuration): every intermediate lives
@@ -955,8 +953,8 @@ __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c
 // the normal case -- the launch costs a quarter of a one-workgroup-per-distro grid.
 constexpr int kGenericGrid = 128;
 constexpr int kGenericLds = 2048 * 16;  // one tile of 128-bit keys
-// skip_flat: the flat pipeline (evg_generic_flat.hip.h) ran first and finished the large distros whose keys packed.
-__global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a, int skip_flat) {
+// skip_tiled: the tiled pipeline (evg_tiled.hip.h) ran first and finished the large distros it could take.
+__global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a, int skip_tiled) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
   // Almost always nothing is flagged: find that out with ONE round trip (independent loads) instead of one per distro.
@@ -965,80 +963,12 @@ __global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a, int s
   if (!any) return;
   for (int d = a.d0 + blockIdx.x; d < a.d1; d += gridDim.x) {
     if (!a.w_generic[d]) continue;
-    if (skip_flat && a.in.task_off[d + 1] - a.in.task_off[d] > 1024 && a.w_gstate[d].fast) continue;
+    if (skip_tiled && tiled_done(a, d)) continue;
     const DC c = distro_context(a, d);
     __syncthreads();
     if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
     __syncthreads();
     plan_generic_body(a, c, s_red, (K128*)gsm);
-  }
-}
-
-// ---- the staged generic pipeline: pre -> [sort] -> mid -> [sort] -> post -----------------------------------------------
-// For distros that need the generic path AND are large, the two packed-key sorts are the bulk of the work; run inside the
-// distro's single workgroup they leave most of the chip idle. The pipeline keeps the per-distro phases on one workgroup
-// (pre / mid / post, strided over the flagged distros) and spreads the sorts over every CU: one workgroup per 2048-key
-// tile (k_gsort_tiles, k_gsort_merge) and per 1024 pairs of a cross-tile stage (k_gsort_global).
-template <int STAGE>
-__global__ void __launch_bounds__(kBlock) k_generic_stage(const PlanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
-  for (int d = a.d0 + blockIdx.x; d < a.d1; d += gridDim.x) {
-    if (!a.w_generic[d]) continue;
-    const DC c = distro_context(a, d);
-    __syncthreads();
-    if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
-    __syncthreads();
-    if (STAGE == 2) {
-      const GState g = a.w_gstate[d];
-      if (g.fast)
-        second_sort_keys((K128*)a.w_key + 2 * (size_t)c.lo, c.n, c.lo, a.in.tasks, g.tmin, g.nmax, g.pmax, g.dmax, g.bn, g.bp, g.bd, (int*)gsm);
-    } else {
-      plan_generic_body<STAGE>(a, c, s_red, (K128*)gsm);
-    }
-  }
-}
-
-// MODE 0: full sort of each registered tile; MODE 1: the in-tile stages of merge kk.
-template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_gsort_tiles(const PlanArgs a, int kk) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-  const int w = blockIdx.x;
-  if (w >= *a.w_ntiles) return;
-  const int d = a.w_tiles[2 * w], tile = a.w_tiles[2 * w + 1];
-  const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo;
-  int P = 1;
-  while (P < n) P <<= 1;
-  if (MODE == 1 && kk > P) return;
-  K128* keys = (K128*)a.w_key + 2 * (size_t)lo + (size_t)tile * 2048;
-  const int tid = threadIdx.x;
-  K128 k[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) k[e] = keys[tid * 4 + e];
-  if (MODE == 0) bitonic_sort4_fixed<2048, K128>(k, tid, (K128*)gsm, (K128*)gsm, tile * 2048);
-  else bitonic_merge4_fixed<2048, K128>(k, tid, (K128*)gsm, ((tile * 2048) & kk) == 0);
-#pragma unroll
-  for (int e = 0; e < 4; e++) keys[tid * 4 + e] = k[e];
-}
-
-// One cross-tile stage (partner distance j >= 2048) of merge kk: workgroup (distro, tile) takes 1024 of the distro's P/2 pairs.
-__global__ void __launch_bounds__(kBlock) k_gsort_global(const PlanArgs a, int kk, int j) {
-  const int w = blockIdx.x;
-  if (w >= *a.w_ntiles) return;
-  const int d = a.w_tiles[2 * w], tile = a.w_tiles[2 * w + 1];
-  const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo;
-  int P = 1;
-  while (P < n) P <<= 1;
-  if (kk > P) return;
-  K128* keys = (K128*)a.w_key + 2 * (size_t)lo;
-#pragma unroll
-  for (int r = 0; r < 2; r++) {
-    const int t = tile * 1024 + r * kBlock + threadIdx.x;  // pair index in [0, P/2)
-    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-    const int x = i | j;
-    const K128 ka = keys[i], kb = keys[x];
-    const bool asc = (i & kk) == 0;
-    if (key_lt(kb, ka) == asc) { keys[i] = kb; keys[x] = ka; }
   }
 }
 

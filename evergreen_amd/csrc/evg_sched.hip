@@ -18,7 +18,6 @@
 
 #include "evg_alloc.hip.h"
 #include "evg_plan_lds.hip.h"
-#include "evg_generic_flat.hip.h"
 #include "evg_dispatch.hip.h"
 
 namespace evg {
@@ -289,10 +288,11 @@ struct evg_ctx {
   std::mutex mu;
   hipStream_t stream = nullptr;  // used by the host-pointer entry points
   // scratch of the large-distro path + allocator
-  std::vector<DevBuf> scratch = std::vector<DevBuf>(32);  // 0-23 planner, 24-27 allocator, 28 dispatcher
+  std::vector<DevBuf> scratch = std::vector<DevBuf>(48);  // 0-23 planner, 24-27 allocator, 28 dispatcher, 32-41 tiled path
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
+  bool tiled_attr_set = false;
   bool dispatch_attr_set = false;
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts = nullptr;
@@ -490,12 +490,11 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.out = *out;
   a.d0 = 0;
   a.d1 = D;
-  // scratch of the large-distro path (untouched pages cost nothing; small distros never use it)
-  size_t sz[24] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
+  // scratch of the generic path (untouched pages cost nothing; small distros never use it)
+  size_t sz[22] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
                    4 * (N + 1), 8 * (N + 1), 8 * (N + 1), 8 * (N + 1), 4 * (N + 1),
-                   4 * G, 4 * G, 4 * G, 4 * G, 4 * G, 8 * G, 8 * G, 4 * (size_t)D, 16 * (2 * N + 4096),
-                   sizeof(GState) * (size_t)D, 8 * (2 * N / 2048 + (size_t)D + 8)};
-  for (int i = 0; i < 24; i++) {
+                   4 * G, 4 * G, 4 * G, 4 * G, 4 * G, 8 * G, 8 * G, 4 * (size_t)D, 16 * (2 * N + 4096)};
+  for (int i = 0; i < 22; i++) {
     int rc = ensure(c, c->scratch[i], sz[i]);
     if (rc) return rc;
   }
@@ -509,9 +508,8 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.g_dover = (uint64_t*)c->scratch[19].p;
   a.w_generic = (int32_t*)c->scratch[20].p;
   a.w_key = c->scratch[21].p;
-  a.w_gstate = (GState*)c->scratch[22].p;
-  a.w_tiles = (int32_t*)c->scratch[23].p;
-  a.w_ntiles = a.w_tiles + 2 * (2 * N / 2048 + (size_t)D + 4);
+  a.w_ts = nullptr; a.w_rtile = nullptr; a.w_stile = nullptr; a.w_ntile = nullptr; a.w_bucket = nullptr; a.w_rec = nullptr;
+  a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr;
 #ifdef EVG_PHASE_TIMING
   a.dbg_ts = c->dbg_ts;
 #endif
@@ -549,57 +547,64 @@ static int prepare_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_
   return EVG_OK;
 }
 
-// The generic path behind the LDS kernel. evg_plan_input.max_distro_tasks (0 = unknown) tells how large a distro can
-// be: with every distro <= 2048 tasks only data-dependent fallbacks can be flagged and one kernel finishes them; otherwise
-// the staged pipeline spreads the packed-key sorts of the large distros over all CUs. The launches are unconditional
-// (nothing is read back); kernels of stages that have no work exit at once.
-static int launch_generic(evg_ctx* c, const evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st) {
+// Scratch of the tiled large-distro path (evg_tiled.hip.h); sized from host-known totals, allocated on first need.
+static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in) {
   using namespace evg;
-  const int D = in->n_distros;
+  const size_t N = (size_t)in->tasks.n_tasks, E = (size_t)in->tasks.n_edges, D = (size_t)in->n_distros;
+  const size_t Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions, G = D + (size_t)in->n_task_groups;
+  const size_t max_rt = N / kRT + D + 1, max_st = Stot / kST + D + 1;
+  const size_t st_cap = std::min<size_t>(max_st, kMaxST);  // slot tiles of ONE distro
+  const size_t sz[10] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
+                         4 * (E + 1), sizeof(K192) * max_rt * kRT, sizeof(K192) * max_rt * kRT, 8 * G};
+  for (int i = 0; i < 10; i++) {
+    int rc = ensure(c, c->scratch[32 + i], sz[i]);
+    if (rc) return rc;
+  }
+  a.w_ts = (TState*)c->scratch[32].p; a.w_rtile = (int32_t*)c->scratch[33].p; a.w_stile = (int32_t*)c->scratch[34].p;
+  a.w_ntile = (int32_t*)c->scratch[35].p; a.w_bucket = c->scratch[36].p; a.w_rec = c->scratch[37].p;
+  a.w_eslot = (int32_t*)c->scratch[38].p; a.w_keyA = c->scratch[39].p; a.w_keyB = c->scratch[40].p;
+  a.w_gfirst = (unsigned long long*)c->scratch[41].p;
+  if (!c->tiled_attr_set) {
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledReduceLds));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_elect, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_merge, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
+    c->tiled_attr_set = true;
+  }
+  return EVG_OK;
+}
+
+// The distros the LDS kernel flagged (on the device; nothing is read back, so everything below is launched
+// unconditionally and exits at once where there is no work). evg_plan_input.max_distro_tasks (0 = unknown) only shapes
+// the launch, never the result:
+//   hint <= 2048  only data-dependent fallbacks can be flagged: ONE kernel, one workgroup per flagged distro (k_plan_generic);
+//   otherwise     the tiled pipeline (evg_tiled.hip.h, many workgroups per distro) with the number of merge passes the hint
+//                 (or, without a hint, the task count) allows, then k_plan_generic for whatever the pipeline left: small
+//                 flagged distros, distros it cannot take, and distros larger than the hint promised.
+// TaskPlan.Len() (out->n_units) needs the set-equality pass that only the one-workgroup kernel has.
+static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st) {
+  using namespace evg;
+  const int D = a.d1 - a.d0;
   const dim3 gg(D < kGenericGrid ? D : kGenericGrid), bb(kBlock);
   const long long hint = in->max_distro_tasks > 0 ? in->max_distro_tasks : in->tasks.n_tasks;
-  if (hint <= 2048) {
+  if (hint <= kRT || a.out.n_units) {
     hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 0);
     HIP_TRY(c, hipGetLastError());
     return EVG_OK;
   }
-  long long pmax = 2048;
-  while (pmax < hint) pmax <<= 1;
-  const int max_tiles = (int)(2 * (size_t)in->tasks.n_tasks / 2048 + (size_t)D + 4);
-  auto sort_all = [&]() {
-    hipLaunchKernelGGL(k_gsort_tiles<0>, dim3(max_tiles), bb, kGenericLds, st, a, 0);
-    for (long long kk = 4096; kk <= pmax; kk <<= 1) {
-      for (long long j = kk >> 1; j >= 2048; j >>= 1) hipLaunchKernelGGL(k_gsort_global, dim3(max_tiles), bb, 0, st, a, (int)kk, (int)j);
-      hipLaunchKernelGGL(k_gsort_tiles<1>, dim3(max_tiles), bb, kGenericLds, st, a, (int)kk);
-    }
-  };
-  if (a.out.n_units) {
-    // TaskPlan.Len() needs the set-equality pass of the one-workgroup form: staged per-distro pipeline
-    hipLaunchKernelGGL(k_generic_stage<1>, gg, bb, kGenericLds, st, a);
-    sort_all();
-    hipLaunchKernelGGL(k_generic_stage<2>, gg, bb, kGenericLds, st, a);
-    sort_all();
-    hipLaunchKernelGGL(k_generic_stage<3>, gg, bb, kGenericLds, st, a);
-    HIP_TRY(c, hipGetLastError());
-    return EVG_OK;
-  }
-  // flat pipeline: every phase of the large flagged distros over the whole chip
+  int rc = prepare_tiled(c, a, in);
+  if (rc) return rc;
+  const long long cap = hint < kTiledMaxRows ? hint : kTiledMaxRows - 1;
+  int passes = 0;
+  while (((long long)kRT << passes) < cap) passes++;
   const size_t N = (size_t)in->tasks.n_tasks, Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions;
-  auto blocks = [](size_t n) { return dim3((unsigned)((n + kFlatBlock - 1) / kFlatBlock)); };
-  const dim3 fb(kFlatBlock);
-  hipLaunchKernelGGL(k_flat_init, dim3(1024), fb, 0, st, a);
-  hipLaunchKernelGGL(k_flat_reduce, blocks(N), fb, 0, st, a);
-  hipLaunchKernelGGL(k_flat_score, blocks(Stot), fb, 0, st, a);
-  hipLaunchKernelGGL(k_flat_elect, blocks(N), fb, 0, st, a);
-  hipLaunchKernelGGL(k_flat_keys, blocks(2 * N), fb, 0, st, a);
-  sort_all();
-  hipLaunchKernelGGL(k_generic_stage<2>, gg, bb, kGenericLds, st, a);
-  sort_all();
-  hipLaunchKernelGGL(k_flat_order, blocks(N), fb, 0, st, a);
-  hipLaunchKernelGGL(k_flat_deps_met, blocks(N), fb, 0, st, a);
-  hipLaunchKernelGGL(k_flat_sums, blocks(N), fb, 0, st, a);
-  hipLaunchKernelGGL(k_flat_rows, gg, fb, 0, st, a);
-  // flagged distros that are small, or whose ranges did not pack
+  const dim3 rt((unsigned)(N / kRT + D + 1)), stl((unsigned)(Stot / kST + D + 1)), tb(kTiledBlock);
+  hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, st, a, passes);
+  hipLaunchKernelGGL(k_tiled_scatter, rt, tb, 0, st, a);
+  hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, st, a);
+  hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, st, a);
+  for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, st, a, p);
+  hipLaunchKernelGGL(k_tiled_finish, rt, tb, 0, st, a);
+  hipLaunchKernelGGL(k_tiled_rows, gg, dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 1);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
