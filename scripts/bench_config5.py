@@ -13,7 +13,7 @@ ctx = native.Context(0)
 pool = resident.ResidentPool(ctx, b, torch.device("cuda:0"))
 pool.step(fused=False); torch.cuda.synchronize()
 t0 = time.perf_counter()
-K = 3
+K = int(sys.argv[sys.argv.index('--steps') + 1]) if '--steps' in sys.argv else 3
 for _ in range(K):
     pool.step(fused=False)
 torch.cuda.synchronize()
