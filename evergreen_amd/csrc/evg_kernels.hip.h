@@ -88,6 +88,15 @@ struct PlanArgs {
 #define EVG_STAMP(k) do {} while (0)
 #endif
 
+// Diagnostics builds only (scripts/ablate.sh): -DEVG_STOP_AFTER=k ends the LDS path at phase boundary k, so that the
+// launch durations of a series of builds give each phase's marginal cost with both workgroups of a CU running (the
+// stamps of EVG_PHASE_TIMING add barriers and cannot see what the neighbour workgroup costs). Results are garbage.
+#ifdef EVG_STOP_AFTER
+#define EVG_STOP(k) do { if ((k) == EVG_STOP_AFTER) return true; } while (0)
+#else
+#define EVG_STOP(k) do {} while (0)
+#endif
+
 // Kernel arguments the late phases need, fetched late. The compiler loads the whole argument block at the top of a kernel
 // and keeps it in SGPRs; the planner has ~30 pointers in there and spills SGPRs into VGPR lanes (v_writelane / v_readlane
 // on the VALU it is bound by). EVG_LATE_ARG reads one field of the FIRST kernel argument (a PlanArgs) from the kernarg
@@ -259,7 +268,104 @@ __device__ __forceinline__ int64_t target_time_for_queue(const evg_distro_params
 
 namespace evg {
 
-// unitInfo.value()  planner.go:209-300. bd == nullptr: only TotalValue.
+// ---- unitInfo.value()  planner.go:209-300 -------------------------------------------------------------------------
+// The three time terms, as the Go code states them (IEEE fp64 divisions, 64-bit integer divisions):
+//   floor(Duration.Minutes() / float64(n))         expected runtime, patch time in queue   (:231, :262)
+//   tiq / n ; int64((week - avg).Hours())          mainline time in queue                  (:243-247)
+struct UnitTimeTerms {
+  int64_t rt_minutes;   // floor(dur.Minutes() / n)
+  int64_t pw_minutes;   // floor(tiq.Minutes() / n)            (patch units)
+  int64_t main_hours;   // int64((week - tiq/n).Hours())       (mainline units with tiq/n < one week: main_on)
+  bool main_on;
+};
+__device__ __forceinline__ int64_t floor_minutes_per(int64_t d, int64_t n) { return (int64_t)floor(dur_minutes(d) / (double)n); }
+__device__ __forceinline__ void main_hours_of(int64_t tiq, int64_t n, UnitTimeTerms& o) {
+  const int64_t avg = tiq / n;
+  o.main_on = avg < 7 * 24 * kHour;
+  o.main_hours = o.main_on ? (int64_t)dur_hours(wrap_sub(7 * 24 * kHour, avg)) : 0;
+}
+
+// The same three terms without the IEEE division sequences and without a 64-bit integer division (they were ~300 of the
+// ~425 VALU instructions of one scoring trip). MI355X issues an fp64 FMA at the rate of an int32 add, so exact integer
+// arithmetic on doubles below 2^53 is the cheap form of "64-bit" here. For 0 <= X < 2^53 ns and 1 <= n < 2^24:
+//
+//  * Go's  b = RN(RN(m + RN(ns / 6e10)) / n)  with m = X / 6e10, ns = X % 6e10 is monotone in X, equals q exactly at
+//    X = q * 6e10 * n and q + 1 at (q + 1) * 6e10 * n, so floor(b) is q = floor(X / (6e10 n)) unless b rounds up to q + 1
+//    exactly; its three roundings are within (1 + 2^-53)^3 of the true quotient, so that needs
+//    (6e10 n - X mod (6e10 n)) <= X * 2^-51.9 + 6e10 n * 2^-52.9. The fast path computes q exactly (estimate by a
+//    reciprocal, exact remainder by one FMA -- the remainder is an integer below 2^53 -- one correction step) and hands
+//    every lane within 16x that margin of the boundary to the Go-shaped code above: bit-exact by construction, the
+//    estimate's accuracy only decides how often the slow code runs (never, in practice).
+//  * int64((week - avg).Hours()) = (week - avg) / hour for 0 <= week - avg < 4096 h: the fraction added to the whole hours
+//    is at most 1 - 2.7e-13 and ulp(h + f) <= 2^-41 there, so the sum never rounds up to h + 1. avg = floor(X / n) by a
+//    two-step reciprocal estimate with exact FMA remainders (first-step error <= 8, second step exact after one fix-up).
+//
+// evg_selftest_unit_value (tests/test_gpu_parity.py) sweeps both forms against each other on the device: every n up to
+// 2^16 against quotient boundaries +- a few ns, random (X, n) pairs over all magnitudes, the slow-path hand-over included.
+__device__ __forceinline__ double u53_to_double(int64_t x) {  // exact for 0 <= x < 2^53
+  return __builtin_fma((double)(uint32_t)((uint64_t)x >> 32), 4294967296.0, (double)(uint32_t)x);
+}
+__device__ __forceinline__ UnitTimeTerms unit_time_terms(int64_t n, int64_t tiq, int64_t dur, bool in_patch, bool in_cq) {
+  UnitTimeTerms o{0, 0, 0, false};
+  bool slow = (((uint64_t)tiq | (uint64_t)dur) >> 53) != 0;  // negative or huge sums: the Go-shaped code
+  if (!slow) {
+    const double nd = (double)(int32_t)n;
+    double y = __builtin_amdgcn_rcp(nd);  // ~1/n; two Newton steps take it to 2^-52 whatever the instruction's accuracy
+    y = __builtin_fma(__builtin_fma(-nd, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-nd, y, 1.0), y, y);
+    const double Dv = nd * 6e10;                 // exact: 6e10 = 2^10 * 58593750, n < 2^24
+    const double yc = y * (1.0 / 6e10);          // ~1 / Dv
+    auto minutes_per = [&](double X) {           // floor(X / Dv), exact; flags the lanes near a quotient boundary
+      double q = __builtin_trunc(X * yc);
+      double r = __builtin_fma(-q, Dv, X);       // exact: an integer of magnitude < 2^53
+      const bool lo = r < 0.0, hi = r >= Dv;
+      q = lo ? q - 1.0 : hi ? q + 1.0 : q;
+      r = lo ? r + Dv : hi ? r - Dv : r;
+      slow |= Dv - r <= __builtin_fma(X + Dv, 0x1p-48, 16.0);
+      return (int64_t)(int32_t)q;                // < 2^53 / 6e10 < 2^18
+    };
+    o.rt_minutes = minutes_per(u53_to_double(dur));
+    if (in_patch) {
+      o.pw_minutes = minutes_per(u53_to_double(tiq));
+    } else if (!in_cq) {
+      const double X = u53_to_double(tiq);
+      const double q1 = __builtin_trunc(X * y);
+      const double r1 = __builtin_fma(-q1, nd, X);      // exact, |r1| <= 9 n
+      double q2 = __builtin_floor(r1 * y);
+      const double r2 = __builtin_fma(-q2, nd, r1);
+      q2 = r2 < 0.0 ? q2 - 1.0 : r2 >= nd ? q2 + 1.0 : q2;
+      const double avg = q1 + q2;                       // tiq / n
+      const double kWeek = 604800e9, kHourD = 3600e9;
+      if (avg < kWeek) {
+        const double z = kWeek - avg;
+        double h = __builtin_trunc(z * (1.0 / 3600e9));
+        const double rh = __builtin_fma(-h, kHourD, z);
+        h = rh < 0.0 ? h - 1.0 : rh >= kHourD ? h + 1.0 : h;
+        o.main_hours = (int64_t)(int32_t)h;             // <= 168
+        o.main_on = true;
+      }
+    }
+  }
+  if (slow) {  // rare, per lane
+    o.rt_minutes = floor_minutes_per(dur, n);
+    o.pw_minutes = 0;
+    o.main_hours = 0;
+    o.main_on = false;
+    if (in_patch) o.pw_minutes = floor_minutes_per(tiq, n);
+    else if (!in_cq) main_hours_of(tiq, n, o);
+  }
+  return o;
+}
+// The Go-shaped terms only (the self-test's reference side).
+__device__ __forceinline__ UnitTimeTerms unit_time_terms_go(int64_t n, int64_t tiq, int64_t dur, bool in_patch, bool in_cq) {
+  UnitTimeTerms o{floor_minutes_per(dur, n), 0, 0, false};
+  if (in_patch) o.pw_minutes = floor_minutes_per(tiq, n);
+  else if (!in_cq) main_hours_of(tiq, n, o);
+  return o;
+}
+
+// bd == nullptr: only TotalValue. GO_FORM: every step as the Go code states it (self-test reference).
+template <bool GO_FORM = false>
 __device__ inline int64_t unit_value(const evg_distro_params& p, int64_t n, int64_t tiq, int64_t dur, int64_t maxpri,
                                      int64_t maxnd, uint32_t fl, int64_t* bd) {
   const bool in_cq = fl & UF_MERGE, in_patch = fl & UF_PATCH, nongroup = fl & UF_NONGROUP, gen = fl & UF_GENERATE,
@@ -276,21 +382,20 @@ __device__ inline int64_t unit_value(const evg_distro_params& p, int64_t n, int6
   }
   if (in_cq) { b_cq = 200; pri = wrap_add(pri, 200); }
   // computeRankValue :223-265
+  const UnitTimeTerms tt = GO_FORM ? unit_time_terms_go(n, tiq, dur, in_patch, in_cq) : unit_time_terms(n, tiq, dur, in_patch, in_cq);
   int64_t r_patch = 0, r_patchwait = 0, r_cq = 0, r_main = 0, r_step = 0;
   if (in_patch) {
     r_patch = getter(p.patch_factor);
-    r_patchwait = wrap_mul(getter(p.patch_time_in_queue_factor), (int64_t)floor(dur_minutes(tiq) / (double)n));
+    r_patchwait = wrap_mul(getter(p.patch_time_in_queue_factor), tt.pw_minutes);
   } else if (in_cq) {
     r_cq = getter(p.commit_queue_factor);
   } else {
-    int64_t avg = tiq / n;
-    if (avg < 7 * 24 * kHour)
-      r_main = wrap_mul(getter(p.mainline_time_in_queue_factor), (int64_t)dur_hours(wrap_sub(7 * 24 * kHour, avg)));
+    if (tt.main_on) r_main = wrap_mul(getter(p.mainline_time_in_queue_factor), tt.main_hours);
     if (stepback) r_step = getter(p.stepback_task_factor);
   }
   double ndf = p.num_dependents_factor <= 0 ? 1.0 : p.num_dependents_factor;
   int64_t r_nd = (int64_t)(ndf * (double)maxnd);
-  int64_t r_rt = wrap_mul(getter(p.expected_runtime_factor), (int64_t)floor(dur_minutes(dur) / (double)n));
+  int64_t r_rt = wrap_mul(getter(p.expected_runtime_factor), tt.rt_minutes);
   int64_t rank = 1;
   rank = wrap_add(rank, r_patch); rank = wrap_add(rank, r_patchwait); rank = wrap_add(rank, r_main);
   rank = wrap_add(rank, r_cq); rank = wrap_add(rank, r_step); rank = wrap_add(rank, r_nd); rank = wrap_add(rank, r_rt);

@@ -286,7 +286,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   }
   if (tid < 4) s_rng[tid] = (tid & 1) ? 0ull : ~0ull;
   if (tid < 6) s_r32[tid] = (tid & 1) ? 0u : ~0u;
-  EVG_STAMP(1);
+  EVG_STAMP(1); EVG_STOP(1);
   __syncthreads();
 
   // ---- B: resolve the edge records; segmented reduce of Unit.info (planner.go:302-337) -------------------------
@@ -343,7 +343,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       m.edge[x] = (uint16_t)rec;
     }
   }
-  EVG_STAMP(2);
+  EVG_STAMP(2); EVG_STOP(2);
   EVG_PRIO(5);
   __syncthreads();
 
@@ -359,7 +359,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     if (nu > 0 && (cw & UF_DISTRO)) v = unit_value(p, nu, m.tiq[u], m.dur[u], (int64_t)m.maxpri[u], (int64_t)m.maxnd[u], cw, nullptr);
     m.val[u] = v;
   }
-  EVG_STAMP(3);
+  EVG_STAMP(3); EVG_STOP(3);
   __syncthreads();
 
   // ---- C' (RICH, optional): TaskPlan.Len() after UnitCache.Export's set-equality dedup (planner.go:73-89) ----
@@ -400,7 +400,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     __syncthreads();
     if (tid == 0) a.out.n_units[d] = (int32_t)s_red[7];
   }
-  EVG_STAMP(4);
+  EVG_STAMP(4); EVG_STOP(4);
 
   // ---- D: elect each task's emitting unit ------------------------------------------------------------------
   int64_t bv[4];
@@ -457,7 +457,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   EVG_OPAQUE_ZERO(late1);
   load4(EVG_LATE_ARG(const int64_t*, in.tasks.scheduled_ts_ns, late1) + lo, i0, n, (int64_t)0, sched);
   load4(EVG_LATE_ARG(const int64_t*, in.tasks.deps_met_ts_ns, late1) + lo, i0, n, (int64_t)0, dmt);
-  EVG_STAMP(5);
+  EVG_STAMP(5); EVG_STOP(5);
   EVG_PRIO(10);
   __syncthreads();  // accumulators are dead from here on
 
@@ -489,7 +489,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       const int i = i0 + e;
       k[e] = i < n ? ((vmax - ub(bv[e])) << 34) | ((uint64_t)bm[e] << 23) | ((uint64_t)bs[e] << 11) | (uint64_t)i : ~0ull;
     }
-    EVG_STAMP(6);
+    EVG_STAMP(6); EVG_STOP(6);
     if (P == 2048) bitonic_sort4_fixed<2048, uint64_t, 11>(k, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
     else bitonic_sort4<uint64_t>(k, P, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
 #pragma unroll
@@ -501,12 +501,12 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       const int i = i0 + e;
       k[e] = i < n ? K128{vmax - ub(bv[e]), ((uint64_t)bm[e] << 23) | ((uint64_t)bs[e] << 11) | (uint64_t)i} : K128{~0ull, ~0ull};
     }
-    EVG_STAMP(6);
+    EVG_STAMP(6); EVG_STOP(6);
     bitonic_sort4<K128>(k, P, tid, (K128*)(smem + X_BUF0), (K128*)(smem + X_BUF0));
 #pragma unroll
     for (int e = 0; e < 4; e++) srt[e] = (uint32_t)k[e].lo & 0x7FFFFFu;
   }
-  EVG_STAMP(7);
+  EVG_STAMP(7); EVG_STOP(7);
   EVG_PRIO(15);
   __syncthreads();  // the exchange buffers are re-used below
 
@@ -661,7 +661,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     EVG_OPAQUE_ZERO(late2);
     store4(EVG_LATE_ARG(int32_t*, out.order, late2) + lo, i0, n, o4);
   }
-  EVG_STAMP(8);
+  EVG_STAMP(8); EVG_STOP(8);
   EVG_PRIO(16);
 
   // ---- G: GetDistroQueueInfo (scheduler.go:57-178) -----------------------------------------------------------
@@ -710,7 +710,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     for (int e = 0; e < 4; e++) m4[e] = met[e] ? 1 : 0;
     store4(EVG_LATE_ARG(uint8_t*, out.deps_met, late3) + lo, i0, n, m4);
   }
-  EVG_STAMP(9);
+  EVG_STAMP(9); EVG_STOP(9);
   EVG_PRIO(17);
   const bool has_mq = __syncthreads_or(any_mq ? 1 : 0) != 0;  // also orders the zeroing of the group rows
   const int64_t T = target_time_for_queue(p, has_mq);
@@ -773,7 +773,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     if (n_s3) atomicAdd(&s_red[3], n_s3);
   }
   if (__any(sec) && lane == 0) atomicOr(&s_red[4], 1u);
-  EVG_STAMP(10);
+  EVG_STAMP(10); EVG_STOP(10);
   EVG_PRIO(18);
   __syncthreads();
 
@@ -826,7 +826,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     di.n_task_group_infos = (int32_t)s_red[8];
     EVG_LATE_ARG(evg_distro_info*, out.distro_info, late3)[d] = di;
   }
-  EVG_STAMP(11);
+  EVG_STAMP(11); EVG_STOP(11);
   if (FUSED) {
     // ---- H: UtilizationBasedHostAllocator for this distro (evg_alloc.hip.h) ----------------------------------
     const int len_met = (int)s_red[1];

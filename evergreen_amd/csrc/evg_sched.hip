@@ -271,6 +271,72 @@ __global__ void __launch_bounds__(64) k_allocator_report(int D, const int32_t* t
   report[d] = r;
 }
 
+// ---- self-test of the scoring arithmetic (evg_selftest_unit_value) --------------------------------------------------
+// unit_value's fast time terms against the Go-shaped statement of the same formula, all 13 breakdown fields, on inputs
+// built to sit on and around everything the fast form's proof leans on. Case i (grid-stride):
+//   class 0  quotient boundaries: X = k * 6e10 * n + delta, every n in [1, 65536], |delta| <= 80 ns (inside and outside the
+//            hand-over margin), k spread over the magnitudes reachable below 2^53;
+//   class 1  random X below 2^b, b in [1, 53], random n below 2^nb, nb in [1, 24];
+//   class 2  mainline boundaries: X = n * (week - h * hour + e) + delta around every whole hour h in [0, 168];
+//   class 3  negative / beyond-2^53 sums (the Go-shaped code must take over).
+__global__ void k_selftest_unit_value(uint64_t seed, uint64_t n_cases, unsigned long long* out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long bad = 0, first = ~0ull;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cases; i += stride) {
+    const uint64_t h0 = mix64(seed ^ i), h1 = mix64(h0), h2 = mix64(h1), h3 = mix64(h2), h4 = mix64(h3);
+    const uint32_t cls = (uint32_t)(i & 3);
+    int64_t n, X[2];
+    const uint64_t lim = 1ull << 53;
+    if (cls == 0) {
+      n = 1 + (int64_t)((i >> 2) & 0xFFFF);
+      const uint64_t Dv = (uint64_t)n * 60000000000ull;
+      const uint64_t kmax = (lim - 1) / Dv;  // >= 2 for n <= 65536
+      for (int w = 0; w < 2; w++) {
+        const uint64_t hh = w ? h2 : h1;
+        const uint64_t k = (1 + (hh >> 8) % kmax) >> (((hh >> 2) & 31) % 18);  // quotients of every magnitude (0 -> 1 below)
+        const int64_t delta = (int64_t)(hh >> 40) % 161 - 80;
+        int64_t x = (int64_t)((k ? k : 1) * Dv) + delta;
+        X[w] = x < 0 ? 0 : x >= (int64_t)lim ? (int64_t)lim - 1 : x;
+      }
+    } else if (cls == 1) {
+      n = 1 + (int64_t)((h0 >> 8) & ((1ull << (1 + (h0 & 0xFF) % 24)) - 1));
+      if (n >= (1 << 24)) n = (1 << 24) - 1;
+      X[0] = (int64_t)(h1 & ((1ull << (1 + (h3 & 0xFF) % 53)) - 1));
+      X[1] = (int64_t)(h2 & ((1ull << (1 + ((h3 >> 8) & 0xFF) % 53)) - 1));
+    } else if (cls == 2) {
+      n = 1 + (int64_t)((h0 >> 8) % ((i & 4) ? 4096 : 12));
+      const int64_t hr = (int64_t)((h0 >> 32) % 170);
+      const int64_t e = (int64_t)((h1 >> 8) % 5) - 2, delta = (int64_t)((h1 >> 16) % 9) - 4;
+      int64_t x = n * (7 * 24 * kHour - hr * kHour + e) + delta;
+      X[0] = x < 0 ? 0 : x;
+      X[1] = (int64_t)(h2 & (lim - 1)) >> ((h2 >> 56) & 31);
+    } else {
+      n = 1 + (int64_t)((h0 >> 8) & 0xFFFF);
+      X[0] = (int64_t)h1;  // any int64, negative half the time
+      X[1] = (h3 & 1) ? (int64_t)h2 : (int64_t)(h2 >> 11);
+    }
+    evg_distro_params p;
+    const int64_t facs[8] = {0, 1, 2, 5, 10, 100, -3, (int64_t)(h4 >> 20)};
+    p.patch_factor = facs[h4 & 7]; p.patch_time_in_queue_factor = facs[(h4 >> 3) & 7]; p.commit_queue_factor = facs[(h4 >> 6) & 7];
+    p.mainline_time_in_queue_factor = facs[(h4 >> 9) & 7]; p.expected_runtime_factor = facs[(h4 >> 12) & 7];
+    p.generate_task_factor = facs[(h4 >> 15) & 7]; p.stepback_task_factor = facs[(h4 >> 18) & 7];
+    const double ndfs[4] = {0.0, 0.5, 2.5, 10.0};
+    p.num_dependents_factor = ndfs[(h4 >> 21) & 3];
+    p.target_time_ns = 0; p.merge_queue_target_time_ns = 0; p.group_versions = 0; p.includes_dependencies = 0;
+    const uint32_t req = (uint32_t)(h3 >> 16) % 3;  // 0 mainline, 1 patch, 2 merge queue
+    const uint32_t fl = (req == 1 ? UF_PATCH : req == 2 ? UF_MERGE : 0u) | ((h3 & 0x100000) ? UF_NONGROUP : 0u) |
+                        ((h3 & 0x200000) ? UF_GENERATE : 0u) | ((h3 & 0x400000) ? UF_STEPBACK : 0u);
+    const int64_t maxpri = (int64_t)((h3 >> 24) & 0x7F), maxnd = (int64_t)((h3 >> 32) & 0xFF);
+    int64_t a[EVG_BREAKDOWN_FIELDS], b[EVG_BREAKDOWN_FIELDS];
+    const int64_t va = unit_value<false>(p, n, X[0], X[1], maxpri, maxnd, fl, a);
+    const int64_t vb = unit_value<true>(p, n, X[0], X[1], maxpri, maxnd, fl, b);
+    bool same = va == vb;
+    for (int k = 0; k < EVG_BREAKDOWN_FIELDS; k++) same &= a[k] == b[k];
+    if (!same) { bad++; first = i < first ? i : first; }
+  }
+  if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first); }
+}
+
 }  // namespace evg
 
 // =============================================================================================================
@@ -385,7 +451,7 @@ static evg_plan_input stage_plan_input(Stager& s, const evg_plan_input* in) {
 
 extern "C" {
 
-int32_t evg_abi_version(void) { return (1 << 16) | 1; }
+int32_t evg_abi_version(void) { return (1 << 16) | 2; }
 
 #ifdef EVG_PHASE_TIMING
 // diagnostics build only (scripts/phase_timing.py): device buffer of D x 16 s_memtime stamps
@@ -434,6 +500,23 @@ void evg_destroy(evg_ctx* c) {
   for (auto& b : c->stage) if (b.p) (void)hipFree(b.p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+int evg_selftest_unit_value(evg_ctx* c, uint64_t seed, uint64_t n_cases, uint64_t* mismatches, uint64_t* first_bad_case) {
+  if (!c || !mismatches) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure(c, c->scratch[29], 16);
+  if (rc) return rc;
+  unsigned long long h[2] = {0, ~0ull};
+  HIP_TRY(c, hipMemcpyAsync(c->scratch[29].p, h, 16, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(evg::k_selftest_unit_value, dim3(4096), dim3(256), 0, c->stream, seed, n_cases, (unsigned long long*)c->scratch[29].p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(h, c->scratch[29].p, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *mismatches = h[0];
+  if (first_bad_case) *first_bad_case = h[1];
+  return EVG_OK;
 }
 
 int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len) {

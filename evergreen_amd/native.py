@@ -22,7 +22,7 @@ EXPORTS = [
     "evg_cap_queue_device", "evg_plan_allocate_device", "evg_materialize_queue_device",
     "evg_allocator_report_device", "evg_filter_runnable_device", "evg_dispatch_order_device",
     "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
-    "evg_plan_distro_range_device", "evg_allocate_host_range_device",
+    "evg_plan_distro_range_device", "evg_allocate_host_range_device", "evg_selftest_unit_value",
 ]
 
 _lib = None
@@ -78,6 +78,8 @@ def load_library() -> C.CDLL:
     lib.evg_allocator_report.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
     lib.evg_cap_queue_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p]
+    if hasattr(lib, "evg_selftest_unit_value"):  # absent from older builds loaded through EVG_SCHED_LIB (A/B runs)
+        lib.evg_selftest_unit_value.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
 
@@ -108,6 +110,12 @@ class Context:
         if rc != abi.EVG_OK:
             msg = self.lib.evg_last_error(self.h)
             raise NativeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def selftest_unit_value(self, n_cases: int, seed: int = 0x5EED):
+        """evg_selftest_unit_value: (mismatching cases, index of the first one or None)."""
+        bad, first = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.evg_selftest_unit_value(self.h, seed, n_cases, C.byref(bad), C.byref(first)), "evg_selftest_unit_value")
+        return int(bad.value), (int(first.value) if bad.value else None)
 
     # ---- scheduler.Backend -------------------------------------------------------------------
     def plan(self, batch: abi.PlanBatch, breakdown: bool = True, n_units: bool = True) -> abi.PlanResult:

@@ -478,241 +478,6 @@ def make_task_planner(backend: Backend, now_ns: int) -> Callable[[Distro, Sequen
     return planner
 
 
-def capTaskQueueLength(tasks: Sequence[Task], maxScheduledTasks: int) -> List[Task]:
-    """scheduler/task_queue_persister.go:66-83 on already-ordered host objects (the device-side version
-    for the batched path is evg_cap_queue_device)."""
-    if maxScheduledTasks <= 0 or len(tasks) <= maxScheduledTasks:
-        return list(tasks)
-    cut = maxScheduledTasks
-    while cut < len(tasks) and tasks[cut].TaskGroup != "" and tasks[cut].TaskGroup == tasks[cut - 1].TaskGroup:
-        cut += 1
-    return list(tasks[:cut])
-
-
-@dataclass
-class TaskQueueItem:                               # model/task_queue.go:181-205 (the fields the path fills)
-    Id: str = ""
-    Group: str = ""
-    GroupMaxHosts: int = 0
-    GroupIndex: int = 0
-    Version: str = ""
-    BuildVariant: str = ""
-    Requester: str = ""
-    Project: str = ""
-    ExpectedDuration: int = 0
-    Priority: int = 0
-    SortingValueBreakdown: Optional[Dict[str, int]] = None
-    Dependencies: List[str] = field(default_factory=list)
-    DependenciesMet: bool = False
-    ActivatedBy: str = ""
-
-
-def BuildTaskQueue(tasks: Sequence[Task], maxScheduledTasks: int) -> List[TaskQueueItem]:
-    """What PersistTaskQueue hands to TaskQueue.Save (task_queue_persister.go:17-52, task_queue.go:269-272), from an
-    already planned task list: cap, build the items, truncate to 10,000. Host-object form; the batched device form is
-    evg_materialize_queue_device."""
-    out = []
-    for t in capTaskQueueLength(tasks, maxScheduledTasks):
-        out.append(TaskQueueItem(Id=t.Id, Group=t.TaskGroup, GroupMaxHosts=t.TaskGroupMaxHosts, GroupIndex=t.TaskGroupOrder, Version=t.Version,
-                                 BuildVariant=t.BuildVariant, Requester=t.Requester, Project=t.Project, ExpectedDuration=t.ExpectedDuration,
-                                 Priority=t.Priority, SortingValueBreakdown=t.SortingValueBreakdown, Dependencies=[d.TaskId for d in t.DependsOn],
-                                 DependenciesMet=t.HasDependenciesMet(), ActivatedBy=t.ActivatedBy))
-    return out[:abi.TASK_QUEUE_SAVE_LIMIT]
-
-
-def compositeGroupID(group: str, variant: str, project: str, version: str) -> str:   # task_queue_service_dependency.go:695-697
-    return "%s_%s_%s_%s" % (group, variant, project, version)
-
-
-def _sort_stabilized(n: int, from_: Dict[int, List[int]]) -> Tuple[List[Optional[int]], int]:
-    """gonum.org/v1/gonum v0.17.0 graph/topo SortStabilized with order = ascending node (node == queueIndex,
-    task_queue_service_dependency.go:207-216): Tarjan's search over the nodes in descending order, successors in
-    descending order; components in reverse order of completion; a component of more than one node becomes one None.
-    Host-object form (explicit stack instead of recursion); returns (sorted, number of unorderable components)."""
-    index_of, low, on_stack, stack, sccs, counter = {}, {}, set(), [], [], 0
-    for root in range(n - 1, -1, -1):
-        if root in index_of:
-            continue
-        frames = []
-
-        def enter(v):
-            nonlocal counter
-            counter += 1
-            index_of[v] = low[v] = counter
-            stack.append(v)
-            on_stack.add(v)
-            frames.append((v, iter(sorted(set(from_.get(v, ())), reverse=True))))
-
-        enter(root)
-        while frames:
-            v, it = frames[-1]
-            w = next(it, None)
-            if w is None:
-                frames.pop()
-                if frames:
-                    u = frames[-1][0]
-                    low[u] = min(low[u], low[v])
-                if low[v] == index_of[v]:
-                    comp = []
-                    while True:
-                        x = stack.pop()
-                        on_stack.discard(x)
-                        comp.append(x)
-                        if x == v:
-                            break
-                    sccs.append(comp)
-            elif w not in index_of:
-                enter(w)
-            elif w in on_stack:
-                low[v] = min(low[v], index_of[w])
-    out = [c[0] if len(c) == 1 else None for c in sccs]
-    out.reverse()
-    return out, sum(1 for c in sccs if len(c) != 1)
-
-
-@dataclass
-class schedulableUnit:                             # model/task_queue_service.go (the fields rebuild fills)
-    id: str = ""
-    group: str = ""
-    project: str = ""
-    version: str = ""
-    variant: str = ""
-    maxHosts: int = 0
-    tasks: List[TaskQueueItem] = field(default_factory=list)
-
-
-class basicCachedDAGDispatcherImpl:
-    """The part of model/task_queue_service_dependency.go the batched evg_dispatch_order_device computes: rebuild
-    (:153-250). `sorted` holds the items in dispatcher order (None = the nil entry of a dependency cycle); `taskGroups`
-    maps compositeGroupID -> schedulableUnit with its tasks stable-sorted by GroupIndex. FindNextTask (DB reads, host
-    state, locking) is the caller's."""
-
-    def __init__(self, distroID: str = ""):
-        self.distroID = distroID
-        self.sorted: List[Optional[TaskQueueItem]] = []
-        self.taskGroups: Dict[str, schedulableUnit] = {}
-        self.cycles = 0
-
-    def rebuild(self, items: Sequence[TaskQueueItem]) -> None:
-        itemNodeMap = {it.Id: i for i, it in enumerate(items)}             # addItem, queueIndex = i   :161-164
-        self.taskGroups = {}
-        for it in items:                                                   # :166-188
-            if it.Group != "":
-                gid = compositeGroupID(it.Group, it.BuildVariant, it.Project, it.Version)
-                su = self.taskGroups.get(gid)
-                if su is None:
-                    su = self.taskGroups[gid] = schedulableUnit(gid, it.Group, it.Project, it.Version, it.BuildVariant, it.GroupMaxHosts)
-                su.tasks.append(it)
-        for su in self.taskGroups.values():                                # sort.SliceStable by GroupIndex   :190-195
-            su.tasks.sort(key=lambda x: x.GroupIndex)
-        from_: Dict[int, List[int]] = {}
-        for i, it in enumerate(items):                                     # addEdge(dependency, item.Id)   :197-204
-            for dep in it.Dependencies:
-                if dep in itemNodeMap:                                     # no node for the dependency: no edge   :125-128
-                    from_.setdefault(itemNodeMap[dep], []).append(i)
-        order, self.cycles = _sort_stabilized(len(items), from_)
-        self.sorted = [None if q is None else items[q] for q in order]
-
-
-def FindRunnableTasks(d: Distro, undispatched: Sequence[Task], can_dispatch: Callable[[Task], bool],
-                      dep_lookup: Optional[DepLookup] = None) -> List[Task]:
-    """Host-object restatement of LegacyFindRunnableTasks' filter (scheduler/task_finder.go:40-116) after the DB queries:
-    `undispatched` is what task.FindHostSchedulable returned, `can_dispatch` folds the project-ref checks (:59-84),
-    `dep_lookup` stands for getDependencyTaskCache's batched fetch of dependencies outside the list (:289-320)."""
-    cache = {t.Id: t for t in undispatched}
-    check = d.DispatcherSettings.Version != DispatcherVersionRevisedWithDependencies
-    out = []
-    for t in undispatched:
-        if not can_dispatch(t):
-            continue
-        if check and not t.HasDependenciesMet():
-            ok = True
-            for dep in t.DependsOn:
-                if dep.TaskId in cache:
-                    other = cache[dep.TaskId]
-                    status, blocked = other.Status, other.Blocked()
-                else:
-                    found = dep_lookup(dep.TaskId) if dep_lookup else None
-                    if found is None:
-                        ok = False                 # DependenciesMet returns an error: "skipping" (:86-99)
-                        break
-                    status, blocked = found
-                req = _dep_req(t, dep.TaskId)      # SatisfiesDependency scans DependsOn for that id (task.go:546-561)
-                sat = (status == TaskSucceeded if req == abi.DEP_REQ_SUCCESS else status == TaskFailed if req == abi.DEP_REQ_FAILED
-                       else (status in (TaskSucceeded, TaskFailed) or blocked) if req == abi.DEP_REQ_ALL else False)
-                if not sat:
-                    ok = False
-                    break
-            if not ok:
-                continue
-        out.append(t)
-    return out
-
-
-@dataclass
-class AllocatorReport:                             # what units/host_allocator.go:250-334,393-424 computes after the allocator
-    timeToEmpty: int = 0
-    timeToEmptyNoSpawns: int = 0
-    hostQueueRatio: float = 0.0
-    noSpawnsRatio: float = 0.0
-    hostsAvail: int = 0
-    drawdown: bool = False
-    NewCapTarget: int = 0
-    killableHosts: int = 0
-
-
-def HostAllocatorReport(info: DistroQueueInfo, hostsSpawned: int, nHostsFree: int, numUpHosts: int, minimumHosts: int,
-                        drawdownAllowed: bool) -> AllocatorReport:
-    """Host-object restatement of the allocator job's report math (units/host_allocator.go:250-334) and of
-    setTargetAndTerminate (:393-424); float32 steps via numpy.float32. The batched device form is
-    evg_allocator_report_device."""
-    f32 = np.float32
-    freeTG = reqTG = overTG = 0
-    durOverTG = durTG = 0
-    for g in info.TaskGroupInfos:
-        if g.Name != "":
-            overTG += g.CountDurationOverThreshold
-            durOverTG += g.DurationOverThreshold
-            durTG += g.ExpectedDuration
-            freeTG += g.CountFree
-            reqTG += g.CountRequired
-    scheduled = (info.ExpectedDuration - durTG) - (info.DurationOverThreshold - durOverTG)
-    overNoTG = info.CountDurationOverThreshold - overTG
-    correctedSpawned = hostsSpawned - reqTG
-    hostsAvail = (nHostsFree - freeTG) + correctedSpawned - overNoTG
-    maxD = 2532000 * HOUR
-    tte = tteNS = 0
-    if scheduled > 0:
-        noSpawns = hostsAvail - correctedSpawned
-        if hostsAvail <= 0:
-            tte = tteNS = maxD
-        elif noSpawns <= 0:
-            tte, tteNS = int(scheduled / hostsAvail) if False else _go_div(scheduled, hostsAvail), maxD
-        else:
-            tte, tteNS = _go_div(scheduled, hostsAvail), _go_div(scheduled, noSpawns)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        ratio = f32(tte) / f32(info.MaxDurationThreshold)
-        ratioNS = f32(tteNS) / f32(info.MaxDurationThreshold)
-    rep = AllocatorReport(tte, tteNS, float(ratio), float(ratioNS), hostsAvail)
-    if drawdownAllowed and ratio < f32(0.25) and numUpHosts > 0:
-        target = 0
-        if ratio == 0:
-            killable = numUpHosts
-        else:
-            killable = int(f32(numUpHosts) * (f32(1) - ratio))
-            target = numUpHosts - killable
-        target = max(target, minimumHosts)
-        rep.killableHosts = killable
-        if killable > 0:
-            rep.drawdown, rep.NewCapTarget = True, target
-    return rep
-
-
-def _go_div(a: int, b: int) -> int:                # Go's integer division truncates toward zero
-    q = abs(a) // abs(b)
-    return q if (a >= 0) == (b >= 0) else -q
-
-
 class AllocatorError(Exception):
     pass
 

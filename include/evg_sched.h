@@ -295,6 +295,12 @@ int32_t evg_abi_version(void);
 /* Host-side check of the layout contract; no GPU work. */
 int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len);
 
+/* Device self-test of the planner's scoring arithmetic: runs unitInfo.value() (planner.go:209-300) over `n_cases`
+ * generated inputs twice -- the kernels' fast exact form and a statement that follows the Go code step by step (IEEE fp64
+ * divisions, int64 divisions) -- and counts the cases where any of the 13 SortingValueBreakdown fields differs. Inputs
+ * sit on and around the quotient boundaries the fast form's exactness argument depends on. Synchronous. ABI 1.2. */
+int evg_selftest_unit_value(evg_ctx* ctx, uint64_t seed, uint64_t n_cases, uint64_t* mismatches, uint64_t* first_bad_case);
+
 /* Plans all D distros: replaces, per distro,
  *   PrepareTasksForPlanning(ctx, d, tasks).Export(ctx)   scheduler/scheduler.go:43
  *   GetDistroQueueInfo(ctx, d, plan, opts)               scheduler/scheduler.go:44,57-178

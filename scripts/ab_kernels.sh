@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in A B A B; do
   lib=$R/evergreen_amd/csrc/libevg_sched.so; [ $v = A ] && lib=$R/evergreen_amd/csrc/libevg_sched_base.so
   rm -rf /tmp/abk
-  EVG_SCHED_LIB=$lib rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abk -o k -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --in-flight 1 > /tmp/abk.log 2>&1
+  EVG_SCHED_LIB=$lib rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abk -o k -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-extras --in-flight 1 > /tmp/abk.log 2>&1
   f=$(find /tmp/abk -name '*kernel_stats.csv' | head -1)
   python - "$f" $v <<'PY'
 import csv, sys

@@ -2,7 +2,7 @@
 # Per-kernel average durations of a short bench.py run (rocprofv3 kernel trace); prints the top kernels.
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --in-flight 1 > /tmp/ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --in-flight 1 > /tmp/ks.log 2>&1
 f=$(find /tmp/ks -name '*kernel_stats.csv' | head -1)
 python - "$f" <<'PY'
 import csv, sys

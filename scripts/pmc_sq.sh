@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_FLAT"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/$TAG-sq$i -o $TAG -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 > $OUT/$TAG-sq$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/$TAG-sq$i -o $TAG -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/$TAG-sq$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections

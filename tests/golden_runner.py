@@ -7,6 +7,7 @@ import numpy as np
 from evergreen_amd import abi
 from evergreen_amd import scheduler as S
 from tests import golden_cases as G
+from tests import host_restatements as H
 
 
 def _plan(backend, d, tasks, **kw):
@@ -192,4 +193,4 @@ def check_cap(cap_fn):
         order = np.arange(len(tasks), dtype=np.int32)
         cut = cap_fn(packed.batch, order, limit)
         assert int(cut[0]) == want, name
-        assert len(S.capTaskQueueLength(tasks, limit)) == want, name
+        assert len(H.capTaskQueueLength(tasks, limit)) == want, name

@@ -1,5 +1,5 @@
 """the host-allocator job's report math (units/host_allocator.go:250-334, setTargetAndTerminate :393-424).
-CPU: the oracle against the host-object restatement (scheduler.HostAllocatorReport) on the allocator's own golden
+CPU: the oracle against the host-object restatement (tests/host_restatements.py: HostAllocatorReport) on the allocator's own golden
 scenarios and on a synthetic pool. GPU: evg_allocator_report_device against the oracle, bit for bit (incl. float32)."""
 import numpy as np
 import pytest
@@ -7,6 +7,7 @@ import pytest
 from evergreen_amd import abi, gen
 from evergreen_amd import scheduler as S
 from tests import golden_cases as G
+from tests import host_restatements as H
 
 
 def _random_rows(seed, D=600):
@@ -58,7 +59,7 @@ def test_oracle_report_matches_host_object_restatement(oracle):
                                                            ExpectedDuration=int(g["expected_duration_ns"]),
                                                            CountDurationOverThreshold=int(g["count_duration_over_threshold"]),
                                                            DurationOverThreshold=int(g["duration_over_threshold_ns"])))
-        want = S.HostAllocatorReport(info, int(spawned[d]), int(free[d]), int(params[d]["n_up_hosts"]),
+        want = H.HostAllocatorReport(info, int(spawned[d]), int(free[d]), int(params[d]["n_up_hosts"]),
                                      int(params[d]["minimum_hosts"]), bool(params[d]["drawdown_allowed"]))
         r = rep[d]
         assert int(r["time_to_empty_ns"]) == want.timeToEmpty and int(r["time_to_empty_no_spawns_ns"]) == want.timeToEmptyNoSpawns, d
@@ -79,7 +80,7 @@ def test_report_on_the_allocators_golden_scenarios(oracle):
     nothing short is queued, and the 'no spawns' estimate is never faster than the one with the spawned hosts."""
     for name, data, running, want, line in G.allocator_cases():
         n, free, err = S.AllocateHosts(oracle, [data], G.NOW, running.get)[0]
-        r = S.HostAllocatorReport(data.DistroQueueInfo, n, free, len(data.ExistingHosts), data.Distro.HostAllocatorSettings.MinimumHosts, True)
+        r = H.HostAllocatorReport(data.DistroQueueInfo, n, free, len(data.ExistingHosts), data.Distro.HostAllocatorSettings.MinimumHosts, True)
         assert r.timeToEmpty >= 0 and r.timeToEmptyNoSpawns >= r.timeToEmpty, name
         q = data.DistroQueueInfo
         short = (q.ExpectedDuration - sum(g.ExpectedDuration for g in q.TaskGroupInfos if g.Name)) - (

@@ -1,5 +1,5 @@
 """the DAG dispatcher's rebuild (model/task_queue_service_dependency.go:153-250).
-CPU: the oracle and the host-object restatement (scheduler.basicCachedDAGDispatcherImpl) against the reference's own
+CPU: the oracle and the host-object restatement (tests/host_restatements.py: basicCachedDAGDispatcherImpl) against the reference's own
 known-answer tests (tests/golden/dispatcher_vectors.json, transcribed from model/task_queue_service_test.go) and against
 each other on random graphs (cycles and self-edges included). GPU: evg_dispatch_order_device against the oracle."""
 import json
@@ -11,13 +11,14 @@ import pytest
 from evergreen_amd import abi, gen
 from evergreen_amd import scheduler as S
 from tests import golden_cases as G
+from tests import host_restatements as H
 
 NOW = G.NOW
 VEC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dispatcher_vectors.json")))
 
 
 def _items(spec):
-    return [S.TaskQueueItem(Id=i["Id"], Group=i.get("Group", ""), BuildVariant=i.get("BuildVariant", ""), Version=i.get("Version", ""),
+    return [H.TaskQueueItem(Id=i["Id"], Group=i.get("Group", ""), BuildVariant=i.get("BuildVariant", ""), Version=i.get("Version", ""),
                             Project=i.get("Project", ""), GroupMaxHosts=i.get("GroupMaxHosts", 0), GroupIndex=i.get("GroupIndex", 0),
                             Dependencies=list(i.get("Dependencies", []))) for i in spec]
 
@@ -39,7 +40,7 @@ def _oracle_rebuild(oracle, queues):
 def _check_against_object(packed, res, queues):
     b = packed.batch
     for d, items in enumerate(queues):
-        disp = S.basicCachedDAGDispatcherImpl("distro_%d" % d)
+        disp = H.basicCachedDAGDispatcherImpl("distro_%d" % d)
         disp.rebuild(items)
         got = [None if q < 0 else items[int(q)].Id for q in res.distro_sorted(b.task_off, d)]
         assert got == [None if it is None else it.Id for it in disp.sorted], d
@@ -53,7 +54,7 @@ def test_constructor_vector(oracle):
     """TestConstructor (task_queue_service_test.go:529-657): the 100-item queue of SetupTest."""
     v = VEC["constructor"]
     items = _items(v["items"])
-    disp = S.basicCachedDAGDispatcherImpl("distro_1")
+    disp = H.basicCachedDAGDispatcherImpl("distro_1")
     disp.rebuild(items)
     assert [it.Id for it in disp.sorted] == v["sorted"]
     assert {k: len(su.tasks) for k, su in disp.taskGroups.items()} == v["task_groups"]
@@ -68,7 +69,7 @@ def test_single_host_group_ordering_vector(oracle):
     """TestSingleHostTaskGroupOrdering (:1748-1804): GroupIndex 2,0,4,1,3 dispatches 1,3,0,4,2."""
     v = VEC["single_host_group_ordering"]
     items = _items(v["items"])
-    disp = S.basicCachedDAGDispatcherImpl()
+    disp = H.basicCachedDAGDispatcherImpl()
     disp.rebuild(items)
     (su,) = disp.taskGroups.values()
     assert [t.Id for t in su.tasks] == v["group_tasks"]
@@ -94,7 +95,7 @@ def test_self_edge_and_cycle_vectors(oracle):
 def _random_queue(rng, d, n, cyclic):
     items = []
     for i in range(n):
-        it = S.TaskQueueItem(Id="d%d-t%d" % (d, i), BuildVariant="bv%d" % int(rng.integers(0, 2)), Version="v%d" % int(rng.integers(0, 3)), Project="p")
+        it = H.TaskQueueItem(Id="d%d-t%d" % (d, i), BuildVariant="bv%d" % int(rng.integers(0, 2)), Version="v%d" % int(rng.integers(0, 3)), Project="p")
         if rng.random() < 0.3:
             it.Group, it.GroupIndex, it.GroupMaxHosts = "tg%d" % int(rng.integers(0, 4)), int(rng.integers(0, 6)), int(rng.integers(1, 3))
         for _ in range(int(rng.integers(0, 4)) if rng.random() < 0.6 else 0):
@@ -241,7 +242,7 @@ def test_oracle_matches_host_object_restatement_property(oracle):
         n = draw(st.integers(0, 14))
         items = []
         for i in range(n):
-            it = S.TaskQueueItem(Id="t%d" % i, BuildVariant="bv", Version="v", Project="p")
+            it = H.TaskQueueItem(Id="t%d" % i, BuildVariant="bv", Version="v", Project="p")
             if draw(st.booleans()) and draw(st.booleans()):
                 it.Group, it.GroupIndex = "g%d" % draw(st.integers(0, 2)), draw(st.integers(0, 2))
             it.Dependencies = ["t%d" % j for j in draw(st.lists(st.integers(0, n + 1), max_size=4))]   # n, n+1: not in the queue

@@ -1,5 +1,5 @@
 """the task finder's dependency filter (scheduler/task_finder.go:40-116, Task.DependenciesMet
-task.go:649-688). CPU: the oracle's batched filter against the host-object restatement (scheduler.FindRunnableTasks).
+task.go:649-688). CPU: the oracle's batched filter against the host-object restatement (tests/host_restatements.py: FindRunnableTasks).
 GPU: evg_filter_runnable_device against the oracle (keep flags, deps-met flags, order-preserving compaction)."""
 import numpy as np
 import pytest
@@ -7,6 +7,7 @@ import pytest
 from evergreen_amd import abi, gen
 from evergreen_amd import scheduler as S
 from tests import golden_cases as G
+from tests import host_restatements as H
 
 NOW = G.NOW
 
@@ -50,7 +51,7 @@ def test_oracle_filter_matches_host_object_restatement(oracle):
     disp = np.asarray([1 if can(t) else 0 for _, ts in queues for t in ts], np.uint8)
     met, keep, rows, cnt = oracle.filter_runnable(b, disp)
     for d, (dist, tasks) in enumerate(queues):
-        want = S.FindRunnableTasks(dist, tasks, can, outside.get)
+        want = H.FindRunnableTasks(dist, tasks, can, outside.get)
         lo = int(b.task_off[d])
         got = [tasks[int(r) - lo].Id for r in rows[lo:lo + int(cnt[d])]]
         assert got == [t.Id for t in want], d
@@ -129,7 +130,7 @@ def _reference_unsatisfied_dependencies_case():
 
 def test_reference_unsatisfied_dependencies_vector(oracle):
     dist, tasks, outside, want = _reference_unsatisfied_dependencies_case()
-    assert [t.Id for t in S.FindRunnableTasks(dist, tasks, lambda t: True, outside.get)] == want
+    assert [t.Id for t in H.FindRunnableTasks(dist, tasks, lambda t: True, outside.get)] == want
     b = S.pack_queues([(dist, tasks)], NOW, outside.get).batch
     met, keep, rows, cnt = oracle.filter_runnable(b, np.ones(b.n_tasks, np.uint8))
     assert [tasks[int(r)].Id for r in rows[:int(cnt[0])]] == want

@@ -25,6 +25,16 @@ def test_reference_golden_vectors(native_ctx, check):
     check(native_ctx)
 
 
+def test_unit_value_fast_form_against_the_go_form(native_ctx):
+    """unitInfo.value() as the kernels compute it (exact FMA remainders, no IEEE division sequence, no int64 division)
+    against the step-by-step Go form (planner.go:209-300), on the device: 2^33 generated cases -- every member count up to
+    65536 against quotient boundaries +- 80 ns at every reachable magnitude, the whole-hour boundaries of the mainline
+    term, random (sum, n) pairs, negative and beyond-2^53 sums. Any differing breakdown field is a failure."""
+    for seed in (0x5EED, 0xE5E7):
+        bad, first = native_ctx.selftest_unit_value(1 << 32, seed)
+        assert bad == 0, "unit_value fast form differs from the Go form in %d cases (first: case %s, seed %#x)" % (bad, first, seed)
+
+
 def test_allocator_fuzz_matches_oracle(native_ctx, oracle):
     got = R.check_fuzz_invariants(native_ctx)
     want = R.check_fuzz_invariants(oracle)

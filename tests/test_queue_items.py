@@ -1,12 +1,13 @@
 """PersistTaskQueue's queue materialisation (task_queue_persister.go:17-62 + TaskQueue.Save's 10,000
 truncation, task_queue.go:269-272). CPU: the oracle's batched item list against the host-object restatement
-(scheduler.BuildTaskQueue over the planned Task objects). GPU: evg_materialize_queue_device against the oracle."""
+(tests/host_restatements.py: BuildTaskQueue over the planned Task objects). GPU: evg_materialize_queue_device against the oracle."""
 import numpy as np
 import pytest
 
 from evergreen_amd import abi, gen
 from evergreen_amd import scheduler as S
 from tests import golden_cases as G
+from tests import host_restatements as H
 
 NOW = G.NOW
 
@@ -41,10 +42,10 @@ def test_oracle_items_match_host_object_restatement(oracle, limit):
     items = oracle.materialize_queue(packed.batch, res, limit)
     b = packed.batch
     for d, (plan, _) in enumerate(planned):
-        want = S.BuildTaskQueue(plan, limit)
+        want = H.BuildTaskQueue(plan, limit)
         lo, hi = int(items.item_off[d]), int(items.item_off[d + 1])
         assert hi - lo == len(want), (d, hi - lo, len(want))
-        assert int(items.cut[d]) == len(S.capTaskQueueLength(plan, limit))
+        assert int(items.cut[d]) == len(H.capTaskQueueLength(plan, limit))
         for k, w in enumerate(want):
             o = lo + k
             row = int(items.cols["row"][o])
