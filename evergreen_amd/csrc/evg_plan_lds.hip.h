@@ -173,17 +173,71 @@ __device__ __forceinline__ int inunit_cmp(const evg_task_soa& t, int ra, int rb)
   return 0;
 }
 
+// Per-distro uniform state from the offset tables; (lo, n) = the distro's row range, already fetched.
+__device__ __forceinline__ DC distro_context(const PlanArgs& a, int d, int lo, int n) {
+  DC c;
+  c.d = d;
+  c.D = a.in.n_distros;
+  c.lo = lo;
+  c.n = n;
+  c.tg_lo = a.in.tg_off[d];
+  c.ntg = a.in.tg_off[d + 1] - c.tg_lo;
+  c.ver_lo = a.in.ver_off[d];
+  c.nver = a.in.ver_off[d + 1] - c.ver_lo;
+  c.gv = a.in.distros[d].group_versions != 0;
+  c.now = a.in.now_ns;
+  // slot map: !gv: own task units [0,n) then task groups; gv: task groups then versions (no own units)
+  if (c.gv) { c.tg_base = 0; c.ver_base = c.ntg; c.S = c.ntg + c.nver; }
+  else { c.tg_base = c.n; c.ver_base = c.n + c.ntg; c.S = c.n + c.ntg; }
+  int P = 1;
+  while (P < c.n) P <<= 1;
+  c.P = P;
+  c.eb = a.in.tasks.dep_off[c.lo];
+  c.ne = a.in.tasks.dep_off[c.lo + c.n] - c.eb;
+  c.eL = true;
+  return c;
+}
+__device__ __forceinline__ DC distro_context(const PlanArgs& a, int d) {
+  const int lo = a.in.task_off[d];
+  return distro_context(a, d, lo, a.in.task_off[d + 1] - lo);
+}
+__device__ __forceinline__ bool fits_lds_path(const DC& c) {
+  return c.n <= kN && c.S <= kS && c.ntg + 1 <= kG && c.ne >= 0 && lds_budget_ok(c.S, c.ne);
+}
+
 // The LDS path. Returns false (uniformly, before writing any output) when the distro must take the generic path.
 // s_red: 32 zeroed words of static LDS.
 // FUSED: the distro's UtilizationBasedHostAllocator pass (q) runs as the tail of the same workgroup: its host rows are
 // fetched before the sort, so their latency hides behind the planner's compute, and the queue info it consumes never
 // leaves the CU.
 template <bool RICH, bool FUSED>
-__device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocArgs& q, const DC& c, unsigned char* smem, unsigned* s_red) {
+__device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocArgs& q, const int d, const int lo, const int n,
+                                                unsigned char* smem, unsigned* s_red) {
   const evg_task_soa& t = a.in.tasks;
-  const int d = c.d, lo = c.lo, n = c.n, S = c.S;
   const int tid = threadIdx.x, lane = tid & 63;
   const int i0 = tid * kE;
+
+  EVG_PRIO(0);
+  // ---- A: load ------------------------------------------------------------------------------------------
+  // The column loads need the distro's first row and its row count only, so they are issued FIRST: the rest of the
+  // per-distro context (task-group / version ranges, planner flags, the edge range -- a chain of dependent scalar loads,
+  // the last of which misses to HBM) resolves while they are in flight, and the does-it-fit decision comes after.
+  int32_t tgk[4], verk[4], nd[4], tgo[4];
+  uint16_t fl[4];
+  int64_t pri[4], dur[4], qts[4];
+  int32_t o4[4];
+  load4(t.tg_key + lo, i0, n, (int32_t)-1, tgk);
+  load4(t.version_key + lo, i0, n, (int32_t)0, verk);
+  load4(t.flags + lo, i0, n, (uint16_t)0, fl);
+  load4(t.priority + lo, i0, n, (int64_t)0, pri);
+  load4(t.expected_duration_ns + lo, i0, n, (int64_t)0, dur);
+  load4(t.queue_ts_ns + lo, i0, n, (int64_t)EVG_TIME_GO_ZERO, qts);
+  load4(t.num_dependents + lo, i0, n, (int32_t)0, nd);
+  load4(t.task_group_order + lo, i0, n, (int32_t)0, tgo);
+  load4(t.dep_off + lo, i0, n, (int32_t)0, o4);
+  const DC c = distro_context(a, d, lo, n);
+  if (!fits_lds_path(c)) return false;  // uniform; nothing has been written
+  const int S = c.S;
 
   LdsView m;
   {
@@ -198,23 +252,8 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   unsigned long long* s_rng = (unsigned long long*)(s_red + 16);  // 0 vmin 1 vmax 2 durmin 3 durmax (biased)
   uint32_t* s_r32 = s_red + 24;                                   // 0 tgomin 1 tgomax 2 ndmin 3 ndmax 4 primin 5 primax
 
-  EVG_PRIO(0);
-  // ---- A: load ------------------------------------------------------------------------------------------
-  int32_t tgk[4], verk[4], nd[4], tgo[4];
-  uint16_t fl[4];
-  int64_t pri[4], dur[4], qts[4];
-  load4(t.tg_key + lo, i0, n, (int32_t)-1, tgk);
-  load4(t.version_key + lo, i0, n, (int32_t)c.ver_lo, verk);
-  load4(t.flags + lo, i0, n, (uint16_t)0, fl);
-  load4(t.priority + lo, i0, n, (int64_t)0, pri);
-  load4(t.expected_duration_ns + lo, i0, n, (int64_t)0, dur);
-  load4(t.queue_ts_ns + lo, i0, n, (int64_t)EVG_TIME_GO_ZERO, qts);
-  load4(t.num_dependents + lo, i0, n, (int32_t)0, nd);
-  load4(t.task_group_order + lo, i0, n, (int32_t)0, tgo);
   int doff[5];  // local edge offsets of the thread's rows; rows past n get empty ranges
   {
-    int32_t o4[4];
-    load4(t.dep_off + lo, i0, n, (int32_t)0, o4);
     const int last = i0 + 3 < n ? t.dep_off[lo + i0 + 4] - c.eb : c.ne;
 #pragma unroll
     for (int e = 0; e < 4; e++) doff[e] = i0 + e < n ? o4[e] - c.eb : last;
@@ -867,47 +906,33 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   return true;
 }
 
-// Per-distro uniform state from the offset tables.
-__device__ __forceinline__ DC distro_context(const PlanArgs& a, int d) {
-  DC c;
-  c.d = d;
-  c.D = a.in.n_distros;
-  c.lo = a.in.task_off[d];
-  c.n = a.in.task_off[d + 1] - c.lo;
-  c.tg_lo = a.in.tg_off[d];
-  c.ntg = a.in.tg_off[d + 1] - c.tg_lo;
-  c.ver_lo = a.in.ver_off[d];
-  c.nver = a.in.ver_off[d + 1] - c.ver_lo;
-  c.gv = a.in.distros[d].group_versions != 0;
-  c.now = a.in.now_ns;
-  // slot map: !gv: own task units [0,n) then task groups; gv: task groups then versions (no own units)
-  if (c.gv) { c.tg_base = 0; c.ver_base = c.ntg; c.S = c.ntg + c.nver; }
-  else { c.tg_base = c.n; c.ver_base = c.n + c.ntg; c.S = c.n + c.ntg; }
-  int P = 1;
-  while (P < c.n) P <<= 1;
-  c.P = P;
-  c.eb = a.in.tasks.dep_off[c.lo];
-  c.ne = a.in.tasks.dep_off[c.lo + c.n] - c.eb;
-  c.eL = true;
-  return c;
-}
-__device__ __forceinline__ bool fits_lds_path(const DC& c) {
-  return c.n <= kN && c.S <= kS && c.ntg + 1 <= kG && c.ne >= 0 && lds_budget_ok(c.S, c.ne);
-}
-
 // One workgroup per distro: the LDS path. Distros it cannot take are flagged in a.w_generic[d] and left to
 // k_plan_generic, which is enqueued right behind this kernel.
 template <bool RICH>
 __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
+#ifdef EVG_EXP_SHIFT  // experiment: who shares a CU with whom (blocks b and b + 256 do, in a 512-workgroup launch)
+  const int d = a.d0 + (gridDim.x == 512 && blockIdx.x >= 256 ? 256 + ((blockIdx.x - 256 + EVG_EXP_SHIFT) & 255) : blockIdx.x);
+#else
   const int d = a.d0 + blockIdx.x;
-  const DC c = distro_context(a, d);
+#endif
+  const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo;
   if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
   __syncthreads();
+#ifdef EVG_PHASE_TIMING
+  struct { int d; } c{d};
+#endif
   EVG_STAMP(0);
+#ifdef EVG_PHASE_TIMING
+  if (threadIdx.x == 0 && a.dbg_ts) {  // where did the dispatcher put this workgroup? HW_ID (cu / sh / se) and XCC_ID
+    a.dbg_ts[(size_t)d * 16 + 13] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    a.dbg_ts[(size_t)d * 16 + 14] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    a.dbg_ts[(size_t)d * 16 + 15] = blockIdx.x;
+  }
+#endif
   const AllocArgs none{};
-  const bool done = fits_lds_path(c) && plan_distro_lds<RICH, false>(a, none, c, smem, s_red);
+  const bool done = n <= kN && plan_distro_lds<RICH, false>(a, none, d, lo, n, smem, s_red);
   if (threadIdx.x == 0) a.w_generic[d] = done ? 0 : 1;
 }
 
@@ -921,12 +946,15 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const Fu
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
   const int d = blockIdx.x;
-  const DC c = distro_context(f.p, d);
+  const int lo = f.p.in.task_off[d], n = f.p.in.task_off[d + 1] - lo;
   if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
   __syncthreads();
   [[maybe_unused]] const PlanArgs& a = f.p;  // EVG_STAMP's
+#ifdef EVG_PHASE_TIMING
+  struct { int d; } c{d};
+#endif
   EVG_STAMP(0);
-  const bool done = fits_lds_path(c) && plan_distro_lds<RICH, true>(f.p, f.q, c, smem, s_red);
+  const bool done = n <= kN && plan_distro_lds<RICH, true>(f.p, f.q, d, lo, n, smem, s_red);
   if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
 }
 

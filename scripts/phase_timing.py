@@ -56,6 +56,21 @@ def main():
         print("  tail: staging (plan stamp 11 -> alloc entry) %.1f | nfree+early outs %.1f | bucket loop %.1f | write back %.1f | final %.1f" % (
             (t2[ok2, 6] - tt[ok2, 11]).mean(), (t2[ok2, 2] - t2[ok2, 6]).mean(), (t2[ok2, 3] - t2[ok2, 2]).mean(),
             (t2[ok2, 4] - t2[ok2, 3]).mean(), (t2[ok2, 7] - t2[ok2, 4]).mean()))
+    hw = ts.cpu().numpy().reshape(-1, 16)[:, 13:16]
+    if hw[:, 0].any():
+        hid, xcc, blk = hw[:, 0], hw[:, 1] & 0xF, hw[:, 2]
+        cu, sh, se = (hid >> 8) & 0xF, (hid >> 12) & 1, (hid >> 13) & 7
+        place = xcc * 4096 + se * 64 + sh * 16 + cu
+        print("placement: blockIdx %% 8 == XCC_ID for %d of %d workgroups; distinct (xcc, se, sh, cu) = %d" % (
+            int((blk % 8 == xcc).sum()), len(blk), len(np.unique(place))))
+        by = {}
+        for b, pl in zip(blk, place):
+            by.setdefault(int(pl), []).append(int(b))
+        diffs = sorted(set(tuple(sorted(v)) for v in by.values()))[:6]
+        print("  workgroups sharing a CU (first few, by blockIdx):", diffs)
+        print("  blockIdx -> (xcc, se, sh, cu) for blocks 0..23:", [(int(xcc[np.where(blk == b)[0][0]]), int(se[np.where(blk == b)[0][0]]),
+              int(sh[np.where(blk == b)[0][0]]), int(cu[np.where(blk == b)[0][0]])) for b in range(min(24, len(blk)))])
+        print("  per-CU workgroup counts:", np.bincount(np.array([len(v) for v in by.values()])))
     t = ts.cpu().numpy().reshape(-1, 16)[:, :12]
     dt = np.diff(t, axis=1).astype(np.float64)
     tot = (t[:, 11] - t[:, 0]).astype(np.float64)
