@@ -131,10 +131,10 @@ def pipelined_rate(batch, dev, in_flight, steps, native, resident, torch):
             "what": "%d pools of the same workload, each on its own HIP stream with its own context / scratch / outputs, ticks issued round-robin" % in_flight}
 
 
-def resident_rate(batch, dev, native, resident, torch, steps=10, warmup=2):
+def resident_rate(batch, dev, native, resident, torch, steps=10, warmup=2, units=False):
     """ms per tick (plan + allocate, device-resident, one batch at a time) of `batch` + the device results."""
     ctx = native.Context(dev.index or 0)
-    pool = resident.ResidentPool(ctx, batch, dev, breakdown=False, n_units=False)
+    pool = resident.ResidentPool(ctx, batch, dev, breakdown=False, n_units=False, units=units)
     for _ in range(warmup):
         pool.step(fused=False)
     torch.cuda.synchronize(dev)
@@ -380,20 +380,46 @@ def main():
                     line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
 
             def end_to_end():
-                # host pointers in, host pointers out: what INTEGRATION.md's planBatch binds to (PCIe both ways inside)
-                ts = []
-                for _ in range(5):
-                    t = time.perf_counter()
-                    r = ctx.plan(batch, breakdown=False, n_units=False)
-                    ctx.allocate(batch, r.distro_info, r.group_info)
-                    ts.append(time.perf_counter() - t)
-                ts.sort()
+                # host pointers in, host pointers out: what INTEGRATION.md's planBatch binds to (PCIe both ways inside).
+                # The shim's buffers come from evg_host_alloc (page-locked, allocated once, re-used every tick); the same
+                # calls on pageable numpy arrays are timed next to it.
+                from evergreen_amd import abi
+
+                def timed(b, r, a):
+                    ts = []
+                    for _ in range(7):
+                        t = time.perf_counter()
+                        ctx.plan(b, into=r)
+                        ctx.allocate(b, r.distro_info, r.group_info, into=a)
+                        ts.append(time.perf_counter() - t)
+                    ts.sort()
+                    return ts
+                r0, a0 = abi.PlanResult.alloc_host(batch, breakdown=False, n_units=False), abi.AllocResult.alloc_host(batch.n_distros)
+                tp = timed(batch, r0, a0)
+                pb, r, a = ctx.pinned_batch(batch), ctx.pinned_result(r0), ctx.pinned_result(a0)
+                r.order[:] = -1
+                ts = timed(pb, r, a)
                 b_in = sum(v.nbytes for v in batch.cols.values()) + batch.dep_off.nbytes + sum(v.nbytes for v in batch.edges.values()) + \
                     sum(v.nbytes for v in batch.hosts.values())
                 b_out = r.order.nbytes + r.deps_met.nbytes + r.wait_ns.nbytes + r.distro_info.nbytes + r.group_info.nbytes
-                return {"value": batch.n_tasks / ts[len(ts) // 2], "unit": "tasks/s", "ms_per_call": ts[len(ts) // 2] * 1e3, "ms_min": ts[0] * 1e3,
-                        "bytes_in": b_in, "bytes_out": b_out, "identical_to_resident": bool(np.array_equal(r.order, got.order)),
-                        "what": "evg_plan_distros + evg_allocate_hosts on host numpy buffers: H2D of every column, the kernels, D2H of the outputs"}
+                ms = ts[len(ts) // 2] * 1e3
+                return {"value": batch.n_tasks / ts[len(ts) // 2], "unit": "tasks/s", "ms_per_call": ms, "ms_min": ts[0] * 1e3,
+                        "pageable_ms_per_call": tp[len(tp) // 2] * 1e3, "bytes_in": b_in, "bytes_out": b_out,
+                        "link_GBps": (b_in + b_out) / (ms * 1e-3) / 1e9,
+                        "identical_to_resident": bool(np.array_equal(r.order, got.order) and np.array_equal(r0.order, got.order)),
+                        "what": "evg_plan_distros + evg_allocate_hosts on host buffers from evg_host_alloc: H2D of every column, the kernels, "
+                                "D2H of the outputs (pageable_ms_per_call: the same calls on pageable numpy arrays)"}
+            def drop_in():
+                # what the TaskPlanner contract needs on top of the order: SortingValueBreakdown for every returned task
+                # (model/task/task.go:4152) -- as rows per unit + the emitting unit of each task (evg_plan_output, ABI 1.2)
+                ms, p_ms, a_ms, r, _ = resident_rate(batch, dev, native, resident, torch, steps=20, warmup=3, units=True)
+                same = bool(full is not None and np.array_equal(r.expand_breakdown(), full.breakdown) and np.array_equal(r.order, got.order))
+                return {"value": batch.n_tasks / (ms * 1e-3), "unit": "tasks/s", "ms_per_step": ms, "planning-distro_ms": p_ms, "host-allocation_ms": a_ms,
+                        "vs_lean_plan": p_ms / plan_ms[0], "rows_identical_to_per_task_breakdown": same,
+                        "bytes_out_extra": int(r.unit_of_task.nbytes + r.unit_breakdown.nbytes),
+                        "what": "the resident tick with unit_of_task + unit_breakdown requested (k_plan_distros<false, true>: same LDS block, two "
+                                "workgroups per CU; 13 stores per live unit in the scoring phase, 4 bytes per task)"}
+            guarded("drop_in", drop_in)
             guarded("end_to_end", end_to_end)
             guarded("skewed", lambda: extra_workload("skewed", gen.config(3, skew=True), "BASELINE config 3, skewed variant: Zipf(s=1) distro sizes "
                                                      "truncated to [64, 65536]", dev, native, resident, torch, gen, np))

@@ -52,7 +52,7 @@ class PlanInput(C.Structure):
 
 class PlanOutput(C.Structure):
     _fields_ = [("order", _p), ("breakdown", _p), ("deps_met", _p), ("wait_ns", _p),
-                ("distro_info", _p), ("group_info", _p), ("n_units", _p)]
+                ("distro_info", _p), ("group_info", _p), ("n_units", _p), ("unit_of_task", _p), ("unit_breakdown", _p)]
 
 
 class HostSoa(C.Structure):
@@ -257,11 +257,21 @@ class PlanResult:
     distro_info: np.ndarray
     group_info: np.ndarray
     n_units: Optional[np.ndarray]
+    unit_of_task: Optional[np.ndarray] = None     # N by row: slot of the emitting unit (evg_plan_output.unit_of_task)
+    unit_breakdown: Optional[np.ndarray] = None   # 13 x (N + n_task_groups + n_versions): field-major, by unit slot
+
+    def expand_breakdown(self) -> np.ndarray:
+        """SortingValueBreakdown rows by TASK from the rows by unit: what TaskPlan.Export stamps on each task
+        (planner.go:475) -- a gather, no arithmetic."""
+        return np.ascontiguousarray(self.unit_breakdown[:, self.unit_of_task].T)
 
     @staticmethod
-    def alloc_host(batch: PlanBatch, breakdown=True, n_units=True) -> "PlanResult":
+    def alloc_host(batch: PlanBatch, breakdown=True, n_units=True, units=False) -> "PlanResult":
         n, d, g = batch.n_tasks, batch.n_distros, batch.n_task_groups
+        nslots = n + g + int(batch.ver_off[-1])
         return PlanResult(
+            unit_of_task=np.full(n, -1, np.int32) if units else None,
+            unit_breakdown=np.zeros((BREAKDOWN_FIELDS, nslots), np.int64) if units else None,
             order=np.full(n, -1, np.int32),
             breakdown=np.zeros((n, BREAKDOWN_FIELDS), np.int64) if breakdown else None,
             deps_met=np.zeros(n, np.uint8), wait_ns=np.zeros(n, np.int64),
@@ -274,6 +284,7 @@ class PlanResult:
         out.deps_met, out.wait_ns = _ptr(self.deps_met), _ptr(self.wait_ns)
         out.distro_info, out.group_info = _ptr(self.distro_info), _ptr(self.group_info)
         out.n_units = _ptr(self.n_units)
+        out.unit_of_task, out.unit_breakdown = _ptr(self.unit_of_task), _ptr(self.unit_breakdown)
         return out
 
 

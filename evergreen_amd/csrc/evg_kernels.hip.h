@@ -364,10 +364,12 @@ __device__ __forceinline__ UnitTimeTerms unit_time_terms_go(int64_t n, int64_t t
   return o;
 }
 
-// bd == nullptr: only TotalValue. GO_FORM: every step as the Go code states it (self-test reference).
+// bd == nullptr: only TotalValue; else field k of the breakdown goes to bd[k * bd_stride] (the unit rows are stored
+// field-major, evg_plan_output.unit_breakdown: one store instruction of a wave then covers 64 consecutive words).
+// GO_FORM: every step as the Go code states it (self-test reference).
 template <bool GO_FORM = false>
 __device__ inline int64_t unit_value(const evg_distro_params& p, int64_t n, int64_t tiq, int64_t dur, int64_t maxpri,
-                                     int64_t maxnd, uint32_t fl, int64_t* bd) {
+                                     int64_t maxnd, uint32_t fl, int64_t* bd, size_t bd_stride = 1) {
   const bool in_cq = fl & UF_MERGE, in_patch = fl & UF_PATCH, nongroup = fl & UF_NONGROUP, gen = fl & UF_GENERATE,
              stepback = fl & UF_STEPBACK;
   // computePriority :271-300
@@ -401,13 +403,19 @@ __device__ inline int64_t unit_value(const evg_distro_params& p, int64_t n, int6
   rank = wrap_add(rank, r_cq); rank = wrap_add(rank, r_step); rank = wrap_add(rank, r_nd); rank = wrap_add(rank, r_rt);
   int64_t total = wrap_add(wrap_mul(pri, rank), n);
   if (bd) {
-    bd[EVG_BD_TASK_GROUP_LENGTH] = n; bd[EVG_BD_TOTAL_VALUE] = total;
-    bd[EVG_BD_PRI_INITIAL] = b_init; bd[EVG_BD_PRI_TASK_GROUP] = b_tg; bd[EVG_BD_PRI_GENERATOR] = b_gen;
-    bd[EVG_BD_PRI_COMMIT_QUEUE] = b_cq; bd[EVG_BD_RANK_COMMIT_QUEUE] = r_cq; bd[EVG_BD_RANK_NUM_DEPENDENTS] = r_nd;
-    bd[EVG_BD_RANK_EST_RUNTIME] = r_rt; bd[EVG_BD_RANK_MAINLINE_WAIT] = r_main; bd[EVG_BD_RANK_STEPBACK] = r_step;
-    bd[EVG_BD_RANK_PATCH] = r_patch; bd[EVG_BD_RANK_PATCH_WAIT] = r_patchwait;
+    bd[EVG_BD_TASK_GROUP_LENGTH * bd_stride] = n; bd[EVG_BD_TOTAL_VALUE * bd_stride] = total;
+    bd[EVG_BD_PRI_INITIAL * bd_stride] = b_init; bd[EVG_BD_PRI_TASK_GROUP * bd_stride] = b_tg; bd[EVG_BD_PRI_GENERATOR * bd_stride] = b_gen;
+    bd[EVG_BD_PRI_COMMIT_QUEUE * bd_stride] = b_cq; bd[EVG_BD_RANK_COMMIT_QUEUE * bd_stride] = r_cq;
+    bd[EVG_BD_RANK_NUM_DEPENDENTS * bd_stride] = r_nd; bd[EVG_BD_RANK_EST_RUNTIME * bd_stride] = r_rt;
+    bd[EVG_BD_RANK_MAINLINE_WAIT * bd_stride] = r_main; bd[EVG_BD_RANK_STEPBACK * bd_stride] = r_step;
+    bd[EVG_BD_RANK_PATCH * bd_stride] = r_patch; bd[EVG_BD_RANK_PATCH_WAIT * bd_stride] = r_patchwait;
   }
   return total;
+}
+
+// Unit slots of the whole batch = the row length of the field-major unit_breakdown (evg_plan_output).
+__device__ __forceinline__ size_t unit_slots(const evg_plan_input& in) {
+  return (size_t)in.tasks.n_tasks + (size_t)in.n_task_groups + (size_t)in.n_versions;
 }
 
 // Per-distro uniform state.
@@ -438,6 +446,7 @@ struct Mem {
   const int32_t *c_tgo, *c_nd;
   uint32_t *g_cnt, *g_cover, *g_wait, *g_mq, *g_first;  // group accumulators
   uint64_t *g_dur, *g_dover;
+  size_t sb;   // first unit slot of the distro in the batch-wide numbering (evg_plan_output.unit_of_task)
   int g0, gk;  // index of the standalone row and of task group 0 in the g_* arrays
   __device__ __forceinline__ int grow(int tgk_local) const { return tgk_local < 0 ? g0 : gk + tgk_local; }
 };
@@ -597,7 +606,9 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem&
     const uint32_t cw = m.cnt[u];
     const int64_t nu = cw & UF_COUNT_MASK;
     int64_t v = INT64_MIN;
-    if (nu > 0 && (cw & UF_DISTRO)) v = unit_value(p, nu, m.tiq[u], m.dur[u], m.maxpri[u], m.maxnd[u], cw, nullptr);
+    if (nu > 0 && (cw & UF_DISTRO))
+      v = unit_value(p, nu, m.tiq[u], m.dur[u], m.maxpri[u], m.maxnd[u], cw,
+                     a.out.unit_breakdown ? a.out.unit_breakdown + (m.sb + (size_t)u) : nullptr, unit_slots(a.in));
     m.val[u] = v;
   }
   __syncthreads();
@@ -658,11 +669,7 @@ __device__ __forceinline__ void plan_distro(const PlanArgs& a, const DC& c, Mem&
                               });
     m.k0[i] = bv;
     m.k1[i] = ((k1_t)bm << Mem::kShift) | (k1_t)best;
-    if (a.out.breakdown) {
-      const uint32_t cw = m.cnt[best];
-      unit_value(p, cw & UF_COUNT_MASK, m.tiq[best], m.dur[best], m.maxpri[best], m.maxnd[best], cw,
-                 a.out.breakdown + (size_t)r * EVG_BREAKDOWN_FIELDS);
-    }
+    if (a.out.unit_of_task) a.out.unit_of_task[r] = (int32_t)(m.sb + (size_t)best);
   }
   __syncthreads();  // accumulators are dead from here on
   }

@@ -24,8 +24,9 @@
 // branches -- uniformly, before any output is written -- to the generic path of evg_kernels.hip.h. Value ranges
 // that do not compress into 64 bits take wider-key variants of E / F inside this path.
 //
-// RICH = the optional outputs (SortingValueBreakdown rows, TaskPlan.Len()) are requested: 34 KiB more LDS
-// (one workgroup per CU); chosen at launch.
+// RICH = TaskPlan.Len() is requested: 18 KiB more LDS for the unit hashes (one workgroup per CU); chosen at launch.
+// BD   = SortingValueBreakdown rows are requested: phase C stores the 13 fields of every live unit (once per UNIT, where
+//        the score is computed anyway) and phase D the emitting unit of every task; same LDS block as the lean kernel.
 #pragma once
 
 #include "evg_alloc.hip.h"
@@ -52,7 +53,7 @@ constexpr int kG = 1024;             // task-group rows (incl. the standalone ro
 // edges, or 1600 slots with up to 9.2k edges). RICH appends val i64[kS] | hash u64[kS] behind the lean block.
 constexpr int kLdsLean = 79872;
 constexpr int B_PSLOT = kLdsLean - 2 * kN;
-constexpr int R_VAL = kLdsLean, R_HASH = R_VAL + 8 * kS, kLdsRich = R_HASH + 8 * kS;
+constexpr int R_HASH = kLdsLean, kLdsRich = R_HASH + 8 * kS;
 // region A re-used after D:
 constexpr int X_BUF0 = 0, X_BUF1 = 8 * kN, X_IK = 16 * kN, X_IK_END = X_IK + 8 * kN;  // sort exchange, in-unit keys by task
 constexpr int Y_SIK = 0, Y_SSLOT = 8 * kN, Y_SIDX = Y_SSLOT + 2 * kN;                  // by sorted position
@@ -210,7 +211,7 @@ __device__ __forceinline__ bool fits_lds_path(const DC& c) {
 // FUSED: the distro's UtilizationBasedHostAllocator pass (q) runs as the tail of the same workgroup: its host rows are
 // fetched before the sort, so their latency hides behind the planner's compute, and the queue info it consumes never
 // leaves the CU.
-template <bool RICH, bool FUSED>
+template <bool RICH, bool FUSED, bool BD>
 __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocArgs& q, const int d, const int lo, const int n,
                                                 unsigned char* smem, unsigned* s_red) {
   const evg_task_soa& t = a.in.tasks;
@@ -246,7 +247,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     m.cnt = (uint32_t*)(m.maxpri + Sp); m.maxnd = (int32_t*)(m.cnt + Sp); m.minrow = (uint32_t*)(m.maxnd + Sp);
     m.pslot = (uint16_t*)(smem + B_PSLOT); m.edge = m.pslot - lds_pad_edges(c.ne);
   }
-  m.val = RICH ? (int64_t*)(smem + R_VAL) : m.tiq;  // lean: TotalValue overwrites the unit's TimeInQueue sum
+  m.val = m.tiq;  // TotalValue overwrites the unit's TimeInQueue sum
   // s_red words: 0 any met merge-queue task, 1 n_met, 2 n_mq, 3 n_s3, 4 secondary, 5 t_cover, 6 t_wait, 7 n_units,
   // 8 rows, 10-11 t_dur, 12-13 t_dover; 16-23 four 64-bit range words; 24-29 six 32-bit range words
   unsigned long long* s_rng = (unsigned long long*)(s_red + 16);  // 0 vmin 1 vmax 2 durmin 3 durmax (biased)
@@ -389,13 +390,34 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // The distro's planner settings are 22 SGPRs and nothing before this point reads them: fetched here, behind an index
   // the compiler cannot see through, they stay out of the register file while phases A and B are short of SGPRs.
   EVG_OPAQUE_ZERO(late0);
-  const evg_distro_params p = a.in.distros[d + late0];
+  // Read through the constant address space (the settings are an input no kernel writes): scalar loads into SGPRs. As a
+  // plain global read the compiler uses VECTOR loads (it cannot prove the array unclobbered), and threads that skip the
+  // scoring loop leave them pending: the s_waitcnt vmcnt(0) that then guards their destination registers after the loop
+  // also waits for every unit-breakdown store of the loop -- +22 us on the breakdown build.
+  evg_distro_params p;
+  {
+    typedef const __attribute__((address_space(4))) uint32_t* const_words;
+    const const_words q = (const_words)(uintptr_t)(a.in.distros + (d + late0));
+    uint32_t w[sizeof(evg_distro_params) / 4];
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(evg_distro_params) / 4; k++) w[k] = q[k];
+    __builtin_memcpy(&p, w, sizeof p);
+  }
   // ---- C: score every unit (planner.go:209-300); units whose distro is nil are dropped (:81) -----------------
+  const int sb = lo + c.tg_lo + c.ver_lo;  // first unit slot of the distro in the batch-wide numbering (evg_plan_output)
+  int64_t* ubd = nullptr;
+  if (BD) {
+    ubd = EVG_LATE_ARG(int64_t*, out.unit_breakdown, late0);  // NULL when only TaskPlan.Len() was asked of the <RICH, BD> kernel
+    if (ubd) ubd += sb;
+  }
+  const size_t ubd_stride = BD ? (size_t)EVG_LATE_ARG(int32_t, in.tasks.n_tasks, late0) + (size_t)EVG_LATE_ARG(int32_t, in.n_task_groups, late0) +
+                                     (size_t)EVG_LATE_ARG(int32_t, in.n_versions, late0) : 1;
   for (int u = tid; u < S; u += kBlock) {
     const uint32_t cw = m.cnt[u];
     const int64_t nu = cw & UF_COUNT_MASK;
     int64_t v = INT64_MIN;
-    if (nu > 0 && (cw & UF_DISTRO)) v = unit_value(p, nu, m.tiq[u], m.dur[u], (int64_t)m.maxpri[u], (int64_t)m.maxnd[u], cw, nullptr);
+    if (nu > 0 && (cw & UF_DISTRO))
+      v = unit_value(p, nu, m.tiq[u], m.dur[u], (int64_t)m.maxpri[u], (int64_t)m.maxnd[u], cw, BD && ubd ? ubd + u : nullptr, ubd_stride);
     m.val[u] = v;
   }
   EVG_STAMP(3); EVG_STOP(3);
@@ -469,11 +491,6 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       if (!(er & (ED_OUT | ER_SKIP))) consider((int)(er & ER_SLOT));
     }
     bv[e] = bvv; bm[e] = bmm; bs[e] = best;
-    if (RICH && a.out.breakdown) {
-      const uint32_t cw = m.cnt[best];
-      unit_value(p, cw & UF_COUNT_MASK, m.tiq[best], m.dur[best], (int64_t)m.maxpri[best], (int64_t)m.maxnd[best], cw,
-                 a.out.breakdown + (size_t)(lo + i) * EVG_BREAKDOWN_FIELDS);
-    }
     const uint64_t uv = ub(bvv), ud = ub(dur[e]);
     const uint32_t ut = ub(tgo[e]), un = ub(nd[e]), up = ub((int32_t)pri[e]);
     r_vmin = uv < r_vmin ? uv : r_vmin; r_vmax = uv > r_vmax ? uv : r_vmax;
@@ -494,6 +511,13 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // the columns of phase G: fetched now, consumed after the sort
   int64_t sched[4], dmt[4];
   EVG_OPAQUE_ZERO(late1);
+  if (BD) {  // the unit each task is emitted from = the row of unit_breakdown that TaskPlan.Export stamps on it
+    int32_t u4[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) u4[e] = sb + bs[e];
+    int32_t* uot = EVG_LATE_ARG(int32_t*, out.unit_of_task, late1);
+    if (uot) store4(uot + lo, i0, n, u4);
+  }
   load4(EVG_LATE_ARG(const int64_t*, in.tasks.scheduled_ts_ns, late1) + lo, i0, n, (int64_t)0, sched);
   load4(EVG_LATE_ARG(const int64_t*, in.tasks.deps_met_ts_ns, late1) + lo, i0, n, (int64_t)0, dmt);
   EVG_STAMP(5); EVG_STOP(5);
@@ -908,7 +932,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
 
 // One workgroup per distro: the LDS path. Distros it cannot take are flagged in a.w_generic[d] and left to
 // k_plan_generic, which is enqueued right behind this kernel.
-template <bool RICH>
+template <bool RICH, bool BD>
 __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
@@ -932,7 +956,7 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const Pla
   }
 #endif
   const AllocArgs none{};
-  const bool done = n <= kN && plan_distro_lds<RICH, false>(a, none, d, lo, n, smem, s_red);
+  const bool done = n <= kN && plan_distro_lds<RICH, false, BD>(a, none, d, lo, n, smem, s_red);
   if (threadIdx.x == 0) a.w_generic[d] = done ? 0 : 1;
 }
 
@@ -941,7 +965,7 @@ struct FusedArgs {
   PlanArgs p;
   AllocArgs q;  // q.in.distro_info / q.in.group_info alias p.out.distro_info / p.out.group_info
 };
-template <bool RICH>
+template <bool RICH, bool BD>
 __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const FusedArgs f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
@@ -954,7 +978,7 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const Fu
   struct { int d; } c{d};
 #endif
   EVG_STAMP(0);
-  const bool done = n <= kN && plan_distro_lds<RICH, true>(f.p, f.q, d, lo, n, smem, s_red);
+  const bool done = n <= kN && plan_distro_lds<RICH, true, BD>(f.p, f.q, d, lo, n, smem, s_red);
   if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
 }
 
@@ -964,6 +988,7 @@ __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c
   Mem m;
   m.tiq = a.w_tiq + sb; m.dur = a.w_dur + sb; m.maxpri = a.w_maxpri + sb; m.val = a.w_val + sb;
   m.cnt = a.w_cnt + sb; m.maxnd = a.w_maxnd + sb; m.minrow = a.w_minrow + sb; m.hash = a.w_hash + sb;
+  m.sb = sb;
   m.pslot = a.w_pslot + c.lo;
   m.k0 = a.w_k0 + c.lo; m.k1 = a.w_k1 + c.lo; m.idx = a.w_idx + 2 * (size_t)c.lo; m.pos = a.w_pos + c.lo;
   const evg_task_soa& t = a.in.tasks;

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "evg_alloc.hip.h"
@@ -271,6 +272,17 @@ __global__ void __launch_bounds__(64) k_allocator_report(int D, const int32_t* t
   report[d] = r;
 }
 
+// SortingValueBreakdown rows by TASK from the field-major rows by unit (evg_plan_output.breakdown is an expansion of
+// unit_breakdown by unit_of_task: TaskPlan.Export stamps the unit's value on each of its tasks, planner.go:475). One thread
+// per int64 of the output: the writes are consecutive words, the reads 13 lines per row that the rows of a distro share.
+__global__ void __launch_bounds__(256) k_expand_breakdown(size_t n_rows, size_t n_slots, const int32_t* unit_of_task,
+                                                          const int64_t* unit_breakdown, int64_t* breakdown) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_rows * EVG_BREAKDOWN_FIELDS) return;
+  const size_t row = j / EVG_BREAKDOWN_FIELDS, f = j - row * EVG_BREAKDOWN_FIELDS;
+  breakdown[j] = unit_breakdown[f * n_slots + (size_t)unit_of_task[row]];
+}
+
 // ---- self-test of the scoring arithmetic (evg_selftest_unit_value) --------------------------------------------------
 // unit_value's fast time terms against the Go-shaped statement of the same formula, all 13 breakdown fields, on inputs
 // built to sit on and around everything the fast form's proof leans on. Case i (grid-stride):
@@ -397,6 +409,13 @@ static int ensure(evg_ctx* c, DevBuf& b, size_t bytes) {
   return EVG_OK;
 }
 
+// The host-pointer entry points are synchronous and retain nothing: whatever way they leave (an error after some copies
+// were enqueued included), the context's stream is drained first, so no copy touches caller memory after the return.
+struct StreamDrain {
+  evg_ctx* c;
+  ~StreamDrain() { (void)hipStreamSynchronize(c->stream); }
+};
+
 struct Stager {
   evg_ctx* c;
   int slot = 0;
@@ -519,6 +538,58 @@ int evg_selftest_unit_value(evg_ctx* c, uint64_t seed, uint64_t n_cases, uint64_
   return EVG_OK;
 }
 
+void* evg_host_alloc(evg_ctx* c, size_t bytes) {
+  if (!c || bytes == 0) return nullptr;
+  std::lock_guard<std::mutex> lk(c->mu);
+  void* p = nullptr;
+  if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    set_err(c, EVG_E_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    return nullptr;
+  }
+  return p;
+}
+
+void evg_host_free(evg_ctx* c, void* p) {
+  if (!c || !p) return;
+  std::lock_guard<std::mutex> lk(c->mu);
+  (void)hipSetDevice(c->device);
+  (void)hipHostFree(p);
+}
+
+// One distro's share of the layout contract; 0 or EVG_E_CONTRACT with the message in `err`.
+static int validate_distro(const evg_plan_input* in, int d, char* err, size_t err_len) {
+  const evg_task_soa& t = in->tasks;
+  auto fail = [&](const char* fmt, long a, long b) {
+    snprintf(err, err_len, fmt, a, b);
+    return EVG_E_CONTRACT;
+  };
+  const int lo = in->task_off[d], hi = in->task_off[d + 1];
+  if (hi < lo) return fail("task_off not monotone at distro %ld (%ld)", d, hi);
+  if (hi - lo >= (1 << 24)) return fail("distro %ld has %ld tasks; the limit is 2^24-1", d, hi - lo);
+  int next_tg = in->tg_off[d], next_ver = in->ver_off[d];
+  for (int r = lo; r < hi; r++) {
+    const int g = t.tg_key[r], v = t.version_key[r];
+    if (g >= 0) {
+      if (g > next_tg || g < in->tg_off[d]) return fail("row %ld: tg_key %ld is not in first-appearance order", r, g);
+      if (g == next_tg) next_tg++;
+    } else if (g != -1) return fail("row %ld: tg_key %ld (use -1 for no task group)", r, g);
+    if (v > next_ver || v < in->ver_off[d]) return fail("row %ld: version_key %ld is not in first-appearance order", r, v);
+    if (v == next_ver) next_ver++;
+    const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
+    if (e1 < e0) return fail("dep_off not monotone at row %ld (%ld)", r, e1);
+    if (e0 < 0 || e1 > t.n_edges) return fail("row %ld: dep_off %ld outside [0, n_edges]", r, e1);
+    // a dependency is a row of the SAME distro's queue or -1 (not in this queue: its state rides in dep_info); a row of
+    // another distro would be read as "not in the queue" with status bits nobody filled
+    for (int e = e0; e < e1; e++) {
+      const int j = t.dep_idx[e];
+      if (j != -1 && (j < lo || j >= hi)) return fail("edge %ld: dep_idx %ld is neither -1 nor a row of the same distro", e, j);
+    }
+  }
+  if (next_tg != in->tg_off[d + 1]) return fail("distro %ld: tg keys do not fill [tg_off[d], tg_off[d+1]) (%ld)", d, next_tg);
+  if (next_ver != in->ver_off[d + 1]) return fail("distro %ld: version keys do not fill their range (%ld)", d, next_ver);
+  return EVG_OK;
+}
+
 int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len) {
   auto fail = [&](const char* fmt, long a, long b) {
     if (msg && msg_len > 0) snprintf(msg, msg_len, fmt, a, b);
@@ -530,28 +601,35 @@ int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len
   if (D < 0 || t.n_tasks < 0 || t.n_edges < 0) return fail("negative size (%ld, %ld)", D, t.n_tasks);
   if (D == 0) return EVG_OK;
   if (!in->task_off || !in->tg_off || !in->ver_off || !in->distros) return EVG_E_INVALID;
+  if (t.n_tasks > 0 && (!t.tg_key || !t.version_key || !t.dep_off || (t.n_edges > 0 && !t.dep_idx))) return EVG_E_INVALID;
   if (in->task_off[0] != 0 || in->task_off[D] != t.n_tasks) return fail("task_off must span [0, n_tasks] (%ld..%ld)", in->task_off[0], in->task_off[D]);
   if (in->tg_off[0] != 0 || in->tg_off[D] != in->n_task_groups) return fail("tg_off must span [0, n_task_groups] (%ld..%ld)", in->tg_off[0], in->tg_off[D]);
   if (in->ver_off[0] != 0 || in->ver_off[D] != in->n_versions) return fail("ver_off must span [0, n_versions] (%ld..%ld)", in->ver_off[0], in->ver_off[D]);
+  if (t.n_tasks && t.dep_off[0] != 0) return fail("dep_off[0]=%ld must be 0 (n_edges=%ld)", t.dep_off[0], t.n_edges);
   if (t.n_tasks && t.dep_off[t.n_tasks] != t.n_edges) return fail("dep_off[N]=%ld != n_edges=%ld", t.dep_off[t.n_tasks], t.n_edges);
-  for (int d = 0; d < D; d++) {
-    const int lo = in->task_off[d], hi = in->task_off[d + 1];
-    if (hi < lo) return fail("task_off not monotone at distro %ld (%ld)", d, hi);
-    if (hi - lo >= (1 << 24)) return fail("distro %ld has %ld tasks; the limit is 2^24-1", d, hi - lo);
-    int next_tg = in->tg_off[d], next_ver = in->ver_off[d];
-    for (int r = lo; r < hi; r++) {
-      const int g = t.tg_key[r], v = t.version_key[r];
-      if (g >= 0) {
-        if (g > next_tg || g < in->tg_off[d]) return fail("row %ld: tg_key %ld is not in first-appearance order", r, g);
-        if (g == next_tg) next_tg++;
-      } else if (g != -1) return fail("row %ld: tg_key %ld (use -1 for no task group)", r, g);
-      if (v > next_ver || v < in->ver_off[d]) return fail("row %ld: version_key %ld is not in first-appearance order", r, v);
-      if (v == next_ver) next_ver++;
-      if (t.dep_off[r + 1] < t.dep_off[r]) return fail("dep_off not monotone at row %ld (%ld)", r, t.dep_off[r + 1]);
-    }
-    if (next_tg != in->tg_off[d + 1]) return fail("distro %ld: tg keys do not fill [tg_off[d], tg_off[d+1]) (%ld)", d, next_tg);
-    if (next_ver != in->ver_off[d + 1]) return fail("distro %ld: version keys do not fill their range (%ld)", d, next_ver);
+  if (in->max_distro_tasks < 0) return fail("max_distro_tasks %ld is negative (0 = unknown) (%ld)", in->max_distro_tasks, 0);
+  // The per-row checks are independent per distro: a large batch is checked by a few threads (this runs inside every
+  // host-pointer call; one thread needs ~1.5 ms for 1M rows + 1.3M edges). The FIRST failing distro's message is reported.
+  const int nt = t.n_tasks + t.n_edges < (1 << 18) ? 1 : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  std::vector<int> first_bad(nt, D);
+  std::vector<std::string> errs(nt);
+  auto work = [&](int w) {
+    char buf[256];
+    for (int d = (int)((long long)D * w / nt), d1 = (int)((long long)D * (w + 1) / nt); d < d1; d++)
+      if (validate_distro(in, d, buf, sizeof buf) != EVG_OK) { first_bad[w] = d; errs[w] = buf; return; }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int w = 1; w < nt; w++) th.emplace_back(work, w);
+    work(0);
+    for (auto& x : th) x.join();
   }
+  for (int w = 0; w < nt; w++)
+    if (first_bad[w] < D) {
+      if (msg && msg_len > 0) snprintf(msg, msg_len, "%s", errs[w].c_str());
+      return EVG_E_CONTRACT;
+    }
   return EVG_OK;
 }
 
@@ -597,12 +675,39 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.dbg_ts = c->dbg_ts;
 #endif
   if (!c->lds_attr_set) {
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
     c->lds_attr_set = true;
   }
+  // SortingValueBreakdown: the kernels write rows per UNIT (+ the emitting unit of every task); rows per task are an
+  // expansion of those, done by k_expand_breakdown after the plan (finish_breakdown) into the caller's `breakdown`.
+  if ((out->unit_of_task != nullptr) != (out->unit_breakdown != nullptr))
+    return set_err(c, EVG_E_INVALID, "unit_of_task and unit_breakdown come together (both or neither)");
+  a.out.breakdown = nullptr;
+  if (out->breakdown && !out->unit_breakdown) {
+    int rc = ensure(c, c->scratch[30], 4 * (N + 1));
+    if (!rc) rc = ensure(c, c->scratch[31], 8 * EVG_BREAKDOWN_FIELDS * Stot);
+    if (rc) return rc;
+    a.out.unit_of_task = (int32_t*)c->scratch[30].p;
+    a.out.unit_breakdown = (int64_t*)c->scratch[31].p;
+  }
+  return EVG_OK;
+}
+
+// Rows by task for the caller that asked for them, rows [task_off[d0], task_off[d1]) -- as a row range because task_off is
+// device memory on the _device paths: the range form expands the whole batch's rows only when it plans the whole batch.
+static int finish_breakdown(evg_ctx* c, const evg::PlanArgs& a, const evg_plan_output* out, hipStream_t st, bool whole_batch) {
+  if (!out->breakdown) return EVG_OK;
+  if (!whole_batch) return set_err(c, EVG_E_INVALID, "rows by task (breakdown) are not available from the distro-range entry point; "
+                                                     "ask for unit_of_task + unit_breakdown");
+  const size_t N = (size_t)a.in.tasks.n_tasks, words = N * EVG_BREAKDOWN_FIELDS;
+  if (!words) return EVG_OK;
+  hipLaunchKernelGGL(evg::k_expand_breakdown, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, N,
+                     N + (size_t)a.in.n_task_groups + (size_t)a.in.n_versions, a.out.unit_of_task, a.out.unit_breakdown, out->breakdown);
+  HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }
 
@@ -706,12 +811,15 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
     if (d_begin == d_end) return EVG_OK;
   }
   const int D = a.d1 - a.d0;
-  // the optional outputs need 36 KiB more LDS per workgroup (one workgroup per CU instead of two)
-  if (out->breakdown || out->n_units) hipLaunchKernelGGL(k_plan_distros<true>, dim3(D), dim3(kBlock), kLdsRich, st, a);
-  else hipLaunchKernelGGL(k_plan_distros<false>, dim3(D), dim3(kBlock), kLdsLean, st, a);
+  // TaskPlan.Len() needs 18 KiB more LDS per workgroup (one workgroup per CU instead of two); the breakdown rows do not
+  if (out->n_units) hipLaunchKernelGGL((k_plan_distros<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, a);
+  else if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros<false, true>), dim3(D), dim3(kBlock), kLdsLean, st, a);
+  else hipLaunchKernelGGL((k_plan_distros<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, a);
   HIP_TRY(c, hipGetLastError());
   // distros the LDS path could not take (flagged on the device); the workgroups exit at once otherwise
-  return launch_generic(c, a, in, st);
+  rc = launch_generic(c, a, in, st);
+  if (rc) return rc;
+  return finish_breakdown(c, a, out, st, d_end < 0 || (d_begin == 0 && d_end == in->n_distros));
 }
 
 int evg_plan_distros_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, void* hip_stream) {
@@ -776,12 +884,12 @@ int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_pla
   if (rc) return rc;
   const int D = in->n_distros;
   hipStream_t st = (hipStream_t)hip_stream;
-  if (out->breakdown || out->n_units) hipLaunchKernelGGL(k_plan_allocate<true>, dim3(D), dim3(kBlock), kLdsRich, st, f);
-  else hipLaunchKernelGGL(k_plan_allocate<false>, dim3(D), dim3(kBlock), kLdsLean, st, f);
+  if (f.p.out.unit_breakdown || out->n_units) hipLaunchKernelGGL((k_plan_allocate<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, f);
+  else hipLaunchKernelGGL((k_plan_allocate<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, f);
   HIP_TRY(c, hipGetLastError());
   hipLaunchKernelGGL(k_plan_allocate_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), kGenericLds, st, f);
   HIP_TRY(c, hipGetLastError());
-  return EVG_OK;
+  return finish_breakdown(c, f.p, out, st, true);
 }
 
 int evg_cap_queue_device(evg_ctx* c, int32_t n_distros, const int32_t* task_off, const int32_t* order,
@@ -921,15 +1029,21 @@ int evg_allocator_report_device(evg_ctx* c, int32_t n_distros, const int32_t* tg
 static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const int32_t* tg_name_key,
                          int32_t max_scheduled, const evg_queue_items* items, const evg_dispatch_order* disp) {
   HIP_TRY(c, hipSetDevice(c->device));
+  if (in->n_distros < 0 || in->tasks.n_tasks < 0 || in->tasks.n_edges < 0 || in->n_task_groups < 0 || in->n_versions < 0)
+    return set_err(c, EVG_E_CONTRACT, "negative size");
+  const size_t N = in->tasks.n_tasks, D = in->n_distros, G = D + in->n_task_groups, TG = in->n_task_groups;
+  if (D == 0) return EVG_OK;
+  if (!in->task_off || !in->tg_off || !in->ver_off || !in->distros) return set_err(c, EVG_E_INVALID, "invalid plan input");
+  if (disp && !items) return set_err(c, EVG_E_INVALID, "the dispatcher order is built from the persisted queues: items is required");
+  if (items && items->breakdown && !out->breakdown) return set_err(c, EVG_E_INVALID, "item breakdowns need the plan's breakdown output");
+  StreamDrain drain{c};
+  Stager s{c};
+  // the uploads are enqueued first (plain DMA from evg_host_alloc buffers) and the contract is checked while they run;
+  // nothing is launched on a batch that fails it
+  evg_plan_input di = stage_plan_input(s, in);
   char msg[256];
   int rc = evg_validate_plan_input(in, msg, sizeof msg);
   if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
-  const size_t N = in->tasks.n_tasks, D = in->n_distros, G = D + in->n_task_groups, TG = in->n_task_groups;
-  if (D == 0) return EVG_OK;
-  if (disp && !items) return set_err(c, EVG_E_INVALID, "the dispatcher order is built from the persisted queues: items is required");
-  if (items && items->breakdown && !out->breakdown) return set_err(c, EVG_E_INVALID, "item breakdowns need the plan's breakdown output");
-  Stager s{c};
-  evg_plan_input di = stage_plan_input(s, in);
   evg_plan_output dout;
   dout.order = s.out<int32_t>(N, true);
   dout.breakdown = s.out<int64_t>(N * EVG_BREAKDOWN_FIELDS, out->breakdown != nullptr);
@@ -953,7 +1067,12 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
   if (disp) {
     od.sorted = s.out<int32_t>(N, true); od.n_sorted = s.out<int32_t>(D, true); od.n_cycles = s.out<int32_t>(D, true);
     od.group_items = s.out<int32_t>(N, true); od.group_start = s.out<int32_t>(TG, true); od.group_count = s.out<int32_t>(TG, true);
+  } else {
+    s.slot += 6;
   }
+  const size_t Stot = N + TG + (size_t)in->n_versions;
+  dout.unit_of_task = s.out<int32_t>(N, out->unit_of_task != nullptr);
+  dout.unit_breakdown = s.out<int64_t>(Stot * EVG_BREAKDOWN_FIELDS, out->unit_breakdown != nullptr);
   if (s.rc) return s.rc;
   if (N == 0) {  // nothing to order or persist; the kernels still want non-null required pointers
     DevBuf& b = c->stage[47];
@@ -984,6 +1103,8 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
   s.down(out->distro_info, dout.distro_info, D);
   s.down(out->group_info, dout.group_info, G);
   s.down(out->n_units, dout.n_units, D);
+  s.down(out->unit_of_task, dout.unit_of_task, N);
+  s.down(out->unit_breakdown, dout.unit_breakdown, Stot * EVG_BREAKDOWN_FIELDS);
   if (items) {
     s.down(items->cut, qi.cut, D); s.down(items->item_off, qi.item_off, D + 1); s.down(items->row, qi.row, N);
     s.down(items->expected_duration_ns, qi.expected_duration_ns, N); s.down(items->priority, qi.priority, N);
@@ -1042,6 +1163,7 @@ int evg_rebuild_dispatchers(evg_ctx* c, int32_t n_distros, const int32_t* item_o
         return set_err(c, EVG_E_CONTRACT, "group_key of item %d is outside its distro's range", i);
     }
   HIP_TRY(c, hipSetDevice(c->device));
+  StreamDrain drain{c};
   Stager s{c};
   evg_plan_input di{};
   di.n_distros = n_distros; di.n_task_groups = (int32_t)TG;
@@ -1077,6 +1199,7 @@ int evg_filter_runnable(evg_ctx* c, const evg_plan_input* in, const uint8_t* dis
   const size_t N = in->tasks.n_tasks, D = in->n_distros;
   if (D == 0) return EVG_OK;
   if (!runnable_count || (N > 0 && (!dispatchable || !deps_met || !keep || !runnable_row))) return set_err(c, EVG_E_INVALID, "null finder-filter argument");
+  StreamDrain drain{c};
   Stager s{c};
   evg_plan_input di = stage_plan_input(s, in);
   const uint8_t* d_disp = s.up(dispatchable, N);
@@ -1109,6 +1232,7 @@ int evg_allocator_report(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, c
     return set_err(c, EVG_E_INVALID, "null allocator-report argument");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t D = n_distros, G = D + (size_t)tg_off[D];
+  StreamDrain drain{c};
   Stager s{c};
   const int32_t* d_off = s.up(tg_off, D + 1);
   const evg_distro_info* d_di = s.up(distro_info, D);
@@ -1135,6 +1259,7 @@ int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_ou
   if (!in->params || !in->host_off || !in->tg_off || !in->distro_info || !in->group_info || !out->new_hosts ||
       !out->free_hosts || !out->status)
     return set_err(c, EVG_E_INVALID, "null allocator argument");
+  StreamDrain drain{c};
   Stager s{c};
   s.slot = 24;
   evg_alloc_input di = *in;

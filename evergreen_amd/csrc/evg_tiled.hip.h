@@ -500,13 +500,11 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     const uint32_t cw = m_cnt[u];
     const int64_t nu = cw & UF_COUNT_MASK;
     int64_t v = INT64_MIN;
-    if (nu > 0 && (cw & UF_DISTRO)) v = unit_value(p, nu, m_tiq[u], m_dur[u], (int64_t)m_maxpri[u], (int64_t)m_maxnd[u], cw, nullptr);
+    if (nu > 0 && (cw & UF_DISTRO))
+      v = unit_value(p, nu, m_tiq[u], m_dur[u], (int64_t)m_maxpri[u], (int64_t)m_maxnd[u], cw,
+                     a.out.unit_breakdown ? a.out.unit_breakdown + (sb + su) : nullptr, unit_slots(a.in));
     a.w_val[sb + su] = v;
     a.w_minrow[sb + su] = m_minrow[u];
-    if (a.out.breakdown) {
-      a.w_tiq[sb + su] = m_tiq[u]; a.w_dur[sb + su] = m_dur[u]; a.w_maxpri[sb + su] = m_maxpri[u]; a.w_cnt[sb + su] = cw;
-      a.w_maxnd[sb + su] = m_maxnd[u];
-    }
     const int k = su - c.tg_base;
     if (k >= 0 && k < c.ntg) {  // model.TaskGroupInfo of task group k; MaxHosts comes with the queue order (k_tiled_finish)
       evg_group_info gi;
@@ -587,12 +585,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_elect(const PlanArgs a) {
       const int sl = a.w_eslot[e];
       if (sl >= 0) consider(sl);
     }
-    if (a.out.breakdown) {
-      const evg_distro_params p = a.in.distros[d];
-      const uint32_t cw = a.w_cnt[sb + best];
-      unit_value(p, cw & UF_COUNT_MASK, a.w_tiq[sb + best], a.w_dur[sb + best], a.w_maxpri[sb + best], (int64_t)a.w_maxnd[sb + best], cw,
-                 a.out.breakdown + (size_t)r * EVG_BREAKDOWN_FIELDS);
-    }
+    if (a.out.unit_of_task) a.out.unit_of_task[r] = (int32_t)(sb + best);
     // TaskList.Less key (planner.go:386-405): group order asc | num dependents desc | priority desc | duration desc
     const uint64_t ik = shl64((uint64_t)(ub(t.task_group_order[r]) - tmin), bn + bp + bd) | shl64((uint64_t)(nmax - ub(t.num_dependents[r])), bp + bd) |
                         shl64((uint64_t)(pmax - ub((int32_t)t.priority[r])), bd) | (dmax - ub(t.expected_duration_ns[r]));

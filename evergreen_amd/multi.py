@@ -197,14 +197,21 @@ class ShardedPool:
         D, N, G = lay.D, lay.N, lay.D + lay.TG
         z = lambda n, dt: torch.zeros(max(int(n), 1), dtype=dt, device=dev)  # noqa: E731
         self.o_order, self.o_met, self.o_wait = z(N, torch.int32), z(N, torch.uint8), z(N, torch.int64)
-        self.o_bd = z(N * abi.BREAKDOWN_FIELDS, torch.int64) if self.breakdown else None
+        # SortingValueBreakdown rows travel per UNIT (evg_plan_output.unit_of_task / unit_breakdown): a distro range owns a
+        # contiguous range of unit slots, so a rank's rows are one slice like everything else; rows by task are a gather
+        self.ver_off = v["ver_off"].cpu().numpy().astype(np.int64)
+        self.slot_off = self.task_off + self.tg_off + self.ver_off
+        self.o_uot = z(N, torch.int32) if self.breakdown else None
+        self.o_ubd = z(int(self.slot_off[-1]) * abi.BREAKDOWN_FIELDS, torch.int64) if self.breakdown else None
         self.o_di = z(D * abi.DISTRO_INFO_DTYPE.itemsize, torch.uint8)
         self.o_gi = z(G * abi.GROUP_INFO_DTYPE.itemsize, torch.uint8)
         meta = _Meta(lay, self.task_off)
         self.inp = abi.make_plan_input(meta, v)
         self.out = abi.PlanOutput()
         self.out.order, self.out.deps_met, self.out.wait_ns = self.o_order.data_ptr(), self.o_met.data_ptr(), self.o_wait.data_ptr()
-        self.out.breakdown = self.o_bd.data_ptr() if self.breakdown else None
+        self.out.breakdown = None
+        self.out.unit_of_task = self.o_uot.data_ptr() if self.breakdown else None
+        self.out.unit_breakdown = self.o_ubd.data_ptr() if self.breakdown else None
         self.out.distro_info, self.out.group_info, self.out.n_units = self.o_di.data_ptr(), self.o_gi.data_ptr(), None
         self.has_hosts = lay.has_hosts
         if self.has_hosts:
@@ -255,8 +262,10 @@ class ShardedPool:
         di, gi = abi.DISTRO_INFO_DTYPE.itemsize, abi.GROUP_INFO_DTYPE.itemsize
         s = [self.o_order[r0:r1], self.o_met[r0:r1], self.o_wait[r0:r1], self.o_di[d0 * di:d1 * di],
              self.o_gi[d0 * gi:d1 * gi], self.o_gi[g0 * gi:g1 * gi]]
-        if self.o_bd is not None:
-            s.append(self.o_bd[r0 * abi.BREAKDOWN_FIELDS:r1 * abi.BREAKDOWN_FIELDS])
+        if self.o_uot is not None:
+            u0, u1 = int(self.slot_off[d0]), int(self.slot_off[d1])
+            ns = int(self.slot_off[-1])  # field-major: the range's slots are one slice per field
+            s += [self.o_uot[r0:r1]] + [self.o_ubd[f * ns + u0:f * ns + u1] for f in range(abi.BREAKDOWN_FIELDS)]
         if self.has_hosts:
             D = lay.D
             s += [self.o_alloc[k * D + d0:k * D + d1] for k in range(3)]
@@ -288,8 +297,10 @@ class ShardedPool:
     def plan_result(self) -> abi.PlanResult:
         self._sync()
         n = self.layout.N
-        return abi.PlanResult(order=self.o_order.cpu().numpy()[:n],
-                              breakdown=self.o_bd.cpu().numpy().reshape(-1, abi.BREAKDOWN_FIELDS)[:n] if self.o_bd is not None else None,
+        uot = self.o_uot.cpu().numpy()[:n] if self.o_uot is not None else None
+        ubd = self.o_ubd.cpu().numpy().reshape(abi.BREAKDOWN_FIELDS, -1) if self.o_ubd is not None else None
+        return abi.PlanResult(order=self.o_order.cpu().numpy()[:n], unit_of_task=uot, unit_breakdown=ubd,
+                              breakdown=np.ascontiguousarray(ubd[:, uot].T) if ubd is not None else None,
                               deps_met=self.o_met.cpu().numpy()[:n], wait_ns=self.o_wait.cpu().numpy()[:n],
                               distro_info=self.o_di.cpu().numpy().view(abi.DISTRO_INFO_DTYPE),
                               group_info=self.o_gi.cpu().numpy().view(abi.GROUP_INFO_DTYPE), n_units=None)

@@ -23,6 +23,7 @@ EXPORTS = [
     "evg_allocator_report_device", "evg_filter_runnable_device", "evg_dispatch_order_device",
     "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
     "evg_plan_distro_range_device", "evg_allocate_host_range_device", "evg_selftest_unit_value",
+    "evg_host_alloc", "evg_host_free",
 ]
 
 _lib = None
@@ -78,6 +79,10 @@ def load_library() -> C.CDLL:
     lib.evg_allocator_report.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
     lib.evg_cap_queue_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p]
+    if hasattr(lib, "evg_host_alloc"):
+        lib.evg_host_alloc.restype = C.c_void_p
+        lib.evg_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        lib.evg_host_free.argtypes = [C.c_void_p, C.c_void_p]
     if hasattr(lib, "evg_selftest_unit_value"):  # absent from older builds loaded through EVG_SCHED_LIB (A/B runs)
         lib.evg_selftest_unit_value.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
@@ -90,6 +95,7 @@ class Context:
 
     def __init__(self, device_ordinal: int = 0):
         self.lib = load_library()
+        self._pinned = []
         self.h = self.lib.evg_create(device_ordinal)
         if not self.h:
             msg = self.lib.evg_last_error(None)
@@ -97,6 +103,9 @@ class Context:
 
     def close(self) -> None:
         if self.h:
+            for p in self._pinned:  # numpy views over these must not be used after close()
+                self.lib.evg_host_free(self.h, p)
+            self._pinned = []
             self.lib.evg_destroy(self.h)
             self.h = None
 
@@ -111,6 +120,39 @@ class Context:
             msg = self.lib.evg_last_error(self.h)
             raise NativeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
 
+    # ---- page-locked host buffers (evg_host_alloc): numpy views for the host-pointer entry points ---------------------
+    def pinned_empty(self, shape, dtype) -> np.ndarray:
+        """A numpy array over evg_host_alloc memory (freed with the context). The host-pointer entry points DMA straight
+        from / into such arrays; pageable arrays are bounced through the driver's staging buffers."""
+        dt = np.dtype(dtype)
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        if nbytes == 0:
+            return np.empty(shape, dt)
+        p = self.lib.evg_host_alloc(self.h, nbytes)
+        if not p:
+            raise NativeError("evg_host_alloc(%d) failed: %s" % (nbytes, (self.lib.evg_last_error(self.h) or b"?").decode()))
+        self._pinned.append(p)
+        buf = (C.c_char * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dt).reshape(shape)
+
+    def pinned_copy(self, a):
+        """`a` (array, dict of arrays or None) copied into page-locked memory."""
+        if a is None:
+            return None
+        if isinstance(a, dict):
+            return {k: self.pinned_copy(v) for k, v in a.items()}
+        out = self.pinned_empty(a.shape, a.dtype)
+        out[...] = a
+        return out
+
+    def pinned_batch(self, batch: abi.PlanBatch) -> abi.PlanBatch:
+        """The batch with every column in page-locked memory: what a shim that builds its columns in evg_host_alloc
+        buffers hands to evg_plan_distros / evg_allocate_hosts."""
+        import dataclasses
+        return dataclasses.replace(batch, **{f.name: self.pinned_copy(getattr(batch, f.name)) for f in dataclasses.fields(batch)
+                                             if isinstance(getattr(batch, f.name), (np.ndarray, dict))})
+
     def selftest_unit_value(self, n_cases: int, seed: int = 0x5EED):
         """evg_selftest_unit_value: (mismatching cases, index of the first one or None)."""
         bad, first = C.c_uint64(0), C.c_uint64(0)
@@ -118,15 +160,23 @@ class Context:
         return int(bad.value), (int(first.value) if bad.value else None)
 
     # ---- scheduler.Backend -------------------------------------------------------------------
-    def plan(self, batch: abi.PlanBatch, breakdown: bool = True, n_units: bool = True) -> abi.PlanResult:
-        res = abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=n_units)
+    def pinned_result(self, res):
+        """A PlanResult / AllocResult whose arrays live in page-locked memory (re-use it across calls with `into=`)."""
+        import dataclasses
+        return dataclasses.replace(res, **{f.name: self.pinned_copy(getattr(res, f.name)) for f in dataclasses.fields(res)
+                                           if isinstance(getattr(res, f.name), np.ndarray)})
+
+    def plan(self, batch: abi.PlanBatch, breakdown: bool = True, n_units: bool = True, units: bool = False,
+             into: Optional[abi.PlanResult] = None) -> abi.PlanResult:
+        res = into if into is not None else abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=n_units, units=units)
         inp = abi.make_plan_input(batch)
         out = res.c_output()
         self._check(self.lib.evg_plan_distros(self.h, C.byref(inp), C.byref(out)), "evg_plan_distros")
         return res
 
-    def allocate(self, batch: abi.PlanBatch, distro_info: np.ndarray, group_info: np.ndarray) -> abi.AllocResult:
-        res = abi.AllocResult.alloc_host(batch.n_distros)
+    def allocate(self, batch: abi.PlanBatch, distro_info: np.ndarray, group_info: np.ndarray,
+                 into: Optional[abi.AllocResult] = None) -> abi.AllocResult:
+        res = into if into is not None else abi.AllocResult.alloc_host(batch.n_distros)
         inp = abi.make_alloc_input(batch, distro_info, group_info)
         out = res.c_output()
         self._check(self.lib.evg_allocate_hosts(self.h, C.byref(inp), C.byref(out)), "evg_allocate_hosts")

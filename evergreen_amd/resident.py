@@ -11,7 +11,10 @@ from . import abi, native
 
 
 class ResidentPool:
-    def __init__(self, ctx: native.Context, batch: abi.PlanBatch, device, breakdown: bool = False, n_units: bool = False):
+    def __init__(self, ctx: native.Context, batch: abi.PlanBatch, device, breakdown: bool = False, n_units: bool = False,
+                 units: bool = False):
+        """breakdown: SortingValueBreakdown rows by task (expanded on the device); units: the rows by unit + the emitting
+        unit of every task (what a shim should ask for: every distinct row once)."""
         import torch
         self.torch = torch
         self.ctx, self.batch, self.device = ctx, batch, device
@@ -25,12 +28,18 @@ class ResidentPool:
         self.o_di = z(D * abi.DISTRO_INFO_DTYPE.itemsize, dt=torch.uint8)
         self.o_gi = z(G * abi.GROUP_INFO_DTYPE.itemsize, dt=torch.uint8)
         self.o_nu = z(D, dt=torch.int32) if n_units else None
+        nslots = n + batch.n_task_groups + int(batch.ver_off[-1])
+        self.o_uot = z(max(n, 1), dt=torch.int32) if units else None
+        self.n_slots = nslots
+        self.o_ubd = z(max(nslots * abi.BREAKDOWN_FIELDS, 1), dt=torch.int64) if units else None
         self.inp = abi.make_plan_input(batch, self.t)
         self.out = abi.PlanOutput()
         self.out.order, self.out.deps_met, self.out.wait_ns = self.o_order.data_ptr(), self.o_met.data_ptr(), self.o_wait.data_ptr()
         self.out.breakdown = self.o_bd.data_ptr() if breakdown else None
         self.out.distro_info, self.out.group_info = self.o_di.data_ptr(), self.o_gi.data_ptr()
         self.out.n_units = self.o_nu.data_ptr() if n_units else None
+        self.out.unit_of_task = self.o_uot.data_ptr() if units else None
+        self.out.unit_breakdown = self.o_ubd.data_ptr() if units else None
         self.has_hosts = batch.alloc_params is not None
         if self.has_hosts:
             self.o_new, self.o_free, self.o_status = z(D, dt=torch.int32), z(D, dt=torch.int32), z(D, dt=torch.int32)
@@ -113,7 +122,10 @@ class ResidentPool:
             breakdown=self.o_bd.cpu().numpy().reshape(-1, abi.BREAKDOWN_FIELDS)[:n] if self.o_bd is not None else None,
             deps_met=self.o_met.cpu().numpy()[:n], wait_ns=self.o_wait.cpu().numpy()[:n],
             distro_info=self.o_di.cpu().numpy().view(abi.DISTRO_INFO_DTYPE), group_info=self.o_gi.cpu().numpy().view(abi.GROUP_INFO_DTYPE),
-            n_units=self.o_nu.cpu().numpy() if self.o_nu is not None else None)
+            n_units=self.o_nu.cpu().numpy() if self.o_nu is not None else None,
+            unit_of_task=self.o_uot.cpu().numpy()[:n] if self.o_uot is not None else None,
+            unit_breakdown=(self.o_ubd.cpu().numpy()[:self.n_slots * abi.BREAKDOWN_FIELDS].reshape(abi.BREAKDOWN_FIELDS, self.n_slots)
+                            if self.o_ubd is not None else None))
 
     def alloc_result(self) -> abi.AllocResult:
         self.torch.cuda.synchronize(self.device)

@@ -371,13 +371,17 @@ inline std::vector<PlannedQueue> PlanDistros(const Backend& be, const std::vecto
                                              const std::vector<bool>* includes_dependencies = nullptr) {
   const PackedQueues p = pack_queues(queues, now, lookup, includes_dependencies);
   const size_t n = p.priority.size(), D = queues.size(), G = D + (size_t)p.tg_off.back();
-  std::vector<int32_t> order(n + 1), n_units(D + 1);
-  std::vector<int64_t> breakdown((n + 1) * EVG_BREAKDOWN_FIELDS), wait(n + 1);
+  // SortingValueBreakdown: one row per UNIT + the emitting unit of every task (evg_plan_output.unit_of_task); the stamp on
+  // each task (planner.go:475) is a copy of its unit's row
+  const size_t n_slots = n + (size_t)p.tg_off.back() + (size_t)p.ver_off.back();
+  std::vector<int32_t> order(n + 1), n_units(D + 1), unit_of_task(n + 1);
+  std::vector<int64_t> unit_breakdown((n_slots + 1) * EVG_BREAKDOWN_FIELDS), wait(n + 1);
   std::vector<uint8_t> met(n + 1);
   std::vector<evg_distro_info> di(D + 1);
   std::vector<evg_group_info> gi(G + 1);
   const evg_plan_input in = p.input();
-  evg_plan_output out{order.data(), breakdown.data(), met.data(), wait.data(), di.data(), gi.data(), n_units.data()};
+  evg_plan_output out{order.data(), nullptr, met.data(), wait.data(), di.data(), gi.data(), n_units.data(), unit_of_task.data(),
+                      unit_breakdown.data()};
   const int rc = be.plan(&in, &out);
   if (rc != EVG_OK) throw PlanError("evg_plan_distros failed (" + std::to_string(rc) + "): " + (be.last_error ? be.last_error() : ""));
   std::vector<PlannedQueue> res(D);
@@ -389,7 +393,8 @@ inline std::vector<PlannedQueue> PlanDistros(const Backend& be, const std::vecto
     for (int q = lo; q < hi; q++) {
       const int r = order[q];
       Task t = src[r - lo];  // the same task value, re-ordered (planner_test.go:493,507,525)
-      const int64_t* b = &breakdown[(size_t)r * EVG_BREAKDOWN_FIELDS];
+      int64_t b[EVG_BREAKDOWN_FIELDS];  // the unit's row of the field-major table
+      for (int k = 0; k < EVG_BREAKDOWN_FIELDS; k++) b[k] = unit_breakdown[(size_t)k * n_slots + (size_t)unit_of_task[r]];
       auto& sb = t.SortingValueBreakdown;  // stamped at planner.go:475
       sb.TaskGroupLength = b[EVG_BD_TASK_GROUP_LENGTH]; sb.TotalValue = b[EVG_BD_TOTAL_VALUE];
       sb.PriorityBreakdown.InitialPriorityImpact = b[EVG_BD_PRI_INITIAL]; sb.PriorityBreakdown.TaskGroupImpact = b[EVG_BD_PRI_TASK_GROUP];

@@ -35,6 +35,7 @@
 #ifndef EVG_SCHED_H
 #define EVG_SCHED_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -219,6 +220,18 @@ typedef struct evg_plan_output {
   evg_group_info* group_info;   /* D + n_task_groups */
   int32_t* n_units;        /* D: TaskPlan.Len() after UnitCache.Export dedup (planner.go:73-89),
                               or NULL to skip                                                    */
+  /* The breakdown per UNIT (ABI 1.2). TaskPlan.Export stamps the emitting unit's value on every task of the unit
+   * (planner.go:475; task.go:4118-4153), so N x 13 rows by task repeat each unit's row once per member; these two
+   * outputs hold every distinct row once, and the planner kernels never write rows by task (when `breakdown` is
+   * requested the library expands these, on the device). Both or neither; NULL to skip.
+   * Unit slots: distro d owns slots [U(d), U(d+1)), U(d) = task_off[d] + tg_off[d] + ver_off[d] -- at most one slot per
+   * task, task group and version of the distro, N + n_task_groups + n_versions in all. Rows of slots that emit no
+   * task are unspecified. */
+  int32_t* unit_of_task;   /* N by ROW: the slot of the unit the task is emitted from              */
+  int64_t* unit_breakdown; /* 13 x n_slots, FIELD-MAJOR: field f (enum evg_breakdown_field) of slot u is
+                              unit_breakdown[f * n_slots + u], n_slots = N + n_task_groups + n_versions (the kernels'
+                              stores of one field are consecutive words; row-major 104-byte records cost 64 cache-line
+                              requests per store instruction)                                       */
 } evg_plan_output;
 
 /* ---- allocator inputs ----------------------------------------------------------------------- */
@@ -285,6 +298,14 @@ typedef struct evg_ctx evg_ctx;
  * flight: see the stream-ordering rule at the *_device prototypes. */
 evg_ctx* evg_create(int device_ordinal);
 void evg_destroy(evg_ctx* ctx);
+
+/* Page-locked host memory for the buffers of the host-pointer entry points (ABI 1.2). Those entry points accept any host
+ * memory; from pageable memory every column is bounced through the driver's staging buffers (about 24 GB/s on an MI355X
+ * box), from memory allocated here the copies are plain DMA at the link's rate (about 55 GB/s), and the 1M-task tick goes
+ * from 4.1 ms to under 2 ms. A shim allocates its column and output buffers here once and re-uses them every tick (cgo:
+ * unsafe.Slice over the returned pointer). NULL on failure (message via evg_last_error). */
+void* evg_host_alloc(evg_ctx* ctx, size_t bytes);
+void evg_host_free(evg_ctx* ctx, void* p);
 
 /* Last error message of `ctx` (or of the failed evg_create when ctx == NULL). */
 const char* evg_last_error(const evg_ctx* ctx);

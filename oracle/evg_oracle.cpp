@@ -922,6 +922,17 @@ void plan_one(const evg_plan_input* in, const evg_plan_output* out, int d) {
     const Task& t = plan[p];
     if (out->order) out->order[lo + (int32_t)p] = t.Id;
     if (out->breakdown) store_breakdown(out->breakdown + (size_t)t.Id * EVG_BREAKDOWN_FIELDS, t.Breakdown);
+    if (out->unit_of_task && out->unit_breakdown) {
+      // evg_plan_output's rows by unit: any slot assignment inside the distro's slot range with
+      // unit_breakdown[unit_of_task[row]] == the row's stamped breakdown (planner.go:475) meets the contract; the oracle
+      // gives every task the slot of its own row (the kernels share one slot between the tasks of a unit).
+      const size_t slot = (size_t)lo + tg_lo + ver_lo + (size_t)(t.Id - lo);
+      out->unit_of_task[t.Id] = (int32_t)slot;
+      int64_t row[EVG_BREAKDOWN_FIELDS];
+      store_breakdown(row, t.Breakdown);
+      const size_t n_slots = (size_t)s.n_tasks + (size_t)in->n_task_groups + (size_t)in->n_versions;
+      for (int k = 0; k < EVG_BREAKDOWN_FIELDS; k++) out->unit_breakdown[(size_t)k * n_slots + slot] = row[k];  // field-major
+    }
     if (out->deps_met) out->deps_met[t.Id] = met[p];
     if (out->wait_ns) out->wait_ns[t.Id] = t.WaitSinceDependenciesMet;
   }

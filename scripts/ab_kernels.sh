@@ -10,6 +10,6 @@ for v in A B A B; do
   python - "$f" $v <<'PY'
 import csv, sys
 rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[1]))}
-print(sys.argv[2], " ".join("%s %.2f" % (k.split("(")[0].replace("void evg::", "").replace("evg::", ""), v) for k, v in rows.items() if "evg::" in k and "true" not in k))
+print(sys.argv[2], " ".join("%s %.2f" % (k.split("(")[0].replace("void evg::", "").replace("evg::", ""), v) for k, v in rows.items() if "evg::" in k and "true" not in k.split("(")[0]))
 PY
 done

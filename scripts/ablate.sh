@@ -23,6 +23,6 @@ for k in $KS full; do
   python - "$f" $k <<'PY'
 import csv, sys
 rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[1]))}
-print("stop after %-4s" % sys.argv[2], " ".join("%s %.2f" % (k.split("(")[0].replace("void evg::", "").replace("evg::", ""), v) for k, v in rows.items() if "k_plan_distros<false>" in k))
+print("stop after %-4s" % sys.argv[2], " ".join("%s %.2f" % (k.split("(")[0].replace("void evg::", "").replace("evg::", ""), v) for k, v in rows.items() if "k_plan_distros<false, false>" in k))
 PY
 done

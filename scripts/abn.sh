@@ -11,7 +11,7 @@ for l in "$@"; do
   python - "$f" $l <<'PY'
 import csv, sys
 rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[1]))}
-print("%-24s" % sys.argv[2], " ".join("%s %.2f" % (k.split("(")[0].replace("void evg::", "").replace("evg::", ""), v) for k, v in rows.items() if "evg::" in k and "true" not in k))
+print("%-24s" % sys.argv[2], " ".join("%s %.2f" % (k.split("(")[0].replace("void evg::", "").replace("evg::", ""), v) for k, v in rows.items() if "evg::" in k))
 PY
 done
 done

@@ -3,7 +3,7 @@
 # usage: scripts/asm_kernel.sh <tag> [mangled-name-substring]
 R=$(cd "$(dirname "$0")/.." && pwd)
 TAG=${1:-k}
-SYM=${2:-_ZN3evg14k_plan_distrosILb0EEEvNS_8PlanArgsE}
+SYM=${2:-_ZN3evg14k_plan_distrosILb0ELb0EEEvNS_8PlanArgsE}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None \
   --cuda-device-only -S $R/evergreen_amd/csrc/evg_sched.hip -o /tmp/$TAG-all.s 2>/dev/null
 awk -v s="^$SYM:" '$0 ~ s {f=1} f{print} /s_endpgm/{if(f)exit}' /tmp/$TAG-all.s > /tmp/$TAG.s

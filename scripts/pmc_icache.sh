@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("$OUT/ic*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_plan_distros<false>" not in k: continue
+        if "k_plan_distros<false, false>" not in k: continue
         a = acc[k][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, cs in acc.items():

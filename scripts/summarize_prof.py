@@ -48,7 +48,7 @@ def main():
                 k[:50], v["hbm_bytes_per_launch_raw"] / 1e6, v["hbm_bytes_per_launch_corrected"] / 1e6))
     # what bench.py reports as roofline.traffic: HBM bytes per launch of the planner kernel (lean instantiation)
     for k, v in out.get("pmc", {}).items():
-        if "k_plan_distros<false>" in k and "hbm_bytes_per_launch_corrected" in v:
+        if "k_plan_distros<false, false>" in k and "hbm_bytes_per_launch_corrected" in v:
             out["k_plan_distros_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch_corrected"]
             out["k_plan_distros_hbm_bytes_per_launch_raw"] = v["hbm_bytes_per_launch_raw"]
     json.dump(out, open(os.path.join(d, tag + "-pmc.json"), "w"), indent=1)

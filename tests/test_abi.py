@@ -84,6 +84,29 @@ def test_validate_plan_input_on_host(lib):
     b.task_off[-1] -= 1
     inp = abi.make_plan_input(b)
     assert lib.evg_validate_plan_input(C.byref(inp), msg, 256) == abi.EVG_E_CONTRACT
+    # a dependency edge names a row of the SAME distro or -1: a row of another distro is a contract violation (its status
+    # bits would be read from a byte the caller never filled)
+    b = gen.generate(gen.config(1))
+    e = int(np.nonzero(b.edges["dep_idx"] >= 0)[0][0])
+    row = int(np.searchsorted(b.dep_off, e, side="right") - 1)
+    d = int(np.searchsorted(b.task_off, row, side="right") - 1)
+    b.edges["dep_idx"][e] = b.task_off[(d + 1) % b.n_distros]  # first row of another distro
+    inp = abi.make_plan_input(b)
+    assert lib.evg_validate_plan_input(C.byref(inp), msg, 256) == abi.EVG_E_CONTRACT
+    assert b"dep_idx" in msg.value
+    b = gen.generate(gen.config(1))
+    b.dep_off[0] = 1
+    inp = abi.make_plan_input(b)
+    assert lib.evg_validate_plan_input(C.byref(inp), msg, 256) == abi.EVG_E_CONTRACT
+    # large batches are checked by several threads: the first failing distro's message is the one reported
+    b = gen.generate(gen.config(2))
+    inp = abi.make_plan_input(b)
+    assert lib.evg_validate_plan_input(C.byref(inp), msg, 256) == abi.EVG_OK
+    b.cols["tg_key"][int(b.task_off[40]) + 3] = -7
+    b.cols["tg_key"][int(b.task_off[9]) + 1] = -5
+    inp = abi.make_plan_input(b)
+    assert lib.evg_validate_plan_input(C.byref(inp), msg, 256) == abi.EVG_E_CONTRACT
+    assert b"tg_key -5" in msg.value, msg.value
 
 
 def test_abi_version(lib):

@@ -63,10 +63,27 @@ def test_cap_task_queue_length(native_ctx):
 
 
 # ---- synthetic pools: full bit-exact comparison ---------------------------------------------------------------
+def _check_unit_rows(batch, got, what):
+    """The breakdown per UNIT (evg_plan_output.unit_of_task / unit_breakdown): every task's slot lies in its distro's slot
+    range, tasks that share a slot are tasks of one unit (same stamped value), and the gather of the unit rows is the rows
+    by task -- which _full_compare checks against the oracle field by field."""
+    n = batch.n_tasks
+    if n == 0:
+        return
+    slot_off = batch.task_off.astype(np.int64) + batch.tg_off + batch.ver_off
+    d_of = np.repeat(np.arange(batch.n_distros), np.diff(batch.task_off))
+    assert np.all(got.unit_of_task >= slot_off[d_of]) and np.all(got.unit_of_task < slot_off[d_of + 1]), what + ": unit slot outside the distro's range"
+    assert np.array_equal(got.expand_breakdown(), got.breakdown), what + ": unit rows do not expand to the rows by task"
+
+
 def _full_compare(native_ctx, oracle, batch, what, validity=True):
-    got = native_ctx.plan(batch)
+    got = native_ctx.plan(batch, units=True)
     want = oracle.plan(batch)
     compare.assert_plan_equal(got, want, batch, what)
+    _check_unit_rows(batch, got, what)
+    # the same through the kernel a shim would run: unit rows only, no TaskPlan.Len(), no rows by task (two workgroups per CU)
+    lean = native_ctx.plan(batch, breakdown=False, n_units=False, units=True)
+    assert np.array_equal(lean.order, got.order) and np.array_equal(lean.expand_breakdown(), got.breakdown), what + ": unit-rows-only plan differs"
     compare.queue_properties(batch, got)
     if validity:  # could the Go code have emitted this queue? -- checked without the oracle (tests/ref_validity.py)
         compare.reference_validity(batch, got)
@@ -309,3 +326,50 @@ def test_many_dependencies_per_task(native_ctx, oracle):
     b = S.pack_queues(queues, NOW).batch
     assert int(np.diff(b.dep_off).max()) >= 8
     _full_compare(native_ctx, oracle, b, "many dependencies per task")
+
+
+def test_size_hint_never_changes_the_plan(native_ctx, oracle):
+    """evg_plan_input.max_distro_tasks shapes the launch of the large-distro path only: understated (a distro larger than
+    promised), overstated or absent, the queue is the same (the pipeline leaves what it was not launched for to the
+    one-workgroup kernel)."""
+    b = gen.generate(gen.config(3, n_tasks=60_000, n_distros=6, skew=True))
+    sizes = np.diff(b.task_off)
+    assert sizes.max() > 8192
+    want = oracle.plan(b, breakdown=False, n_units=False)
+    for hint in (0, 2049, 3000, int(sizes.max()) - 1, int(sizes.max()), 1 << 20):
+        res = abi.PlanResult.alloc_host(b, breakdown=False, n_units=False)
+        inp, out = abi.make_plan_input(b), res.c_output()
+        inp.max_distro_tasks = hint
+        rc = native_ctx.lib.evg_plan_distros(native_ctx.h, C.byref(inp), C.byref(out))
+        assert rc == abi.EVG_OK, (hint, rc)
+        compare.assert_plan_equal(res, want, b, "hint %d" % hint)
+
+
+def test_host_pointer_calls_from_page_locked_buffers(native_ctx, oracle):
+    """evg_host_alloc memory in, evg_host_alloc memory out: the same plan as from pageable numpy arrays."""
+    b = gen.generate(gen.config(2))
+    want = native_ctx.plan(b)
+    want_alloc = native_ctx.allocate(b, want.distro_info, want.group_info.copy())  # the allocator writes CountFree / CountRequired in place
+    pb = native_ctx.pinned_batch(b)
+    r = native_ctx.pinned_result(abi.PlanResult.alloc_host(b))
+    r.order[:] = -1
+    for _ in range(2):  # the buffers are re-used tick after tick
+        native_ctx.plan(pb, into=r)
+        compare.assert_plan_equal(r, want, b, "pinned")
+        a = native_ctx.allocate(pb, r.distro_info, r.group_info, into=native_ctx.pinned_result(abi.AllocResult.alloc_host(b.n_distros)))
+        compare.assert_alloc_equal(a, want_alloc, "pinned")
+
+
+def test_error_exit_leaves_no_copy_in_flight(native_ctx):
+    """A host-pointer call that fails after it enqueued copies (here: the allocator with a null output) drains its stream
+    before returning: the caller may free or re-use its buffers at once."""
+    b = gen.generate(gen.config(2))
+    res = abi.PlanResult.alloc_host(b, breakdown=False, n_units=False)
+    inp, out = abi.make_plan_input(b), res.c_output()
+    out.unit_of_task = res.order.ctypes.data  # unit_of_task without unit_breakdown: rejected after the inputs were staged
+    rc = native_ctx.lib.evg_plan_distros(native_ctx.h, C.byref(inp), C.byref(out))
+    assert rc == abi.EVG_E_INVALID
+    for k in b.cols:
+        b.cols[k][:] = 0  # scribble over the inputs right away; a copy still in flight would be undefined behaviour
+    want = native_ctx.plan(gen.generate(gen.config(1)))
+    assert want.order.size > 0
