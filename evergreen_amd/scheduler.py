@@ -96,6 +96,10 @@ class Task:                                        # the model/task/task.go:96-3
     DurationPrediction: CachedDurationValue = field(default_factory=CachedDurationValue)
     Status: str = ""
     CachedProjectStorageMethod: str = ""
+    # carried through to the TaskQueueItem untouched (task_queue_persister.go:30-36): they follow the item's row
+    DisplayName: str = ""
+    RevisionOrderNumber: int = 0
+    Revision: str = ""
     # written by the planner
     SortingValueBreakdown: Optional[Dict[str, int]] = None
     WaitSinceDependenciesMet: int = 0

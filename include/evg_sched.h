@@ -379,9 +379,11 @@ int evg_cap_queue_device(evg_ctx* ctx, int32_t n_distros, const int32_t* task_of
 /* ---- PersistTaskQueue's queue materialisation -------------------------------------------------
  * scheduler/task_queue_persister.go:17-62 + model/task_queue.go:181-205,269-275: cap the plan with capTaskQueueLength
  * (task-group-aware cut), truncate to the 10,000-item limit of TaskQueue.Save, and build one model.TaskQueueItem per
- * persisted queue position. Strings never cross the ABI, so an item carries the ROW of its task (the shim fills
- * Id / DisplayName / BuildVariant / Revision / Project / Requester / Version / ActivatedBy / Group and the
- * Dependencies id list from its own task slice) plus every numeric field of the item. Struct-of-arrays output,
+ * persisted queue position. Strings never cross the ABI, so an item carries the ROW of its task: the shim copies the
+ * pass-through fields -- Id / DisplayName / BuildVariant / RevisionOrderNumber / Revision / Project / Requester / Version /
+ * ActivatedBy / Group and the Dependencies id list (task_queue_persister.go:30-45) -- from its own task slice by that row
+ * (pinned by TestDBTaskQueuePersister, task_queue_persister_test.go:20-213, tests/golden_runner.py:check_persister);
+ * the arrays below are the numeric fields the path computes or re-orders. Struct-of-arrays output,
  * items of distro d at [item_off[d], item_off[d+1]) in queue order; each array must hold n_tasks entries. */
 #define EVG_TASK_QUEUE_SAVE_LIMIT 10000 /* model/task_queue.go:270-272 */
 typedef struct evg_queue_items {

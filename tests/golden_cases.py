@@ -354,3 +354,19 @@ def cap_cases():
             ("ZeroLimitDisablesCap", build(10), 0, 10),
             ("GroupStraddlingCapKeptWhole", build(8, {"g": (4, 7)}), 5, 7),
             ("HugeGroupPastCapKeptWhole", build(13, {"g": (4, 13)}), 5, 13)]
+
+
+# ---- scheduler/task_queue_persister_test.go:20-213 TestDBTaskQueuePersister -----------------------------
+# Two distros, five tasks; every TaskQueueItem field must equal its task's (:137-205), ExpectedDuration is the
+# FetchExpectedDuration average GetDistroQueueInfo stored on the task (1..4 min; the 10-minute default for t5, whose
+# DurationPrediction is empty, :204-205), and the infos are Length 3 / 3 with dependencies met, 2 / 1 (:126-129: t5 depends on
+# "someTask", which is in no queue and not in the DB).
+def persister_case():
+    ts = []
+    for i in range(5):
+        ts.append(Task(Id="t%d" % (i + 1), DisplayName="dn%d" % (i + 1), BuildVariant="bv%d" % (i + 1), RevisionOrderNumber=i,
+                       Requester="r%d" % (i + 1), Revision="g%d" % (i + 1), Project="p%d" % (i + 1), ActivatedBy="u%d" % (i + 1),
+                       DurationPrediction=S.CachedDurationValue(Value=(i + 1) * MIN if i < 4 else 0)))
+    ts[4].DependsOn = [Dependency("someTask", S.TaskSucceeded)]
+    want_duration = {"t1": 1 * MIN, "t2": 2 * MIN, "t3": 3 * MIN, "t4": 4 * MIN, "t5": 10 * MIN}
+    return [("d1", ts[0:3], dict(Length=3, LengthWithDependenciesMet=3)), ("d2", ts[3:], dict(Length=2, LengthWithDependenciesMet=1))], want_duration

@@ -194,3 +194,37 @@ def check_cap(cap_fn):
         cut = cap_fn(packed.batch, order, limit)
         assert int(cut[0]) == want, name
         assert len(H.capTaskQueueLength(tasks, limit)) == want, name
+
+
+def check_persister(backend, materialize):
+    """TestDBTaskQueuePersister (task_queue_persister_test.go:20-213). `materialize(batch, plan_result, limit)` is the batched
+    PersistTaskQueue item list (evg_materialize_queue[_device] / the oracle's): every item is compared with the task of its
+    row, field by field, as the reference test does; strings and RevisionOrderNumber are carried by the row."""
+    cases, want_duration = G.persister_case()
+    queues = [(S.Distro(Id=name), tasks) for name, tasks, _ in cases]
+    planned = S.PlanDistros(backend, queues, G.NOW)
+    packed = S.pack_queues(queues, G.NOW)
+    res = backend.plan(packed.batch)
+    items = materialize(packed.batch, res, 0)
+    b = packed.batch
+    for d, ((name, tasks, want_info), (plan, info)) in enumerate(zip(cases, planned)):
+        for k, v in want_info.items():
+            assert getattr(info, k) == v, "%s: %s=%r want %r (task_queue_persister_test.go:126-129)" % (name, k, getattr(info, k), v)
+        queue = H.BuildTaskQueue(plan, 0)
+        assert [q.Id for q in queue] == [t.Id for t in plan] and len(queue) == len(tasks)
+        by_id = {t.Id: t for t in tasks}
+        lo, hi = int(items.item_off[d]), int(items.item_off[d + 1])
+        assert hi - lo == len(tasks), name
+        for pos, q in enumerate(queue):
+            t = by_id[q.Id]
+            for f in ("DisplayName", "BuildVariant", "RevisionOrderNumber", "Requester", "Revision", "Project", "ActivatedBy"):
+                assert getattr(q, f) == getattr(t, f), (name, q.Id, f)                          # :137-205
+            assert q.ExpectedDuration == want_duration[q.Id], (name, q.Id, q.ExpectedDuration)
+            # the batched item list: same queue position, same task (its row carries the strings / RevisionOrderNumber)
+            o = lo + pos
+            row_task = packed.tasks[d][int(items.cols["row"][o]) - int(b.task_off[d])]
+            assert row_task.Id == q.Id, (name, pos, row_task.Id, q.Id)
+            assert row_task.RevisionOrderNumber == t.RevisionOrderNumber
+            assert int(items.cols["expected_duration_ns"][o]) == want_duration[q.Id]
+            assert int(items.cols["n_dependencies"][o]) == len(t.DependsOn)
+            assert bool(items.cols["dependencies_met"][o]) == q.DependenciesMet == (q.Id != "t5")

@@ -45,6 +45,9 @@ class TaskQueueItem:                               # model/task_queue.go:181-205
     Dependencies: List[str] = field(default_factory=list)
     DependenciesMet: bool = False
     ActivatedBy: str = ""
+    DisplayName: str = ""
+    RevisionOrderNumber: int = 0
+    Revision: str = ""
 
 
 def BuildTaskQueue(tasks: Sequence[Task], maxScheduledTasks: int) -> List[TaskQueueItem]:
@@ -56,7 +59,8 @@ def BuildTaskQueue(tasks: Sequence[Task], maxScheduledTasks: int) -> List[TaskQu
         out.append(TaskQueueItem(Id=t.Id, Group=t.TaskGroup, GroupMaxHosts=t.TaskGroupMaxHosts, GroupIndex=t.TaskGroupOrder, Version=t.Version,
                                  BuildVariant=t.BuildVariant, Requester=t.Requester, Project=t.Project, ExpectedDuration=t.ExpectedDuration,
                                  Priority=t.Priority, SortingValueBreakdown=t.SortingValueBreakdown, Dependencies=[d.TaskId for d in t.DependsOn],
-                                 DependenciesMet=t.HasDependenciesMet(), ActivatedBy=t.ActivatedBy))
+                                 DependenciesMet=t.HasDependenciesMet(), ActivatedBy=t.ActivatedBy, DisplayName=t.DisplayName,
+                                 RevisionOrderNumber=t.RevisionOrderNumber, Revision=t.Revision))
     return out[:abi.TASK_QUEUE_SAVE_LIMIT]
 
 

@@ -42,6 +42,57 @@ def _random_rows(seed, D=600):
     return tg_off, di, gi, spawned, free, params
 
 
+def _vector_rows():
+    """tests/golden/allocator_report_vectors.py as the ABI's rows (one distro per vector)."""
+    from tests.golden import allocator_report_vectors as V
+    D = len(V.VECTORS)
+    named = [[g for g in v[3] if g[0] != ""] for v in V.VECTORS]
+    tg_off = np.zeros(D + 1, np.int32)
+    tg_off[1:] = np.cumsum([len(g) for g in named])
+    di, gi = np.zeros(D, abi.DISTRO_INFO_DTYPE), np.zeros(D + int(tg_off[-1]), abi.GROUP_INFO_DTYPE)
+    spawned, free, params = np.zeros(D, np.int32), np.zeros(D, np.int32), np.zeros(D, abi.REPORT_PARAMS_DTYPE)
+    for d, (name, lines, info, groups, sp, fr, up, minimum, allowed, want) in enumerate(V.VECTORS):
+        di["expected_duration_ns"][d], di["duration_over_threshold_ns"][d], di["count_duration_over_threshold"][d], di["max_duration_threshold_ns"][d] = info
+        for g in groups:  # the standalone row (Name == "") lives in row d and must be ignored by the report
+            k = d if g[0] == "" else D + int(tg_off[d]) + named[d].index(g)
+            gi["present"][k] = 1
+            gi["expected_duration_ns"][k], gi["duration_over_threshold_ns"][k], gi["count_duration_over_threshold"][k] = g[1], g[2], g[3]
+            gi["count_free"][k], gi["count_required"][k] = g[4], g[5]
+        spawned[d], free[d] = sp, fr
+        params["n_up_hosts"][d], params["minimum_hosts"][d], params["drawdown_allowed"][d] = up, minimum, allowed
+    return V.VECTORS, tg_off, di, gi, spawned, free, params
+
+
+def _check_vector_rows(vectors, rep):
+    for d, (name, lines, info, groups, sp, fr, up, minimum, allowed, want) in enumerate(vectors):
+        r, T = rep[d], info[3]
+        got = (int(r["time_to_empty_ns"]), int(r["time_to_empty_no_spawns_ns"]), int(r["hosts_avail"]), bool(r["drawdown"]),
+               int(r["new_cap_target"]), int(r["killable_hosts"]))
+        assert got == want, "%s (units/host_allocator.go:%s): got %r want %r" % (name, lines, got, want)
+        assert np.float32(r["host_queue_ratio"]) == np.float32(want[0]) / np.float32(T), name          # :319
+        assert np.float32(r["no_spawns_ratio"]) == np.float32(want[1]) / np.float32(T), name           # :321
+
+
+def test_hand_derived_vectors_oracle_and_restatement(oracle):
+    """One vector per branch of units/host_allocator.go:250-334,393-424, derived by hand from the Go source (the reference
+    holds no expected values for this code: parity unpinned by the reference, see the fixture's header)."""
+    vectors, tg_off, di, gi, spawned, free, params = _vector_rows()
+    _check_vector_rows(vectors, oracle.allocator_report(len(vectors), tg_off, di, gi, spawned, free, params))
+    for name, lines, info, groups, sp, fr, up, minimum, allowed, want in vectors:
+        q = S.DistroQueueInfo(ExpectedDuration=info[0], DurationOverThreshold=info[1], CountDurationOverThreshold=info[2], MaxDurationThreshold=info[3])
+        q.TaskGroupInfos = [S.TaskGroupInfo(Name=g[0], ExpectedDuration=g[1], DurationOverThreshold=g[2], CountDurationOverThreshold=g[3],
+                                            CountFree=g[4], CountRequired=g[5]) for g in groups]
+        r = H.HostAllocatorReport(q, sp, fr, up, minimum, allowed)
+        assert (r.timeToEmpty, r.timeToEmptyNoSpawns, r.hostsAvail, r.drawdown, r.NewCapTarget, r.killableHosts) == want, name
+        assert np.float32(r.hostQueueRatio) == np.float32(want[0]) / np.float32(info[3]), name
+
+
+@pytest.mark.gpu
+def test_hand_derived_vectors_hip(native_ctx):
+    vectors, tg_off, di, gi, spawned, free, params = _vector_rows()
+    _check_vector_rows(vectors, native_ctx.allocator_report(len(vectors), tg_off, di, gi, spawned, free, params))
+
+
 def test_oracle_report_matches_host_object_restatement(oracle):
     tg_off, di_rows, gi, spawned, free, params = _random_rows(3)
     D = len(di_rows)

@@ -62,6 +62,14 @@ def test_cap_task_queue_length(native_ctx):
     R.check_cap(_cap_gpu(native_ctx))
 
 
+def test_db_task_queue_persister(native_ctx):
+    """TestDBTaskQueuePersister (task_queue_persister_test.go:20-213) through evg_schedule_distros' item list."""
+    def materialize(batch, res, limit):
+        _, items, _ = native_ctx.schedule(batch, max_scheduled=limit, dispatch=False)
+        return items
+    R.check_persister(native_ctx, materialize)
+
+
 # ---- synthetic pools: full bit-exact comparison ---------------------------------------------------------------
 def _check_unit_rows(batch, got, what):
     """The breakdown per UNIT (evg_plan_output.unit_of_task / unit_breakdown): every task's slot lies in its distro's slot

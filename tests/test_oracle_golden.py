@@ -71,6 +71,10 @@ def test_cap_task_queue_length(oracle):
     R.check_cap(oracle.cap_queue)
 
 
+def test_db_task_queue_persister(oracle):
+    R.check_persister(oracle, lambda batch, res, limit: oracle.materialize_queue(batch, res, limit))
+
+
 # ---- planner_test.go:54-196: UnitCache / Unit semantics, through the oracle's handle API ----------------
 @pytest.fixture
 def cache():
