@@ -61,11 +61,16 @@ struct HostRec {
   uint32_t flags;
 };
 constexpr int kAllocLdsBuckets = 1025;
+constexpr int kAllocFilterBits = 2048;  // which-buckets-have-hosts filter, indexed by bucket mod 2048
 struct HostStage {
   HostRec* rec;   // [nh]
   int* n_hosts;   // [ntg + 1]
   int* n_free;    // [ntg + 1]
-  bool staged;    // false: too many hosts / buckets for LDS -- the bucket pass reads global memory (a.w_term)
+  bool staged;    // false: too many hosts for LDS -- the bucket pass reads global memory (a.w_term)
+  // A distro with more task groups than counter words (a 19.5k-task distro has ~1,100): the host records are still in LDS,
+  // the per-bucket counts are not. Nearly every bucket has no host at all, so a 2048-bit filter (bit = bucket mod 2048,
+  // set while staging) tells a bucket's thread whether it has to walk the records; a false positive costs one walk.
+  uint32_t* filter = nullptr;  // [kAllocFilterBits / 32], zeroed; non-null <=> staged without counters
 };
 __device__ __forceinline__ void stage_host(const HostStage& s, const AllocArgs& a, int h0, int i, uint32_t f, int32_t key, double term,
                                            int tg_lo, int ntg) {
@@ -73,6 +78,7 @@ __device__ __forceinline__ void stage_host(const HostStage& s, const AllocArgs& 
   s.rec[i] = HostRec{term, key, f};
   const int b = key == -1 ? 0 : (key >= tg_lo && key < tg_lo + ntg) ? 1 + key - tg_lo : -1;
   if (b >= 0) {
+    if (s.filter) { atomicOr(&s.filter[(b & (kAllocFilterBits - 1)) >> 5], 1u << (b & 31)); return; }
     atomicAdd(&s.n_hosts[b], 1);
     if (f & EVG_HF_FREE) atomicAdd(&s.n_free[b], 1);
   }
@@ -118,7 +124,17 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
     const int want_key = b == 0 ? -1 : tg_lo + (b - 1);
     int n_hosts_b = 0, n_free_b = 0;
     double soon = 0.0;
-    if (staged) {
+    if (staged && hs.filter) {
+      // no counter words for this many buckets: walk the records only if the filter says the bucket may have hosts
+      if (hs.filter[(b & (kAllocFilterBits - 1)) >> 5] >> (b & 31) & 1u)
+        for (int i = 0; i < nh; i++) {
+          const HostRec r = hs.rec[i];
+          const bool mine = r.key == want_key;
+          n_hosts_b += mine ? 1 : 0;
+          n_free_b += mine && (r.flags & EVG_HF_FREE) ? 1 : 0;
+          soon += mine ? r.term : 0.0;
+        }
+    } else if (staged) {
       // counts were taken while staging; the fp64 sum must follow host order (the canonical order), so the one
       // thread of the bucket walks the 16-byte records -- 4 independent LDS reads per trip, +0.0 for other buckets
       // (leaves a partial sum unchanged bit for bit). Buckets without hosts skip the walk.

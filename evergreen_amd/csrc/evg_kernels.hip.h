@@ -71,6 +71,7 @@ struct PlanArgs {
   int32_t* w_eslot;            // [E] unit slot a dependency edge adds a membership to, or -1
   void *w_keyA, *w_keyB;       // 192-bit sort keys, ping-pong
   unsigned long long* w_gfirst;  // [D + n_tg] (first queue position << 32) | TaskGroupMaxHosts of that task
+  unsigned long long* w_tgbit;   // one bit per row of every row tile: the row is a task-group task
   int32_t d0, d1;      // the distros this call plans: [d0, d1) of the batch (evg_plan_distro_range_device; else 0, D).
                        // Outputs keep the FULL batch's row / info-row numbering.
 #ifdef EVG_PHASE_TIMING

@@ -25,10 +25,16 @@ namespace evg {
 
 // Standalone UtilizationBasedHostAllocator: one 256-thread workgroup per distro (what the reference's separate
 // host-allocator job maps to; the batched tick uses the fused kernel of evg_plan_lds.hip.h instead).
-__global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs a) {
+// BLOCK threads: 256, or 1024 for batches whose distros average hundreds of task groups (a bucket's evaluation is a chain of
+// dependent global round trips: with one trip of the bucket loop per thread the chains run side by side, and every
+// bucket's result stays in its thread's registers).
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_allocate_hosts(const AllocArgs a) {
+  constexpr int kAllocBlock = BLOCK;
   __shared__ int s_i[8];  // 0: #free hosts, 1: sum new, 2: sum free, 4: first failing bucket, 5: its error
   __shared__ HostRec s_rec[kAllocLdsHosts];
   __shared__ int s_cnt[2 * kAllocLdsBuckets];
+  __shared__ uint32_t s_filter[kAllocFilterBits / 32];
   const int d = a.d0 + blockIdx.x, tid = threadIdx.x;
   const evg_alloc_params p = a.in.params[d];
   const evg_host_soa& h = a.in.hosts;
@@ -41,9 +47,13 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
   if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
   // free hosts of the distro (:33-37) and every running host's fractional-free term (:340-368); the host columns
   // the bucket loop re-reads are staged in LDS when they fit
-  HostStage hs{s_rec, s_cnt, s_cnt + kAllocLdsBuckets, nh <= kAllocLdsHosts && ntg + 1 <= kAllocLdsBuckets};
-  if (hs.staged)
+  HostStage hs{s_rec, s_cnt, s_cnt + kAllocLdsBuckets, nh <= kAllocLdsHosts};
+  if (hs.staged && ntg + 1 > kAllocLdsBuckets) {
+    hs.filter = s_filter;
+    if (tid < kAllocFilterBits / 32) s_filter[tid] = 0;
+  } else if (hs.staged) {
     for (int b = tid; b < ntg + 1; b += kAllocBlock) { hs.n_hosts[b] = 0; hs.n_free[b] = 0; }
+  }
   __syncthreads();
   uint32_t nfree = 0;
   for (int i = tid; i < nh; i += kAllocBlock) {
@@ -55,7 +65,7 @@ __global__ void __launch_bounds__(kAllocBlock) k_allocate_hosts(const AllocArgs 
   }
   __syncthreads();
   ALLOC_STAMP(1);
-  allocate_distro<kAllocBlock>(a, d, p, h0, nh, tg_lo, ntg, T, len_met, nfree, hs, s_i);
+  allocate_distro<BLOCK>(a, d, p, h0, nh, tg_lo, ntg, T, len_met, nfree, hs, s_i);
   ALLOC_STAMP(5);
 }
 
@@ -670,7 +680,7 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.w_generic = (int32_t*)c->scratch[20].p;
   a.w_key = c->scratch[21].p;
   a.w_ts = nullptr; a.w_rtile = nullptr; a.w_stile = nullptr; a.w_ntile = nullptr; a.w_bucket = nullptr; a.w_rec = nullptr;
-  a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr;
+  a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr; a.w_tgbit = nullptr;
 #ifdef EVG_PHASE_TIMING
   a.dbg_ts = c->dbg_ts;
 #endif
@@ -742,9 +752,9 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
   const size_t Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions, G = D + (size_t)in->n_task_groups;
   const size_t max_rt = N / kRT + D + 1, max_st = Stot / kST + D + 1;
   const size_t st_cap = std::min<size_t>(max_st, kMaxST);  // slot tiles of ONE distro
-  const size_t sz[10] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
-                         4 * (E + 1), sizeof(K192) * max_rt * kRT, sizeof(K192) * max_rt * kRT, 8 * G};
-  for (int i = 0; i < 10; i++) {
+  const size_t sz[11] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
+                         4 * (E + 1), sizeof(K192) * max_rt * kRT, sizeof(K192) * max_rt * kRT, 8 * G, 8 * max_rt * (kRT / 64)};
+  for (int i = 0; i < 11; i++) {
     int rc = ensure(c, c->scratch[32 + i], sz[i]);
     if (rc) return rc;
   }
@@ -752,6 +762,7 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
   a.w_ntile = (int32_t*)c->scratch[35].p; a.w_bucket = c->scratch[36].p; a.w_rec = c->scratch[37].p;
   a.w_eslot = (int32_t*)c->scratch[38].p; a.w_keyA = c->scratch[39].p; a.w_keyB = c->scratch[40].p;
   a.w_gfirst = (unsigned long long*)c->scratch[41].p;
+  a.w_tgbit = (unsigned long long*)c->scratch[42].p;
   if (!c->tiled_attr_set) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledReduceLds));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_elect, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
@@ -791,7 +802,6 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
   hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, st, a);
   hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, st, a);
   for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, st, a, p);
-  hipLaunchKernelGGL(k_tiled_finish, rt, tb, 0, st, a);
   hipLaunchKernelGGL(k_tiled_rows, gg, dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 1);
   HIP_TRY(c, hipGetLastError());
@@ -840,7 +850,9 @@ static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_o
     nd = d_end - d_begin;
     if (nd == 0) return EVG_OK;
   }
-  hipLaunchKernelGGL(k_allocate_hosts, dim3(nd), dim3(kAllocBlock), 0, st, a);
+  // task groups per distro, on average (host-known sizes): many -> one 1024-thread workgroup per distro
+  if ((long long)in->n_task_groups > 300LL * in->n_distros) hipLaunchKernelGGL(k_allocate_hosts<1024>, dim3(nd), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(k_allocate_hosts<kAllocBlock>, dim3(nd), dim3(kAllocBlock), 0, st, a);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }

@@ -19,7 +19,8 @@
 //                       final queue order is the plain ascending order of these keys -- and the tile sorted in LDS
 //   T4 k_tiled_merge    log2(tiles) passes of merge-path: every workgroup produces 2048 consecutive outputs of the merge of
 //                       two sorted runs (wave-wide 64-ary diagonal search, then one 11-stage bitonic merge in registers/LDS)
-//   T5 k_tiled_finish   queue order out; first queue position of every task group (TaskGroupInfo.MaxHosts, scheduler.go:103-106)
+//   T5 (tail of T4's last pass) queue order out; first queue position of every task group (TaskGroupInfo.MaxHosts,
+//                       scheduler.go:103-106) -- the last pass's merged keys never go back to memory
 //   T6 k_tiled_rows     model.DistroQueueInfo / the standalone TaskGroupInfo row
 //
 // Device-scope atomics left: a handful per WORKGROUP (ranges, distro counters), one per task-group row in T5.
@@ -237,28 +238,64 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a)
     const int64_t dmt = t.deps_met_ts_ns[r];
     bool met = (e1 == e0) || (f & EVG_TF_OVERRIDE_DEPS) || !is_zero_time(dmt);  // HasDependenciesMet task.go:3406
     bool all = true;
+    int prev0 = -1, prev1 = -1, prev2 = -1, prev3 = -1;  // unit slots the row's last four edges named (-1: none)
+    // The row's first three edges are fetched together, and so are the dependency rows' columns they point at: two round
+    // trips for the row instead of two per edge (the kernel is bound by these chains of dependent loads).
+    constexpr int kFast = 3;
+    int pj[kFast], ptg[kFast], pver[kFast];
+    uint32_t pinfo[kFast], pfl[kFast];
+#pragma unroll
+    for (int q = 0; q < kFast; q++) {
+      const bool has = e0 + q < e1;
+      pj[q] = has ? t.dep_idx[e0 + q] - lo : -1;
+      pinfo[q] = has ? (uint32_t)t.dep_info[e0 + q] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < kFast; q++) {
+      const bool inq = (unsigned)pj[q] < (unsigned)n;
+      const int rj = lo + (inq ? pj[q] : 0);
+      pfl[q] = inq ? (uint32_t)t.flags[rj] : 0u;
+      ptg[q] = inq ? t.tg_key[rj] : -1;
+      pver[q] = inq && c.gv ? t.version_key[rj] : c.ver_lo;
+    }
     for (int e = e0; e < e1; e++) {
-      const int j = t.dep_idx[e] - lo;
-      const uint32_t info = t.dep_info[e];
+      const int q = e - e0;
+      int j, tgj, verj = c.ver_lo;
+      uint32_t info, fj = 0;
+      if (q < kFast) {
+        j = q == 0 ? pj[0] : q == 1 ? pj[1] : pj[2]; info = q == 0 ? pinfo[0] : q == 1 ? pinfo[1] : pinfo[2];
+        fj = q == 0 ? pfl[0] : q == 1 ? pfl[1] : pfl[2]; tgj = q == 0 ? ptg[0] : q == 1 ? ptg[1] : ptg[2];
+        verj = q == 0 ? pver[0] : q == 1 ? pver[1] : pver[2];
+      } else {
+        j = t.dep_idx[e] - lo;
+        info = t.dep_info[e];
+        tgj = -1;
+        if ((unsigned)j < (unsigned)n) {
+          fj = (uint32_t)t.flags[lo + j];
+          tgj = t.tg_key[lo + j];
+          if (c.gv) verj = t.version_key[lo + j];
+        }
+      }
       uint32_t st;
       bool blk;
       int sl = -1;
       if ((unsigned)j < (unsigned)n) {
-        const int rj = lo + j;
-        const uint32_t fj = (uint32_t)t.flags[rj];
         st = (fj & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT;
         blk = fj & EVG_TF_BLOCKED;
-        const int tgj = t.tg_key[rj];
-        sl = tgj >= 0 ? c.tg_base + (tgj - c.tg_lo) : c.gv ? c.ver_base + (t.version_key[rj] - c.ver_lo) : j;
+        sl = tgj >= 0 ? c.tg_base + (tgj - c.tg_lo) : c.gv ? c.ver_base + (verj - c.ver_lo) : j;
         if (sl == m.t0 || sl == m.t1) sl = -1;  // Unit.Add is keyed by task id (planner.go:131): already a member
-        for (int e2 = e0; sl >= 0 && e2 < e; e2++)
-          if (a.w_eslot[e2] == sl) sl = -1;     // named by an earlier edge of this row (written by this thread)
+        // named by an earlier edge of this row? The last four ride in registers; only a row with more than four
+        // dependencies reads its older ones back (its own stores: a round trip through memory each)
+        if (sl == prev0 || sl == prev1 || sl == prev2 || sl == prev3) sl = -1;
+        for (int e2 = e0; sl >= 0 && e2 < e - 4; e2++)
+          if (a.w_eslot[e2] == sl) sl = -1;
       } else {
         st = (info & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT;
         blk = info & EVG_DEP_BLOCKED;
         if (info & EVG_DEP_MISSING) all = false;
       }
       a.w_eslot[e] = sl;
+      prev3 = prev2; prev2 = prev1; prev1 = prev0; prev0 = sl;
       if (sl >= 0) atomicAdd(&s_cnt[sl / kST], 1);
       const uint32_t req = info & EVG_DEP_REQ_MASK;  // SatisfiesDependency task.go:546-561
       const bool sat = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
@@ -303,6 +340,13 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a)
     m.bits = ((uf >> 24) << 10) | qi;
     if (!m.own) atomicAdd(&s_cnt[m.t0 / kST], 1);
     if (m.t1 >= 0) atomicAdd(&s_cnt[m.t1 / kST], 1);
+  }
+  // one bit per row: is it a task-group task? (the tail of the last merge pass classifies the rows it meets in QUEUE order with this -- a
+  // 2.4 KB table per 19.5k-row distro that stays in cache -- instead of gathering tg_key by row)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned long long bits = __ballot(rm[k].live && !(rm[k].bits & (((UF_NONGROUP >> 24)) << 10)));
+    if (lane == 0) a.w_tgbit[((size_t)ts->rt_base + tile) * (kRT / 64) + (k * kTiledBlock + tid) / 64] = bits;
   }
   // ---- per-workgroup reductions -> a few device atomics ----
   r_dmin = wave_min(r_dmin); r_dmax = wave_max(r_dmax);
@@ -506,7 +550,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     a.w_val[sb + su] = v;
     a.w_minrow[sb + su] = m_minrow[u];
     const int k = su - c.tg_base;
-    if (k >= 0 && k < c.ntg) {  // model.TaskGroupInfo of task group k; MaxHosts comes with the queue order (k_tiled_finish)
+    if (k >= 0 && k < c.ntg) {  // model.TaskGroupInfo of task group k; MaxHosts comes with the queue order (tiled_emit_order)
       evg_group_info gi;
       gi.expected_duration_ns = (int64_t)g_dur[u];
       gi.duration_over_threshold_ns = (int64_t)g_dover[u];
@@ -598,6 +642,46 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_elect(const PlanArgs a) {
   for (int e4 = 0; e4 < 4; e4++) out[e4] = k[e4];
 }
 
+// ---- T5 (the tail of a distro's LAST merge pass): queue order out; first queue position per task group ---------------
+// k[e] = the key at queue position q0 + e of distro d. Called by every thread of the workgroup.
+__device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, int d, long long q0, const K192 (&k)[4]) {
+  __shared__ unsigned long long s_first;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo, D = a.in.n_distros;
+  if (tid == 0) s_first = ~0ull;
+  __syncthreads();
+  const unsigned long long* tgbit = a.w_tgbit + (size_t)ts->rt_base * (kRT / 64);
+  unsigned long long first = ~0ull;  // (queue position << 32) | row of the first stand-alone task this thread met
+  int32_t o4[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const long long q = q0 + e;
+    o4[e] = 0;
+    if (q >= n) continue;
+    const int i = (int)(k[e].lo & 0xFFFFFu);
+    const int r = lo + i;
+    o4[e] = r;
+    if (!((tgbit[i >> 6] >> (i & 63)) & 1ull)) {  // row tiles are 2048 rows: bit i of the distro's table
+      const unsigned long long packed = ((unsigned long long)q << 32) | (uint32_t)i;
+      first = packed < first ? packed : first;
+    } else {
+      const int tgk = a.in.tasks.tg_key[r];
+      const unsigned long long packed = ((unsigned long long)q << 32) | (uint32_t)a.in.tasks.task_group_max_hosts[r];
+      if (__hip_atomic_load(&a.w_gfirst[D + tgk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > packed) atomicMin(&a.w_gfirst[D + tgk], packed);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+    if (q0 + e < n) a.out.order[lo + q0 + e] = o4[e];
+  first = wave_min((uint64_t)first);
+  if (lane == 0 && first != ~0ull) atomicMin(&s_first, first);
+  __syncthreads();
+  if (tid == 0 && s_first != ~0ull) {  // MaxHosts of the stand-alone row = TaskGroupMaxHosts of its first task in queue order
+    const unsigned long long packed = (s_first & 0xFFFFFFFF00000000ull) | (uint32_t)a.in.tasks.task_group_max_hosts[lo + (int)(s_first & 0xFFFFFFFFu)];
+    atomicMin(&ts->s_first, packed);
+  }
+}
+
 // ---- T4: one merge-path pass ---------------------------------------------------------------------------------------
 // First index a in [lo, hi] with !(A[a] <= B[diag - 1 - a]) (hi if none): the number of A keys among the first `diag`
 // outputs of merge(A, B). One wave, 64 probes per round.
@@ -624,7 +708,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_merge(const PlanArgs a, i
   const int w = blockIdx.x;
   if (w >= a.w_ntile[0]) return;
   const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
-  const TState* ts = &a.w_ts[d];
+  TState* ts = &a.w_ts[d];
   if (!tiled_live(ts) || pass >= ts->passes) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const K192* src = (const K192*)((pass & 1) ? a.w_keyB : a.w_keyA) + (size_t)ts->rt_base * kRT;
@@ -656,40 +740,12 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_merge(const PlanArgs a, i
     }
     bitonic_merge4_fixed<kRT, K192>(k, tid, (K192*)smem, true);
   }
+  if (pass == ts->passes - 1) {  // the distro's last pass: the merged keys ARE the queue -- nothing is written back
+    tiled_emit_order(a, ts, d, pos0 + tid * 4, k);
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 4; e++) dst[pos0 + tid * 4 + e] = k[e];
-}
-
-// ---- T5: queue order out; first queue position per task group ---------------------------------------------------------
-__global__ void __launch_bounds__(kTiledBlock) k_tiled_finish(const PlanArgs a) {
-  __shared__ unsigned long long s_first;
-  const int w = blockIdx.x;
-  if (w >= a.w_ntile[0]) return;
-  const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
-  TState* ts = &a.w_ts[d];
-  if (!tiled_live(ts)) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo, D = a.in.n_distros;
-  const K192* keys = (const K192*)((ts->passes & 1) ? a.w_keyB : a.w_keyA) + (size_t)ts->rt_base * kRT;
-  if (tid == 0) s_first = ~0ull;
-  __syncthreads();
-  unsigned long long first = ~0ull;
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const int q = tile * kRT + e * kTiledBlock + tid;
-    if (q >= n) continue;
-    const int i = (int)(keys[q].lo & 0xFFFFFu);
-    const int r = lo + i;
-    a.out.order[lo + q] = r;
-    const int tgk = a.in.tasks.tg_key[r];
-    const unsigned long long packed = ((unsigned long long)q << 32) | (uint32_t)a.in.tasks.task_group_max_hosts[r];
-    if (tgk < 0) first = packed < first ? packed : first;
-    else if (__hip_atomic_load(&a.w_gfirst[D + tgk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > packed) atomicMin(&a.w_gfirst[D + tgk], packed);
-  }
-  first = wave_min((uint64_t)first);
-  if (lane == 0 && first != ~0ull) atomicMin(&s_first, first);
-  __syncthreads();
-  if (tid == 0 && s_first != ~0ull) atomicMin(&ts->s_first, s_first);
 }
 
 // ---- T6: model.DistroQueueInfo, the standalone row, MaxHosts of the task-group rows ---------------------------------------
