@@ -57,7 +57,7 @@ constexpr int R_HASH = kLdsLean, kLdsRich = R_HASH + 8 * kS;
 // region A re-used after D:
 constexpr int X_BUF0 = 0, X_BUF1 = 8 * kN, X_IK = 16 * kN, X_IK_END = X_IK + 8 * kN;  // sort exchange, in-unit keys by task
 constexpr int Y_SIK = 0, Y_SSLOT = 8 * kN, Y_SIDX = Y_SSLOT + 2 * kN;                  // by sorted position
-constexpr int Y_SCAN = Y_SIDX + 2 * kN, Y_REN = Y_SCAN + 4 * kBlock;                  // run-start scan, run end by run start
+constexpr int Y_SCAN = Y_SIDX + 2 * kN, Y_REN = Y_SCAN + 4 * kBlock + 64;             // run-start scan (+ 8 wave totals), run end by run start
 static_assert(Y_REN + 2 * kN <= X_IK, "run bookkeeping must not overlap the in-unit keys by task");
 constexpr int Y_POS = X_IK_END, Y_FIDX = Y_POS + 2 * kN, Y_END = Y_FIDX + 2 * kN;      // final position by task / task by position
 constexpr int Z_G = 0;                                                                 // group accumulators (36 B per row)
@@ -621,6 +621,8 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   __syncthreads();
   int incoming = lane ? scan[tid - 1] : -1;  // last run start before this thread's positions
   for (int w = 0; w < (tid >> 6); w++) { const int x = scan[w * 64 + 63]; incoming = x > incoming ? x : incoming; }
+  // Work items of the chunked ranking below: a run is cut into chunks of four consecutive positions, one item per chunk.
+  // `items` = how many start inside this thread; their numbers come from a sum-scan over the workgroup.
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const int q = i0 + e;
@@ -637,8 +639,106 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     if (q < n) { en[e] = ren[st[e]]; multi |= en[e] - st[e] > 1; }
     else { st[e] = q; en[e] = q; }
   }
+  // Items that start inside this thread: low half = items of LONG runs (more than four positions), high half = items of
+  // short runs (one item, no loop). Long-run items are numbered first, so that when a distro has more items than threads
+  // the second round is made of short-run items.
+  uint32_t items = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+    if (i0 + e < n && ((i0 + e - st[e]) & 3) == 0) items += en[e] - st[e] > 4 ? 1u : 0x10000u;
+  uint32_t item_excl;  // packed counts of the items that start in earlier threads
+  {
+    uint32_t v = items;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1 ... 8: inclusive scan of the 16-lane row
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                   r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const int row = lane >> 4;
+    v += (row >= 1 ? r0 : 0u) + (row >= 2 ? r1 : 0u) + (row >= 3 ? r2 : 0u);
+    item_excl = v - items;
+    if (lane == 63) scan[kBlock + (tid >> 6)] = (int32_t)v;  // the wave's totals, behind the max-scan words
+  }
+  __syncthreads();
+  uint32_t item_tot = 0;
+  {
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) { const uint32_t x = (uint32_t)scan[kBlock + w]; base += w < (tid >> 6) ? x : 0u; item_tot += x; }
+    item_excl += base;
+  }
+  const int n_long = (int)(item_tot & 0xFFFFu), n_items = n_long + (int)(item_tot >> 16);
   int rank[4] = {0, 0, 0, 0};
-  if (multi) {
+  // ---- chunked ranking: every lane ranks ONE chunk of four positions of ONE run against the rest of that run ------------
+  // With a thread's four positions fixed by its lane (the loops below), the lane on a boundary between two long runs walks
+  // all of the first run AND all of the second, and the wave waits for it: ~2L/4 trips where L/4 are needed. Here no item
+  // straddles a run, every item of a run makes the same ceil(L/4) - 1 trips, and the keys are stored as 2 * key + 1 so
+  // that "an earlier position precedes on <=, a later one on <" is one subtraction of 0 / 1 from the loaded key.
+  // Taken when the run structure gives at most two items per thread (long runs: grouped-version distros) and the in-unit key
+  // fits 63 bits; a distro of short runs has several items per thread and its loops below are short anyway.
+  constexpr int kMaxItems = 2 * kBlock;
+  const bool chunked = ik_ok && bt + bn + bp + bd <= 63 && n_items <= kMaxItems;
+  if (chunked) {
+    uint16_t* itq = (uint16_t*)(smem + X_IK);       // item -> its first position; the in-unit keys by task are dead
+    uint16_t* its = itq + kMaxItems;                // item -> start of its run
+    {
+      int kl = (int)(item_excl & 0xFFFFu), ks = n_long + (int)(item_excl >> 16);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int q = i0 + e;
+        if (q < n) sik[q] = (myik[e] << 1) | 1ull;
+        if (q < n && ((q - st[e]) & 3) == 0) {
+          const int k = en[e] - st[e] > 4 ? kl++ : ks++;
+          itq[k] = (uint16_t)q; its[k] = (uint16_t)st[e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int item = tid; item < n_items; item += kBlock) {
+      const int q0 = itq[item], rs = its[item], re = ren[rs];
+      const int L = re - rs, cnt = re - q0 < 4 ? re - q0 : 4;
+      uint64_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = e < cnt ? sik[q0 + e] : 0ull;  // 0: nothing is ever below it
+      const int kc = (q0 - rs) >> 2, nfull = L >> 2;
+      const int trips = nfull - (kc < nfull ? 1 : 0);
+      int rk[4] = {0, 0, 0, 0};
+      for (int j = 0; j < trips; j++) {
+        const bool before = j < kc;
+        const int base = rs + 4 * (before ? j : j + 1);
+        const uint64_t adj = before ? 1ull : 0ull;
+        const uint64_t k0 = sik[base] - adj, k1 = sik[base + 1] - adj, k2 = sik[base + 2] - adj, k3 = sik[base + 3] - adj;
+#pragma unroll
+        for (int e = 0; e < 4; e++) rk[e] += (k0 < o[e] ? 1 : 0) + (k1 < o[e] ? 1 : 0) + (k2 < o[e] ? 1 : 0) + (k3 < o[e] ? 1 : 0);
+      }
+      if ((L & 3) && kc < nfull) {  // the run's partial last chunk, when it is not this item: later positions
+        const int base = rs + 4 * nfull;
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+          const uint64_t kx = base + x < re ? sik[base + x] : ~0ull;
+#pragma unroll
+          for (int e = 0; e < 4; e++) rk[e] += kx < o[e] ? 1 : 0;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int f = e + 1; f < 4; f++) {
+          const bool both = f < cnt;
+          const bool f_first = o[f] < o[e];  // ties: the earlier position (row order) stays first
+          rk[e] += both && f_first ? 1 : 0;
+          rk[f] += both && !f_first ? 1 : 0;
+        }
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (e < cnt) {
+          const int fin = rs + rk[e], i = (int)sidx[q0 + e];
+          pos[i] = (uint16_t)fin;
+          fidx[fin] = (uint16_t)i;
+        }
+    }
+  } else if (multi) {
     if (ik_ok) {
       // The thread's positions are consecutive. Positions BEFORE them can only belong to the run of its first position,
       // positions AFTER them only to the run of its last one, and every run in between lies inside the thread. So, for all
@@ -707,14 +807,16 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       }
     }
   }
+  if (!chunked) {
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const int q = i0 + e;
-    if (q >= n) continue;
-    const int fin = st[e] + rank[e];
-    const int i = (int)(srt[e] & 0x7FFu);
-    pos[i] = (uint16_t)fin;
-    fidx[fin] = (uint16_t)i;
+    for (int e = 0; e < 4; e++) {
+      const int q = i0 + e;
+      if (q >= n) continue;
+      const int fin = st[e] + rank[e];
+      const int i = (int)(srt[e] & 0x7FFu);
+      pos[i] = (uint16_t)fin;
+      fidx[fin] = (uint16_t)i;
+    }
   }
   __syncthreads();
   {
