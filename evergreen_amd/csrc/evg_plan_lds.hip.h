@@ -248,7 +248,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     m.pslot = (uint16_t*)(smem + B_PSLOT); m.edge = m.pslot - lds_pad_edges(c.ne);
   }
   m.val = m.tiq;  // TotalValue overwrites the unit's TimeInQueue sum
-  // s_red words: 0 any met merge-queue task, 1 n_met, 2 n_mq, 3 n_s3, 4 secondary, 5 t_cover, 6 t_wait, 7 n_units,
+  // s_red words: 0 any met merge-queue task, 4 secondary, 5 t_cover, 6 t_wait, 7 n_units, 14-15 n_met | n_mq << 16 | n_s3 << 32,
   // 8 rows, 10-11 t_dur, 12-13 t_dover; 16-23 four 64-bit range words; 24-29 six 32-bit range words
   unsigned long long* s_rng = (unsigned long long*)(s_red + 16);  // 0 vmin 1 vmax 2 durmin 3 durmax (biased)
   uint32_t* s_r32 = s_red + 24;                                   // 0 tgomin 1 tgomax 2 ndmin 3 ndmax 4 primin 5 primax
@@ -831,13 +831,14 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
 
   // ---- G: GetDistroQueueInfo (scheduler.go:57-178) -----------------------------------------------------------
   EVG_OPAQUE_ZERO(late3);
+  // Per task-group row: two 64-bit sums, the four counters packed into ONE 64-bit word (count | over threshold << 16 |
+  // waited over threshold << 32 | met merge-queue tasks << 48: a distro on this path has at most 2048 tasks, so no field
+  // carries into the next), the first queue position. A task-group task costs four unconditional LDS atomics.
   uint64_t* g_dur = (uint64_t*)(smem + Z_G);
   uint64_t* g_dover = g_dur + kG;
-  uint32_t* g_cnt = (uint32_t*)(g_dover + kG);
-  uint32_t *g_cover = g_cnt + kG, *g_wait = g_cover + kG, *g_mq = g_wait + kG, *g_first = g_mq + kG;
-  for (int k = tid; k < c.ntg + 1; k += kBlock) {
-    g_cnt[k] = 0; g_cover[k] = 0; g_wait[k] = 0; g_mq[k] = 0; g_first[k] = 0xFFFFFFFFu; g_dur[k] = 0; g_dover[k] = 0;
-  }
+  uint64_t* g_pk = g_dover + kG;
+  uint32_t* g_first = (uint32_t*)(g_pk + kG);
+  for (int k = tid; k < c.ntg + 1; k += kBlock) { g_pk[k] = 0; g_first[k] = 0xFFFFFFFFu; g_dur[k] = 0; g_dover[k] = 0; }
   // pass A: checkDependenciesMet per task; does any met merge-queue task exist?
   const bool incl = p.includes_dependencies != 0;
   bool met[4];
@@ -882,8 +883,9 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
 
   // pass B: segmented sums keyed by task group (row 0 = ""). The standalone row takes ~90% of the tasks: it is
   // summed in registers and wave-reduced, one atomic per wave; task-group rows take direct LDS atomics.
-  uint32_t n_met = 0, n_mq = 0, n_s3 = 0, sec = 0;
-  uint32_t s_cnt = 0, s_cover = 0, s_wait = 0, s_mq = 0, s_first = 0xFFFFFFFFu;
+  uint32_t sec = 0, s_first = 0xFFFFFFFFu;
+  uint64_t s_pk = 0;   // the stand-alone row's counters, packed like g_pk
+  uint64_t n_pk = 0;   // distro counters: deps met | met merge-queue << 16 | met with S3 parser-project storage << 32
   uint64_t s_dur = 0, s_dover = 0;
   int64_t wait4[4];
 #pragma unroll
@@ -905,37 +907,30 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       wait_over = wait4[e] > T;
     }
     if (f & EVG_TF_OTHER_DISTRO) sec = 1;
-    if (mt) { n_met++; if (merge) n_mq++; if (f & EVG_TF_S3_STORAGE) n_s3++; }
-    const int g = tgk[e] < 0 ? 0 : 1 + (tgk[e] - c.tg_lo);
+    n_pk += mt ? 1ull | (merge ? 1ull << 16 : 0ull) | ((f & EVG_TF_S3_STORAGE) ? 1ull << 32 : 0ull) : 0ull;
+    const uint64_t pk = (count ? 1ull : 0ull) | (over ? 1ull << 16 : 0ull) | (wait_over ? 1ull << 32 : 0ull) | (mt && merge ? 1ull << 48 : 0ull);
+    const uint64_t du_c = count ? (uint64_t)du : 0ull, du_o = over ? (uint64_t)du : 0ull;
     const uint32_t qp = (uint32_t)pos[i];
-    if (g == 0) {
+    if (tgk[e] < 0) {
       s_first = qp < s_first ? qp : s_first;
-      s_cnt += count; s_dur += count ? (uint64_t)du : 0; s_cover += over; s_dover += over ? (uint64_t)du : 0;
-      s_wait += wait_over; s_mq += (mt && merge);
+      s_pk += pk; s_dur += du_c; s_dover += du_o;
     } else {
+      const int g = 1 + (tgk[e] - c.tg_lo);
       atomicMin(&g_first[g], qp);
-      if (count) { atomicAdd(&g_cnt[g], 1u); atomicAdd((unsigned long long*)&g_dur[g], (unsigned long long)du); }
-      if (over) { atomicAdd(&g_cover[g], 1u); atomicAdd((unsigned long long*)&g_dover[g], (unsigned long long)du); }
-      if (wait_over) atomicAdd(&g_wait[g], 1u);
-      if (mt && merge) atomicAdd(&g_mq[g], 1u);
+      atomicAdd((unsigned long long*)&g_pk[g], (unsigned long long)pk);
+      atomicAdd((unsigned long long*)&g_dur[g], (unsigned long long)du_c);
+      atomicAdd((unsigned long long*)&g_dover[g], (unsigned long long)du_o);
     }
   }
   store4(EVG_LATE_ARG(int64_t*, out.wait_ns, late3) + lo, i0, n, wait4);
-  s_cnt = row_sum(s_cnt); s_cover = row_sum(s_cover); s_wait = row_sum(s_wait); s_mq = row_sum(s_mq);
-  s_dur = row_sum(s_dur); s_dover = row_sum(s_dover);
-  n_met = row_sum(n_met); n_mq = row_sum(n_mq); n_s3 = row_sum(n_s3);
+  s_pk = row_sum(s_pk); s_dur = row_sum(s_dur); s_dover = row_sum(s_dover); n_pk = row_sum(n_pk);
   s_first = row_min(s_first);
   if ((lane & 15) == 0) {  // the four row leaders
     if (s_first != 0xFFFFFFFFu) atomicMin(&g_first[0], s_first);
-    if (s_cnt) atomicAdd(&g_cnt[0], s_cnt);
+    if (s_pk) atomicAdd((unsigned long long*)&g_pk[0], (unsigned long long)s_pk);
     if (s_dur) atomicAdd((unsigned long long*)&g_dur[0], (unsigned long long)s_dur);
-    if (s_cover) atomicAdd(&g_cover[0], s_cover);
     if (s_dover) atomicAdd((unsigned long long*)&g_dover[0], (unsigned long long)s_dover);
-    if (s_wait) atomicAdd(&g_wait[0], s_wait);
-    if (s_mq) atomicAdd(&g_mq[0], s_mq);
-    if (n_met) atomicAdd(&s_red[1], n_met);
-    if (n_mq) atomicAdd(&s_red[2], n_mq);
-    if (n_s3) atomicAdd(&s_red[3], n_s3);
+    if (n_pk) atomicAdd((unsigned long long*)&s_red[14], (unsigned long long)n_pk);
   }
   if (__any(sec) && lane == 0) atomicOr(&s_red[4], 1u);
   EVG_STAMP(10); EVG_STOP(10);
@@ -954,16 +949,17 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     evg_group_info gi;
     gi.expected_duration_ns = (int64_t)g_dur[k];
     gi.duration_over_threshold_ns = (int64_t)g_dover[k];
-    gi.count = (int32_t)g_cnt[k];
+    const uint64_t pk = g_pk[k];
+    gi.count = (int32_t)(pk & 0xFFFFu);
     gi.max_hosts = present ? tg_max_hosts[lo + (int)fidx[first]] : 0;
-    gi.count_duration_over_threshold = (int32_t)g_cover[k];
-    gi.count_wait_over_threshold = (int32_t)g_wait[k];
-    gi.count_dep_filled_merge_queue_tasks = (int32_t)g_mq[k];
+    gi.count_duration_over_threshold = (int32_t)((pk >> 16) & 0xFFFFu);
+    gi.count_wait_over_threshold = (int32_t)((pk >> 32) & 0xFFFFu);
+    gi.count_dep_filled_merge_queue_tasks = (int32_t)(pk >> 48);
     gi.present = present ? 1 : 0;
     gi.count_free = 0;
     gi.count_required = 0;
     *o = gi;
-    t_dur += g_dur[k]; t_dover += g_dover[k]; t_cover += g_cover[k]; t_wait += g_wait[k];
+    t_dur += g_dur[k]; t_dover += g_dover[k]; t_cover += (uint32_t)((pk >> 16) & 0xFFFFu); t_wait += (uint32_t)((pk >> 32) & 0xFFFFu);
     t_rows += present ? 1u : 0u;
   }
   t_dur = row_sum(t_dur); t_dover = row_sum(t_dover);
@@ -982,11 +978,12 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     di.max_duration_threshold_ns = T;
     di.duration_over_threshold_ns = (int64_t)(*(unsigned long long*)&s_red[12]);
     di.length = n;
-    di.length_with_dependencies_met = (int32_t)s_red[1];
-    di.count_dep_filled_merge_queue_tasks = (int32_t)s_red[2];
+    const unsigned long long n_pk_all = *(unsigned long long*)&s_red[14];  // deps met | met merge-queue << 16 | met + S3 storage << 32
+    di.length_with_dependencies_met = (int32_t)(n_pk_all & 0xFFFFu);
+    di.count_dep_filled_merge_queue_tasks = (int32_t)((n_pk_all >> 16) & 0xFFFFu);
     di.count_duration_over_threshold = (int32_t)s_red[5];
     di.count_wait_over_threshold = (int32_t)s_red[6];
-    di.num_queued_large_parser_project_tasks = (int32_t)s_red[3];
+    di.num_queued_large_parser_project_tasks = (int32_t)((n_pk_all >> 32) & 0xFFFFu);
     di.secondary_queue = (int32_t)s_red[4];
     di.n_task_group_infos = (int32_t)s_red[8];
     EVG_LATE_ARG(evg_distro_info*, out.distro_info, late3)[d] = di;
@@ -994,7 +991,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   EVG_STAMP(11); EVG_STOP(11);
   if (FUSED) {
     // ---- H: UtilizationBasedHostAllocator for this distro (evg_alloc.hip.h) ----------------------------------
-    const int len_met = (int)s_red[1];
+    const int len_met = (int)(*(unsigned long long*)&s_red[14] & 0xFFFFu);
     __syncthreads();  // group rows are in global memory (same CU: visible after the barrier); region A and s_red are free
     const int lds_room = (int)((unsigned char*)m.edge - smem);
     const int nb = c.ntg + 1;
