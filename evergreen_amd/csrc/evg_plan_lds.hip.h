@@ -60,9 +60,10 @@ constexpr int Y_SIK = 0, Y_SSLOT = 8 * kN, Y_SIDX = Y_SSLOT + 2 * kN;           
 constexpr int Y_SCAN = Y_SIDX + 2 * kN, Y_REN = Y_SCAN + 4 * kBlock + 64;             // run-start scan (+ 8 wave totals), run end by run start
 static_assert(Y_REN + 2 * kN <= X_IK, "run bookkeeping must not overlap the in-unit keys by task");
 constexpr int Y_POS = X_IK_END, Y_FIDX = Y_POS + 2 * kN, Y_END = Y_FIDX + 2 * kN;      // final position by task / task by position
-constexpr int Z_G = 0;                                                                 // group accumulators (36 B per row)
+constexpr int Z_G = 0;                                                                 // group accumulators (28 B per row)
 static_assert(Y_SIDX + 2 * kN <= X_IK, "by-position arrays must not overlap the in-unit keys by task");
-static_assert(Z_G + 36 * kG <= Y_POS, "region A re-use");
+static_assert(Z_G + 28 * kG <= X_IK, "group accumulators (28 B per row) end before the parked TaskGroupMaxHosts column");
+static_assert(X_IK + 4 * kN <= Y_POS, "the parked TaskGroupMaxHosts column ends before the final positions");
 static_assert(kLdsLean + 512 <= 80 * 1024, "lean configuration: two workgroups per CU");
 static_assert(kLdsRich + 512 <= 160 * 1024, "rich configuration");
 static_assert(kS < 4096 && kN <= 2048, "slot ids are 12 bits, rows 11 bits");
@@ -839,6 +840,11 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   uint64_t* g_pk = g_dover + kG;
   uint32_t* g_first = (uint32_t*)(g_pk + kG);
   for (int k = tid; k < c.ntg + 1; k += kBlock) { g_pk[k] = 0; g_first[k] = 0xFFFFFFFFu; g_dur[k] = 0; g_dover[k] = 0; }
+  // TaskGroupMaxHosts of the rows: a row of model.TaskGroupInfo takes it from the group's first task in QUEUE order, known only
+  // at the very end -- a gather by row there is a global round trip nothing can hide. Fetched now (coalesced), parked in LDS.
+  int32_t mh4[4];
+  load4(EVG_LATE_ARG(const int32_t*, in.tasks.task_group_max_hosts, late3) + lo, i0, n, (int32_t)0, mh4);
+  int32_t* mh_lds = (int32_t*)(smem + X_IK);  // the in-unit keys by task (and phase F's item tables) are dead
   // pass A: checkDependenciesMet per task; does any met merge-queue task exist?
   const bool incl = p.includes_dependencies != 0;
   bool met[4];
@@ -923,6 +929,9 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     }
   }
   store4(EVG_LATE_ARG(int64_t*, out.wait_ns, late3) + lo, i0, n, wait4);
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+    if (i0 + e < n) mh_lds[i0 + e] = mh4[e];
   s_pk = row_sum(s_pk); s_dur = row_sum(s_dur); s_dover = row_sum(s_dover); n_pk = row_sum(n_pk);
   s_first = row_min(s_first);
   if ((lane & 15) == 0) {  // the four row leaders
@@ -939,7 +948,6 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
 
   // rows out: model.TaskGroupInfo; MaxHosts = first task of the group in QUEUE order (scheduler.go:103-106)
   evg_group_info* out_group_info = EVG_LATE_ARG(evg_group_info*, out.group_info, late3);
-  const int32_t* tg_max_hosts = EVG_LATE_ARG(const int32_t*, in.tasks.task_group_max_hosts, late3);
   uint64_t t_dur = 0, t_dover = 0;
   uint32_t t_cover = 0, t_wait = 0, t_rows = 0;
   for (int k = tid; k < c.ntg + 1; k += kBlock) {
@@ -951,7 +959,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     gi.duration_over_threshold_ns = (int64_t)g_dover[k];
     const uint64_t pk = g_pk[k];
     gi.count = (int32_t)(pk & 0xFFFFu);
-    gi.max_hosts = present ? tg_max_hosts[lo + (int)fidx[first]] : 0;
+    gi.max_hosts = present ? mh_lds[fidx[first]] : 0;
     gi.count_duration_over_threshold = (int32_t)((pk >> 16) & 0xFFFFu);
     gi.count_wait_over_threshold = (int32_t)((pk >> 32) & 0xFFFFu);
     gi.count_dep_filled_merge_queue_tasks = (int32_t)(pk >> 48);
