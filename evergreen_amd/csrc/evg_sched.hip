@@ -380,6 +380,9 @@ struct evg_ctx {
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
+  // evg_profile_plan_kernel: HIP events around the LDS planner kernel alone, on the stream it is launched on
+  bool profile = false;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool tiled_attr_set = false;
   bool dispatch_attr_set = false;
 #ifdef EVG_PHASE_TIMING
@@ -527,6 +530,8 @@ void evg_destroy(evg_ctx* c) {
   (void)hipSetDevice(c->device);
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->stage) if (b.p) (void)hipFree(b.p);
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -545,6 +550,27 @@ int evg_selftest_unit_value(evg_ctx* c, uint64_t seed, uint64_t n_cases, uint64_
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *mismatches = h[0];
   if (first_bad_case) *first_bad_case = h[1];
+  return EVG_OK;
+}
+
+int evg_profile_plan_kernel(evg_ctx* c, int enable) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (enable && !c->ev_start) {
+    HIP_TRY(c, hipEventCreate(&c->ev_start));
+    HIP_TRY(c, hipEventCreate(&c->ev_stop));
+  }
+  c->profile = enable != 0;
+  return EVG_OK;
+}
+
+int evg_last_plan_kernel_ms(evg_ctx* c, float* ms) {
+  if (!c || !ms) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->ev_start) return set_err(c, EVG_E_INVALID, "evg_profile_plan_kernel was never enabled on this context");
+  HIP_TRY(c, hipEventSynchronize(c->ev_stop));
+  HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
   return EVG_OK;
 }
 
@@ -821,11 +847,13 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
     if (d_begin == d_end) return EVG_OK;
   }
   const int D = a.d1 - a.d0;
+  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st));
   // TaskPlan.Len() needs 18 KiB more LDS per workgroup (one workgroup per CU instead of two); the breakdown rows do not
   if (out->n_units) hipLaunchKernelGGL((k_plan_distros<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, a);
   else if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros<false, true>), dim3(D), dim3(kBlock), kLdsLean, st, a);
   else hipLaunchKernelGGL((k_plan_distros<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, a);
   HIP_TRY(c, hipGetLastError());
+  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_stop, st));
   // distros the LDS path could not take (flagged on the device); the workgroups exit at once otherwise
   rc = launch_generic(c, a, in, st);
   if (rc) return rc;

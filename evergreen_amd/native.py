@@ -23,7 +23,7 @@ EXPORTS = [
     "evg_allocator_report_device", "evg_filter_runnable_device", "evg_dispatch_order_device",
     "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
     "evg_plan_distro_range_device", "evg_allocate_host_range_device", "evg_selftest_unit_value",
-    "evg_host_alloc", "evg_host_free",
+    "evg_host_alloc", "evg_host_free", "evg_profile_plan_kernel", "evg_last_plan_kernel_ms",
 ]
 
 _lib = None
@@ -83,6 +83,9 @@ def load_library() -> C.CDLL:
         lib.evg_host_alloc.restype = C.c_void_p
         lib.evg_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
         lib.evg_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    if hasattr(lib, "evg_profile_plan_kernel"):
+        lib.evg_profile_plan_kernel.argtypes = [C.c_void_p, C.c_int]
+        lib.evg_last_plan_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     if hasattr(lib, "evg_selftest_unit_value"):  # absent from older builds loaded through EVG_SCHED_LIB (A/B runs)
         lib.evg_selftest_unit_value.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
@@ -152,6 +155,15 @@ class Context:
         import dataclasses
         return dataclasses.replace(batch, **{f.name: self.pinned_copy(getattr(batch, f.name)) for f in dataclasses.fields(batch)
                                              if isinstance(getattr(batch, f.name), (np.ndarray, dict))})
+
+    def profile_plan_kernel(self, enable: bool = True) -> None:
+        self._check(self.lib.evg_profile_plan_kernel(self.h, 1 if enable else 0), "evg_profile_plan_kernel")
+
+    def last_plan_kernel_ms(self) -> float:
+        """HIP-event interval around the planner kernel of the last plan call (waits for it)."""
+        ms = C.c_float(0)
+        self._check(self.lib.evg_last_plan_kernel_ms(self.h, C.byref(ms)), "evg_last_plan_kernel_ms")
+        return float(ms.value)
 
     def selftest_unit_value(self, n_cases: int, seed: int = 0x5EED):
         """evg_selftest_unit_value: (mismatching cases, index of the first one or None)."""
