@@ -15,13 +15,15 @@ cases += [gen.GenConfig(1_000_000, 512, gen.SEED_BASE + 200, dag_depth=8, tg_fra
           gen.GenConfig(600_000, 300, gen.SEED_BASE + 202, tg_fraction=0.6, all_tg_version_fraction=0.3)]
 for cfg in cases:
     b = gen.generate(cfg)
-    pool = resident.ResidentPool(ctx, b, dev, breakdown=False, n_units=False)
+    pool = resident.ResidentPool(ctx, b, dev, breakdown=False, n_units=False, units=True)  # the drop-in configuration: unit rows
     pool.step(fused=False)
     got, ga = pool.plan_result(), pool.alloc_result()
     t0 = time.perf_counter()
-    want = o.plan(b, breakdown=False, n_units=False)
-    want.breakdown, want.n_units = None, None
+    want = o.plan(b, breakdown=True, n_units=False)
+    want.n_units = None
+    got.breakdown = got.expand_breakdown()  # rows by task from the rows by unit: compared field by field with the oracle's
     wa = o.allocate(b, want.distro_info, want.group_info)
     compare.assert_plan_equal(got, want, b, repr(cfg))
     compare.assert_alloc_equal(ga, wa, repr(cfg))
+    compare.reference_validity(b, got)
     print("ok", cfg, "oracle %.1f s" % (time.perf_counter() - t0), flush=True)
