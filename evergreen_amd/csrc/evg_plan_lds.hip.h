@@ -363,10 +363,11 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       const bool out = (raw & ED_OUT) != 0;
       const uint32_t pj = m.pslot[out ? 0u : raw & 0x7FFu];
       const int sl = (int)(pj & PS_SLOT);
-      const uint32_t req = out ? raw & EVG_DEP_REQ_MASK : (raw >> 11) & 3u;
-      const uint32_t st = out ? (raw & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT : (pj >> 12) & 3u;
-      const uint32_t blk = out ? (raw >> 4) & 1u : (pj >> 14) & 1u;
-      const bool sat = ((kDepSatTable >> (req | (st << 2) | (blk << 4))) & 1u) != 0 && !(out && (raw & EVG_DEP_MISSING));
+      // table index  req | status << 2 | blocked << 4: an out-of-queue record carries exactly these five bits at the bottom
+      // (EVG_DEP_*), an in-queue one has req at bit 11 and takes status / blocked from bits 12-14 of the dependency's pslot
+      static_assert(EVG_DEP_REQ_MASK == 3u && EVG_DEP_STATE_MASK == 0xCu && EVG_DEP_BLOCKED == 0x10u, "edge byte layout");
+      const uint32_t tix = out ? raw & 0x1Fu : ((raw >> 11) & 3u) | ((pj >> 10) & 0x1Cu);
+      const bool sat = ((kDepSatTable >> tix) & 1u) != 0 && !(out && (raw & EVG_DEP_MISSING));
       bool skip = out || sl == t0 || sl == t1;
       // already named by an earlier edge of this row? The last four in-queue edges ride in a register (16 bits each,
       // 0xFFFF = none; a slot is 12 bits); only a row with more than four dependencies re-reads its older records.
