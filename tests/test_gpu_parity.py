@@ -381,3 +381,41 @@ def test_error_exit_leaves_no_copy_in_flight(native_ctx):
         b.cols[k][:] = 0  # scribble over the inputs right away; a copy still in flight would be undefined behaviour
     want = native_ctx.plan(gen.generate(gen.config(1)))
     assert want.order.size > 0
+
+
+def test_run_structures_of_the_chunked_ranking(native_ctx, oracle):
+    """Phase F ranks a unit's tasks in chunks of four positions (at most two chunks per thread, long runs first) or, for
+    distros of short runs, with lane-fixed loops. Distros built to sit on every seam: runs of every length from 1 to 13 and a few
+    long ones (chunk boundaries, partial last chunks), item counts just under / over one and two per thread, equal in-unit keys
+    (ties fall back on row order), grouped and plain versions, and sizes around 512 / 1024 / 2048 rows."""
+    rng = np.random.default_rng(777)
+    queues = []
+
+    def distro(d, run_lengths, gv, dup_keys):
+        tasks, i = [], 0
+        for v, L in enumerate(run_lengths):
+            for k in range(L):
+                dur = 7 if dup_keys and k % 3 else int(rng.integers(1, 10**6))          # many equal durations: ties inside a run
+                tasks.append(S.Task(Id="d%d-t%d" % (d, i), DistroId="distro%d" % d, Version="v%d" % v, BuildVariant="bv", Project="p",
+                                    Requester=S.RepotrackerVersionRequester, Priority=int(rng.integers(0, 3)) if not dup_keys else 0,
+                                    NumDependents=int(rng.integers(0, 4)) if not dup_keys else 0, ExpectedDuration=dur * S.SECOND,
+                                    ActivatedTime=NOW - (v + 1) * S.HOUR))
+                i += 1
+        order = rng.permutation(len(tasks))
+        queues.append((S.Distro(Id="distro%d" % d, PlannerSettings=S.PlannerSettings(GroupVersions=gv)), [tasks[j] for j in order]))
+
+    d = 0
+    for gv in (True, False):
+        for dup in (False, True):
+            distro(d, list(range(1, 14)) * 3, gv, dup); d += 1                      # every run length 1..13, three times
+            distro(d, [4] * 128, gv, dup); d += 1                                   # 512 rows in exactly 128 full chunks
+            distro(d, [5] * 103, gv, dup); d += 1                                   # 515 rows: two items per run, 206 long items
+            distro(d, [9] * 227 + [5], gv, dup); d += 1                             # 2048 rows, 3 items per run: 684 items > 512
+            distro(d, [3] * 341 + [1], gv, dup); d += 1                             # 1024 short runs: 342 one-chunk items
+            distro(d, [1] * 600 + [80, 79, 81, 200], gv, dup); d += 1               # 600 singletons + long runs: > 512 items
+            distro(d, [2] * 1023 + [2], gv, dup); d += 1                            # 1024 items: the limit of the chunked path
+            distro(d, [2] * 1000 + [7, 7, 7, 6, 5, 5, 4, 4, 3], gv, dup); d += 1    # just over: the lane-fixed loops
+            distro(d, [500, 513, 511, 524], gv, dup); d += 1                        # runs longer than a wave's 256 positions
+    b = S.pack_queues(queues, NOW).batch
+    assert int(np.diff(b.task_off).max()) <= 2048
+    _full_compare(native_ctx, oracle, b, "run structures")
