@@ -47,7 +47,10 @@ class TaskSoa(C.Structure):
 class PlanInput(C.Structure):
     _fields_ = [("n_distros", C.c_int32), ("n_task_groups", C.c_int32), ("n_versions", C.c_int32),
                 ("max_distro_tasks", C.c_int32), ("tasks", TaskSoa), ("distros", _p), ("task_off", _p),
-                ("tg_off", _p), ("ver_off", _p), ("now_ns", C.c_int64)]
+                ("tg_off", _p), ("ver_off", _p), ("now_ns", C.c_int64), ("promises", C.c_int32), ("reserved0", C.c_int32)]
+
+
+EVG_PROMISE_ALL_ON_LDS_PATH = 1
 
 
 class PlanOutput(C.Structure):

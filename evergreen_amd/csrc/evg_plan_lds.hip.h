@@ -67,9 +67,9 @@ static_assert(X_IK + 4 * kN <= Y_POS, "the parked TaskGroupMaxHosts column ends 
 static_assert(kLdsLean + 512 <= 80 * 1024, "lean configuration: two workgroups per CU");
 static_assert(kLdsRich + 512 <= 160 * 1024, "rich configuration");
 static_assert(kS < 4096 && kN <= 2048, "slot ids are 12 bits, rows 11 bits");
-__device__ __forceinline__ int lds_pad_slots(int S) { return (S + 1) & ~1; }
-__device__ __forceinline__ int lds_pad_edges(int ne) { return (ne + 7) & ~7; }
-__device__ __forceinline__ bool lds_budget_ok(int S, int ne) {
+__host__ __device__ __forceinline__ int lds_pad_slots(int S) { return (S + 1) & ~1; }
+__host__ __device__ __forceinline__ int lds_pad_edges(int ne) { return (ne + 7) & ~7; }
+__host__ __device__ __forceinline__ bool lds_budget_ok(int S, int ne) {
   const int a = 32 * lds_pad_slots(S);
   return (a > Y_END ? a : Y_END) + 2 * lds_pad_edges(ne) <= B_PSLOT;
 }
@@ -203,9 +203,12 @@ __device__ __forceinline__ DC distro_context(const PlanArgs& a, int d) {
   const int lo = a.in.task_off[d];
   return distro_context(a, d, lo, a.in.task_off[d + 1] - lo);
 }
-__device__ __forceinline__ bool fits_lds_path(const DC& c) {
-  return c.n <= kN && c.S <= kS && c.ntg + 1 <= kG && c.ne >= 0 && lds_budget_ok(c.S, c.ne);
+// The structural part of "the LDS path can take this distro" (the other part is data: every |priority| below 2^31). Also
+// evaluated on the HOST by evg_plan_launch_hints (EVG_PROMISE_ALL_ON_LDS_PATH): one definition for both.
+__host__ __device__ __forceinline__ bool fits_lds_shape(int n, int S, int ntg, int ne) {
+  return n <= kN && S <= kS && ntg + 1 <= kG && ne >= 0 && lds_budget_ok(S, ne);
 }
+__device__ __forceinline__ bool fits_lds_path(const DC& c) { return fits_lds_shape(c.n, c.S, c.ntg, c.ne); }
 
 // The LDS path. Returns false (uniformly, before writing any output) when the distro must take the generic path.
 // s_red: 32 zeroed words of static LDS.

@@ -481,6 +481,22 @@ static evg_plan_input stage_plan_input(Stager& s, const evg_plan_input* in) {
   return di;
 }
 
+// D-way parallel loop over the distros on up to 8 threads (large batches only): f(d) -> false stops that thread's range.
+template <class F>
+static void for_distros_parallel(const evg_plan_input* in, F f) {
+  const int D = in->n_distros;
+  const int nt = in->tasks.n_tasks + in->tasks.n_edges < (1 << 18) ? 1 : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  auto work = [&](int w) {
+    for (int d = (int)((long long)D * w / nt), d1 = (int)((long long)D * (w + 1) / nt); d < d1; d++)
+      if (!f(d, w)) return;
+  };
+  if (nt == 1) { work(0); return; }
+  std::vector<std::thread> th;
+  for (int w = 1; w < nt; w++) th.emplace_back(work, w);
+  work(0);
+  for (auto& x : th) x.join();
+}
+
 extern "C" {
 
 int32_t evg_abi_version(void) { return (1 << 16) | 2; }
@@ -592,6 +608,19 @@ void evg_host_free(evg_ctx* c, void* p) {
   (void)hipHostFree(p);
 }
 
+// Can the one-workgroup kernel plan distro d (host pointers)? The kernel's own test (fits_lds_shape) + the priority range.
+static bool distro_on_lds_path(const evg_plan_input* in, int d) {
+  const evg_task_soa& t = in->tasks;
+  const int lo = in->task_off[d], hi = in->task_off[d + 1], n = hi - lo;
+  const int ntg = in->tg_off[d + 1] - in->tg_off[d], nver = in->ver_off[d + 1] - in->ver_off[d];
+  const int S = in->distros[d].group_versions ? ntg + nver : n + ntg;
+  const int ne = n > 0 ? t.dep_off[hi] - t.dep_off[lo] : 0;
+  if (n < 0 || !evg::fits_lds_shape(n, S, ntg, ne)) return false;
+  for (int r = lo; r < hi; r++)
+    if (t.priority[r] != (int64_t)(int32_t)t.priority[r]) return false;
+  return true;
+}
+
 // One distro's share of the layout contract; 0 or EVG_E_CONTRACT with the message in `err`.
 static int validate_distro(const evg_plan_input* in, int d, char* err, size_t err_len) {
   const evg_task_soa& t = in->tasks;
@@ -623,6 +652,26 @@ static int validate_distro(const evg_plan_input* in, int d, char* err, size_t er
   }
   if (next_tg != in->tg_off[d + 1]) return fail("distro %ld: tg keys do not fill [tg_off[d], tg_off[d+1]) (%ld)", d, next_tg);
   if (next_ver != in->ver_off[d + 1]) return fail("distro %ld: version keys do not fill their range (%ld)", d, next_ver);
+  return EVG_OK;
+}
+
+int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, int32_t* promises) {
+  if (!in || !max_distro_tasks || !promises) return EVG_E_INVALID;
+  *max_distro_tasks = 0;
+  *promises = 0;
+  const int D = in->n_distros;
+  if (D <= 0) return D == 0 ? EVG_OK : EVG_E_INVALID;
+  if (!in->task_off || !in->tg_off || !in->ver_off || !in->distros) return EVG_E_INVALID;
+  if (in->tasks.n_tasks > 0 && (!in->tasks.priority || !in->tasks.dep_off)) return EVG_E_INVALID;
+  for (int d = 0; d < D; d++) *max_distro_tasks = std::max(*max_distro_tasks, in->task_off[d + 1] - in->task_off[d]);
+  int off_path[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for_distros_parallel(in, [&](int d, int w) {
+    if (!distro_on_lds_path(in, d)) { off_path[w] = 1; return false; }
+    return true;
+  });
+  int any = 0;
+  for (int w = 0; w < 8; w++) any |= off_path[w];
+  if (!any) *promises |= EVG_PROMISE_ALL_ON_LDS_PATH;
   return EVG_OK;
 }
 
@@ -854,9 +903,12 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   else hipLaunchKernelGGL((k_plan_distros<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, a);
   HIP_TRY(c, hipGetLastError());
   if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_stop, st));
-  // distros the LDS path could not take (flagged on the device); the workgroups exit at once otherwise
-  rc = launch_generic(c, a, in, st);
-  if (rc) return rc;
+  // distros the LDS path could not take (flagged on the device); the workgroups exit at once otherwise. Not enqueued at all
+  // when the caller promises (evg_plan_launch_hints; the host-pointer entry points work it out themselves) that there are none.
+  if (!(in->promises & EVG_PROMISE_ALL_ON_LDS_PATH)) {
+    rc = launch_generic(c, a, in, st);
+    if (rc) return rc;
+  }
   return finish_breakdown(c, a, out, st, d_end < 0 || (d_begin == 0 && d_end == in->n_distros));
 }
 
@@ -927,8 +979,10 @@ int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_pla
   if (f.p.out.unit_breakdown || out->n_units) hipLaunchKernelGGL((k_plan_allocate<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, f);
   else hipLaunchKernelGGL((k_plan_allocate<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, f);
   HIP_TRY(c, hipGetLastError());
-  hipLaunchKernelGGL(k_plan_allocate_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), kGenericLds, st, f);
-  HIP_TRY(c, hipGetLastError());
+  if (!(in->promises & EVG_PROMISE_ALL_ON_LDS_PATH)) {
+    hipLaunchKernelGGL(k_plan_allocate_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), kGenericLds, st, f);
+    HIP_TRY(c, hipGetLastError());
+  }
   return finish_breakdown(c, f.p, out, st, true);
 }
 
@@ -1084,6 +1138,12 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
   char msg[256];
   int rc = evg_validate_plan_input(in, msg, sizeof msg);
   if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
+  {  // the caller's promises are ignored on this path: the batch is host memory, the library looks for itself
+    int32_t mx = 0, pr = 0;
+    rc = evg_plan_launch_hints(in, &mx, &pr);
+    if (rc) return set_err(c, rc, "invalid plan input");
+    di.promises = pr;
+  }
   evg_plan_output dout;
   dout.order = s.out<int32_t>(N, true);
   dout.breakdown = s.out<int64_t>(N * EVG_BREAKDOWN_FIELDS, out->breakdown != nullptr);

@@ -31,7 +31,7 @@ ALIGN = 256
 MAGIC = 0x45564750_4F4F4C31  # "EVGPOOL1"
 HEADER_WORDS = 32            # int64 words = 256 bytes
 # header words
-H_MAGIC, H_TOTAL, H_NOW, H_D, H_N, H_E, H_TG, H_VER, H_H, H_HAS_HOSTS, H_HAS_NAME, H_MAX_DISTRO = range(12)
+H_MAGIC, H_TOTAL, H_NOW, H_D, H_N, H_E, H_TG, H_VER, H_H, H_HAS_HOSTS, H_HAS_NAME, H_MAX_DISTRO, H_PROMISES = range(13)
 
 
 def balanced_ranges(task_off: Sequence[int], world: int) -> List[Tuple[int, int]]:
@@ -56,9 +56,10 @@ class PoolLayout:
     A pure function of the sizes in the header, so every rank derives the same offsets from the broadcast header."""
 
     def __init__(self, n_distros: int, n_tasks: int, n_edges: int, n_task_groups: int, n_versions: int, n_hosts: int,
-                 has_hosts: bool, has_name_key: bool, now_ns: int = 0, max_distro_tasks: int = 0):
+                 has_hosts: bool, has_name_key: bool, now_ns: int = 0, max_distro_tasks: int = 0, promises: int = 0):
         self.D, self.N, self.E, self.TG, self.V, self.H = n_distros, n_tasks, n_edges, n_task_groups, n_versions, n_hosts
         self.has_hosts, self.has_name_key, self.now_ns, self.max_distro_tasks = has_hosts, has_name_key, now_ns, max_distro_tasks
+        self.promises = promises  # evg_plan_launch_hints of the host batch on rank `src`: travels in the header
         D, N, E, H = self.D, self.N, self.E, self.H
         sec: List[Tuple[str, np.dtype, int]] = []
         for k, dt in abi.TASK_COLUMNS.items():
@@ -89,6 +90,7 @@ class PoolLayout:
         h[H_MAGIC], h[H_TOTAL], h[H_NOW] = MAGIC, self.total_bytes, self.now_ns
         h[H_D], h[H_N], h[H_E], h[H_TG], h[H_VER], h[H_H] = self.D, self.N, self.E, self.TG, self.V, self.H
         h[H_HAS_HOSTS], h[H_HAS_NAME], h[H_MAX_DISTRO] = int(self.has_hosts), int(self.has_name_key), self.max_distro_tasks
+        h[H_PROMISES] = self.promises
         return h
 
     @staticmethod
@@ -97,7 +99,7 @@ class PoolLayout:
         if int(h[H_MAGIC]) != MAGIC:
             raise ValueError("packed pool: bad magic %x" % int(h[H_MAGIC]))
         lay = PoolLayout(int(h[H_D]), int(h[H_N]), int(h[H_E]), int(h[H_TG]), int(h[H_VER]), int(h[H_H]), bool(h[H_HAS_HOSTS]),
-                         bool(h[H_HAS_NAME]), int(h[H_NOW]), int(h[H_MAX_DISTRO]))
+                         bool(h[H_HAS_NAME]), int(h[H_NOW]), int(h[H_MAX_DISTRO]), int(h[H_PROMISES]))
         if lay.total_bytes != int(h[H_TOTAL]):
             raise ValueError("packed pool: header sizes do not add up (%d vs %d bytes)" % (lay.total_bytes, int(h[H_TOTAL])))
         return lay
@@ -105,9 +107,10 @@ class PoolLayout:
 
 def pack_pool(batch: abi.PlanBatch) -> np.ndarray:
     """The batch as ONE host byte buffer in PoolLayout order (what a shim writes its columns into, pinned, once per tick)."""
+    from . import native
+    max_distro, promises = native.launch_hints(batch)  # host work: the launch hint and what the batch lets the library skip
     lay = PoolLayout(batch.n_distros, batch.n_tasks, batch.n_edges, batch.n_task_groups, batch.n_versions, batch.n_hosts,
-                     batch.alloc_params is not None, batch.tg_name_key is not None, batch.now_ns,
-                     int(np.diff(batch.task_off).max()) if batch.n_distros else 0)
+                     batch.alloc_params is not None, batch.tg_name_key is not None, batch.now_ns, max_distro, promises)
     buf = np.zeros(lay.total_bytes, np.uint8)
     buf[:HEADER_WORDS * 8] = lay.header().view(np.uint8)
     src: Dict[str, np.ndarray] = dict(batch.cols)
@@ -207,6 +210,7 @@ class ShardedPool:
         self.o_gi = z(G * abi.GROUP_INFO_DTYPE.itemsize, torch.uint8)
         meta = _Meta(lay, self.task_off)
         self.inp = abi.make_plan_input(meta, v)
+        self.inp.max_distro_tasks, self.inp.promises = lay.max_distro_tasks, lay.promises
         self.out = abi.PlanOutput()
         self.out.order, self.out.deps_met, self.out.wait_ns = self.o_order.data_ptr(), self.o_met.data_ptr(), self.o_wait.data_ptr()
         self.out.breakdown = None

@@ -23,7 +23,7 @@ EXPORTS = [
     "evg_allocator_report_device", "evg_filter_runnable_device", "evg_dispatch_order_device",
     "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
     "evg_plan_distro_range_device", "evg_allocate_host_range_device", "evg_selftest_unit_value",
-    "evg_host_alloc", "evg_host_free", "evg_profile_plan_kernel", "evg_last_plan_kernel_ms",
+    "evg_host_alloc", "evg_host_free", "evg_profile_plan_kernel", "evg_last_plan_kernel_ms", "evg_plan_launch_hints",
 ]
 
 _lib = None
@@ -83,6 +83,8 @@ def load_library() -> C.CDLL:
         lib.evg_host_alloc.restype = C.c_void_p
         lib.evg_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
         lib.evg_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    if hasattr(lib, "evg_plan_launch_hints"):
+        lib.evg_plan_launch_hints.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     if hasattr(lib, "evg_profile_plan_kernel"):
         lib.evg_profile_plan_kernel.argtypes = [C.c_void_p, C.c_int]
         lib.evg_last_plan_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -90,6 +92,20 @@ def load_library() -> C.CDLL:
         lib.evg_selftest_unit_value.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
+
+
+def launch_hints(batch: abi.PlanBatch):
+    """evg_plan_launch_hints on the HOST batch: (max_distro_tasks, promises) for the evg_plan_input of a *_device call. Host
+    work only (no context, no GPU); (0, 0) -- "unknown, nothing promised" -- from a build that does not export the call."""
+    lib = load_library()
+    if not hasattr(lib, "evg_plan_launch_hints"):
+        return 0, 0
+    inp = abi.make_plan_input(batch)
+    mx, pr = C.c_int32(0), C.c_int32(0)
+    rc = lib.evg_plan_launch_hints(C.byref(inp), C.byref(mx), C.byref(pr))
+    if rc != abi.EVG_OK:
+        raise NativeError("evg_plan_launch_hints failed (%d)" % rc)
+    return int(mx.value), int(pr.value)
 
 
 class Context:

@@ -33,6 +33,8 @@ class ResidentPool:
         self.n_slots = nslots
         self.o_ubd = z(max(nslots * abi.BREAKDOWN_FIELDS, 1), dt=torch.int64) if units else None
         self.inp = abi.make_plan_input(batch, self.t)
+        # what the host knows about the batch it uploaded: the launch hint and the promises (evg_plan_launch_hints)
+        self.inp.max_distro_tasks, self.inp.promises = native.launch_hints(batch)
         self.out = abi.PlanOutput()
         self.out.order, self.out.deps_met, self.out.wait_ns = self.o_order.data_ptr(), self.o_met.data_ptr(), self.o_wait.data_ptr()
         self.out.breakdown = self.o_bd.data_ptr() if breakdown else None

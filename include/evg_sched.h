@@ -170,7 +170,17 @@ typedef struct evg_plan_input {
   const int32_t* tg_off;              /* D+1 */
   const int32_t* ver_off;             /* D+1 */
   int64_t now_ns;
+  int32_t promises;                   /* EVG_PROMISE_* (ABI 1.2), 0 = none. Unlike the hint above a promise is part of the
+                                         contract: a false one gives a wrong plan. The host-pointer entry points work them
+                                         out themselves and ignore this field; a *_device caller takes them from
+                                         evg_plan_launch_hints on its host copy of the batch                          */
+  int32_t reserved0;
 } evg_plan_input;
+
+/* Every distro of the batch can be planned by the one-workgroup kernel: at most 2048 tasks, unit slots + dependency
+ * edges inside its LDS budget, at most 1023 task groups, every |priority| below 2^31. The library then does not enqueue the
+ * kernels that pick up what that kernel leaves (one empty launch, ~4.5 us of a ~70 us tick on BASELINE config 3). */
+#define EVG_PROMISE_ALL_ON_LDS_PATH 0x1
 
 /* ---- outputs -------------------------------------------------------------------------------- */
 
@@ -322,6 +332,10 @@ int32_t evg_abi_version(void);
 
 /* Host-side check of the layout contract; no GPU work. */
 int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len);
+
+/* Host side, no GPU work: the launch hint and the promises that hold for a batch whose pointers are HOST pointers -- what a
+ * *_device caller copies into the evg_plan_input it passes with device pointers (max_distro_tasks, promises). ABI 1.2. */
+int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, int32_t* promises);
 
 /* Device self-test of the planner's scoring arithmetic: runs unitInfo.value() (planner.go:209-300) over `n_cases`
  * generated inputs twice -- the kernels' fast exact form and a statement that follows the Go code step by step (IEEE fp64

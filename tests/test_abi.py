@@ -130,3 +130,27 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "libevg_oracle" not in text and "oracle_lib" not in text and "evg_oracle_" not in text, f
+
+
+def test_plan_launch_hints_on_host(lib):
+    """evg_plan_launch_hints: host work only. EVG_PROMISE_ALL_ON_LDS_PATH holds exactly when every distro passes the planner
+    kernel's own shape test (<= 2048 tasks, slots + edges inside the LDS budget, <= 1023 task groups) and no priority needs
+    more than 32 bits."""
+    def hints(b):
+        inp = abi.make_plan_input(b)
+        mx, pr = C.c_int32(-1), C.c_int32(-1)
+        assert lib.evg_plan_launch_hints(C.byref(inp), C.byref(mx), C.byref(pr)) == abi.EVG_OK
+        return mx.value, pr.value
+    b = gen.generate(gen.config(2))
+    assert hints(b) == (int(np.diff(b.task_off).max()), abi.EVG_PROMISE_ALL_ON_LDS_PATH)
+    b.cols["priority"][int(b.task_off[7]) + 5] = 2**31                       # one priority beyond int32: that distro leaves the path
+    assert hints(b)[1] == 0
+    b.cols["priority"][int(b.task_off[7]) + 5] = -(2**31)                    # the most negative int32 still fits
+    assert hints(b)[1] == abi.EVG_PROMISE_ALL_ON_LDS_PATH
+    big = gen.generate(gen.GenConfig(6000, 2, 5, with_hosts=False))          # 3000 tasks per distro: more than 2048
+    assert hints(big) == (3000, 0)
+    edges = gen.generate(gen.GenConfig(4000, 2, 6, dag_depth=8, with_hosts=False))
+    n_e = np.diff(edges.dep_off[edges.task_off])                             # 2000 tasks + many edges: the LDS budget decides
+    S = np.diff(edges.task_off) + np.diff(edges.tg_off)
+    fits = all(max(32 * ((s + 1) & ~1), 57344) + 2 * ((e + 7) & ~7) <= 79872 - 4096 for s, e in zip(S, n_e))
+    assert hints(edges)[1] == (abi.EVG_PROMISE_ALL_ON_LDS_PATH if fits else 0)

@@ -419,3 +419,31 @@ def test_run_structures_of_the_chunked_ranking(native_ctx, oracle):
     b = S.pack_queues(queues, NOW).batch
     assert int(np.diff(b.task_off).max()) <= 2048
     _full_compare(native_ctx, oracle, b, "run structures")
+
+
+def test_promise_all_on_lds_path(native_ctx, oracle):
+    """With EVG_PROMISE_ALL_ON_LDS_PATH (from evg_plan_launch_hints on the host batch) the device entry points do not enqueue the
+    kernels that pick up what the one-workgroup kernel leaves: same plan. Batches the hints make no promise for keep them."""
+    import torch
+    from evergreen_amd import native, resident
+    dev = torch.device("cuda:0")
+    for cfg, promised in ((gen.config(2), True), (gen.GenConfig(30_000, 6, 41, skew=True), False),
+                          (gen.GenConfig(9_000, 5, 42, dag_depth=9, tg_fraction=0.5), None)):
+        b = gen.generate(cfg)
+        mx, pr = native.launch_hints(b)
+        if promised is not None:
+            assert bool(pr & abi.EVG_PROMISE_ALL_ON_LDS_PATH) == promised, cfg
+        pool = resident.ResidentPool(native_ctx, b, dev, breakdown=True)
+        assert pool.inp.promises == pr and pool.inp.max_distro_tasks == mx
+        pool.plan()
+        want = oracle.plan(b, n_units=False)
+        want.n_units = None
+        compare.assert_plan_equal(pool.plan_result(), want, b, "promise %r" % (cfg,))
+        pool.step(fused=True)  # plan + allocate in one launch: the allocator writes CountFree / CountRequired into the group rows
+        want_alloc = oracle.allocate(b, want.distro_info, want.group_info)
+        compare.assert_plan_equal(pool.plan_result(), want, b, "promise, fused %r" % (cfg,))
+        compare.assert_alloc_equal(pool.alloc_result(), want_alloc, "promise, fused %r" % (cfg,))
+    # a batch with a 2^31 priority: the host-pointer path works the promise out itself and must not skip the fallback
+    b = gen.generate(gen.config(1))
+    b.cols["priority"][3] = 2**40
+    _full_compare(native_ctx, oracle, b, "wide priority", validity=False)
