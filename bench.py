@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--tasks", type=int, default=0, help="override the task count (parity/debug runs only)")
     ap.add_argument("--distros", type=int, default=0)
     ap.add_argument("--weak", action="store_true", help="round 1's mode: every rank plans its OWN pool, no collective (weak scaling)")
+    ap.add_argument("--two-calls", action="store_true", help="time plan and allocate as two calls even when the batch allows the single fused launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / skewed / config5_share / pipelined (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=3, help="also report the sustained rate with this many independent pools in flight "
@@ -233,7 +234,7 @@ def main():
     batch = gen.generate(cfg) if have_batch else None
     ctx = native.Context(local_rank)
     # One code path for every N: the packed pool buffer + range entry points (a range of all distros at N = 1 / --weak).
-    pool = multi.ShardedPool(ctx, dev, collective=not args.weak)
+    pool = multi.ShardedPool(ctx, dev, collective=not args.weak, fused=not args.two_calls)
     pool.setup(multi.pack_pool(batch) if have_batch else None)
 
     def barrier():
@@ -273,8 +274,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     for k in range(args.steps):
-        pool.plan()
-        pool.allocate()
+        pool.plan_allocate()
     barrier()
     elapsed_k = time.perf_counter() - t1
 
@@ -316,9 +316,14 @@ def main():
             "config": {"workload": workload + ", tunable planner + GetDistroQueueInfo + UtilizationBasedHostAllocator (%d hosts), SplitMix64 seed 0x%X" % (lay.H, cfg.seed),
                        "tasks": lay.N, "distros": lay.D, "dep_edges": lay.E, "task_groups": lay.TG, "hosts": lay.H, "parallelism": par,
                        "rank0_distro_range": [d0, d1]},
-            "timed_region": "`steps` ticks of broadcast -> plan -> allocate -> gather (the collectives are no-ops at 1 rank), wall clock between "
-                            "barrier + synchronize on both sides, max over ranks; the HIP-event figures below come from a second pass of the same "
-                            "ticks with events between the phases (an event record costs microseconds of stream time at these step lengths)",
+            "timed_region": "`steps` ticks of broadcast -> plan + allocate -> gather (the collectives are no-ops at 1 rank), wall clock between "
+                            "barrier + synchronize on both sides, max over ranks. " + (
+                                "Plan + allocate run as ONE launch (evg_plan_allocate_range_device: the allocator is the tail of each distro's planner "
+                                "workgroup, bit-identical to the two calls) because the batch promises EVG_PROMISE_ALL_ON_LDS_PATH; "
+                                if (pool.fused and pool.has_hosts and (pool.inp.promises & 1)) else "Plan and allocate are two calls; ") +
+                            "the HIP-event figures below (phases_ms, roofline) come from further passes that make the two calls separately, with events "
+                            "between them (an event record costs microseconds of stream time at these step lengths)",
+            "plan_allocate": "one launch" if (pool.fused and pool.has_hosts and (pool.inp.promises & 1)) else "two calls",
             "step_ms_hip_events_rank0": {"median": step_ev[0], "min": step_ev[1], "mean": step_ev[2]},
             "phases_ms": {"pool-broadcast": bc_ms[0], "planning-distro": plan_ms[0], "host-allocation": alloc_ms[0], "queue-gather": ga_ms[0],
                           "what": "rank 0, median over the timed steps' HIP events; planning-distro / host-allocation are the reference's phase names "

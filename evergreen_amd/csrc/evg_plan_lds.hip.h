@@ -1080,7 +1080,7 @@ template <bool RICH, bool BD>
 __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const FusedArgs f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
-  const int d = blockIdx.x;
+  const int d = f.p.d0 + blockIdx.x;
   const int lo = f.p.in.task_off[d], n = f.p.in.task_off[d + 1] - lo;
   if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
   __syncthreads();
@@ -1143,7 +1143,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_allocate_generic(const FusedArg
   __shared__ HostRec s_rec[kAllocLdsHosts];
   __shared__ int s_cnt[2 * kAllocLdsBuckets];
   const int tid = threadIdx.x;
-  for (int d = blockIdx.x; d < f.p.in.n_distros; d += gridDim.x) {
+  for (int d = f.p.d0 + blockIdx.x; d < f.p.d1; d += gridDim.x) {
   if (!f.p.w_generic[d]) continue;
   const DC c = distro_context(f.p, d);
   __syncthreads();

@@ -957,16 +957,22 @@ int evg_allocate_host_range_device(evg_ctx* c, const evg_alloc_input* in, const 
   return launch_alloc(c, in, out, (hipStream_t)hip_stream, d_begin, d_end);
 }
 
-int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const evg_alloc_input* ain,
-                             const evg_alloc_output* aout, void* hip_stream) {
+static int launch_plan_allocate(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const evg_alloc_input* ain,
+                                const evg_alloc_output* aout, hipStream_t st, int d_begin, int d_end) {
   using namespace evg;
-  if (!c || !in || !out || !ain || !aout) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
   if (ain->n_distros != in->n_distros || ain->n_task_groups != in->n_task_groups)
     return set_err(c, EVG_E_INVALID, "plan and allocator inputs describe different batches");
   FusedArgs f;
   int rc = prepare_plan(c, in, out, &f.p);
   if (rc || in->n_distros == 0) return rc;
+  if (d_end >= 0) {
+    if (d_begin < 0 || d_end < d_begin || d_end > in->n_distros) return set_err(c, EVG_E_INVALID, "distro range [%d, %d) outside [0, %d)", d_begin, d_end, in->n_distros);
+    if (out->breakdown && !(d_begin == 0 && d_end == in->n_distros))
+      return set_err(c, EVG_E_INVALID, "rows by task (breakdown) are not available from a distro-range entry point; ask for unit_of_task + unit_breakdown");
+    f.p.d0 = d_begin;
+    f.p.d1 = d_end;
+    if (d_begin == d_end) return EVG_OK;
+  }
   evg_alloc_input ai = *ain;
   ai.distro_info = out->distro_info;  // the allocator consumes what the planner of the same launch produced
   ai.group_info = out->group_info;
@@ -974,8 +980,8 @@ int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_pla
   ai.now_ns = in->now_ns;
   rc = prepare_alloc(c, &ai, aout, &f.q);
   if (rc) return rc;
-  const int D = in->n_distros;
-  hipStream_t st = (hipStream_t)hip_stream;
+  f.q.d0 = f.p.d0;
+  const int D = f.p.d1 - f.p.d0;
   if (f.p.out.unit_breakdown || out->n_units) hipLaunchKernelGGL((k_plan_allocate<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, f);
   else hipLaunchKernelGGL((k_plan_allocate<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, f);
   HIP_TRY(c, hipGetLastError());
@@ -984,6 +990,20 @@ int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_pla
     HIP_TRY(c, hipGetLastError());
   }
   return finish_breakdown(c, f.p, out, st, true);
+}
+
+int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const evg_alloc_input* ain,
+                             const evg_alloc_output* aout, void* hip_stream) {
+  if (!c || !in || !out || !ain || !aout) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return launch_plan_allocate(c, in, out, ain, aout, (hipStream_t)hip_stream, 0, -1);
+}
+
+int evg_plan_allocate_range_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const evg_alloc_input* ain,
+                                   const evg_alloc_output* aout, int32_t d_begin, int32_t d_end, void* hip_stream) {
+  if (!c || !in || !out || !ain || !aout || d_end < 0) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return launch_plan_allocate(c, in, out, ain, aout, (hipStream_t)hip_stream, d_begin, d_end);
 }
 
 int evg_cap_queue_device(evg_ctx* c, int32_t n_distros, const int32_t* task_off, const int32_t* order,

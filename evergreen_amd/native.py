@@ -24,6 +24,7 @@ EXPORTS = [
     "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
     "evg_plan_distro_range_device", "evg_allocate_host_range_device", "evg_selftest_unit_value",
     "evg_host_alloc", "evg_host_free", "evg_profile_plan_kernel", "evg_last_plan_kernel_ms", "evg_plan_launch_hints",
+    "evg_plan_allocate_range_device",
 ]
 
 _lib = None
@@ -83,6 +84,9 @@ def load_library() -> C.CDLL:
         lib.evg_host_alloc.restype = C.c_void_p
         lib.evg_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
         lib.evg_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    if hasattr(lib, "evg_plan_allocate_range_device"):
+        lib.evg_plan_allocate_range_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.POINTER(abi.AllocInput),
+                                                       C.POINTER(abi.AllocOutput), C.c_int32, C.c_int32, C.c_void_p]
     if hasattr(lib, "evg_plan_launch_hints"):
         lib.evg_plan_launch_hints.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     if hasattr(lib, "evg_profile_plan_kernel"):
@@ -261,6 +265,13 @@ class Context:
         """Distros [d_begin, d_end) of a batch that is resident as a whole (the multi-GPU shard of one rank)."""
         self._check(self.lib.evg_plan_distro_range_device(self.h, C.byref(inp), C.byref(out), d_begin, d_end, stream),
                     "evg_plan_distro_range_device")
+
+    def plan_allocate_range_device(self, inp: abi.PlanInput, out: abi.PlanOutput, ainp: abi.AllocInput, aout: abi.AllocOutput,
+                                   d_begin: int, d_end: int, stream: Optional[int] = None) -> None:
+        """Plan + host allocation of distros [d_begin, d_end) in ONE launch (the allocator runs as the tail of each distro's
+        planner workgroup)."""
+        self._check(self.lib.evg_plan_allocate_range_device(self.h, C.byref(inp), C.byref(out), C.byref(ainp), C.byref(aout), d_begin, d_end, stream),
+                    "evg_plan_allocate_range_device")
 
     def allocate_range_device(self, inp: abi.AllocInput, out: abi.AllocOutput, d_begin: int, d_end: int, stream: Optional[int] = None) -> None:
         self._check(self.lib.evg_allocate_host_range_device(self.h, C.byref(inp), C.byref(out), d_begin, d_end, stream),

@@ -388,6 +388,10 @@ int evg_allocate_host_range_device(evg_ctx* ctx, const evg_alloc_input* in, cons
  * Results are identical to the two separate calls. Device pointers; enqueued on hip_stream. */
 int evg_plan_allocate_device(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out,
                              const evg_alloc_input* ain, const evg_alloc_output* aout, void* hip_stream);
+/* The same for distros [d_begin, d_end) of a batch that is resident as a whole (see evg_plan_distro_range_device). ABI 1.2. */
+int evg_plan_allocate_range_device(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out,
+                                   const evg_alloc_input* alloc_in, const evg_alloc_output* alloc_out, int32_t d_begin,
+                                   int32_t d_end, void* hip_stream);
 
 /* capTaskQueueLength (scheduler/task_queue_persister.go:66-83) for all D distros: cut[d] = number of
  * leading queue positions of distro d to persist for limit max_scheduled (<= 0 disables). The
