@@ -195,7 +195,9 @@ def main():
     ap.add_argument("--tasks", type=int, default=0, help="override the task count (parity/debug runs only)")
     ap.add_argument("--distros", type=int, default=0)
     ap.add_argument("--weak", action="store_true", help="round 1's mode: every rank plans its OWN pool, no collective (weak scaling)")
-    ap.add_argument("--two-calls", action="store_true", help="time plan and allocate as two calls even when the batch allows the single fused launch")
+    ap.add_argument("--one-launch", action="store_true", help="the timed tick runs plan + allocate as ONE launch when the batch allows it "
+                    "(evg_plan_allocate_range_device); by default they are the reference's two jobs = two calls, and the one-launch tick is "
+                    "reported next to it as `one_launch`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / skewed / config5_share / pipelined (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=3, help="also report the sustained rate with this many independent pools in flight "
@@ -234,7 +236,7 @@ def main():
     batch = gen.generate(cfg) if have_batch else None
     ctx = native.Context(local_rank)
     # One code path for every N: the packed pool buffer + range entry points (a range of all distros at N = 1 / --weak).
-    pool = multi.ShardedPool(ctx, dev, collective=not args.weak, fused=not args.two_calls)
+    pool = multi.ShardedPool(ctx, dev, collective=not args.weak, fused=args.one_launch)
     pool.setup(multi.pack_pool(batch) if have_batch else None)
 
     def barrier():
@@ -337,31 +339,45 @@ def main():
             abytes, e_in = algorithmic_bytes(batch, int(full.n_units[d0:d1].sum()), d0, d1)
             # the dominant kernel alone: HIP events recorded by the library right before / after k_plan_distros on the stream
             # it is launched on (evg_profile_plan_kernel), one plan call at a time, median over the steps
+            one_launch = bool(pool.fused and pool.has_hosts and (pool.inp.promises & 1))
             ctx.profile_plan_kernel(True)
-            kms = []
-            for _ in range(max(args.steps, 20)):
-                pool.plan()
-                kms.append(ctx.last_plan_kernel_ms())
+
+            def kernel_events(call):
+                ks = []
+                for _ in range(max(args.steps, 20)):
+                    call()
+                    ks.append(ctx.last_plan_kernel_ms())
+                ks.sort()
+                return ks
+            kms_plan = kernel_events(pool.plan)            # k_plan_distros: the planner alone
+            kms = kernel_events(pool.plan_allocate) if one_launch else kms_plan  # the kernel of the timed tick
             ctx.profile_plan_kernel(False)
-            kms.sort()
             kernel_ms = kms[len(kms) // 2]
+            planner_bytes = abytes
+            if one_launch:  # planner + the allocator as its tail: SURVEY 8(d) adds 29 B per host for the allocator
+                h0, h1 = int(batch.host_off[d0]), int(batch.host_off[d1])
+                abytes += 29 * (h1 - h0)
             achieved = abytes / (kernel_ms * 1e-3) / 1e9
             traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc) and world == 1:
                 try:
                     j = json.load(open(pmc))
-                    traffic = j.get("k_plan_distros_hbm_bytes_per_launch")
+                    traffic = j.get("k_plan_allocate_hbm_bytes_per_launch" if one_launch else "k_plan_distros_hbm_bytes_per_launch")
                     traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this workload, NOT measured in this run)" % j.get("source", "pmc_latest.json")
                 except Exception:
                     traffic = None
-            line["roofline"] = {"bound": "hbm", "kernel": "k_plan_distros", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            line["roofline"] = {"bound": "hbm", "kernel": "k_plan_allocate (the planner with the host allocator as the tail of each workgroup)" if one_launch else "k_plan_distros",
+                                "achieved": achieved, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                 "algorithmic_bytes_per_launch": abytes, "kernel_ms": kernel_ms, "kernel_ms_min": kms[0], "kernel_ms_mean": sum(kms) / len(kms),
+                                "planner_alone": {"kernel": "k_plan_distros", "kernel_ms": kms_plan[len(kms_plan) // 2], "algorithmic_bytes_per_launch": planner_bytes,
+                                                  "achieved": planner_bytes / (kms_plan[len(kms_plan) // 2] * 1e-3) / 1e9,
+                                                  "frac": planner_bytes / (kms_plan[len(kms_plan) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                                 "plan_entry_point_ms": plan_ms[0], "allocator_ms": alloc_ms[0],
-                                "kernel_ms_scope": "median HIP-event interval around k_plan_distros alone, events recorded by the library on the launch stream "
-                                                   "(evg_profile_plan_kernel); plan_entry_point_ms = the interval around the whole plan call in the timed "
-                                                   "steps (k_plan_distros + the empty large-distro check behind it)",
+                                "kernel_ms_scope": "median HIP-event interval around the dominant kernel of the timed tick alone, events recorded by the library on "
+                                                   "the launch stream (evg_profile_plan_kernel), one call at a time; plan_entry_point_ms / allocator_ms = the intervals "
+                                                   "around the two separate calls in the phases pass",
                                 "bytes_per_task": abytes / max(int(batch.task_off[d1] - batch.task_off[d0]), 1)}
             got, got_alloc = pool.plan_result(), pool.alloc_result()
         except Exception as e:
@@ -444,6 +460,29 @@ def main():
                                                             "BASELINE config 5's per-GPU share: 10M tasks x 512 distros over 8 GPUs = 1.25M tasks x 64 "
                                                             "distros of ~19.5k tasks, DAG depth 8, 20% task-group tasks (large-distro path)",
                                                             dev, native, resident, torch, gen, np))
+            def one_launch():
+                # the same tick with plan + allocate as ONE launch (the allocator as the tail of each distro's planner workgroup)
+                if not (pool.has_hosts and (pool.inp.promises & 1)):
+                    return {"skipped": "the batch does not promise EVG_PROMISE_ALL_ON_LDS_PATH"}
+                was = pool.fused
+                pool.fused = True
+                try:
+                    for _ in range(5):
+                        pool.tick()
+                    barrier()
+                    t = time.perf_counter()
+                    for _ in range(args.steps):
+                        pool.tick()
+                    barrier()
+                    dt = (time.perf_counter() - t) / args.steps
+                    r1, a1 = pool.plan_result(), pool.alloc_result()
+                finally:
+                    pool.fused = was
+                same = bool(np.array_equal(r1.order, got.order) and np.array_equal(r1.distro_info, got.distro_info) and np.array_equal(r1.wait_ns, got.wait_ns) and
+                            np.array_equal(a1.new_hosts, got_alloc.new_hosts) and np.array_equal(a1.free_hosts, got_alloc.free_hosts))
+                return {"value": batch.n_tasks / dt, "unit": "tasks/s", "ms_per_step": dt * 1e3, "identical_to_two_calls": same,
+                        "what": "the timed tick with evg_plan_allocate_range_device instead of the two calls (bench.py --one-launch makes it the headline tick)"}
+            guarded("one_launch", one_launch)
             if args.in_flight > 1:
                 guarded("pipelined", lambda: pipelined_rate(batch, dev, args.in_flight, min(args.steps, 60), native, resident, torch))
         print(json.dumps(line), flush=True)

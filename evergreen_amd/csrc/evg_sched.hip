@@ -982,9 +982,11 @@ static int launch_plan_allocate(evg_ctx* c, const evg_plan_input* in, const evg_
   if (rc) return rc;
   f.q.d0 = f.p.d0;
   const int D = f.p.d1 - f.p.d0;
+  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st));
   if (f.p.out.unit_breakdown || out->n_units) hipLaunchKernelGGL((k_plan_allocate<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, f);
   else hipLaunchKernelGGL((k_plan_allocate<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, f);
   HIP_TRY(c, hipGetLastError());
+  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_stop, st));
   if (!(in->promises & EVG_PROMISE_ALL_ON_LDS_PATH)) {
     hipLaunchKernelGGL(k_plan_allocate_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), kGenericLds, st, f);
     HIP_TRY(c, hipGetLastError());

@@ -318,7 +318,7 @@ void* evg_host_alloc(evg_ctx* ctx, size_t bytes);
 void evg_host_free(evg_ctx* ctx, void* p);
 
 /* Measurement hook (ABI 1.2): when enabled, every plan call on `ctx` records a HIP event right before and right after the
- * planner kernel (k_plan_distros) on the stream it is launched on; evg_last_plan_kernel_ms waits for the last call's stop
+ * planner kernel (k_plan_distros; k_plan_allocate for the fused entry points) on the stream it is launched on; evg_last_plan_kernel_ms waits for the last call's stop
  * event and returns the interval -- that kernel alone, without the large-distro kernels enqueued behind it. bench.py's
  * roofline block is measured with it. */
 int evg_profile_plan_kernel(evg_ctx* ctx, int enable);
