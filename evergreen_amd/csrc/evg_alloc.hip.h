@@ -71,6 +71,7 @@ struct HostStage {
   // the per-bucket counts are not. Nearly every bucket has no host at all, so a 2048-bit filter (bit = bucket mod 2048,
   // set while staging) tells a bucket's thread whether it has to walk the records; a false positive costs one walk.
   uint32_t* filter = nullptr;  // [kAllocFilterBits / 32], zeroed; non-null <=> staged without counters
+  int* cnt32 = nullptr;        // 32 words of scratch for the compaction of the records before the ordered sums; null: no compaction
 };
 __device__ __forceinline__ void stage_host(const HostStage& s, const AllocArgs& a, int h0, int i, uint32_t f, int32_t key, double term,
                                            int tg_lo, int ntg) {
@@ -115,6 +116,43 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
   }
 
   ALLOC_STAMP(2);
+  // The ordered fp64 sums below walk the host records one after the other (the order of the sum is the canonical one); a host
+  // whose term is +0.0 -- free, not running a found task, overrun, nothing left inside the target time -- leaves every
+  // partial sum unchanged bit for bit, so the walk only needs the others: stable compaction of the records in place
+  // (every thread holds its records, barrier, writes them to their ranks). The launch lasts as long as its slowest
+  // workgroup, and that is the distro with the longest walk. s_i[6..7]: scratch words of the caller (zero).
+  int n_walk = nh;
+  if (staged && !hs.filter && hs.cnt32) {
+    constexpr int kTrips = (kAllocLdsHosts + kAllocBlock - 1) / kAllocBlock, kWaves = kAllocBlock / 64;  // kTrips * kWaves == 32
+    static_assert(kTrips * kWaves <= 32, "hs.cnt32 holds one count per (trip, wave)");
+    HostRec mine[kTrips];
+    int pre[kTrips];
+#pragma unroll
+    for (int k = 0; k < kTrips; k++) {
+      const int i = k * kAllocBlock + tid;
+      mine[k] = i < nh ? hs.rec[i] : HostRec{0.0, 0, 0u};
+      // rank of a kept record = kept records with a smaller host index: the hosts of trip k come before those of trip k + 1,
+      // and inside a trip the threads are in host order -> a ballot prefix inside the wave + the (trip, wave) counts
+      const unsigned long long b = __ballot(mine[k].term != 0.0);
+      pre[k] = __popcll(b & ((1ull << lane) - 1ull));
+      if (lane == 0) hs.cnt32[k * kWaves + (tid >> 6)] = __popcll(b);
+    }
+    __syncthreads();  // every record is in a register, every count is written
+    int before = 0;
+#pragma unroll
+    for (int k = 0; k < kTrips; k++) {
+      int mine_at = before;
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) {
+        const int c2 = hs.cnt32[k * kWaves + w];
+        mine_at += w < (tid >> 6) ? c2 : 0;
+        before += c2;
+      }
+      if (mine[k].term != 0.0) hs.rec[mine_at + pre[k]] = mine[k];
+    }
+    n_walk = before;
+    __syncthreads();
+  }
   // per bucket: evalHostUtilization (:134-205)
   const bool ephemeral = p.provider != 0;
   int r_new = 0, r_free = 0, r_err = -1;  // results of this thread's first bucket (b == tid) stay in registers
@@ -142,14 +180,14 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
       n_free_b = hs.n_free[b];
       if (n_hosts_b > 0) {
         int i = 0;
-        for (; i + 4 <= nh; i += 4) {
+        for (; i + 4 <= n_walk; i += 4) {
           HostRec r[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) r[k] = hs.rec[i + k];
 #pragma unroll
           for (int k = 0; k < 4; k++) soon += r[k].key == want_key ? r[k].term : 0.0;
         }
-        for (; i < nh; i++) { const HostRec r = hs.rec[i]; soon += r.key == want_key ? r.term : 0.0; }
+        for (; i < n_walk; i++) { const HostRec r = hs.rec[i]; soon += r.key == want_key ? r.term : 0.0; }
       }
     } else {
       for (int i = 0; i < nh; i++) {

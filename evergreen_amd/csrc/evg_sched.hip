@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(BLOCK) k_allocate_hosts(const AllocArgs a) {
   __shared__ HostRec s_rec[kAllocLdsHosts];
   __shared__ int s_cnt[2 * kAllocLdsBuckets];
   __shared__ uint32_t s_filter[kAllocFilterBits / 32];
+  __shared__ int s_cnt32[32];
   const int d = a.d0 + blockIdx.x, tid = threadIdx.x;
   const evg_alloc_params p = a.in.params[d];
   const evg_host_soa& h = a.in.hosts;
@@ -48,6 +49,7 @@ __global__ void __launch_bounds__(BLOCK) k_allocate_hosts(const AllocArgs a) {
   // free hosts of the distro (:33-37) and every running host's fractional-free term (:340-368); the host columns
   // the bucket loop re-reads are staged in LDS when they fit
   HostStage hs{s_rec, s_cnt, s_cnt + kAllocLdsBuckets, nh <= kAllocLdsHosts};
+  hs.cnt32 = s_cnt32;
   if (hs.staged && ntg + 1 > kAllocLdsBuckets) {
     hs.filter = s_filter;
     if (tid < kAllocFilterBits / 32) s_filter[tid] = 0;
