@@ -3,7 +3,7 @@
 # Build here (no GPU needed):  scripts/ablate.sh build     Run on the GPU box:  scripts/ablate.sh run
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/evergreen_amd/csrc
-KS="1 2 3 5 7 8 9 10"
+KS="1 2 3 4 5 7 8 9 10"
 if [ "$1" = build ]; then
   for k in $KS; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -amdgpu-atomic-optimizer-strategy=None \
