@@ -57,7 +57,9 @@ constexpr int R_HASH = kLdsLean, kLdsRich = R_HASH + 8 * kS;
 // region A re-used after D:
 constexpr int X_BUF0 = 0, X_BUF1 = 8 * kN, X_IK = 16 * kN, X_IK_END = X_IK + 8 * kN;  // sort exchange, in-unit keys by task
 constexpr int Y_SIK = 0, Y_SSLOT = 8 * kN, Y_SIDX = Y_SSLOT + 2 * kN;                  // by sorted position
-constexpr int Y_SCAN = Y_SIDX + 2 * kN, Y_REN = Y_SCAN + 4 * kBlock + 64;             // run-start scan (+ 8 wave totals), run end by run start
+constexpr int Y_SCAN = Y_SIDX + 2 * kN, Y_REN = Y_SCAN + 2048 + 64;                   // run-start scan (2048 B) + a total per wave, run end by run start
+template <int E> struct ScanWord { typedef int32_t type; };                            // 512 threads x int32
+template <> struct ScanWord<2> { typedef int16_t type; };                              // 1024 threads x int16
 static_assert(Y_REN + 2 * kN <= X_IK, "run bookkeeping must not overlap the in-unit keys by task");
 constexpr int Y_POS = X_IK_END, Y_FIDX = Y_POS + 2 * kN, Y_END = Y_FIDX + 2 * kN;      // final position by task / task by position
 constexpr int Z_G = 0;                                                                 // group accumulators (28 B per row)
@@ -90,32 +92,32 @@ __device__ __forceinline__ uint32_t pack_edge(int j, int n, uint32_t info) {
   return (unsigned)j < (unsigned)n ? ((info & EVG_DEP_REQ_MASK) << 11) | (uint32_t)j : ED_OUT | (info & 0x3Fu);
 }
 
-// ---- 4-wide column loads: one 16 B (8 B for 16-bit columns) access per lane when the 4 rows exist ------
-template <class T>
-struct __attribute__((packed, aligned(sizeof(T)))) Vec4 {
-  T v[4];
+// ---- E-wide column loads (E = tasks per thread: 4 or 2): one 16 B access per lane for a 32-bit column of 4 rows ---------
+template <class T, int E>
+struct __attribute__((packed, aligned(sizeof(T)))) VecN {
+  T v[E];
 };
-template <class T>
-__device__ __forceinline__ void load4(const T* __restrict__ p, int i0, int n, T fill, T (&out)[4]) {
-  if (i0 + 3 < n) {
-    const Vec4<T> x = *reinterpret_cast<const Vec4<T>*>(p + i0);
+template <class T, int E>
+__device__ __forceinline__ void loadv(const T* __restrict__ p, int i0, int n, T fill, T (&out)[E]) {
+  if (i0 + E - 1 < n) {
+    const VecN<T, E> x = *reinterpret_cast<const VecN<T, E>*>(p + i0);
 #pragma unroll
-    for (int e = 0; e < 4; e++) out[e] = x.v[e];
+    for (int e = 0; e < E; e++) out[e] = x.v[e];
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; e++) out[e] = i0 + e < n ? p[i0 + e] : fill;
+    for (int e = 0; e < E; e++) out[e] = i0 + e < n ? p[i0 + e] : fill;
   }
 }
-template <class T>
-__device__ __forceinline__ void store4(T* __restrict__ p, int i0, int n, const T (&v)[4]) {
-  if (i0 + 3 < n) {
-    Vec4<T> x;
+template <class T, int E>
+__device__ __forceinline__ void storev(T* __restrict__ p, int i0, int n, const T (&v)[E]) {
+  if (i0 + E - 1 < n) {
+    VecN<T, E> x;
 #pragma unroll
-    for (int e = 0; e < 4; e++) x.v[e] = v[e];
-    *reinterpret_cast<Vec4<T>*>(p + i0) = x;
+    for (int e = 0; e < E; e++) x.v[e] = v[e];
+    *reinterpret_cast<VecN<T, E>*>(p + i0) = x;
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; e++)
+    for (int e = 0; e < E; e++)
       if (i0 + e < n) p[i0 + e] = v[e];
   }
 }
@@ -215,31 +217,32 @@ __device__ __forceinline__ bool fits_lds_path(const DC& c) { return fits_lds_sha
 // FUSED: the distro's UtilizationBasedHostAllocator pass (q) runs as the tail of the same workgroup: its host rows are
 // fetched before the sort, so their latency hides behind the planner's compute, and the queue info it consumes never
 // leaves the CU.
-template <bool RICH, bool FUSED, bool BD>
+template <bool RICH, bool FUSED, bool BD, int E = kE>
 __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocArgs& q, const int d, const int lo, const int n,
                                                 unsigned char* smem, unsigned* s_red) {
   const evg_task_soa& t = a.in.tasks;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int i0 = tid * kE;
+  constexpr int BLK = kN / E;  // threads of the workgroup: E tasks each
+  const int i0 = tid * E;
 
   EVG_PRIO(0);
   // ---- A: load ------------------------------------------------------------------------------------------
   // The column loads need the distro's first row and its row count only, so they are issued FIRST: the rest of the
   // per-distro context (task-group / version ranges, planner flags, the edge range -- a chain of dependent scalar loads,
   // the last of which misses to HBM) resolves while they are in flight, and the does-it-fit decision comes after.
-  int32_t tgk[4], verk[4], nd[4], tgo[4];
-  uint16_t fl[4];
-  int64_t pri[4], dur[4], qts[4];
-  int32_t o4[4];
-  load4(t.tg_key + lo, i0, n, (int32_t)-1, tgk);
-  load4(t.version_key + lo, i0, n, (int32_t)0, verk);
-  load4(t.flags + lo, i0, n, (uint16_t)0, fl);
-  load4(t.priority + lo, i0, n, (int64_t)0, pri);
-  load4(t.expected_duration_ns + lo, i0, n, (int64_t)0, dur);
-  load4(t.queue_ts_ns + lo, i0, n, (int64_t)EVG_TIME_GO_ZERO, qts);
-  load4(t.num_dependents + lo, i0, n, (int32_t)0, nd);
-  load4(t.task_group_order + lo, i0, n, (int32_t)0, tgo);
-  load4(t.dep_off + lo, i0, n, (int32_t)0, o4);
+  int32_t tgk[E], verk[E], nd[E], tgo[E];
+  uint16_t fl[E];
+  int64_t pri[E], dur[E], qts[E];
+  int32_t o4[E];
+  loadv(t.tg_key + lo, i0, n, (int32_t)-1, tgk);
+  loadv(t.version_key + lo, i0, n, (int32_t)0, verk);
+  loadv(t.flags + lo, i0, n, (uint16_t)0, fl);
+  loadv(t.priority + lo, i0, n, (int64_t)0, pri);
+  loadv(t.expected_duration_ns + lo, i0, n, (int64_t)0, dur);
+  loadv(t.queue_ts_ns + lo, i0, n, (int64_t)EVG_TIME_GO_ZERO, qts);
+  loadv(t.num_dependents + lo, i0, n, (int32_t)0, nd);
+  loadv(t.task_group_order + lo, i0, n, (int32_t)0, tgo);
+  loadv(t.dep_off + lo, i0, n, (int32_t)0, o4);
   const DC c = distro_context(a, d, lo, n);
   if (!fits_lds_path(c)) return false;  // uniform; nothing has been written
   const int S = c.S;
@@ -257,12 +260,12 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   unsigned long long* s_rng = (unsigned long long*)(s_red + 16);  // 0 vmin 1 vmax 2 durmin 3 durmax (biased)
   uint32_t* s_r32 = s_red + 24;                                   // 0 tgomin 1 tgomax 2 ndmin 3 ndmax 4 primin 5 primax
 
-  int doff[5];  // local edge offsets of the thread's rows; rows past n get empty ranges
+  int doff[E + 1];  // local edge offsets of the thread's rows; rows past n get empty ranges
   {
-    const int last = i0 + 3 < n ? t.dep_off[lo + i0 + 4] - c.eb : c.ne;
+    const int last = i0 + E - 1 < n ? t.dep_off[lo + i0 + E] - c.eb : c.ne;
 #pragma unroll
-    for (int e = 0; e < 4; e++) doff[e] = i0 + e < n ? o4[e] - c.eb : last;
-    doff[4] = last;
+    for (int e = 0; e < E; e++) doff[e] = i0 + e < n ? o4[e] - c.eb : last;
+    doff[E] = last;
   }
   // FUSED: the distro's host rows are fetched with the task columns, reduced to what does not depend on the target
   // time ({time left, bucket key, flags}) and parked in the LDS bytes between the unit accumulators / re-use area and
@@ -280,7 +283,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     fnh = q.in.host_off[d + 1] - fh0;
     fpre = park_off + 16 * fnh <= (int)((unsigned char*)m.edge - smem);
     if (fpre)
-      for (int i = tid; i < fnh; i += kBlock) {
+      for (int i = tid; i < fnh; i += BLK) {
         const uint32_t f = q.in.hosts.flags[fh0 + i];
         const HostLeft hl = host_left(c.now, f, q.in.hosts.start_ts_ns[fh0 + i], q.in.hosts.expected_duration_ns[fh0 + i],
                                       q.in.hosts.duration_stddev_ns[fh0 + i]);
@@ -289,23 +292,23 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   }
   bool wide_pri = false;
 #pragma unroll
-  for (int e = 0; e < 4; e++) wide_pri |= pri[e] != (int64_t)(int32_t)pri[e];
+  for (int e = 0; e < E; e++) wide_pri |= pri[e] != (int64_t)(int32_t)pri[e];
   if (__syncthreads_or(wide_pri ? 1 : 0)) return false;  // int32 priority accumulators would not be exact
 
   // Unit.info contribution of each row (planner.go:302-337)
-  int64_t tiq[4];
-  uint32_t uf[4];
+  int64_t tiq[E];
+  uint32_t uf[E];
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     const uint32_t f = fl[e];
     tiq[e] = qts[e] == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, qts[e]);
     const uint32_t rc = f & EVG_TF_REQ_MASK;
     uf[e] = (rc == EVG_TF_REQ_MERGE ? UF_MERGE : rc == EVG_TF_REQ_PATCH ? UF_PATCH : 0u) | (tgk[e] < 0 ? UF_NONGROUP : 0u) |
             ((f & EVG_TF_GENERATE) ? UF_GENERATE : 0u) | ((f & EVG_TF_STEPBACK) ? UF_STEPBACK : 0u);
   }
-  int ps[4];  // primary unit slot
+  int ps[E];  // primary unit slot
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     const int i = i0 + e;
     ps[e] = tgk[e] >= 0 ? c.tg_base + (tgk[e] - c.tg_lo) : c.gv ? c.ver_base + (verk[e] - c.ver_lo) : i;
     if (i < n) {
@@ -324,8 +327,8 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       }
     }
   }
-  for (int x = tid; x < c.ne; x += kBlock) m.edge[x] = (uint16_t)pack_edge(t.dep_idx[c.eb + x] - lo, n, t.dep_info[c.eb + x]);
-  for (int u = (c.gv ? 0 : n) + tid; u < S; u += kBlock) {
+  for (int x = tid; x < c.ne; x += BLK) m.edge[x] = (uint16_t)pack_edge(t.dep_idx[c.eb + x] - lo, n, t.dep_info[c.eb + x]);
+  for (int u = (c.gv ? 0 : n) + tid; u < S; u += BLK) {
     m.tiq[u] = 0; m.dur[u] = 0; m.maxpri[u] = 0; m.cnt[u] = 0; m.maxnd[u] = 0; m.minrow[u] = 0xFFFFFFFFu;
   }
   if (tid < 4) s_rng[tid] = (tid & 1) ? 0ull : ~0ull;
@@ -335,9 +338,9 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
 
   // ---- B: resolve the edge records; segmented reduce of Unit.info (planner.go:302-337) -------------------------
   const int n_own = c.gv ? 0 : n;  // slots below n_own were initialised by their owner (NONGROUP | DISTRO, min row = slot)
-  int tv[4];                       // version unit of a task-group row when versions are grouped, else -1
+  int tv[E];                       // version unit of a task-group row when versions are grouped, else -1
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     EVG_PRIO4(1, e);
     const int i = i0 + e;
     tv[e] = c.gv && tgk[e] >= 0 ? c.ver_base + (verk[e] - c.ver_lo) : -1;
@@ -417,7 +420,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   }
   const size_t ubd_stride = BD ? (size_t)EVG_LATE_ARG(int32_t, in.tasks.n_tasks, late0) + (size_t)EVG_LATE_ARG(int32_t, in.n_task_groups, late0) +
                                      (size_t)EVG_LATE_ARG(int32_t, in.n_versions, late0) : 1;
-  for (int u = tid; u < S; u += kBlock) {
+  for (int u = tid; u < S; u += BLK) {
     const uint32_t cw = m.cnt[u];
     const int64_t nu = cw & UF_COUNT_MASK;
     int64_t v = INT64_MIN;
@@ -434,10 +437,10 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // unit's duplicates are among the units of that one task.
   if (RICH && a.out.n_units) {
     uint64_t* hash = (uint64_t*)(smem + R_HASH);
-    for (int u = tid; u < S; u += kBlock) hash[u] = 0;
+    for (int u = tid; u < S; u += BLK) hash[u] = 0;
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
+    for (int e = 0; e < E; e++) {
       const int i = i0 + e;
       if (i >= n) continue;
       const uint64_t h = mix64((uint64_t)i);
@@ -445,7 +448,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     }
     __syncthreads();
     uint32_t mine = 0;
-    for (int u = tid; u < S; u += kBlock) {
+    for (int u = tid; u < S; u += BLK) {
       if (m.val[u] == INT64_MIN) continue;
       const int i = (int)m.minrow[u];
       const int r = lo + i;
@@ -469,13 +472,13 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   EVG_STAMP(4); EVG_STOP(4);
 
   // ---- D: elect each task's emitting unit ------------------------------------------------------------------
-  int64_t bv[4];
-  uint32_t bm[4];
-  int bs[4];
+  int64_t bv[E];
+  uint32_t bm[E];
+  int bs[E];
   uint64_t r_vmin = ~0ull, r_vmax = 0, r_dmin = ~0ull, r_dmax = 0;
   uint32_t r_tmin = ~0u, r_tmax = 0, r_nmin = ~0u, r_nmax = 0, r_pmin = ~0u, r_pmax = 0;
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     EVG_PRIO4(6, e);
     const int i = i0 + e;
     bv[e] = INT64_MIN; bm[e] = 0; bs[e] = -1;
@@ -511,68 +514,74 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     atomicMin(&s_rng[0], (unsigned long long)r_vmin); atomicMax(&s_rng[1], (unsigned long long)r_vmax);
     atomicMin(&s_rng[2], (unsigned long long)r_dmin); atomicMax(&s_rng[3], (unsigned long long)r_dmax);
     atomicMin(&s_r32[0], r_tmin); atomicMax(&s_r32[1], r_tmax); atomicMin(&s_r32[2], r_nmin); atomicMax(&s_r32[3], r_nmax);
-    atomicMin(&s_r32[4], r_pmin); atomicMax(&s_r32[5], r_pmax);
+    atomicMin(&s_r32[E], r_pmin); atomicMax(&s_r32[5], r_pmax);
   }
   // the columns of phase G: fetched now, consumed after the sort
-  int64_t sched[4], dmt[4];
+  int64_t sched[E], dmt[E];
   EVG_OPAQUE_ZERO(late1);
   if (BD) {  // the unit each task is emitted from = the row of unit_breakdown that TaskPlan.Export stamps on it
-    int32_t u4[4];
+    int32_t u4[E];
 #pragma unroll
-    for (int e = 0; e < 4; e++) u4[e] = sb + bs[e];
+    for (int e = 0; e < E; e++) u4[e] = sb + bs[e];
     int32_t* uot = EVG_LATE_ARG(int32_t*, out.unit_of_task, late1);
-    if (uot) store4(uot + lo, i0, n, u4);
+    if (uot) storev(uot + lo, i0, n, u4);
   }
-  load4(EVG_LATE_ARG(const int64_t*, in.tasks.scheduled_ts_ns, late1) + lo, i0, n, (int64_t)0, sched);
-  load4(EVG_LATE_ARG(const int64_t*, in.tasks.deps_met_ts_ns, late1) + lo, i0, n, (int64_t)0, dmt);
+  loadv(EVG_LATE_ARG(const int64_t*, in.tasks.scheduled_ts_ns, late1) + lo, i0, n, (int64_t)0, sched);
+  loadv(EVG_LATE_ARG(const int64_t*, in.tasks.deps_met_ts_ns, late1) + lo, i0, n, (int64_t)0, dmt);
   EVG_STAMP(5); EVG_STOP(5);
   EVG_PRIO(10);
   __syncthreads();  // accumulators are dead from here on
 
   // ---- E: keys + sort --------------------------------------------------------------------------------------
-  const int P = c.P < 4 ? 4 : c.P;
+  const int P = c.P < E ? E : c.P;
   const uint64_t vmax = n ? s_rng[1] : 0, vspan = n ? s_rng[1] - s_rng[0] : 0;
   const int vb = bits_of(vspan);
   // in-unit key  [tgo asc | num_dependents desc | priority desc | expected duration desc]  planner.go:386-405
   const uint64_t dmax = s_rng[3];
   const uint32_t tmin = s_r32[0], nmax = s_r32[3], pmax = s_r32[5];
   const int bt = n ? bits_of((uint64_t)(s_r32[1] - s_r32[0])) : 0, bn = n ? bits_of((uint64_t)(s_r32[3] - s_r32[2])) : 0,
-            bp = n ? bits_of((uint64_t)(s_r32[5] - s_r32[4])) : 0, bd = n ? bits_of(s_rng[3] - s_rng[2]) : 0;
+            bp = n ? bits_of((uint64_t)(s_r32[5] - s_r32[E])) : 0, bd = n ? bits_of(s_rng[3] - s_rng[2]) : 0;
   const bool ik_ok = bt + bn + bp + bd <= 64;
   uint64_t* xik = (uint64_t*)(smem + X_IK);
   if (ik_ok) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
+    for (int e = 0; e < E; e++) {
       const int i = i0 + e;
       if (i >= n) continue;
       xik[i] = shl64((uint64_t)(ub(tgo[e]) - tmin), bn + bp + bd) | shl64((uint64_t)(nmax - ub(nd[e])), bp + bd) |
                shl64((uint64_t)(pmax - ub((int32_t)pri[e])), bd) | (dmax - ub(dur[e]));
     }
   }
-  uint32_t srt[4];  // after the sort: (unit slot << 11) | local row at sorted position i0+e
+  uint32_t srt[E];  // after the sort: (unit slot << 11) | local row at sorted position i0+e
   if (vb + 34 <= 64) {
-    uint64_t k[4];
+    uint64_t k[E];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
+    for (int e = 0; e < E; e++) {
       const int i = i0 + e;
       k[e] = i < n ? ((vmax - ub(bv[e])) << 34) | ((uint64_t)bm[e] << 23) | ((uint64_t)bs[e] << 11) | (uint64_t)i : ~0ull;
     }
     EVG_STAMP(6); EVG_STOP(6);
-    if (P == 2048) bitonic_sort4_fixed<2048, uint64_t, 11>(k, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
-    else bitonic_sort4<uint64_t>(k, P, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
+    if constexpr (E == 4) {
+      if (P == 2048) bitonic_sort4_fixed<2048, uint64_t, 11>(k, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
+      else bitonic_sort4<uint64_t>(k, P, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
+    } else {
+      if (P == 2048) bitonic_sort2_fixed<2048, uint64_t, 11>(k, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
+      else bitonic_sort2<uint64_t>(k, P, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
+    }
 #pragma unroll
-    for (int e = 0; e < 4; e++) srt[e] = (uint32_t)k[e] & 0x7FFFFFu;
+    for (int e = 0; e < E; e++) srt[e] = (uint32_t)k[e] & 0x7FFFFFu;
   } else {
-    K128 k[4];
+    K128 k[E];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
+    for (int e = 0; e < E; e++) {
       const int i = i0 + e;
       k[e] = i < n ? K128{vmax - ub(bv[e]), ((uint64_t)bm[e] << 23) | ((uint64_t)bs[e] << 11) | (uint64_t)i} : K128{~0ull, ~0ull};
     }
     EVG_STAMP(6); EVG_STOP(6);
-    bitonic_sort4<K128>(k, P, tid, (K128*)(smem + X_BUF0), (K128*)(smem + X_BUF0));
+    if constexpr (E == 4) bitonic_sort4<K128>(k, P, tid, (K128*)(smem + X_BUF0), (K128*)(smem + X_BUF0));
+    else bitonic_sort2<K128>(k, P, tid, (K128*)(smem + X_BUF0), (K128*)(smem + X_BUF0));
 #pragma unroll
-    for (int e = 0; e < 4; e++) srt[e] = (uint32_t)k[e].lo & 0x7FFFFFu;
+    for (int e = 0; e < E; e++) srt[e] = (uint32_t)k[e].lo & 0x7FFFFFu;
   }
   EVG_STAMP(7); EVG_STOP(7);
   EVG_PRIO(15);
@@ -585,13 +594,15 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   uint64_t* sik = (uint64_t*)(smem + Y_SIK);
   uint16_t* sslot = (uint16_t*)(smem + Y_SSLOT);
   uint16_t* sidx = (uint16_t*)(smem + Y_SIDX);
-  int32_t* scan = (int32_t*)(smem + Y_SCAN);
+  typedef typename ScanWord<E>::type scan_t;  // positions -1..2047: 2048 bytes of scan words whatever E is
+  scan_t* scan = (scan_t*)(smem + Y_SCAN);
+  uint32_t* wtot = (uint32_t*)(smem + Y_SCAN + 2048);  // one packed item total per wave
   uint16_t* ren = (uint16_t*)(smem + Y_REN);
   uint16_t* pos = (uint16_t*)(smem + Y_POS);
   uint16_t* fidx = (uint16_t*)(smem + Y_FIDX);
-  uint64_t myik[4];
+  uint64_t myik[E];
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     const int q = i0 + e;
     myik[e] = 0;
     if (q >= n) continue;
@@ -601,11 +612,11 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   }
   __syncthreads();
   // run starts: position q starts a run when the slot changes
-  bool brk[4];
-  int st[4], en[4];
+  bool brk[E];
+  int st[E], en[E];
   int lb = -1;  // last run start inside this thread
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     const int q = i0 + e;
     const uint32_t prev = e ? srt[e - 1] >> 11 : (q > 0 && q <= n ? (uint32_t)sslot[q - 1] : 0xFFFFu);
     brk[e] = q < n && (q == 0 || prev != (srt[e] >> 11));
@@ -621,7 +632,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
     const int row = lane >> 4;
     v = mx(v, row >= 1 ? r0 : -1); v = mx(v, row >= 2 ? r1 : -1); v = mx(v, row >= 3 ? r2 : -1);
-    scan[tid] = v;
+    scan[tid] = (scan_t)v;
   }
   __syncthreads();
   int incoming = lane ? scan[tid - 1] : -1;  // last run start before this thread's positions
@@ -629,7 +640,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // Work items of the chunked ranking below: a run is cut into chunks of four consecutive positions, one item per chunk.
   // `items` = how many start inside this thread; their numbers come from a sum-scan over the workgroup.
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     const int q = i0 + e;
     const int before = e ? st[e - 1] : incoming;
     st[e] = brk[e] ? q : before;
@@ -639,7 +650,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   __syncthreads();
   bool multi = false;
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     const int q = i0 + e;
     if (q < n) { en[e] = ren[st[e]]; multi |= en[e] - st[e] > 1; }
     else { st[e] = q; en[e] = q; }
@@ -649,7 +660,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // the second round is made of short-run items.
   uint32_t items = 0;
 #pragma unroll
-  for (int e = 0; e < 4; e++)
+  for (int e = 0; e < E; e++)
     if (i0 + e < n && ((i0 + e - st[e]) & 3) == 0) items += en[e] - st[e] > 4 ? 1u : 0x10000u;
   uint32_t item_excl;  // packed counts of the items that start in earlier threads
   {
@@ -663,18 +674,18 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     const int row = lane >> 4;
     v += (row >= 1 ? r0 : 0u) + (row >= 2 ? r1 : 0u) + (row >= 3 ? r2 : 0u);
     item_excl = v - items;
-    if (lane == 63) scan[kBlock + (tid >> 6)] = (int32_t)v;  // the wave's totals, behind the max-scan words
+    if (lane == 63) wtot[tid >> 6] = v;  // the wave's totals, behind the max-scan words
   }
   __syncthreads();
   uint32_t item_tot = 0;
   {
     uint32_t base = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; w++) { const uint32_t x = (uint32_t)scan[kBlock + w]; base += w < (tid >> 6) ? x : 0u; item_tot += x; }
+    for (int w = 0; w < BLK / 64; w++) { const uint32_t x = wtot[w]; base += w < (tid >> 6) ? x : 0u; item_tot += x; }
     item_excl += base;
   }
   const int n_long = (int)(item_tot & 0xFFFFu), n_items = n_long + (int)(item_tot >> 16);
-  int rank[4] = {0, 0, 0, 0};
+  int rank[E] = {};
   // ---- chunked ranking: every lane ranks ONE chunk of four positions of ONE run against the rest of that run ------------
   // With a thread's four positions fixed by its lane (the loops below), the lane on a boundary between two long runs walks
   // all of the first run AND all of the second, and the wave waits for it: ~2L/4 trips where L/4 are needed. Here no item
@@ -682,7 +693,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // that "an earlier position precedes on <=, a later one on <" is one subtraction of 0 / 1 from the loaded key.
   // Taken when the run structure gives at most two items per thread (long runs: grouped-version distros) and the in-unit key
   // fits 63 bits; a distro of short runs has several items per thread and its loops below are short anyway.
-  constexpr int kMaxItems = 2 * kBlock;
+  constexpr int kMaxItems = 2 * BLK;
   const bool chunked = ik_ok && bt + bn + bp + bd <= 63 && n_items <= kMaxItems;
   if (chunked) {
     uint16_t* itq = (uint16_t*)(smem + X_IK);       // item -> its first position; the in-unit keys by task are dead
@@ -690,7 +701,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     {
       int kl = (int)(item_excl & 0xFFFFu), ks = n_long + (int)(item_excl >> 16);
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
+      for (int e = 0; e < E; e++) {
         const int q = i0 + e;
         if (q < n) sik[q] = (myik[e] << 1) | 1ull;
         if (q < n && ((q - st[e]) & 3) == 0) {
@@ -700,7 +711,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       }
     }
     __syncthreads();
-    for (int item = tid; item < n_items; item += kBlock) {
+    for (int item = tid; item < n_items; item += BLK) {
       const int q0 = itq[item], rs = its[item], re = ren[rs];
       const int L = re - rs, cnt = re - q0 < 4 ? re - q0 : 4;
       uint64_t o[4];
@@ -753,46 +764,46 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       // element. (One pair of loops per lane, whatever the number of run boundaries inside a wave.)
       int nv = 0;  // the thread's valid positions: [i0, i0 + nv)
 #pragma unroll
-      for (int e = 0; e < 4; e++) nv += i0 + e < n ? 1 : 0;
+      for (int e = 0; e < E; e++) nv += i0 + e < n ? 1 : 0;
       if (nv > 0) {
         const int rs = st[0], le = nv - 1, re = en[le];
-        uint64_t khi[4], klo[4];
+        uint64_t khi[E], klo[E];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < E; e++) {
           khi[e] = e < nv && st[e] == rs ? myik[e] : ~0ull;       // never "greater than the other key"
           klo[e] = e < nv && st[e] == st[le] ? myik[e] : 0ull;   // never "less than ..."
         }
-        int gt[4] = {0, 0, 0, 0};
+        int gt[E] = {};
         {  // earlier positions precede unless their key is greater; 4 independent LDS reads per trip
           int q2 = rs;
           for (; q2 + 4 <= i0; q2 += 4) {
             const uint64_t k0 = sik[q2], k1 = sik[q2 + 1], k2 = sik[q2 + 2], k3 = sik[q2 + 3];
 #pragma unroll
-            for (int e = 0; e < 4; e++) gt[e] += (khi[e] < k0 ? 1 : 0) + (khi[e] < k1 ? 1 : 0) + (khi[e] < k2 ? 1 : 0) + (khi[e] < k3 ? 1 : 0);
+            for (int e = 0; e < E; e++) gt[e] += (khi[e] < k0 ? 1 : 0) + (khi[e] < k1 ? 1 : 0) + (khi[e] < k2 ? 1 : 0) + (khi[e] < k3 ? 1 : 0);
           }
           for (; q2 < i0; q2++) {
             const uint64_t k0 = sik[q2];
 #pragma unroll
-            for (int e = 0; e < 4; e++) gt[e] += khi[e] < k0 ? 1 : 0;
+            for (int e = 0; e < E; e++) gt[e] += khi[e] < k0 ? 1 : 0;
           }
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++) rank[e] += (e < nv && st[e] == rs) ? (i0 - rs) - gt[e] : 0;
+        for (int e = 0; e < E; e++) rank[e] += (e < nv && st[e] == rs) ? (i0 - rs) - gt[e] : 0;
         {  // later positions precede only when their key is smaller
           int q2 = i0 + nv;
           for (; q2 + 4 <= re; q2 += 4) {
             const uint64_t k0 = sik[q2], k1 = sik[q2 + 1], k2 = sik[q2 + 2], k3 = sik[q2 + 3];
 #pragma unroll
-            for (int e = 0; e < 4; e++) rank[e] += (k0 < klo[e] ? 1 : 0) + (k1 < klo[e] ? 1 : 0) + (k2 < klo[e] ? 1 : 0) + (k3 < klo[e] ? 1 : 0);
+            for (int e = 0; e < E; e++) rank[e] += (k0 < klo[e] ? 1 : 0) + (k1 < klo[e] ? 1 : 0) + (k2 < klo[e] ? 1 : 0) + (k3 < klo[e] ? 1 : 0);
           }
           for (; q2 < re; q2++) {
             const uint64_t k0 = sik[q2];
 #pragma unroll
-            for (int e = 0; e < 4; e++) rank[e] += k0 < klo[e] ? 1 : 0;
+            for (int e = 0; e < E; e++) rank[e] += k0 < klo[e] ? 1 : 0;
           }
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++)
+        for (int e = 0; e < E; e++)
 #pragma unroll
           for (int f = e + 1; f < 4; f++) {
             const bool both = f < nv && st[e] == st[f];
@@ -803,7 +814,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       }
     } else {  // value ranges too wide to compress into 64 bits: compare the columns themselves
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
+      for (int e = 0; e < E; e++) {
         const int q = i0 + e, r = lo + (int)(srt[e] & 0x7FFu);
         for (int q2 = st[e]; q2 < en[e]; q2++) {
           const int cmp = inunit_cmp(t, lo + sidx[q2], r);
@@ -814,7 +825,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   }
   if (!chunked) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
+    for (int e = 0; e < E; e++) {
       const int q = i0 + e;
       if (q >= n) continue;
       const int fin = st[e] + rank[e];
@@ -825,11 +836,11 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   }
   __syncthreads();
   {
-    int32_t o4[4];
+    int32_t o4[E];
 #pragma unroll
-    for (int e = 0; e < 4; e++) o4[e] = i0 + e < n ? lo + (int)fidx[i0 + e] : 0;
+    for (int e = 0; e < E; e++) o4[e] = i0 + e < n ? lo + (int)fidx[i0 + e] : 0;
     EVG_OPAQUE_ZERO(late2);
-    store4(EVG_LATE_ARG(int32_t*, out.order, late2) + lo, i0, n, o4);
+    storev(EVG_LATE_ARG(int32_t*, out.order, late2) + lo, i0, n, o4);
   }
   EVG_STAMP(8); EVG_STOP(8);
   EVG_PRIO(16);
@@ -843,19 +854,19 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   uint64_t* g_dover = g_dur + kG;
   uint64_t* g_pk = g_dover + kG;
   uint32_t* g_first = (uint32_t*)(g_pk + kG);
-  for (int k = tid; k < c.ntg + 1; k += kBlock) { g_pk[k] = 0; g_first[k] = 0xFFFFFFFFu; g_dur[k] = 0; g_dover[k] = 0; }
+  for (int k = tid; k < c.ntg + 1; k += BLK) { g_pk[k] = 0; g_first[k] = 0xFFFFFFFFu; g_dur[k] = 0; g_dover[k] = 0; }
   // TaskGroupMaxHosts of the rows: a row of model.TaskGroupInfo takes it from the group's first task in QUEUE order, known only
   // at the very end -- a gather by row there is a global round trip nothing can hide. Fetched now (coalesced), parked in LDS.
-  int32_t mh4[4];
-  load4(EVG_LATE_ARG(const int32_t*, in.tasks.task_group_max_hosts, late3) + lo, i0, n, (int32_t)0, mh4);
+  int32_t mh4[E];
+  loadv(EVG_LATE_ARG(const int32_t*, in.tasks.task_group_max_hosts, late3) + lo, i0, n, (int32_t)0, mh4);
   int32_t* mh_lds = (int32_t*)(smem + X_IK);  // the in-unit keys by task (and phase F's item tables) are dead
   // pass A: checkDependenciesMet per task; does any met merge-queue task exist?
   const bool incl = p.includes_dependencies != 0;
-  bool met[4];
-  int64_t mettime[4];
+  bool met[E];
+  int64_t mettime[E];
   bool any_mq = false;
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     const int i = i0 + e;
     met[e] = false; mettime[e] = 0;
     if (i >= n) continue;
@@ -881,10 +892,10 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     if (mt && (f & EVG_TF_REQ_MASK) == EVG_TF_REQ_MERGE) any_mq = true;
   }
   {
-    uint8_t m4[4];
+    uint8_t m4[E];
 #pragma unroll
-    for (int e = 0; e < 4; e++) m4[e] = met[e] ? 1 : 0;
-    store4(EVG_LATE_ARG(uint8_t*, out.deps_met, late3) + lo, i0, n, m4);
+    for (int e = 0; e < E; e++) m4[e] = met[e] ? 1 : 0;
+    storev(EVG_LATE_ARG(uint8_t*, out.deps_met, late3) + lo, i0, n, m4);
   }
   EVG_STAMP(9); EVG_STOP(9);
   EVG_PRIO(17);
@@ -897,9 +908,9 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   uint64_t s_pk = 0;   // the stand-alone row's counters, packed like g_pk
   uint64_t n_pk = 0;   // distro counters: deps met | met merge-queue << 16 | met with S3 parser-project storage << 32
   uint64_t s_dur = 0, s_dover = 0;
-  int64_t wait4[4];
+  int64_t wait4[E];
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
+  for (int e = 0; e < E; e++) {
     const int i = i0 + e;
     wait4[e] = 0;
     if (i >= n) continue;
@@ -932,9 +943,9 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       atomicAdd((unsigned long long*)&g_dover[g], (unsigned long long)du_o);
     }
   }
-  store4(EVG_LATE_ARG(int64_t*, out.wait_ns, late3) + lo, i0, n, wait4);
+  storev(EVG_LATE_ARG(int64_t*, out.wait_ns, late3) + lo, i0, n, wait4);
 #pragma unroll
-  for (int e = 0; e < 4; e++)
+  for (int e = 0; e < E; e++)
     if (i0 + e < n) mh_lds[i0 + e] = mh4[e];
   s_pk = row_sum(s_pk); s_dur = row_sum(s_dur); s_dover = row_sum(s_dover); n_pk = row_sum(n_pk);
   s_first = row_min(s_first);
@@ -945,7 +956,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     if (s_dover) atomicAdd((unsigned long long*)&g_dover[0], (unsigned long long)s_dover);
     if (n_pk) atomicAdd((unsigned long long*)&s_red[14], (unsigned long long)n_pk);
   }
-  if (__any(sec) && lane == 0) atomicOr(&s_red[4], 1u);
+  if (__any(sec) && lane == 0) atomicOr(&s_red[E], 1u);
   EVG_STAMP(10); EVG_STOP(10);
   EVG_PRIO(18);
   __syncthreads();
@@ -954,7 +965,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   evg_group_info* out_group_info = EVG_LATE_ARG(evg_group_info*, out.group_info, late3);
   uint64_t t_dur = 0, t_dover = 0;
   uint32_t t_cover = 0, t_wait = 0, t_rows = 0;
-  for (int k = tid; k < c.ntg + 1; k += kBlock) {
+  for (int k = tid; k < c.ntg + 1; k += BLK) {
     evg_group_info* o = &out_group_info[k == 0 ? d : c.D + c.tg_lo + (k - 1)];
     const uint32_t first = g_first[k];
     const bool present = first != 0xFFFFFFFFu;
@@ -996,7 +1007,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     di.count_duration_over_threshold = (int32_t)s_red[5];
     di.count_wait_over_threshold = (int32_t)s_red[6];
     di.num_queued_large_parser_project_tasks = (int32_t)((n_pk_all >> 32) & 0xFFFFu);
-    di.secondary_queue = (int32_t)s_red[4];
+    di.secondary_queue = (int32_t)s_red[E];
     di.n_task_group_infos = (int32_t)s_red[8];
     EVG_LATE_ARG(evg_distro_info*, out.distro_info, late3)[d] = di;
   }
@@ -1015,10 +1026,10 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     int* s_i = (int*)s_red;
     if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
     if (hs.staged)
-      for (int b = tid; b < nb; b += kBlock) { hs.n_hosts[b] = 0; hs.n_free[b] = 0; }
+      for (int b = tid; b < nb; b += BLK) { hs.n_hosts[b] = 0; hs.n_free[b] = 0; }
     __syncthreads();
     uint32_t nfree = 0;
-    for (int i = tid; i < fnh; i += kBlock) {
+    for (int i = tid; i < fnh; i += BLK) {
       uint32_t f;
       int32_t key;
       HostLeft hl;
@@ -1035,7 +1046,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       stage_host(hs, q, fh0, i, f, key, host_term(ap.future_host_fraction, T, hl), c.tg_lo, c.ntg);
     }
     __syncthreads();
-    allocate_distro<kBlock>(q, d, ap, fh0, fnh, c.tg_lo, c.ntg, T, len_met, nfree, hs, s_i);
+    allocate_distro<BLK>(q, d, ap, fh0, fnh, c.tg_lo, c.ntg, T, len_met, nfree, hs, s_i);
     EVG_STAMP(12);
   }
   return true;
@@ -1092,6 +1103,44 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const Fu
   const bool done = n <= kN && plan_distro_lds<RICH, true, BD>(f.p, f.q, d, lo, n, smem, s_red);
   if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
 }
+
+#ifdef EVG_WITH_WIDE
+// Experiment (not in the default build): the same phases with TWO tasks per thread -- 1024-thread workgroups, 16 waves, two
+// workgroups per CU = 8 waves per SIMD at 64 VGPRs -- to see whether twice the waves hide the latencies of the phases.
+// Bit-identical results (the whole GPU suite passes with EVG_PLAN_WIDE=1); measured on config 3: a workgroup alone on its CU
+// takes as long as before (39.4 vs 39.1 us), two per CU take longer (59.2 vs 55.8 us). See DESIGN.md section 3.1.
+template <bool BD>
+__global__ void __launch_bounds__(kN / 2, 8) k_plan_distros_wide(const PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
+  const int d = a.d0 + blockIdx.x;
+  const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo;
+  if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
+  __syncthreads();
+#ifdef EVG_PHASE_TIMING
+  struct { int d; } c{d};
+#endif
+  EVG_STAMP(0);
+  const AllocArgs none{};
+  const bool done = n <= kN && plan_distro_lds<false, false, BD, 2>(a, none, d, lo, n, smem, s_red);
+  if (threadIdx.x == 0) a.w_generic[d] = done ? 0 : 1;
+}
+__global__ void __launch_bounds__(kN / 2, 8) k_plan_allocate_wide(const FusedArgs f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
+  const int d = f.p.d0 + blockIdx.x;
+  const int lo = f.p.in.task_off[d], n = f.p.in.task_off[d + 1] - lo;
+  if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
+  __syncthreads();
+  [[maybe_unused]] const PlanArgs& a = f.p;  // EVG_STAMP's
+#ifdef EVG_PHASE_TIMING
+  struct { int d; } c{d};
+#endif
+  EVG_STAMP(0);
+  const bool done = n <= kN && plan_distro_lds<false, true, false, 2>(f.p, f.q, d, lo, n, smem, s_red);
+  if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
+}
+#endif
 
 __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c, unsigned* s_red, K128* sort_buf) {
   const int d = c.d;

@@ -382,6 +382,8 @@ struct evg_ctx {
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
+  // experiment builds (-DEVG_WITH_WIDE): EVG_PLAN_WIDE=1 plans with 1024-thread workgroups, two tasks per thread
+  bool wide = false;
   // evg_profile_plan_kernel: HIP events around the LDS planner kernel alone, on the stream it is launched on
   bool profile = false;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -535,6 +537,9 @@ evg_ctx* evg_create(int device_ordinal) {
   }
   evg_ctx* c = new evg_ctx();
   c->device = device_ordinal;
+#ifdef EVG_WITH_WIDE
+  if (const char* w = getenv("EVG_PLAN_WIDE")) c->wide = w[0] == '1';
+#endif
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     set_err(nullptr, EVG_E_HIP, "cannot create a stream on device %d", device_ordinal);
     delete c;
@@ -765,6 +770,11 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
+#ifdef EVG_WITH_WIDE
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate_wide, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
+#endif
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
     c->lds_attr_set = true;
@@ -901,6 +911,10 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st));
   // TaskPlan.Len() needs 18 KiB more LDS per workgroup (one workgroup per CU instead of two); the breakdown rows do not
   if (out->n_units) hipLaunchKernelGGL((k_plan_distros<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, a);
+#ifdef EVG_WITH_WIDE
+  else if (c->wide && a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros_wide<true>), dim3(D), dim3(kN / 2), kLdsLean, st, a);
+  else if (c->wide) hipLaunchKernelGGL((k_plan_distros_wide<false>), dim3(D), dim3(kN / 2), kLdsLean, st, a);
+#endif
   else if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros<false, true>), dim3(D), dim3(kBlock), kLdsLean, st, a);
   else hipLaunchKernelGGL((k_plan_distros<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, a);
   HIP_TRY(c, hipGetLastError());
@@ -986,6 +1000,9 @@ static int launch_plan_allocate(evg_ctx* c, const evg_plan_input* in, const evg_
   const int D = f.p.d1 - f.p.d0;
   if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st));
   if (f.p.out.unit_breakdown || out->n_units) hipLaunchKernelGGL((k_plan_allocate<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, f);
+#ifdef EVG_WITH_WIDE
+  else if (c->wide) hipLaunchKernelGGL(k_plan_allocate_wide, dim3(D), dim3(kN / 2), kLdsLean, st, f);
+#endif
   else hipLaunchKernelGGL((k_plan_allocate<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, f);
   HIP_TRY(c, hipGetLastError());
   if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_stop, st));

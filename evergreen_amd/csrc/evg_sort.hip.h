@@ -29,6 +29,9 @@ __device__ __forceinline__ uint64_t key_xor(uint64_t v) { return ((uint64_t)word
 template <int M>
 __device__ __forceinline__ K128 key_xor(const K128& v) { return K128{key_xor<M>(v.hi), key_xor<M>(v.lo)}; }
 // compare-exchange of the lane's 4 keys with lane (lane ^ M): keep the smaller (take_min) or the larger of each pair
+// (Measured: issuing the four exchanges as three groups -- all partner fetches, all compares, all selects, fenced with
+// sched_barrier -- instead of key by key, as the compiler does, re-using two VGPRs and one SGPR pair, changes nothing with
+// two workgroups per CU: the other waves fill each key's DPP -> v_cmp -> s_xor -> v_cndmask chain.)
 template <int M, class K>
 __device__ __forceinline__ void shuffle_stage(K (&k)[4], bool take_min) {
 #pragma unroll
@@ -207,6 +210,88 @@ __device__ __forceinline__ void bitonic_sort4(K (&k)[4], int P, int tid, K* buf0
         if (kk == 2) { cmpx(k[0], k[1], true); cmpx(k[2], k[3], false); }
         else { cmpx(k[0], k[1], asc_t); cmpx(k[2], k[3], asc_t); }
       }
+    }
+  }
+}
+
+// ---- the same network with TWO keys per lane (1024-thread workgroups: position p = 2*tid + e) ----------------------------
+// Partner distance j: 1 inside the lane, 2..64 by wave shuffles (lane ^ j/2), 128 and up through LDS (lane distance 64+:
+// another wave). A 2048-key sort has 10 LDS stages here against 6 with four keys per lane, and twice the waves to hide them.
+template <int M, class K>
+__device__ __forceinline__ void shuffle_stage2(K (&k)[2], bool take_min) {
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const K o = key_xor<M>(k[e]);
+    const bool lt = key_lt(o, k[e]);
+    if (take_min == lt) k[e] = o;
+  }
+}
+template <class K>
+__device__ __forceinline__ void lds_stage2(K (&k)[2], int tid, int j, bool take_min, K* buf, bool sync_first) {
+  const int p0 = tid * 2;
+  if (sync_first) __syncthreads();
+  buf[p0] = k[0];
+  buf[p0 + 1] = k[1];
+  __syncthreads();
+  const int q0 = (tid ^ (j >> 1)) * 2;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const K o = buf[q0 + e];
+    const bool lt = key_lt(o, k[e]);
+    if (take_min == lt) k[e] = o;
+  }
+}
+template <int P, class K, int PRIO_STEP = -1>
+__device__ __forceinline__ void bitonic_sort2_fixed(K (&k)[2], int tid, K* buf0, K* buf1) {
+  const int p0 = tid * 2;
+  int which = 0;
+#pragma unroll
+  for (int kk = 2; kk <= P; kk <<= 1) {
+    if constexpr (PRIO_STEP >= 0) {
+      if (kk == P / 8) EVG_PRIO(PRIO_STEP);
+      else if (kk == P / 4) EVG_PRIO(PRIO_STEP + 1);
+      else if (kk == P / 2) EVG_PRIO(PRIO_STEP + 2);
+      else if (kk == P) EVG_PRIO(PRIO_STEP + 3);
+    }
+    const bool asc_t = (p0 & kk) == 0;
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      const bool take_min = ((p0 & j) == 0) == asc_t;
+      if (j >= 128) {
+        lds_stage2(k, tid, j, take_min, which ? buf1 : buf0, buf0 == buf1);
+        which ^= 1;
+      } else if (j == 64) shuffle_stage2<32>(k, take_min);
+      else if (j == 32) shuffle_stage2<16>(k, take_min);
+      else if (j == 16) shuffle_stage2<8>(k, take_min);
+      else if (j == 8) shuffle_stage2<4>(k, take_min);
+      else if (j == 4) shuffle_stage2<2>(k, take_min);
+      else if (j == 2) shuffle_stage2<1>(k, take_min);
+      else cmpx(k[0], k[1], asc_t);
+    }
+  }
+}
+// P = 2^m at run time (P >= 2); positions >= P are ignored.
+template <class K>
+__device__ __forceinline__ void bitonic_sort2(K (&k)[2], int P, int tid, K* buf0, K* buf1) {
+  const int p0 = tid * 2;
+  int which = 0;
+  for (int kk = 2; kk <= P; kk <<= 1) {
+    const bool asc_t = (p0 & kk) == 0;
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      const bool take_min = ((p0 & j) == 0) == asc_t;
+      if (j >= 128) {
+        lds_stage2(k, tid, j, take_min, which ? buf1 : buf0, buf0 == buf1);
+        which ^= 1;
+      } else if (j >= 2) {
+        switch (j >> 1) {
+          case 1: shuffle_stage2<1>(k, take_min); break;
+          case 2: shuffle_stage2<2>(k, take_min); break;
+          case 4: shuffle_stage2<4>(k, take_min); break;
+          case 8: shuffle_stage2<8>(k, take_min); break;
+          case 16: shuffle_stage2<16>(k, take_min); break;
+          default: shuffle_stage2<32>(k, take_min); break;
+        }
+      } else cmpx(k[0], k[1], asc_t);
     }
   }
 }
