@@ -15,7 +15,7 @@ import torch  # noqa: E402
 from evergreen_amd import abi, gen, native  # noqa: E402
 
 CSRC = os.path.join(ROOT, "evergreen_amd", "csrc")
-DBG = os.path.join(CSRC, "libevg_sched_dbg.so")
+DBG = os.environ.get("EVG_DBG_LIB") or os.path.join(CSRC, "libevg_sched_dbg.so")
 NAMES = ["A load+slots", "B reduce", "C score", "C' n_units", "D elect+ranges", "E keys", "E sort", "F in-unit+order",
          "G deps met", "G group sums", "G rows out"]
 
