@@ -309,6 +309,15 @@ def test_planner_fuzz_matches_oracle(native_ctx, oracle):
         assert np.array_equal(ga.new_hosts, wa.new_hosts) and np.array_equal(ga.free_hosts, wa.free_hosts) and np.array_equal(ga.status, wa.status), it
 
 
+def test_random_shapes_through_the_resident_tick(native_ctx, oracle):
+    """30 pools of random shape (tests/random_shapes.py: LDS path, large-distro pipeline and both in one pool; two calls or one
+    launch; unit rows on or off) -- bit-exact against the oracle, valid against the reference's invariants."""
+    import torch
+    from tests import random_shapes
+    pools, tasks = random_shapes.run(native_ctx, oracle, torch.device("cuda:0"), seed=42, n_pools=30, max_tasks=250_000)
+    assert pools == 30 and tasks > 0
+
+
 def test_many_dependencies_per_task(native_ctx, oracle):
     """Rows with up to nine dependencies, several of them in ONE task group (= one unit named repeatedly) and spread so that
     the repeat is more than four edges back: the membership dedup beyond the four-edge register window."""
