@@ -14,8 +14,8 @@ from tests import compare
 PER_DISTRO = [3, 60, 500, 1500, 2040, 2047, 2048, 2049, 2100, 4096, 4100, 9000, 20000, 70000]
 
 
-def draw(rng, k, max_tasks=400_000):
-    per = int(rng.choice(PER_DISTRO))
+def draw(rng, k, max_tasks=400_000, large_only=False):
+    per = int(rng.choice([p for p in PER_DISTRO if p > 2048] if large_only else PER_DISTRO))
     D = int(rng.integers(1, 1 + max(1, min(400, max_tasks // per))))
     return gen.GenConfig(per * D + int(rng.integers(0, D)), D, gen.SEED_BASE + 1000 + k,
                          dag_depth=int(rng.choice([1, 2, 3, 8, 20])), tg_fraction=float(rng.choice([0.0, 0.05, 0.2, 0.6, 1.0])),
@@ -23,13 +23,13 @@ def draw(rng, k, max_tasks=400_000):
                          includes_dependencies_fraction=float(rng.choice([0.0, 0.5, 0.75, 1.0])), shuffle=bool(rng.random() < 0.8))
 
 
-def run(ctx, oracle, device, seed, n_pools=None, seconds=None, max_tasks=400_000):
+def run(ctx, oracle, device, seed, n_pools=None, seconds=None, max_tasks=400_000, large_only=False):
     """-> (pools, tasks). Raises AssertionError on the first difference."""
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds if seconds else None
     k = tasks = 0
     while (n_pools is None or k < n_pools) and (t_end is None or time.time() < t_end):
-        cfg = draw(rng, k, max_tasks)
+        cfg = draw(rng, k, max_tasks, large_only)
         b = gen.generate(cfg)
         units = bool(rng.random() < 0.6)
         fused = bool(rng.random() < 0.5)
