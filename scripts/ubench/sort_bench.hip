@@ -44,7 +44,46 @@ static void run(int grid, const char* what) {
   printf("%-40s grid %4d: %8.0f ticks per sort\n", what, grid, s / grid / reps);
   delete[] h; (void)hipFree(out); (void)hipFree(cyc);
 }
+__global__ void __launch_bounds__(512, 4) k_verify(uint64_t* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* b0 = (uint64_t*)smem;
+  const int tid = threadIdx.x;
+  uint64_t k[4];
+  for (int e = 0; e < 4; e++) k[e] = mix64((uint64_t)(blockIdx.x * 2048 + tid * 4 + e)) >> (blockIdx.x & 1 ? 40 : 0);  // odd blocks: many equal keys
+  bitonic_sort4_fixed<2048, uint64_t>(k, tid, b0, b0 + 2048);
+  for (int e = 0; e < 4; e++) out[(size_t)blockIdx.x * 2048 + tid * 4 + e] = k[e];
+}
+static uint64_t hmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static bool verify() {
+  const int grid = 64;
+  uint64_t* out;
+  (void)hipMalloc(&out, (size_t)grid * 2048 * 8);
+  (void)hipFuncSetAttribute((const void*)k_verify, hipFuncAttributeMaxDynamicSharedMemorySize, 79872);
+  k_verify<<<grid, 512, 79872>>>(out);
+  (void)hipDeviceSynchronize();
+  uint64_t* h = new uint64_t[(size_t)grid * 2048];
+  (void)hipMemcpy(h, out, (size_t)grid * 2048 * 8, hipMemcpyDeviceToHost);
+  bool ok = true;
+  for (int b = 0; b < grid && ok; b++) {
+    uint64_t x = 0, y = 0;
+    for (int i = 0; i < 2048; i++) {
+      const uint64_t in = hmix64((uint64_t)(b * 2048 + i)) >> (b & 1 ? 40 : 0);
+      x += in * 0x9E3779B97F4A7C15ull; y += h[(size_t)b * 2048 + i] * 0x9E3779B97F4A7C15ull;
+      if (i && h[(size_t)b * 2048 + i - 1] > h[(size_t)b * 2048 + i]) ok = false;
+    }
+    if (x != y) ok = false;
+  }
+  printf("verify: 64 tiles sorted ascending and permutations of their input: %s\n", ok ? "yes" : "NO");
+  delete[] h; (void)hipFree(out);
+  return ok;
+}
 int main() {
+  if (!verify()) return 1;
   run<2048>(256, "sort of 2048 keys (66 stages, 6 by LDS)");
   run<2048>(512, "sort of 2048 keys (66 stages, 6 by LDS)");
   run<256>(256, "8 sorts of 256 keys (36 stages, none by LDS)");
