@@ -48,30 +48,10 @@ def algorithmic_bytes(batch, n_units_total, d0=0, d1=None):
 
 
 def oracle_threads(batch, want_threads, reps=5):
-    """The oracle over the whole pool with one distro range per worker thread (ctypes drops the GIL): "one amboy job per
-    distro" on the host cores. Returns (PlanResult, AllocResult, best seconds, threads)."""
-    import ctypes as C
-    from evergreen_amd import abi
+    """tests/oracle_lib.plan_threads: the oracle with one distro range per worker thread. Returns (PlanResult, AllocResult,
+    best seconds, threads)."""
     from tests import oracle_lib
-    o, lib = oracle_lib.OracleBackend(), oracle_lib.lib()
-    D = batch.n_distros
-    nt = max(1, min(want_threads, D))
-    bounds = [D * i // nt for i in range(nt + 1)]
-    inp = abi.make_plan_input(batch)
-    res = abi.PlanResult.alloc_host(batch, breakdown=False, n_units=True)
-    out = res.c_output()
-
-    def work(i):
-        lib.evg_oracle_plan_distro_range(C.byref(inp), C.byref(out), bounds[i], bounds[i + 1])
-    best, alloc = float("inf"), None
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        if batch.alloc_params is not None:
-            alloc = o.allocate(batch, res.distro_info, res.group_info)
-        best = min(best, time.perf_counter() - t0)
+    res, alloc, best, _times, nt = oracle_lib.plan_threads(batch, want_threads, reps=reps)
     return res, alloc, best, nt
 
 

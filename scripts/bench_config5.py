@@ -22,8 +22,8 @@ print("config-5 share: %d tasks x %d distros (%d edges): %.3f ms per step = %.1f
 if "--check" in sys.argv:
     from tests import oracle_lib, compare
     got = pool.plan_result()
-    want = oracle_lib.OracleBackend().plan(b, breakdown=False, n_units=False)
+    want, _, best, _, nt = oracle_lib.plan_threads(b, n_units=False)
     want.breakdown = None; want.n_units = None
-    oracle_lib.OracleBackend().allocate(b, want.distro_info, want.group_info)
+    print("oracle: %.2f s on %d threads" % (best, nt))
     compare.assert_plan_equal(got, want, b, "config 5 share")
     print("parity with the oracle: ok")

@@ -58,6 +58,37 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def plan_threads(batch: abi.PlanBatch, want_threads: int = 0, reps: int = 1, n_units: bool = True, allocate: bool = True):
+    """The oracle over the whole pool with one contiguous distro range per worker thread (ctypes drops the GIL): "one amboy
+    job per distro" on the host cores (units/crons.go:303-332). Returns (PlanResult, AllocResult or None, best seconds,
+    every pass's seconds, threads)."""
+    import threading
+    import time
+    o, L = OracleBackend(), lib()
+    D = batch.n_distros
+    nt = max(1, min(want_threads or (os.cpu_count() or 1), D))
+    # contiguous ranges balanced by task count (a distro's cost grows with its size)
+    cum = np.concatenate([[0], np.cumsum(np.diff(batch.task_off).astype(np.int64) + 1)])
+    bounds = [int(np.searchsorted(cum, cum[-1] * i / nt)) for i in range(nt)] + [D]
+    inp = abi.make_plan_input(batch)
+    res = abi.PlanResult.alloc_host(batch, breakdown=False, n_units=n_units)
+    out = res.c_output()
+
+    def work(i):
+        if bounds[i + 1] > bounds[i]:
+            L.evg_oracle_plan_distro_range(C.byref(inp), C.byref(out), bounds[i], bounds[i + 1])
+    times, alloc = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if allocate and batch.alloc_params is not None:
+            alloc = o.allocate(batch, res.distro_info, res.group_info)
+        times.append(time.perf_counter() - t0)
+    return res, alloc, min(times), times, nt
+
+
 class OracleRangeBackend:
     """The two range entry points of the multi-GPU driver (evergreen_amd/multi.py) over the oracle: lets the CPU tests run
     the sharding / broadcast / gather logic with gloo and host tensors. Test infrastructure only."""

@@ -280,6 +280,32 @@ def test_config5_per_gpu_share(native_ctx, oracle):
     compare.assert_alloc_equal(got_alloc, want_alloc, "config 5 share")
 
 
+def test_config5_full_10m_tasks_512_distros(native_ctx):
+    """BASELINE config 5 at its stated size on ONE MI355X: 10,000,000 tasks x 512 distros of 19.5k tasks (DAG depth 8, 20%
+    task-group tasks; 17.3M dependency edges, 587k task groups), through the device-resident entry points -- every distro on
+    the many-workgroups-per-distro pipeline -- plan + allocate bit-exact against the oracle (one distro range per host
+    core), and the order checked as one the Go code could emit (tests/ref_validity.py)."""
+    import torch
+    from evergreen_amd import resident
+    from tests import oracle_lib
+    b = gen.generate(gen.config(5))
+    assert b.n_tasks == 10_000_000 and b.n_distros == 512
+    pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=False, n_units=False, units=True)
+    pool.step(fused=False)
+    got, got_alloc = pool.plan_result(), pool.alloc_result()
+    del pool
+    torch.cuda.empty_cache()
+    want, want_alloc, _, _, _ = oracle_lib.plan_threads(b, n_units=False)
+    want.breakdown, want.n_units = None, None
+    compare.assert_plan_equal(got, want, b, "config 5 full")
+    compare.assert_alloc_equal(got_alloc, want_alloc, "config 5 full")
+    for name in ("count_free", "count_required"):
+        assert np.array_equal(got.group_info[name], want.group_info[name]), "config 5 full " + name
+    got.breakdown = got.expand_breakdown()  # what TaskPlan.Export stamps on every task (planner.go:475)
+    compare.queue_properties(b, got)
+    compare.reference_validity(b, got)
+
+
 def test_big_distro_wide_value_range_falls_back(native_ctx, oracle):
     """A value range beyond 55 bits cannot be packed: the comparator sort of the generic path runs instead."""
     b = gen.generate(gen.GenConfig(9_000, 2, 808, with_hosts=False))
