@@ -72,12 +72,33 @@ struct PlanArgs {
   void *w_keyA, *w_keyB;       // 192-bit sort keys, ping-pong
   unsigned long long* w_gfirst;  // [D + n_tg] (first queue position << 32) | TaskGroupMaxHosts of that task
   unsigned long long* w_tgbit;   // one bit per row of every row tile: the row is a task-group task
+  uint32_t* w_srank;             // [row tiles x 64] rank of every sample key of a sorted tile among ALL keys of its distro
+  int32_t tiled_mode;            // TM_* bits (EVG_TILED_MODE; 0 = default)
   int32_t d0, d1;      // the distros this call plans: [d0, d1) of the batch (evg_plan_distro_range_device; else 0, D).
                        // Outputs keep the FULL batch's row / info-row numbering.
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts;  // [D][16] s_memtime stamps at the phase boundaries (scripts/phase_timing.py)
+  unsigned long long* dbg_tiled;  // [64] cycles between the marks of the large-distro kernels, summed over workgroups; [64..128) counts
 #endif
 };
+
+// Diagnostics build only (scripts/tiled_timing.py): thread 0 of every workgroup adds the cycles since its previous mark
+// to slot k (no barriers added: it is wave 0's own progress).
+#ifdef EVG_PHASE_TIMING
+#define TT_BEGIN() unsigned long long tt_prev_ = __builtin_amdgcn_s_memtime()
+#define TT_MARK(k)                                                                                              \
+  do {                                                                                                          \
+    if (threadIdx.x == 0 && a.dbg_tiled) {                                                                      \
+      const unsigned long long tt_now_ = __builtin_amdgcn_s_memtime();                                          \
+      atomicAdd(&a.dbg_tiled[(k)], tt_now_ - tt_prev_);                                                         \
+      atomicAdd(&a.dbg_tiled[64 + (k)], 1ull);                                                                  \
+      tt_prev_ = tt_now_;                                                                                       \
+    }                                                                                                           \
+  } while (0)
+#else
+#define TT_BEGIN() do {} while (0)
+#define TT_MARK(k) do {} while (0)
+#endif
 
 #ifdef EVG_PHASE_TIMING
 #define EVG_STAMP(k)                                                                                   \

@@ -389,9 +389,11 @@ struct evg_ctx {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool tiled_attr_set = false;
   bool dispatch_attr_set = false;
+  int tiled_mode = 0;  // EVG_TILED_MODE: TM_* bits (evg_tiled.hip.h), A/B runs of the large-distro pipeline's per-row / pairwise forms
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts = nullptr;
   unsigned long long* dbg_ts_alloc = nullptr;
+  unsigned long long* dbg_tiled = nullptr;
 #endif
 };
 
@@ -509,6 +511,7 @@ int32_t evg_abi_version(void) { return (1 << 16) | 2; }
 // diagnostics build only (scripts/phase_timing.py): device buffer of D x 16 s_memtime stamps
 void evg_dbg_phase_buffer(evg_ctx* c, void* dev_ptr) { c->dbg_ts = (unsigned long long*)dev_ptr; }
 void evg_dbg_alloc_phase_buffer(evg_ctx* c, void* dev_ptr) { c->dbg_ts_alloc = (unsigned long long*)dev_ptr; }
+void evg_dbg_tiled_buffer(evg_ctx* c, void* dev_ptr) { c->dbg_tiled = (unsigned long long*)dev_ptr; }  // 128 words
 #endif
 
 const char* evg_last_error(const evg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -540,6 +543,7 @@ evg_ctx* evg_create(int device_ordinal) {
 #ifdef EVG_WITH_WIDE
   if (const char* w = getenv("EVG_PLAN_WIDE")) c->wide = w[0] == '1';
 #endif
+  if (const char* m = getenv("EVG_TILED_MODE")) c->tiled_mode = atoi(m);
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     set_err(nullptr, EVG_E_HIP, "cannot create a stream on device %d", device_ordinal);
     delete c;
@@ -763,8 +767,11 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.w_key = c->scratch[21].p;
   a.w_ts = nullptr; a.w_rtile = nullptr; a.w_stile = nullptr; a.w_ntile = nullptr; a.w_bucket = nullptr; a.w_rec = nullptr;
   a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr; a.w_tgbit = nullptr;
+  a.w_srank = nullptr;
+  a.tiled_mode = c->tiled_mode;
 #ifdef EVG_PHASE_TIMING
   a.dbg_ts = c->dbg_ts;
+  a.dbg_tiled = c->dbg_tiled;
 #endif
   if (!c->lds_attr_set) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
@@ -832,16 +839,30 @@ static int prepare_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_
   return EVG_OK;
 }
 
+// Row tiles / slot tiles the large distros of a batch can have (host-known totals): only a distro of more than kRT rows is
+// tiled, so it has at most 2 n / kRT row tiles and (its slots are at most 2 n) 2.5 n / kST... slot tiles -- whatever D is.
+static size_t tiled_max_row_tiles(const evg_plan_input* in) {
+  const size_t N = (size_t)in->tasks.n_tasks, D = (size_t)in->n_distros;
+  return std::min(N / evg::kRT + D + 1, 2 * N / evg::kRT + 1);
+}
+static size_t tiled_max_slot_tiles(const evg_plan_input* in) {
+  const size_t N = (size_t)in->tasks.n_tasks, D = (size_t)in->n_distros;
+  const size_t Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions;
+  return std::min(Stot / evg::kST + D + 1, 5 * N / (2 * evg::kST) + 1);
+}
+
 // Scratch of the tiled large-distro path (evg_tiled.hip.h); sized from host-known totals, allocated on first need.
-static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in) {
+static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, bool pairwise) {
   using namespace evg;
   const size_t N = (size_t)in->tasks.n_tasks, E = (size_t)in->tasks.n_edges, D = (size_t)in->n_distros;
-  const size_t Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions, G = D + (size_t)in->n_task_groups;
-  const size_t max_rt = N / kRT + D + 1, max_st = Stot / kST + D + 1;
+  const size_t G = D + (size_t)in->n_task_groups;
+  const size_t max_rt = tiled_max_row_tiles(in), max_st = tiled_max_slot_tiles(in);
   const size_t st_cap = std::min<size_t>(max_st, kMaxST);  // slot tiles of ONE distro
-  const size_t sz[11] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
-                         4 * (E + 1), sizeof(K192) * max_rt * kRT, sizeof(K192) * max_rt * kRT, 8 * G, 8 * max_rt * (kRT / 64)};
-  for (int i = 0; i < 11; i++) {
+  // keyB is the pairwise merge passes' second buffer: only distros of more than kMaxWay tiles use it
+  const size_t sz[12] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
+                         4 * (E + 1), sizeof(K192) * max_rt * kRT, pairwise ? sizeof(K192) * max_rt * kRT : 16, 8 * G, 8 * max_rt * (kRT / 64),
+                         4 * max_rt * kSmpPerTile};
+  for (int i = 0; i < 12; i++) {
     int rc = ensure(c, c->scratch[32 + i], sz[i]);
     if (rc) return rc;
   }
@@ -850,10 +871,13 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
   a.w_eslot = (int32_t*)c->scratch[38].p; a.w_keyA = c->scratch[39].p; a.w_keyB = c->scratch[40].p;
   a.w_gfirst = (unsigned long long*)c->scratch[41].p;
   a.w_tgbit = (unsigned long long*)c->scratch[42].p;
+  a.w_srank = (uint32_t*)c->scratch[43].p;
   if (!c->tiled_attr_set) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledReduceLds));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_elect, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_merge, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_srank, hipFuncAttributeMaxDynamicSharedMemorySize, kSrankLds));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_mmerge, hipFuncAttributeMaxDynamicSharedMemorySize, kMmergeLds));
     c->tiled_attr_set = true;
   }
   return EVG_OK;
@@ -863,9 +887,10 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
 // unconditionally and exits at once where there is no work). evg_plan_input.max_distro_tasks (0 = unknown) only shapes
 // the launch, never the result:
 //   hint <= 2048  only data-dependent fallbacks can be flagged: ONE kernel, one workgroup per flagged distro (k_plan_generic);
-//   otherwise     the tiled pipeline (evg_tiled.hip.h, many workgroups per distro) with the number of merge passes the hint
-//                 (or, without a hint, the task count) allows, then k_plan_generic for whatever the pipeline left: small
-//                 flagged distros, distros it cannot take, and distros larger than the hint promised.
+//   otherwise     the tiled pipeline (evg_tiled.hip.h, many workgroups per distro): distros of up to kMaxWay row tiles
+//                 (65,536 rows) are merged by ONE multiway pass; for larger ones the pairwise merge passes the hint (or,
+//                 without a hint, the task count) allows are enqueued too. Then k_plan_generic for whatever the pipeline
+//                 left: small flagged distros, distros it cannot take, and distros larger than the hint promised.
 // TaskPlan.Len() (out->n_units) needs the set-equality pass that only the one-workgroup kernel has.
 static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st) {
   using namespace evg;
@@ -877,17 +902,22 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
     HIP_TRY(c, hipGetLastError());
     return EVG_OK;
   }
-  int rc = prepare_tiled(c, a, in);
-  if (rc) return rc;
   const long long cap = hint < kTiledMaxRows ? hint : kTiledMaxRows - 1;
   int passes = 0;
-  while (((long long)kRT << passes) < cap) passes++;
-  const size_t N = (size_t)in->tasks.n_tasks, Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions;
-  const dim3 rt((unsigned)(N / kRT + D + 1)), stl((unsigned)(Stot / kST + D + 1)), tb(kTiledBlock);
+  if (cap > (long long)kMaxWay * kRT || !(a.tiled_mode & TM_MULTIWAY_MERGE))
+    while (((long long)kRT << passes) < cap) passes++;
+  int rc = prepare_tiled(c, a, in, passes > 0);
+  if (rc) return rc;
+  // + 8: the XCD-aware tile mapping (xcd_tile) rounds the tile count up to a multiple of the 8 XCDs
+  const dim3 rt((unsigned)tiled_max_row_tiles(in) + 8), stl((unsigned)tiled_max_slot_tiles(in) + 8), tb(kTiledBlock);
   hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, st, a, passes);
   hipLaunchKernelGGL(k_tiled_scatter, rt, tb, 0, st, a);
   hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, st, a);
   hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, st, a);
+  if (a.tiled_mode & TM_MULTIWAY_MERGE) {
+    hipLaunchKernelGGL(k_tiled_srank, rt, tb, kSrankLds, st, a);
+    hipLaunchKernelGGL(k_tiled_mmerge, rt, tb, kMmergeLds, st, a);
+  }
   for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, st, a, p);
   hipLaunchKernelGGL(k_tiled_rows, gg, dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 1);

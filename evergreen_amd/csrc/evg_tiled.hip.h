@@ -17,11 +17,22 @@
 //   T3 k_tiled_elect    per row tile: each row's emitting unit (TaskPlan.Export's first-occurrence dedup, planner.go:462-481),
 //                       ONE 192-bit key [value desc | unit min row | unit slot | TaskList.Less key | row] per row -- the
 //                       final queue order is the plain ascending order of these keys -- and the tile sorted in LDS
-//   T4 k_tiled_merge    log2(tiles) passes of merge-path: every workgroup produces 2048 consecutive outputs of the merge of
-//                       two sorted runs (wave-wide 64-ary diagonal search, then one 11-stage bitonic merge in registers/LDS)
-//   T5 (tail of T4's last pass) queue order out; first queue position of every task group (TaskGroupInfo.MaxHosts,
-//                       scheduler.go:103-106) -- the last pass's merged keys never go back to memory
+//   T4 k_tiled_srank    (distros of up to 32 sorted tiles = 65,536 rows) every 32nd key of every sorted tile is a SAMPLE; the
+//      k_tiled_mmerge   exact rank of each sample in the whole distro and its lower bound in every tile (k_tiled_srank), then
+//                       ONE multiway pass: the workgroup of output window [2048 w, 2048 (w + 1)) finds the window's exact
+//                       split of every tile from the samples (the sample of largest rank <= the boundary + at most 33
+//                       candidates per tile, ranked in LDS), loads its <= 32 segments (2048 keys) and ranks every key by
+//                       binary searches over the other segments -- log2(tiles) merge passes and their key traffic are gone
+//      k_tiled_merge    (larger distros) log2(tiles) passes of merge-path: every workgroup produces 2048 consecutive outputs
+//                       of the merge of two sorted runs (wave-wide 64-ary diagonal search, one 11-stage bitonic merge)
+//   T5 (tail of T4)     queue order out; first queue position of every task group (TaskGroupInfo.MaxHosts,
+//                       scheduler.go:103-106) -- the merged keys never go back to memory
 //   T6 k_tiled_rows     model.DistroQueueInfo / the standalone TaskGroupInfo row
+//
+// T1 and T3 resolve a row tile's dependency edges EDGE-parallel into LDS first (the tile's edges are one contiguous CSR
+// range: coalesced loads, then one gather per edge) and only then walk the rows: a handful of dependent round trips per
+// workgroup instead of ~5 per row. Workgroups are mapped to tiles XCD-aware (xcd_tile): the tiles of one distro run on one
+// XCD, so the gathers into the distro's columns / unit values hit that XCD's L2.
 //
 // Device-scope atomics left: a handful per WORKGROUP (ranges, distro counters), one per task-group row in T5.
 // A distro this path cannot take (2^20 rows or more, priorities beyond int32, TaskList.Less ranges beyond 64 bits, more
@@ -34,11 +45,45 @@
 namespace evg {
 
 constexpr int kRT = 2048;             // rows per row tile == keys per sort tile
-constexpr int kST = 1024;             // unit slots per slot tile
-constexpr int kMaxST = 4096;          // slot tiles of one distro the scatter kernel can bucket in LDS
+constexpr int kST = 768;              // unit slots per slot tile: 64 B of accumulators each = 48 KB of LDS, three workgroups per CU
 constexpr int kTiledMaxRows = 1 << 20;
 constexpr int kTiledMaxSlots = 1 << 21;
+constexpr int kMaxST = (kTiledMaxSlots / kST + 511) / 512 * 512;  // slot tiles of one distro: the scatter kernel buckets them in LDS
 constexpr int kTiledBlock = 512;
+constexpr int kMaxWay = 32;           // sorted tiles one multiway pass merges; larger distros take the pairwise passes
+constexpr int kSmpStride = 32, kSmpPerTile = kRT / kSmpStride;  // sample = the last key of every 32-key block of a sorted tile
+constexpr int kCandWin = kSmpStride + 1;  // candidates per tile at a window boundary
+constexpr int kTileEdges = 6144;      // dependency edges of one row tile resolved edge-parallel in LDS (more: per row, from memory)
+// PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs): 1, 2 = the per-row forms of round 2; 4 = the one-pass multiway merge instead of the
+// pairwise passes; 8 = the rank-merge tile sort instead of the bitonic network (both measured equal or slower: DESIGN.md 3.1)
+constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2, TM_MULTIWAY_MERGE = 4, TM_RANK_MERGE_SORT = 8;
+
+// blockIdx -> tile, XCD-aware: workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; tile
+// (b % 8) * ceil(T / 8) + b / 8 gives every XCD a contiguous eighth of the tile list, i.e. whole distros. -1: no tile.
+__device__ __forceinline__ int xcd_tile(int b, int T, int mode = 0) {
+  if (mode & 16) return b < T ? b : -1;  // TM_LINEAR_TILES (A/B runs): consecutive tiles on consecutive XCDs
+  const int per = (T + 7) >> 3, w = (b & 7) * per + (b >> 3);
+  return (b >> 3) < per && w < T ? w : -1;
+}
+
+// Inclusive sum scan over the 512 threads of a workgroup: DPP row scans inside a wave, the eight wave totals through LDS
+// (two barriers instead of the eighteen of a Hillis-Steele scan over the workgroup). s_w: 8 ints of LDS.
+__device__ __forceinline__ int block_scan_sum(int v, int tid, int* s_w) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1, 2, 4, 8: inclusive inside the 16-lane row
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+  const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+  const int row = (tid & 63) >> 4;
+  v += (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+  __syncthreads();  // s_w may still be read from a previous scan
+  if ((tid & 63) == 63) s_w[tid >> 6] = v;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < kTiledBlock / 64; w++) base += w < (tid >> 6) ? s_w[w] : 0;
+  return v + base;
+}
 
 // ---- 192-bit sort key ------------------------------------------------------------------------------------------
 struct K192 {
@@ -66,8 +111,9 @@ constexpr uint32_t RW_QI = 1u << 16, RW_COUNT = 1u << 17, RW_MQ = 1u << 18, RW_W
 struct TState {
   int32_t on;       // the tiled path plans this distro
   int32_t unfit;    // set on the way: leave it to k_plan_generic after all
-  int32_t n_rt, n_st, rt_base, st_base, passes, pad0;
+  int32_t n_rt, n_st, rt_base, st_base, passes, way;  // way: one multiway merge pass (n_rt <= kMaxWay) instead of `passes`
   long long bucket_base;
+  unsigned long long vmin, vmax;                 // biased range of the valid units' TotalValue (k_tiled_reduce)
   unsigned long long dmin, dmax;                 // biased ranges of the TaskList.Less columns
   uint32_t tmin, tmax, nmin, nmax, pmin, pmax;
   uint32_t any_mq, n_met, n_mq, n_s3, sec;       // GetDistroQueueInfo: distro counters
@@ -129,12 +175,14 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
       const int n_rt = (n + kRT - 1) / kRT, n_st = (S + kST - 1) / kST;
       int passes = 0;
       while ((1 << passes) < n_rt) passes++;
-      if (S < kTiledMaxSlots && n_st <= kMaxST && passes <= passes_launched) {
-        t.on = 1; t.n_rt = n_rt; t.n_st = n_st; t.passes = passes;
+      const bool way = n_rt <= kMaxWay && (a.tiled_mode & TM_MULTIWAY_MERGE);  // one multiway pass instead of `passes`
+      if (S < kTiledMaxSlots && n_st <= kMaxST && (way || passes <= passes_launched)) {
+        t.on = 1; t.n_rt = n_rt; t.n_st = n_st; t.passes = way ? 0 : passes; t.way = way ? 1 : 0;
         rt += n_rt; st += n_st; bk += (long long)n_rt * n_st;
       }
     }
     t.dmin = ~0ull; t.tmin = t.nmin = t.pmin = ~0u;
+    t.vmin = ~0ull;
     t.s_first = ~0ull;
     a.w_ts[d] = t;
   }
@@ -163,21 +211,48 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
 }
 
 // ---- T1: rows -> records ---------------------------------------------------------------------------------------
-struct RowMem {  // what pass 2 needs of a row
-  int64_t tiq, dur;
-  int32_t pri, nd, t0, t1, e0, e1;
-  uint32_t bits;  // unit flags (UF_* >> 24) << 10 | RW_* of the row's own task-group record
-  bool live, own;
+struct RowMem {  // what pass 2 keeps of a row in registers (it re-reads the four accumuland columns: 20 registers instead of 44
+                 // for the thread's four rows, which is what lets three workgroups share a CU)
+  int32_t t0, t1, e0, e1;
+  uint32_t bits;  // unit flags (UF_* >> 24) << 10 | RW_* of the row's own task-group record | RM_LIVE | RM_OWN
 };
+constexpr uint32_t RM_LIVE = 1u << 30, RM_OWN = 1u << 31;
 
-__global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a) {
+// One dependency edge resolved: bits 0-20 the unit slot of a dependency that is in this distro's queue (SE_INQ;
+// planner.go:451-455), SE_SAT the edge is satisfied (Task.SatisfiesDependency task.go:546-561; a dependency that is neither
+// in the queue nor in the database never is, scheduler.go:180-186).
+constexpr uint32_t SE_SLOT = 0x1FFFFFu, SE_INQ = 1u << 29, SE_SAT = 1u << 30;
+__device__ __forceinline__ uint32_t tiled_edge(const evg_task_soa& t, const DC& c, int e) {
+  const int j = t.dep_idx[e] - c.lo;
+  const uint32_t info = t.dep_info[e];
+  uint32_t st, rec = 0;
+  bool blk, known = true;
+  if ((unsigned)j < (unsigned)c.n) {
+    const uint32_t fj = (uint32_t)t.flags[c.lo + j];
+    const int tgj = t.tg_key[c.lo + j];
+    const int verj = c.gv && tgj < 0 ? t.version_key[c.lo + j] : c.ver_lo;
+    st = (fj & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT;
+    blk = fj & EVG_TF_BLOCKED;
+    rec = SE_INQ | (uint32_t)(tgj >= 0 ? c.tg_base + (tgj - c.tg_lo) : c.gv ? c.ver_base + (verj - c.ver_lo) : j);
+  } else {
+    st = (info & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT;
+    blk = info & EVG_DEP_BLOCKED;
+    known = !(info & EVG_DEP_MISSING);
+  }
+  const uint32_t req = info & EVG_DEP_REQ_MASK;
+  const bool sat = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
+  return rec | (sat && known ? SE_SAT : 0u);
+}
+
+__global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs a) {
   __shared__ int s_cnt[kMaxST];
-  __shared__ int s_part[kTiledBlock];
+  __shared__ int s_part[8];
+  __shared__ uint32_t s_edge[kTileEdges];  // the tile's dependency edges, resolved (tiled_edge); then each row's FINAL slots
   __shared__ unsigned long long s_u64[8];  // 0 dmin 1 dmax 2 s_dur 3 s_dover_hi 4 s_dover_lo
   __shared__ uint32_t s_u32[20];           // 0 tmin 1 tmax 2 nmin 3 nmax 4 pmin 5 pmax 6 any_mq 7 n_met 8 n_mq 9 n_s3 10 sec 11 s_cnt 12 s_mq
                                            // 13 s_cover_hi 14 s_cover_lo 15 s_wait_hi 16 s_wait_lo 17 wide priority
-  const int w = blockIdx.x;
-  if (w >= a.w_ntile[0]) return;
+  const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);
+  if (w < 0) return;
   const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
   TState* ts = &a.w_ts[d];
   const DC c = tiled_context(a, d);
@@ -186,34 +261,43 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int n_st = ts->n_st;
   const int lo = c.lo, n = c.n;
+  // ---- the tile's dependency edges: one contiguous CSR range, resolved edge-parallel into LDS (coalesced index loads, one
+  // gather of the dependency's columns per edge: two round trips for the whole tile instead of two per row) ----
+  const int i_end = (tile + 1) * kRT < n ? (tile + 1) * kRT : n;
+  const int E0 = t.dep_off[lo + tile * kRT], E1 = t.dep_off[lo + i_end];
+  TT_BEGIN();
+  const bool eL = E1 - E0 <= kTileEdges && !(a.tiled_mode & TM_ROW_SCATTER);
+  if (eL)
+    for (int x = tid; x < E1 - E0; x += kTiledBlock) s_edge[x] = tiled_edge(t, c, E0 + x);
   for (int j = tid; j < n_st; j += kTiledBlock) s_cnt[j] = 0;
   if (tid < 8) s_u64[tid] = tid == 0 ? ~0ull : 0ull;
   if (tid < 20) s_u32[tid] = (tid == 0 || tid == 2 || tid == 4) ? ~0u : 0u;
   __syncthreads();
+  TT_MARK(12);
   const bool incl = p.includes_dependencies != 0;
   const int64_t Thi = target_hi(p), Tlo = target_lo(p);
 
   RowMem rm[4];
   uint64_t r_dmin = ~0ull, r_dmax = 0, x_dur = 0, x_dover_hi = 0, x_dover_lo = 0;
   uint32_t r_tmin = ~0u, r_tmax = 0, r_nmin = ~0u, r_nmax = 0, r_pmin = ~0u, r_pmax = 0;
-  uint32_t any_mq = 0, n_met = 0, n_mq = 0, n_s3 = 0, sec = 0, x_cnt = 0, x_mq = 0, x_cover_hi = 0, x_cover_lo = 0, x_wait_hi = 0, x_wait_lo = 0, wide = 0;
+  // the twelve small counters of a thread's four rows, four bits each, in one word (fields below)
+  uint64_t pk = 0;
+  constexpr int F_ANY_MQ = 0, F_MET = 4, F_MQ = 8, F_S3 = 12, F_SEC = 16, F_CNT = 20, F_XMQ = 24, F_COVER_HI = 28, F_COVER_LO = 32, F_WAIT_HI = 36,
+                F_WAIT_LO = 40, F_WIDE = 44;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int i = tile * kRT + k * kTiledBlock + tid;
     RowMem& m = rm[k];
-    m.live = i < n;
-    m.own = false; m.tiq = 0; m.dur = 0; m.pri = 0; m.nd = 0; m.t0 = 0; m.t1 = -1; m.e0 = 0; m.e1 = 0; m.bits = 0;
-    if (!m.live) continue;
+    m.t0 = 0; m.t1 = -1; m.e0 = 0; m.e1 = 0; m.bits = 0;
+    if (i >= n) continue;
     const int r = lo + i;
     const int tgk = t.tg_key[r], verk = t.version_key[r];
     const uint32_t f = t.flags[r];
     const int64_t pri = t.priority[r], dur = t.expected_duration_ns[r], qts = t.queue_ts_ns[r];
     const int32_t nd = t.num_dependents[r], tgo = t.task_group_order[r];
-    if (pri != (int64_t)(int32_t)pri) wide = 1;
-    m.tiq = qts == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, qts);
-    m.dur = dur;
-    m.pri = pri > 0 ? (int32_t)pri : 0;
-    m.nd = nd > 0 ? nd : 0;
+    const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
+    const int64_t dmt = t.deps_met_ts_ns[r], sched = t.scheduled_ts_ns[r];
+    if (pri != (int64_t)(int32_t)pri) pk |= 1ull << F_WIDE;
     const uint32_t rc = f & EVG_TF_REQ_MASK;
     uint32_t uf = rc == EVG_TF_REQ_MERGE ? UF_MERGE : rc == EVG_TF_REQ_PATCH ? UF_PATCH : 0u;
     uf |= tgk < 0 ? UF_NONGROUP : 0u;
@@ -221,7 +305,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a)
     uf |= (f & EVG_TF_STEPBACK) ? UF_STEPBACK : 0u;
     m.t0 = pslot_of(i, tgk, verk, c);
     m.t1 = c.gv && tgk >= 0 ? c.ver_base + (verk - c.ver_lo) : -1;
-    m.own = !c.gv && tgk < 0;  // its own unit: initialised by the slot tile that holds it (k_tiled_reduce), no record
+    const bool own = !c.gv && tgk < 0;  // its own unit: initialised by the slot tile that holds it (k_tiled_reduce), no record
     a.w_pslot[r] = (uint32_t)m.t0;
     // ranges of the TaskList.Less columns (planner.go:386-405)
     {
@@ -233,73 +317,26 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a)
       r_pmin = up < r_pmin ? up : r_pmin; r_pmax = up > r_pmax ? up : r_pmax;
     }
     // ---- the row's dependency edges: the unit slot each one adds a membership to (-1: none), checkDependenciesMet ----
-    const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
     m.e0 = e0; m.e1 = e1;
-    const int64_t dmt = t.deps_met_ts_ns[r];
     bool met = (e1 == e0) || (f & EVG_TF_OVERRIDE_DEPS) || !is_zero_time(dmt);  // HasDependenciesMet task.go:3406
     bool all = true;
     int prev0 = -1, prev1 = -1, prev2 = -1, prev3 = -1;  // unit slots the row's last four edges named (-1: none)
-    // The row's first three edges are fetched together, and so are the dependency rows' columns they point at: two round
-    // trips for the row instead of two per edge (the kernel is bound by these chains of dependent loads).
-    constexpr int kFast = 3;
-    int pj[kFast], ptg[kFast], pver[kFast];
-    uint32_t pinfo[kFast], pfl[kFast];
-#pragma unroll
-    for (int q = 0; q < kFast; q++) {
-      const bool has = e0 + q < e1;
-      pj[q] = has ? t.dep_idx[e0 + q] - lo : -1;
-      pinfo[q] = has ? (uint32_t)t.dep_info[e0 + q] : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < kFast; q++) {
-      const bool inq = (unsigned)pj[q] < (unsigned)n;
-      const int rj = lo + (inq ? pj[q] : 0);
-      pfl[q] = inq ? (uint32_t)t.flags[rj] : 0u;
-      ptg[q] = inq ? t.tg_key[rj] : -1;
-      pver[q] = inq && c.gv ? t.version_key[rj] : c.ver_lo;
-    }
     for (int e = e0; e < e1; e++) {
-      const int q = e - e0;
-      int j, tgj, verj = c.ver_lo;
-      uint32_t info, fj = 0;
-      if (q < kFast) {
-        j = q == 0 ? pj[0] : q == 1 ? pj[1] : pj[2]; info = q == 0 ? pinfo[0] : q == 1 ? pinfo[1] : pinfo[2];
-        fj = q == 0 ? pfl[0] : q == 1 ? pfl[1] : pfl[2]; tgj = q == 0 ? ptg[0] : q == 1 ? ptg[1] : ptg[2];
-        verj = q == 0 ? pver[0] : q == 1 ? pver[1] : pver[2];
-      } else {
-        j = t.dep_idx[e] - lo;
-        info = t.dep_info[e];
-        tgj = -1;
-        if ((unsigned)j < (unsigned)n) {
-          fj = (uint32_t)t.flags[lo + j];
-          tgj = t.tg_key[lo + j];
-          if (c.gv) verj = t.version_key[lo + j];
-        }
-      }
-      uint32_t st;
-      bool blk;
-      int sl = -1;
-      if ((unsigned)j < (unsigned)n) {
-        st = (fj & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT;
-        blk = fj & EVG_TF_BLOCKED;
-        sl = tgj >= 0 ? c.tg_base + (tgj - c.tg_lo) : c.gv ? c.ver_base + (verj - c.ver_lo) : j;
+      const uint32_t rec = eL ? s_edge[e - E0] : tiled_edge(t, c, e);
+      all &= (rec & SE_SAT) != 0;
+      int sl = (rec & SE_INQ) ? (int)(rec & SE_SLOT) : -1;
+      if (sl >= 0) {
         if (sl == m.t0 || sl == m.t1) sl = -1;  // Unit.Add is keyed by task id (planner.go:131): already a member
         // named by an earlier edge of this row? The last four ride in registers; only a row with more than four
-        // dependencies reads its older ones back (its own stores: a round trip through memory each)
+        // dependencies reads its older ones back (its own FINAL slots)
         if (sl == prev0 || sl == prev1 || sl == prev2 || sl == prev3) sl = -1;
         for (int e2 = e0; sl >= 0 && e2 < e - 4; e2++)
-          if (a.w_eslot[e2] == sl) sl = -1;
-      } else {
-        st = (info & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT;
-        blk = info & EVG_DEP_BLOCKED;
-        if (info & EVG_DEP_MISSING) all = false;
+          if ((eL ? (int)s_edge[e2 - E0] : a.w_eslot[e2]) == sl) sl = -1;
       }
       a.w_eslot[e] = sl;
+      if (eL) s_edge[e - E0] = (uint32_t)sl;
       prev3 = prev2; prev2 = prev1; prev1 = prev0; prev0 = sl;
       if (sl >= 0) atomicAdd(&s_cnt[sl / kST], 1);
-      const uint32_t req = info & EVG_DEP_REQ_MASK;  // SatisfiesDependency task.go:546-561
-      const bool sat = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
-      all &= sat;
     }
     int64_t mettime = dmt;
     if (!met && all) {
@@ -319,33 +356,39 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a)
     int64_t wait = 0;
     bool w_hi = false, w_lo = false;
     if (count && met) {
-      int64_t start = t.scheduled_ts_ns[r];
+      int64_t start = sched;
       if (mettime > start) start = mettime;  // DependenciesMetTime.After(startTime)
       wait = time_sub(c.now, start);
       w_hi = wait > Thi; w_lo = wait > Tlo;
     }
     a.out.deps_met[r] = met ? 1 : 0;
     a.out.wait_ns[r] = wait;
-    if (f & EVG_TF_OTHER_DISTRO) sec = 1;
-    if (met) { n_met++; if (merge) { n_mq++; any_mq = 1; } if (f & EVG_TF_S3_STORAGE) n_s3++; }
+    if (f & EVG_TF_OTHER_DISTRO) pk |= (pk >> F_SEC) & 1ull ? 0ull : 1ull << F_SEC;
+    if (met) {
+      pk += 1ull << F_MET;
+      if (merge) { pk += 1ull << F_MQ; pk |= (pk >> F_ANY_MQ) & 1ull ? 0ull : 1ull << F_ANY_MQ; }
+      if (f & EVG_TF_S3_STORAGE) pk += 1ull << F_S3;
+    }
     uint32_t qi = 0;
     if (tgk < 0) {
-      x_cnt += count; x_dur += count ? (uint64_t)dur : 0; x_mq += (met && merge);
+      x_dur += count ? (uint64_t)dur : 0;
       const bool o_hi = count && dur > Thi, o_lo = count && dur > Tlo;
-      x_cover_hi += o_hi; x_cover_lo += o_lo; x_dover_hi += o_hi ? (uint64_t)dur : 0; x_dover_lo += o_lo ? (uint64_t)dur : 0;
-      x_wait_hi += w_hi; x_wait_lo += w_lo;
+      x_dover_hi += o_hi ? (uint64_t)dur : 0; x_dover_lo += o_lo ? (uint64_t)dur : 0;
+      pk += ((uint64_t)count << F_CNT) + ((uint64_t)(met && merge) << F_XMQ) + ((uint64_t)o_hi << F_COVER_HI) + ((uint64_t)o_lo << F_COVER_LO) +
+            ((uint64_t)w_hi << F_WAIT_HI) + ((uint64_t)w_lo << F_WAIT_LO);
     } else {
       qi = RW_QI | (count ? RW_COUNT : 0u) | ((met && merge) ? RW_MQ : 0u) | (w_hi ? RW_WAIT_HI : 0u) | (w_lo ? RW_WAIT_LO : 0u);
     }
-    m.bits = ((uf >> 24) << 10) | qi;
-    if (!m.own) atomicAdd(&s_cnt[m.t0 / kST], 1);
+    m.bits = ((uf >> 24) << 10) | qi | RM_LIVE | (own ? RM_OWN : 0u);
+    if (!own) atomicAdd(&s_cnt[m.t0 / kST], 1);
     if (m.t1 >= 0) atomicAdd(&s_cnt[m.t1 / kST], 1);
   }
-  // one bit per row: is it a task-group task? (the tail of the last merge pass classifies the rows it meets in QUEUE order with this -- a
+  TT_MARK(13);
+  // one bit per row: is it a task-group task? (the tail of the merge classifies the rows it meets in QUEUE order with this -- a
   // 2.4 KB table per 19.5k-row distro that stays in cache -- instead of gathering tg_key by row)
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const unsigned long long bits = __ballot(rm[k].live && !(rm[k].bits & (((UF_NONGROUP >> 24)) << 10)));
+    const unsigned long long bits = __ballot((rm[k].bits & RM_LIVE) && !(rm[k].bits & (((UF_NONGROUP >> 24)) << 10)));
     if (lane == 0) a.w_tgbit[((size_t)ts->rt_base + tile) * (kRT / 64) + (k * kTiledBlock + tid) / 64] = bits;
   }
   // ---- per-workgroup reductions -> a few device atomics ----
@@ -353,18 +396,24 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a)
   r_tmin = wave_min(r_tmin); r_tmax = wave_max(r_tmax); r_nmin = wave_min(r_nmin); r_nmax = wave_max(r_nmax);
   r_pmin = wave_min(r_pmin); r_pmax = wave_max(r_pmax);
   x_dur = wave_sum(x_dur); x_dover_hi = wave_sum(x_dover_hi); x_dover_lo = wave_sum(x_dover_lo);
-  any_mq = wave_max(any_mq); n_met = wave_sum(n_met); n_mq = wave_sum(n_mq); n_s3 = wave_sum(n_s3); sec = wave_max(sec);
-  x_cnt = wave_sum(x_cnt); x_mq = wave_sum(x_mq); x_cover_hi = wave_sum(x_cover_hi); x_cover_lo = wave_sum(x_cover_lo);
-  x_wait_hi = wave_sum(x_wait_hi); x_wait_lo = wave_sum(x_wait_lo); wide = wave_max(wide);
+  // the packed counters: four bits per field and thread (at most 4 each) -> three words of 16-bit fields for the wave sums
+  auto spread = [&](int first) -> uint64_t {
+    return ((pk >> first) & 0xFull) | (((pk >> (first + 4)) & 0xFull) << 16) | (((pk >> (first + 8)) & 0xFull) << 32) | (((pk >> (first + 12)) & 0xFull) << 48);
+  };
+  const uint64_t sA = wave_sum(spread(0)), sB = wave_sum(spread(16)), sC = wave_sum(spread(32));
+  const uint32_t any_mq = (uint32_t)(sA & 0xFFFF), n_met = (uint32_t)((sA >> 16) & 0xFFFF), n_mq = (uint32_t)((sA >> 32) & 0xFFFF), n_s3 = (uint32_t)(sA >> 48);
+  const uint32_t sec = (uint32_t)(sB & 0xFFFF), x_cnt = (uint32_t)((sB >> 16) & 0xFFFF), x_mq = (uint32_t)((sB >> 32) & 0xFFFF), x_cover_hi = (uint32_t)(sB >> 48);
+  const uint32_t x_cover_lo = (uint32_t)(sC & 0xFFFF), x_wait_hi = (uint32_t)((sC >> 16) & 0xFFFF), x_wait_lo = (uint32_t)((sC >> 32) & 0xFFFF),
+                 wide = (uint32_t)(sC >> 48);
   if (lane == 0) {
     atomicMin(&s_u64[0], (unsigned long long)r_dmin); atomicMax(&s_u64[1], (unsigned long long)r_dmax);
     atomicAdd(&s_u64[2], (unsigned long long)x_dur); atomicAdd(&s_u64[3], (unsigned long long)x_dover_hi);
     atomicAdd(&s_u64[4], (unsigned long long)x_dover_lo);
     atomicMin(&s_u32[0], r_tmin); atomicMax(&s_u32[1], r_tmax); atomicMin(&s_u32[2], r_nmin); atomicMax(&s_u32[3], r_nmax);
     atomicMin(&s_u32[4], r_pmin); atomicMax(&s_u32[5], r_pmax);
-    atomicOr(&s_u32[6], any_mq); atomicAdd(&s_u32[7], n_met); atomicAdd(&s_u32[8], n_mq); atomicAdd(&s_u32[9], n_s3); atomicOr(&s_u32[10], sec);
+    atomicOr(&s_u32[6], any_mq ? 1u : 0u); atomicAdd(&s_u32[7], n_met); atomicAdd(&s_u32[8], n_mq); atomicAdd(&s_u32[9], n_s3); atomicOr(&s_u32[10], sec ? 1u : 0u);
     atomicAdd(&s_u32[11], x_cnt); atomicAdd(&s_u32[12], x_mq); atomicAdd(&s_u32[13], x_cover_hi); atomicAdd(&s_u32[14], x_cover_lo);
-    atomicAdd(&s_u32[15], x_wait_hi); atomicAdd(&s_u32[16], x_wait_lo); atomicOr(&s_u32[17], wide);
+    atomicAdd(&s_u32[15], x_wait_hi); atomicAdd(&s_u32[16], x_wait_lo); atomicOr(&s_u32[17], wide ? 1u : 0u);
   }
   __syncthreads();
   if (tid == 0) {
@@ -396,15 +445,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a)
     loc[q] = j < n_st ? s_cnt[j] : 0;
     sum += loc[q];
   }
-  s_part[tid] = sum;
-  __syncthreads();
-  for (int o = 1; o < kTiledBlock; o <<= 1) {
-    const int x = tid >= o ? s_part[tid - o] : 0;
-    __syncthreads();
-    s_part[tid] += x;
-    __syncthreads();
-  }
-  int run = s_part[tid] - sum;
+  int run = block_scan_sum(sum, tid, s_part) - sum;
   int2* bucket = (int2*)a.w_bucket + ts->bucket_base + (long long)tile * n_st;
 #pragma unroll
   for (int q = 0; q < kPer; q++) {
@@ -413,37 +454,47 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_scatter(const PlanArgs a)
     run += loc[q];
   }
   __syncthreads();
+  TT_MARK(14);
   // ---- pass 2: the records ----
   TRec* rec = (TRec*)a.w_rec + rec_region(a, c, tile);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const RowMem& m = rm[k];
-    if (!m.live) continue;
+    if (!(m.bits & RM_LIVE)) continue;
     const int i = tile * kRT + k * kTiledBlock + tid;
+    const bool any = !(m.bits & RM_OWN) || m.e1 > m.e0;  // a stand-alone row without dependencies emits nothing
+    if (!any) continue;
+    // the row's Unit.info contribution (planner.go:302-337), from its columns again
+    const int r = lo + i;
+    const int64_t qts = t.queue_ts_ns[r], dur = t.expected_duration_ns[r], pri64 = t.priority[r];
+    const int32_t nd0 = t.num_dependents[r];
+    const int64_t tiq = qts == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, qts);
+    const int32_t pri = pri64 > 0 ? (int32_t)pri64 : 0, nd = nd0 > 0 ? nd0 : 0;
     const uint32_t uf10 = m.bits & (0x3Fu << 10), qi = m.bits & (RW_QI | RW_COUNT | RW_MQ | RW_WAIT_HI | RW_WAIT_LO);
     auto emit = [&](int sl, uint32_t bits) {
       const int pos = atomicAdd(&s_cnt[sl / kST], 1);
-      rec[pos] = TRec{m.tiq, m.dur, (uint32_t)(sl % kST) | bits, (uint32_t)i, m.pri, m.nd};
+      rec[pos] = TRec{tiq, dur, (uint32_t)(sl % kST) | bits, (uint32_t)i, pri, nd};
     };
-    if (!m.own) emit(m.t0, uf10 | ((UF_DISTRO >> 24) << 10) | qi);  // SetDistro only via the primary key (planner.go:447)
+    if (!(m.bits & RM_OWN)) emit(m.t0, uf10 | ((UF_DISTRO >> 24) << 10) | qi);  // SetDistro only via the primary key (planner.go:447)
     if (m.t1 >= 0) emit(m.t1, uf10);
     for (int e = m.e0; e < m.e1; e++) {
-      const int sl = a.w_eslot[e];
+      const int sl = eL ? (int)s_edge[e - E0] : a.w_eslot[e];
       if (sl >= 0) emit(sl, uf10);
     }
   }
+  TT_MARK(15);
 }
 
 // ---- T2: records -> Unit.info -> unitInfo.value(); TaskGroupInfo sums ---------------------------------------------
 constexpr int kTiledReduceLds = 64 * kST;
 __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_pref[kTiledBlock + 1];
+  __shared__ int s_pref[kTiledBlock + 1], s_w8[8];
   __shared__ long long s_base[kTiledBlock];
-  __shared__ unsigned long long s_t64[2];
+  __shared__ unsigned long long s_t64[4];  // 0 t_dur 1 t_dover 2 vmin 3 vmax
   __shared__ uint32_t s_t32[2];
-  const int w = blockIdx.x;
-  if (w >= a.w_ntile[1]) return;
+  const int w = xcd_tile(blockIdx.x, a.w_ntile[1], a.tiled_mode);
+  if (w < 0) return;
   const int d = a.w_stile[2 * w], j = a.w_stile[2 * w + 1];
   TState* ts = &a.w_ts[d];
   if (!tiled_live(ts)) return;
@@ -464,6 +515,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
   const bool has_mq = ts->any_mq != 0;
   const int64_t T = has_mq ? target_lo(p) : target_hi(p);
   const uint32_t wait_bit = has_mq ? RW_WAIT_LO : RW_WAIT_HI;
+  TT_BEGIN();
   // ---- init: a stand-alone row's own unit starts with that row (plain stores); everything else empty ----
   for (int u = tid; u < ns; u += kTiledBlock) {
     const int su = s0 + u;
@@ -489,6 +541,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     m_tiq[u] = tq; m_dur[u] = du; m_maxpri[u] = mp; m_cnt[u] = cw; m_maxnd[u] = mn; m_minrow[u] = mr;
     g_dur[u] = 0; g_dover[u] = 0; g_cnt[u] = 0; g_cover[u] = 0; g_wait[u] = 0; g_mq[u] = 0;
   }
+  TT_MARK(16);
   // ---- where this tile's records are: one bucket per source row tile ----
   const int n_rt = ts->n_rt;
   const int2* bucket = (const int2*)a.w_bucket + ts->bucket_base + j;
@@ -498,15 +551,10 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     mine = b.y;
     s_base[tid] = rec_region(a, c, tid) + b.x;
   }
-  s_pref[tid + 1] = mine;
-  if (tid == 0) { s_pref[0] = 0; s_t64[0] = 0; s_t64[1] = 0; s_t32[0] = 0; s_t32[1] = 0; }
+  if (tid == 0) { s_pref[0] = 0; s_t64[0] = 0; s_t64[1] = 0; s_t64[2] = ~0ull; s_t64[3] = 0; s_t32[0] = 0; s_t32[1] = 0; }
+  s_pref[tid + 1] = block_scan_sum(mine, tid, s_w8);
   __syncthreads();
-  for (int o = 1; o < kTiledBlock; o <<= 1) {
-    const int x = tid >= o ? s_pref[tid + 1 - o] : 0;
-    __syncthreads();
-    s_pref[tid + 1] += x;
-    __syncthreads();
-  }
+  TT_MARK(17);
   const int total = s_pref[n_rt];
   const TRec* recs = (const TRec*)a.w_rec;
   for (int x = tid; x < total; x += kTiledBlock) {
@@ -535,18 +583,22 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     }
   }
   __syncthreads();
+  TT_MARK(18);
   // ---- score; rows out ----
   const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // the distro's slot range in the global slot arrays
-  uint64_t t_dur = 0, t_dover = 0;
+  uint64_t t_dur = 0, t_dover = 0, r_vmin = ~0ull, r_vmax = 0;
   uint32_t t_cover = 0, t_wait = 0;
   for (int u = tid; u < ns; u += kTiledBlock) {
     const int su = s0 + u;
     const uint32_t cw = m_cnt[u];
     const int64_t nu = cw & UF_COUNT_MASK;
     int64_t v = INT64_MIN;
-    if (nu > 0 && (cw & UF_DISTRO))
+    if (nu > 0 && (cw & UF_DISTRO)) {
       v = unit_value(p, nu, m_tiq[u], m_dur[u], (int64_t)m_maxpri[u], (int64_t)m_maxnd[u], cw,
                      a.out.unit_breakdown ? a.out.unit_breakdown + (sb + su) : nullptr, unit_slots(a.in));
+      const uint64_t uv = ub(v);  // range of the valid units' values: k_tiled_elect packs (value, min row, slot) into 64 bits with it
+      r_vmin = uv < r_vmin ? uv : r_vmin; r_vmax = uv > r_vmax ? uv : r_vmax;
+    }
     a.w_val[sb + su] = v;
     a.w_minrow[sb + su] = m_minrow[u];
     const int k = su - c.tg_base;
@@ -568,30 +620,161 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     }
   }
   t_dur = wave_sum(t_dur); t_dover = wave_sum(t_dover); t_cover = wave_sum(t_cover); t_wait = wave_sum(t_wait);
+  r_vmin = wave_min(r_vmin); r_vmax = wave_max(r_vmax);
   if (lane == 0) {
     atomicAdd(&s_t64[0], (unsigned long long)t_dur); atomicAdd(&s_t64[1], (unsigned long long)t_dover);
+    atomicMin(&s_t64[2], (unsigned long long)r_vmin); atomicMax(&s_t64[3], (unsigned long long)r_vmax);
     atomicAdd(&s_t32[0], t_cover); atomicAdd(&s_t32[1], t_wait);
   }
   __syncthreads();
   if (tid == 0) {
+    if (s_t64[2] <= s_t64[3]) { atomicMin(&ts->vmin, s_t64[2]); atomicMax(&ts->vmax, s_t64[3]); }
     if (s_t64[0]) atomicAdd(&ts->t_dur, s_t64[0]);
     if (s_t64[1]) atomicAdd(&ts->t_dover, s_t64[1]);
     if (s_t32[0]) atomicAdd(&ts->t_cover, s_t32[0]);
     if (s_t32[1]) atomicAdd(&ts->t_wait, s_t32[1]);
   }
+  TT_MARK(19);
+}
+
+// ---- sorting by rank searches in LDS ---------------------------------------------------------------------------------
+// Keys live in LDS as three arrays of 64-bit words (s_hi | s_mid | s_lo, `cap` entries each) and, four per thread, in
+// registers. One search step for the thread's four keys: the four probes are issued side by side (independent LDS reads),
+// the first word decides unless the probed key belongs to the same unit (or, in the wide-value key layout, has the same
+// value): only then are the other two words read.
+//   z[e]  index of the probe (any valid index when !ok[e])     ok[e]  the step applies to key e
+// Returns, per key, "the probed key is below mine".
+// Position i of a key array lives at word lpad(i): one spare word after every 32, so that the probes of a round -- which sit
+// at equal offsets of runs that start at multiples of a power of two -- spread over the LDS banks instead of piling on one.
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 5); }
+constexpr int kPadRT = kRT + kRT / 32;  // words per padded key array of one tile
+__device__ __forceinline__ void probe4(const K192 (&key)[4], const int (&zi)[4], const bool (&ok)[4], const uint64_t* s_hi, const uint64_t* s_mid,
+                                       const uint64_t* s_lo, bool (&lt)[4]) {
+  uint64_t h[4];
+  int z[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) { z[e] = lpad(zi[e]); h[e] = s_hi[z[e]]; }
+  bool tie = false;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    lt[e] = ok[e] && h[e] < key[e].hi;
+    tie |= ok[e] && h[e] == key[e].hi;
+  }
+  if (tie) {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (ok[e] && h[e] == key[e].hi) {
+        const uint64_t m = s_mid[z[e]];
+        lt[e] = m != key[e].mid ? m < key[e].mid : s_lo[z[e]] < key[e].lo;
+      }
+  }
+}
+
+// Sort of P = 2^m keys by one 512-thread workgroup, ascending; thread t holds positions 4t..4t+3 before and after. The
+// thread's four keys are sorted in registers (five compare-exchanges), then log2(P) - 2 rounds of pairwise RANK merges of
+// runs of L = 4, 8, .. P/2 keys: every key counts the keys of the partner run that are below it (log2(L) + 1 uniform steps
+// of four side-by-side probes) and moves to its place in the merged run. 63 probe steps for P = 2048 against the 66
+// compare-exchange stages of the bitonic network -- each of which moves and compares all six words of a key across lanes.
+// Keys must be distinct. smem: 3 * (P + P / 32) * 8 bytes (lpad).
+template <int P>
+__device__ __forceinline__ void lds_merge_sort4(K192 (&k)[4], int tid, uint64_t* smem64) {
+  uint64_t *s_hi = smem64, *s_mid = s_hi + (P + P / 32), *s_lo = s_mid + (P + P / 32);
+  cmpx(k[0], k[1], true); cmpx(k[2], k[3], true); cmpx(k[0], k[2], true); cmpx(k[1], k[3], true); cmpx(k[1], k[2], true);
+  int place[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) { place[e] = tid * 4 + e; const int q = lpad(place[e]); s_hi[q] = k[e].hi; s_mid[q] = k[e].mid; s_lo[q] = k[e].lo; }
+  __syncthreads();
+  // (rolled loops on purpose: unrolled, the 63 probe steps are ~100 KB of code and the waves of a CU thrash its instruction cache)
+#pragma clang loop unroll(disable)
+  for (int L = 4; L < P; L <<= 1) {
+    int base[4], cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; e++) base[e] = (place[e] & ~(L - 1)) ^ L;  // start of the partner run
+#pragma clang loop unroll(disable)
+    for (int step = L; step > 0; step >>= 1) {
+      int z[4];
+      bool ok[4], lt[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { ok[e] = cnt[e] + step <= L; z[e] = base[e] + (ok[e] ? cnt[e] + step - 1 : 0); }
+      probe4(k, z, ok, s_hi, s_mid, s_lo, lt);
+#pragma unroll
+      for (int e = 0; e < 4; e++) cnt[e] += lt[e] ? step : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) place[e] = (place[e] & L) ? place[e] - (L - cnt[e]) : place[e] + cnt[e];
+    __syncthreads();  // every search of this round is done
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const int q = lpad(place[e]); s_hi[q] = k[e].hi; s_mid[q] = k[e].mid; s_lo[q] = k[e].lo; }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) { const int q = lpad(tid * 4 + e); k[e] = K192{s_hi[q], s_mid[q], s_lo[q]}; }
+}
+
+// The same rank merges over SEGMENTS of any length: segment g is the sorted keys at [s_seg[g], s_seg[g + 1]). Round r merges
+// the runs of 2^r segments pairwise; s_maxrun[r] = the longest run of round r (the uniform search depth). On entry key[e]
+// sits at place[e] inside segment seg[e] (seg[e] < 0: no key); on return place[e] is its position in its merged run of
+// 2^rounds segments. The arrays are rewritten in place every round.
+__device__ __forceinline__ void seg_merge_tree(const K192 (&key)[4], const int (&seg)[4], int (&place)[4], const int* s_seg, int nseg, int rounds,
+                                               const int* s_maxrun, uint64_t* s_hi, uint64_t* s_mid, uint64_t* s_lo) {
+#pragma clang loop unroll(disable)
+  for (int r = 0; r < rounds; r++) {
+    const int mx = s_maxrun[r];
+    int b0[4], nv[4], cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int pr = (seg[e] >> r) ^ 1;  // the partner run of my run of 2^r segments
+      const int q0 = pr << r < nseg ? pr << r : nseg, q1 = (pr + 1) << r < nseg ? (pr + 1) << r : nseg;
+      b0[e] = seg[e] >= 0 ? s_seg[q0] : 0;
+      nv[e] = seg[e] >= 0 ? s_seg[q1] - b0[e] : 0;
+    }
+#pragma clang loop unroll(disable)
+    for (int step = mx ? 1 << (31 - __builtin_clz(mx)) : 0; step > 0; step >>= 1) {
+      int z[4];
+      bool ok[4], lt[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { ok[e] = cnt[e] + step <= nv[e]; z[e] = ok[e] ? b0[e] + cnt[e] + step - 1 : 0; }
+      probe4(key, z, ok, s_hi, s_mid, s_lo, lt);
+#pragma unroll
+      for (int e = 0; e < 4; e++) cnt[e] += lt[e] ? step : 0;
+    }
+    // a key of the left run moves right by the partner keys below it; a key of the right run moves left by the partner
+    // keys that are NOT below it (keys are distinct)
+#pragma unroll
+    for (int e = 0; e < 4; e++) place[e] = ((seg[e] >> r) & 1) ? place[e] - (nv[e] - cnt[e]) : place[e] + cnt[e];
+    __syncthreads();  // every search of this round is done
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (seg[e] >= 0) { const int q = lpad(place[e]); s_hi[q] = key[e].hi; s_mid[q] = key[e].mid; s_lo[q] = key[e].lo; }
+    __syncthreads();
+  }
+}
+// s_maxrun[r], r < rounds, for seg_merge_tree; called by one thread.
+__device__ __forceinline__ void seg_max_runs(const int* s_seg, int nseg, int rounds, int* s_maxrun) {
+#pragma clang loop unroll(disable)
+  for (int r = 0; r < rounds; r++) {
+    int mx = 0;
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < nseg; q += 1 << r) {
+      const int q1 = q + (1 << r) < nseg ? q + (1 << r) : nseg;
+      mx = s_seg[q1] - s_seg[q] > mx ? s_seg[q1] - s_seg[q] : mx;
+    }
+    s_maxrun[r] = mx;
+  }
 }
 
 // ---- T3: elect, keys, tile sort ----------------------------------------------------------------------------------
-constexpr int kTiledSortLds = kRT * (int)sizeof(K192);
+constexpr int kTiledSortLds = 3 * 8 * (kRT + kRT / 32);  // three padded arrays of 64-bit words (lpad)
+static_assert(kTileEdges * 8 <= kTiledSortLds && kRT * (int)sizeof(K192) <= kTiledSortLds, "the staged candidates and the network's exchange buffer share the bytes");
 __device__ __forceinline__ bool tiled_key_bits(const TState* ts, int& bn, int& bp, int& bd) {
   const int bt = bits_of((uint64_t)(ts->tmax - ts->tmin));
   bn = bits_of((uint64_t)(ts->nmax - ts->nmin)); bp = bits_of((uint64_t)(ts->pmax - ts->pmin)); bd = bits_of(ts->dmax - ts->dmin);
   return bt + bn + bp + bd <= 64;
 }
-__global__ void __launch_bounds__(kTiledBlock) k_tiled_elect(const PlanArgs a) {
+__global__ void __launch_bounds__(kTiledBlock, 4) k_tiled_elect(const PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int w = blockIdx.x;
-  if (w >= a.w_ntile[0]) return;
+  const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);
+  if (w < 0) return;
   const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
   TState* ts = &a.w_ts[d];
   if (!tiled_live(ts)) return;
@@ -606,45 +789,95 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_elect(const PlanArgs a) {
   const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;
   const uint32_t tmin = ts->tmin, nmax = ts->nmax, pmax = ts->pmax;
   const uint64_t dmax = ts->dmax;
+  // A unit as ONE 64-bit word [max value - value | unit min row | unit slot] -- smaller = emitted earlier (TotalValue desc,
+  // canonical tie-break) -- when the distro's ranges allow it (`ukl`, the same decision in every workgroup of the distro);
+  // a dropped unit (planner.go:81) is ~0. Then the sort key is [unit word : 64][TaskList.Less key : 64][row]: its FIRST
+  // word decides every comparison between rows of different units, which is what the merge's searches mostly meet.
+  const uint64_t vmaxu = ts->vmax;
+  const int vb = ts->vmin <= ts->vmax ? bits_of(ts->vmax - ts->vmin) : 0;
+  const int bmr = bits_of((uint64_t)(c.n - 1)), bsl = bits_of((uint64_t)(c.S - 1));
+  const int i_end = (tile + 1) * kRT < c.n ? (tile + 1) * kRT : c.n;
+  const int E0 = t.dep_off[c.lo + tile * kRT], E1 = t.dep_off[c.lo + i_end];
+  const bool ukl = vb + bmr + bsl <= 63 && !(a.tiled_mode & TM_ROW_ELECT);
+  const bool stage = ukl && E1 - E0 <= kTileEdges;
+  auto ukey = [&](int u) -> uint64_t {
+    const int64_t v = a.w_val[sb + u];
+    const uint32_t mr = a.w_minrow[sb + u];
+    return v == INT64_MIN ? ~0ull : (shl64(vmaxu - ub(v), bmr + bsl) | ((uint64_t)mr << bsl) | (uint64_t)u);
+  };
+  TT_BEGIN();
+  // The units the tile's dependency edges name, edge-parallel into LDS (the slots come coalesced, one gather per edge).
+  // (Fetching the four rows' columns ahead of this loop was measured: 85 VGPRs, one workgroup less per CU, slower.)
+  uint64_t* s_uk = (uint64_t*)smem;
+  if (stage) {
+    for (int x = tid; x < E1 - E0; x += kTiledBlock) {
+      const int sl = a.w_eslot[E0 + x];
+      s_uk[x] = sl >= 0 ? ukey(sl) : ~0ull;
+    }
+    __syncthreads();
+  }
+  TT_MARK(8);
   K192 k[4];
 #pragma unroll
   for (int e4 = 0; e4 < 4; e4++) {
     const int i = tile * kRT + e4 * kTiledBlock + tid;
-    k[e4] = K192{~0ull, ~0ull, ~0ull};
+    k[e4] = K192{~0ull, ~0ull, 0xFFFFFFFFFFF00000ull | (uint64_t)i};  // past the end: distinct keys above every row's
     if (i >= c.n) continue;
     const int r = c.lo + i;
     const int tgk = t.tg_key[r];
-    int best = (int)a.w_pslot[r];  // the primary unit is always valid: it got its distro from this row
-    int64_t bv = a.w_val[sb + best];
-    uint32_t bm = a.w_minrow[sb + best];
-    auto consider = [&](int u) {
-      const int64_t v = a.w_val[sb + u];  // INT64_MIN for a dropped unit: never better
-      const uint32_t mr = a.w_minrow[sb + u];
-      const bool better = v > bv || (v == bv && (mr < bm || (mr == bm && u < best)));
-      best = better ? u : best; bv = better ? v : bv; bm = better ? mr : bm;
-    };
-    if (c.gv && tgk >= 0) consider(c.ver_base + (t.version_key[r] - c.ver_lo));
     const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
-    for (int e = e0; e < e1; e++) {
-      const int sl = a.w_eslot[e];
-      if (sl >= 0) consider(sl);
-    }
-    if (a.out.unit_of_task) a.out.unit_of_task[r] = (int32_t)(sb + best);
     // TaskList.Less key (planner.go:386-405): group order asc | num dependents desc | priority desc | duration desc
     const uint64_t ik = shl64((uint64_t)(ub(t.task_group_order[r]) - tmin), bn + bp + bd) | shl64((uint64_t)(nmax - ub(t.num_dependents[r])), bp + bd) |
                         shl64((uint64_t)(pmax - ub((int32_t)t.priority[r])), bd) | (dmax - ub(t.expected_duration_ns[r]));
-    // [value desc : 64][unit min row : 20 | unit slot : 21 | key, upper 23][key, lower 41 | row : 20]
-    k[e4] = K192{~ub(bv), ((uint64_t)bm << 44) | ((uint64_t)best << 23) | (ik >> 41), ((ik & ((1ull << 41) - 1)) << 20) | (uint64_t)i};
+    int best;
+    if (ukl) {
+      uint64_t bk = ukey((int)a.w_pslot[r]);  // the primary unit is always valid: it got its distro from this row
+      if (c.gv && tgk >= 0) { const uint64_t x = ukey(c.ver_base + (t.version_key[r] - c.ver_lo)); bk = x < bk ? x : bk; }
+      if (stage) {
+        for (int e = e0; e < e1; e++) { const uint64_t x = s_uk[e - E0]; bk = x < bk ? x : bk; }
+      } else {
+        for (int e = e0; e < e1; e++) {
+          const int sl = a.w_eslot[e];
+          if (sl >= 0) { const uint64_t x = ukey(sl); bk = x < bk ? x : bk; }
+        }
+      }
+      best = (int)(bk & ((1ull << bsl) - 1ull));
+      k[e4] = K192{bk, ik, (uint64_t)i};
+    } else {
+      best = (int)a.w_pslot[r];
+      int64_t bv = a.w_val[sb + best];
+      uint32_t bm = a.w_minrow[sb + best];
+      auto consider = [&](int u) {
+        const int64_t v = a.w_val[sb + u];  // INT64_MIN for a dropped unit: never better
+        const uint32_t mr = a.w_minrow[sb + u];
+        const bool better = v > bv || (v == bv && (mr < bm || (mr == bm && u < best)));
+        best = better ? u : best; bv = better ? v : bv; bm = better ? mr : bm;
+      };
+      if (c.gv && tgk >= 0) consider(c.ver_base + (t.version_key[r] - c.ver_lo));
+      for (int e = e0; e < e1; e++) {
+        const int sl = a.w_eslot[e];
+        if (sl >= 0) consider(sl);
+      }
+      // [value desc : 64][unit min row : 20 | unit slot : 21 | key, upper 23][key, lower 41 | row : 20]
+      k[e4] = K192{~ub(bv), ((uint64_t)bm << 44) | ((uint64_t)best << 23) | (ik >> 41), ((ik & ((1ull << 41) - 1)) << 20) | (uint64_t)i};
+    }
+    if (a.out.unit_of_task) a.out.unit_of_task[r] = (int32_t)(sb + best);
   }
-  bitonic_sort4_fixed<kRT, K192>(k, tid, (K192*)smem, (K192*)smem);
+  TT_MARK(9);
+  __syncthreads();  // the staged candidates are dead: the sort works in the same bytes
+  // The tile sort: thread t holds the keys of positions 4t..4t+3.
+  if (a.tiled_mode & TM_RANK_MERGE_SORT) lds_merge_sort4<kRT>(k, tid, (uint64_t*)smem);
+  else bitonic_sort4_fixed<kRT, K192>(k, tid, (K192*)smem, (K192*)smem);
+  TT_MARK(10);
   K192* out = (K192*)a.w_keyA + ((size_t)ts->rt_base + tile) * kRT + tid * 4;
 #pragma unroll
   for (int e4 = 0; e4 < 4; e4++) out[e4] = k[e4];
+  TT_MARK(11);
 }
 
-// ---- T5 (the tail of a distro's LAST merge pass): queue order out; first queue position per task group ---------------
-// k[e] = the key at queue position q0 + e of distro d. Called by every thread of the workgroup.
-__device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, int d, long long q0, const K192 (&k)[4]) {
+// ---- T5 (the tail of the merge): queue order out; first queue position per task group ----------------------------------
+// i4[e] = the (local) row at queue position q0 + e of distro d. Called by every thread of the workgroup.
+__device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, int d, long long q0, const uint32_t (&i4)[4]) {
   __shared__ unsigned long long s_first;
   const int tid = threadIdx.x, lane = tid & 63;
   const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo, D = a.in.n_distros;
@@ -658,7 +891,7 @@ __device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, 
     const long long q = q0 + e;
     o4[e] = 0;
     if (q >= n) continue;
-    const int i = (int)(k[e].lo & 0xFFFFFu);
+    const int i = (int)i4[e];
     const int r = lo + i;
     o4[e] = r;
     if (!((tgbit[i >> 6] >> (i & 63)) & 1ull)) {  // row tiles are 2048 rows: bit i of the distro's table
@@ -680,6 +913,203 @@ __device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, 
     const unsigned long long packed = (s_first & 0xFFFFFFFF00000000ull) | (uint32_t)a.in.tasks.task_group_max_hosts[lo + (int)(s_first & 0xFFFFFFFFu)];
     atomicMin(&ts->s_first, packed);
   }
+}
+
+// ---- T4 (distros of up to kMaxWay sorted tiles): sample ranks, then ONE multiway merge pass -----------------------------
+// Number of keys below `key` among the n sorted keys at(0..n-1): the same number of steps for every lane (n is uniform).
+template <class At, class K>
+__device__ __forceinline__ int count_below(int n, const K& key, At at) {
+  int pos = 0;
+  for (int step = n ? 1 << (31 - __builtin_clz(n)) : 0; step > 0; step >>= 1)
+    if (pos + step <= n && key_lt(at(pos + step - 1), key)) pos += step;
+  return pos;
+}
+
+// k_tiled_srank: the workgroup of sorted tile `tile` ranks the tile's 64 samples (the key at the end of every 32-key block)
+// in the whole distro: G[sample] = the sum over the distro's tiles of the keys below the sample -- for another tile, a search
+// over that tile's samples in LDS, then inside ONE 32-key block in memory: two rounds of side-by-side probes (every 5th
+// key, then the 4 keys in between) instead of five dependent steps.
+constexpr int kSrankLds = kMaxWay * kSmpPerTile * (int)sizeof(K192);
+__global__ void __launch_bounds__(kTiledBlock) k_tiled_srank(const PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_G[kSmpPerTile];
+  const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);
+  if (w < 0) return;
+  const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
+  const TState* ts = &a.w_ts[d];
+  if (!tiled_live(ts) || !ts->way) return;
+  const int k = ts->n_rt, tid = threadIdx.x;
+  const K192* keys = (const K192*)a.w_keyA + (size_t)ts->rt_base * kRT;
+  TT_BEGIN();
+  K192* smp = (K192*)smem;
+  for (int x = tid; x < k * kSmpPerTile; x += kTiledBlock)
+    smp[x] = keys[(size_t)(x / kSmpPerTile) * kRT + (x % kSmpPerTile) * kSmpStride + kSmpStride - 1];
+  if (tid < kSmpPerTile) s_G[tid] = 0;
+  __syncthreads();
+  TT_MARK(20);
+  for (int pair = tid; pair < k * kSmpPerTile; pair += kTiledBlock) {
+    const int m = pair % kSmpPerTile, j = pair / kSmpPerTile;  // a wave: 64 samples against one tile
+    int below;
+    if (j == tile) {
+      below = m * kSmpStride + kSmpStride - 1;  // the sample's own position
+    } else {
+      const K192 key = smp[tile * kSmpPerTile + m];
+      const K192* sj = smp + j * kSmpPerTile;
+      const int blk = count_below(kSmpPerTile, key, [&](int q) { return sj[q]; });  // tile j's samples below the key
+      below = kRT;
+      if (blk < kSmpPerTile) {  // inside block `blk`: its last key (the sample) is above, the 31 before it are undecided
+        const K192* kb = keys + (size_t)j * kRT + blk * kSmpStride;
+        int c5 = 0;  // keys 4, 9, 14, 19, 24, 29 of the block, probed together
+#pragma unroll
+        for (int q = 0; q < 6; q++) c5 += key_lt(kb[5 * q + 4], key) ? 1 : 0;
+        int c1 = 0;  // the (at most) four keys before the first probe that is not below
+#pragma unroll
+        for (int q = 0; q < 4; q++) c1 += (5 * c5 + q < kSmpStride - 1) && key_lt(kb[5 * c5 + q], key) ? 1 : 0;
+        below = blk * kSmpStride + 5 * c5 + c1;
+      }
+    }
+    atomicAdd(&s_G[m], (uint32_t)below);
+  }
+  __syncthreads();
+  if (tid < kSmpPerTile) a.w_srank[(size_t)(ts->rt_base + tile) * kSmpPerTile + tid] = s_G[tid];
+  TT_MARK(21);
+}
+
+// k_tiled_mmerge: the workgroup of output window [R0, R1) = [2048 w, 2048 (w + 1)) of the distro's queue.
+//  (1) The window's split of every tile at both boundaries (side by side). For boundary R and tile j: m = the tile's samples
+//      of rank below R. The 32 m keys up to the last of them are among the R smallest; the next sample (rank >= R) and
+//      everything after it are not; the 31 keys in between are CANDIDATES. The R smallest keys are those certain ones plus
+//      the R - sum(32 m) smallest candidates (a down-set), so: the candidates of every tile into LDS (at most 31 per tile
+//      and boundary, 1,984 in all), merged per boundary by the rank-merge tree, and the ones of rank below that number taken.
+//  (2) The window's <= 32 segments (exactly 2048 keys, four per thread, in registers and in LDS) merged by the same TREE of
+//      pairwise rank merges: in round r every key counts the keys below it in the partner run of its run of 2^r segments
+//      (one uniform-step search, four keys side by side) and moves to its place in the merged run -- ceil(log2 k) rounds of
+//      one search each. The rows in queue order go to tiled_emit_order.
+constexpr int kMmergeLds = 3 * 8 * kPadRT;
+constexpr int kCandPer = kSmpStride - 1;  // candidates per tile and boundary
+static_assert(2 * kMaxWay * kCandPer <= kRT, "both boundaries' candidates fit the segment buffer, four per thread");
+__global__ void __launch_bounds__(kTiledBlock) k_tiled_mmerge(const PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_split[2][kMaxWay], s_m[2][kMaxWay], s_take[2][kMaxWay], s_seg[2 * kMaxWay + 1], s_maxrun[8];
+  const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);
+  if (w < 0) return;
+  const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
+  TState* ts = &a.w_ts[d];
+  if (!tiled_live(ts) || !ts->way) return;
+  const int k = ts->n_rt, tid = threadIdx.x;
+  const K192* keys = (const K192*)a.w_keyA + (size_t)ts->rt_base * kRT;
+  const uint32_t* G = a.w_srank + (size_t)ts->rt_base * kSmpPerTile;
+  uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kPadRT, *s_lo = s_mid + kPadRT;
+  // boundary b: rank R = 2048 (tile + b); the first boundary of the first window and the last of the last are trivial
+  const bool open0 = tile > 0, open1 = tile + 1 < k;
+  const uint32_t R0 = (uint32_t)tile * kRT, R1 = R0 + kRT;
+  int k2 = 1, lg2 = 0;  // the tiles rounded up to a power of two: boundary 1's windows start at segment k2
+  while (k2 < k) { k2 <<= 1; lg2++; }
+  TT_BEGIN();
+  if (tid < k) { s_m[0][tid] = 0; s_m[1][tid] = 0; s_take[0][tid] = 0; s_take[1][tid] = 0; }
+  __syncthreads();
+  for (int x = tid; x < k * kSmpPerTile; x += kTiledBlock) {  // samples of rank below the boundary, per tile
+    const uint32_t g = G[x];
+    const int j = x / kSmpPerTile;
+    if (open0 && g < R0) atomicAdd(&s_m[0][j], 1);
+    if (open1 && g < R1) atomicAdd(&s_m[1][j], 1);
+  }
+  __syncthreads();
+  TT_MARK(0);
+  if (tid == 0) {  // candidate windows as segments: boundary 0's tiles at [0, k), boundary 1's at [k2, k2 + k)
+    int o = 0;
+#pragma clang loop unroll(disable)
+    for (int g = 0; g < 2 * k2; g++) {
+      const int b = g >= k2, j = g - b * k2;
+      s_seg[g] = o;
+      if (j < k && (b ? open1 : open0) && s_m[b][j] < kSmpPerTile) o += kCandPer;
+    }
+    s_seg[2 * k2] = o;
+    seg_max_runs(s_seg, 2 * k2, lg2, s_maxrun);
+  }
+  __syncthreads();
+  TT_MARK(1);
+  {
+    const int ncand = s_seg[2 * k2];
+    K192 key[4];
+    int seg[4], place[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int x = e * kTiledBlock + tid;
+      seg[e] = -1; place[e] = x; key[e] = K192{0, 0, 0};
+      if (x < ncand) {
+        int g = 0;
+#pragma clang loop unroll(disable)
+        for (int q = 1; q < 2 * k2; q++) g += s_seg[q] <= x ? 1 : 0;  // the last segment that starts at or before x
+        const int b = g >= k2, j = g - b * k2;
+        seg[e] = g;
+        key[e] = keys[(size_t)j * kRT + s_m[b][j] * kSmpStride + (x - s_seg[g])];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      if (seg[e] >= 0) { const int q = lpad(place[e]); s_hi[q] = key[e].hi; s_mid[q] = key[e].mid; s_lo[q] = key[e].lo; }
+    __syncthreads();
+    TT_MARK(2);
+    seg_merge_tree(key, seg, place, s_seg, 2 * k2, lg2, s_maxrun, s_hi, s_mid, s_lo);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (seg[e] < 0) continue;
+      const int b = seg[e] >= k2, j = seg[e] - b * k2;
+      int certain = 0;  // keys of the boundary that are certainly among its R smallest
+#pragma clang loop unroll(disable)
+      for (int q = 0; q < k; q++) certain += s_m[b][q] * kSmpStride;
+      const int need = (int)(b ? R1 : R0) - certain;
+      const int rank = place[e] - s_seg[b * k2];  // among the boundary's candidates
+      if (rank < need) atomicMax(&s_take[b][j], (e * kTiledBlock + tid) - s_seg[seg[e]] + 1);
+    }
+    __syncthreads();
+  }
+  TT_MARK(3);
+  if (tid < 2 * k) {
+    const int b = tid >= k, j = tid - b * k;
+    s_split[b][j] = (b ? open1 : open0) ? s_m[b][j] * kSmpStride + s_take[b][j] : (b ? kRT : 0);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < k; j++) { s_seg[j] = o; o += s_split[1][j] - s_split[0][j]; }
+    s_seg[k] = o;
+    seg_max_runs(s_seg, k, lg2, s_maxrun);
+  }
+  __syncthreads();
+  if (s_seg[k] != kRT) {  // cannot happen; if it ever did, the one-workgroup kernel plans the distro instead
+    if (tid == 0) atomicOr((unsigned*)&ts->unfit, 1u);
+    return;
+  }
+  TT_MARK(4);
+  K192 key[4];
+  int seg[4], place[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int x = e * kTiledBlock + tid;
+    int j = 0;
+#pragma clang loop unroll(disable)
+    for (int q = 1; q < k; q++) j += s_seg[q] <= x ? 1 : 0;  // the last segment that starts at or before x
+    seg[e] = j; place[e] = x;
+    key[e] = keys[(size_t)j * kRT + s_split[0][j] + (x - s_seg[j])];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) { const int q = lpad(place[e]); s_hi[q] = key[e].hi; s_mid[q] = key[e].mid; s_lo[q] = key[e].lo; }
+  __syncthreads();
+  TT_MARK(5);
+  seg_merge_tree(key, seg, place, s_seg, k, lg2, s_maxrun, s_hi, s_mid, s_lo);
+  TT_MARK(6);
+  uint32_t* s_row = (uint32_t*)smem;
+#pragma unroll
+  for (int e = 0; e < 4; e++) s_row[place[e]] = (uint32_t)(key[e].lo & 0xFFFFFu);
+  __syncthreads();
+  uint32_t i4[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) i4[e] = s_row[tid * 4 + e];
+  tiled_emit_order(a, ts, d, (long long)tile * kRT + tid * 4, i4);
+  TT_MARK(7);
 }
 
 // ---- T4: one merge-path pass ---------------------------------------------------------------------------------------
@@ -741,7 +1171,10 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_merge(const PlanArgs a, i
     bitonic_merge4_fixed<kRT, K192>(k, tid, (K192*)smem, true);
   }
   if (pass == ts->passes - 1) {  // the distro's last pass: the merged keys ARE the queue -- nothing is written back
-    tiled_emit_order(a, ts, d, pos0 + tid * 4, k);
+    uint32_t i4[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) i4[e] = (uint32_t)(k[e].lo & 0xFFFFFu);
+    tiled_emit_order(a, ts, d, pos0 + tid * 4, i4);
     return;
   }
 #pragma unroll

@@ -7,12 +7,19 @@ that moves between GPUs is what north_star names:
     per-distro tables, the allocator's host columns) lives in ONE packed device buffer whose layout (`PoolLayout`) is a
     256-byte header plus 256-byte-aligned sections, so the collective is a single `broadcast` of one byte tensor and the
     kernels read the columns in place through typed views -- nothing is unpacked, copied or re-uploaded;
-  * every rank plans a CONTIGUOUS range of distros chosen by prefix-sum balancing of the task counts
-    (`balanced_ranges`) with evg_plan_distro_range_device / evg_allocate_host_range_device, which keep the full batch's
-    numbering, so a rank's results are contiguous slices of full-size output arrays;
+  * every rank plans a CONTIGUOUS range of distros chosen by prefix-sum balancing of the distros' COSTS (`balanced_ranges`,
+    `distro_costs`: a task of a distro beyond the one-workgroup path costs LARGE_PATH_COST tasks of one inside it) with
+    evg_plan_distro_range_device / evg_allocate_host_range_device, which keep the full batch's numbering, so a rank's
+    results are contiguous slices of full-size output arrays;
   * ONE gather of those slices (queue order 4 B/task, deps-met 1 B, wait 8 B, the info rows and the host counts) to
     rank 0: a single group of point-to-point sends/receives (what RCCL's own ncclGather is, rccl.h:745) that lands each
     slice directly at its final offset in rank 0's arrays -- no staging buffer, no unpack.
+
+`mode="scatter"` is SURVEY 8(e)'s cheaper way in: instead of the whole pool, rank r receives only the slices of every column
+that its distro range reads (rows [task_off[d0], task_off[d1]), their edges, their hosts) plus the small per-distro tables --
+at the SAME offsets of its own full-size buffer, so the kernels and the full-batch numbering do not change; rank 0 sends
+1/world of the pool down each link instead of all of it round a ring. north_star names the broadcast, so that stays the
+default and the headline; bench.py reports the scatter tick next to it.
 
 One process per GPU; the caller initialises torch.distributed (backend "nccl" == RCCL on a GPU box, "gloo" in the CPU
 tests). torch is plumbing here: it owns the device buffer and issues the collectives. Nothing in this file computes a
@@ -34,20 +41,47 @@ HEADER_WORDS = 32            # int64 words = 256 bytes
 H_MAGIC, H_TOTAL, H_NOW, H_D, H_N, H_E, H_TG, H_VER, H_H, H_HAS_HOSTS, H_HAS_NAME, H_MAX_DISTRO, H_PROMISES = range(13)
 
 
-def balanced_ranges(task_off: Sequence[int], world: int) -> List[Tuple[int, int]]:
-    """Contiguous distro ranges [d0, d1) per rank with ~N/world tasks each: boundary r is the distro boundary whose
-    prefix sum is nearest to r*N/world (a distro is never split). Deterministic: every rank computes the same table."""
+# Cost of one task of a distro that takes the many-workgroups-per-distro pipeline (more than LDS_PATH_TASKS tasks), in
+# tasks of a distro on the one-workgroup path: measured on MI355X (round 3: 0.21 ns against 0.056 ns per task).
+LDS_PATH_TASKS = 2048
+LARGE_PATH_COST = 4.0
+
+
+def distro_costs(task_off: Sequence[int]) -> np.ndarray:
+    """Planning cost of every distro in LDS-path task units (what balanced_ranges balances)."""
+    n = np.diff(np.asarray(task_off, np.int64)).astype(np.float64)
+    return np.where(n > LDS_PATH_TASKS, n * LARGE_PATH_COST, n)
+
+
+def balanced_ranges(task_off: Sequence[int], world: int, costs: Optional[Sequence[float]] = None) -> List[Tuple[int, int]]:
+    """Contiguous distro ranges [d0, d1) per rank (a distro is never split; a rank's results must be contiguous slices of the
+    full-size outputs) that MINIMISE the largest rank cost -- the tick lasts as long as its slowest rank. Costs default to
+    distro_costs (in quarter-task integers, so that every rank computes the same table bit for bit): the smallest bound L
+    such that a left-to-right fill with ranges of cost <= L needs at most `world` ranges (binary search over L), then that
+    fill. Ranks past the last range get empty ranges."""
     off = np.asarray(task_off, np.int64)
-    D, N = len(off) - 1, int(off[-1])
-    cuts = [0]
-    for r in range(1, world):
-        target = r * N / world
-        k = int(np.searchsorted(off, target, side="left"))
-        k = min(max(k, 0), D)
-        if k > 0 and abs(off[k - 1] - target) <= abs(off[k] - target):
-            k -= 1
-        cuts.append(min(max(k, cuts[-1]), D))
-    cuts.append(D)
+    D = len(off) - 1
+    c = np.rint(4.0 * (distro_costs(off) if costs is None else np.asarray(costs, np.float64))).astype(np.int64)
+    pre = np.concatenate([[0], np.cumsum(c)])
+
+    def fill(limit: int) -> List[int]:
+        cuts, d = [0], 0
+        while d < D and len(cuts) <= world:
+            # the furthest boundary whose range cost stays within the limit (at least one distro: limit >= max cost)
+            k = int(np.searchsorted(pre, pre[d] + limit, side="right")) - 1
+            d = min(max(k, d + 1), D)
+            cuts.append(d)
+        return cuts
+    lo, hi = int(c.max()) if D else 0, int(pre[-1])
+    while lo < hi:
+        mid = (lo + hi) // 2
+        cu = fill(mid)
+        if cu[-1] == D and len(cu) - 1 <= world:
+            hi = mid
+        else:
+            lo = mid + 1
+    cuts = fill(lo) if D else [0]
+    cuts += [D] * (world + 1 - len(cuts))
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
@@ -154,16 +188,25 @@ def _torch_dtype(dt: np.dtype):
 
 
 class ShardedPool:
-    """One rank's side of the sharded tick: broadcast -> plan my distro range -> allocate -> gather to rank `dst`.
+    """One rank's side of the sharded tick: pool in (broadcast, or scatter of each rank's slices) -> plan my distro range ->
+    allocate -> gather to rank `dst`.
 
     backend: plan_range_device(inp, out, d0, d1, stream) / allocate_range_device(ainp, aout, d0, d1, stream) over the
-    C-ABI structs (native.Context; the CPU tests pass an oracle-backed object with the same two methods)."""
+    C-ABI structs (native.Context; the CPU tests pass an oracle-backed object with the same two methods).
+
+    Every NEW pool goes through setup() on every rank (a collective): the header -- sizes, `now`, the launch hint and the
+    promises of evg_plan_launch_hints -- and the per-distro tables are re-read, the ranges and slice bounds recomputed and
+    the argument blocks rebuilt; device buffers are kept when the sizes did not change. tick() re-runs the pool that
+    setup() placed. (Reloading the device buffer behind setup()'s back would leave stale promises / offsets: there is no
+    public load().)"""
 
     def __init__(self, backend, device, src: int = 0, dst: int = 0, breakdown: bool = False, group=None, collective: bool = True,
-                 fused: bool = True):
+                 fused: bool = True, mode: str = "broadcast"):
         import torch
+        assert mode in ("broadcast", "scatter")
         self.torch, self.backend, self.device, self.src, self.dst, self.breakdown, self.group = torch, backend, device, src, dst, breakdown, group
         self.fused = fused  # tick(): one launch for plan + allocate when the batch allows it (plan_allocate)
+        self.mode = mode
         self.dist = None
         try:
             import torch.distributed as dist
@@ -175,12 +218,13 @@ class ShardedPool:
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.buf = None
         self.layout: Optional[PoolLayout] = None
+        self._sizes = None
 
-    # ---- setup (untimed): agree on the buffer size, place the pool, build the views and the argument blocks ----------
+    # ---- setup (once per pool): agree on the sizes, place the pool, read its tables, build the argument blocks ----------
     def setup(self, packed: Optional[np.ndarray]) -> None:
-        """`packed` (pack_pool's buffer) on rank `src`, None elsewhere. Broadcasts the 256-byte header so that every rank
-        can size its buffer, then the pool itself once; later ticks call broadcast() alone (the sizes of a pool change
-        slowly: a tick whose pool outgrows the buffer calls setup again)."""
+        """`packed` (pack_pool's buffer) on rank `src`, None elsewhere; every rank calls it for every new pool. One small
+        broadcast (the 256-byte header, the per-distro offset tables and the edge offsets at the range cuts) tells every
+        rank the sizes and its range; then the pool moves (the data-path collective: broadcast() or scatter())."""
         torch, dev = self.torch, self.device
         hdr = torch.zeros(HEADER_WORDS, dtype=torch.int64, device=dev)
         if self.rank == self.src:
@@ -188,31 +232,47 @@ class ShardedPool:
         if self.dist and self.world > 1:
             self.dist.broadcast(hdr, self.src, group=self.group)
         self.layout = lay = PoolLayout.from_header(hdr.cpu().numpy())
-        self.buf = torch.zeros(lay.total_bytes, dtype=torch.uint8, device=dev)
+        D, N, G = lay.D, lay.N, lay.D + lay.TG
+        # the per-distro tables on the host (4 x (D+1) ints) + the edge offset at every range cut: ranges and slice bounds
+        meta = torch.zeros(4 * (D + 1) + self.world + 1, dtype=torch.int64, device=dev)
         if self.rank == self.src:
-            self.load(packed)
-        self.broadcast()
+            def sec(name):
+                pos, dt, count = lay.sections[name]
+                return packed[pos:pos + dt.itemsize * count].view(dt).astype(np.int64)
+            tabs = [sec("task_off"), sec("tg_off"), sec("ver_off"), sec("host_off") if lay.has_hosts else np.zeros(D + 1, np.int64)]
+            cuts = [r[0] for r in balanced_ranges(tabs[0], self.world)] + [D]
+            dep_off = sec("dep_off")
+            ecut = np.array([dep_off[tabs[0][c]] for c in cuts], np.int64)
+            meta.copy_(torch.from_numpy(np.concatenate(tabs + [ecut])))
+        if self.dist and self.world > 1:
+            self.dist.broadcast(meta, self.src, group=self.group)
+        m = meta.cpu().numpy()
+        self.task_off, self.tg_off, self.ver_off, self.host_off = (m[i * (D + 1):(i + 1) * (D + 1)].copy() for i in range(4))
+        self.ranges = balanced_ranges(self.task_off, self.world)
+        self.edge_cut = m[4 * (D + 1):].copy()  # dep_off at the first row of every rank's range (and E at the end)
+        self.slot_off = self.task_off + self.tg_off + self.ver_off
+        sizes = (lay.total_bytes, D, N, lay.E, lay.TG, lay.V, lay.H, lay.has_hosts, lay.has_name_key, int(self.slot_off[-1]))
+        if sizes != self._sizes:  # (re)allocate; a pool of the same sizes re-uses every buffer
+            self._sizes = sizes
+            self.buf = torch.zeros(lay.total_bytes, dtype=torch.uint8, device=dev)
+            z = lambda n, dt: torch.zeros(max(int(n), 1), dtype=dt, device=dev)  # noqa: E731
+            self.o_order, self.o_met, self.o_wait = z(N, torch.int32), z(N, torch.uint8), z(N, torch.int64)
+            # SortingValueBreakdown rows travel per UNIT (evg_plan_output.unit_of_task / unit_breakdown): a distro range owns a
+            # contiguous range of unit slots, so a rank's rows are one slice like everything else; rows by task are a gather
+            self.o_uot = z(N, torch.int32) if self.breakdown else None
+            self.o_ubd = z(int(self.slot_off[-1]) * abi.BREAKDOWN_FIELDS, torch.int64) if self.breakdown else None
+            self.o_di = z(D * abi.DISTRO_INFO_DTYPE.itemsize, torch.uint8)
+            self.o_gi = z(G * abi.GROUP_INFO_DTYPE.itemsize, torch.uint8)
+            self.o_alloc = z(3 * D, torch.int32) if lay.has_hosts else None  # new_hosts | free_hosts | status
+        if self.rank == self.src:
+            self.buf[:packed.size].copy_(torch.from_numpy(packed), non_blocking=True)  # one H2D copy of the packed bytes
+        self.move_in()
         self._sync()
         v = self.views = {name: self.buf[pos:pos + dt.itemsize * count].view(_torch_dtype(dt))
                           for name, (pos, dt, count) in lay.sections.items()}
-        # the per-distro tables on the host (3 x (D+1) ints): ranges and slice bounds are computed from them
-        self.task_off = v["task_off"].cpu().numpy().astype(np.int64)
-        self.tg_off = v["tg_off"].cpu().numpy().astype(np.int64)
-        self.ranges = balanced_ranges(self.task_off, self.world)
-        D, N, G = lay.D, lay.N, lay.D + lay.TG
-        z = lambda n, dt: torch.zeros(max(int(n), 1), dtype=dt, device=dev)  # noqa: E731
-        self.o_order, self.o_met, self.o_wait = z(N, torch.int32), z(N, torch.uint8), z(N, torch.int64)
-        # SortingValueBreakdown rows travel per UNIT (evg_plan_output.unit_of_task / unit_breakdown): a distro range owns a
-        # contiguous range of unit slots, so a rank's rows are one slice like everything else; rows by task are a gather
-        self.ver_off = v["ver_off"].cpu().numpy().astype(np.int64)
-        self.slot_off = self.task_off + self.tg_off + self.ver_off
-        self.o_uot = z(N, torch.int32) if self.breakdown else None
-        self.o_ubd = z(int(self.slot_off[-1]) * abi.BREAKDOWN_FIELDS, torch.int64) if self.breakdown else None
-        self.o_di = z(D * abi.DISTRO_INFO_DTYPE.itemsize, torch.uint8)
-        self.o_gi = z(G * abi.GROUP_INFO_DTYPE.itemsize, torch.uint8)
-        meta = _Meta(lay, self.task_off)
-        self.inp = abi.make_plan_input(meta, v)
-        self.inp.max_distro_tasks, self.inp.promises = lay.max_distro_tasks, lay.promises
+        meta_b = _Meta(lay, self.task_off)
+        self.inp = abi.make_plan_input(meta_b, v)
+        self.inp.max_distro_tasks, self.inp.promises = lay.max_distro_tasks, lay.promises  # this pool's, from this pool's header
         self.out = abi.PlanOutput()
         self.out.order, self.out.deps_met, self.out.wait_ns = self.o_order.data_ptr(), self.o_met.data_ptr(), self.o_wait.data_ptr()
         self.out.breakdown = None
@@ -221,17 +281,12 @@ class ShardedPool:
         self.out.distro_info, self.out.group_info, self.out.n_units = self.o_di.data_ptr(), self.o_gi.data_ptr(), None
         self.has_hosts = lay.has_hosts
         if self.has_hosts:
-            self.o_alloc = z(3 * D, torch.int32)  # new_hosts | free_hosts | status
             hv = {"alloc_params": v["alloc_params"], "host_off": v["host_off"], "tg_off": v["tg_off"]}
             hv.update({k: v[k] for k in v if k.startswith("host_")})
-            self.ainp = abi.make_alloc_input(_HostMeta(meta), self.o_di, self.o_gi, hv)
+            self.ainp = abi.make_alloc_input(_HostMeta(meta_b), self.o_di, self.o_gi, hv)
             self.aout = abi.AllocOutput()
             base, isz = self.o_alloc.data_ptr(), 4
             self.aout.new_hosts, self.aout.free_hosts, self.aout.status = base, base + isz * D, base + 2 * isz * D
-
-    def load(self, packed: np.ndarray) -> None:
-        """Rank `src`: the tick's pool into the device buffer (one H2D copy of the packed bytes)."""
-        self.buf[:packed.size].copy_(self.torch.from_numpy(packed), non_blocking=True)
 
     def _sync(self) -> None:
         if self.device.type == "cuda":
@@ -245,6 +300,54 @@ class ShardedPool:
         """THE data-path collective on the way in: one broadcast of the packed pool buffer."""
         if self.dist and self.world > 1:
             self.dist.broadcast(self.buf, self.src, group=self.group)
+
+    def _in_slices(self, r: int):
+        """What rank r's distro range reads of the packed pool, as slices of the (full-size) buffer at their own offsets:
+        the rows [task_off[d0], task_off[d1]) of every task column, dep_off over the same rows (+ 1), the rows' edges, the
+        range's hosts, and -- whole -- the header and the per-distro tables (a few KB)."""
+        lay = self.layout
+        d0, d1 = self.ranges[r]
+        r0, r1 = int(self.task_off[d0]), int(self.task_off[d1])
+        e0, e1 = int(self.edge_cut[r]), int(self.edge_cut[r + 1])
+        h0, h1 = int(self.host_off[d0]), int(self.host_off[d1])
+        out = [self.buf[:HEADER_WORDS * 8]]
+        for name, (pos, dt, count) in lay.sections.items():
+            isz = dt.itemsize
+            if name in abi.TASK_COLUMNS or name == "tg_name_key":
+                lo, hi = r0, r1
+            elif name == "dep_off":
+                lo, hi = r0, r1 + 1
+            elif name in abi.EDGE_COLUMNS:
+                lo, hi = e0, e1
+            elif name.startswith("host_") and name != "host_off":
+                lo, hi = h0, h1
+            else:  # distros, task_off, tg_off, ver_off, alloc_params, host_off: whole (bytes)
+                lo, hi = 0, count
+            if hi > lo:
+                out.append(self.buf[pos + lo * isz:pos + hi * isz])
+        return out
+
+    def scatter(self) -> None:
+        """SURVEY 8(e)'s cheaper way in: ONE group of point-to-point sends -- rank r receives only what its range reads."""
+        if not (self.dist and self.world > 1):
+            return
+        dist, ops = self.dist, []
+        if self.rank == self.src:
+            for r in range(self.world):
+                if r != self.src:
+                    ops += [dist.P2POp(dist.isend, t, r, group=self.group) for t in self._in_slices(r)]
+        else:
+            ops = [dist.P2POp(dist.irecv, t, self.src, group=self.group) for t in self._in_slices(self.rank)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def move_in(self) -> None:
+        """The data-path collective on the way in, by mode."""
+        if self.mode == "scatter":
+            self.scatter()
+        else:
+            self.broadcast()
 
     @property
     def my_range(self) -> Tuple[int, int]:
@@ -306,7 +409,7 @@ class ShardedPool:
             self.allocate()
 
     def tick(self) -> None:
-        self.broadcast()
+        self.move_in()
         self.plan_allocate()
         self.gather()
 
