@@ -24,6 +24,7 @@ TF_OTHER_DISTRO, TF_S3_STORAGE, TF_BLOCKED = 0x20, 0x40, 0x80
 TF_STATUS_SHIFT = 8
 DEP_REQ_SUCCESS, DEP_REQ_FAILED, DEP_REQ_ALL, DEP_REQ_NEVER = 0, 1, 2, 3
 DEP_STATE_SHIFT = 2
+DEP_REQ_MASK = 0x3
 DEP_BLOCKED, DEP_MISSING = 0x10, 0x20
 HF_FREE, HF_RUNNING, HF_RUNNING_FOUND = 0x1, 0x2, 0x4
 
@@ -56,6 +57,18 @@ EVG_PROMISE_ALL_ON_LDS_PATH = 1
 class PlanOutput(C.Structure):
     _fields_ = [("order", _p), ("breakdown", _p), ("deps_met", _p), ("wait_ns", _p),
                 ("distro_info", _p), ("group_info", _p), ("n_units", _p), ("unit_of_task", _p), ("unit_breakdown", _p)]
+
+
+class RowUpdate(C.Structure):  # evg_row_update
+    _fields_ = [("n_rows", C.c_int32), ("reserved", C.c_int32), ("rows", _p), ("priority", _p), ("expected_duration_ns", _p),
+                ("queue_ts_ns", _p), ("scheduled_ts_ns", _p), ("deps_met_ts_ns", _p), ("num_dependents", _p), ("flags", _p)]
+
+
+class EdgeUpdate(C.Structure):  # evg_edge_update
+    _fields_ = [("n_edges", C.c_int32), ("reserved", C.c_int32), ("edges", _p), ("dep_info", _p), ("dep_finished_ts_ns", _p)]
+
+
+EVG_ABI_MAJOR, EVG_ABI_MINOR = 2, 0
 
 
 class HostSoa(C.Structure):

@@ -74,6 +74,8 @@ struct PlanArgs {
   unsigned long long* w_tgbit;   // one bit per row of every row tile: the row is a task-group task
   uint32_t* w_srank;             // [row tiles x 64] rank of every sample key of a sorted tile among ALL keys of its distro
   int32_t tiled_mode;            // TM_* bits (EVG_TILED_MODE; 0 = default)
+  uint32_t* w_status;            // host-visible status word of the context (evg_take_device_status), or nullptr: set to 1 by a
+                                 // planner workgroup that cannot plan its distro although the batch promised it could
   int32_t d0, d1;      // the distros this call plans: [d0, d1) of the batch (evg_plan_distro_range_device; else 0, D).
                        // Outputs keep the FULL batch's row / info-row numbering.
 #ifdef EVG_PHASE_TIMING

@@ -1079,7 +1079,10 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const Pla
 #endif
   const AllocArgs none{};
   const bool done = n <= kN && plan_distro_lds<RICH, false, BD>(a, none, d, lo, n, smem, s_red);
-  if (threadIdx.x == 0) a.w_generic[d] = done ? 0 : 1;
+  if (threadIdx.x == 0) {
+    a.w_generic[d] = done ? 0 : 1;
+    if (!done && a.w_status) *(volatile uint32_t*)a.w_status = 1u;  // EVG_PROMISE_ALL_ON_LDS_PATH was false: nobody will plan this distro
+  }
 }
 
 // The batched tick in one launch: plan every distro AND run its host allocator (evg_plan_allocate_device).
@@ -1101,7 +1104,10 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const Fu
 #endif
   EVG_STAMP(0);
   const bool done = n <= kN && plan_distro_lds<RICH, true, BD>(f.p, f.q, d, lo, n, smem, s_red);
-  if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
+  if (threadIdx.x == 0) {
+    f.p.w_generic[d] = done ? 0 : 1;
+    if (!done && f.p.w_status) *(volatile uint32_t*)f.p.w_status = 1u;
+  }
 }
 
 #ifdef EVG_WITH_WIDE

@@ -295,6 +295,33 @@ __global__ void __launch_bounds__(256) k_expand_breakdown(size_t n_rows, size_t 
   breakdown[j] = unit_breakdown[f * n_slots + (size_t)unit_of_task[row]];
 }
 
+// ---- evg_pool_update: new values into the resident pool's columns ---------------------------------------------------
+struct RowCols {
+  int64_t *priority, *expected_duration_ns, *queue_ts_ns, *scheduled_ts_ns, *deps_met_ts_ns;
+  int32_t* num_dependents;
+  uint16_t* flags;
+};
+__global__ void __launch_bounds__(256) k_update_rows(int n, const int32_t* rows, RowCols dst, RowCols src) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int r = rows[i];
+  if (src.priority) dst.priority[r] = src.priority[i];
+  if (src.expected_duration_ns) dst.expected_duration_ns[r] = src.expected_duration_ns[i];
+  if (src.queue_ts_ns) dst.queue_ts_ns[r] = src.queue_ts_ns[i];
+  if (src.scheduled_ts_ns) dst.scheduled_ts_ns[r] = src.scheduled_ts_ns[i];
+  if (src.deps_met_ts_ns) dst.deps_met_ts_ns[r] = src.deps_met_ts_ns[i];
+  if (src.num_dependents) dst.num_dependents[r] = src.num_dependents[i];
+  if (src.flags) dst.flags[r] = src.flags[i];
+}
+__global__ void __launch_bounds__(256) k_update_edges(int n, const int32_t* edges, uint8_t* dst_info, int64_t* dst_fin, const uint8_t* info,
+                                                      const int64_t* fin) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int e = edges[i];
+  if (info) dst_info[e] = info[i];
+  if (fin && dst_fin) dst_fin[e] = fin[i];
+}
+
 // ---- self-test of the scoring arithmetic (evg_selftest_unit_value) --------------------------------------------------
 // unit_value's fast time terms against the Go-shaped statement of the same formula, all 13 breakdown fields, on inputs
 // built to sit on and around everything the fast form's proof leans on. Case i (grid-stride):
@@ -389,6 +416,17 @@ struct evg_ctx {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool tiled_attr_set = false;
   bool dispatch_attr_set = false;
+  uint32_t* status_word = nullptr;  // page-locked, device-visible: what evg_take_device_status reports
+  // small host-pointer batches: ONE page-locked block + ONE device block (inputs packed in, outputs packed out: one copy each way)
+  unsigned char *pack_h = nullptr, *pack_d = nullptr;
+  size_t pack_cap = 0;
+  // large host-pointer batches: uploads (stream), kernels (stream_k) and downloads (stream_d) of consecutive distro ranges overlap
+  hipStream_t stream_k = nullptr, stream_d = nullptr;
+  hipEvent_t ev_up[8] = {}, ev_plan[8] = {};
+  // the resident pool (evg_pool_load / _update / _plan): device copies of a batch + what the host must remember of it
+  std::vector<DevBuf> pool = std::vector<DevBuf>(20);
+  evg_plan_input pool_in{};  // device pointers into `pool`
+  bool pool_loaded = false;
   int tiled_mode = 0;  // EVG_TILED_MODE: TM_* bits (evg_tiled.hip.h), A/B runs of the large-distro pipeline's per-row / pairwise forms
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts = nullptr;
@@ -432,17 +470,60 @@ static int ensure(evg_ctx* c, DevBuf& b, size_t bytes) {
 // were enqueued included), the context's stream is drained first, so no copy touches caller memory after the return.
 struct StreamDrain {
   evg_ctx* c;
-  ~StreamDrain() { (void)hipStreamSynchronize(c->stream); }
+  ~StreamDrain() {
+    (void)hipStreamSynchronize(c->stream);
+    if (c->stream_k) (void)hipStreamSynchronize(c->stream_k);
+    if (c->stream_d) (void)hipStreamSynchronize(c->stream_d);
+  }
 };
+
+// Batches up to this many bytes (inputs + outputs) travel packed: the calls of the reference's own shape -- one distro per
+// TaskPlanner / HostAllocator call, a few thousand tasks -- are bound by the NUMBER of copies (~30 x 5-10 us), not by bytes.
+constexpr size_t kPackLimit = 8u << 20;
 
 struct Stager {
   evg_ctx* c;
   int slot = 0;
   int rc = EVG_OK;
-  // uploads `bytes` from host pointer h; returns device pointer (nullptr when h is null / empty)
+  // packed mode: inputs are memcpy'd into the context's page-locked block and leave in ONE H2D copy (flush_in); outputs are
+  // carved out of the same device block behind them and come back in ONE D2H copy (flush_out), then to the caller's buffers
+  bool packed = false;
+  size_t in_off = 0, in_cap = 0, out_off = 0;
+  struct Down { void* host; size_t off, bytes; };
+  std::vector<Down> downs;
+  static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+  // in_bytes / out_bytes: upper bounds INCLUDING 256 bytes of alignment per array
+  int begin_packed(size_t in_bytes, size_t out_bytes) {
+    in_bytes = al(in_bytes);  // the outputs start behind the inputs: aligned like everything else (scalar loads ignore low address bits)
+    const size_t need = in_bytes + out_bytes;
+    if (need > c->pack_cap) {
+      if (c->pack_h) (void)hipHostFree(c->pack_h);
+      if (c->pack_d) (void)hipFree(c->pack_d);
+      c->pack_h = c->pack_d = nullptr;
+      c->pack_cap = 0;
+      const size_t want = need + need / 4 + 4096;
+      if (hipHostMalloc((void**)&c->pack_h, want, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&c->pack_d, want) != hipSuccess)
+        return rc = set_err(c, EVG_E_NOMEM, "cannot allocate the %zu-byte staging blocks", want);
+      c->pack_cap = want;
+    }
+    packed = true;
+    in_cap = in_bytes;
+    return EVG_OK;
+  }
+  // uploads `count` elements from host pointer h; returns the device pointer (nullptr when h is null / empty)
   template <class T>
   T* up(const T* h, size_t count) {
     if (rc || !h || count == 0) { slot++; return nullptr; }
+    if (packed) {
+      slot++;
+      const size_t bytes = count * sizeof(T);
+      if (in_off + al(bytes) > in_cap) { rc = set_err(c, EVG_E_INVALID, "internal: packed staging overflow (in)"); return nullptr; }
+      memcpy(c->pack_h + in_off, h, bytes);
+      T* d = (T*)(c->pack_d + in_off);
+      in_off += al(bytes);
+      return d;
+    }
     DevBuf& b = c->stage[slot++];
     rc = ensure(c, b, count * sizeof(T));
     if (rc) return nullptr;
@@ -452,39 +533,105 @@ struct Stager {
     }
     return (T*)b.p;
   }
+  // device room for `count` elements of column `slot` WITHOUT a copy (the pipelined path uploads the column in pieces)
   template <class T>
-  T* out(size_t count, bool wanted) {
-    if (rc || !wanted || count == 0) { slot++; return nullptr; }
+  T* room(const T* h, size_t count) {
+    if (rc || !h || count == 0) { slot++; return nullptr; }
     DevBuf& b = c->stage[slot++];
     rc = ensure(c, b, count * sizeof(T));
     return rc ? nullptr : (T*)b.p;
   }
   template <class T>
-  void down(T* h, const T* dptr, size_t count) {
+  T* out(size_t count, bool wanted) {
+    if (rc || !wanted || count == 0) { slot++; return nullptr; }
+    if (packed) {
+      slot++;
+      const size_t bytes = count * sizeof(T);
+      if (in_cap + out_off + al(bytes) > c->pack_cap) { rc = set_err(c, EVG_E_INVALID, "internal: packed staging overflow (out)"); return nullptr; }
+      T* d = (T*)(c->pack_d + in_cap + out_off);
+      out_off += al(bytes);
+      return d;
+    }
+    DevBuf& b = c->stage[slot++];
+    rc = ensure(c, b, count * sizeof(T));
+    return rc ? nullptr : (T*)b.p;
+  }
+  int flush_in() {
+    if (rc || !packed || in_off == 0) return rc;
+    if (hipMemcpyAsync(c->pack_d, c->pack_h, in_off, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = set_err(c, EVG_E_HIP, "H2D copy failed");
+    return rc;
+  }
+  template <class T>
+  void down(T* h, const T* dptr, size_t count, hipStream_t st = nullptr) {
     if (rc || !h || !dptr || count == 0) return;
-    if (hipMemcpyAsync(h, dptr, count * sizeof(T), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+    if (packed) { downs.push_back({(void*)h, (size_t)((const unsigned char*)dptr - c->pack_d), count * sizeof(T)}); return; }
+    if (hipMemcpyAsync(h, dptr, count * sizeof(T), hipMemcpyDeviceToHost, st ? st : c->stream) != hipSuccess)
       rc = set_err(c, EVG_E_HIP, "D2H copy failed");
+  }
+  // packed: the ONE copy back, the wait, and the caller's buffers filled from the block; else just the wait
+  int finish() {
+    if (rc) return rc;
+    if (packed && out_off) {
+      if (hipMemcpyAsync(c->pack_h + in_cap, c->pack_d + in_cap, out_off, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        return rc = set_err(c, EVG_E_HIP, "D2H copy failed");
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return rc = set_err(c, EVG_E_HIP, "hipStreamSynchronize failed");
+    for (const Down& x : downs) memcpy(x.host, c->pack_h + x.off, x.bytes);
+    return EVG_OK;
   }
 };
 
 // Uploads the planner's batch (stage slots 0..18); returns the device-side view.
-static evg_plan_input stage_plan_input(Stager& s, const evg_plan_input* in) {
+// pieces: the row / edge columns only get device room here; upload_plan_rows copies them range by range (the per-distro
+// tables always travel whole, first).
+static evg_plan_input stage_plan_input(Stager& s, const evg_plan_input* in, bool pieces = false) {
   const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, D = in->n_distros;
   evg_plan_input di = *in;
   if (di.max_distro_tasks <= 0)  // the offsets are host memory here: fill the launch hint in
     for (size_t d = 0; d < D; d++) di.max_distro_tasks = std::max(di.max_distro_tasks, in->task_off[d + 1] - in->task_off[d]);
   const evg_task_soa& t = in->tasks;
   evg_task_soa& dt = di.tasks;
-  dt.priority = s.up(t.priority, N); dt.expected_duration_ns = s.up(t.expected_duration_ns, N);
-  dt.queue_ts_ns = s.up(t.queue_ts_ns, N); dt.scheduled_ts_ns = s.up(t.scheduled_ts_ns, N);
-  dt.deps_met_ts_ns = s.up(t.deps_met_ts_ns, N); dt.num_dependents = s.up(t.num_dependents, N);
-  dt.task_group_order = s.up(t.task_group_order, N); dt.task_group_max_hosts = s.up(t.task_group_max_hosts, N);
-  dt.tg_key = s.up(t.tg_key, N); dt.version_key = s.up(t.version_key, N); dt.flags = s.up(t.flags, N);
-  dt.dep_off = s.up(t.dep_off, N + 1); dt.dep_idx = s.up(t.dep_idx, E); dt.dep_info = s.up(t.dep_info, E);
-  dt.dep_finished_ts_ns = s.up(t.dep_finished_ts_ns, E);
+  auto col = [&](auto* h, size_t n) { return pieces ? s.room(h, n) : s.up(h, n); };
+  dt.priority = col(t.priority, N); dt.expected_duration_ns = col(t.expected_duration_ns, N);
+  dt.queue_ts_ns = col(t.queue_ts_ns, N); dt.scheduled_ts_ns = col(t.scheduled_ts_ns, N);
+  dt.deps_met_ts_ns = col(t.deps_met_ts_ns, N); dt.num_dependents = col(t.num_dependents, N);
+  dt.task_group_order = col(t.task_group_order, N); dt.task_group_max_hosts = col(t.task_group_max_hosts, N);
+  dt.tg_key = col(t.tg_key, N); dt.version_key = col(t.version_key, N); dt.flags = col(t.flags, N);
+  dt.dep_off = col(t.dep_off, N + 1); dt.dep_idx = col(t.dep_idx, E); dt.dep_info = col(t.dep_info, E);
+  dt.dep_finished_ts_ns = col(t.dep_finished_ts_ns, E);
   di.distros = s.up(in->distros, D); di.task_off = s.up(in->task_off, D + 1); di.tg_off = s.up(in->tg_off, D + 1);
   di.ver_off = s.up(in->ver_off, D + 1);
   return di;
+}
+
+// Rows [r0, r1) of every row column and their dependency edges, host -> device, on the upload stream.
+static int upload_plan_rows(evg_ctx* c, const evg_plan_input* in, const evg_plan_input& di, size_t r0, size_t r1) {
+  const evg_task_soa &t = in->tasks, &dt = di.tasks;
+  auto cp = [&](const auto* h, const auto* d, size_t lo, size_t hi) -> int {
+    if (!h || !d || hi <= lo) return EVG_OK;
+    typedef std::remove_const_t<std::remove_pointer_t<decltype(h)>> T;
+    if (hipMemcpyAsync((void*)(d + lo), h + lo, (hi - lo) * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      return set_err(c, EVG_E_HIP, "H2D copy failed");
+    return EVG_OK;
+  };
+  const size_t e0 = (size_t)t.dep_off[r0], e1 = (size_t)t.dep_off[r1];
+  int rc = EVG_OK;
+  if (!rc) rc = cp(t.priority, dt.priority, r0, r1);
+  if (!rc) rc = cp(t.expected_duration_ns, dt.expected_duration_ns, r0, r1);
+  if (!rc) rc = cp(t.queue_ts_ns, dt.queue_ts_ns, r0, r1);
+  if (!rc) rc = cp(t.scheduled_ts_ns, dt.scheduled_ts_ns, r0, r1);
+  if (!rc) rc = cp(t.deps_met_ts_ns, dt.deps_met_ts_ns, r0, r1);
+  if (!rc) rc = cp(t.num_dependents, dt.num_dependents, r0, r1);
+  if (!rc) rc = cp(t.task_group_order, dt.task_group_order, r0, r1);
+  if (!rc) rc = cp(t.task_group_max_hosts, dt.task_group_max_hosts, r0, r1);
+  if (!rc) rc = cp(t.tg_key, dt.tg_key, r0, r1);
+  if (!rc) rc = cp(t.version_key, dt.version_key, r0, r1);
+  if (!rc) rc = cp(t.flags, dt.flags, r0, r1);
+  if (!rc) rc = cp(t.dep_off, dt.dep_off, r0, r1 + 1);
+  if (!rc) rc = cp(t.dep_idx, dt.dep_idx, e0, e1);
+  if (!rc) rc = cp(t.dep_info, dt.dep_info, e0, e1);
+  if (!rc) rc = cp(t.dep_finished_ts_ns, dt.dep_finished_ts_ns, e0, e1);
+  return rc;
 }
 
 // D-way parallel loop over the distros on up to 8 threads (large batches only): f(d) -> false stops that thread's range.
@@ -505,7 +652,32 @@ static void for_distros_parallel(const evg_plan_input* in, F f) {
 
 extern "C" {
 
-int32_t evg_abi_version(void) { return (1 << 16) | 2; }
+int32_t evg_abi_version(void) { return (EVG_ABI_MAJOR << 16) | EVG_ABI_MINOR; }
+
+int evg_check_abi(int32_t major, int32_t minor, size_t sizeof_plan_input, size_t sizeof_plan_output, size_t sizeof_alloc_input,
+                  size_t sizeof_group_info) {
+  if (major != EVG_ABI_MAJOR || minor > EVG_ABI_MINOR) return EVG_E_INVALID;
+  if (sizeof_plan_input != sizeof(evg_plan_input) || sizeof_plan_output != sizeof(evg_plan_output) ||
+      sizeof_alloc_input != sizeof(evg_alloc_input) || sizeof_group_info != sizeof(evg_group_info))
+    return EVG_E_INVALID;
+  return EVG_OK;
+}
+
+// The sticky device-side status (a false EVG_PROMISE_ALL_ON_LDS_PATH seen by the planner kernel): every entry point checks it first.
+static int pending_status(evg_ctx* c) {
+  if (c->status_word && *(volatile uint32_t*)c->status_word)
+    return set_err(c, EVG_E_CONTRACT, "a batch passed with EVG_PROMISE_ALL_ON_LDS_PATH held a distro the one-workgroup kernel cannot plan: "
+                                      "its plan was not computed (evg_take_device_status clears this)");
+  return EVG_OK;
+}
+
+int evg_take_device_status(evg_ctx* c) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  const int rc = pending_status(c);
+  if (c->status_word) *(volatile uint32_t*)c->status_word = 0;
+  return rc;
+}
 
 #ifdef EVG_PHASE_TIMING
 // diagnostics build only (scripts/phase_timing.py): device buffer of D x 16 s_memtime stamps
@@ -544,11 +716,14 @@ evg_ctx* evg_create(int device_ordinal) {
   if (const char* w = getenv("EVG_PLAN_WIDE")) c->wide = w[0] == '1';
 #endif
   if (const char* m = getenv("EVG_TILED_MODE")) c->tiled_mode = atoi(m);
-  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-    set_err(nullptr, EVG_E_HIP, "cannot create a stream on device %d", device_ordinal);
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void**)&c->status_word, 64, hipHostMallocDefault) != hipSuccess) {
+    set_err(nullptr, EVG_E_HIP, "cannot create a stream / the status word on device %d", device_ordinal);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return nullptr;
   }
+  *c->status_word = 0;
   return c;
 }
 
@@ -557,9 +732,17 @@ void evg_destroy(evg_ctx* c) {
   (void)hipSetDevice(c->device);
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->stage) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->pool) if (b.p) (void)hipFree(b.p);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->status_word) (void)hipHostFree(c->status_word);
+  if (c->pack_h) (void)hipHostFree(c->pack_h);
+  if (c->pack_d) (void)hipFree(c->pack_d);
+  if (c->stream_k) (void)hipStreamDestroy(c->stream_k);
+  if (c->stream_d) (void)hipStreamDestroy(c->stream_d);
+  for (auto e : c->ev_up) if (e) (void)hipEventDestroy(e);
+  for (auto e : c->ev_plan) if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -733,6 +916,7 @@ int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len
 static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, evg::PlanArgs* pa) {
   using namespace evg;
   if (!c || !in || !out) return EVG_E_INVALID;
+  if (int rc = pending_status(c)) return rc;
   const int D = in->n_distros;
   if (D < 0 || in->tasks.n_tasks < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
   if (D == 0) return EVG_OK;
@@ -769,6 +953,7 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr; a.w_tgbit = nullptr;
   a.w_srank = nullptr;
   a.tiled_mode = c->tiled_mode;
+  a.w_status = (in->promises & EVG_PROMISE_ALL_ON_LDS_PATH) ? c->status_word : nullptr;
 #ifdef EVG_PHASE_TIMING
   a.dbg_ts = c->dbg_ts;
   a.dbg_tiled = c->dbg_tiled;
@@ -783,6 +968,7 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate_wide, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
 #endif
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
     c->lds_attr_set = true;
   }
@@ -818,6 +1004,7 @@ static int finish_breakdown(evg_ctx* c, const evg::PlanArgs& a, const evg_plan_o
 static int prepare_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, evg::AllocArgs* qa) {
   using namespace evg;
   if (!c || !in || !out) return EVG_E_INVALID;
+  if (int rc = pending_status(c)) return rc;
   if (in->n_distros < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
   if (in->n_distros == 0) return EVG_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -933,6 +1120,9 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   if (rc || in->n_distros == 0) return rc;
   if (d_end >= 0) {
     if (d_begin < 0 || d_end < d_begin || d_end > in->n_distros) return set_err(c, EVG_E_INVALID, "distro range [%d, %d) outside [0, %d)", d_begin, d_end, in->n_distros);
+    if (out->breakdown && !(d_begin == 0 && d_end == in->n_distros))  // before anything is enqueued
+      return set_err(c, EVG_E_INVALID, "rows by task (breakdown) are not available from the distro-range entry point; "
+                                       "ask for unit_of_task + unit_breakdown");
     a.d0 = d_begin;
     a.d1 = d_end;
     if (d_begin == d_end) return EVG_OK;
@@ -1029,7 +1219,8 @@ static int launch_plan_allocate(evg_ctx* c, const evg_plan_input* in, const evg_
   f.q.d0 = f.p.d0;
   const int D = f.p.d1 - f.p.d0;
   if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st));
-  if (f.p.out.unit_breakdown || out->n_units) hipLaunchKernelGGL((k_plan_allocate<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, f);
+  if (out->n_units) hipLaunchKernelGGL((k_plan_allocate<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, f);
+  else if (f.p.out.unit_breakdown) hipLaunchKernelGGL((k_plan_allocate<false, true>), dim3(D), dim3(kBlock), kLdsLean, st, f);  // rows per unit need no extra LDS
 #ifdef EVG_WITH_WIDE
   else if (c->wide) hipLaunchKernelGGL(k_plan_allocate_wide, dim3(D), dim3(kN / 2), kLdsLean, st, f);
 #endif
@@ -1194,18 +1385,66 @@ int evg_allocator_report_device(evg_ctx* c, int32_t n_distros, const int32_t* tg
 static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const int32_t* tg_name_key,
                          int32_t max_scheduled, const evg_queue_items* items, const evg_dispatch_order* disp) {
   HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = pending_status(c)) return rc;
   if (in->n_distros < 0 || in->tasks.n_tasks < 0 || in->tasks.n_edges < 0 || in->n_task_groups < 0 || in->n_versions < 0)
     return set_err(c, EVG_E_CONTRACT, "negative size");
-  const size_t N = in->tasks.n_tasks, D = in->n_distros, G = D + in->n_task_groups, TG = in->n_task_groups;
+  const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, D = in->n_distros, G = D + in->n_task_groups, TG = in->n_task_groups;
   if (D == 0) return EVG_OK;
   if (!in->task_off || !in->tg_off || !in->ver_off || !in->distros) return set_err(c, EVG_E_INVALID, "invalid plan input");
   if (disp && !items) return set_err(c, EVG_E_INVALID, "the dispatcher order is built from the persisted queues: items is required");
   if (items && items->breakdown && !out->breakdown) return set_err(c, EVG_E_INVALID, "item breakdowns need the plan's breakdown output");
+  const size_t Stot = N + TG + (size_t)in->n_versions;
   StreamDrain drain{c};
   Stager s{c};
+  // ---- how the batch travels ----------------------------------------------------------------------------------------
+  //   packed     (small batches: the reference's own one-distro calls) one page-locked block in, one block out;
+  //   pipelined  (large batches, plan only) distro range k + 1 uploads while range k is planned and range k - 1 downloads;
+  //   plain      one copy per column on one stream.
+  constexpr size_t A = 256;  // alignment slack per array
+  const size_t in_bytes = N * (5 * 8 + 5 * 4 + 2) + (N + 1) * 4 + E * (4 + 1 + 8) + D * sizeof(evg_distro_params) + 3 * (D + 1) * 4 + (items ? N * 4 : 0) + 24 * A;
+  const size_t out_bytes = N * (4 + 1 + 8) + (out->breakdown ? N * 8 * EVG_BREAKDOWN_FIELDS : 0) + D * sizeof(evg_distro_info) + G * sizeof(evg_group_info) +
+                           (out->n_units ? D * 4 : 0) + (out->unit_of_task ? N * 4 : 0) + (out->unit_breakdown ? Stot * 8 * EVG_BREAKDOWN_FIELDS : 0) +
+                           (items ? D * 4 + (D + 1) * 4 + N * (4 + 8 + 8 + 4 + 4 + 4 + 1) + (items->breakdown ? N * 8 * EVG_BREAKDOWN_FIELDS : 0) : 0) +
+                           (disp ? 2 * N * 4 + 2 * D * 4 + 2 * TG * 4 : 0) + 40 * A;
+  if (in_bytes + out_bytes <= kPackLimit && N > 0) {
+    if (int rc = s.begin_packed(in_bytes, out_bytes)) return rc;
+  }
+  const bool pipelined = !s.packed && !items && !disp && !out->breakdown && !out->n_units && D >= 8 && N + E >= (size_t)(1 << 19);
   // the uploads are enqueued first (plain DMA from evg_host_alloc buffers) and the contract is checked while they run;
   // nothing is launched on a batch that fails it
-  evg_plan_input di = stage_plan_input(s, in);
+  evg_plan_input di = stage_plan_input(s, in, pipelined);
+  if (s.rc) return s.rc;
+  constexpr int kRanges = 4;
+  int cut[kRanges + 1] = {0, 0, 0, 0, 0};
+  if (pipelined) {
+    if (!c->stream_k) {
+      HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_k, hipStreamNonBlocking));
+      HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_d, hipStreamNonBlocking));
+      for (int k = 0; k < 8; k++) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_plan[k], hipEventDisableTiming));
+      }
+    }
+    // offsets are not validated yet: clamp them so that the copies stay inside the caller's arrays whatever they hold
+    const int32_t* to = in->task_off;
+    if (to[0] != 0 || to[D] != (int32_t)N || in->tasks.dep_off[0] != 0 || in->tasks.dep_off[N] != (int32_t)E)
+      return set_err(c, EVG_E_CONTRACT, "task_off / dep_off do not span the batch");
+    for (size_t d = 0; d < D; d++)
+      if (to[d + 1] < to[d]) return set_err(c, EVG_E_CONTRACT, "task_off not monotone at distro %zu", d);
+    for (int k = 1; k < kRanges; k++)
+      cut[k] = (int)(std::lower_bound(to, to + D + 1, (int32_t)(N * k / kRanges)) - to);
+    cut[kRanges] = (int)D;
+    for (int k = 1; k <= kRanges; k++) cut[k] = std::max(cut[k], cut[k - 1]);
+    for (int k = 0; k < kRanges; k++) {  // the edge ranges the copies will use
+      const int32_t e0 = in->tasks.dep_off[to[cut[k]]], e1 = in->tasks.dep_off[to[cut[k + 1]]];
+      if (e0 < 0 || e1 < e0 || e1 > (int32_t)E) return set_err(c, EVG_E_CONTRACT, "dep_off not monotone around distro %d", cut[k]);
+    }
+    for (int k = 0; k < kRanges; k++) {
+      int rc = upload_plan_rows(c, in, di, (size_t)to[cut[k]], (size_t)to[cut[k + 1]]);
+      if (rc) return rc;
+      HIP_TRY(c, hipEventRecord(c->ev_up[k], c->stream));
+    }
+  }
   char msg[256];
   int rc = evg_validate_plan_input(in, msg, sizeof msg);
   if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
@@ -1241,7 +1480,6 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
   } else {
     s.slot += 6;
   }
-  const size_t Stot = N + TG + (size_t)in->n_versions;
   dout.unit_of_task = s.out<int32_t>(N, out->unit_of_task != nullptr);
   dout.unit_breakdown = s.out<int64_t>(Stot * EVG_BREAKDOWN_FIELDS, out->unit_breakdown != nullptr);
   if (s.rc) return s.rc;
@@ -1256,6 +1494,37 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
       qi.group_index = (int32_t*)b.p; qi.n_dependencies = (int32_t*)b.p; qi.dependencies_met = (uint8_t*)b.p;
     }
   }
+  if (pipelined) {
+    // range k: planned on stream_k once its rows are up (the ranges are planned one after the other: one context, one set of
+    // scratch), downloaded on stream_d once it is planned -- while range k + 1 is still uploading on c->stream
+    const int32_t *to = in->task_off, *tgo = in->tg_off, *vo = in->ver_off;
+    for (int k = 0; k < kRanges; k++) {
+      const int d0 = cut[k], d1 = cut[k + 1];
+      if (d1 == d0) continue;
+      HIP_TRY(c, hipStreamWaitEvent(c->stream_k, c->ev_up[k], 0));
+      rc = launch_plan(c, &di, &dout, c->stream_k, d0, d1);
+      if (rc) return rc;
+      HIP_TRY(c, hipEventRecord(c->ev_plan[k], c->stream_k));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream_d, c->ev_plan[k], 0));
+      const size_t r0 = to[d0], r1 = to[d1];
+      s.down(out->order + r0, dout.order + r0, r1 - r0, c->stream_d);
+      s.down(out->deps_met + r0, dout.deps_met + r0, r1 - r0, c->stream_d);
+      s.down(out->wait_ns + r0, dout.wait_ns + r0, r1 - r0, c->stream_d);
+      s.down(out->distro_info + d0, dout.distro_info + d0, (size_t)(d1 - d0), c->stream_d);
+      s.down(out->group_info + d0, dout.group_info + d0, (size_t)(d1 - d0), c->stream_d);
+      s.down(out->group_info + D + tgo[d0], dout.group_info + D + tgo[d0], (size_t)(tgo[d1] - tgo[d0]), c->stream_d);
+      if (out->unit_of_task) {
+        s.down(out->unit_of_task + r0, dout.unit_of_task + r0, r1 - r0, c->stream_d);
+        const size_t u0 = (size_t)to[d0] + tgo[d0] + vo[d0], u1 = (size_t)to[d1] + tgo[d1] + vo[d1];  // the range's unit slots, per field
+        for (size_t f = 0; f < EVG_BREAKDOWN_FIELDS; f++)
+          s.down(out->unit_breakdown + f * Stot + u0, dout.unit_breakdown + f * Stot + u0, u1 - u0, c->stream_d);
+      }
+    }
+    if (s.rc) return s.rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream_d));
+    return EVG_OK;
+  }
+  if (s.flush_in()) return s.rc;
   rc = launch_plan(c, &di, &dout, c->stream);
   if (rc) return rc;
   if (items) {
@@ -1288,9 +1557,7 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
     s.down(disp->group_items, od.group_items, N); s.down(disp->group_start, od.group_start, TG);
     s.down(disp->group_count, od.group_count, TG);
   }
-  if (s.rc) return s.rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return EVG_OK;
+  return s.finish();
 }
 
 int evg_plan_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out) {
@@ -1359,6 +1626,150 @@ int evg_rebuild_dispatchers(evg_ctx* c, int32_t n_distros, const int32_t* item_o
   return EVG_OK;
 }
 
+int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
+  if (!c || !in) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = pending_status(c)) return rc;
+  c->pool_loaded = false;
+  char msg[256];
+  int rc = evg_validate_plan_input(in, msg, sizeof msg);
+  if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
+  StreamDrain drain{c};
+  evg_plan_input di = *in;
+  rc = evg_plan_launch_hints(in, &di.max_distro_tasks, &di.promises);
+  if (rc) return set_err(c, rc, "invalid plan input");
+  const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, D = in->n_distros;
+  int slot = 0;
+  auto up = [&](const auto* h, size_t count) -> decltype(h) {
+    DevBuf& b = c->pool[slot++];
+    if (rc || !h || count == 0) return nullptr;
+    typedef std::remove_const_t<std::remove_pointer_t<decltype(h)>> T;
+    rc = ensure(c, b, count * sizeof(T));
+    if (rc) return nullptr;
+    if (hipMemcpyAsync(b.p, h, count * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = set_err(c, EVG_E_HIP, "H2D copy failed"); return nullptr; }
+    return (decltype(h))b.p;
+  };
+  const evg_task_soa& t = in->tasks;
+  evg_task_soa& dt = di.tasks;
+  dt.priority = up(t.priority, N); dt.expected_duration_ns = up(t.expected_duration_ns, N); dt.queue_ts_ns = up(t.queue_ts_ns, N);
+  dt.scheduled_ts_ns = up(t.scheduled_ts_ns, N); dt.deps_met_ts_ns = up(t.deps_met_ts_ns, N); dt.num_dependents = up(t.num_dependents, N);
+  dt.task_group_order = up(t.task_group_order, N); dt.task_group_max_hosts = up(t.task_group_max_hosts, N);
+  dt.tg_key = up(t.tg_key, N); dt.version_key = up(t.version_key, N); dt.flags = up(t.flags, N);
+  dt.dep_off = up(t.dep_off, N + 1); dt.dep_idx = up(t.dep_idx, E); dt.dep_info = up(t.dep_info, E);
+  dt.dep_finished_ts_ns = up(t.dep_finished_ts_ns, E);
+  di.distros = up(in->distros, D); di.task_off = up(in->task_off, D + 1); di.tg_off = up(in->tg_off, D + 1); di.ver_off = up(in->ver_off, D + 1);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->pool_in = di;
+  c->pool_loaded = true;
+  return EVG_OK;
+}
+
+int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update* eu) {
+  if (!c) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = pending_status(c)) return rc;
+  if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_update: no pool is loaded on this context");
+  const evg_plan_input& p = c->pool_in;
+  const int nr = ru ? ru->n_rows : 0, ne = eu ? eu->n_edges : 0;
+  if (nr < 0 || ne < 0 || (nr > 0 && !ru->rows) || (ne > 0 && !eu->edges)) return set_err(c, EVG_E_INVALID, "evg_pool_update: null or negative");
+  for (int i = 0; i < nr; i++) {
+    if (ru->rows[i] < 0 || ru->rows[i] >= p.tasks.n_tasks) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: row %d is outside the pool", ru->rows[i]);
+    // a priority beyond int32 takes the distro off the one-workgroup path: the promise made at load time no longer holds
+    if (ru->priority && ru->priority[i] != (int64_t)(int32_t)ru->priority[i]) c->pool_in.promises &= ~EVG_PROMISE_ALL_ON_LDS_PATH;
+  }
+  for (int i = 0; i < ne; i++)
+    if (eu->edges[i] < 0 || eu->edges[i] >= p.tasks.n_edges) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: edge %d is outside the pool", eu->edges[i]);
+  if (ne > 0 && eu->dep_finished_ts_ns && !p.tasks.dep_finished_ts_ns)
+    return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_finished_ts_ns");
+  if (nr == 0 && ne == 0) return EVG_OK;
+  StreamDrain drain{c};
+  Stager s{c};
+  const size_t in_bytes = (size_t)nr * (4 + 5 * 8 + 4 + 2) + (size_t)ne * (4 + 1 + 8) + 16 * 256;
+  if (in_bytes <= kPackLimit)
+    if (int rc = s.begin_packed(in_bytes, 256)) return rc;
+  if (nr > 0) {
+    const int32_t* d_rows = s.up(ru->rows, nr);
+    evg::RowCols src{(int64_t*)s.up(ru->priority, nr), (int64_t*)s.up(ru->expected_duration_ns, nr), (int64_t*)s.up(ru->queue_ts_ns, nr),
+                     (int64_t*)s.up(ru->scheduled_ts_ns, nr), (int64_t*)s.up(ru->deps_met_ts_ns, nr), (int32_t*)s.up(ru->num_dependents, nr),
+                     (uint16_t*)s.up(ru->flags, nr)};
+    if (s.rc) return s.rc;
+    if (s.flush_in()) return s.rc;
+    const evg_task_soa& t = p.tasks;
+    evg::RowCols dst{(int64_t*)t.priority, (int64_t*)t.expected_duration_ns, (int64_t*)t.queue_ts_ns, (int64_t*)t.scheduled_ts_ns,
+                     (int64_t*)t.deps_met_ts_ns, (int32_t*)t.num_dependents, (uint16_t*)t.flags};
+    hipLaunchKernelGGL(evg::k_update_rows, dim3((nr + 255) / 256), dim3(256), 0, c->stream, nr, d_rows, dst, src);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the packed block is re-used below
+  }
+  if (ne > 0) {
+    Stager s2{c};
+    if (in_bytes <= kPackLimit)
+      if (int rc = s2.begin_packed(in_bytes, 256)) return rc;
+    const int32_t* d_edges = s2.up(eu->edges, ne);
+    const uint8_t* d_info = s2.up(eu->dep_info, ne);
+    const int64_t* d_fin = s2.up(eu->dep_finished_ts_ns, ne);
+    if (s2.rc) return s2.rc;
+    if (s2.flush_in()) return s2.rc;
+    hipLaunchKernelGGL(evg::k_update_edges, dim3((ne + 255) / 256), dim3(256), 0, c->stream, ne, d_edges, (uint8_t*)p.tasks.dep_info,
+                       (int64_t*)p.tasks.dep_finished_ts_ns, d_info, d_fin);
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EVG_OK;
+}
+
+int evg_pool_plan(evg_ctx* c, int64_t now_ns, const evg_plan_output* out) {
+  if (!c || !out) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = pending_status(c)) return rc;
+  if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_plan: no pool is loaded on this context");
+  if (!out->order || !out->deps_met || !out->wait_ns || !out->distro_info || !out->group_info)
+    return set_err(c, EVG_E_INVALID, "order, deps_met, wait_ns, distro_info and group_info outputs are required");
+  evg_plan_input di = c->pool_in;
+  di.now_ns = now_ns;
+  const size_t N = di.tasks.n_tasks, D = di.n_distros, G = D + di.n_task_groups, Stot = N + (size_t)di.n_task_groups + (size_t)di.n_versions;
+  if (D == 0) return EVG_OK;
+  StreamDrain drain{c};
+  Stager s{c};
+  const size_t out_bytes = N * (4 + 1 + 8) + (out->breakdown ? N * 8 * EVG_BREAKDOWN_FIELDS : 0) + D * sizeof(evg_distro_info) + G * sizeof(evg_group_info) +
+                           (out->n_units ? D * 4 : 0) + (out->unit_of_task ? N * 4 : 0) + (out->unit_breakdown ? Stot * 8 * EVG_BREAKDOWN_FIELDS : 0) + 16 * 256;
+  if (out_bytes <= kPackLimit && N > 0)
+    if (int rc = s.begin_packed(256, out_bytes)) return rc;
+  evg_plan_output dout;
+  dout.order = s.out<int32_t>(N, true);
+  dout.breakdown = s.out<int64_t>(N * EVG_BREAKDOWN_FIELDS, out->breakdown != nullptr);
+  dout.deps_met = s.out<uint8_t>(N, true);
+  dout.wait_ns = s.out<int64_t>(N, true);
+  dout.distro_info = s.out<evg_distro_info>(D, true);
+  dout.group_info = s.out<evg_group_info>(G, true);
+  dout.n_units = s.out<int32_t>(D, out->n_units != nullptr);
+  dout.unit_of_task = s.out<int32_t>(N, out->unit_of_task != nullptr);
+  dout.unit_breakdown = s.out<int64_t>(Stot * EVG_BREAKDOWN_FIELDS, out->unit_breakdown != nullptr);
+  if (s.rc) return s.rc;
+  if (N == 0) {
+    DevBuf& b = c->stage[47];
+    int rc = ensure(c, b, 64);
+    if (rc) return rc;
+    dout.order = (int32_t*)b.p; dout.deps_met = (uint8_t*)b.p; dout.wait_ns = (int64_t*)b.p;
+  }
+  int rc = launch_plan(c, &di, &dout, c->stream);
+  if (rc) return rc;
+  s.down(out->order, dout.order, N);
+  s.down(out->breakdown, dout.breakdown, N * EVG_BREAKDOWN_FIELDS);
+  s.down(out->deps_met, dout.deps_met, N);
+  s.down(out->wait_ns, dout.wait_ns, N);
+  s.down(out->distro_info, dout.distro_info, D);
+  s.down(out->group_info, dout.group_info, G);
+  s.down(out->n_units, dout.n_units, D);
+  s.down(out->unit_of_task, dout.unit_of_task, N);
+  s.down(out->unit_breakdown, dout.unit_breakdown, Stot * EVG_BREAKDOWN_FIELDS);
+  return s.finish();
+}
+
 int evg_filter_runnable(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
                         int32_t* runnable_row, int32_t* runnable_count) {
   if (!c || !in) return EVG_E_INVALID;
@@ -1425,6 +1836,7 @@ int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_ou
   if (!c || !in || !out) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = pending_status(c)) return rc;
   const size_t D = in->n_distros, G = D + in->n_task_groups, H = in->hosts.n_hosts;
   if (D == 0) return EVG_OK;
   if (!in->params || !in->host_off || !in->tg_off || !in->distro_info || !in->group_info || !out->new_hosts ||
@@ -1433,6 +1845,11 @@ int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_ou
   StreamDrain drain{c};
   Stager s{c};
   s.slot = 24;
+  const size_t in_bytes = D * (sizeof(evg_alloc_params) + sizeof(evg_distro_info)) + 2 * (D + 1) * 4 + H * (1 + 4 + 3 * 8) + G * sizeof(evg_group_info) + 12 * 256;
+  const size_t out_bytes = 3 * D * 4 + 4 * 256;
+  if (in_bytes + out_bytes <= kPackLimit) {  // one HostAllocator call of the reference: one distro, a few hundred hosts
+    if (int rc = s.begin_packed(in_bytes, out_bytes)) return rc;
+  }
   evg_alloc_input di = *in;
   di.params = s.up(in->params, D); di.host_off = s.up(in->host_off, D + 1); di.tg_off = s.up(in->tg_off, D + 1);
   di.hosts.flags = s.up(in->hosts.flags, H); di.hosts.tg_key = s.up(in->hosts.tg_key, H);
@@ -1444,14 +1861,18 @@ int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_ou
   evg_alloc_output dout;
   dout.new_hosts = s.out<int32_t>(D, true); dout.free_hosts = s.out<int32_t>(D, true); dout.status = s.out<int32_t>(D, true);
   if (s.rc) return s.rc;
+  if (s.flush_in()) return s.rc;
   int rc = launch_alloc(c, &di, &dout, c->stream);
   if (rc) return rc;
   s.down(out->new_hosts, dout.new_hosts, D); s.down(out->free_hosts, dout.free_hosts, D);
   s.down(out->status, dout.status, D);
-  s.down(in->group_info, (const evg_group_info*)di.group_info, G);
-  if (s.rc) return s.rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return EVG_OK;
+  if (s.packed) {  // group_info is in/out and sits in the INPUT half of the block: its own small copy back
+    if (hipMemcpyAsync(in->group_info, di.group_info, G * sizeof(evg_group_info), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+      return set_err(c, EVG_E_HIP, "D2H copy failed");
+  } else {
+    s.down(in->group_info, (const evg_group_info*)di.group_info, G);
+  }
+  return s.finish();
 }
 
 }  // extern "C"

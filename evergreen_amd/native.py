@@ -24,7 +24,7 @@ EXPORTS = [
     "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
     "evg_plan_distro_range_device", "evg_allocate_host_range_device", "evg_selftest_unit_value",
     "evg_host_alloc", "evg_host_free", "evg_profile_plan_kernel", "evg_last_plan_kernel_ms", "evg_plan_launch_hints",
-    "evg_plan_allocate_range_device",
+    "evg_plan_allocate_range_device", "evg_check_abi", "evg_take_device_status", "evg_pool_load", "evg_pool_update", "evg_pool_plan",
 ]
 
 _lib = None
@@ -92,6 +92,18 @@ def load_library() -> C.CDLL:
     if hasattr(lib, "evg_profile_plan_kernel"):
         lib.evg_profile_plan_kernel.argtypes = [C.c_void_p, C.c_int]
         lib.evg_last_plan_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    if hasattr(lib, "evg_check_abi"):
+        lib.evg_check_abi.argtypes = [C.c_int32, C.c_int32] + [C.c_size_t] * 4
+        lib.evg_take_device_status.argtypes = [C.c_void_p]
+        lib.evg_pool_load.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput)]
+        lib.evg_pool_update.argtypes = [C.c_void_p, C.POINTER(abi.RowUpdate), C.POINTER(abi.EdgeUpdate)]
+        lib.evg_pool_plan.argtypes = [C.c_void_p, C.c_int64, C.POINTER(abi.PlanOutput)]
+        # what a binding does once at start-up: refuse a library whose structs are not the ones it was written against
+        rc = lib.evg_check_abi(abi.EVG_ABI_MAJOR, abi.EVG_ABI_MINOR, C.sizeof(abi.PlanInput), C.sizeof(abi.PlanOutput), C.sizeof(abi.AllocInput),
+                               abi.GROUP_INFO_DTYPE.itemsize)
+        if rc != abi.EVG_OK:
+            raise NativeError("%s: ABI %#x does not match this binding (%d.%d, struct sizes)" % (LIB_PATH, lib.evg_abi_version(), abi.EVG_ABI_MAJOR,
+                                                                                             abi.EVG_ABI_MINOR))
     if hasattr(lib, "evg_selftest_unit_value"):  # absent from older builds loaded through EVG_SCHED_LIB (A/B runs)
         lib.evg_selftest_unit_value.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
@@ -205,6 +217,55 @@ class Context:
         out = res.c_output()
         self._check(self.lib.evg_plan_distros(self.h, C.byref(inp), C.byref(out)), "evg_plan_distros")
         return res
+
+    # ---- the resident pool: load once, update the rows that changed, plan (evg_pool_*) --------------------------------
+    def pool_load(self, batch: abi.PlanBatch) -> None:
+        inp = abi.make_plan_input(batch)
+        self._check(self.lib.evg_pool_load(self.h, C.byref(inp)), "evg_pool_load")
+
+    def pool_update(self, rows: Optional[np.ndarray] = None, cols: Optional[dict] = None, edges: Optional[np.ndarray] = None,
+                    dep_info: Optional[np.ndarray] = None, dep_finished_ts_ns: Optional[np.ndarray] = None) -> None:
+        """cols: {column name of evg_row_update: new values in the order of `rows`}."""
+        ru, eu, keep = None, None, []
+        if rows is not None and len(rows):
+            ru = abi.RowUpdate()
+            r = np.ascontiguousarray(rows, np.int32)
+            keep.append(r)
+            ru.n_rows, ru.rows = len(r), r.ctypes.data
+            dts = {"priority": np.int64, "expected_duration_ns": np.int64, "queue_ts_ns": np.int64, "scheduled_ts_ns": np.int64,
+                   "deps_met_ts_ns": np.int64, "num_dependents": np.int32, "flags": np.uint16}
+            for k, v in (cols or {}).items():
+                a = np.ascontiguousarray(v, dts[k])
+                assert len(a) == len(r)
+                keep.append(a)
+                setattr(ru, k, a.ctypes.data)
+        if edges is not None and len(edges):
+            eu = abi.EdgeUpdate()
+            e = np.ascontiguousarray(edges, np.int32)
+            keep.append(e)
+            eu.n_edges, eu.edges = len(e), e.ctypes.data
+            if dep_info is not None:
+                a = np.ascontiguousarray(dep_info, np.uint8)
+                keep.append(a)
+                eu.dep_info = a.ctypes.data
+            if dep_finished_ts_ns is not None:
+                a = np.ascontiguousarray(dep_finished_ts_ns, np.int64)
+                keep.append(a)
+                eu.dep_finished_ts_ns = a.ctypes.data
+        self._check(self.lib.evg_pool_update(self.h, C.byref(ru) if ru is not None else None, C.byref(eu) if eu is not None else None),
+                    "evg_pool_update")
+
+    def pool_plan(self, batch: abi.PlanBatch, now_ns: int, breakdown: bool = False, n_units: bool = False, units: bool = False,
+                  into: Optional[abi.PlanResult] = None) -> abi.PlanResult:
+        """`batch` only sizes the result arrays (the pool on the device is what is planned)."""
+        res = into if into is not None else abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=n_units, units=units)
+        out = res.c_output()
+        self._check(self.lib.evg_pool_plan(self.h, now_ns, C.byref(out)), "evg_pool_plan")
+        return res
+
+    def take_device_status(self) -> int:
+        """EVG_OK, or EVG_E_CONTRACT when a batch enqueued with a false EVG_PROMISE_ALL_ON_LDS_PATH was seen by the kernels."""
+        return self.lib.evg_take_device_status(self.h)
 
     def allocate(self, batch: abi.PlanBatch, distro_info: np.ndarray, group_info: np.ndarray,
                  into: Optional[abi.AllocResult] = None) -> abi.AllocResult:

@@ -171,15 +171,17 @@ typedef struct evg_plan_input {
   const int32_t* ver_off;             /* D+1 */
   int64_t now_ns;
   int32_t promises;                   /* EVG_PROMISE_* (ABI 1.2), 0 = none. Unlike the hint above a promise is part of the
-                                         contract: a false one gives a wrong plan. The host-pointer entry points work them
-                                         out themselves and ignore this field; a *_device caller takes them from
-                                         evg_plan_launch_hints on its host copy of the batch                          */
+                                         contract: a false one leaves the plan uncomputed (and evg_take_device_status
+                                         reports it). The host-pointer entry points work them out themselves and ignore
+                                         this field; a *_device caller takes them from evg_plan_launch_hints on its host
+                                         copy of the batch                                                             */
   int32_t reserved0;
 } evg_plan_input;
 
 /* Every distro of the batch can be planned by the one-workgroup kernel: at most 2048 tasks, unit slots + dependency
  * edges inside its LDS budget, at most 1023 task groups, every |priority| below 2^31. The library then does not enqueue the
- * kernels that pick up what that kernel leaves (one empty launch, ~4.5 us of a ~70 us tick on BASELINE config 3). */
+ * kernels that pick up what that kernel leaves (one empty launch, ~4.5 us of a ~70 us tick on BASELINE config 3). A false
+ * promise is detected on the device and reported by evg_take_device_status: the plan of such a batch must not be used. */
 #define EVG_PROMISE_ALL_ON_LDS_PATH 0x1
 
 /* ---- outputs -------------------------------------------------------------------------------- */
@@ -327,8 +329,25 @@ int evg_last_plan_kernel_ms(evg_ctx* ctx, float* ms);
 /* Last error message of `ctx` (or of the failed evg_create when ctx == NULL). */
 const char* evg_last_error(const evg_ctx* ctx);
 
-/* Library/ABI version: (major << 16) | minor. */
+/* Library/ABI version: (major << 16) | minor. MAJOR changes whenever a struct of this header changes size or layout (2.0:
+ * evg_plan_input / evg_plan_output as they have been since 1.2 -- growing them under a MINOR bump was a mistake, a shim built
+ * against 1.0 would have passed shorter structs); MINOR adds entry points only. */
+#define EVG_ABI_MAJOR 2
+#define EVG_ABI_MINOR 0
 int32_t evg_abi_version(void);
+/* What a binding calls once at start-up with ITS compile-time view of the header: EVG_OK iff the library's major equals
+ * `major`, its minor is at least `minor`, and the four struct sizes are the library's. A binding must refuse the library
+ * otherwise (the library reads every field of the structs it is handed). */
+int evg_check_abi(int32_t major, int32_t minor, size_t sizeof_plan_input, size_t sizeof_plan_output, size_t sizeof_alloc_input,
+                  size_t sizeof_group_info);
+
+/* Sticky device-side status of `ctx` (ABI 2.0). The *_device entry points only enqueue, so a contract violation that only
+ * the kernels can see -- today: a batch passed with EVG_PROMISE_ALL_ON_LDS_PATH that holds a distro the one-workgroup kernel
+ * cannot plan (its plan was NOT computed) -- is recorded by the kernel in a host-visible word. This call returns
+ * EVG_E_CONTRACT (message via evg_last_error) if a batch enqueued on `ctx` before the caller's last stream synchronisation
+ * recorded one, and clears it; EVG_OK otherwise. Every later entry point on the context fails with EVG_E_CONTRACT too until
+ * the status is taken. A caller that passes promises calls this after it synchronised the stream, before it uses the plan. */
+int evg_take_device_status(evg_ctx* ctx);
 
 /* Host-side check of the layout contract; no GPU work. */
 int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len);
@@ -489,6 +508,38 @@ int evg_rebuild_dispatchers(evg_ctx* ctx, int32_t n_distros, const int32_t* item
  * Every pointer is host memory; synchronous. Results are identical to the separate calls. */
 int evg_schedule_distros(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out, const int32_t* tg_name_key,
                          int32_t max_scheduled, const evg_queue_items* items, const evg_dispatch_order* dispatch);
+
+/* ---- a pool that stays on the device between ticks (ABI 2.0) -----------------------------------------------------------
+ * The reference re-plans every distro every 15 s (units/crons_remote_fifteen_second.go:21) over a queue of which a few per
+ * cent changed. evg_pool_load validates a batch, uploads it ONCE and keeps it on the device (owned by `ctx`: one pool per
+ * context); evg_pool_update overwrites the listed rows' per-task VALUE columns and the listed dependency edges' state, so a
+ * tick that changes 5 % of the pool moves 5 % of the bytes; evg_pool_plan plans the resident pool for a new `now_ns` and
+ * downloads the outputs (exactly evg_plan_distros's, bit for bit, on the updated batch). The pool's STRUCTURE -- the row set,
+ * the distro / key / CSR layout -- is what evg_pool_load saw: a tick that adds or removes tasks loads again. Host pointers;
+ * synchronous; nothing of the caller's is retained. */
+typedef struct evg_row_update {
+  int32_t n_rows;
+  int32_t reserved;
+  const int32_t* rows;                  /* n_rows row numbers, distinct */
+  /* new values, n_rows entries each, in the order of `rows`; NULL = the column is unchanged */
+  const int64_t* priority;
+  const int64_t* expected_duration_ns;
+  const int64_t* queue_ts_ns;
+  const int64_t* scheduled_ts_ns;
+  const int64_t* deps_met_ts_ns;
+  const int32_t* num_dependents;
+  const uint16_t* flags;                /* EVG_TF_*: status, blocked, override ... (the task-group / version keys are structure) */
+} evg_row_update;
+typedef struct evg_edge_update {
+  int32_t n_edges;
+  int32_t reserved;
+  const int32_t* edges;                 /* n_edges edge numbers (positions in dep_idx), distinct */
+  const uint8_t* dep_info;              /* EVG_DEP_* of the edge (a dependency outside the queue finished, became blocked ...), or NULL */
+  const int64_t* dep_finished_ts_ns;    /* Dependency.FinishedAt, or NULL */
+} evg_edge_update;
+int evg_pool_load(evg_ctx* ctx, const evg_plan_input* in);
+int evg_pool_update(evg_ctx* ctx, const evg_row_update* rows, const evg_edge_update* edges); /* either may be NULL */
+int evg_pool_plan(evg_ctx* ctx, int64_t now_ns, const evg_plan_output* out);
 
 /* Host-pointer forms of evg_filter_runnable_device and evg_allocator_report_device (stage in, run, stage out). */
 int evg_filter_runnable(evg_ctx* ctx, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,

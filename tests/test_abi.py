@@ -42,7 +42,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     """sizeof / offsetof from the real header (gcc) against the ctypes structs and numpy dtypes."""
     structs = {"evg_task_soa": abi.TaskSoa, "evg_plan_input": abi.PlanInput, "evg_plan_output": abi.PlanOutput,
                "evg_host_soa": abi.HostSoa, "evg_alloc_input": abi.AllocInput, "evg_alloc_output": abi.AllocOutput,
-               "evg_queue_items": abi.QueueItems, "evg_dispatch_order": abi.DispatchOrder}
+               "evg_queue_items": abi.QueueItems, "evg_dispatch_order": abi.DispatchOrder, "evg_row_update": abi.RowUpdate,
+               "evg_edge_update": abi.EdgeUpdate}
     dtypes = {"evg_distro_params": abi.DISTRO_PARAMS_DTYPE, "evg_group_info": abi.GROUP_INFO_DTYPE,
               "evg_distro_info": abi.DISTRO_INFO_DTYPE, "evg_alloc_params": abi.ALLOC_PARAMS_DTYPE,
               "evg_report_params": abi.REPORT_PARAMS_DTYPE, "evg_alloc_report": abi.ALLOC_REPORT_DTYPE}
@@ -110,7 +111,20 @@ def test_validate_plan_input_on_host(lib):
 
 
 def test_abi_version(lib):
-    assert lib.evg_abi_version() >> 16 == 1
+    assert lib.evg_abi_version() == (abi.EVG_ABI_MAJOR << 16) | abi.EVG_ABI_MINOR
+    src = open(HEADER).read()
+    assert "#define EVG_ABI_MAJOR %d" % abi.EVG_ABI_MAJOR in src and "#define EVG_ABI_MINOR %d" % abi.EVG_ABI_MINOR in src
+
+
+def test_check_abi_refuses_other_majors_and_struct_sizes(lib):
+    """What a binding calls once: its own compile-time view of the header must be the library's (a shim built
+    against shorter structs would have had `promises` read out of bounds)."""
+    sz = (C.sizeof(abi.PlanInput), C.sizeof(abi.PlanOutput), C.sizeof(abi.AllocInput), abi.GROUP_INFO_DTYPE.itemsize)
+    assert lib.evg_check_abi(abi.EVG_ABI_MAJOR, abi.EVG_ABI_MINOR, *sz) == abi.EVG_OK
+    assert lib.evg_check_abi(abi.EVG_ABI_MAJOR, 0, *sz) == abi.EVG_OK                      # an older minor of the same major is fine
+    assert lib.evg_check_abi(abi.EVG_ABI_MAJOR - 1, 2, *sz) == abi.EVG_E_INVALID          # a 1.x binding
+    assert lib.evg_check_abi(abi.EVG_ABI_MAJOR, abi.EVG_ABI_MINOR + 1, *sz) == abi.EVG_E_INVALID  # built against a newer minor
+    assert lib.evg_check_abi(abi.EVG_ABI_MAJOR, abi.EVG_ABI_MINOR, sz[0] - 8, *sz[1:]) == abi.EVG_E_INVALID  # a shorter evg_plan_input
 
 
 def test_no_gpu_means_no_context_and_no_fallback(lib):

@@ -482,3 +482,111 @@ def test_promise_all_on_lds_path(native_ctx, oracle):
     b = gen.generate(gen.config(1))
     b.cols["priority"][3] = 2**40
     _full_compare(native_ctx, oracle, b, "wide priority", validity=False)
+
+
+def test_false_promise_is_reported_not_silently_wrong(native_ctx, oracle):
+    """A batch passed to a *_device entry point with EVG_PROMISE_ALL_ON_LDS_PATH although one distro holds more than 2048 tasks
+    (a false promise used to give a wrong plan with EVG_OK): the planner workgroup of that distro records it in the
+    context's host-visible status word; evg_take_device_status reports EVG_E_CONTRACT once and clears it, every other entry
+    point refuses to run until then, and the same batch without the promise plans correctly afterwards."""
+    import torch
+    from evergreen_amd import native, resident
+    b = gen.generate(gen.GenConfig(12_000, 4, 4243, skew=True))
+    assert int(np.diff(b.task_off).max()) > 2048
+    pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"))
+    assert not (pool.inp.promises & abi.EVG_PROMISE_ALL_ON_LDS_PATH)  # the hints never promise this
+    assert native_ctx.take_device_status() == abi.EVG_OK
+    pool.inp.promises = abi.EVG_PROMISE_ALL_ON_LDS_PATH                 # ... a caller lies
+    pool.plan()
+    torch.cuda.synchronize()
+    with pytest.raises(native.NativeError):                             # the next call on the context refuses
+        pool.plan()
+    assert native_ctx.take_device_status() == abi.EVG_E_CONTRACT
+    assert native_ctx.take_device_status() == abi.EVG_OK                # taken: cleared
+    pool.inp.promises = 0
+    pool.plan()
+    torch.cuda.synchronize()
+    assert native_ctx.take_device_status() == abi.EVG_OK
+    want = oracle.plan(b, breakdown=False, n_units=False)
+    want.breakdown, want.n_units = None, None
+    compare.assert_plan_equal(pool.plan_result(), want, b, "after the false promise")
+
+
+def _changed_batch(b, frac, seed, now_ns):
+    """A copy of batch b in which `frac` of the rows got new values in every updatable column and `frac` of the out-of-queue
+    dependency edges a new state -- what 15 s of a live queue do (priorities bumped, durations re-estimated, dependencies
+    finishing) -- plus the row / edge lists and the new values, as evg_pool_update takes them."""
+    import copy
+    rng = np.random.default_rng(seed)
+    b2 = copy.deepcopy(b)
+    b2.now_ns = now_ns
+    n, e = b.n_tasks, b.n_edges
+    rows = np.sort(rng.choice(n, max(1, int(n * frac)), replace=False)).astype(np.int32)
+    k = len(rows)
+    cols = {
+        "priority": rng.integers(0, 120, k).astype(np.int64),
+        "expected_duration_ns": (rng.integers(10, 14_000, k) * 10**9).astype(np.int64),
+        "queue_ts_ns": (now_ns - rng.integers(0, 9 * 24 * 3600, k) * 10**9).astype(np.int64),
+        "scheduled_ts_ns": (now_ns - rng.integers(0, 3600, k) * 10**9).astype(np.int64),
+        "deps_met_ts_ns": np.where(rng.random(k) < 0.2, now_ns - rng.integers(0, 7200, k) * 10**9, 0).astype(np.int64),
+        "num_dependents": rng.integers(0, 60, k).astype(np.int32),
+        "flags": (((b.cols["flags"][rows] ^ np.where(rng.random(k) < 0.3, abi.TF_OVERRIDE_DEPS, 0).astype(np.uint16)) & np.uint16(~(3 << abi.TF_STATUS_SHIFT) & 0xFFFF)) |
+                  (rng.integers(0, 3, k).astype(np.uint16) << abi.TF_STATUS_SHIFT)).astype(np.uint16),
+    }
+    for name, v in cols.items():
+        b2.cols[name][rows] = v
+    ooq = np.nonzero(b.edges["dep_idx"] < 0)[0]
+    edges = np.sort(rng.choice(ooq, max(1, int(len(ooq) * frac)), replace=False)).astype(np.int32) if len(ooq) else np.zeros(0, np.int32)
+    info = ((b.edges["dep_info"][edges] & abi.DEP_REQ_MASK) | (rng.integers(0, 3, len(edges)).astype(np.uint8) << abi.DEP_STATE_SHIFT)).astype(np.uint8)
+    fin = (now_ns - rng.integers(0, 3600, len(edges)) * 10**9).astype(np.int64)
+    b2.edges["dep_info"][edges] = info
+    b2.edges["dep_finished_ts_ns"][edges] = fin
+    return b2, rows, cols, edges, info, fin
+
+
+@pytest.mark.parametrize("cfg", [gen.config(2), gen.GenConfig(40_000, 9, 515, skew=True, dag_depth=6)], ids=["config2", "zipf-large-distros"])
+def test_resident_pool_updates_equal_a_full_upload(native_ctx, oracle, cfg):
+    """evg_pool_load once, then per tick evg_pool_update with the 5 % of rows / out-of-queue edges that changed and
+    evg_pool_plan with the tick's clock: bit-identical to planning the changed batch from scratch (host-pointer path and oracle)."""
+    b = gen.generate(cfg)
+    native_ctx.pool_load(b)
+    got = native_ctx.pool_plan(b, b.now_ns, units=True)
+    want = oracle.plan(b, breakdown=False, n_units=False)
+    want.breakdown, want.n_units = None, None
+    compare.assert_plan_equal(got, want, b, "pool as loaded")
+    cur = b
+    for tick in range(1, 4):
+        cur, rows, cols, edges, info, fin = _changed_batch(cur, 0.05, 100 + tick, b.now_ns + tick * 15 * 10**9)
+        native_ctx.pool_update(rows, cols, edges, info, fin)
+        got = native_ctx.pool_plan(cur, cur.now_ns, units=True)
+        want = oracle.plan(cur, breakdown=True, n_units=False)
+        want.n_units = None
+        got.breakdown = got.expand_breakdown()
+        compare.assert_plan_equal(got, want, cur, "pool after tick %d" % tick)
+        full = native_ctx.plan(cur, breakdown=True, n_units=False)
+        assert np.array_equal(full.order, got.order) and np.array_equal(full.breakdown, got.breakdown)
+    # an update may take a distro off the one-workgroup path: the promise made at load time must not survive it
+    rows = np.array([3], np.int32)
+    native_ctx.pool_update(rows, {"priority": np.array([2**40], np.int64)})
+    cur.cols["priority"][3] = 2**40
+    got = native_ctx.pool_plan(cur, cur.now_ns)
+    want = oracle.plan(cur, breakdown=False, n_units=False)
+    want.breakdown, want.n_units = None, None
+    compare.assert_plan_equal(got, want, cur, "pool after a 2^40 priority")
+
+
+def test_large_host_pointer_batch_travels_in_overlapping_ranges(native_ctx, oracle):
+    """BASELINE config 3 through evg_plan_distros on host buffers: beyond the packed-staging size the call uploads, plans and
+    downloads four distro ranges on three streams (range k + 1 uploads while range k plans and range k - 1 downloads); the
+    result -- unit rows included -- is the resident tick's and the oracle's, and the next call re-uses everything."""
+    b = gen.generate(gen.config(3))
+    want = oracle.plan(b, breakdown=True, n_units=False)
+    want.n_units = None
+    pb = native_ctx.pinned_batch(b)
+    for rep in range(2):
+        got = native_ctx.plan(pb, breakdown=False, n_units=False, units=True)
+        got.breakdown = got.expand_breakdown()
+        compare.assert_plan_equal(got, want, b, "pipelined host path, call %d" % rep)
+    got = native_ctx.plan(b, breakdown=False, n_units=False)  # pageable memory, no unit rows
+    want.breakdown = None
+    compare.assert_plan_equal(got, want, b, "pipelined host path, pageable")
