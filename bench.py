@@ -56,7 +56,9 @@ def oracle_threads(batch, want_threads, reps=5):
 
 
 def cpu_baseline(batch, want_threads):
-    """Times the oracle (oracle/libevg_oracle.so) on the SAME pool: all host cores, plus a single-thread pass."""
+    """Times the oracle (oracle/libevg_oracle.so) on the SAME pool: all host cores (5 passes: min and median -- the figure
+    moves 2x with where the threads land), plus a single-thread pass. Returns (PlanResult, AllocResult, single-thread s,
+    min s, median s, threads)."""
     import ctypes as C
     from evergreen_amd import abi
     from tests import oracle_lib
@@ -70,10 +72,131 @@ def cpu_baseline(batch, want_threads):
         if batch.alloc_params is not None:
             o.allocate(batch, res1.distro_info, res1.group_info)
         t1 = min(t1, time.perf_counter() - t0)
-    res, alloc, tn, nt = oracle_threads(batch, want_threads)
+    res, alloc, tn, times, nt = oracle_lib.plan_threads(batch, want_threads, reps=5)
     import numpy as np
     assert np.array_equal(res.order, res1.order)
-    return res, alloc, t1, tn, nt
+    return res, alloc, t1, tn, sorted(times)[len(times) // 2], nt
+
+
+def per_distro_calls(batch, native, got, got_alloc, dev_index):
+    """The reference's OWN call shape: one TaskPlanner call and one HostAllocator call PER DISTRO (units/crons.go:303-332 ->
+    scheduler/scheduler.go:28-52; units/host_allocator.go:183-188), host pointers in and out (evg_plan_distros +
+    evg_allocate_hosts on a batch of one: the packed-staging path, one copy each way). Sequential on one context, then on 8 and
+    32 threads with one context each (amboy runs the distro jobs concurrently, units/scheduler.go:48-49). The ctypes argument
+    blocks are built before the clock starts; the timed loops are the C calls alone."""
+    import ctypes as C
+    import numpy as np
+    from evergreen_amd import abi
+    lib = native.load_library()
+    D = batch.n_distros
+    subs = [batch.one_distro(d) for d in range(D)]
+    res = [abi.PlanResult.alloc_host(b, breakdown=False, n_units=False, units=True) for b in subs]
+    ares = [abi.AllocResult.alloc_host(1) for _ in subs]
+    pin = [abi.make_plan_input(b) for b in subs]
+    pout = [r.c_output() for r in res]
+    ain = [abi.make_alloc_input(b, r.distro_info, r.group_info) for b, r in zip(subs, res)]
+    aout = [a.c_output() for a in ares]
+
+    def run(ctxs):
+        nt = len(ctxs)
+        lat = [[] for _ in range(nt)]
+        bad = []
+
+        def work(w):
+            h = ctxs[w].h
+            for d in range(w, D, nt):
+                t0 = time.perf_counter()
+                rc = lib.evg_plan_distros(h, C.byref(pin[d]), C.byref(pout[d]))
+                rc2 = lib.evg_allocate_hosts(h, C.byref(ain[d]), C.byref(aout[d]))
+                lat[w].append(time.perf_counter() - t0)
+                if rc or rc2:
+                    bad.append((d, rc, rc2))
+        t0 = time.perf_counter()
+        if nt == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(w,)) for w in range(nt)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        wall = time.perf_counter() - t0
+        xs = sorted(x for l in lat for x in l)
+        return wall, xs, bad
+    out = {"what": "BASELINE config 3's 512 distros planned + allocated as 512 one-distro host-pointer calls (evg_plan_distros + evg_allocate_hosts, "
+                   "unit rows requested), the reference's own call shape; the reference's budget per distro is its 15 s cron cadence "
+                   "(units/crons_remote_fifteen_second.go:21)", "distros": D, "tasks": batch.n_tasks}
+    for nt in (1, 8, 32):
+        ctxs = [native.Context(dev_index) for _ in range(nt)]
+        try:
+            run(ctxs)  # warm-up: staging blocks, scratch
+            wall, xs, bad = run(ctxs)
+        finally:
+            for c in ctxs:
+                c.close()
+        out["threads_%d" % nt] = {"wall_ms": wall * 1e3, "tasks_per_s": batch.n_tasks / wall, "us_per_call_pair_p50": xs[len(xs) // 2] * 1e6,
+                                  "us_per_call_pair_p99": xs[int(len(xs) * 0.99)] * 1e6, "errors": len(bad)}
+    # parity: the 512 single-distro plans, re-based, are the batched plan
+    same = True
+    for d in range(D):
+        lo, hi = int(batch.task_off[d]), int(batch.task_off[d + 1])
+        same &= bool(np.array_equal(res[d].order + lo, got.order[lo:hi]) and np.array_equal(res[d].wait_ns, got.wait_ns[lo:hi]))
+        if got_alloc is not None:
+            same &= bool(ares[d].new_hosts[0] == got_alloc.new_hosts[d] and ares[d].free_hosts[0] == got_alloc.free_hosts[d])
+    out["identical_to_the_batched_tick"] = same
+    return out
+
+
+def delta_tick(batch, native, dev_index, got):
+    """The resident pool with delta updates (evg_pool_load once; per tick evg_pool_update with the 5 % of rows that changed +
+    evg_pool_plan) against re-uploading the whole pool every tick (evg_plan_distros on page-locked buffers)."""
+    import numpy as np
+    from evergreen_amd import abi
+    ctx = native.Context(dev_index)
+    try:
+        rng = np.random.default_rng(5)
+        n = batch.n_tasks
+        k = n // 20
+        pb = ctx.pinned_batch(batch)
+        res = ctx.pinned_result(abi.PlanResult.alloc_host(batch, breakdown=False, n_units=False))
+        ctx.pool_load(pb)
+        r0 = ctx.pool_plan(batch, batch.now_ns, into=res)
+        same0 = bool(np.array_equal(r0.order, got.order))
+        ticks, t_upd, t_plan = 5, [], []
+        cur_pri = batch.cols["priority"].copy()
+        cur_dur = batch.cols["expected_duration_ns"].copy()
+        now = batch.now_ns
+        for _ in range(ticks):
+            rows = np.sort(rng.choice(n, k, replace=False)).astype(np.int32)
+            pri = rng.integers(0, 100, k).astype(np.int64)
+            dur = (rng.integers(10, 14_000, k) * 10**9).astype(np.int64)
+            cur_pri[rows], cur_dur[rows] = pri, dur
+            now += 15 * 10**9
+            t0 = time.perf_counter()
+            ctx.pool_update(rows, {"priority": pri, "expected_duration_ns": dur})
+            t1 = time.perf_counter()
+            ctx.pool_plan(batch, now, into=res)
+            t2 = time.perf_counter()
+            t_upd.append(t1 - t0)
+            t_plan.append(t2 - t1)
+        # the same final state planned from a full upload
+        import copy
+        b2 = copy.copy(batch)
+        b2.cols = dict(batch.cols)
+        b2.cols["priority"], b2.cols["expected_duration_ns"], b2.now_ns = cur_pri, cur_dur, now
+        full = ctx.plan(b2, breakdown=False, n_units=False)
+        same = bool(np.array_equal(full.order, res.order) and np.array_equal(full.wait_ns, res.wait_ns) and
+                    np.array_equal(full.distro_info, res.distro_info))
+        bytes_delta = k * (4 + 8 + 8)
+        ms = (sorted(t_upd)[ticks // 2] + sorted(t_plan)[ticks // 2]) * 1e3
+        return {"value": n / (ms * 1e-3), "unit": "tasks/s", "ms_per_tick": ms, "update_ms": sorted(t_upd)[ticks // 2] * 1e3,
+                "plan_and_download_ms": sorted(t_plan)[ticks // 2] * 1e3, "rows_changed_per_tick": int(k), "bytes_in_per_tick": int(bytes_delta),
+                "identical_to_full_upload": same and same0,
+                "what": "evg_pool_load once, then per tick evg_pool_update (5 % of the rows: new priority + expected duration) + evg_pool_plan "
+                        "(new now_ns; order / deps_met / wait / info rows downloaded into page-locked buffers)"}
+    finally:
+        ctx.close()
+
+
+
 
 
 def order_match(batch, got, want):
@@ -166,6 +289,80 @@ def extra_workload(name, cfg, what, dev, native, resident, torch, gen, np):
             "cpu_oracle_threads_s": tn, "cpu_threads": nt}
 
 
+def sharded_workload(make_batch, what, ctx, dev, dist, rank, world, mode, steps, warmup, multi, torch, check=True):
+    """A second pool through the SAME sharded tick as the headline (pool in -> plan + allocate of this rank's distro range ->
+    gather to rank 0), timed the same way (barriers on both sides, max over ranks). Collective: every rank calls it; rank 0
+    returns the object (its parity against the oracle included), the others None."""
+    import numpy as np
+    batch = make_batch() if rank == 0 else None
+    pool = multi.ShardedPool(ctx, dev, fused=False, mode=mode, breakdown=False)
+    pool.setup(multi.pack_pool(batch) if rank == 0 else None)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(warmup):
+        pool.tick()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pool.tick()
+    barrier()
+    el = time.perf_counter() - t0
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        pool.plan_allocate()
+    barrier()
+    el_k = time.perf_counter() - t1
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(steps)]
+    for e in ev:
+        e[0].record(); pool.plan(); e[1].record(); pool.allocate(); e[2].record()
+    barrier()
+    red = torch.tensor([el, el_k], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+    el, el_k = float(red[0]), float(red[1])
+    pool.tick()  # rank 0 holds every rank's slices again
+    barrier()
+    if rank != 0:
+        return None
+    lay = pool.layout
+    plan_ms = sorted(e[0].elapsed_time(e[1]) for e in ev)[len(ev) // 2]
+    alloc_ms = sorted(e[1].elapsed_time(e[2]) for e in ev)[len(ev) // 2]
+    sizes = np.diff(batch.task_off)
+    obj = {"workload": what, "tasks": lay.N, "distros": lay.D, "dep_edges": lay.E, "task_groups": lay.TG, "hosts": lay.H, "n_gpus": world,
+           "pool_in": mode, "pool_bytes": lay.total_bytes, "largest_distro": int(sizes.max()), "distros_over_2048_tasks": int((sizes > 2048).sum()),
+           "rank0_distro_range": list(pool.my_range),
+           "value": lay.N * steps / el, "unit": "tasks/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+           "kernel_only": {"value": lay.N * steps / el_k, "ms_per_step": el_k / steps * 1e3},
+           "rank0_planning-distro_ms": plan_ms, "rank0_host-allocation_ms": alloc_ms}
+    if check:
+        from tests import compare, oracle_lib
+        got, got_alloc = pool.plan_result(), pool.alloc_result()
+        want, want_alloc, tbest, times, nt = oracle_lib.plan_threads(batch, reps=1)
+        n_units = int(want.n_units.sum())
+        want.n_units = None
+        parity = True
+        try:
+            compare.assert_plan_equal(got, want, batch, what)
+            if got_alloc is not None:
+                compare.assert_alloc_equal(got_alloc, want_alloc, what)
+            compare.reference_validity(batch, got)
+        except AssertionError as e:
+            parity = str(e)[:300]
+        d0, d1 = pool.my_range
+        abytes, _ = algorithmic_bytes(batch, int(n_units * (batch.task_off[d1] - batch.task_off[d0]) / max(lay.N, 1)), d0, d1)
+        ach = abytes / (plan_ms * 1e-3) / 1e9
+        obj.update({"parity_vs_oracle": parity, "queue_order_match": order_match(batch, got, want),
+                    "cpu_baseline": {"value": lay.N / tbest, "unit": "tasks/s", "cores": nt, "kind": "port", "sample": "the whole pool, one pass, one distro range per thread"},
+                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": abytes, "kernel_ms": plan_ms,
+                                 "kernel_ms_scope": "rank 0: HIP events around its range's plan call (every kernel of the large-distro pipeline)"}})
+    return obj
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +377,7 @@ def main():
                     "reported next to it as `one_launch`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / skewed / config5_share / pipelined (profiling runs)")
+    ap.add_argument("--no-config5", action="store_true", help="skip BASELINE config 5 at full size (10M tasks: ~90 s of generation and checking)")
     ap.add_argument("--in-flight", type=int, default=3, help="also report the sustained rate with this many independent pools in flight "
                                                              "on their own streams (the `pipelined` object; 1 = skip)")
     args = ap.parse_args()
@@ -271,6 +469,24 @@ def main():
     else:
         sum_tasks = my_tasks
     total_tasks = sum_tasks if args.weak else float(pool.layout.N)
+
+    # ---- collective extras (every rank takes part; rank 0 keeps the objects) -------------------------------------------
+    extra_objs = {}
+    if not args.weak and not args.no_extras:
+        def collective(key, fn):
+            try:
+                extra_objs[key] = fn()
+            except Exception as e:  # must not cost the headline; a collective that failed on one rank fails on all
+                extra_objs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world > 1:  # SURVEY 8(e)'s cheaper way in, next to the broadcast north_star names
+            collective("scatter", lambda: sharded_workload(
+                lambda: batch, "BASELINE config 4 with the pool scattered instead of broadcast: rank r receives only the column slices of its distro range",
+                native.Context(local_rank), dev, dist, rank, world, "scatter", args.steps, args.warmup, multi, torch, check=True))
+        if not args.no_config5:
+            collective("config5_full" if world == 1 else "config5", lambda: sharded_workload(
+                lambda: gen.generate(gen.config(5)), "BASELINE config 5 at full size: 10,000,000 tasks x 512 distros of 19.5k tasks, DAG depth 8, 20% task-group tasks"
+                + (" on one MI355X" if world == 1 else ", distros sharded over %d ranks (one broadcast of the packed pool + one grouped gather per tick)" % world),
+                native.Context(local_rank), dev, dist, rank, world, "broadcast", max(3, min(args.steps, 10)), 2, multi, torch, check=True))
 
     if rank == 0:
         def med(i, j):
@@ -366,7 +582,7 @@ def main():
         if got is not None and not args.no_cpu_baseline:
             try:
                 from tests import compare
-                want, want_alloc, t1s, tn, nt = cpu_baseline(batch, os.cpu_count() or 1)
+                want, want_alloc, t1s, tn, tmed, nt = cpu_baseline(batch, os.cpu_count() or 1)
                 line["queue_order_match"] = order_match(batch, got, want)
                 line["host_counts_match"] = bool(got_alloc is None or (np.array_equal(got_alloc.new_hosts, want_alloc.new_hosts) and
                                                                        np.array_equal(got_alloc.free_hosts, want_alloc.free_hosts)))
@@ -376,13 +592,14 @@ def main():
                     line["reference_validity"] = True
                 except AssertionError as e:
                     line["reference_validity"] = str(e)[:300]
-                if world == 1:
-                    line["cpu_baseline"] = {
-                        "value": batch.n_tasks / tn, "unit": "tasks/s", "cores": nt, "kind": "port",
-                        "single_thread_value": batch.n_tasks / t1s,
-                        "sample": "the whole workload (%d tasks x %d distros), best of 5 passes with %d worker threads, one distro range each "
-                                  "(%.2f s per pass), and best of 3 passes on one thread (%.2f s per pass): C++ oracle, a port of the Go "
-                                  "algorithm (the Go reference cannot be built here: no Go toolchain)" % (batch.n_tasks, batch.n_distros, nt, tn, t1s)}
+                # north_star: "alongside the Go CPU scheduler timed on the same box's host cores in the same run" -- for every N
+                line["cpu_baseline"] = {
+                    "value": batch.n_tasks / tn, "unit": "tasks/s", "cores": nt, "kind": "port", "median_value": batch.n_tasks / tmed,
+                    "single_thread_value": batch.n_tasks / t1s,
+                    "sample": "the whole workload (%d tasks x %d distros) on rank 0's host: 5 passes with %d worker threads, one distro range "
+                              "each (best %.2f s = `value`, median %.2f s = `median_value`: the figure moves with where the threads land), and "
+                              "best of 3 passes on one thread (%.2f s): C++ oracle, a port of the Go algorithm (the Go reference cannot be "
+                              "built here: no Go toolchain)" % (batch.n_tasks, batch.n_distros, nt, tn, tmed, t1s)}
             except Exception as e:
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.weak and not args.no_extras:
@@ -391,6 +608,8 @@ def main():
                     line[key] = fn()
                 except Exception as e:  # an extra measurement must never cost the headline line
                     line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            guarded("per_distro_calls", lambda: per_distro_calls(batch, native, got, got_alloc, dev.index or 0))
+            guarded("delta_5pct", lambda: delta_tick(batch, native, dev.index or 0, got))
 
             def end_to_end():
                 # host pointers in, host pointers out: what INTEGRATION.md's planBatch binds to (PCIe both ways inside).
@@ -465,6 +684,9 @@ def main():
             guarded("one_launch", one_launch)
             if args.in_flight > 1:
                 guarded("pipelined", lambda: pipelined_rate(batch, dev, args.in_flight, min(args.steps, 60), native, resident, torch))
+        for k, v in extra_objs.items():
+            if v is not None:
+                line[k] = v
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -420,9 +420,6 @@ struct evg_ctx {
   // small host-pointer batches: ONE page-locked block + ONE device block (inputs packed in, outputs packed out: one copy each way)
   unsigned char *pack_h = nullptr, *pack_d = nullptr;
   size_t pack_cap = 0;
-  // large host-pointer batches: uploads (stream), kernels (stream_k) and downloads (stream_d) of consecutive distro ranges overlap
-  hipStream_t stream_k = nullptr, stream_d = nullptr;
-  hipEvent_t ev_up[8] = {}, ev_plan[8] = {};
   // the resident pool (evg_pool_load / _update / _plan): device copies of a batch + what the host must remember of it
   std::vector<DevBuf> pool = std::vector<DevBuf>(20);
   evg_plan_input pool_in{};  // device pointers into `pool`
@@ -470,11 +467,7 @@ static int ensure(evg_ctx* c, DevBuf& b, size_t bytes) {
 // were enqueued included), the context's stream is drained first, so no copy touches caller memory after the return.
 struct StreamDrain {
   evg_ctx* c;
-  ~StreamDrain() {
-    (void)hipStreamSynchronize(c->stream);
-    if (c->stream_k) (void)hipStreamSynchronize(c->stream_k);
-    if (c->stream_d) (void)hipStreamSynchronize(c->stream_d);
-  }
+  ~StreamDrain() { (void)hipStreamSynchronize(c->stream); }
 };
 
 // Batches up to this many bytes (inputs + outputs) travel packed: the calls of the reference's own shape -- one distro per
@@ -533,14 +526,6 @@ struct Stager {
     }
     return (T*)b.p;
   }
-  // device room for `count` elements of column `slot` WITHOUT a copy (the pipelined path uploads the column in pieces)
-  template <class T>
-  T* room(const T* h, size_t count) {
-    if (rc || !h || count == 0) { slot++; return nullptr; }
-    DevBuf& b = c->stage[slot++];
-    rc = ensure(c, b, count * sizeof(T));
-    return rc ? nullptr : (T*)b.p;
-  }
   template <class T>
   T* out(size_t count, bool wanted) {
     if (rc || !wanted || count == 0) { slot++; return nullptr; }
@@ -562,10 +547,10 @@ struct Stager {
     return rc;
   }
   template <class T>
-  void down(T* h, const T* dptr, size_t count, hipStream_t st = nullptr) {
+  void down(T* h, const T* dptr, size_t count) {
     if (rc || !h || !dptr || count == 0) return;
     if (packed) { downs.push_back({(void*)h, (size_t)((const unsigned char*)dptr - c->pack_d), count * sizeof(T)}); return; }
-    if (hipMemcpyAsync(h, dptr, count * sizeof(T), hipMemcpyDeviceToHost, st ? st : c->stream) != hipSuccess)
+    if (hipMemcpyAsync(h, dptr, count * sizeof(T), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
       rc = set_err(c, EVG_E_HIP, "D2H copy failed");
   }
   // packed: the ONE copy back, the wait, and the caller's buffers filled from the block; else just the wait
@@ -582,56 +567,23 @@ struct Stager {
 };
 
 // Uploads the planner's batch (stage slots 0..18); returns the device-side view.
-// pieces: the row / edge columns only get device room here; upload_plan_rows copies them range by range (the per-distro
-// tables always travel whole, first).
-static evg_plan_input stage_plan_input(Stager& s, const evg_plan_input* in, bool pieces = false) {
+static evg_plan_input stage_plan_input(Stager& s, const evg_plan_input* in) {
   const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, D = in->n_distros;
   evg_plan_input di = *in;
   if (di.max_distro_tasks <= 0)  // the offsets are host memory here: fill the launch hint in
     for (size_t d = 0; d < D; d++) di.max_distro_tasks = std::max(di.max_distro_tasks, in->task_off[d + 1] - in->task_off[d]);
   const evg_task_soa& t = in->tasks;
   evg_task_soa& dt = di.tasks;
-  auto col = [&](auto* h, size_t n) { return pieces ? s.room(h, n) : s.up(h, n); };
-  dt.priority = col(t.priority, N); dt.expected_duration_ns = col(t.expected_duration_ns, N);
-  dt.queue_ts_ns = col(t.queue_ts_ns, N); dt.scheduled_ts_ns = col(t.scheduled_ts_ns, N);
-  dt.deps_met_ts_ns = col(t.deps_met_ts_ns, N); dt.num_dependents = col(t.num_dependents, N);
-  dt.task_group_order = col(t.task_group_order, N); dt.task_group_max_hosts = col(t.task_group_max_hosts, N);
-  dt.tg_key = col(t.tg_key, N); dt.version_key = col(t.version_key, N); dt.flags = col(t.flags, N);
-  dt.dep_off = col(t.dep_off, N + 1); dt.dep_idx = col(t.dep_idx, E); dt.dep_info = col(t.dep_info, E);
-  dt.dep_finished_ts_ns = col(t.dep_finished_ts_ns, E);
+  dt.priority = s.up(t.priority, N); dt.expected_duration_ns = s.up(t.expected_duration_ns, N);
+  dt.queue_ts_ns = s.up(t.queue_ts_ns, N); dt.scheduled_ts_ns = s.up(t.scheduled_ts_ns, N);
+  dt.deps_met_ts_ns = s.up(t.deps_met_ts_ns, N); dt.num_dependents = s.up(t.num_dependents, N);
+  dt.task_group_order = s.up(t.task_group_order, N); dt.task_group_max_hosts = s.up(t.task_group_max_hosts, N);
+  dt.tg_key = s.up(t.tg_key, N); dt.version_key = s.up(t.version_key, N); dt.flags = s.up(t.flags, N);
+  dt.dep_off = s.up(t.dep_off, N + 1); dt.dep_idx = s.up(t.dep_idx, E); dt.dep_info = s.up(t.dep_info, E);
+  dt.dep_finished_ts_ns = s.up(t.dep_finished_ts_ns, E);
   di.distros = s.up(in->distros, D); di.task_off = s.up(in->task_off, D + 1); di.tg_off = s.up(in->tg_off, D + 1);
   di.ver_off = s.up(in->ver_off, D + 1);
   return di;
-}
-
-// Rows [r0, r1) of every row column and their dependency edges, host -> device, on the upload stream.
-static int upload_plan_rows(evg_ctx* c, const evg_plan_input* in, const evg_plan_input& di, size_t r0, size_t r1) {
-  const evg_task_soa &t = in->tasks, &dt = di.tasks;
-  auto cp = [&](const auto* h, const auto* d, size_t lo, size_t hi) -> int {
-    if (!h || !d || hi <= lo) return EVG_OK;
-    typedef std::remove_const_t<std::remove_pointer_t<decltype(h)>> T;
-    if (hipMemcpyAsync((void*)(d + lo), h + lo, (hi - lo) * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess)
-      return set_err(c, EVG_E_HIP, "H2D copy failed");
-    return EVG_OK;
-  };
-  const size_t e0 = (size_t)t.dep_off[r0], e1 = (size_t)t.dep_off[r1];
-  int rc = EVG_OK;
-  if (!rc) rc = cp(t.priority, dt.priority, r0, r1);
-  if (!rc) rc = cp(t.expected_duration_ns, dt.expected_duration_ns, r0, r1);
-  if (!rc) rc = cp(t.queue_ts_ns, dt.queue_ts_ns, r0, r1);
-  if (!rc) rc = cp(t.scheduled_ts_ns, dt.scheduled_ts_ns, r0, r1);
-  if (!rc) rc = cp(t.deps_met_ts_ns, dt.deps_met_ts_ns, r0, r1);
-  if (!rc) rc = cp(t.num_dependents, dt.num_dependents, r0, r1);
-  if (!rc) rc = cp(t.task_group_order, dt.task_group_order, r0, r1);
-  if (!rc) rc = cp(t.task_group_max_hosts, dt.task_group_max_hosts, r0, r1);
-  if (!rc) rc = cp(t.tg_key, dt.tg_key, r0, r1);
-  if (!rc) rc = cp(t.version_key, dt.version_key, r0, r1);
-  if (!rc) rc = cp(t.flags, dt.flags, r0, r1);
-  if (!rc) rc = cp(t.dep_off, dt.dep_off, r0, r1 + 1);
-  if (!rc) rc = cp(t.dep_idx, dt.dep_idx, e0, e1);
-  if (!rc) rc = cp(t.dep_info, dt.dep_info, e0, e1);
-  if (!rc) rc = cp(t.dep_finished_ts_ns, dt.dep_finished_ts_ns, e0, e1);
-  return rc;
 }
 
 // D-way parallel loop over the distros on up to 8 threads (large batches only): f(d) -> false stops that thread's range.
@@ -739,10 +691,6 @@ void evg_destroy(evg_ctx* c) {
   if (c->status_word) (void)hipHostFree(c->status_word);
   if (c->pack_h) (void)hipHostFree(c->pack_h);
   if (c->pack_d) (void)hipFree(c->pack_d);
-  if (c->stream_k) (void)hipStreamDestroy(c->stream_k);
-  if (c->stream_d) (void)hipStreamDestroy(c->stream_d);
-  for (auto e : c->ev_up) if (e) (void)hipEventDestroy(e);
-  for (auto e : c->ev_plan) if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -1397,9 +1345,11 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
   StreamDrain drain{c};
   Stager s{c};
   // ---- how the batch travels ----------------------------------------------------------------------------------------
-  //   packed     (small batches: the reference's own one-distro calls) one page-locked block in, one block out;
-  //   pipelined  (large batches, plan only) distro range k + 1 uploads while range k is planned and range k - 1 downloads;
-  //   plain      one copy per column on one stream.
+  //   packed   (small batches: the reference's own one-distro calls) one page-locked block in, one block out;
+  //   plain    one copy per column on one stream. (Measured and dropped: four distro ranges uploaded / planned / downloaded
+  //            on three streams so that the download of range k hides behind the upload of range k + 1 -- the copies are a
+  //            quarter the size and four times as many, and their fixed cost outweighs the 0.26 ms of download it hides:
+  //            2.64 ms against 2.3 ms per 1M-task call. A tick that re-plans a mostly unchanged pool uses evg_pool_*.)
   constexpr size_t A = 256;  // alignment slack per array
   const size_t in_bytes = N * (5 * 8 + 5 * 4 + 2) + (N + 1) * 4 + E * (4 + 1 + 8) + D * sizeof(evg_distro_params) + 3 * (D + 1) * 4 + (items ? N * 4 : 0) + 24 * A;
   const size_t out_bytes = N * (4 + 1 + 8) + (out->breakdown ? N * 8 * EVG_BREAKDOWN_FIELDS : 0) + D * sizeof(evg_distro_info) + G * sizeof(evg_group_info) +
@@ -1409,42 +1359,10 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
   if (in_bytes + out_bytes <= kPackLimit && N > 0) {
     if (int rc = s.begin_packed(in_bytes, out_bytes)) return rc;
   }
-  const bool pipelined = !s.packed && !items && !disp && !out->breakdown && !out->n_units && D >= 8 && N + E >= (size_t)(1 << 19);
   // the uploads are enqueued first (plain DMA from evg_host_alloc buffers) and the contract is checked while they run;
   // nothing is launched on a batch that fails it
-  evg_plan_input di = stage_plan_input(s, in, pipelined);
+  evg_plan_input di = stage_plan_input(s, in);
   if (s.rc) return s.rc;
-  constexpr int kRanges = 4;
-  int cut[kRanges + 1] = {0, 0, 0, 0, 0};
-  if (pipelined) {
-    if (!c->stream_k) {
-      HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_k, hipStreamNonBlocking));
-      HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_d, hipStreamNonBlocking));
-      for (int k = 0; k < 8; k++) {
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_up[k], hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_plan[k], hipEventDisableTiming));
-      }
-    }
-    // offsets are not validated yet: clamp them so that the copies stay inside the caller's arrays whatever they hold
-    const int32_t* to = in->task_off;
-    if (to[0] != 0 || to[D] != (int32_t)N || in->tasks.dep_off[0] != 0 || in->tasks.dep_off[N] != (int32_t)E)
-      return set_err(c, EVG_E_CONTRACT, "task_off / dep_off do not span the batch");
-    for (size_t d = 0; d < D; d++)
-      if (to[d + 1] < to[d]) return set_err(c, EVG_E_CONTRACT, "task_off not monotone at distro %zu", d);
-    for (int k = 1; k < kRanges; k++)
-      cut[k] = (int)(std::lower_bound(to, to + D + 1, (int32_t)(N * k / kRanges)) - to);
-    cut[kRanges] = (int)D;
-    for (int k = 1; k <= kRanges; k++) cut[k] = std::max(cut[k], cut[k - 1]);
-    for (int k = 0; k < kRanges; k++) {  // the edge ranges the copies will use
-      const int32_t e0 = in->tasks.dep_off[to[cut[k]]], e1 = in->tasks.dep_off[to[cut[k + 1]]];
-      if (e0 < 0 || e1 < e0 || e1 > (int32_t)E) return set_err(c, EVG_E_CONTRACT, "dep_off not monotone around distro %d", cut[k]);
-    }
-    for (int k = 0; k < kRanges; k++) {
-      int rc = upload_plan_rows(c, in, di, (size_t)to[cut[k]], (size_t)to[cut[k + 1]]);
-      if (rc) return rc;
-      HIP_TRY(c, hipEventRecord(c->ev_up[k], c->stream));
-    }
-  }
   char msg[256];
   int rc = evg_validate_plan_input(in, msg, sizeof msg);
   if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
@@ -1493,36 +1411,6 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
       qi.row = (int32_t*)b.p; qi.expected_duration_ns = (int64_t*)b.p; qi.priority = (int64_t*)b.p; qi.group_max_hosts = (int32_t*)b.p;
       qi.group_index = (int32_t*)b.p; qi.n_dependencies = (int32_t*)b.p; qi.dependencies_met = (uint8_t*)b.p;
     }
-  }
-  if (pipelined) {
-    // range k: planned on stream_k once its rows are up (the ranges are planned one after the other: one context, one set of
-    // scratch), downloaded on stream_d once it is planned -- while range k + 1 is still uploading on c->stream
-    const int32_t *to = in->task_off, *tgo = in->tg_off, *vo = in->ver_off;
-    for (int k = 0; k < kRanges; k++) {
-      const int d0 = cut[k], d1 = cut[k + 1];
-      if (d1 == d0) continue;
-      HIP_TRY(c, hipStreamWaitEvent(c->stream_k, c->ev_up[k], 0));
-      rc = launch_plan(c, &di, &dout, c->stream_k, d0, d1);
-      if (rc) return rc;
-      HIP_TRY(c, hipEventRecord(c->ev_plan[k], c->stream_k));
-      HIP_TRY(c, hipStreamWaitEvent(c->stream_d, c->ev_plan[k], 0));
-      const size_t r0 = to[d0], r1 = to[d1];
-      s.down(out->order + r0, dout.order + r0, r1 - r0, c->stream_d);
-      s.down(out->deps_met + r0, dout.deps_met + r0, r1 - r0, c->stream_d);
-      s.down(out->wait_ns + r0, dout.wait_ns + r0, r1 - r0, c->stream_d);
-      s.down(out->distro_info + d0, dout.distro_info + d0, (size_t)(d1 - d0), c->stream_d);
-      s.down(out->group_info + d0, dout.group_info + d0, (size_t)(d1 - d0), c->stream_d);
-      s.down(out->group_info + D + tgo[d0], dout.group_info + D + tgo[d0], (size_t)(tgo[d1] - tgo[d0]), c->stream_d);
-      if (out->unit_of_task) {
-        s.down(out->unit_of_task + r0, dout.unit_of_task + r0, r1 - r0, c->stream_d);
-        const size_t u0 = (size_t)to[d0] + tgo[d0] + vo[d0], u1 = (size_t)to[d1] + tgo[d1] + vo[d1];  // the range's unit slots, per field
-        for (size_t f = 0; f < EVG_BREAKDOWN_FIELDS; f++)
-          s.down(out->unit_breakdown + f * Stot + u0, dout.unit_breakdown + f * Stot + u0, u1 - u0, c->stream_d);
-      }
-    }
-    if (s.rc) return s.rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream_d));
-    return EVG_OK;
   }
   if (s.flush_in()) return s.rc;
   rc = launch_plan(c, &di, &dout, c->stream);

@@ -1,0 +1,589 @@
+// test_shim_twin.cpp -- the C++ twin of the cgo shim (shim/gpu_planner.go, shim/gpu_allocator.go).
+//
+// The Go files cannot be compiled here (no Go toolchain). This driver is their statement-for-statement transliteration --
+// the same helpers under the same names (gpuCtx.reserve / carve, intern, taskFlags, depRequired, statusClass,
+// breakdownOfUnit, depsMetTime, queueInfoFromRows, planBatch, providerClass, allocateBatch) making the SAME C-ABI calls in
+// the SAME order:
+//
+//     evg_check_abi -> evg_create -> evg_host_alloc (the arena) -> [pack: first-appearance interning] -> evg_plan_distros
+//     -> [stamp loop] ... evg_host_alloc / re-use -> [pack hosts] -> evg_allocate_hosts -> [CountFree / CountRequired in place]
+//
+// and it is run on the reference's known-answer cases (tests/cpp/golden_cases.inc, generated from tests/golden_cases.py,
+// transcribed from /root/reference/scheduler/*_test.go):
+//
+//   test_shim_twin hip    <libevg_sched.so>     MI355X: the product library, every call of the list above (pytest -m gpu)
+//   test_shim_twin oracle <libevg_oracle.so>    CPU: the same packing / stamping code with the oracle's two batched calls behind
+//                                               it (the context, the ABI check and the page-locked arena do not exist there)
+//
+// What differs from the Go files, by necessity: Go maps -> std::unordered_map; task.Find / FetchExpectedDuration (DB) -> the
+// lookup tables the test cases carry; errors -> strings.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+
+#include "evg_host.hpp"  // the reference's struct shapes (Task, Distro, Host, ...) and constants; its packing code is NOT used
+
+using namespace evergreen;
+
+static int g_checks = 0, g_fail = 0;
+#define EXPECT(cond, ...)                                        \
+  do {                                                           \
+    g_checks++;                                                  \
+    if (!(cond)) {                                               \
+      g_fail++;                                                  \
+      std::fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__);  \
+      std::fprintf(stderr, __VA_ARGS__);                         \
+      std::fprintf(stderr, "\n");                                \
+    }                                                            \
+  } while (0)
+
+// ---- the library, as cgo sees it (C.evg_*) --------------------------------------------------------------------------
+struct Lib {
+  bool hip = false;
+  evg_ctx* (*create)(int) = nullptr;
+  void (*destroy)(evg_ctx*) = nullptr;
+  const char* (*last_error)(const evg_ctx*) = nullptr;
+  int (*check_abi)(int32_t, int32_t, size_t, size_t, size_t, size_t) = nullptr;
+  void* (*host_alloc)(evg_ctx*, size_t) = nullptr;
+  void (*host_free)(evg_ctx*, void*) = nullptr;
+  int (*plan_distros)(evg_ctx*, const evg_plan_input*, const evg_plan_output*) = nullptr;
+  int (*allocate_hosts)(evg_ctx*, const evg_alloc_input*, const evg_alloc_output*) = nullptr;
+  // oracle mode: the two batched calls without a context
+  int (*o_plan)(const evg_plan_input*, const evg_plan_output*) = nullptr;
+  int (*o_alloc)(const evg_alloc_input*, const evg_alloc_output*) = nullptr;
+  int calls_host_alloc = 0, calls_plan = 0, calls_alloc = 0;
+};
+static Lib L;
+
+template <class F>
+static F sym(void* h, const char* name) {
+  F f = reinterpret_cast<F>(dlsym(h, name));
+  if (!f) throw std::runtime_error(std::string("missing entry point ") + name);
+  return f;
+}
+
+// ---- gpuCtx / gpuCtxPool (gpu_planner.go) -----------------------------------------------------------------------------
+struct gpuCtx {
+  evg_ctx* c = nullptr;
+  unsigned char* arena = nullptr;
+  size_t size = 0, used = 0;
+  void reserve(size_t bytes) {
+    used = 0;
+    if (bytes <= size) return;
+    if (arena) {
+      if (L.hip) L.host_free(c, arena); else std::free(arena);
+      arena = nullptr; size = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    void* p = L.hip ? L.host_alloc(c, want) : std::malloc(want);
+    L.calls_host_alloc++;
+    if (!p) throw std::runtime_error("evg_host_alloc failed");
+    arena = (unsigned char*)p; size = want;
+  }
+  void* carve(size_t count, size_t elem) {
+    used = (used + 63) & ~(size_t)63;
+    void* p = arena + used;
+    used += count * elem + elem;  // one spare element: a zero-length column still has a valid address
+    if (used > size) throw std::runtime_error("arena overflow: reserve() was too small");
+    return p;
+  }
+  template <class T>
+  T* carveSlice(size_t n) { return (T*)carve(n, sizeof(T)); }
+};
+static gpuCtx g_ctx;  // the pool hands out one context; one goroutine here
+static bool g_abi_checked = false;
+
+static gpuCtx* pool_get() {
+  if (L.hip && !g_abi_checked) {  // p.once.Do(...)
+    if (L.check_abi(EVG_ABI_MAJOR, EVG_ABI_MINOR, sizeof(evg_plan_input), sizeof(evg_plan_output), sizeof(evg_alloc_input), sizeof(evg_group_info)) != EVG_OK)
+      throw std::runtime_error("libevg_sched ABI does not match this binding");
+    g_abi_checked = true;
+  }
+  if (L.hip && !g_ctx.c) {
+    g_ctx.c = L.create(0);
+    if (!g_ctx.c) throw std::runtime_error(std::string("evg_create: ") + L.last_error(nullptr));
+  }
+  return &g_ctx;
+}
+
+// ---- small conversions ----------------------------------------------------------------------------------------------
+// unixNS: the C++ structs already hold int64 ns with Go's zero Time as kGoZeroTime (== EVG_TIME_GO_ZERO)
+static int32_t intern(std::unordered_map<std::string, int32_t>& m, const std::string& s, int* next) {
+  auto it = m.find(s);
+  if (it != m.end()) return it->second;
+  const int32_t k = (int32_t)*next;
+  m[s] = k;
+  (*next)++;
+  return k;
+}
+static uint32_t statusClass(const std::string& status) { return status == TaskSucceeded ? 1u : status == TaskFailed ? 2u : 0u; }
+static uint16_t taskFlags(const Task& t, const Distro& d) {
+  uint32_t f = 0;
+  if (t.Requester == GithubMergeRequester) f = EVG_TF_REQ_MERGE;
+  else if (t.Requester == PatchVersionRequester || t.Requester == GithubPRRequester) f = EVG_TF_REQ_PATCH;  // evergreen.IsPatchRequester
+  if (t.GenerateTask) f |= EVG_TF_GENERATE;
+  if (t.ActivatedBy == StepbackTaskActivator) f |= EVG_TF_STEPBACK;
+  if (t.OverrideDependencies) f |= EVG_TF_OVERRIDE_DEPS;
+  if (t.DistroId != d.Id) f |= EVG_TF_OTHER_DISTRO;
+  if (t.CachedProjectStorageMethod == ProjectStorageMethodS3) f |= EVG_TF_S3_STORAGE;
+  if (t.Blocked()) f |= EVG_TF_BLOCKED;
+  f |= statusClass(t.Status) << EVG_TF_STATUS_SHIFT;
+  return (uint16_t)f;
+}
+static uint8_t depRequired(const Task& t, const std::string& id) {
+  for (const auto& d : t.DependsOn) {
+    if (d.TaskId != id) continue;
+    if (d.Status == TaskSucceeded || d.Status.empty()) return 0;
+    if (d.Status == TaskFailed) return 1;
+    if (d.Status == AllStatuses) return 2;
+  }
+  return 3;
+}
+static SortingValueBreakdown breakdownOfUnit(const int64_t* ub, int u, int nSlots) {
+  auto f = [&](int k) { return ub[(size_t)k * nSlots + u]; };
+  SortingValueBreakdown b;
+  b.TaskGroupLength = f(EVG_BD_TASK_GROUP_LENGTH); b.TotalValue = f(EVG_BD_TOTAL_VALUE);
+  b.PriorityBreakdown.InitialPriorityImpact = f(EVG_BD_PRI_INITIAL); b.PriorityBreakdown.TaskGroupImpact = f(EVG_BD_PRI_TASK_GROUP);
+  b.PriorityBreakdown.GeneratorTaskImpact = f(EVG_BD_PRI_GENERATOR); b.PriorityBreakdown.CommitQueueImpact = f(EVG_BD_PRI_COMMIT_QUEUE);
+  b.RankValueBreakdown.CommitQueueImpact = f(EVG_BD_RANK_COMMIT_QUEUE); b.RankValueBreakdown.NumDependentsImpact = f(EVG_BD_RANK_NUM_DEPENDENTS);
+  b.RankValueBreakdown.EstimatedRuntimeImpact = f(EVG_BD_RANK_EST_RUNTIME); b.RankValueBreakdown.MainlineWaitTimeImpact = f(EVG_BD_RANK_MAINLINE_WAIT);
+  b.RankValueBreakdown.StepbackImpact = f(EVG_BD_RANK_STEPBACK); b.RankValueBreakdown.PatchImpact = f(EVG_BD_RANK_PATCH);
+  b.RankValueBreakdown.PatchWaitTimeImpact = f(EVG_BD_RANK_PATCH_WAIT);
+  return b;
+}
+static Time depsMetTime(const Task& t, Time now) {  // Task.setDependenciesMetTime task.go:690-701
+  Time met = 0;
+  for (const auto& dep : t.DependsOn)
+    if (!IsZeroTime(dep.FinishedAt) && dep.FinishedAt > met) met = dep.FinishedAt;
+  return IsZeroTime(met) ? now : met;
+}
+static DistroQueueInfo queueInfoFromRows(const evg_distro_info* di, const evg_group_info* gi, int d, int D, const int32_t* tgOff,
+                                         const std::vector<std::string>& tgNames) {
+  const evg_distro_info& i = di[d];
+  DistroQueueInfo info;
+  info.Length = i.length; info.LengthWithDependenciesMet = i.length_with_dependencies_met;
+  info.CountDepFilledMergeQueueTasks = i.count_dep_filled_merge_queue_tasks; info.ExpectedDuration = i.expected_duration_ns;
+  info.MaxDurationThreshold = i.max_duration_threshold_ns; info.CountDurationOverThreshold = i.count_duration_over_threshold;
+  info.DurationOverThreshold = i.duration_over_threshold_ns; info.CountWaitOverThreshold = i.count_wait_over_threshold;
+  info.NumQueuedLargeParserProjectTasks = i.num_queued_large_parser_project_tasks; info.SecondaryQueue = i.secondary_queue != 0;
+  auto add = [&](const evg_group_info& g, const std::string& name) {
+    if (!g.present) return;
+    TaskGroupInfo t;
+    t.Name = name; t.Count = g.count; t.CountFree = g.count_free; t.CountRequired = g.count_required; t.MaxHosts = g.max_hosts;
+    t.ExpectedDuration = g.expected_duration_ns; t.CountDurationOverThreshold = g.count_duration_over_threshold;
+    t.CountWaitOverThreshold = g.count_wait_over_threshold; t.CountDepFilledMergeQueueTasks = g.count_dep_filled_merge_queue_tasks;
+    t.DurationOverThreshold = g.duration_over_threshold_ns;
+    info.TaskGroupInfos.push_back(t);
+  };
+  add(gi[d], "");
+  for (int k = tgOff[d]; k < tgOff[d + 1]; k++) add(gi[D + k], tgNames[(size_t)k]);
+  return info;
+}
+
+// ---- planBatch (gpu_planner.go) -----------------------------------------------------------------------------------------
+struct PlanOut {
+  std::vector<std::vector<Task>> plans;
+  std::vector<DistroQueueInfo> infos;
+};
+// depState: fetchedDepStates' result (what task.FindWithFields would return for the dependencies outside the queues);
+// includesDeps: the test cases set opts.IncludesDependencies directly where the Go test does.
+static PlanOut planBatch(const std::vector<const Distro*>& ds, const std::vector<const std::vector<Task>*>& queues, Time now,
+                         const std::unordered_map<std::string, uint8_t>& depState = {}, const std::vector<bool>* includesDeps = nullptr) {
+  gpuCtx* g = pool_get();
+  const int D = (int)ds.size();
+  int n = 0, e = 0;
+  for (auto* q : queues) {
+    n += (int)q->size();
+    for (const Task& t : *q) e += (int)t.DependsOn.size();
+  }
+  const size_t maxSlots = 3 * (size_t)n + 1;
+  const size_t bytes = (size_t)n * (5 * 8 + 5 * 4 + 2) + (size_t)(n + 1) * 4 + (size_t)e * (4 + 1 + 8) + (size_t)D * sizeof(evg_distro_params) +
+                       3 * (size_t)(D + 1) * 4 + (size_t)n * (4 + 1 + 8 + 4) + maxSlots * EVG_BREAKDOWN_FIELDS * 8 + (size_t)D * sizeof(evg_distro_info) +
+                       (size_t)(D + n) * sizeof(evg_group_info) + 64 * 40 + 32 * 16;
+  g->reserve(bytes);
+  int64_t *priority = g->carveSlice<int64_t>(n), *expDur = g->carveSlice<int64_t>(n), *queueTS = g->carveSlice<int64_t>(n);
+  int64_t *schedTS = g->carveSlice<int64_t>(n), *metTS = g->carveSlice<int64_t>(n);
+  int32_t *numDep = g->carveSlice<int32_t>(n), *tgOrder = g->carveSlice<int32_t>(n), *tgMaxHosts = g->carveSlice<int32_t>(n);
+  int32_t *tgKey = g->carveSlice<int32_t>(n), *verKey = g->carveSlice<int32_t>(n);
+  uint16_t* flags = g->carveSlice<uint16_t>(n);
+  int32_t* depOff = g->carveSlice<int32_t>(n + 1);
+  int32_t* depIdx = g->carveSlice<int32_t>(e);
+  uint8_t* depInfo = g->carveSlice<uint8_t>(e);
+  int64_t* depFin = g->carveSlice<int64_t>(e);
+  evg_distro_params* params = g->carveSlice<evg_distro_params>(D);
+  int32_t *taskOff = g->carveSlice<int32_t>(D + 1), *tgOff = g->carveSlice<int32_t>(D + 1), *verOff = g->carveSlice<int32_t>(D + 1);
+
+  std::vector<std::string> tgNames;
+  int nTG = 0, nVer = 0, row = 0, edge = 0;
+  depOff[0] = 0;
+  for (int di = 0; di < D; di++) {
+    const Distro& d = *ds[di];
+    taskOff[di] = row; tgOff[di] = nTG; verOff[di] = nVer;
+    const auto& ps = d.PlannerSettings;
+    evg_distro_params p{};
+    p.patch_factor = ps.PatchFactor; p.patch_time_in_queue_factor = ps.PatchTimeInQueueFactor; p.commit_queue_factor = ps.CommitQueueFactor;
+    p.mainline_time_in_queue_factor = ps.MainlineTimeInQueueFactor; p.expected_runtime_factor = ps.ExpectedRuntimeFactor;
+    p.generate_task_factor = ps.GenerateTaskFactor; p.stepback_task_factor = ps.StepbackTaskFactor; p.num_dependents_factor = ps.NumDependentsFactor;
+    p.target_time_ns = ps.TargetTime; p.merge_queue_target_time_ns = ps.MergeQueueTargetTime;
+    p.group_versions = ps.ShouldGroupVersions() ? 1 : 0;
+    p.includes_dependencies = includesDeps ? ((*includesDeps)[(size_t)di] ? 1 : 0) : (d.DispatcherSettings.Version == DispatcherVersionRevisedWithDependencies ? 1 : 0);
+    params[di] = p;
+    const std::vector<Task>& q = *queues[di];
+    std::unordered_map<std::string, int32_t> rowOf, tgKeys, verKeys;
+    for (size_t i = 0; i < q.size(); i++) rowOf[q[i].Id] = row + (int32_t)i;
+    for (size_t i = 0; i < q.size(); i++) {
+      const Task& t = q[i];
+      const int r = row + (int)i;
+      priority[r] = t.Priority;
+      expDur[r] = FetchExpectedDuration(t, now).first;
+      Time qt = t.ActivatedTime;  // planner.go:318-322
+      if (qt == kGoZeroTime) qt = t.IngestTime;
+      queueTS[r] = qt; schedTS[r] = t.ScheduledTime; metTS[r] = t.DependenciesMetTime;
+      numDep[r] = t.NumDependents; tgOrder[r] = t.TaskGroupOrder; tgMaxHosts[r] = t.TaskGroupMaxHosts;
+      tgKey[r] = -1;
+      if (!t.TaskGroup.empty()) {
+        const int before = nTG;
+        tgKey[r] = intern(tgKeys, t.GetTaskGroupString(), &nTG);
+        if (nTG != before) tgNames.push_back(t.GetTaskGroupString());
+      }
+      verKey[r] = intern(verKeys, t.Version, &nVer);
+      flags[r] = taskFlags(t, d);
+      for (const auto& dep : t.DependsOn) {
+        uint8_t info = depRequired(t, dep.TaskId);
+        int32_t idx = -1;
+        auto it = rowOf.find(dep.TaskId);
+        if (it != rowOf.end()) idx = it->second;
+        else {
+          auto st = depState.find(dep.TaskId);
+          info |= st == depState.end() ? (uint8_t)EVG_DEP_MISSING : st->second;
+        }
+        depIdx[edge] = idx; depInfo[edge] = info;
+        depFin[edge] = dep.FinishedAt == kGoZeroTime ? 0 : dep.FinishedAt;
+        edge++;
+      }
+      depOff[r + 1] = edge;
+    }
+    row += (int)q.size();
+  }
+  taskOff[D] = row; tgOff[D] = nTG; verOff[D] = nVer;
+
+  const int nSlots = n + nTG + nVer;
+  int32_t *order = g->carveSlice<int32_t>(n), *unitOf = g->carveSlice<int32_t>(n);
+  uint8_t* met = g->carveSlice<uint8_t>(n);
+  int64_t* wait = g->carveSlice<int64_t>(n);
+  int64_t* unitRows = g->carveSlice<int64_t>((size_t)nSlots * EVG_BREAKDOWN_FIELDS);
+  evg_distro_info* distroInfo = g->carveSlice<evg_distro_info>(D);
+  evg_group_info* groupInfo = g->carveSlice<evg_group_info>(D + nTG);
+
+  evg_plan_input in{};
+  in.n_distros = D; in.n_task_groups = nTG; in.n_versions = nVer;
+  in.distros = params; in.task_off = taskOff; in.tg_off = tgOff; in.ver_off = verOff; in.now_ns = now;
+  in.tasks.n_tasks = n; in.tasks.n_edges = e;
+  in.tasks.priority = priority; in.tasks.expected_duration_ns = expDur; in.tasks.queue_ts_ns = queueTS; in.tasks.scheduled_ts_ns = schedTS;
+  in.tasks.deps_met_ts_ns = metTS; in.tasks.num_dependents = numDep; in.tasks.task_group_order = tgOrder; in.tasks.task_group_max_hosts = tgMaxHosts;
+  in.tasks.tg_key = tgKey; in.tasks.version_key = verKey; in.tasks.flags = flags; in.tasks.dep_off = depOff; in.tasks.dep_idx = depIdx;
+  in.tasks.dep_info = depInfo; in.tasks.dep_finished_ts_ns = depFin;
+  evg_plan_output out{};
+  out.order = order; out.deps_met = met; out.wait_ns = wait; out.distro_info = distroInfo; out.group_info = groupInfo;
+  out.unit_of_task = unitOf; out.unit_breakdown = unitRows;  // breakdown (rows by task) and n_units stay NULL
+
+  const int rc = L.hip ? L.plan_distros(g->c, &in, &out) : L.o_plan(&in, &out);
+  L.calls_plan++;
+  if (rc != EVG_OK) throw std::runtime_error(std::string("evg_plan_distros: ") + (L.hip ? L.last_error(g->c) : "oracle") + " (" + std::to_string(rc) + ")");
+
+  PlanOut res;
+  res.plans.resize((size_t)D); res.infos.resize((size_t)D);
+  for (int di = 0; di < D; di++) {
+    const int lo = taskOff[di], hi = taskOff[di + 1];
+    for (int p = lo; p < hi; p++) {
+      const int r = order[p];
+      Task t = (*queues[di])[(size_t)(r - lo)];  // the same task value, re-ordered
+      t.SortingValueBreakdown = breakdownOfUnit(unitRows, unitOf[r], nSlots);
+      t.ExpectedDuration = expDur[r];
+      t.WaitSinceDependenciesMet = wait[r];
+      if (met[r] != 0 && IsZeroTime(t.DependenciesMetTime) && !t.DependsOn.empty() && !t.OverrideDependencies) t.DependenciesMetTime = depsMetTime(t, now);
+      res.plans[(size_t)di].push_back(std::move(t));
+    }
+    res.infos[(size_t)di] = queueInfoFromRows(distroInfo, groupInfo, di, D, tgOff, tgNames);
+  }
+  return res;
+}
+
+// ---- allocateBatch (gpu_allocator.go) --------------------------------------------------------------------------------------
+static int32_t providerClass(const Distro& d) { return d.Provider == ProviderNameDocker ? 2 : d.IsEphemeral() ? 1 : 0; }
+struct allocResult {
+  int newHosts = 0, freeHosts = 0;
+  std::string err;
+};
+static std::vector<allocResult> allocateBatch(std::vector<HostAllocatorData*>& datas, Time now, const std::map<std::string, Task>& running) {
+  gpuCtx* g = pool_get();
+  const int D = (int)datas.size();
+  int nHosts = 0, nGroups = 0;
+  for (auto* d : datas) { nHosts += (int)d->ExistingHosts.size(); nGroups += (int)d->DistroQueueInfo.TaskGroupInfos.size(); }
+  const size_t bytes = (size_t)D * (sizeof(evg_alloc_params) + sizeof(evg_distro_info) + 3 * 4) + 2 * (size_t)(D + 1) * 4 + (size_t)nHosts * (1 + 4 + 3 * 8) +
+                       (size_t)(D + nGroups) * sizeof(evg_group_info) + 64 * 20 + 48 * 16;
+  g->reserve(bytes);
+  evg_alloc_params* params = g->carveSlice<evg_alloc_params>(D);
+  int32_t *hostOff = g->carveSlice<int32_t>(D + 1), *tgOff = g->carveSlice<int32_t>(D + 1);
+  uint8_t* hFlags = g->carveSlice<uint8_t>(nHosts);
+  int32_t* hKey = g->carveSlice<int32_t>(nHosts);
+  int64_t *hStart = g->carveSlice<int64_t>(nHosts), *hExp = g->carveSlice<int64_t>(nHosts), *hDev = g->carveSlice<int64_t>(nHosts);
+  evg_distro_info* distroInfo = g->carveSlice<evg_distro_info>(D);
+  evg_group_info* groupInfo = g->carveSlice<evg_group_info>(D + nGroups);
+  std::memset(groupInfo, 0, sizeof(evg_group_info) * (size_t)(D + nGroups));
+  int32_t *newHosts = g->carveSlice<int32_t>(D), *freeHosts = g->carveSlice<int32_t>(D), *status = g->carveSlice<int32_t>(D);
+
+  std::vector<std::vector<int>> groupRow((size_t)D);
+  int h = 0, key = 0;
+  for (int di = 0; di < D; di++) {
+    const HostAllocatorData& data = *datas[(size_t)di];
+    const Distro& d = data.Distro;
+    const auto& s = d.HostAllocatorSettings;
+    evg_alloc_params ap{};
+    ap.future_host_fraction = s.FutureHostFraction; ap.minimum_hosts = s.MinimumHosts; ap.maximum_hosts = s.MaximumHosts;
+    ap.provider = providerClass(d); ap.disabled = d.Disabled ? 1 : 0;
+    ap.round_up = s.RoundingRule == HostAllocatorRoundUp ? 1 : 0;
+    ap.feedback_waits_over_thresh = s.FeedbackRule == HostAllocatorWaitsOverThreshFeedback ? 1 : 0;
+    params[di] = ap;
+    hostOff[di] = h; tgOff[di] = key;
+    const DistroQueueInfo& q = data.DistroQueueInfo;
+    evg_distro_info x{};
+    x.expected_duration_ns = q.ExpectedDuration; x.max_duration_threshold_ns = q.MaxDurationThreshold; x.duration_over_threshold_ns = q.DurationOverThreshold;
+    x.length = q.Length; x.length_with_dependencies_met = q.LengthWithDependenciesMet;
+    x.count_dep_filled_merge_queue_tasks = q.CountDepFilledMergeQueueTasks; x.count_duration_over_threshold = q.CountDurationOverThreshold;
+    x.count_wait_over_threshold = q.CountWaitOverThreshold; x.num_queued_large_parser_project_tasks = q.NumQueuedLargeParserProjectTasks;
+    x.secondary_queue = q.SecondaryQueue ? 1 : 0; x.n_task_group_infos = (int32_t)q.TaskGroupInfos.size();
+    distroInfo[di] = x;
+    std::unordered_map<std::string, int32_t> keyOf;
+    groupRow[(size_t)di].resize(q.TaskGroupInfos.size());
+    for (size_t gi = 0; gi < q.TaskGroupInfos.size(); gi++) {
+      const TaskGroupInfo& info = q.TaskGroupInfos[gi];
+      int rowi = di;
+      if (!info.Name.empty()) {
+        keyOf[info.Name] = key;
+        rowi = D + key;
+        key++;
+      }
+      groupRow[(size_t)di][gi] = rowi;
+      evg_group_info r{};
+      r.expected_duration_ns = info.ExpectedDuration; r.duration_over_threshold_ns = info.DurationOverThreshold; r.count = info.Count;
+      r.max_hosts = info.MaxHosts; r.count_duration_over_threshold = info.CountDurationOverThreshold;
+      r.count_wait_over_threshold = info.CountWaitOverThreshold; r.count_dep_filled_merge_queue_tasks = info.CountDepFilledMergeQueueTasks;
+      r.present = 1;
+      groupInfo[rowi] = r;
+    }
+    for (const Host& eh : data.ExistingHosts) {
+      uint8_t f = 0;
+      if (eh.IsFree()) f |= EVG_HF_FREE;
+      hKey[h] = -1;
+      hStart[h] = hExp[h] = hDev[h] = 0;
+      if (!eh.RunningTask.empty()) {
+        f |= EVG_HF_RUNNING;
+        if (!eh.RunningTaskGroup.empty()) {
+          auto it = keyOf.find(eh.GetTaskGroupString());
+          hKey[h] = it != keyOf.end() ? it->second : -2;
+        }
+        auto rt = running.find(eh.RunningTask);
+        if (rt != running.end()) {
+          f |= EVG_HF_RUNNING_FOUND;
+          const auto st = FetchExpectedDuration(rt->second, now);
+          hStart[h] = rt->second.StartTime; hExp[h] = st.first; hDev[h] = st.second;
+        }
+      }
+      hFlags[h] = f;
+      h++;
+    }
+  }
+  hostOff[D] = h; tgOff[D] = key;
+
+  evg_alloc_input in{};
+  in.n_distros = D; in.n_task_groups = key; in.params = params; in.host_off = hostOff; in.tg_off = tgOff;
+  in.distro_info = distroInfo; in.group_info = groupInfo; in.now_ns = now;
+  in.hosts.n_hosts = nHosts; in.hosts.flags = hFlags; in.hosts.tg_key = hKey; in.hosts.start_ts_ns = hStart;
+  in.hosts.expected_duration_ns = hExp; in.hosts.duration_stddev_ns = hDev;
+  evg_alloc_output out{newHosts, freeHosts, status};
+  const int rc = L.hip ? L.allocate_hosts(g->c, &in, &out) : L.o_alloc(&in, &out);
+  L.calls_alloc++;
+  if (rc != EVG_OK) throw std::runtime_error(std::string("evg_allocate_hosts: ") + (L.hip ? L.last_error(g->c) : "oracle"));
+
+  std::vector<allocResult> res((size_t)D);
+  for (int di = 0; di < D; di++) {
+    HostAllocatorData& data = *datas[(size_t)di];
+    auto& infos = data.DistroQueueInfo.TaskGroupInfos;
+    for (size_t gi = 0; gi < infos.size(); gi++)
+      if (!infos[gi].Name.empty()) {  // in place, like utilization_based_host_allocator.go:106-109
+        const evg_group_info& r = groupInfo[groupRow[(size_t)di][gi]];
+        infos[gi].CountFree = r.count_free; infos[gi].CountRequired = r.count_required;
+      }
+    res[(size_t)di].newHosts = newHosts[di]; res[(size_t)di].freeHosts = freeHosts[di];
+    if (status[di] == EVG_ALLOC_E_FUTURE_FRACTION)
+      res[(size_t)di].err = "calculating hosts for distro '" + data.Distro.Id + "': future host factor cannot be greater than 1";
+    else if (status[di] == EVG_ALLOC_E_POOL_SIZE)
+      res[(size_t)di].err = "calculating hosts for distro '" + data.Distro.Id + "': unable to plan hosts for distro " + data.Distro.Id +
+                            " due to pool size of " + std::to_string(data.Distro.HostAllocatorSettings.MaximumHosts);
+  }
+  return res;
+}
+
+// ---- the reference's known-answer cases through the twin -----------------------------------------------------------------
+static bool verify_rank_breakdown(const SortingValueBreakdown& b) {  // planner_test.go:561-574
+  const auto& r = b.RankValueBreakdown;
+  const auto& p = b.PriorityBreakdown;
+  const int64_t rank = r.StepbackImpact + r.PatchImpact + r.PatchWaitTimeImpact + r.MainlineWaitTimeImpact + r.EstimatedRuntimeImpact +
+                       r.NumDependentsImpact + r.CommitQueueImpact;
+  const int64_t pri = p.InitialPriorityImpact + p.CommitQueueImpact + p.GeneratorTaskImpact + p.TaskGroupImpact;
+  return pri + b.TaskGroupLength + rank * pri == b.TotalValue;
+}
+
+static void check_unit_value(const Backend&, const char* name, int line, const Distro& d, const std::vector<Task>& tasks, int64_t want);
+static void check_task_list(const Backend&, const char* name, int line, const std::vector<Task>& tasks, std::vector<std::string> want);
+static void check_prepare(const Backend&, const char* name, int line, const Distro& d, const std::vector<Task>& tasks, int n_units);
+static void check_queue_info(const Backend&, const char* name, int line, const Distro& d, const std::vector<Task>& tasks,
+                             std::vector<std::pair<std::string, int64_t>> want);
+static void check_allocator(const Backend&, const char* name, int line, HostAllocatorData& data, const std::map<std::string, Task>& running,
+                            int want_hosts, int want_free);
+static void check_cap(const char*, const std::vector<Task>&, int, int) {}
+static void check_dispatcher(const Backend&, const char*, const std::vector<TaskQueueItem>&, std::vector<std::string>, int, std::map<std::string, int>) {}
+static void check_group_order(const Backend&, const char*, const std::vector<TaskQueueItem>&, std::vector<std::string>) {}
+static void check_report(const Backend&, const char*, const DistroQueueInfo&, int, int, int, int, bool, int64_t, int64_t, float, float, int, bool, int, int) {}
+
+#include "golden_cases.inc"
+
+static void check_unit_value(const Backend&, const char* name, int line, const Distro& d, const std::vector<Task>& tasks, int64_t want) {
+  const PlanOut po = planBatch({&d}, {&tasks}, NOW);
+  EXPECT(po.plans[0].size() == tasks.size(), "%s: %zu tasks planned", name, po.plans[0].size());
+  for (const Task& t : po.plans[0]) {
+    EXPECT(t.SortingValueBreakdown.TotalValue == want, "%s (planner_test.go:%d): TotalValue %lld, the reference asserts %lld", name, line,
+           (long long)t.SortingValueBreakdown.TotalValue, (long long)want);
+    EXPECT(verify_rank_breakdown(t.SortingValueBreakdown), "%s: breakdown identity", name);
+    EXPECT(t.SortingValueBreakdown.TaskGroupLength == (int64_t)tasks.size(), "%s: unit length", name);
+  }
+}
+static void check_task_list(const Backend&, const char* name, int line, const std::vector<Task>& tasks, std::vector<std::string> want) {
+  Distro d;
+  d.PlannerSettings.GroupVersions = true;
+  const PlanOut po = planBatch({&d}, {&tasks}, NOW);
+  std::vector<std::string> ids;
+  for (const Task& t : po.plans[0]) ids.push_back(t.Id);
+  EXPECT(ids == want, "%s (planner_test.go:%d): order differs", name, line);
+}
+static void check_prepare(const Backend&, const char* name, int, const Distro& d, const std::vector<Task>& tasks, int) {
+  // TaskPlan.Len() is not part of what the shim asks for (n_units stays NULL); the no-drop / no-duplicate property is
+  const PlanOut po = planBatch({&d}, {&tasks}, NOW);
+  std::multiset<std::string> a, b;
+  for (const Task& t : po.plans[0]) a.insert(t.Id);
+  for (const Task& t : tasks) b.insert(t.Id);
+  EXPECT(a == b, "%s: a task was dropped or duplicated", name);
+}
+static void check_queue_info(const Backend&, const char* name, int line, const Distro& d, const std::vector<Task>& tasks,
+                             std::vector<std::pair<std::string, int64_t>> want) {
+  std::vector<bool> inc{true};
+  const PlanOut po = planBatch({&d}, {&tasks}, NOW, {}, &inc);
+  const DistroQueueInfo& info = po.infos[0];
+  for (const auto& kv : want) {
+    int64_t got = -1;
+    if (kv.first == "MaxDurationThreshold") got = info.MaxDurationThreshold;
+    else if (kv.first == "CountDepFilledMergeQueueTasks") got = info.CountDepFilledMergeQueueTasks;
+    else if (kv.first == "CountDurationOverThreshold") got = info.CountDurationOverThreshold;
+    else if (kv.first == "DurationOverThreshold") got = info.DurationOverThreshold;
+    else if (kv.first == "LengthWithDependenciesMet") got = info.LengthWithDependenciesMet;
+    EXPECT(got == kv.second, "%s (scheduler_test.go:%d): %s = %lld, the reference asserts %lld", name, line, kv.first.c_str(), (long long)got,
+           (long long)kv.second);
+  }
+}
+static void check_allocator(const Backend&, const char* name, int line, HostAllocatorData& data, const std::map<std::string, Task>& running,
+                            int want_hosts, int want_free) {
+  std::vector<HostAllocatorData*> one{&data};
+  const allocResult r = allocateBatch(one, NOW, running)[0];
+  EXPECT(r.err.empty() && r.newHosts == want_hosts && r.freeHosts == want_free,
+         "%s (utilization_based_host_allocator_test.go:%d): (%d, %d) %s, the reference asserts (%d, %d)", name, line, r.newHosts, r.freeHosts, r.err.c_str(),
+         want_hosts, want_free);
+}
+
+static void run_twin_specifics() {
+  // a batch of SEVERAL distros in one call (the batched cron's shape): first-appearance interning is per distro, rows re-based
+  Distro d1, d2;
+  d1.Id = "d1"; d2.Id = "d2"; d2.PlannerSettings.GroupVersions = true;
+  std::vector<Task> q1(3), q2(3);
+  const char* ids1[3] = {"a", "b", "c"};
+  const char* ids2[3] = {"x", "y", "z"};
+  for (int i = 0; i < 3; i++) { q1[(size_t)i].Id = ids1[i]; q1[(size_t)i].DistroId = "d1"; q2[(size_t)i].Id = ids2[i]; q2[(size_t)i].DistroId = "d2"; q2[(size_t)i].Version = "v"; }
+  q1[1].Priority = 10;
+  q1[2].TaskGroup = "tg"; q1[2].TaskGroupMaxHosts = 2; q1[2].BuildVariant = "bv"; q1[2].Project = "p"; q1[2].Version = "v1";
+  Dependency dep; dep.TaskId = "a"; q1[2].DependsOn.push_back(dep);
+  Dependency out_of_queue; out_of_queue.TaskId = "finished-elsewhere"; q2[0].DependsOn.push_back(out_of_queue);
+  const std::unordered_map<std::string, uint8_t> depState{{"finished-elsewhere", (uint8_t)(1u << EVG_DEP_STATE_SHIFT)}};  // success
+  const PlanOut po = planBatch({&d1, &d2}, {&q1, &q2}, NOW, depState);
+  EXPECT(po.plans[0].size() == 3 && po.plans[1].size() == 3, "two distros in one call");
+  EXPECT(po.plans[0][0].Id == "b", "the priority-10 task leads distro 1 (got %s)", po.plans[0][0].Id.c_str());
+  EXPECT(po.infos[0].Length == 3 && po.infos[1].Length == 3, "queue info lengths");
+  bool has_tg = false;
+  for (const auto& gi : po.infos[0].TaskGroupInfos) has_tg |= gi.Name == "tg_bv_p_v1" && gi.MaxHosts == 2 && gi.Count == 1;
+  EXPECT(has_tg, "the task group row carries its GetTaskGroupString() name");
+  for (const Task& t : po.plans[1]) EXPECT(t.SortingValueBreakdown.TaskGroupLength == 3, "grouped version: one unit of three");
+  for (const Task& t : po.plans[1])
+    if (t.Id == "x") EXPECT(!IsZeroTime(t.DependenciesMetTime), "x's only dependency succeeded outside the queue: DependenciesMetTime is set");
+  // errors: the reference's two allocator errors, with the tuple it returns next to them
+  HostAllocatorData data;
+  data.Distro.Id = "testDistro"; data.Distro.Provider = ProviderNameEc2Fleet;
+  data.Distro.HostAllocatorSettings.MaximumHosts = 50; data.Distro.HostAllocatorSettings.FutureHostFraction = 1.5;
+  data.ExistingHosts.push_back(Host{});
+  data.ExistingHosts[0].Id = "h1";
+  TaskGroupInfo gi; gi.Count = 1; gi.ExpectedDuration = Minute;
+  data.DistroQueueInfo.LengthWithDependenciesMet = 1; data.DistroQueueInfo.MaxDurationThreshold = 30 * Minute;
+  data.DistroQueueInfo.TaskGroupInfos.push_back(gi);
+  std::vector<HostAllocatorData*> one{&data};
+  const allocResult r = allocateBatch(one, NOW, {})[0];
+  EXPECT(r.err.find("future host factor cannot be greater than 1") != std::string::npos && r.newHosts == 0 && r.freeHosts == 1, "FutureHostFraction 1.5: %s (%d, %d)",
+         r.err.c_str(), r.newHosts, r.freeHosts);
+  // in-place CountFree / CountRequired of a named group
+  HostAllocatorData d3;
+  d3.Distro.Id = "d"; d3.Distro.Provider = ProviderNameEc2Fleet; d3.Distro.HostAllocatorSettings.MaximumHosts = 50; d3.Distro.HostAllocatorSettings.FutureHostFraction = 0.5;
+  TaskGroupInfo g0; g0.Name = "g_a_b_c"; g0.Count = 3; g0.MaxHosts = 2; g0.ExpectedDuration = 90 * Minute;
+  d3.DistroQueueInfo.LengthWithDependenciesMet = 3; d3.DistroQueueInfo.MaxDurationThreshold = 30 * Minute;
+  d3.DistroQueueInfo.TaskGroupInfos.push_back(g0);
+  std::vector<HostAllocatorData*> two{&d3};
+  const allocResult r3 = allocateBatch(two, NOW, {})[0];
+  EXPECT(r3.err.empty() && d3.DistroQueueInfo.TaskGroupInfos[0].CountRequired == 2 && r3.newHosts == 2, "named group: CountRequired %d written in place, %d new hosts",
+         d3.DistroQueueInfo.TaskGroupInfos[0].CountRequired, r3.newHosts);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: %s oracle|hip <library path>\n", argv[0]);
+    return 2;
+  }
+  try {
+    void* h = dlopen(argv[2], RTLD_NOW | RTLD_LOCAL);
+    if (!h) throw std::runtime_error(std::string("cannot load ") + argv[2] + ": " + dlerror());
+    L.hip = std::string(argv[1]) == "hip";
+    if (L.hip) {
+      L.create = sym<decltype(L.create)>(h, "evg_create"); L.destroy = sym<decltype(L.destroy)>(h, "evg_destroy");
+      L.last_error = sym<decltype(L.last_error)>(h, "evg_last_error"); L.check_abi = sym<decltype(L.check_abi)>(h, "evg_check_abi");
+      L.host_alloc = sym<decltype(L.host_alloc)>(h, "evg_host_alloc"); L.host_free = sym<decltype(L.host_free)>(h, "evg_host_free");
+      L.plan_distros = sym<decltype(L.plan_distros)>(h, "evg_plan_distros"); L.allocate_hosts = sym<decltype(L.allocate_hosts)>(h, "evg_allocate_hosts");
+    } else {
+      L.o_plan = sym<decltype(L.o_plan)>(h, "evg_oracle_plan_distros"); L.o_alloc = sym<decltype(L.o_alloc)>(h, "evg_oracle_allocate_hosts");
+    }
+    const Backend none;
+    run_unit_value_cases(none);
+    run_task_list_cases(none);
+    run_prepare_cases(none);
+    run_queue_info_cases(none);
+    run_allocator_cases(none);
+    run_twin_specifics();
+    if (L.hip && g_ctx.c) {
+      if (g_ctx.arena) L.host_free(g_ctx.c, g_ctx.arena);
+      L.destroy(g_ctx.c);
+    }
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 1;
+  }
+  std::printf("shim twin, %s backend: %d checks, %d failed; %d evg_plan_distros, %d evg_allocate_hosts, %d arena (re)allocations\n", argv[1], g_checks, g_fail,
+              L.calls_plan, L.calls_alloc, L.calls_host_alloc);
+  return g_fail ? 1 : 0;
+}

@@ -575,10 +575,10 @@ def test_resident_pool_updates_equal_a_full_upload(native_ctx, oracle, cfg):
     compare.assert_plan_equal(got, want, cur, "pool after a 2^40 priority")
 
 
-def test_large_host_pointer_batch_travels_in_overlapping_ranges(native_ctx, oracle):
-    """BASELINE config 3 through evg_plan_distros on host buffers: beyond the packed-staging size the call uploads, plans and
-    downloads four distro ranges on three streams (range k + 1 uploads while range k plans and range k - 1 downloads); the
-    result -- unit rows included -- is the resident tick's and the oracle's, and the next call re-uses everything."""
+def test_large_host_pointer_batch(native_ctx, oracle):
+    """BASELINE config 3 through evg_plan_distros on host buffers (beyond the packed-staging size: one copy per column): the
+    result -- unit rows included -- is the oracle's, from page-locked and from pageable memory, and the next call re-uses
+    every staging buffer."""
     b = gen.generate(gen.config(3))
     want = oracle.plan(b, breakdown=True, n_units=False)
     want.n_units = None
@@ -586,7 +586,7 @@ def test_large_host_pointer_batch_travels_in_overlapping_ranges(native_ctx, orac
     for rep in range(2):
         got = native_ctx.plan(pb, breakdown=False, n_units=False, units=True)
         got.breakdown = got.expand_breakdown()
-        compare.assert_plan_equal(got, want, b, "pipelined host path, call %d" % rep)
+        compare.assert_plan_equal(got, want, b, "large host batch, call %d" % rep)
     got = native_ctx.plan(b, breakdown=False, n_units=False)  # pageable memory, no unit rows
     want.breakdown = None
-    compare.assert_plan_equal(got, want, b, "pipelined host path, pageable")
+    compare.assert_plan_equal(got, want, b, "large host batch, pageable")

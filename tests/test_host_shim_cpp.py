@@ -55,3 +55,51 @@ def test_cpp_host_layer_and_oracle_under_sanitizers(tmp_path):
     out = subprocess.run([exe, "oracle", lib], capture_output=True, text=True, env=env)
     assert out.returncode == 0 and "0 failed" in out.stdout, out.stdout + out.stderr
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr
+
+
+# ---- the C++ twin of the cgo shim (shim/*.go cannot be compiled here): the same call sequence on the same cases -------------
+TWIN = os.path.join(CPP, "test_shim_twin")
+
+
+def _build_twin():
+    srcs = [os.path.join(CPP, "test_shim_twin.cpp"), os.path.join(CPP, "golden_cases.inc"), os.path.join(ROOT, "include", "evg_host.hpp"),
+            os.path.join(ROOT, "include", "evg_sched.h")]
+    if not os.path.exists(TWIN) or any(os.path.getmtime(s) > os.path.getmtime(TWIN) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), srcs[0], "-o", TWIN, "-ldl"])
+    return TWIN
+
+
+def test_shim_twin_with_oracle_backend():
+    """The transliterated packing / stamping / write-back code of shim/gpu_planner.go and shim/gpu_allocator.go on the reference's
+    known-answer cases, the oracle's two batched calls behind it (CPU)."""
+    oracle_lib.lib()
+    out = subprocess.run([_build_twin(), "oracle", oracle_lib.LIB], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 failed" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_shim_twin_with_hip_backend():
+    """... and the identical call sequence against the product library on the MI355X: evg_check_abi, evg_create, the evg_host_alloc
+    arena, evg_plan_distros, evg_allocate_hosts."""
+    from evergreen_amd import native
+    out = subprocess.run([_build_twin(), "hip", native.LIB_PATH], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 failed" in out.stdout, out.stdout + out.stderr
+
+
+def test_go_shim_files_are_complete():
+    """shim/*.go cannot be compiled here; at least every helper they call is defined in them, every C symbol they name is
+    declared in include/evg_sched.h, and the build tag keeps them out of an ordinary build of the reference."""
+    import re
+    shim = os.path.join(ROOT, "shim")
+    src = "".join(open(os.path.join(shim, f)).read() for f in sorted(os.listdir(shim)) if f.endswith(".go"))
+    header = open(os.path.join(ROOT, "include", "evg_sched.h")).read()
+    for f in sorted(os.listdir(shim)):
+        if f.endswith(".go"):
+            assert open(os.path.join(shim, f)).read().startswith("//go:build cgo && evg_mi355x"), f
+    for name in set(re.findall(r"\bC\.(evg_[a-z_]+)\b", src)) | set(re.findall(r"\bC\.(EVG_[A-Z0-9_]+)\b", src)):
+        assert re.search(r"\b%s\b" % name, header), "shim names C.%s, which include/evg_sched.h does not declare" % name
+    defined = set(re.findall(r"^func (?:\([^)]*\) )?([A-Za-z_][A-Za-z0-9_]*)", src, flags=re.M))
+    for helper in ("planBatch", "allocateBatch", "intern", "taskFlags", "depRequired", "fetchedDepStates", "breakdownOfUnit", "depsMetTime",
+                   "queueInfoFromRows", "providerClass", "unixNS", "boolToC", "statusClass", "carveSlice", "runGPUPlanner"):
+        assert helper in defined, "shim helper %s is named but not defined" % helper
+    assert "var GPUTaskPlanner TaskPlanner" in src and "var GPUHostAllocator HostAllocator" in src
