@@ -1176,6 +1176,7 @@ constexpr int kGenericLds = 2048 * 16;  // one tile of 128-bit keys
 __global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a, int skip_tiled) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
+  if (skip_tiled) tiled_rows(a);  // the info rows of the distros the pipeline finished (evg_tiled.hip.h T6)
   // Almost always nothing is flagged: find that out with ONE round trip (independent loads) instead of one per distro.
   int any = 0;
   for (int d = a.d0 + blockIdx.x; d < a.d1; d += gridDim.x) any |= a.w_generic[d];

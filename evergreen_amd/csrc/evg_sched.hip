@@ -1054,8 +1054,7 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
     hipLaunchKernelGGL(k_tiled_mmerge, rt, tb, kMmergeLds, st, a);
   }
   for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, st, a, p);
-  hipLaunchKernelGGL(k_tiled_rows, gg, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 1);
+  hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 1);  // its head writes the info rows of the distros the pipeline finished
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }

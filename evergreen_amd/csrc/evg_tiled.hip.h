@@ -156,10 +156,30 @@ __device__ __forceinline__ long long rec_region(const PlanArgs& a, const DC& c, 
 // ---- T0: directory ---------------------------------------------------------------------------------------------
 // One workgroup. passes_launched: merge passes the host enqueued behind (from the launch hint, or from n_tasks when there is
 // no hint); a distro that needs more stays with the generic kernel.
+// Inclusive sum scan inside a wave (DPP row scans + the three row totals).
+__device__ __forceinline__ long long wave_scan_sum(long long v, int lane) {
+  auto shr = [&](long long x, auto ctrl) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(uint64_t)x, decltype(ctrl)::value, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)x >> 32), decltype(ctrl)::value, 0xF, 0xF, false);
+    return (long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+  };
+  v += shr(v, std::integral_constant<int, 0x111>{});
+  v += shr(v, std::integral_constant<int, 0x112>{});
+  v += shr(v, std::integral_constant<int, 0x114>{});
+  v += shr(v, std::integral_constant<int, 0x118>{});
+  auto rl = [&](int l) {
+    return (long long)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, l));
+  };
+  const long long r0 = rl(15), r1 = rl(31), r2 = rl(47);
+  const int row = lane >> 4;
+  return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+}
+
 __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passes_launched) {
-  __shared__ int s_rt[1024], s_st[1024];
-  __shared__ long long s_bk[1024];
-  const int tid = threadIdx.x;
+  __shared__ int s_rt[1024], s_st[1024];  // exclusive prefixes: row tiles / slot tiles before thread t's distros
+  __shared__ long long s_w[3][16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int d0 = a.d0, D = a.d1 - a.d0;
   const int per = (D + 1023) / 1024;
   int rt = 0, st = 0;
@@ -186,28 +206,48 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
     t.s_first = ~0ull;
     a.w_ts[d] = t;
   }
-  s_rt[tid] = rt; s_st[tid] = st; s_bk[tid] = bk;
+  // three inclusive scans over the 1024 threads: inside the wave by DPP, the 16 wave totals through LDS
+  long long irt = wave_scan_sum(rt, lane), ist = wave_scan_sum(st, lane), ibk = wave_scan_sum(bk, lane);
+  if (lane == 63) { s_w[0][wv] = irt; s_w[1][wv] = ist; s_w[2][wv] = ibk; }
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int x = tid >= o ? s_rt[tid - o] : 0, y = tid >= o ? s_st[tid - o] : 0;
-    const long long z = tid >= o ? s_bk[tid - o] : 0;
-    __syncthreads();
-    s_rt[tid] += x; s_st[tid] += y; s_bk[tid] += z;
-    __syncthreads();
+  long long trt = 0, tst = 0;
+  for (int w = 0; w < 16; w++) {
+    if (w < wv) { irt += s_w[0][w]; ist += s_w[1][w]; ibk += s_w[2][w]; }
+    trt += s_w[0][w]; tst += s_w[1][w];
   }
-  int rb = s_rt[tid] - rt, sb = s_st[tid] - st;
-  long long bb = s_bk[tid] - bk;
+  int rb = (int)irt - rt, sb = (int)ist - st;
+  long long bb = ibk - bk;
+  s_rt[tid] = rb; s_st[tid] = sb;
   for (int k = 0; k < per; k++) {
     const int d = d0 + tid * per + k;
     if (d >= a.d1) break;
     TState* t = &a.w_ts[d];
     if (!t->on) continue;
     t->rt_base = rb; t->st_base = sb; t->bucket_base = bb;
-    for (int q = 0; q < t->n_rt; q++) { a.w_rtile[2 * (rb + q)] = d; a.w_rtile[2 * (rb + q) + 1] = q; }
-    for (int q = 0; q < t->n_st; q++) { a.w_stile[2 * (sb + q)] = d; a.w_stile[2 * (sb + q) + 1] = q; }
     rb += t->n_rt; sb += t->n_st; bb += (long long)t->n_rt * t->n_st;
   }
-  if (tid == 1023) { a.w_ntile[0] = s_rt[1023]; a.w_ntile[1] = s_st[1023]; }
+  if (tid == 0) { a.w_ntile[0] = (int)trt; a.w_ntile[1] = (int)tst; }
+  __syncthreads();  // the TState rows (same workgroup: visible after the barrier) and the prefixes
+  // the two directories, every thread a share: tile x belongs to the last thread whose prefix is <= x, then to one of its distros
+  auto fill = [&](int total, const int* pre, int32_t* dir, bool rows) {
+    for (int x = tid; x < total; x += 1024) {
+      int lo = 0, hi = 1024;  // last t with pre[t] <= x
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= x) lo = mid; else hi = mid;
+      }
+      for (int k = 0; k < per; k++) {
+        const int d = d0 + lo * per + k;
+        if (d >= a.d1) break;
+        const TState* t = &a.w_ts[d];
+        if (!t->on) continue;
+        const int base = rows ? t->rt_base : t->st_base, cnt = rows ? t->n_rt : t->n_st;
+        if (x >= base && x < base + cnt) { dir[2 * x] = d; dir[2 * x + 1] = x - base; break; }
+      }
+    }
+  };
+  fill((int)trt, s_rt, a.w_rtile, true);
+  fill((int)tst, s_st, a.w_stile, false);
 }
 
 // ---- T1: rows -> records ---------------------------------------------------------------------------------------
@@ -1182,13 +1222,15 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_merge(const PlanArgs a, i
 }
 
 // ---- T6: model.DistroQueueInfo, the standalone row, MaxHosts of the task-group rows ---------------------------------------
-__global__ void __launch_bounds__(256) k_tiled_rows(const PlanArgs a) {
-  const int tid = threadIdx.x;
+// Runs at the head of k_plan_generic's launch behind the pipeline (one launch instead of two): the workgroup that strides
+// over distro d writes d's rows when the pipeline finished d. nthreads = blockDim.x.
+__device__ __forceinline__ void tiled_rows(const PlanArgs& a) {
+  const int tid = threadIdx.x, nthreads = blockDim.x;
   for (int d = a.d0 + blockIdx.x; d < a.d1; d += gridDim.x) {
     const TState* ts = &a.w_ts[d];
     if (!tiled_live(ts)) continue;
     const int D = a.in.n_distros, tg_lo = a.in.tg_off[d], ntg = a.in.tg_off[d + 1] - tg_lo;
-    for (int k = tid; k < ntg; k += 256) a.out.group_info[D + tg_lo + k].max_hosts = (int32_t)(uint32_t)(a.w_gfirst[D + tg_lo + k] & 0xFFFFFFFFu);
+    for (int k = tid; k < ntg; k += nthreads) a.out.group_info[D + tg_lo + k].max_hosts = (int32_t)(uint32_t)(a.w_gfirst[D + tg_lo + k] & 0xFFFFFFFFu);
     if (tid == 0) {
       const evg_distro_params p = a.in.distros[d];
       const int v = ts->any_mq ? 1 : 0;
