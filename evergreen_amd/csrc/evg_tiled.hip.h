@@ -45,7 +45,7 @@
 namespace evg {
 
 constexpr int kRT = 2048;             // rows per row tile == keys per sort tile
-constexpr int kST = 768;              // unit slots per slot tile: 64 B of accumulators each = 48 KB of LDS, three workgroups per CU
+constexpr int kST = 704;              // unit slots per slot tile: 64 B of accumulators each = 44 KB of LDS (+ 6 KB static): three workgroups per CU
 constexpr int kTiledMaxRows = 1 << 20;
 constexpr int kTiledMaxSlots = 1 << 21;
 constexpr int kMaxST = (kTiledMaxSlots / kST + 511) / 512 * 512;  // slot tiles of one distro: the scatter kernel buckets them in LDS
@@ -56,7 +56,7 @@ constexpr int kCandWin = kSmpStride + 1;  // candidates per tile at a window bou
 constexpr int kTileEdges = 6144;      // dependency edges of one row tile resolved edge-parallel in LDS (more: per row, from memory)
 // PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs): 1, 2 = the per-row forms of round 2; 4 = the one-pass multiway merge instead of the
 // pairwise passes; 8 = the rank-merge tile sort instead of the bitonic network (both measured equal or slower: DESIGN.md 3.1)
-constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2, TM_MULTIWAY_MERGE = 4, TM_RANK_MERGE_SORT = 8;
+constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2, TM_MULTIWAY_MERGE = 4, TM_RANK_MERGE_SORT = 8;  // 16: linear tile mapping (xcd_tile)
 
 // blockIdx -> tile, XCD-aware: workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; tile
 // (b % 8) * ceil(T / 8) + b / 8 gives every XCD a contiguous eighth of the tile list, i.e. whole distros. -1: no tile.
@@ -905,11 +905,15 @@ __global__ void __launch_bounds__(kTiledBlock, 4) k_tiled_elect(const PlanArgs a
   }
   TT_MARK(9);
   __syncthreads();  // the staged candidates are dead: the sort works in the same bytes
-  // The tile sort: thread t holds the keys of positions 4t..4t+3.
+  // The tile sort: thread t holds the keys of positions 4t..4t+3. (Measured and dropped: sorting ONE 64-bit word per row --
+  // [unit word | row in the tile], when the unit word fits 53 bits -- on the planner's 64-bit network and ranking the rows
+  // inside each unit's run by counting: k_tiled_elect 96 -> 76 us on the config-5 share, but the runs of ~50 rows of
+  // grouped-version distros cost more than the network saves on the skewed pool (+7 %), and without them few distros qualify.)
+  K192* const tile_out = (K192*)a.w_keyA + ((size_t)ts->rt_base + tile) * kRT;
   if (a.tiled_mode & TM_RANK_MERGE_SORT) lds_merge_sort4<kRT>(k, tid, (uint64_t*)smem);
   else bitonic_sort4_fixed<kRT, K192>(k, tid, (K192*)smem, (K192*)smem);
   TT_MARK(10);
-  K192* out = (K192*)a.w_keyA + ((size_t)ts->rt_base + tile) * kRT + tid * 4;
+  K192* out = tile_out + tid * 4;
 #pragma unroll
   for (int e4 = 0; e4 < 4; e4++) out[e4] = k[e4];
   TT_MARK(11);
