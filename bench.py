@@ -353,7 +353,7 @@ def sharded_workload(make_batch, what, ctx, dev, dist, rank, world, mode, steps,
         except AssertionError as e:
             parity = str(e)[:300]
         d0, d1 = pool.my_range
-        abytes, _ = algorithmic_bytes(batch, int(n_units * (batch.task_off[d1] - batch.task_off[d0]) / max(lay.N, 1)), d0, d1)
+        abytes, _ = algorithmic_bytes(batch, int(n_units) * (int(batch.task_off[d1]) - int(batch.task_off[d0])) // max(int(lay.N), 1), d0, d1)
         ach = abytes / (plan_ms * 1e-3) / 1e9
         obj.update({"parity_vs_oracle": parity, "queue_order_match": order_match(batch, got, want),
                     "cpu_baseline": {"value": lay.N / tbest, "unit": "tasks/s", "cores": nt, "kind": "port", "sample": "the whole pool, one pass, one distro range per thread"},
