@@ -42,6 +42,16 @@ __device__ __forceinline__ void shuffle_stage(K (&k)[4], bool take_min) {
   }
 }
 
+// LDS exchange buffer of the stages with partner distance >= 256: thread t's four keys in, key e of thread t out. The
+// default is an array of keys by position; a key type may overload both with a layout of its own (K192 does).
+template <class K>
+__device__ __forceinline__ void lds_put4(K* buf, int t, const K (&k)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) buf[t * 4 + e] = k[e];
+}
+template <class K>
+__device__ __forceinline__ K lds_get(const K* buf, int t, int e) { return buf[t * 4 + e]; }
+
 template <class K>
 __device__ __forceinline__ void cmpx(K& a, K& b, bool asc) {  // a at the lower position
   // one compare: for a != b, a < b is !(b < a); equal keys are the same bits, so swapping them is harmless
@@ -75,13 +85,12 @@ __device__ __forceinline__ void bitonic_sort4_fixed(K (&k)[4], int tid, K* buf0,
         K* buf = which ? buf1 : buf0;
         which ^= 1;
         if (buf0 == buf1) __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; e++) buf[p0 + e] = k[e];
+        lds_put4(buf, tid, k);
         __syncthreads();
-        const int q0 = (tid ^ (j >> 2)) * 4;
+        const int qt = tid ^ (j >> 2);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const K o = buf[q0 + e];
+          const K o = lds_get(buf, qt, e);
           const bool lt = key_lt(o, k[e]);
           if (take_min == lt) k[e] = o;
         }
@@ -108,13 +117,12 @@ __device__ __forceinline__ void bitonic_merge4_fixed(K (&k)[4], int tid, K* buf,
     const bool take_min = ((p0 & j) == 0) == asc;
     if (j >= 256) {
       __syncthreads();
-#pragma unroll
-      for (int e = 0; e < 4; e++) buf[p0 + e] = k[e];
+      lds_put4(buf, tid, k);
       __syncthreads();
-      const int q0 = (tid ^ (j >> 2)) * 4;
+      const int qt = tid ^ (j >> 2);
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const K o = buf[q0 + e];
+        const K o = lds_get(buf, qt, e);
         const bool lt = key_lt(o, k[e]);
         if (take_min == lt) k[e] = o;
       }

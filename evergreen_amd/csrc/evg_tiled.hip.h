@@ -94,6 +94,19 @@ __device__ __forceinline__ bool key_lt(const K192& a, const K192& b) {
 }
 template <int M>
 __device__ __forceinline__ K192 key_xor(const K192& v) { return K192{key_xor<M>(v.hi), key_xor<M>(v.mid), key_xor<M>(v.lo)}; }
+// The exchange buffer of the sorting networks' LDS stages for 192-bit keys: word c of key e of thread t at
+// [(4 c + e) * 512 + t] -- consecutive lanes, consecutive 8-byte words, whichever partner thread is read. (As an array of
+// 24-byte keys a thread's four keys are a 96-byte stride between lanes: eight-way bank conflicts on every access. For the
+// planner's 64-bit keys the two layouts measure the same.)
+__device__ __forceinline__ void lds_put4(K192* buf, int t, const K192 (&k)[4]) {
+  uint64_t* w = (uint64_t*)buf;
+#pragma unroll
+  for (int e = 0; e < 4; e++) { w[e * kTiledBlock + t] = k[e].hi; w[(4 + e) * kTiledBlock + t] = k[e].mid; w[(8 + e) * kTiledBlock + t] = k[e].lo; }
+}
+__device__ __forceinline__ K192 lds_get(const K192* buf, int t, int e) {
+  const uint64_t* w = (const uint64_t*)buf;
+  return K192{w[e * kTiledBlock + t], w[(4 + e) * kTiledBlock + t], w[(8 + e) * kTiledBlock + t]};
+}
 
 // ---- membership record -----------------------------------------------------------------------------------------
 // w0: bits 0-9 slot inside the destination tile | 10-15 unit flags (UF_* >> 24) | 16 carries queue info (the row's own
@@ -805,6 +818,20 @@ __device__ __forceinline__ void seg_max_runs(const int* s_seg, int nseg, int rou
 
 // ---- T3: elect, keys, tile sort ----------------------------------------------------------------------------------
 constexpr int kTiledSortLds = 3 * 8 * (kRT + kRT / 32);  // three padded arrays of 64-bit words (lpad)
+
+// A tile's 2048 keys (four per thread, positions 4 tid .. 4 tid + 3) out to global memory as 6144 consecutive 64-bit words,
+// through LDS: a wave's store covers 512 contiguous bytes. (Each thread storing its own four 24-byte keys is a 96-byte stride
+// between lanes: 64 requests per store instruction.) smem: 48 KB; barriers inside.
+__device__ __forceinline__ void store_tile_keys(const K192 (&k)[4], K192* dst, int tid, unsigned char* smem) {
+  __syncthreads();  // whoever still reads the exchange buffer of the last LDS stage
+#pragma unroll
+  for (int e = 0; e < 4; e++) ((K192*)smem)[tid * 4 + e] = k[e];
+  __syncthreads();
+  const uint64_t* sw = (const uint64_t*)smem;
+  uint64_t* g = (uint64_t*)dst;
+#pragma unroll
+  for (int q = 0; q < 12; q++) g[q * kTiledBlock + tid] = sw[q * kTiledBlock + tid];
+}
 static_assert(kTileEdges * 8 <= kTiledSortLds && kRT * (int)sizeof(K192) <= kTiledSortLds, "the staged candidates and the network's exchange buffer share the bytes");
 __device__ __forceinline__ bool tiled_key_bits(const TState* ts, int& bn, int& bp, int& bd) {
   const int bt = bits_of((uint64_t)(ts->tmax - ts->tmin));
@@ -913,9 +940,13 @@ __global__ void __launch_bounds__(kTiledBlock, 4) k_tiled_elect(const PlanArgs a
   if (a.tiled_mode & TM_RANK_MERGE_SORT) lds_merge_sort4<kRT>(k, tid, (uint64_t*)smem);
   else bitonic_sort4_fixed<kRT, K192>(k, tid, (K192*)smem, (K192*)smem);
   TT_MARK(10);
-  K192* out = tile_out + tid * 4;
+  if (a.tiled_mode & 32) {  // A/B: every thread stores its own four keys
+    K192* out = tile_out + tid * 4;
 #pragma unroll
-  for (int e4 = 0; e4 < 4; e4++) out[e4] = k[e4];
+    for (int e4 = 0; e4 < 4; e4++) out[e4] = k[e4];
+  } else {
+    store_tile_keys(k, tile_out, tid, smem);
+  }
   TT_MARK(11);
 }
 
@@ -1199,20 +1230,30 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_merge(const PlanArgs a, i
   } else {
     const K192 *A = src + pair_lo, *B = src + a_hi;
     const int diag0 = (int)(pos0 - pair_lo);
+    TT_BEGIN();
     if (tid < 128) {
       const int s = merge_split(A, B, na, nb, diag0 + (tid >> 6) * kRT, lane);
       if (lane == 0) s_split[tid >> 6] = s;
     }
     __syncthreads();
+    TT_MARK(22);
     const int a0 = s_split[0], a1 = s_split[1];
     const int b1 = diag0 + kRT - a1, cnt_a = a1 - a0;
-    // positions [0, cnt_a): A ascending; [cnt_a, 2048): B descending -- a bitonic sequence
+    // positions [0, cnt_a): A ascending; [cnt_a, 2048): B descending -- a bitonic sequence. (Measured: bringing the two
+    // contiguous key ranges in as 6144 consecutive 64-bit words through LDS -- 8 requests per load instruction instead of 64
+    // -- is SLOWER, 0.347 -> 0.372 ms per config-5-share plan: the 96-byte-stride reads that take the keys back out of LDS
+    // conflict eight ways, and the loads were latency, not request rate.)
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int x = tid * 4 + e;
       k[e] = x < cnt_a ? A[a0 + x] : B[b1 - 1 - (x - cnt_a)];
     }
+#ifdef EVG_PHASE_TIMING
+    if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    TT_MARK(23);
+#endif
     bitonic_merge4_fixed<kRT, K192>(k, tid, (K192*)smem, true);
+    TT_MARK(24);
   }
   if (pass == ts->passes - 1) {  // the distro's last pass: the merged keys ARE the queue -- nothing is written back
     uint32_t i4[4];
@@ -1221,8 +1262,12 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_merge(const PlanArgs a, i
     tiled_emit_order(a, ts, d, pos0 + tid * 4, i4);
     return;
   }
+  if (a.tiled_mode & 32) {
 #pragma unroll
-  for (int e = 0; e < 4; e++) dst[pos0 + tid * 4 + e] = k[e];
+    for (int e = 0; e < 4; e++) dst[pos0 + tid * 4 + e] = k[e];
+  } else {
+    store_tile_keys(k, dst + pos0, tid, smem);
+  }
 }
 
 // ---- T6: model.DistroQueueInfo, the standalone row, MaxHosts of the task-group rows ---------------------------------------
