@@ -107,6 +107,73 @@ __device__ __forceinline__ void bitonic_sort4_fixed(K (&k)[4], int tid, K* buf0,
   }
 }
 
+// ---- merge path for the last levels of a tile sort ------------------------------------------------------------------------
+// src holds sorted runs of L keys by position (REV: the odd runs are descending, as the network leaves them). Every thread
+// finds, by a binary search along its diagonal, where its four consecutive outputs of the merge of its pair of runs begin
+// (log2(L) + 1 rounds of two LDS reads, uniform over the workgroup) and then merges them one after the other (one LDS read
+// per output: only the side that advanced). 4 keys x 9..11 compare-exchange stages become ~28 LDS reads and ~100 VALU
+// instructions. Equal keys (the planner's pads) may come out in any order. Measured alone (scripts/ubench/sort_bench.hip):
+// the 2048-key sort 16.2 k -> 14.6 k ticks; a 4-ary search or reading both four-key windows at once and merging them by
+// ranks in registers are SLOWER (16.8 k / 17.6 k): the rounds are bound by LDS reads, not by their latency. INSIDE the planner
+// kernel (sort2048_merge_path in place of the network) it is a loss, 54.7 -> 56.4 us: the other workgroup of the CU is in its
+// LDS-heavy phases while this one sorts, and the network's DPP stages do not touch the LDS pipe. The planner keeps the network;
+// the large-distro kernels, whose 192-bit network is VALU-bound with every workgroup of the CU sorting, use the rounds
+// (evg_tiled.hip.h).
+template <int L, bool REV, class K>
+__device__ __forceinline__ void merge_path_round(K (&k)[4], int tid, const K* src) {
+  const int pos = tid * 4, base = pos & ~(2 * L - 1), diag = pos - base;
+  const K* A = src + base;
+  const K* B = A + L;
+  auto b_at = [&](int j) { return REV ? B[L - 1 - j] : B[j]; };
+  int lo = diag - L > 0 ? diag - L : 0, hi = diag < L ? diag : L;
+#pragma unroll
+  for (int it = 0; it < 32 - __builtin_clz(L); it++) {
+    const bool go = lo < hi;
+    const int mid = go ? (lo + hi) >> 1 : 0;
+    const K a = A[mid], b = b_at(go ? diag - 1 - mid : 0);
+    const bool a_first = key_lt(a, b);
+    lo = go && a_first ? mid + 1 : lo;
+    hi = go && !a_first ? mid : hi;
+  }
+  int ia = lo, ib = diag - lo;
+  K ka = A[ia < L ? ia : L - 1], kb = b_at(ib < L ? ib : L - 1);
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const bool take_a = ib >= L || (ia < L && key_lt(ka, kb));
+    k[e] = take_a ? ka : kb;
+    ia += take_a ? 1 : 0;
+    ib += take_a ? 0 : 1;
+    if (e < 3) {
+      const int ja = ia < L ? ia : L - 1, jb = ib < L ? ib : L - 1;
+      const K nx = take_a ? A[ja] : b_at(jb);
+      ka = take_a ? nx : ka;
+      kb = take_a ? kb : nx;
+    }
+  }
+}
+// Sort of 2048 64-bit keys: the network up to sorted runs of 256 (36 of its 66 stages, none through LDS), then three
+// merge-path rounds. buf0 / buf1: 2048 keys of LDS each. PRIO_STEP as in bitonic_sort4_fixed.
+template <int PRIO_STEP = -1>
+__device__ __forceinline__ void sort2048_merge_path(uint64_t (&k)[4], int tid, uint64_t* buf0, uint64_t* buf1) {
+  if constexpr (PRIO_STEP >= 0) EVG_PRIO(PRIO_STEP);
+  bitonic_sort4_fixed<256, uint64_t>(k, tid, buf0, buf1);
+#pragma unroll
+  for (int e = 0; e < 4; e++) buf0[tid * 4 + e] = k[e];
+  __syncthreads();
+  if constexpr (PRIO_STEP >= 0) EVG_PRIO(PRIO_STEP + 1);
+  merge_path_round<256, true>(k, tid, buf0);
+#pragma unroll
+  for (int e = 0; e < 4; e++) buf1[tid * 4 + e] = k[e];
+  __syncthreads();
+  if constexpr (PRIO_STEP >= 0) EVG_PRIO(PRIO_STEP + 2);
+  merge_path_round<512, false>(k, tid, buf1);
+#pragma unroll
+  for (int e = 0; e < 4; e++) buf0[tid * 4 + e] = k[e];
+  __syncthreads();
+  if constexpr (PRIO_STEP >= 0) EVG_PRIO(PRIO_STEP + 3);
+  merge_path_round<1024, false>(k, tid, buf0);
+}
+
 // The in-tile half of one merge of a larger network: stages j = P/2 .. 1 of the merge whose direction for this whole
 // tile is `asc` (the tile lies inside one 2^m-aligned block of the merge). Same stage kinds as above.
 template <int P, class K>

@@ -819,6 +819,71 @@ __device__ __forceinline__ void seg_max_runs(const int* s_seg, int nseg, int rou
 // ---- T3: elect, keys, tile sort ----------------------------------------------------------------------------------
 constexpr int kTiledSortLds = 3 * 8 * (kRT + kRT / 32);  // three padded arrays of 64-bit words (lpad)
 
+// ---- merge path on 192-bit keys in LDS ----------------------------------------------------------------------------------
+// Keys by position in three arrays of 64-bit words (s_hi | s_mid | s_lo, kRT entries each). Two sorted ranges, A = [a0, a0 +
+// la) ascending and B = lb keys from b0 (b_rev: stored descending, the j-th smallest at b0 + lb - 1 - j): the thread produces
+// outputs diag .. diag + 3 of their merge. A binary search along the diagonal (ITER >= log2(max(la, lb)) + 1 uniform rounds;
+// the first word decides unless both keys belong to the same unit) finds where they begin, then they are merged one after the
+// other -- ~30 LDS reads and ~150 VALU instructions where the network spends 4 keys x 9..11 stages x ~18. Keys are distinct.
+// TM_NETWORK_MERGE (EVG_TILED_MODE bit 64) keeps the networks for A/B runs.
+constexpr int TM_NETWORK_MERGE = 64;
+// field by field: a ?: on the structs makes the compiler park both in scratch memory and load through a selected pointer
+__device__ __forceinline__ K192 key_sel(bool c, const K192& x, const K192& y) { return K192{c ? x.hi : y.hi, c ? x.mid : y.mid, c ? x.lo : y.lo}; }
+template <int ITER>
+__device__ __forceinline__ void merge_path4_k192(K192 (&k)[4], const uint64_t* s_hi, const uint64_t* s_mid, const uint64_t* s_lo, int a0, int la,
+                                                 int b0, int lb, bool b_rev, int diag) {
+  auto bi = [&](int j) { return b_rev ? b0 + lb - 1 - j : b0 + j; };
+  auto lt = [&](int x, int y) -> bool {  // key at x < key at y
+    const uint64_t xh = s_hi[x], yh = s_hi[y];
+    bool r = xh < yh;
+    if (xh == yh) { const uint64_t xm = s_mid[x], ym = s_mid[y]; r = xm != ym ? xm < ym : s_lo[x] < s_lo[y]; }
+    return r;
+  };
+  int lo = diag - lb > 0 ? diag - lb : 0, hi = diag < la ? diag : la;
+#pragma unroll
+  for (int it = 0; it < ITER; it++) {
+    const bool go = lo < hi;
+    const int mid = go ? (lo + hi) >> 1 : 0;
+    const bool a_first = lt(a0 + (go ? mid : 0), go ? bi(diag - 1 - mid) : a0);
+    lo = go && a_first ? mid + 1 : lo;
+    hi = go && !a_first ? mid : hi;
+  }
+  int ia = lo, ib = diag - lo;
+  auto ld = [&](int x) { return K192{s_hi[x], s_mid[x], s_lo[x]}; };
+  K192 ka = ld(ia < la ? a0 + ia : a0), kb = ld(ib < lb ? bi(ib) : a0);
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const bool take_a = ib >= lb || (ia < la && key_lt(ka, kb));
+    k[e] = key_sel(take_a, ka, kb);
+    ia += take_a ? 1 : 0;
+    ib += take_a ? 0 : 1;
+    if (e < 3) {
+      const K192 nx = ld(take_a ? (ia < la ? a0 + ia : a0) : (ib < lb ? bi(ib) : a0));
+      ka = key_sel(take_a, nx, ka);
+      kb = key_sel(take_a, kb, nx);
+    }
+  }
+}
+__device__ __forceinline__ void lds_put4_soa(uint64_t* s_hi, uint64_t* s_mid, uint64_t* s_lo, int p0, const K192 (&k)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) { s_hi[p0 + e] = k[e].hi; s_mid[p0 + e] = k[e].mid; s_lo[p0 + e] = k[e].lo; }
+}
+// Sort of a tile's 2048 keys (positions 4 tid .. 4 tid + 3): the network up to sorted runs of 256 (36 of the 66 stages, none
+// through LDS), then three merge-path rounds. smem: 48 KB.
+__device__ __forceinline__ void tile_sort_merge_path(K192 (&k)[4], int tid, unsigned char* smem) {
+  uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kRT, *s_lo = s_mid + kRT;
+  bitonic_sort4_fixed<256, K192>(k, tid, (K192*)smem, (K192*)smem);  // even runs ascending, odd runs descending
+  const int pos = tid * 4;
+#pragma unroll
+  for (int L = 256; L <= 1024; L <<= 1) {
+    if (L > 256) __syncthreads();  // every thread has merged the previous round's runs out of LDS
+    lds_put4_soa(s_hi, s_mid, s_lo, pos, k);
+    __syncthreads();
+    const int base = pos & ~(2 * L - 1);
+    merge_path4_k192<11>(k, s_hi, s_mid, s_lo, base, L, base + L, L, L == 256, pos - base);
+  }
+}
+
 // A tile's 2048 keys (four per thread, positions 4 tid .. 4 tid + 3) out to global memory as 6144 consecutive 64-bit words,
 // through LDS: a wave's store covers 512 contiguous bytes. (Each thread storing its own four 24-byte keys is a 96-byte stride
 // between lanes: 64 requests per store instruction.) smem: 48 KB; barriers inside.
@@ -838,7 +903,7 @@ __device__ __forceinline__ bool tiled_key_bits(const TState* ts, int& bn, int& b
   bn = bits_of((uint64_t)(ts->nmax - ts->nmin)); bp = bits_of((uint64_t)(ts->pmax - ts->pmin)); bd = bits_of(ts->dmax - ts->dmin);
   return bt + bn + bp + bd <= 64;
 }
-__global__ void __launch_bounds__(kTiledBlock, 4) k_tiled_elect(const PlanArgs a) {
+__global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);
   if (w < 0) return;
@@ -938,7 +1003,8 @@ __global__ void __launch_bounds__(kTiledBlock, 4) k_tiled_elect(const PlanArgs a
   // grouped-version distros cost more than the network saves on the skewed pool (+7 %), and without them few distros qualify.)
   K192* const tile_out = (K192*)a.w_keyA + ((size_t)ts->rt_base + tile) * kRT;
   if (a.tiled_mode & TM_RANK_MERGE_SORT) lds_merge_sort4<kRT>(k, tid, (uint64_t*)smem);
-  else bitonic_sort4_fixed<kRT, K192>(k, tid, (K192*)smem, (K192*)smem);
+  else if (a.tiled_mode & TM_NETWORK_MERGE) bitonic_sort4_fixed<kRT, K192>(k, tid, (K192*)smem, (K192*)smem);
+  else tile_sort_merge_path(k, tid, smem);
   TT_MARK(10);
   if (a.tiled_mode & 32) {  // A/B: every thread stores its own four keys
     K192* out = tile_out + tid * 4;
@@ -1207,7 +1273,7 @@ __device__ __forceinline__ int merge_split(const K192* A, const K192* B, int na,
   return lo < hi ? lo : hi;
 }
 
-__global__ void __launch_bounds__(kTiledBlock) k_tiled_merge(const PlanArgs a, int pass) {
+__global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a, int pass) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_split[2];
   const int w = blockIdx.x;
@@ -1243,16 +1309,24 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_merge(const PlanArgs a, i
     // contiguous key ranges in as 6144 consecutive 64-bit words through LDS -- 8 requests per load instruction instead of 64
     // -- is SLOWER, 0.347 -> 0.372 ms per config-5-share plan: the 96-byte-stride reads that take the keys back out of LDS
     // conflict eight ways, and the loads were latency, not request rate.)
+    const bool net = (a.tiled_mode & TM_NETWORK_MERGE) != 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int x = tid * 4 + e;
-      k[e] = x < cnt_a ? A[a0 + x] : B[b1 - 1 - (x - cnt_a)];
+      k[e] = x < cnt_a ? A[a0 + x] : net ? B[b1 - 1 - (x - cnt_a)] : B[b1 - (kRT - cnt_a) + (x - cnt_a)];
+    }
+    if (!net) {  // both ranges ascending in LDS, one merge-path round
+      uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kRT, *s_lo = s_mid + kRT;
+      lds_put4_soa(s_hi, s_mid, s_lo, tid * 4, k);
+      __syncthreads();
+      merge_path4_k192<12>(k, s_hi, s_mid, s_lo, 0, cnt_a, cnt_a, kRT - cnt_a, false, tid * 4);
+      __syncthreads();  // the arrays are re-used below
     }
 #ifdef EVG_PHASE_TIMING
     if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     TT_MARK(23);
 #endif
-    bitonic_merge4_fixed<kRT, K192>(k, tid, (K192*)smem, true);
+    if (net) bitonic_merge4_fixed<kRT, K192>(k, tid, (K192*)smem, true);
     TT_MARK(24);
   }
   if (pass == ts->passes - 1) {  // the distro's last pass: the merged keys ARE the queue -- nothing is written back

@@ -30,6 +30,190 @@ __global__ void __launch_bounds__(512, 4) k_sort(uint64_t* out, unsigned long lo
   for (int e = 0; e < 4; e++) out[(size_t)blockIdx.x * 2048 + tid * 4 + e] = k[e];
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// ---- merge path for the last three levels of the sort ------------------------------------------------------------------------
+// The network up to sorted runs of 256 keys (36 of its 66 stages, none through LDS), then three rounds in which every thread
+// finds, by a binary search along its diagonal, where its four consecutive outputs of the merge of two runs begin, and merges
+// them one after the other (30 compare-exchange stages of four keys against ~11 + 4 dependent LDS reads).
+// src: runs of L keys; REV: odd runs are descending (what the network leaves). Output: positions 4 tid .. 4 tid + 3 in k.
+template <int L, bool REV>
+__device__ __forceinline__ void merge_path_round(uint64_t (&k)[4], int tid, const uint64_t* src) {
+  const int pos = tid * 4, base = pos & ~(2 * L - 1), diag = pos - base;
+  const uint64_t* A = src + base;
+  const uint64_t* B = A + L;
+  auto b_at = [&](int j) { return REV ? B[L - 1 - j] : B[j]; };
+  int lo = diag - L > 0 ? diag - L : 0, hi = diag < L ? diag : L;
+#pragma unroll
+  for (int it = 0; it < 32 - __builtin_clz(L); it++) {  // log2(L) + 1 uniform rounds
+    const bool go = lo < hi;
+    const int mid = go ? (lo + hi) >> 1 : 0;
+    const int bj = go ? diag - 1 - mid : 0;
+    const uint64_t a = A[mid], b = b_at(bj);
+    const bool a_first = a < b;
+    lo = go && a_first ? mid + 1 : lo;
+    hi = go && !a_first ? mid : hi;
+  }
+  int ia = lo, ib = diag - lo;
+  uint64_t ka = A[ia < L ? ia : L - 1], kb = b_at(ib < L ? ib : L - 1);
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const bool take_a = ib >= L || (ia < L && ka < kb);
+    k[e] = take_a ? ka : kb;
+    ia += take_a ? 1 : 0;
+    ib += take_a ? 0 : 1;
+    if (e < 3) {
+      const int ja = ia < L ? ia : L - 1, jb = ib < L ? ib : L - 1;
+      const uint64_t nx = take_a ? A[ja] : b_at(jb);  // one read: only the side that advanced
+      ka = take_a ? nx : ka;
+      kb = take_a ? kb : nx;
+    }
+  }
+}
+// v2: 4-ary search (three probe pairs per round, log4 rounds), then the two four-key windows read at once and merged in
+// registers by ranks -- no chain of dependent LDS reads after the search.
+template <int L, bool REV, bool SEARCH4, bool WINDOW>
+__device__ __forceinline__ void merge_path_round4(uint64_t (&k)[4], int tid, const uint64_t* src) {
+  const int pos = tid * 4, base = pos & ~(2 * L - 1), diag = pos - base;
+  const uint64_t* A = src + base;
+  const uint64_t* B = A + L;
+  auto b_at = [&](int j) { return REV ? B[L - 1 - j] : B[j]; };
+  int lo = diag - L > 0 ? diag - L : 0, hi = diag < L ? diag : L;
+  if constexpr (SEARCH4) {
+  constexpr int ITER = (31 - __builtin_clz(L)) / 2 + 2;
+#pragma unroll
+  for (int it = 0; it < ITER; it++) {
+    const bool go = lo < hi;
+    const int sz = hi - lo;
+    const int m1 = go ? lo + (sz >> 2) : 0, m2 = go ? lo + (sz >> 1) : 0, m3 = go ? lo + ((3 * sz) >> 2) : 0;
+    const uint64_t a1 = A[m1], a2 = A[m2], a3 = A[m3];
+    const uint64_t b1 = b_at(go ? diag - 1 - m1 : 0), b2 = b_at(go ? diag - 1 - m2 : 0), b3 = b_at(go ? diag - 1 - m3 : 0);
+    const bool p1 = a1 < b1, p2 = a2 < b2, p3 = a3 < b3;
+    const int nlo = p3 ? m3 + 1 : p2 ? m2 + 1 : p1 ? m1 + 1 : lo;
+    const int nhi = !p1 ? m1 : !p2 ? m2 : !p3 ? m3 : hi;
+    lo = go ? nlo : lo;
+    hi = go ? nhi : hi;
+  }
+  } else {
+#pragma unroll
+  for (int it = 0; it < 32 - __builtin_clz(L); it++) {
+    const bool go = lo < hi;
+    const int mid = go ? (lo + hi) >> 1 : 0;
+    const int bj = go ? diag - 1 - mid : 0;
+    const uint64_t a = A[mid], b = b_at(bj);
+    const bool a_first = a < b;
+    lo = go && a_first ? mid + 1 : lo;
+    hi = go && !a_first ? mid : hi;
+  }
+  }
+  if constexpr (!WINDOW) {
+  int ia = lo, ib = diag - lo;
+  uint64_t ka = A[ia < L ? ia : L - 1], kb = b_at(ib < L ? ib : L - 1);
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const bool take_a = ib >= L || (ia < L && ka < kb);
+    k[e] = take_a ? ka : kb;
+    ia += take_a ? 1 : 0;
+    ib += take_a ? 0 : 1;
+    if (e < 3) {
+      const int ja = ia < L ? ia : L - 1, jb = ib < L ? ib : L - 1;
+      const uint64_t nx = take_a ? A[ja] : b_at(jb);
+      ka = take_a ? nx : ka;
+      kb = take_a ? kb : nx;
+    }
+  }
+  return;
+  }
+  const int ia = lo, ib = diag - lo;
+  uint64_t a[4], b[4];
+  bool va[4], vb[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    va[i] = ia + i < L; vb[i] = ib + i < L;
+    a[i] = A[va[i] ? ia + i : L - 1];
+    b[i] = b_at(vb[i] ? ib + i : L - 1);
+  }
+  int pa[4] = {0, 1, 2, 3}, pb[4] = {0, 1, 2, 3};
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool a_first = va[i] && (!vb[j] || a[i] < b[j]);
+      pa[i] += a_first ? 0 : 1;
+      pb[j] += a_first ? 1 : 0;
+    }
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { o = pa[i] == e ? a[i] : o; o = pb[i] == e ? b[i] : o; }
+    k[e] = o;
+  }
+}
+template <int V>
+__global__ void __launch_bounds__(512, 4) k_sort_mp(uint64_t* out, unsigned long long* cyc, int reps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* b0 = (uint64_t*)smem;
+  uint64_t* b1 = b0 + 2048;
+  const int tid = threadIdx.x;
+  uint64_t k[4];
+  for (int e = 0; e < 4; e++) k[e] = mix64((uint64_t)(blockIdx.x * 2048 + tid * 4 + e));
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; r++) {
+    bitonic_sort4_fixed<256, uint64_t>(k, tid, b0, b1);  // runs of 256: even runs ascending, odd runs descending
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; e++) b0[tid * 4 + e] = k[e];
+    __syncthreads();
+    if (V == 0) merge_path_round<256, true>(k, tid, b0); else merge_path_round4<256, true, (V & 1) != 0, (V & 2) != 0>(k, tid, b0);
+#pragma unroll
+    for (int e = 0; e < 4; e++) b1[tid * 4 + e] = k[e];
+    __syncthreads();
+    if (V == 0) merge_path_round<512, false>(k, tid, b1); else merge_path_round4<512, false, (V & 1) != 0, (V & 2) != 0>(k, tid, b1);
+#pragma unroll
+    for (int e = 0; e < 4; e++) b0[tid * 4 + e] = k[e];
+    __syncthreads();
+    if (V == 0) merge_path_round<1024, false>(k, tid, b0); else merge_path_round4<1024, false, (V & 1) != 0, (V & 2) != 0>(k, tid, b0);
+    if (r + 1 < reps)
+      for (int e = 0; e < 4; e++) k[e] = (k[e] ^ (k[e] << 13)) * 0x9E3779B97F4A7C15ull + (uint64_t)r;  // unsort
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  for (int e = 0; e < 4; e++) out[(size_t)blockIdx.x * 2048 + tid * 4 + e] = k[e];
+  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+static uint64_t host_mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+template <int V>
+static void run_mp(int grid, const char* what) {
+  uint64_t* out; unsigned long long* cyc;
+  (void)hipMalloc(&out, (size_t)grid * 2048 * 8); (void)hipMalloc(&cyc, grid * 8);
+  (void)hipFuncSetAttribute((const void*)k_sort_mp<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 79872);
+  k_sort_mp<V><<<grid, 512, 79872>>>(out, cyc, 1);
+  (void)hipDeviceSynchronize();
+  uint64_t* hk = new uint64_t[(size_t)grid * 2048];
+  (void)hipMemcpy(hk, out, (size_t)grid * 2048 * 8, hipMemcpyDeviceToHost);
+  bool ok = true;
+  for (int b = 0; b < grid && ok; b++) {
+    uint64_t x = 0;
+    for (int i = 0; i < 2048; i++) {
+      x ^= hk[(size_t)b * 2048 + i] ^ host_mix64((uint64_t)(b * 2048 + i));
+      if (i && hk[(size_t)b * 2048 + i - 1] >= hk[(size_t)b * 2048 + i]) ok = false;
+    }
+    if (x) ok = false;  // the same multiset (xor check) in strictly ascending order
+  }
+  delete[] hk;
+  const int reps = 20;
+  for (int i = 0; i < 3; i++) k_sort_mp<V><<<grid, 512, 79872>>>(out, cyc, reps);
+  (void)hipDeviceSynchronize();
+  unsigned long long* h = new unsigned long long[grid];
+  (void)hipMemcpy(h, cyc, grid * 8, hipMemcpyDeviceToHost);
+  double sum = 0; for (int i = 0; i < grid; i++) sum += h[i];
+  printf("%-40s grid %4d: %8.0f ticks per sort (sorted, same keys: %s)\n", what, grid, sum / grid / reps, ok ? "yes" : "NO");
+  delete[] h; (void)hipFree(out); (void)hipFree(cyc);
+}
+
 // ---- the alternative north_star names: a stable LSD radix sort in LDS, 8-bit digits --------------------------------------
 // Best case for it: the keys are assumed to be ALREADY ordered by their low 34 bits (unit min row | unit slot | row), so only
 // the value bits are sorted -- PASSES stable passes of 8 bits (a 24-bit value range: three). A pass, for the 2048 keys of a
@@ -192,6 +376,14 @@ int main() {
   run<256>(512, "8 sorts of 256 keys (36 stages, none by LDS)");
   run<64>(256, "32 sorts of 64 keys (21 stages: DPP only)");
   run<64>(512, "32 sorts of 64 keys (21 stages: DPP only)");
+  run_mp<0>(256, "runs of 256 + 3 merge-path rounds");
+  run_mp<0>(512, "runs of 256 + 3 merge-path rounds");
+  run_mp<1>(256, "  4-ary search, sequential merge");
+  run_mp<1>(512, "  4-ary search, sequential merge");
+  run_mp<2>(256, "  binary search, window merge");
+  run_mp<2>(512, "  binary search, window merge");
+  run_mp<3>(256, "  4-ary search, window merge");
+  run_mp<3>(512, "  4-ary search, window merge");
   run_radix<2>(256, "LSD radix, 2 x 8-bit stable passes");
   run_radix<2>(512, "LSD radix, 2 x 8-bit stable passes");
   run_radix<3>(256, "LSD radix, 3 x 8-bit stable passes");
