@@ -1035,6 +1035,9 @@ __device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, 
     const int i = (int)i4[e];
     const int r = lo + i;
     o4[e] = r;
+    // (Measured: issuing the task-group rows' gathers and the reads of the current minimum for all four rows before any is used --
+    // +3 % per plan, the merge kernels sit at their 80-register limit; the atomic without the read first -- the rows of a large
+    // group serialise on one address, skewed pool 0.314 -> 0.364 ms.)
     if (!((tgbit[i >> 6] >> (i & 63)) & 1ull)) {  // row tiles are 2048 rows: bit i of the distro's table
       const unsigned long long packed = ((unsigned long long)q << 32) | (uint32_t)i;
       first = packed < first ? packed : first;
@@ -1310,14 +1313,32 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a
     // -- is SLOWER, 0.347 -> 0.372 ms per config-5-share plan: the 96-byte-stride reads that take the keys back out of LDS
     // conflict eight ways, and the loads were latency, not request rate.)
     const bool net = (a.tiled_mode & TM_NETWORK_MERGE) != 0;
+    if (net) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int x = tid * 4 + e;
-      k[e] = x < cnt_a ? A[a0 + x] : net ? B[b1 - 1 - (x - cnt_a)] : B[b1 - (kRT - cnt_a) + (x - cnt_a)];
-    }
-    if (!net) {  // both ranges ascending in LDS, one merge-path round
-      uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kRT, *s_lo = s_mid + kRT;
-      lds_put4_soa(s_hi, s_mid, s_lo, tid * 4, k);
+      for (int e = 0; e < 4; e++) {
+        const int x = tid * 4 + e;
+        k[e] = x < cnt_a ? A[a0 + x] : B[b1 - 1 - (x - cnt_a)];
+      }
+    } else {
+      // Both ranges ascending into LDS, one merge-path round. The two ranges are contiguous 24-byte keys: they come in as 6144
+      // consecutive 64-bit words, twelve per thread (a wave's load is 512 contiguous bytes: 8 requests, where a thread fetching
+      // its own four keys is a 96-byte stride between lanes, 64 requests), straight into the three word arrays the merge reads;
+      // the arrays start 22 entries apart modulo the banks, so that the 66 entries a wave writes at once are spread like a copy.
+      uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kRT + 22, *s_lo = s_mid + kRT + 22;
+      const uint64_t *gA = (const uint64_t*)(A + a0), *gB = (const uint64_t*)(B + (b1 - (kRT - cnt_a)));
+      const int wa = 3 * cnt_a;
+      uint64_t v[12];
+#pragma unroll
+      for (int q = 0; q < 12; q++) {
+        const int w = q * kTiledBlock + tid;
+        v[q] = w < wa ? gA[w] : gB[w - wa];
+      }
+#pragma unroll
+      for (int q = 0; q < 12; q++) {
+        const int w = q * kTiledBlock + tid;  // word w of the window's 2048 keys: key w / 3, word w % 3
+        const int x = (int)(((unsigned)w * 43691u) >> 17), c = w - 3 * x;  // exact for w < 98304
+        (c == 0 ? s_hi : c == 1 ? s_mid : s_lo)[x] = v[q];
+      }
       __syncthreads();
       merge_path4_k192<12>(k, s_hi, s_mid, s_lo, 0, cnt_a, cnt_a, kRT - cnt_a, false, tid * 4);
       __syncthreads();  // the arrays are re-used below
