@@ -275,14 +275,23 @@ constexpr uint32_t RM_LIVE = 1u << 30, RM_OWN = 1u << 31;
 // planner.go:451-455), SE_SAT the edge is satisfied (Task.SatisfiesDependency task.go:546-561; a dependency that is neither
 // in the queue nor in the database never is, scheduler.go:180-186).
 constexpr uint32_t SE_SLOT = 0x1FFFFFu, SE_INQ = 1u << 29, SE_SAT = 1u << 30;
-__device__ __forceinline__ uint32_t tiled_edge(const evg_task_soa& t, const DC& c, int e) {
-  const int j = t.dep_idx[e] - c.lo;
-  const uint32_t info = t.dep_info[e];
+// What tiled_edge reads about the dependency: two dependent rounds of loads (the edge, then the dependency's row). The
+// edge-parallel staging loops issue each round for a batch of edges before they use any of it.
+struct EdgeIn { int j; uint32_t info; };
+struct EdgeDep { uint32_t fj; int tgj; };
+__device__ __forceinline__ EdgeIn edge_fetch(const evg_task_soa& t, const DC& c, int e) { return EdgeIn{t.dep_idx[e] - c.lo, (uint32_t)t.dep_info[e]}; }
+__device__ __forceinline__ EdgeDep edge_gather(const evg_task_soa& t, const DC& c, const EdgeIn& in) {
+  const bool inq = (unsigned)in.j < (unsigned)c.n;
+  return EdgeDep{inq ? (uint32_t)t.flags[c.lo + in.j] : 0u, inq ? t.tg_key[c.lo + in.j] : -1};
+}
+__device__ __forceinline__ uint32_t edge_resolve(const evg_task_soa& t, const DC& c, const EdgeIn& in, const EdgeDep& dep) {
+  const int j = in.j;
+  const uint32_t info = in.info;
   uint32_t st, rec = 0;
   bool blk, known = true;
   if ((unsigned)j < (unsigned)c.n) {
-    const uint32_t fj = (uint32_t)t.flags[c.lo + j];
-    const int tgj = t.tg_key[c.lo + j];
+    const uint32_t fj = dep.fj;
+    const int tgj = dep.tgj;
     const int verj = c.gv && tgj < 0 ? t.version_key[c.lo + j] : c.ver_lo;
     st = (fj & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT;
     blk = fj & EVG_TF_BLOCKED;
@@ -295,6 +304,10 @@ __device__ __forceinline__ uint32_t tiled_edge(const evg_task_soa& t, const DC& 
   const uint32_t req = info & EVG_DEP_REQ_MASK;
   const bool sat = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
   return rec | (sat && known ? SE_SAT : 0u);
+}
+__device__ __forceinline__ uint32_t tiled_edge(const evg_task_soa& t, const DC& c, int e) {
+  const EdgeIn in = edge_fetch(t, c, e);
+  return edge_resolve(t, c, in, edge_gather(t, c, in));
 }
 
 __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs a) {
@@ -320,8 +333,27 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
   const int E0 = t.dep_off[lo + tile * kRT], E1 = t.dep_off[lo + i_end];
   TT_BEGIN();
   const bool eL = E1 - E0 <= kTileEdges && !(a.tiled_mode & TM_ROW_SCATTER);
-  if (eL)
-    for (int x = tid; x < E1 - E0; x += kTiledBlock) s_edge[x] = tiled_edge(t, c, E0 + x);
+  if (eL) {
+    // six edges per thread at a time: their index loads together, then the gathers of the dependencies' rows together (edge
+    // after edge the loop was two dependent round trips per trip, ~7 trips: 16.8 us of a workgroup's 51)
+    constexpr int kB = 6;
+    for (int x0 = tid; x0 < E1 - E0; x0 += kB * kTiledBlock) {
+      EdgeIn in[kB];
+      EdgeDep dep[kB];
+#pragma unroll
+      for (int q = 0; q < kB; q++) {
+        const int x = x0 + q * kTiledBlock;
+        in[q] = x < E1 - E0 ? edge_fetch(t, c, E0 + x) : EdgeIn{-1, 0u};
+      }
+#pragma unroll
+      for (int q = 0; q < kB; q++) dep[q] = edge_gather(t, c, in[q]);
+#pragma unroll
+      for (int q = 0; q < kB; q++) {
+        const int x = x0 + q * kTiledBlock;
+        if (x < E1 - E0) s_edge[x] = edge_resolve(t, c, in[q], dep[q]);
+      }
+    }
+  }
   for (int j = tid; j < n_st; j += kTiledBlock) s_cnt[j] = 0;
   if (tid < 8) s_u64[tid] = tid == 0 ? ~0ull : 0ull;
   if (tid < 20) s_u32[tid] = (tid == 0 || tid == 2 || tid == 4) ? ~0u : 0u;
@@ -870,17 +902,21 @@ __device__ __forceinline__ void lds_put4_soa(uint64_t* s_hi, uint64_t* s_mid, ui
 }
 // Sort of a tile's 2048 keys (positions 4 tid .. 4 tid + 3): the network up to sorted runs of 256 (36 of the 66 stages, none
 // through LDS), then three merge-path rounds. smem: 48 KB.
+#ifndef EVG_TILE_SORT_RUN
+#define EVG_TILE_SORT_RUN 256
+#endif
 __device__ __forceinline__ void tile_sort_merge_path(K192 (&k)[4], int tid, unsigned char* smem) {
+  constexpr int R0 = EVG_TILE_SORT_RUN;  // the network sorts runs of R0 keys, merge-path rounds do the rest
   uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kRT, *s_lo = s_mid + kRT;
-  bitonic_sort4_fixed<256, K192>(k, tid, (K192*)smem, (K192*)smem);  // even runs ascending, odd runs descending
+  bitonic_sort4_fixed<R0, K192>(k, tid, (K192*)smem, (K192*)smem);  // even runs ascending, odd runs descending
   const int pos = tid * 4;
 #pragma unroll
-  for (int L = 256; L <= 1024; L <<= 1) {
-    if (L > 256) __syncthreads();  // every thread has merged the previous round's runs out of LDS
+  for (int L = R0; L <= 1024; L <<= 1) {
+    if (L > R0) __syncthreads();  // every thread has merged the previous round's runs out of LDS
     lds_put4_soa(s_hi, s_mid, s_lo, pos, k);
     __syncthreads();
     const int base = pos & ~(2 * L - 1);
-    merge_path4_k192<11>(k, s_hi, s_mid, s_lo, base, L, base + L, L, L == 256, pos - base);
+    merge_path4_k192<11>(k, s_hi, s_mid, s_lo, base, L, base + L, L, L == R0, pos - base);
   }
 }
 
@@ -942,9 +978,27 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
   // (Fetching the four rows' columns ahead of this loop was measured: 85 VGPRs, one workgroup less per CU, slower.)
   uint64_t* s_uk = (uint64_t*)smem;
   if (stage) {
-    for (int x = tid; x < E1 - E0; x += kTiledBlock) {
-      const int sl = a.w_eslot[E0 + x];
-      s_uk[x] = sl >= 0 ? ukey(sl) : ~0ull;
+    constexpr int kB = 6;  // batched like the scatter kernel's staging: slots together, then the units' (value, min row) together
+    for (int x0 = tid; x0 < E1 - E0; x0 += kB * kTiledBlock) {
+      int sl[kB];
+      int64_t v[kB];
+      uint32_t mr[kB];
+#pragma unroll
+      for (int q = 0; q < kB; q++) {
+        const int x = x0 + q * kTiledBlock;
+        sl[q] = x < E1 - E0 ? a.w_eslot[E0 + x] : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < kB; q++) {
+        v[q] = sl[q] >= 0 ? a.w_val[sb + sl[q]] : INT64_MIN;
+        mr[q] = sl[q] >= 0 ? a.w_minrow[sb + sl[q]] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < kB; q++) {
+        const int x = x0 + q * kTiledBlock;
+        if (x < E1 - E0)
+          s_uk[x] = v[q] == INT64_MIN ? ~0ull : (shl64(vmaxu - ub(v[q]), bmr + bsl) | ((uint64_t)mr[q] << bsl) | (uint64_t)sl[q]);
+      }
     }
     __syncthreads();
   }
