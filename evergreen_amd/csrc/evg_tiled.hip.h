@@ -601,6 +601,17 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
   const int64_t T = has_mq ? target_lo(p) : target_hi(p);
   const uint32_t wait_bit = has_mq ? RW_WAIT_LO : RW_WAIT_HI;
   TT_BEGIN();
+  // where this tile's records are (one bucket per source row tile): a chain of dependent loads, issued ahead of the init loop
+  // whose own loads it does not depend on
+  const int n_rt = ts->n_rt;
+  const int2* bucket = (const int2*)a.w_bucket + ts->bucket_base + j;
+  int mine = 0;
+  long long my_base = 0;
+  if (tid < n_rt) {
+    const int2 b = bucket[(long long)tid * ts->n_st];
+    mine = b.y;
+    my_base = rec_region(a, c, tid) + b.x;
+  }
   // ---- init: a stand-alone row's own unit starts with that row (plain stores); everything else empty ----
   for (int u = tid; u < ns; u += kTiledBlock) {
     const int su = s0 + u;
@@ -627,28 +638,30 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     g_dur[u] = 0; g_dover[u] = 0; g_cnt[u] = 0; g_cover[u] = 0; g_wait[u] = 0; g_mq[u] = 0;
   }
   TT_MARK(16);
-  // ---- where this tile's records are: one bucket per source row tile ----
-  const int n_rt = ts->n_rt;
-  const int2* bucket = (const int2*)a.w_bucket + ts->bucket_base + j;
-  int mine = 0;
-  if (tid < n_rt) {
-    const int2 b = bucket[(long long)tid * ts->n_st];
-    mine = b.y;
-    s_base[tid] = rec_region(a, c, tid) + b.x;
-  }
+  if (tid < n_rt) s_base[tid] = my_base;
   if (tid == 0) { s_pref[0] = 0; s_t64[0] = 0; s_t64[1] = 0; s_t64[2] = ~0ull; s_t64[3] = 0; s_t32[0] = 0; s_t32[1] = 0; }
   s_pref[tid + 1] = block_scan_sum(mine, tid, s_w8);
   __syncthreads();
   TT_MARK(17);
   const int total = s_pref[n_rt];
   const TRec* recs = (const TRec*)a.w_rec;
-  for (int x = tid; x < total; x += kTiledBlock) {
+  constexpr int kRB = 3;  // records per thread in flight: their loads are issued together
+  for (int x0 = tid; x0 < total; x0 += kRB * kTiledBlock) {
+   TRec rb[kRB];
+#pragma unroll
+   for (int q = 0; q < kRB; q++) {
+    const int x = x0 + q * kTiledBlock;
     int l = 0, h = n_rt;  // largest src with s_pref[src] <= x
     while (h - l > 1) {
       const int mid = (l + h) >> 1;
       if (s_pref[mid] <= x) l = mid; else h = mid;
     }
-    const TRec r = recs[s_base[l] + (x - s_pref[l])];
+    if (x < total) rb[q] = recs[s_base[l] + (x - s_pref[l])];
+   }
+#pragma unroll
+   for (int q = 0; q < kRB; q++) {
+    if (x0 + q * kTiledBlock >= total) continue;
+    const TRec r = rb[q];
     const int u = (int)(r.w0 & 0x3FFu);
     atomicAdd((unsigned long long*)&m_tiq[u], (unsigned long long)r.tiq);
     atomicAdd((unsigned long long*)&m_dur[u], (unsigned long long)r.dur);
@@ -666,6 +679,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
       if (r.w0 & wait_bit) atomicAdd(&g_wait[u], 1u);
       if (r.w0 & RW_MQ) atomicAdd(&g_mq[u], 1u);
     }
+   }
   }
   __syncthreads();
   TT_MARK(18);
