@@ -1347,7 +1347,7 @@ __device__ __forceinline__ int merge_split(const K192* A, const K192* B, int na,
 __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a, int pass) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_split[2];
-  const int w = blockIdx.x;
+  const int w = blockIdx.x;  // (xcd_tile here measures 22.6 -> 23.9 us per pass: consecutive tiles on consecutive XCDs spread a pair's loads)
   if (w >= a.w_ntile[0]) return;
   const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
   TState* ts = &a.w_ts[d];
