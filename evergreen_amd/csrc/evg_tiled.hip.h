@@ -16,15 +16,15 @@
 //                       source tile are streamed in and applied with LDS atomics; unitInfo.value() per slot
 //   T3 k_tiled_elect    per row tile: each row's emitting unit (TaskPlan.Export's first-occurrence dedup, planner.go:462-481),
 //                       ONE 192-bit key [value desc | unit min row | unit slot | TaskList.Less key | row] per row -- the
-//                       final queue order is the plain ascending order of these keys -- and the tile sorted in LDS
-//   T4 k_tiled_srank    (distros of up to 32 sorted tiles = 65,536 rows) every 32nd key of every sorted tile is a SAMPLE; the
-//      k_tiled_mmerge   exact rank of each sample in the whole distro and its lower bound in every tile (k_tiled_srank), then
-//                       ONE multiway pass: the workgroup of output window [2048 w, 2048 (w + 1)) finds the window's exact
-//                       split of every tile from the samples (the sample of largest rank <= the boundary + at most 33
-//                       candidates per tile, ranked in LDS), loads its <= 32 segments (2048 keys) and ranks every key by
-//                       binary searches over the other segments -- log2(tiles) merge passes and their key traffic are gone
-//      k_tiled_merge    (larger distros) log2(tiles) passes of merge-path: every workgroup produces 2048 consecutive outputs
-//                       of the merge of two sorted runs (wave-wide 64-ary diagonal search, one 11-stage bitonic merge)
+//                       final queue order is the plain ascending order of these keys -- and the tile sorted in LDS: the
+//                       bitonic network up to sorted runs of 256 keys, then three merge-path rounds (merge_path4_k192)
+//   T4 k_tiled_merge    log2(tiles) passes of merge path: every workgroup produces 2048 consecutive outputs of the merge of
+//                       two sorted runs (wave-wide 64-ary diagonal searches in global memory, the window's two key ranges
+//                       staged into LDS as consecutive words, one merge-path round there)
+//      k_tiled_srank    (EVG_TILED_MODE bit 4 only: measured equal, off by default) ONE multiway pass for distros of up to 32
+//      k_tiled_mmerge   tiles: every 32nd key of every sorted tile is a sample with its exact rank in the distro; the workgroup
+//                       of an output window finds the window's split of every tile from the samples + <= 33 candidates per
+//                       tile, loads its <= 32 segments and merges them by rank searches in LDS
 //   T5 (tail of T4)     queue order out; first queue position of every task group (TaskGroupInfo.MaxHosts,
 //                       scheduler.go:103-106) -- the merged keys never go back to memory
 //   T6 k_tiled_rows     model.DistroQueueInfo / the standalone TaskGroupInfo row
@@ -54,8 +54,9 @@ constexpr int kMaxWay = 32;           // sorted tiles one multiway pass merges; 
 constexpr int kSmpStride = 32, kSmpPerTile = kRT / kSmpStride;  // sample = the last key of every 32-key block of a sorted tile
 constexpr int kCandWin = kSmpStride + 1;  // candidates per tile at a window boundary
 constexpr int kTileEdges = 6144;      // dependency edges of one row tile resolved edge-parallel in LDS (more: per row, from memory)
-// PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs): 1, 2 = the per-row forms of round 2; 4 = the one-pass multiway merge instead of the
-// pairwise passes; 8 = the rank-merge tile sort instead of the bitonic network (both measured equal or slower: DESIGN.md 3.1)
+// PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs; every variant is bit-exact, scripts/r03_modes.sh): 1, 2 = the per-row forms of
+// round 2; 4 = the one-pass multiway merge instead of the pairwise passes; 8 = the rank-merge tile sort (both measured equal or
+// slower: DESIGN.md 3.1); 32 = every thread stores its own keys; 64 = the full networks instead of the merge-path rounds
 constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2, TM_MULTIWAY_MERGE = 4, TM_RANK_MERGE_SORT = 8;  // 16: linear tile mapping (xcd_tile)
 
 // blockIdx -> tile, XCD-aware: workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; tile
