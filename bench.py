@@ -239,7 +239,7 @@ def resident_rate(batch, dev, native, resident, torch, steps=10, warmup=2, units
     ctx = native.Context(dev.index or 0)
     pool = resident.ResidentPool(ctx, batch, dev, breakdown=False, n_units=False, units=units)
     for _ in range(warmup):
-        pool.step(fused=False)
+        pool.step()
     torch.cuda.synchronize(dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
@@ -295,7 +295,7 @@ def sharded_workload(make_batch, what, ctx, dev, dist, rank, world, mode, steps,
     returns the object (its parity against the oracle included), the others None."""
     import numpy as np
     batch = make_batch() if rank == 0 else None
-    pool = multi.ShardedPool(ctx, dev, fused=False, mode=mode, breakdown=False)
+    pool = multi.ShardedPool(ctx, dev, mode=mode, breakdown=False)
     pool.setup(multi.pack_pool(batch) if rank == 0 else None)
 
     def barrier():
@@ -372,9 +372,6 @@ def main():
     ap.add_argument("--tasks", type=int, default=0, help="override the task count (parity/debug runs only)")
     ap.add_argument("--distros", type=int, default=0)
     ap.add_argument("--weak", action="store_true", help="round 1's mode: every rank plans its OWN pool, no collective (weak scaling)")
-    ap.add_argument("--one-launch", action="store_true", help="the timed tick runs plan + allocate as ONE launch when the batch allows it "
-                    "(evg_plan_allocate_range_device); by default they are the reference's two jobs = two calls, and the one-launch tick is "
-                    "reported next to it as `one_launch`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / skewed / config5_share / pipelined (profiling runs)")
     ap.add_argument("--no-config5", action="store_true", help="skip BASELINE config 5 at full size (10M tasks: ~90 s of generation and checking)")
@@ -414,7 +411,7 @@ def main():
     batch = gen.generate(cfg) if have_batch else None
     ctx = native.Context(local_rank)
     # One code path for every N: the packed pool buffer + range entry points (a range of all distros at N = 1 / --weak).
-    pool = multi.ShardedPool(ctx, dev, collective=not args.weak, fused=args.one_launch)
+    pool = multi.ShardedPool(ctx, dev, collective=not args.weak)
     pool.setup(multi.pack_pool(batch) if have_batch else None)
 
     def barrier():
@@ -515,13 +512,10 @@ def main():
                        "tasks": lay.N, "distros": lay.D, "dep_edges": lay.E, "task_groups": lay.TG, "hosts": lay.H, "parallelism": par,
                        "rank0_distro_range": [d0, d1]},
             "timed_region": "`steps` ticks of broadcast -> plan + allocate -> gather (the collectives are no-ops at 1 rank), wall clock between "
-                            "barrier + synchronize on both sides, max over ranks. " + (
-                                "Plan + allocate run as ONE launch (evg_plan_allocate_range_device: the allocator is the tail of each distro's planner "
-                                "workgroup, bit-identical to the two calls) because the batch promises EVG_PROMISE_ALL_ON_LDS_PATH; "
-                                if (pool.fused and pool.has_hosts and (pool.inp.promises & 1)) else "Plan and allocate are two calls; ") +
+                            "barrier + synchronize on both sides, max over ranks. Plan and allocate are the reference's two jobs = two calls; "
                             "the HIP-event figures below (phases_ms, roofline) come from further passes that make the two calls separately, with events "
                             "between them (an event record costs microseconds of stream time at these step lengths)",
-            "plan_allocate": "one launch" if (pool.fused and pool.has_hosts and (pool.inp.promises & 1)) else "two calls",
+            "plan_allocate": "two calls",
             "step_ms_hip_events_rank0": {"median": step_ev[0], "min": step_ev[1], "mean": step_ev[2]},
             "phases_ms": {"pool-broadcast": bc_ms[0], "planning-distro": plan_ms[0], "host-allocation": alloc_ms[0], "queue-gather": ga_ms[0],
                           "what": "rank 0, median over the timed steps' HIP events; planning-distro / host-allocation are the reference's phase names "
@@ -535,7 +529,6 @@ def main():
             abytes, e_in = algorithmic_bytes(batch, int(full.n_units[d0:d1].sum()), d0, d1)
             # the dominant kernel alone: HIP events recorded by the library right before / after k_plan_distros on the stream
             # it is launched on (evg_profile_plan_kernel), one plan call at a time, median over the steps
-            one_launch = bool(pool.fused and pool.has_hosts and (pool.inp.promises & 1))
             ctx.profile_plan_kernel(True)
 
             def kernel_events(call):
@@ -545,31 +538,23 @@ def main():
                     ks.append(ctx.last_plan_kernel_ms())
                 ks.sort()
                 return ks
-            kms_plan = kernel_events(pool.plan)            # k_plan_distros: the planner alone
-            kms = kernel_events(pool.plan_allocate) if one_launch else kms_plan  # the kernel of the timed tick
+            kms = kernel_events(pool.plan)                 # k_plan_distros: the dominant kernel of the timed tick
             ctx.profile_plan_kernel(False)
             kernel_ms = kms[len(kms) // 2]
-            planner_bytes = abytes
-            if one_launch:  # planner + the allocator as its tail: SURVEY 8(d) adds 29 B per host for the allocator
-                h0, h1 = int(batch.host_off[d0]), int(batch.host_off[d1])
-                abytes += 29 * (h1 - h0)
             achieved = abytes / (kernel_ms * 1e-3) / 1e9
             traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc) and world == 1:
                 try:
                     j = json.load(open(pmc))
-                    traffic = j.get("k_plan_allocate_hbm_bytes_per_launch" if one_launch else "k_plan_distros_hbm_bytes_per_launch")
+                    traffic = j.get("k_plan_distros_hbm_bytes_per_launch")
                     traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this workload, NOT measured in this run)" % j.get("source", "pmc_latest.json")
                 except Exception:
                     traffic = None
-            line["roofline"] = {"bound": "hbm", "kernel": "k_plan_allocate (the planner with the host allocator as the tail of each workgroup)" if one_launch else "k_plan_distros",
+            line["roofline"] = {"bound": "hbm", "kernel": "k_plan_distros",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                                 "algorithmic_bytes_per_launch": abytes, "kernel_ms": kernel_ms, "kernel_ms_min": kms[0], "kernel_ms_mean": sum(kms) / len(kms),
-                                "planner_alone": {"kernel": "k_plan_distros", "kernel_ms": kms_plan[len(kms_plan) // 2], "algorithmic_bytes_per_launch": planner_bytes,
-                                                  "achieved": planner_bytes / (kms_plan[len(kms_plan) // 2] * 1e-3) / 1e9,
-                                                  "frac": planner_bytes / (kms_plan[len(kms_plan) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                                 "plan_entry_point_ms": plan_ms[0], "allocator_ms": alloc_ms[0],
                                 "kernel_ms_scope": "median HIP-event interval around the dominant kernel of the timed tick alone, events recorded by the library on "
                                                    "the launch stream (evg_profile_plan_kernel), one call at a time; plan_entry_point_ms / allocator_ms = the intervals "
@@ -659,29 +644,31 @@ def main():
                                                             "BASELINE config 5's per-GPU share: 10M tasks x 512 distros over 8 GPUs = 1.25M tasks x 64 "
                                                             "distros of ~19.5k tasks, DAG depth 8, 20% task-group tasks (large-distro path)",
                                                             dev, native, resident, torch, gen, np))
-            def one_launch():
-                # the same tick with plan + allocate as ONE launch (the allocator as the tail of each distro's planner workgroup)
-                if not (pool.has_hosts and (pool.inp.promises & 1)):
-                    return {"skipped": "the batch does not promise EVG_PROMISE_ALL_ON_LDS_PATH"}
-                was = pool.fused
-                pool.fused = True
-                try:
-                    for _ in range(5):
-                        pool.tick()
-                    barrier()
-                    t = time.perf_counter()
-                    for _ in range(args.steps):
-                        pool.tick()
-                    barrier()
-                    dt = (time.perf_counter() - t) / args.steps
-                    r1, a1 = pool.plan_result(), pool.alloc_result()
-                finally:
-                    pool.fused = was
-                same = bool(np.array_equal(r1.order, got.order) and np.array_equal(r1.distro_info, got.distro_info) and np.array_equal(r1.wait_ns, got.wait_ns) and
-                            np.array_equal(a1.new_hosts, got_alloc.new_hosts) and np.array_equal(a1.free_hosts, got_alloc.free_hosts))
-                return {"value": batch.n_tasks / dt, "unit": "tasks/s", "ms_per_step": dt * 1e3, "identical_to_two_calls": same,
-                        "what": "the timed tick with evg_plan_allocate_range_device instead of the two calls (bench.py --one-launch makes it the headline tick)"}
-            guarded("one_launch", one_launch)
+            def cliff():
+                # what a distro just over the 2048-task tier costs a tick that is otherwise all small -- config 3
+                # with 1 / 8 / 64 of its distros grown to 2049, 4096 and 10,000 tasks (2049..4096: the one-per-CU tier,
+                # k_plan_distros_big, beside the small tier's launch; 10,000: the large-distro pipeline), each checked against the oracle
+                from tests import compare
+                base_ms, base_plan, _, _, _ = resident_rate(batch, dev, native, resident, torch, steps=20, warmup=3)
+                out = {"all_small_tick_ms": base_ms, "all_small_plan_ms": base_plan, "cases": [],
+                       "what": "ms per device-resident tick (plan + allocate) of BASELINE config 3 with n_grown distros grown to grown_size tasks, "
+                               "next to the all-small tick; vs_all_small = tick / all-small tick"}
+                for size in (2049, 4096, 10_000):
+                    for k in (1, 8, 64):
+                        b = gen.generate(gen.cliff_config(k, size))
+                        ms, p_ms, a_ms, r, ra = resident_rate(b, dev, native, resident, torch, steps=20, warmup=3)
+                        want, want_alloc, _, _ = oracle_threads(b, os.cpu_count() or 1, reps=1)
+                        want.n_units = None
+                        ok = True
+                        try:
+                            compare.assert_plan_equal(r, want, b, "cliff %d x %d" % (k, size))
+                            compare.assert_alloc_equal(ra, want_alloc, "cliff %d x %d" % (k, size))
+                        except AssertionError as e:
+                            ok = str(e)[:200]
+                        out["cases"].append({"n_grown": k, "grown_size": size, "tasks": b.n_tasks, "ms_per_tick": ms, "planning-distro_ms": p_ms,
+                                             "vs_all_small": ms / base_ms, "parity_vs_oracle": ok})
+                return out
+            guarded("cliff", cliff)
             if args.in_flight > 1:
                 guarded("pipelined", lambda: pipelined_rate(batch, dev, args.in_flight, min(args.steps, 60), native, resident, torch))
         for k, v in extra_objs.items():

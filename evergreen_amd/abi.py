@@ -48,10 +48,11 @@ class TaskSoa(C.Structure):
 class PlanInput(C.Structure):
     _fields_ = [("n_distros", C.c_int32), ("n_task_groups", C.c_int32), ("n_versions", C.c_int32),
                 ("max_distro_tasks", C.c_int32), ("tasks", TaskSoa), ("distros", _p), ("task_off", _p),
-                ("tg_off", _p), ("ver_off", _p), ("now_ns", C.c_int64), ("promises", C.c_int32), ("reserved0", C.c_int32)]
+                ("tg_off", _p), ("ver_off", _p), ("now_ns", C.c_int64), ("promises", C.c_int32), ("n_big_tier_distros", C.c_int32)]
 
 
 EVG_PROMISE_ALL_ON_LDS_PATH = 1
+EVG_PROMISE_ALL_ON_LDS_TIERS = 2
 
 
 class PlanOutput(C.Structure):
@@ -68,7 +69,7 @@ class EdgeUpdate(C.Structure):  # evg_edge_update
     _fields_ = [("n_edges", C.c_int32), ("reserved", C.c_int32), ("edges", _p), ("dep_info", _p), ("dep_finished_ts_ns", _p)]
 
 
-EVG_ABI_MAJOR, EVG_ABI_MINOR = 2, 0
+EVG_ABI_MAJOR, EVG_ABI_MINOR = 3, 0
 
 
 class HostSoa(C.Structure):
@@ -79,7 +80,8 @@ class HostSoa(C.Structure):
 class AllocInput(C.Structure):
     _fields_ = [("n_distros", C.c_int32), ("n_task_groups", C.c_int32), ("params", _p),
                 ("host_off", _p), ("tg_off", _p), ("hosts", HostSoa), ("distro_info", _p),
-                ("group_info", _p), ("now_ns", C.c_int64)]
+                ("group_info", _p), ("now_ns", C.c_int64),
+                ("max_concurrent_large_parser_project_tasks", C.c_int32), ("running_large_parser_project_tasks", C.c_int32)]
 
 
 class QueueItems(C.Structure):
@@ -180,6 +182,9 @@ class PlanBatch:
     hosts: Dict[str, np.ndarray] = field(default_factory=dict)
     # bare Task.TaskGroup name interning for capTaskQueueLength (optional)
     tg_name_key: Optional[np.ndarray] = None
+    # adjustForLargeParserProjectLimit (units/host_allocator.go:479-520): the global limit and the running count; 0 = no limit
+    large_parser_limit: int = 0
+    large_parser_running: int = 0
 
     @property
     def n_tasks(self) -> int:
@@ -359,6 +364,8 @@ def make_alloc_input(batch: PlanBatch, distro_info, group_info, arrays=None) -> 
         setattr(inp.hosts, k, _ptr(batch.hosts[k] if a is None else a["host_" + k]))
     inp.distro_info = _ptr(distro_info)
     inp.group_info = _ptr(group_info)
+    inp.max_concurrent_large_parser_project_tasks = batch.large_parser_limit
+    inp.running_large_parser_project_tasks = batch.large_parser_running
     return inp
 
 

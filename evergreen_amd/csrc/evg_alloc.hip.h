@@ -271,6 +271,15 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
       a.out.new_hosts[d] = 0; a.out.free_hosts[d] = n_free_hosts; a.out.status[d] = s_i[5];
     } else {
       int required = s_i[1];
+      // adjustForLargeParserProjectLimit (units/host_allocator.go:479-520): what the allocator job does to
+      // LengthWithDependenciesMet between reading the queue info and this clamp
+      const int limit = a.in.max_concurrent_large_parser_project_tasks;
+      if (limit > 0) {
+        const int queued = a.in.distro_info[d].num_queued_large_parser_project_tasks;
+        const int room = limit - a.in.running_large_parser_project_tasks;
+        const int blocked = queued - (room > 0 ? room : 0);
+        if (queued != 0 && blocked > 0) len_met -= blocked;
+      }
       if (required + n_free_hosts > len_met) required = len_met - n_free_hosts;  // :113-115
       if (required < 0) required = 0;
       int add_min = 0;

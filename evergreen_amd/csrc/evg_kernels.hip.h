@@ -76,6 +76,7 @@ struct PlanArgs {
   int32_t tiled_mode;            // TM_* bits (EVG_TILED_MODE; 0 = default)
   uint32_t* w_status;            // host-visible status word of the context (evg_take_device_status), or nullptr: set to 1 by a
                                  // planner workgroup that cannot plan its distro although the batch promised it could
+  int32_t big_tier;    // 1: k_plan_distros_big runs beside k_plan_distros and owns w_generic[d] of the tier-12 distros (evg_plan_lds.hip.h)
   int32_t d0, d1;      // the distros this call plans: [d0, d1) of the batch (evg_plan_distro_range_device; else 0, D).
                        // Outputs keep the FULL batch's row / info-row numbering.
 #ifdef EVG_PHASE_TIMING

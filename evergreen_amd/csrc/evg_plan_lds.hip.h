@@ -36,60 +36,78 @@
 namespace evg {
 
 constexpr int kE = 4;                // tasks per thread
-constexpr int kN = kBlock * kE;      // 2048 tasks max on this path
-constexpr int kS = 2304;             // unit slots max (12-bit slot ids); the LDS budget below is the binding limit
 constexpr int kG = 1024;             // task-group rows (incl. the standalone row) max
 
-// ---- LDS map (bytes) ------------------------------------------------------------------------------------
-// The lean configuration is one 79,872-byte block, so that two workgroups fit a CU's 160 KiB whatever the
-// allocation granule:
+// ---- the two tiers of the one-workgroup path -----------------------------------------------------------------------------
+// LG = 11: up to 2048 tasks, 512 threads, one 79,872-byte LDS block -- two workgroups per CU, the headline configuration.
+// LG = 12: up to 4096 tasks, 1024 threads, the CU's whole LDS -- one workgroup per CU; it takes the distros of 2049..4096 tasks,
+//          which otherwise leave the 0.056 ns/task kernel for the eight launches of the large-distro pipeline (evg_tiled.hip.h).
+// Same phases, same code; what differs is the width of a row number (LG bits), of a unit slot id (LG + 1 bits: own units +
+// task groups, or task groups + versions) and the LDS map below. A slot id, the status class and Blocked() fill the 16 bits of a
+// pslot record exactly at LG = 12, and so do [out | satisfied | skip | slot] in an edge record.
+//
+// LDS map (bytes), N = 2^LG rows:
 //   [0, 32*Sp)            region A: unit accumulators (Sp = unit slots rounded up to even), live during B..D:
 //                         tiq i64[Sp] | dur i64[Sp] | maxpri i32[Sp] | cnt u32[Sp] | maxnd i32[Sp] | minrow u32[Sp]
 //   [0, Y_END)            the same bytes re-used after D (sort exchange buffers, in-unit keys, run bookkeeping,
 //                         final positions, task-group accumulators)
-//   [kLdsLean-4096-2*Ep, kLdsLean-4096)  the distro's dependency edge records u16[Ep] (Ep = edges rounded up to 8)
-//   [kLdsLean-4096, kLdsLean)            pslot u16[2048]
-// A distro takes the LDS path when max(32*Sp, Y_END) + 2*Ep + 4096 <= kLdsLean (e.g. 2021 slots with up to 5.5k
-// edges, or 1600 slots with up to 9.2k edges). RICH appends val i64[kS] | hash u64[kS] behind the lean block.
-constexpr int kLdsLean = 79872;
-constexpr int B_PSLOT = kLdsLean - 2 * kN;
-constexpr int R_HASH = kLdsLean, kLdsRich = R_HASH + 8 * kS;
-// region A re-used after D:
-constexpr int X_BUF0 = 0, X_BUF1 = 8 * kN, X_IK = 16 * kN, X_IK_END = X_IK + 8 * kN;  // sort exchange, in-unit keys by task
-constexpr int Y_SIK = 0, Y_SSLOT = 8 * kN, Y_SIDX = Y_SSLOT + 2 * kN;                  // by sorted position
-constexpr int Y_SCAN = Y_SIDX + 2 * kN, Y_REN = Y_SCAN + 2048 + 64;                   // run-start scan (2048 B) + a total per wave, run end by run start
-template <int E> struct ScanWord { typedef int32_t type; };                            // 512 threads x int32
-template <> struct ScanWord<2> { typedef int16_t type; };                              // 1024 threads x int16
-static_assert(Y_REN + 2 * kN <= X_IK, "run bookkeeping must not overlap the in-unit keys by task");
-constexpr int Y_POS = X_IK_END, Y_FIDX = Y_POS + 2 * kN, Y_END = Y_FIDX + 2 * kN;      // final position by task / task by position
-constexpr int Z_G = 0;                                                                 // group accumulators (28 B per row)
-static_assert(Y_SIDX + 2 * kN <= X_IK, "by-position arrays must not overlap the in-unit keys by task");
-static_assert(Z_G + 28 * kG <= X_IK, "group accumulators (28 B per row) end before the parked TaskGroupMaxHosts column");
-static_assert(X_IK + 4 * kN <= Y_POS, "the parked TaskGroupMaxHosts column ends before the final positions");
-static_assert(kLdsLean + 512 <= 80 * 1024, "lean configuration: two workgroups per CU");
-static_assert(kLdsRich + 512 <= 160 * 1024, "rich configuration");
-static_assert(kS < 4096 && kN <= 2048, "slot ids are 12 bits, rows 11 bits");
+//   [LDS-2N-2*Ep, LDS-2N) the distro's dependency edge records u16[Ep] (Ep = edges rounded up to 8)
+//   [LDS-2N, LDS)         pslot u16[N]
+// A distro takes the tier when max(32*Sp, Y_END) + 2*Ep + 2N <= LDS (LG = 11: e.g. 2021 slots with up to 5.5k edges, or 1600
+// slots with up to 9.2k edges). RICH (LG = 11 only) appends val i64[S] | hash u64[S] behind the lean block.
+template <int LG>
+struct Tier {
+  static constexpr int N = 1 << LG;          // rows max
+  static constexpr int BLK = N / kE;         // threads
+  static constexpr int SB = LG + 1;          // bits of a unit slot id
+  static constexpr int S = LG == 11 ? 2304 : 4864;  // unit slots max; the LDS budget below is the binding limit
+  static constexpr int LDS = LG == 11 ? 79872 : 160 * 1024 - 512;
+  static constexpr int B_PSLOT = LDS - 2 * N;
+  static constexpr int R_HASH = LDS, LDS_RICH = R_HASH + 8 * S;
+  // region A re-used after D:
+  static constexpr int X_BUF0 = 0, X_BUF1 = 8 * N, X_IK = 16 * N, X_IK_END = X_IK + 8 * N;  // sort exchange, in-unit keys by task
+  static constexpr int Y_SIK = 0, Y_SSLOT = 8 * N, Y_SIDX = Y_SSLOT + 2 * N;                  // by sorted position
+  static constexpr int Y_SCAN = Y_SIDX + 2 * N, Y_REN = Y_SCAN + 2048 + 64;  // run-start scan (2048 B) + a total per wave, run end by run start
+  static constexpr int Y_POS = X_IK_END, Y_FIDX = Y_POS + 2 * N, Y_END = Y_FIDX + 2 * N;      // final position by task / task by position
+  static constexpr int Z_G = 0;                                                                 // group accumulators (28 B per row)
+  // pslot record: bits [0, SB) unit slot, SB..SB+1 status class (EVG_TF_STATUS), SB+2 Blocked()
+  static constexpr uint32_t PS_SLOT = (1u << SB) - 1u;
+  static_assert(Y_REN + 2 * N <= X_IK, "run bookkeeping must not overlap the in-unit keys by task");
+  static_assert(Y_SIDX + 2 * N <= X_IK, "by-position arrays must not overlap the in-unit keys by task");
+  static_assert(Z_G + 28 * kG <= X_IK, "group accumulators (28 B per row) end before the parked TaskGroupMaxHosts column");
+  static_assert(X_IK + 4 * N <= Y_POS, "the parked TaskGroupMaxHosts column ends before the final positions");
+  static_assert(LDS + 512 <= (LG == 11 ? 80 : 160) * 1024, "LG = 11: two workgroups per CU; LG = 12: one");
+  static_assert(LG != 11 || LDS_RICH + 512 <= 160 * 1024, "rich configuration");
+  static_assert(S < (1 << SB) && SB + 3 <= 16, "a pslot record is 16 bits");
+  static_assert(Y_END + 2 * N <= LDS, "re-use area + pslot fit");
+  static_assert(BLK <= 1024 && (BLK == 512 ? 4 : 2) * BLK == 2048, "scan words: 512 x int32 or 1024 x int16");
+};
+constexpr int kN = Tier<11>::N;           // 2048 tasks max on the two-per-CU tier
+constexpr int kNBig = Tier<12>::N;        // 4096 on the one-per-CU tier
+constexpr int kLdsLean = Tier<11>::LDS, kLdsRich = Tier<11>::LDS_RICH, kLdsBig = Tier<12>::LDS;
+template <int BLK> struct ScanWord { typedef int32_t type; };   // 512 threads x int32
+template <> struct ScanWord<1024> { typedef int16_t type; };    // 1024 threads x int16 (positions -1..4095)
 __host__ __device__ __forceinline__ int lds_pad_slots(int S) { return (S + 1) & ~1; }
 __host__ __device__ __forceinline__ int lds_pad_edges(int ne) { return (ne + 7) & ~7; }
+template <int LG>
 __host__ __device__ __forceinline__ bool lds_budget_ok(int S, int ne) {
   const int a = 32 * lds_pad_slots(S);
-  return (a > Y_END ? a : Y_END) + 2 * lds_pad_edges(ne) <= B_PSLOT;
+  return (a > Tier<LG>::Y_END ? a : Tier<LG>::Y_END) + 2 * lds_pad_edges(ne) <= Tier<LG>::B_PSLOT;
 }
 
-// pslot record: bits 0-11 unit slot, 12-13 status class (EVG_TF_STATUS), 14 Blocked()
-constexpr uint32_t PS_SLOT = 0x0FFFu;
-// edge record as staged (phase A):  in queue  : bit15 = 0, bits 11-12 required status, bits 0-10 local row of the dependency
+// edge record as staged (phase A):  in queue  : bit15 = 0, bits LG..LG+1 required status, bits [0, LG) local row of the dependency
 //                                   otherwise : bit15 = 1, bits 0-5 = dep_info (required status, fetched state, blocked, missing)
 // edge record as resolved (phase B, by the thread that owns the depending row):
 //   ED_OUT  the dependency is not in this distro's queue
 //   ER_SAT  the edge is satisfied (Task.SatisfiesDependency, task.go:546-561)
 //   ER_SKIP in queue, but adds no unit membership: the dependency's unit is the row's own primary / version unit
 //           or was already named by an earlier edge of the same row (Unit.Add is keyed by task id, planner.go:131)
-//   bits 0-11: unit slot of the dependency (in queue)
-constexpr uint32_t ED_OUT = 0x8000u, ER_SAT = 0x4000u, ER_SKIP = 0x2000u, ER_SLOT = 0x0FFFu;
+//   bits [0, SB): unit slot of the dependency (in queue)
+constexpr uint32_t ED_OUT = 0x8000u, ER_SAT = 0x4000u, ER_SKIP = 0x2000u;
 
+template <int LG>
 __device__ __forceinline__ uint32_t pack_edge(int j, int n, uint32_t info) {
-  return (unsigned)j < (unsigned)n ? ((info & EVG_DEP_REQ_MASK) << 11) | (uint32_t)j : ED_OUT | (info & 0x3Fu);
+  return (unsigned)j < (unsigned)n ? ((info & EVG_DEP_REQ_MASK) << LG) | (uint32_t)j : ED_OUT | (info & 0x3Fu);
 }
 
 // ---- E-wide column loads (E = tasks per thread: 4 or 2): one 16 B access per lane for a 32-bit column of 4 rows ---------
@@ -137,12 +155,12 @@ struct LdsView {
 // a task-group task and versions are grouped (:439; -1 otherwise), and the unit of each direct dependency that is in
 // this distro's queue (:451-455) -- each distinct slot once. [x0, x1) = the row's RESOLVED edge records.
 template <class F>
-__device__ __forceinline__ void for_units(const uint16_t* edge, int t0, int t1, int x0, int x1, F f) {
+__device__ __forceinline__ void for_units(const uint16_t* edge, uint32_t slot_mask, int t0, int t1, int x0, int x1, F f) {
   f(t0);
   if (t1 >= 0) f(t1);
   for (int x = x0; x < x1; x++) {
     const uint32_t er = edge[x];
-    if (!(er & (ED_OUT | ER_SKIP))) f((int)(er & ER_SLOT));
+    if (!(er & (ED_OUT | ER_SKIP))) f((int)(er & slot_mask));
   }
 }
 __device__ __forceinline__ bool dep_satisfied(uint32_t req, uint32_t st, bool blk) {  // task.go:546-561
@@ -207,22 +225,29 @@ __device__ __forceinline__ DC distro_context(const PlanArgs& a, int d) {
 }
 // The structural part of "the LDS path can take this distro" (the other part is data: every |priority| below 2^31). Also
 // evaluated on the HOST by evg_plan_launch_hints (EVG_PROMISE_ALL_ON_LDS_PATH): one definition for both.
+template <int LG = 11>
 __host__ __device__ __forceinline__ bool fits_lds_shape(int n, int S, int ntg, int ne) {
-  return n <= kN && S <= kS && ntg + 1 <= kG && ne >= 0 && lds_budget_ok(S, ne);
+  return n <= Tier<LG>::N && S <= Tier<LG>::S && ntg + 1 <= kG && ne >= 0 && lds_budget_ok<LG>(S, ne);
 }
-__device__ __forceinline__ bool fits_lds_path(const DC& c) { return fits_lds_shape(c.n, c.S, c.ntg, c.ne); }
+// Which tier plans a distro of this shape: 11, 12, or 0 (neither: the large-distro pipeline / the generic kernel). The small
+// tier takes whatever it can; the big tier only what the small one cannot. Shared by the kernels and the host (launch hints).
+__host__ __device__ __forceinline__ int lds_tier_of_shape(int n, int S, int ntg, int ne) {
+  return fits_lds_shape<11>(n, S, ntg, ne) ? 11 : fits_lds_shape<12>(n, S, ntg, ne) ? 12 : 0;
+}
 
 // The LDS path. Returns false (uniformly, before writing any output) when the distro must take the generic path.
 // s_red: 32 zeroed words of static LDS.
-// FUSED: the distro's UtilizationBasedHostAllocator pass (q) runs as the tail of the same workgroup: its host rows are
-// fetched before the sort, so their latency hides behind the planner's compute, and the queue info it consumes never
-// leaves the CU.
-template <bool RICH, bool FUSED, bool BD, int E = kE>
-__device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocArgs& q, const int d, const int lo, const int n,
-                                                unsigned char* smem, unsigned* s_red) {
+template <bool RICH, bool BD, int LG>
+__device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const int d, const int lo, const int n, unsigned char* smem, unsigned* s_red) {
+  typedef Tier<LG> TR;
+  constexpr int E = kE;
+  constexpr int BLK = TR::BLK;          // threads of the workgroup: E tasks each
+  constexpr uint32_t RMASK = TR::N - 1;  // a local row number
+  constexpr uint32_t PS_SLOT = TR::PS_SLOT, ER_SLOT = TR::PS_SLOT;
+  constexpr int SB = TR::SB;
+  static_assert(!RICH || LG == 11, "TaskPlan.Len() is computed on the small tier only");
   const evg_task_soa& t = a.in.tasks;
   const int tid = threadIdx.x, lane = tid & 63;
-  constexpr int BLK = kN / E;  // threads of the workgroup: E tasks each
   const int i0 = tid * E;
 
   EVG_PRIO(0);
@@ -244,7 +269,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   loadv(t.task_group_order + lo, i0, n, (int32_t)0, tgo);
   loadv(t.dep_off + lo, i0, n, (int32_t)0, o4);
   const DC c = distro_context(a, d, lo, n);
-  if (!fits_lds_path(c)) return false;  // uniform; nothing has been written
+  if (!fits_lds_shape<LG>(c.n, c.S, c.ntg, c.ne)) return false;  // uniform; nothing has been written
   const int S = c.S;
 
   LdsView m;
@@ -252,7 +277,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     const int Sp = lds_pad_slots(S);
     m.tiq = (int64_t*)smem; m.dur = m.tiq + Sp; m.maxpri = (int32_t*)(m.dur + Sp);
     m.cnt = (uint32_t*)(m.maxpri + Sp); m.maxnd = (int32_t*)(m.cnt + Sp); m.minrow = (uint32_t*)(m.maxnd + Sp);
-    m.pslot = (uint16_t*)(smem + B_PSLOT); m.edge = m.pslot - lds_pad_edges(c.ne);
+    m.pslot = (uint16_t*)(smem + TR::B_PSLOT); m.edge = m.pslot - lds_pad_edges(c.ne);
   }
   m.val = m.tiq;  // TotalValue overwrites the unit's TimeInQueue sum
   // s_red words: 0 any met merge-queue task, 4 secondary, 5 t_cover, 6 t_wait, 7 n_units, 14-15 n_met | n_mq << 16 | n_s3 << 32,
@@ -266,29 +291,6 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
 #pragma unroll
     for (int e = 0; e < E; e++) doff[e] = i0 + e < n ? o4[e] - c.eb : last;
     doff[E] = last;
-  }
-  // FUSED: the distro's host rows are fetched with the task columns, reduced to what does not depend on the target
-  // time ({time left, bucket key, flags}) and parked in the LDS bytes between the unit accumulators / re-use area and
-  // the edge records, where nothing else ever lives: their latency is paid together with phase A's and no register is
-  // held for them. Too many hosts for that gap: they are fetched in the tail instead.
-  int fh0 = 0, fnh = 0;
-  bool fpre = false;
-  evg_alloc_params ap{};
-  struct HostPre { int64_t left; int32_t key; uint32_t flags; };  // flags: EVG_HF_* | bit 8 counted | bit 9 overrun
-  const int park_off = 32 * lds_pad_slots(S) > Y_END ? 32 * lds_pad_slots(S) : Y_END;
-  HostPre* hpre = (HostPre*)(smem + park_off);
-  if (FUSED) {
-    ap = q.in.params[d];
-    fh0 = q.in.host_off[d];
-    fnh = q.in.host_off[d + 1] - fh0;
-    fpre = park_off + 16 * fnh <= (int)((unsigned char*)m.edge - smem);
-    if (fpre)
-      for (int i = tid; i < fnh; i += BLK) {
-        const uint32_t f = q.in.hosts.flags[fh0 + i];
-        const HostLeft hl = host_left(c.now, f, q.in.hosts.start_ts_ns[fh0 + i], q.in.hosts.expected_duration_ns[fh0 + i],
-                                      q.in.hosts.duration_stddev_ns[fh0 + i]);
-        hpre[i] = HostPre{hl.left, q.in.hosts.tg_key[fh0 + i], f | (hl.counted ? 0x100u : 0u) | (hl.overrun ? 0x200u : 0u)};
-      }
   }
   bool wide_pri = false;
 #pragma unroll
@@ -313,7 +315,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     ps[e] = tgk[e] >= 0 ? c.tg_base + (tgk[e] - c.tg_lo) : c.gv ? c.ver_base + (verk[e] - c.ver_lo) : i;
     if (i < n) {
       const uint32_t f = fl[e];
-      m.pslot[i] = (uint16_t)(ps[e] | (((f & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT) << 12) | ((f & EVG_TF_BLOCKED) ? 0x4000u : 0u));
+      m.pslot[i] = (uint16_t)(ps[e] | (((f & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT) << SB) | ((f & EVG_TF_BLOCKED) ? 4u << SB : 0u));
       if (!c.gv) {
         // slot i is the unit keyed by task i's own id: only row i is ever its PRIMARY member, so the owner
         // initialises it with plain stores (empty when i is a task-group task) and phase B only adds dependents
@@ -327,7 +329,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       }
     }
   }
-  for (int x = tid; x < c.ne; x += BLK) m.edge[x] = (uint16_t)pack_edge(t.dep_idx[c.eb + x] - lo, n, t.dep_info[c.eb + x]);
+  for (int x = tid; x < c.ne; x += BLK) m.edge[x] = (uint16_t)pack_edge<LG>(t.dep_idx[c.eb + x] - lo, n, t.dep_info[c.eb + x]);
   for (int u = (c.gv ? 0 : n) + tid; u < S; u += BLK) {
     m.tiq[u] = 0; m.dur[u] = 0; m.maxpri[u] = 0; m.cnt[u] = 0; m.maxnd[u] = 0; m.minrow[u] = 0xFFFFFFFFu;
   }
@@ -367,16 +369,16 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       // branch-free: an out-of-queue edge reads pslot[0] and ignores it
       const uint32_t raw = m.edge[x];
       const bool out = (raw & ED_OUT) != 0;
-      const uint32_t pj = m.pslot[out ? 0u : raw & 0x7FFu];
+      const uint32_t pj = m.pslot[out ? 0u : raw & RMASK];
       const int sl = (int)(pj & PS_SLOT);
       // table index  req | status << 2 | blocked << 4: an out-of-queue record carries exactly these five bits at the bottom
-      // (EVG_DEP_*), an in-queue one has req at bit 11 and takes status / blocked from bits 12-14 of the dependency's pslot
+      // (EVG_DEP_*), an in-queue one has req at bit LG and takes status / blocked from bits SB..SB+2 of the dependency's pslot
       static_assert(EVG_DEP_REQ_MASK == 3u && EVG_DEP_STATE_MASK == 0xCu && EVG_DEP_BLOCKED == 0x10u, "edge byte layout");
-      const uint32_t tix = out ? raw & 0x1Fu : ((raw >> 11) & 3u) | ((pj >> 10) & 0x1Cu);
+      const uint32_t tix = out ? raw & 0x1Fu : ((raw >> LG) & 3u) | ((pj >> (SB - 2)) & 0x1Cu);
       const bool sat = ((kDepSatTable >> tix) & 1u) != 0 && !(out && (raw & EVG_DEP_MISSING));
       bool skip = out || sl == t0 || sl == t1;
       // already named by an earlier edge of this row? The last four in-queue edges ride in a register (16 bits each,
-      // 0xFFFF = none; a slot is 12 bits); only a row with more than four dependencies re-reads its older records.
+      // 0xFFFF = none; a slot is at most 13 bits); only a row with more than four dependencies re-reads its older records.
       const uint32_t s16 = (uint32_t)sl;
       skip |= (uint32_t)(recent & 0xFFFFu) == s16 || (uint32_t)((recent >> 16) & 0xFFFFu) == s16 ||
               (uint32_t)((recent >> 32) & 0xFFFFu) == s16 || (uint32_t)(recent >> 48) == s16;
@@ -436,7 +438,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // identity is a hash too (sha1 of the sorted ids, :154-172). Set-equal units share their min member, so a
   // unit's duplicates are among the units of that one task.
   if (RICH && a.out.n_units) {
-    uint64_t* hash = (uint64_t*)(smem + R_HASH);
+    uint64_t* hash = (uint64_t*)(smem + TR::R_HASH);
     for (int u = tid; u < S; u += BLK) hash[u] = 0;
     __syncthreads();
 #pragma unroll
@@ -444,7 +446,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       const int i = i0 + e;
       if (i >= n) continue;
       const uint64_t h = mix64((uint64_t)i);
-      for_units(m.edge, ps[e], tv[e], doff[e], doff[e + 1], [&](int u) { atomicAdd((unsigned long long*)&hash[u], (unsigned long long)h); });
+      for_units(m.edge, ER_SLOT, ps[e], tv[e], doff[e], doff[e + 1], [&](int u) { atomicAdd((unsigned long long*)&hash[u], (unsigned long long)h); });
     }
     __syncthreads();
     uint32_t mine = 0;
@@ -458,7 +460,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       const uint64_t hu = hash[u];
       const uint32_t cu = m.cnt[u] & UF_COUNT_MASK;
       const int tv_i = c.gv && tg_i >= 0 ? c.ver_base + (t.version_key[r] - c.ver_lo) : -1;
-      for_units(m.edge, m.pslot[i] & PS_SLOT, tv_i, x0, x1, [&](int w) {
+      for_units(m.edge, ER_SLOT, m.pslot[i] & PS_SLOT, tv_i, x0, x1, [&](int w) {
         if (w < u && m.val[w] != INT64_MIN && hash[w] == hu && (m.cnt[w] & UF_COUNT_MASK) == cu && m.minrow[w] == (uint32_t)i)
           dup = true;
       });
@@ -542,7 +544,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   const int bt = n ? bits_of((uint64_t)(s_r32[1] - s_r32[0])) : 0, bn = n ? bits_of((uint64_t)(s_r32[3] - s_r32[2])) : 0,
             bp = n ? bits_of((uint64_t)(s_r32[5] - s_r32[E])) : 0, bd = n ? bits_of(s_rng[3] - s_rng[2]) : 0;
   const bool ik_ok = bt + bn + bp + bd <= 64;
-  uint64_t* xik = (uint64_t*)(smem + X_IK);
+  uint64_t* xik = (uint64_t*)(smem + TR::X_IK);
   if (ik_ok) {
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -552,36 +554,32 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
                shl64((uint64_t)(pmax - ub((int32_t)pri[e])), bd) | (dmax - ub(dur[e]));
     }
   }
-  uint32_t srt[E];  // after the sort: (unit slot << 11) | local row at sorted position i0+e
-  if (vb + 34 <= 64) {
+  uint32_t srt[E];  // after the sort: (unit slot << LG) | local row at sorted position i0+e
+  constexpr int TB = 2 * LG + SB;  // tie-break bits of a sort key: [unit min row : LG][unit slot : SB][row : LG]
+  constexpr uint32_t SRT_MASK = (1u << (LG + SB)) - 1u;
+  if (vb + TB <= 64) {
     uint64_t k[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const int i = i0 + e;
-      k[e] = i < n ? ((vmax - ub(bv[e])) << 34) | ((uint64_t)bm[e] << 23) | ((uint64_t)bs[e] << 11) | (uint64_t)i : ~0ull;
+      k[e] = i < n ? ((vmax - ub(bv[e])) << TB) | ((uint64_t)bm[e] << (LG + SB)) | ((uint64_t)bs[e] << LG) | (uint64_t)i : ~0ull;
     }
     EVG_STAMP(6); EVG_STOP(6);
-    if constexpr (E == 4) {
-      if (P == 2048) bitonic_sort4_fixed<2048, uint64_t, 11>(k, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
-      else bitonic_sort4<uint64_t>(k, P, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
-    } else {
-      if (P == 2048) bitonic_sort2_fixed<2048, uint64_t, 11>(k, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
-      else bitonic_sort2<uint64_t>(k, P, tid, (uint64_t*)(smem + X_BUF0), (uint64_t*)(smem + X_BUF1));
-    }
+    if (P == TR::N) bitonic_sort4_fixed<TR::N, uint64_t, 11>(k, tid, (uint64_t*)(smem + TR::X_BUF0), (uint64_t*)(smem + TR::X_BUF1));
+    else bitonic_sort4<uint64_t>(k, P, tid, (uint64_t*)(smem + TR::X_BUF0), (uint64_t*)(smem + TR::X_BUF1));
 #pragma unroll
-    for (int e = 0; e < E; e++) srt[e] = (uint32_t)k[e] & 0x7FFFFFu;
+    for (int e = 0; e < E; e++) srt[e] = (uint32_t)k[e] & SRT_MASK;
   } else {
     K128 k[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
       const int i = i0 + e;
-      k[e] = i < n ? K128{vmax - ub(bv[e]), ((uint64_t)bm[e] << 23) | ((uint64_t)bs[e] << 11) | (uint64_t)i} : K128{~0ull, ~0ull};
+      k[e] = i < n ? K128{vmax - ub(bv[e]), ((uint64_t)bm[e] << (LG + SB)) | ((uint64_t)bs[e] << LG) | (uint64_t)i} : K128{~0ull, ~0ull};
     }
     EVG_STAMP(6); EVG_STOP(6);
-    if constexpr (E == 4) bitonic_sort4<K128>(k, P, tid, (K128*)(smem + X_BUF0), (K128*)(smem + X_BUF0));
-    else bitonic_sort2<K128>(k, P, tid, (K128*)(smem + X_BUF0), (K128*)(smem + X_BUF0));
+    bitonic_sort4<K128>(k, P, tid, (K128*)(smem + TR::X_BUF0), (K128*)(smem + TR::X_BUF0));
 #pragma unroll
-    for (int e = 0; e < E; e++) srt[e] = (uint32_t)k[e].lo & 0x7FFFFFu;
+    for (int e = 0; e < E; e++) srt[e] = (uint32_t)k[e].lo & SRT_MASK;
   }
   EVG_STAMP(7); EVG_STOP(7);
   EVG_PRIO(15);
@@ -591,24 +589,24 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // After the sort the tasks emitted from one unit are contiguous ("runs"), in row order. Run bounds come from a
   // max-scan of the run-start positions; the place of a task inside its run is the number of run members that
   // precede it under TaskList.Less (ties: row order, which is position order inside the run).
-  uint64_t* sik = (uint64_t*)(smem + Y_SIK);
-  uint16_t* sslot = (uint16_t*)(smem + Y_SSLOT);
-  uint16_t* sidx = (uint16_t*)(smem + Y_SIDX);
-  typedef typename ScanWord<E>::type scan_t;  // positions -1..2047: 2048 bytes of scan words whatever E is
-  scan_t* scan = (scan_t*)(smem + Y_SCAN);
-  uint32_t* wtot = (uint32_t*)(smem + Y_SCAN + 2048);  // one packed item total per wave
-  uint16_t* ren = (uint16_t*)(smem + Y_REN);
-  uint16_t* pos = (uint16_t*)(smem + Y_POS);
-  uint16_t* fidx = (uint16_t*)(smem + Y_FIDX);
+  uint64_t* sik = (uint64_t*)(smem + TR::Y_SIK);
+  uint16_t* sslot = (uint16_t*)(smem + TR::Y_SSLOT);
+  uint16_t* sidx = (uint16_t*)(smem + TR::Y_SIDX);
+  typedef typename ScanWord<BLK>::type scan_t;  // positions -1..N-1: 2048 bytes of scan words in both tiers
+  scan_t* scan = (scan_t*)(smem + TR::Y_SCAN);
+  uint32_t* wtot = (uint32_t*)(smem + TR::Y_SCAN + 2048);  // one packed item total per wave
+  uint16_t* ren = (uint16_t*)(smem + TR::Y_REN);
+  uint16_t* pos = (uint16_t*)(smem + TR::Y_POS);
+  uint16_t* fidx = (uint16_t*)(smem + TR::Y_FIDX);
   uint64_t myik[E];
 #pragma unroll
   for (int e = 0; e < E; e++) {
     const int q = i0 + e;
     myik[e] = 0;
     if (q >= n) continue;
-    sslot[q] = (uint16_t)(srt[e] >> 11);
-    sidx[q] = (uint16_t)(srt[e] & 0x7FFu);
-    if (ik_ok) { myik[e] = xik[srt[e] & 0x7FFu]; sik[q] = myik[e]; }
+    sslot[q] = (uint16_t)(srt[e] >> LG);
+    sidx[q] = (uint16_t)(srt[e] & RMASK);
+    if (ik_ok) { myik[e] = xik[srt[e] & RMASK]; sik[q] = myik[e]; }
   }
   __syncthreads();
   // run starts: position q starts a run when the slot changes
@@ -618,8 +616,8 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
 #pragma unroll
   for (int e = 0; e < E; e++) {
     const int q = i0 + e;
-    const uint32_t prev = e ? srt[e - 1] >> 11 : (q > 0 && q <= n ? (uint32_t)sslot[q - 1] : 0xFFFFu);
-    brk[e] = q < n && (q == 0 || prev != (srt[e] >> 11));
+    const uint32_t prev = e ? srt[e - 1] >> LG : (q > 0 && q <= n ? (uint32_t)sslot[q - 1] : 0xFFFFu);
+    brk[e] = q < n && (q == 0 || prev != (srt[e] >> LG));
     if (brk[e]) lb = q;
   }
   {  // inclusive max-scan over the wave, then over the 8 waves through LDS
@@ -696,7 +694,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   constexpr int kMaxItems = 2 * BLK;
   const bool chunked = ik_ok && bt + bn + bp + bd <= 63 && n_items <= kMaxItems;
   if (chunked) {
-    uint16_t* itq = (uint16_t*)(smem + X_IK);       // item -> its first position; the in-unit keys by task are dead
+    uint16_t* itq = (uint16_t*)(smem + TR::X_IK);       // item -> its first position; the in-unit keys by task are dead
     uint16_t* its = itq + kMaxItems;                // item -> start of its run
     {
       int kl = (int)(item_excl & 0xFFFFu), ks = n_long + (int)(item_excl >> 16);
@@ -815,7 +813,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     } else {  // value ranges too wide to compress into 64 bits: compare the columns themselves
 #pragma unroll
       for (int e = 0; e < E; e++) {
-        const int q = i0 + e, r = lo + (int)(srt[e] & 0x7FFu);
+        const int q = i0 + e, r = lo + (int)(srt[e] & RMASK);
         for (int q2 = st[e]; q2 < en[e]; q2++) {
           const int cmp = inunit_cmp(t, lo + sidx[q2], r);
           rank[e] += cmp < 0 || (cmp == 0 && q2 < q) ? 1 : 0;
@@ -829,7 +827,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
       const int q = i0 + e;
       if (q >= n) continue;
       const int fin = st[e] + rank[e];
-      const int i = (int)(srt[e] & 0x7FFu);
+      const int i = (int)(srt[e] & RMASK);
       pos[i] = (uint16_t)fin;
       fidx[fin] = (uint16_t)i;
     }
@@ -848,9 +846,9 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // ---- G: GetDistroQueueInfo (scheduler.go:57-178) -----------------------------------------------------------
   EVG_OPAQUE_ZERO(late3);
   // Per task-group row: two 64-bit sums, the four counters packed into ONE 64-bit word (count | over threshold << 16 |
-  // waited over threshold << 32 | met merge-queue tasks << 48: a distro on this path has at most 2048 tasks, so no field
+  // waited over threshold << 32 | met merge-queue tasks << 48: a distro on this path has at most 4096 tasks, so no field
   // carries into the next), the first queue position. A task-group task costs four unconditional LDS atomics.
-  uint64_t* g_dur = (uint64_t*)(smem + Z_G);
+  uint64_t* g_dur = (uint64_t*)(smem + TR::Z_G);
   uint64_t* g_dover = g_dur + kG;
   uint64_t* g_pk = g_dover + kG;
   uint32_t* g_first = (uint32_t*)(g_pk + kG);
@@ -859,7 +857,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
   // at the very end -- a gather by row there is a global round trip nothing can hide. Fetched now (coalesced), parked in LDS.
   int32_t mh4[E];
   loadv(EVG_LATE_ARG(const int32_t*, in.tasks.task_group_max_hosts, late3) + lo, i0, n, (int32_t)0, mh4);
-  int32_t* mh_lds = (int32_t*)(smem + X_IK);  // the in-unit keys by task (and phase F's item tables) are dead
+  int32_t* mh_lds = (int32_t*)(smem + TR::X_IK);  // the in-unit keys by task (and phase F's item tables) are dead
   // pass A: checkDependenciesMet per task; does any met merge-queue task exist?
   const bool incl = p.includes_dependencies != 0;
   bool met[E];
@@ -1012,48 +1010,22 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const AllocAr
     EVG_LATE_ARG(evg_distro_info*, out.distro_info, late3)[d] = di;
   }
   EVG_STAMP(11); EVG_STOP(11);
-  if (FUSED) {
-    // ---- H: UtilizationBasedHostAllocator for this distro (evg_alloc.hip.h) ----------------------------------
-    const int len_met = (int)(*(unsigned long long*)&s_red[14] & 0xFFFFu);
-    __syncthreads();  // group rows are in global memory (same CU: visible after the barrier); region A and s_red are free
-    const int lds_room = (int)((unsigned char*)m.edge - smem);
-    const int nb = c.ntg + 1;
-    HostStage hs;
-    hs.n_hosts = (int*)smem;  // the group accumulators are dead
-    hs.n_free = hs.n_hosts + nb;
-    hs.rec = fpre ? (HostRec*)hpre : (HostRec*)(hs.n_free + nb + (nb & 1));
-    hs.staged = fpre || 8 * (nb + 1) + 16 * fnh <= lds_room;
-    int* s_i = (int*)s_red;
-    if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
-    if (hs.staged)
-      for (int b = tid; b < nb; b += BLK) { hs.n_hosts[b] = 0; hs.n_free[b] = 0; }
-    __syncthreads();
-    uint32_t nfree = 0;
-    for (int i = tid; i < fnh; i += BLK) {
-      uint32_t f;
-      int32_t key;
-      HostLeft hl;
-      if (fpre) {  // parked before the sort; the record is converted in place (same 16 bytes)
-        const HostPre hp = hpre[i];
-        f = hp.flags & 0xFFu; key = hp.key;
-        hl = HostLeft{hp.left, (hp.flags & 0x100u) != 0, (hp.flags & 0x200u) != 0};
-      } else {
-        f = q.in.hosts.flags[fh0 + i];
-        key = q.in.hosts.tg_key[fh0 + i];
-        hl = host_left(c.now, f, q.in.hosts.start_ts_ns[fh0 + i], q.in.hosts.expected_duration_ns[fh0 + i], q.in.hosts.duration_stddev_ns[fh0 + i]);
-      }
-      nfree += (f & EVG_HF_FREE) ? 1u : 0u;
-      stage_host(hs, q, fh0, i, f, key, host_term(ap.future_host_fraction, T, hl), c.tg_lo, c.ntg);
-    }
-    __syncthreads();
-    allocate_distro<BLK>(q, d, ap, fh0, fnh, c.tg_lo, c.ntg, T, len_met, nfree, hs, s_i);
-    EVG_STAMP(12);
-  }
   return true;
 }
 
-// One workgroup per distro: the LDS path. Distros it cannot take are flagged in a.w_generic[d] and left to
-// k_plan_generic, which is enqueued right behind this kernel.
+// The tier that plans distro d, from the offset tables alone (a handful of scalar loads): 11, 12 or 0.
+__device__ __forceinline__ int lds_tier_of(const PlanArgs& a, int d) {
+  const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo;
+  if (n > kNBig) return 0;
+  const int ntg = a.in.tg_off[d + 1] - a.in.tg_off[d], nver = a.in.ver_off[d + 1] - a.in.ver_off[d];
+  const int S = a.in.distros[d].group_versions != 0 ? ntg + nver : n + ntg;
+  const int ne = a.in.tasks.dep_off[lo + n] - a.in.tasks.dep_off[lo];
+  return lds_tier_of_shape(n, S, ntg, ne);
+}
+
+// One workgroup per distro: the two-per-CU tier. Distros it cannot take are flagged in a.w_generic[d] and left to the
+// large-distro pipeline / k_plan_generic, which are enqueued behind this kernel -- except those of the one-per-CU tier when
+// k_plan_distros_big runs beside this launch (a.big_tier): that kernel then owns their flag.
 template <bool RICH, bool BD>
 __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1077,76 +1049,67 @@ __global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_distros(const Pla
     a.dbg_ts[(size_t)d * 16 + 15] = blockIdx.x;
   }
 #endif
-  const AllocArgs none{};
-  const bool done = n <= kN && plan_distro_lds<RICH, false, BD>(a, none, d, lo, n, smem, s_red);
+  const bool done = n <= kN && plan_distro_lds<RICH, BD, 11>(a, d, lo, n, smem, s_red);
   if (threadIdx.x == 0) {
-    a.w_generic[d] = done ? 0 : 1;
-    if (!done && a.w_status) *(volatile uint32_t*)a.w_status = 1u;  // EVG_PROMISE_ALL_ON_LDS_PATH was false: nobody will plan this distro
+    if (done) a.w_generic[d] = 0;
+    else if (!(a.big_tier && lds_tier_of(a, d) == 12)) {
+      a.w_generic[d] = 1;
+      if (a.w_status) *(volatile uint32_t*)a.w_status = 1u;  // EVG_PROMISE_ALL_ON_LDS_PATH was false: nobody will plan this distro
+    }
   }
 }
 
-// The batched tick in one launch: plan every distro AND run its host allocator (evg_plan_allocate_device).
-struct FusedArgs {
-  PlanArgs p;
-  AllocArgs q;  // q.in.distro_info / q.in.group_info alias p.out.distro_info / p.out.group_info
-};
-template <bool RICH, bool BD>
-__global__ void __launch_bounds__(kBlock, RICH ? 2 : 4) k_plan_allocate(const FusedArgs f) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
-  const int d = f.p.d0 + blockIdx.x;
-  const int lo = f.p.in.task_off[d], n = f.p.in.task_off[d + 1] - lo;
-  if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
-  __syncthreads();
-  [[maybe_unused]] const PlanArgs& a = f.p;  // EVG_STAMP's
-#ifdef EVG_PHASE_TIMING
-  struct { int d; } c{d};
-#endif
-  EVG_STAMP(0);
-  const bool done = n <= kN && plan_distro_lds<RICH, true, BD>(f.p, f.q, d, lo, n, smem, s_red);
-  if (threadIdx.x == 0) {
-    f.p.w_generic[d] = done ? 0 : 1;
-    if (!done && f.p.w_status) *(volatile uint32_t*)f.p.w_status = 1u;
-  }
-}
-
-#ifdef EVG_WITH_WIDE
-// Experiment (not in the default build): the same phases with TWO tasks per thread -- 1024-thread workgroups, 16 waves, two
-// workgroups per CU = 8 waves per SIMD at 64 VGPRs -- to see whether twice the waves hide the latencies of the phases.
-// Bit-identical results (the whole GPU suite passes with EVG_PLAN_WIDE=1); measured on config 3: a workgroup alone on its CU
-// takes as long as before (39.4 vs 39.1 us), two per CU take longer (59.2 vs 55.8 us). See DESIGN.md section 3.1.
+// The one-per-CU tier: 1024-thread workgroups with the CU's whole LDS plan the distros of tier 12 (2049..4096 tasks, or fewer
+// tasks with more unit slots / edges than the small tier's block holds). The grid is the caller's hint
+// (evg_plan_input.n_big_tier_distros) -- every workgroup needs a CU to itself just to start, so there must be no idle ones --
+// and the workgroups find their distros themselves: the tier-12 distros of [d0, d1) are numbered in distro order (ballots +
+// per-wave counts) and workgroup b plans number b. ONE distro per workgroup: with the planner inside a loop the compiler keeps
+// the argument block and every hoisted lane mask live across it (222 SGPR + 63 VGPR spills against 26 + 0). A tier-12 distro
+// beyond the grid (the hint understated the tier) is flagged for the pipeline behind, by workgroup 0. This kernel owns
+// w_generic[d] of every tier-12 distro.
 template <bool BD>
-__global__ void __launch_bounds__(kN / 2, 8) k_plan_distros_wide(const PlanArgs a) {
+__global__ void __launch_bounds__(Tier<12>::BLK, 1) k_plan_distros_big(const PlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) unsigned s_red[32];
-  const int d = a.d0 + blockIdx.x;
+  __shared__ int s_wcnt[Tier<12>::BLK / 64];
+  __shared__ int s_mine;
+  constexpr int BLK = Tier<12>::BLK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_mine = -1;
+  if (tid < 32) s_red[tid] = 0;
+  int seen = 0;  // tier-12 distros before this chunk
+  for (int base = a.d0; base < a.d1; base += BLK) {
+    const int dm = base + tid;
+    const bool big = dm < a.d1 && lds_tier_of(a, dm) == 12;
+    const unsigned long long bal = __ballot(big);
+    __syncthreads();
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = seen, total = 0;
+#pragma unroll
+    for (int w = 0; w < BLK / 64; w++) { const int x = s_wcnt[w]; before += w < wave ? x : 0; total += x; }
+    const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (big && rank == (int)blockIdx.x) s_mine = dm;
+    if (big && rank >= (int)gridDim.x && blockIdx.x == 0) {
+      a.w_generic[dm] = 1;
+      if (a.w_status) *(volatile uint32_t*)a.w_status = 1u;  // the batch promised the two tiers would take everything
+    }
+    seen += total;
+  }
+  __syncthreads();
+  const int d = __builtin_amdgcn_readfirstlane(s_mine);  // uniform: the distro context stays in SGPRs
+  if (d < 0) return;  // the hint overstated the tier
   const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo;
-  if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
-  __syncthreads();
 #ifdef EVG_PHASE_TIMING
   struct { int d; } c{d};
 #endif
   EVG_STAMP(0);
-  const AllocArgs none{};
-  const bool done = n <= kN && plan_distro_lds<false, false, BD, 2>(a, none, d, lo, n, smem, s_red);
-  if (threadIdx.x == 0) a.w_generic[d] = done ? 0 : 1;
+  const bool done = plan_distro_lds<false, BD, 12>(a, d, lo, n, smem, s_red);
+  if (tid == 0) {
+    a.w_generic[d] = done ? 0 : 1;  // not done: priorities beyond int32 -- the pipeline behind takes it,
+    if (!done && a.w_status) *(volatile uint32_t*)a.w_status = 1u;  // unless the batch promised there would be no need
+  }
 }
-__global__ void __launch_bounds__(kN / 2, 8) k_plan_allocate_wide(const FusedArgs f) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
-  const int d = f.p.d0 + blockIdx.x;
-  const int lo = f.p.in.task_off[d], n = f.p.in.task_off[d + 1] - lo;
-  if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
-  __syncthreads();
-  [[maybe_unused]] const PlanArgs& a = f.p;  // EVG_STAMP's
-#ifdef EVG_PHASE_TIMING
-  struct { int d; } c{d};
-#endif
-  EVG_STAMP(0);
-  const bool done = n <= kN && plan_distro_lds<false, true, false, 2>(f.p, f.q, d, lo, n, smem, s_red);
-  if (threadIdx.x == 0) f.p.w_generic[d] = done ? 0 : 1;
-}
-#endif
 
 __device__ __forceinline__ void plan_generic_body(const PlanArgs& a, const DC& c, unsigned* s_red, K128* sort_buf) {
   const int d = c.d;
@@ -1189,46 +1152,6 @@ __global__ void __launch_bounds__(kBlock) k_plan_generic(const PlanArgs a, int s
     if (threadIdx.x < 32) s_red[threadIdx.x] = 0;
     __syncthreads();
     plan_generic_body(a, c, s_red, (K128*)gsm);
-  }
-}
-
-// The same for the fused entry point: plan, then allocate hosts, for the distros the fused LDS kernel left over.
-__global__ void __launch_bounds__(kBlock) k_plan_allocate_generic(const FusedArgs f) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-  __shared__ __attribute__((aligned(16))) unsigned s_red[32];
-  __shared__ HostRec s_rec[kAllocLdsHosts];
-  __shared__ int s_cnt[2 * kAllocLdsBuckets];
-  const int tid = threadIdx.x;
-  for (int d = f.p.d0 + blockIdx.x; d < f.p.d1; d += gridDim.x) {
-  if (!f.p.w_generic[d]) continue;
-  const DC c = distro_context(f.p, d);
-  __syncthreads();
-  if (tid < 32) s_red[tid] = 0;
-  __syncthreads();
-  plan_generic_body(f.p, c, s_red, (K128*)gsm);
-  __syncthreads();  // the distro's info rows are in global memory, written by this workgroup
-  const AllocArgs& a = f.q;
-  const evg_alloc_params p = a.in.params[d];
-  const evg_host_soa& h = a.in.hosts;
-  const int h0 = a.in.host_off[d], nh = a.in.host_off[d + 1] - h0;
-  const int64_t T = a.in.distro_info[d].max_duration_threshold_ns;
-  const int len_met = a.in.distro_info[d].length_with_dependencies_met;
-  int* s_i = (int*)s_red;
-  if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
-  HostStage hs{s_rec, s_cnt, s_cnt + kAllocLdsBuckets, nh <= kAllocLdsHosts && c.ntg + 1 <= kAllocLdsBuckets};
-  if (hs.staged)
-    for (int b = tid; b < c.ntg + 1; b += kBlock) { hs.n_hosts[b] = 0; hs.n_free[b] = 0; }
-  __syncthreads();
-  uint32_t nfree = 0;
-  for (int i = tid; i < nh; i += kBlock) {
-    const uint32_t fl = h.flags[h0 + i];
-    nfree += (fl & EVG_HF_FREE) ? 1u : 0u;
-    const double term = host_term(p.future_host_fraction, T, host_left(a.in.now_ns, fl, h.start_ts_ns[h0 + i], h.expected_duration_ns[h0 + i],
-                                                                       h.duration_stddev_ns[h0 + i]));
-    stage_host(hs, a, h0, i, fl, hs.staged ? h.tg_key[h0 + i] : 0, term, c.tg_lo, c.ntg);
-  }
-  __syncthreads();
-  allocate_distro<kBlock>(a, d, p, h0, nh, c.tg_lo, c.ntg, T, len_met, nfree, hs, s_i);
   }
 }
 

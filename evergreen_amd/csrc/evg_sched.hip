@@ -23,8 +23,7 @@
 
 namespace evg {
 
-// Standalone UtilizationBasedHostAllocator: one 256-thread workgroup per distro (what the reference's separate
-// host-allocator job maps to; the batched tick uses the fused kernel of evg_plan_lds.hip.h instead).
+// UtilizationBasedHostAllocator: one 256-thread workgroup per distro (the reference's separate host-allocator job).
 // BLOCK threads: 256, or 1024 for batches whose distros average hundreds of task groups (a bucket's evaluation is a chain of
 // dependent global round trips: with one trip of the bucket loop per thread the chains run side by side, and every
 // bucket's result stays in its thread's registers).
@@ -409,8 +408,11 @@ struct evg_ctx {
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
-  // experiment builds (-DEVG_WITH_WIDE): EVG_PLAN_WIDE=1 plans with 1024-thread workgroups, two tasks per thread
-  bool wide = false;
+  // the one-per-CU tier (k_plan_distros_big): 2 = beside the small tier's launch on the context's side stream (default),
+  // 1 = behind it on the caller's stream, 0 = off (tier-12 distros take the large-distro pipeline). EVG_BIG_TIER, for A/B runs.
+  int big_mode = 2;
+  hipStream_t side = nullptr;               // high-priority stream of the big tier's launch
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // evg_profile_plan_kernel: HIP events around the LDS planner kernel alone, on the stream it is launched on
   bool profile = false;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -664,9 +666,7 @@ evg_ctx* evg_create(int device_ordinal) {
   }
   evg_ctx* c = new evg_ctx();
   c->device = device_ordinal;
-#ifdef EVG_WITH_WIDE
-  if (const char* w = getenv("EVG_PLAN_WIDE")) c->wide = w[0] == '1';
-#endif
+  if (const char* m = getenv("EVG_BIG_TIER")) c->big_mode = atoi(m);
   if (const char* m = getenv("EVG_TILED_MODE")) c->tiled_mode = atoi(m);
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void**)&c->status_word, 64, hipHostMallocDefault) != hipSuccess) {
@@ -688,6 +688,9 @@ void evg_destroy(evg_ctx* c) {
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->status_word) (void)hipHostFree(c->status_word);
   if (c->pack_h) (void)hipHostFree(c->pack_h);
   if (c->pack_d) (void)hipFree(c->pack_d);
@@ -750,17 +753,20 @@ void evg_host_free(evg_ctx* c, void* p) {
   (void)hipHostFree(p);
 }
 
-// Can the one-workgroup kernel plan distro d (host pointers)? The kernel's own test (fits_lds_shape) + the priority range.
-static bool distro_on_lds_path(const evg_plan_input* in, int d) {
+// Which tier of the one-workgroup kernels plans distro d (host pointers): the kernels' own shape test (lds_tier_of_shape) + the
+// priority range. 11 = k_plan_distros, 12 = k_plan_distros_big, 0 = neither.
+static int distro_lds_tier(const evg_plan_input* in, int d) {
   const evg_task_soa& t = in->tasks;
   const int lo = in->task_off[d], hi = in->task_off[d + 1], n = hi - lo;
   const int ntg = in->tg_off[d + 1] - in->tg_off[d], nver = in->ver_off[d + 1] - in->ver_off[d];
   const int S = in->distros[d].group_versions ? ntg + nver : n + ntg;
   const int ne = n > 0 ? t.dep_off[hi] - t.dep_off[lo] : 0;
-  if (n < 0 || !evg::fits_lds_shape(n, S, ntg, ne)) return false;
+  if (n < 0) return 0;
+  const int tier = evg::lds_tier_of_shape(n, S, ntg, ne);
+  if (!tier) return 0;
   for (int r = lo; r < hi; r++)
-    if (t.priority[r] != (int64_t)(int32_t)t.priority[r]) return false;
-  return true;
+    if (t.priority[r] != (int64_t)(int32_t)t.priority[r]) return 0;
+  return tier;
 }
 
 // One distro's share of the layout contract; 0 or EVG_E_CONTRACT with the message in `err`.
@@ -797,23 +803,28 @@ static int validate_distro(const evg_plan_input* in, int d, char* err, size_t er
   return EVG_OK;
 }
 
-int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, int32_t* promises) {
-  if (!in || !max_distro_tasks || !promises) return EVG_E_INVALID;
+int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, int32_t* promises, int32_t* n_big_tier_distros) {
+  if (!in || !max_distro_tasks || !promises || !n_big_tier_distros) return EVG_E_INVALID;
   *max_distro_tasks = 0;
   *promises = 0;
+  *n_big_tier_distros = 0;
   const int D = in->n_distros;
   if (D <= 0) return D == 0 ? EVG_OK : EVG_E_INVALID;
   if (!in->task_off || !in->tg_off || !in->ver_off || !in->distros) return EVG_E_INVALID;
   if (in->tasks.n_tasks > 0 && (!in->tasks.priority || !in->tasks.dep_off)) return EVG_E_INVALID;
   for (int d = 0; d < D; d++) *max_distro_tasks = std::max(*max_distro_tasks, in->task_off[d + 1] - in->task_off[d]);
-  int off_path[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int off_path[8] = {0, 0, 0, 0, 0, 0, 0, 0}, off_tiers[8] = {0, 0, 0, 0, 0, 0, 0, 0}, big[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for_distros_parallel(in, [&](int d, int w) {
-    if (!distro_on_lds_path(in, d)) { off_path[w] = 1; return false; }
+    const int tier = distro_lds_tier(in, d);
+    if (tier != 11) off_path[w] = 1;
+    if (tier == 12) big[w]++;
+    if (tier == 0) off_tiers[w] = 1;
     return true;
   });
-  int any = 0;
-  for (int w = 0; w < 8; w++) any |= off_path[w];
+  int any = 0, any_none = 0;
+  for (int w = 0; w < 8; w++) { any |= off_path[w]; *n_big_tier_distros += big[w]; any_none |= off_tiers[w]; }
   if (!any) *promises |= EVG_PROMISE_ALL_ON_LDS_PATH;
+  if (!any_none) *promises |= EVG_PROMISE_ALL_ON_LDS_TIERS;
   return EVG_OK;
 }
 
@@ -901,7 +912,8 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr; a.w_tgbit = nullptr;
   a.w_srank = nullptr;
   a.tiled_mode = c->tiled_mode;
-  a.w_status = (in->promises & EVG_PROMISE_ALL_ON_LDS_PATH) ? c->status_word : nullptr;
+  a.big_tier = 0;
+  a.w_status = (in->promises & EVG_PROMISE_ALL_ON_LDS_PATH) ? c->status_word : nullptr;  // launch_plan arms it for ALL_ON_LDS_TIERS
 #ifdef EVG_PHASE_TIMING
   a.dbg_ts = c->dbg_ts;
   a.dbg_tiled = c->dbg_tiled;
@@ -910,14 +922,8 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
-#ifdef EVG_WITH_WIDE
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate_wide, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
-#endif
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLean));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_allocate<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsRich));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBig));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_plan_distros_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBig));
     c->lds_attr_set = true;
   }
   // SortingValueBreakdown: the kernels write rows per UNIT (+ the emitting unit of every task); rows per task are an
@@ -1075,20 +1081,57 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
     if (d_begin == d_end) return EVG_OK;
   }
   const int D = a.d1 - a.d0;
+  // The one-per-CU tier (distros of 2049..4096 tasks): its workgroups are the launch's critical path -- twice the rows of a small
+  // distro -- so they are enqueued FIRST, on the context's high-priority side stream, and run beside the small tier's launch;
+  // the large-distro pipeline behind waits for both. Only when the caller's hint says there are such distros (a hint: without it
+  // they take the pipeline, with the same result); TaskPlan.Len() needs the small tier's RICH kernel or the generic one.
+  bool promise = (in->promises & EVG_PROMISE_ALL_ON_LDS_PATH) != 0;
+  int n_big = promise || out->n_units || c->big_mode == 0 ? 0 : in->n_big_tier_distros;
+  if (n_big > D) n_big = D;
+  bool big_beside = false;
+  if (n_big > 0) {
+    a.big_tier = 1;
+    if (in->promises & EVG_PROMISE_ALL_ON_LDS_TIERS) {  // the two tiers take everything: nothing behind them, the status word armed
+      promise = true;
+      a.w_status = c->status_word;
+    }
+    big_beside = c->big_mode == 2;
+    if (big_beside && !c->side) {
+      int lo_pri = 0, hi_pri = 0;
+      HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+      HIP_TRY(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi_pri));
+      HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    const dim3 bg((unsigned)n_big), bb(Tier<12>::BLK);
+    if (big_beside) {
+      HIP_TRY(c, hipEventRecord(c->ev_fork, st));  // after whatever produced the batch on the caller's stream
+      HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+      if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros_big<true>), bg, bb, kLdsBig, c->side, a);
+      else hipLaunchKernelGGL((k_plan_distros_big<false>), bg, bb, kLdsBig, c->side, a);
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+    }
+  }
   if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st));
   // TaskPlan.Len() needs 18 KiB more LDS per workgroup (one workgroup per CU instead of two); the breakdown rows do not
   if (out->n_units) hipLaunchKernelGGL((k_plan_distros<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, a);
-#ifdef EVG_WITH_WIDE
-  else if (c->wide && a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros_wide<true>), dim3(D), dim3(kN / 2), kLdsLean, st, a);
-  else if (c->wide) hipLaunchKernelGGL((k_plan_distros_wide<false>), dim3(D), dim3(kN / 2), kLdsLean, st, a);
-#endif
   else if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros<false, true>), dim3(D), dim3(kBlock), kLdsLean, st, a);
   else hipLaunchKernelGGL((k_plan_distros<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, a);
   HIP_TRY(c, hipGetLastError());
   if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_stop, st));
+  if (n_big > 0) {
+    if (big_beside) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    else {
+      const dim3 bg((unsigned)n_big), bb(Tier<12>::BLK);
+      if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros_big<true>), bg, bb, kLdsBig, st, a);
+      else hipLaunchKernelGGL((k_plan_distros_big<false>), bg, bb, kLdsBig, st, a);
+      HIP_TRY(c, hipGetLastError());
+    }
+  }
   // distros the LDS path could not take (flagged on the device); the workgroups exit at once otherwise. Not enqueued at all
   // when the caller promises (evg_plan_launch_hints; the host-pointer entry points work it out themselves) that there are none.
-  if (!(in->promises & EVG_PROMISE_ALL_ON_LDS_PATH)) {
+  if (!promise) {
     rc = launch_generic(c, a, in, st);
     if (rc) return rc;
   }
@@ -1138,61 +1181,6 @@ int evg_allocate_host_range_device(evg_ctx* c, const evg_alloc_input* in, const 
   if (!c || d_end < 0) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return launch_alloc(c, in, out, (hipStream_t)hip_stream, d_begin, d_end);
-}
-
-static int launch_plan_allocate(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const evg_alloc_input* ain,
-                                const evg_alloc_output* aout, hipStream_t st, int d_begin, int d_end) {
-  using namespace evg;
-  if (ain->n_distros != in->n_distros || ain->n_task_groups != in->n_task_groups)
-    return set_err(c, EVG_E_INVALID, "plan and allocator inputs describe different batches");
-  FusedArgs f;
-  int rc = prepare_plan(c, in, out, &f.p);
-  if (rc || in->n_distros == 0) return rc;
-  if (d_end >= 0) {
-    if (d_begin < 0 || d_end < d_begin || d_end > in->n_distros) return set_err(c, EVG_E_INVALID, "distro range [%d, %d) outside [0, %d)", d_begin, d_end, in->n_distros);
-    if (out->breakdown && !(d_begin == 0 && d_end == in->n_distros))
-      return set_err(c, EVG_E_INVALID, "rows by task (breakdown) are not available from a distro-range entry point; ask for unit_of_task + unit_breakdown");
-    f.p.d0 = d_begin;
-    f.p.d1 = d_end;
-    if (d_begin == d_end) return EVG_OK;
-  }
-  evg_alloc_input ai = *ain;
-  ai.distro_info = out->distro_info;  // the allocator consumes what the planner of the same launch produced
-  ai.group_info = out->group_info;
-  ai.tg_off = in->tg_off;
-  ai.now_ns = in->now_ns;
-  rc = prepare_alloc(c, &ai, aout, &f.q);
-  if (rc) return rc;
-  f.q.d0 = f.p.d0;
-  const int D = f.p.d1 - f.p.d0;
-  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st));
-  if (out->n_units) hipLaunchKernelGGL((k_plan_allocate<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, f);
-  else if (f.p.out.unit_breakdown) hipLaunchKernelGGL((k_plan_allocate<false, true>), dim3(D), dim3(kBlock), kLdsLean, st, f);  // rows per unit need no extra LDS
-#ifdef EVG_WITH_WIDE
-  else if (c->wide) hipLaunchKernelGGL(k_plan_allocate_wide, dim3(D), dim3(kN / 2), kLdsLean, st, f);
-#endif
-  else hipLaunchKernelGGL((k_plan_allocate<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, f);
-  HIP_TRY(c, hipGetLastError());
-  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_stop, st));
-  if (!(in->promises & EVG_PROMISE_ALL_ON_LDS_PATH)) {
-    hipLaunchKernelGGL(k_plan_allocate_generic, dim3(D < kGenericGrid ? D : kGenericGrid), dim3(kBlock), kGenericLds, st, f);
-    HIP_TRY(c, hipGetLastError());
-  }
-  return finish_breakdown(c, f.p, out, st, true);
-}
-
-int evg_plan_allocate_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const evg_alloc_input* ain,
-                             const evg_alloc_output* aout, void* hip_stream) {
-  if (!c || !in || !out || !ain || !aout) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
-  return launch_plan_allocate(c, in, out, ain, aout, (hipStream_t)hip_stream, 0, -1);
-}
-
-int evg_plan_allocate_range_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const evg_alloc_input* ain,
-                                   const evg_alloc_output* aout, int32_t d_begin, int32_t d_end, void* hip_stream) {
-  if (!c || !in || !out || !ain || !aout || d_end < 0) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
-  return launch_plan_allocate(c, in, out, ain, aout, (hipStream_t)hip_stream, d_begin, d_end);
 }
 
 int evg_cap_queue_device(evg_ctx* c, int32_t n_distros, const int32_t* task_off, const int32_t* order,
@@ -1366,10 +1354,11 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
   int rc = evg_validate_plan_input(in, msg, sizeof msg);
   if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
   {  // the caller's promises are ignored on this path: the batch is host memory, the library looks for itself
-    int32_t mx = 0, pr = 0;
-    rc = evg_plan_launch_hints(in, &mx, &pr);
+    int32_t mx = 0, pr = 0, nb = 0;
+    rc = evg_plan_launch_hints(in, &mx, &pr, &nb);
     if (rc) return set_err(c, rc, "invalid plan input");
     di.promises = pr;
+    di.n_big_tier_distros = nb;
   }
   evg_plan_output dout;
   dout.order = s.out<int32_t>(N, true);
@@ -1524,7 +1513,7 @@ int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
   if (rc) return set_err(c, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
   StreamDrain drain{c};
   evg_plan_input di = *in;
-  rc = evg_plan_launch_hints(in, &di.max_distro_tasks, &di.promises);
+  rc = evg_plan_launch_hints(in, &di.max_distro_tasks, &di.promises, &di.n_big_tier_distros);
   if (rc) return set_err(c, rc, "invalid plan input");
   const size_t N = in->tasks.n_tasks, E = in->tasks.n_edges, D = in->n_distros;
   int slot = 0;
@@ -1565,12 +1554,24 @@ int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update*
   for (int i = 0; i < nr; i++) {
     if (ru->rows[i] < 0 || ru->rows[i] >= p.tasks.n_tasks) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: row %d is outside the pool", ru->rows[i]);
     // a priority beyond int32 takes the distro off the one-workgroup path: the promise made at load time no longer holds
-    if (ru->priority && ru->priority[i] != (int64_t)(int32_t)ru->priority[i]) c->pool_in.promises &= ~EVG_PROMISE_ALL_ON_LDS_PATH;
+    if (ru->priority && ru->priority[i] != (int64_t)(int32_t)ru->priority[i]) c->pool_in.promises &= ~EVG_PROMISE_ALL_ON_LDS_PATH;  // (n_big_tier_distros is a hint: it may overstate)
   }
   for (int i = 0; i < ne; i++)
     if (eu->edges[i] < 0 || eu->edges[i] >= p.tasks.n_edges) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: edge %d is outside the pool", eu->edges[i]);
   if (ne > 0 && eu->dep_finished_ts_ns && !p.tasks.dep_finished_ts_ns)
     return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_finished_ts_ns");
+  if (ne > 0 && eu->dep_info && !p.tasks.dep_info)  // (k_update_edges would write through a null device pointer)
+    return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_info");
+  {  // `distinct`: a row / edge listed twice would take whichever of its two values the device wrote last
+    std::vector<int32_t> seen;
+    auto dup = [&](const int32_t* v, int n) {
+      seen.assign(v, v + n);
+      std::sort(seen.begin(), seen.end());
+      return std::adjacent_find(seen.begin(), seen.end()) != seen.end();
+    };
+    if (nr > 1 && dup(ru->rows, nr)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: a row is listed twice");
+    if (ne > 1 && dup(eu->edges, ne)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: an edge is listed twice");
+  }
   if (nr == 0 && ne == 0) return EVG_OK;
   StreamDrain drain{c};
   Stager s{c};

@@ -73,6 +73,7 @@ class GenConfig:
                                   # goroutine-completion order, setup_funcs.go:57-64)
     all_tg_version_fraction: float = 0.01
     includes_dependencies_fraction: float = 0.75
+    sizes: Optional[tuple] = None  # explicit tasks per distro (n_tasks must be their sum): the `cliff` workloads of bench.py
 
 
 CONFIGS = {
@@ -89,8 +90,23 @@ def config(num: int, **over) -> GenConfig:
     return GenConfig(**{**c.__dict__, **over})
 
 
+def cliff_config(n_grown: int, grown_size: int, base: int = 3) -> GenConfig:
+    """BASELINE config `base` with `n_grown` of its distros (evenly spaced) grown to `grown_size` tasks: how much one / a few /
+    many distros beyond the 2048-task tier cost a tick that is otherwise all small."""
+    c = config(base)
+    s = np.full(c.n_distros, c.n_tasks // c.n_distros, np.int64)
+    s[: c.n_tasks % c.n_distros] += 1
+    if n_grown:
+        s[(np.arange(n_grown) * (c.n_distros // n_grown)) % c.n_distros] = grown_size
+    return GenConfig(**{**c.__dict__, "n_tasks": int(s.sum()), "sizes": tuple(int(x) for x in s), "seed": c.seed + 7000 + n_grown})
+
+
 def _distro_sizes(cfg: GenConfig, rs: Streams) -> np.ndarray:
     D, N = cfg.n_distros, cfg.n_tasks
+    if cfg.sizes is not None:
+        s = np.asarray(cfg.sizes, np.int64)
+        assert len(s) == D and int(s.sum()) == N, "GenConfig.sizes must list n_distros sizes that add up to n_tasks"
+        return s
     if not cfg.skew:
         s = np.full(D, N // D, np.int64)
         s[: N % D] += 1

@@ -38,7 +38,7 @@ ALIGN = 256
 MAGIC = 0x45564750_4F4F4C31  # "EVGPOOL1"
 HEADER_WORDS = 32            # int64 words = 256 bytes
 # header words
-H_MAGIC, H_TOTAL, H_NOW, H_D, H_N, H_E, H_TG, H_VER, H_H, H_HAS_HOSTS, H_HAS_NAME, H_MAX_DISTRO, H_PROMISES = range(13)
+H_MAGIC, H_TOTAL, H_NOW, H_D, H_N, H_E, H_TG, H_VER, H_H, H_HAS_HOSTS, H_HAS_NAME, H_MAX_DISTRO, H_PROMISES, H_NBIG, H_LP_LIMIT, H_LP_RUNNING = range(16)
 
 
 # Cost of one task of a distro that takes the many-workgroups-per-distro pipeline (more than LDS_PATH_TASKS tasks), in
@@ -90,10 +90,13 @@ class PoolLayout:
     A pure function of the sizes in the header, so every rank derives the same offsets from the broadcast header."""
 
     def __init__(self, n_distros: int, n_tasks: int, n_edges: int, n_task_groups: int, n_versions: int, n_hosts: int,
-                 has_hosts: bool, has_name_key: bool, now_ns: int = 0, max_distro_tasks: int = 0, promises: int = 0):
+                 has_hosts: bool, has_name_key: bool, now_ns: int = 0, max_distro_tasks: int = 0, promises: int = 0, n_big_tier: int = 0,
+                 large_parser: Tuple[int, int] = (0, 0)):
         self.D, self.N, self.E, self.TG, self.V, self.H = n_distros, n_tasks, n_edges, n_task_groups, n_versions, n_hosts
         self.has_hosts, self.has_name_key, self.now_ns, self.max_distro_tasks = has_hosts, has_name_key, now_ns, max_distro_tasks
         self.promises = promises  # evg_plan_launch_hints of the host batch on rank `src`: travels in the header
+        self.n_big_tier = n_big_tier
+        self.large_parser = large_parser  # (limit, running) of adjustForLargeParserProjectLimit; (0, 0) = no limit
         D, N, E, H = self.D, self.N, self.E, self.H
         sec: List[Tuple[str, np.dtype, int]] = []
         for k, dt in abi.TASK_COLUMNS.items():
@@ -124,7 +127,8 @@ class PoolLayout:
         h[H_MAGIC], h[H_TOTAL], h[H_NOW] = MAGIC, self.total_bytes, self.now_ns
         h[H_D], h[H_N], h[H_E], h[H_TG], h[H_VER], h[H_H] = self.D, self.N, self.E, self.TG, self.V, self.H
         h[H_HAS_HOSTS], h[H_HAS_NAME], h[H_MAX_DISTRO] = int(self.has_hosts), int(self.has_name_key), self.max_distro_tasks
-        h[H_PROMISES] = self.promises
+        h[H_PROMISES], h[H_NBIG] = self.promises, self.n_big_tier
+        h[H_LP_LIMIT], h[H_LP_RUNNING] = self.large_parser
         return h
 
     @staticmethod
@@ -133,7 +137,8 @@ class PoolLayout:
         if int(h[H_MAGIC]) != MAGIC:
             raise ValueError("packed pool: bad magic %x" % int(h[H_MAGIC]))
         lay = PoolLayout(int(h[H_D]), int(h[H_N]), int(h[H_E]), int(h[H_TG]), int(h[H_VER]), int(h[H_H]), bool(h[H_HAS_HOSTS]),
-                         bool(h[H_HAS_NAME]), int(h[H_NOW]), int(h[H_MAX_DISTRO]), int(h[H_PROMISES]))
+                         bool(h[H_HAS_NAME]), int(h[H_NOW]), int(h[H_MAX_DISTRO]), int(h[H_PROMISES]), int(h[H_NBIG]),
+                         (int(h[H_LP_LIMIT]), int(h[H_LP_RUNNING])))
         if lay.total_bytes != int(h[H_TOTAL]):
             raise ValueError("packed pool: header sizes do not add up (%d vs %d bytes)" % (lay.total_bytes, int(h[H_TOTAL])))
         return lay
@@ -142,9 +147,10 @@ class PoolLayout:
 def pack_pool(batch: abi.PlanBatch) -> np.ndarray:
     """The batch as ONE host byte buffer in PoolLayout order (what a shim writes its columns into, pinned, once per tick)."""
     from . import native
-    max_distro, promises = native.launch_hints(batch)  # host work: the launch hint and what the batch lets the library skip
+    max_distro, promises, n_big = native.launch_hints(batch)  # host work: the launch hints and what the batch lets the library skip
     lay = PoolLayout(batch.n_distros, batch.n_tasks, batch.n_edges, batch.n_task_groups, batch.n_versions, batch.n_hosts,
-                     batch.alloc_params is not None, batch.tg_name_key is not None, batch.now_ns, max_distro, promises)
+                     batch.alloc_params is not None, batch.tg_name_key is not None, batch.now_ns, max_distro, promises, n_big,
+                     (batch.large_parser_limit, batch.large_parser_running))
     buf = np.zeros(lay.total_bytes, np.uint8)
     buf[:HEADER_WORDS * 8] = lay.header().view(np.uint8)
     src: Dict[str, np.ndarray] = dict(batch.cols)
@@ -173,6 +179,7 @@ class _Meta:
         self.n_task_groups, self.n_versions, self.n_hosts, self.now_ns = lay.TG, lay.V, lay.H, lay.now_ns
         self.task_off = task_off
         self.alloc_params = True if lay.has_hosts else None
+        self.large_parser_limit, self.large_parser_running = lay.large_parser
 
 
 _TORCH_DT = None
@@ -201,11 +208,10 @@ class ShardedPool:
     public load().)"""
 
     def __init__(self, backend, device, src: int = 0, dst: int = 0, breakdown: bool = False, group=None, collective: bool = True,
-                 fused: bool = True, mode: str = "broadcast"):
+                 mode: str = "broadcast"):
         import torch
         assert mode in ("broadcast", "scatter")
         self.torch, self.backend, self.device, self.src, self.dst, self.breakdown, self.group = torch, backend, device, src, dst, breakdown, group
-        self.fused = fused  # tick(): one launch for plan + allocate when the batch allows it (plan_allocate)
         self.mode = mode
         self.dist = None
         try:
@@ -272,7 +278,8 @@ class ShardedPool:
                           for name, (pos, dt, count) in lay.sections.items()}
         meta_b = _Meta(lay, self.task_off)
         self.inp = abi.make_plan_input(meta_b, v)
-        self.inp.max_distro_tasks, self.inp.promises = lay.max_distro_tasks, lay.promises  # this pool's, from this pool's header
+        # this pool's hints, from this pool's header
+        self.inp.max_distro_tasks, self.inp.promises, self.inp.n_big_tier_distros = lay.max_distro_tasks, lay.promises, lay.n_big_tier
         self.out = abi.PlanOutput()
         self.out.order, self.out.deps_met, self.out.wait_ns = self.o_order.data_ptr(), self.o_met.data_ptr(), self.o_wait.data_ptr()
         self.out.breakdown = None
@@ -397,16 +404,9 @@ class ShardedPool:
                 req.wait()
 
     def plan_allocate(self) -> None:
-        """Plan + allocate this rank's range. When the batch promises that every distro stays on the one-workgroup path
-        (EVG_PROMISE_ALL_ON_LDS_PATH) both run as ONE launch -- the allocator as the tail of each distro's planner workgroup,
-        bit-identical to the two calls (60 us against 62-64 us per 1M-task tick); otherwise the two calls (the large-distro
-        pipeline belongs to the plan call)."""
-        if self.has_hosts and self.fused and (self.inp.promises & abi.EVG_PROMISE_ALL_ON_LDS_PATH) and hasattr(self.backend, "plan_allocate_range_device"):
-            d0, d1 = self.my_range
-            self.backend.plan_allocate_range_device(self.inp, self.out, self.ainp, self.aout, d0, d1, self._stream())
-        else:
-            self.plan()
-            self.allocate()
+        """Plan + allocate this rank's range: the reference's two jobs, two calls."""
+        self.plan()
+        self.allocate()
 
     def tick(self) -> None:
         self.move_in()
@@ -438,3 +438,4 @@ class _HostMeta:
 
     def __init__(self, m: _Meta):
         self.n_distros, self.n_task_groups, self.now_ns, self.n_hosts = m.n_distros, m.n_task_groups, m.now_ns, m.n_hosts
+        self.large_parser_limit, self.large_parser_running = m.large_parser_limit, m.large_parser_running

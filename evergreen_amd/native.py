@@ -19,12 +19,12 @@ LIB_PATH = os.environ.get("EVG_SCHED_LIB") or os.path.join(_HERE, "csrc", "libev
 EXPORTS = [
     "evg_create", "evg_destroy", "evg_last_error", "evg_abi_version", "evg_validate_plan_input",
     "evg_plan_distros", "evg_plan_distros_device", "evg_allocate_hosts", "evg_allocate_hosts_device",
-    "evg_cap_queue_device", "evg_plan_allocate_device", "evg_materialize_queue_device",
+    "evg_cap_queue_device", "evg_materialize_queue_device",
     "evg_allocator_report_device", "evg_filter_runnable_device", "evg_dispatch_order_device",
     "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
     "evg_plan_distro_range_device", "evg_allocate_host_range_device", "evg_selftest_unit_value",
     "evg_host_alloc", "evg_host_free", "evg_profile_plan_kernel", "evg_last_plan_kernel_ms", "evg_plan_launch_hints",
-    "evg_plan_allocate_range_device", "evg_check_abi", "evg_take_device_status", "evg_pool_load", "evg_pool_update", "evg_pool_plan",
+    "evg_check_abi", "evg_take_device_status", "evg_pool_load", "evg_pool_update", "evg_pool_plan",
 ]
 
 _lib = None
@@ -65,8 +65,6 @@ def load_library() -> C.CDLL:
     lib.evg_allocate_host_range_device.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_int32, C.c_int32, C.c_void_p]
     lib.evg_allocate_hosts.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput)]
     lib.evg_allocate_hosts_device.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_void_p]
-    lib.evg_plan_allocate_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput),
-                                             C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_void_p]
     lib.evg_materialize_queue_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_void_p, C.c_int32,
                                                  C.POINTER(abi.QueueItems), C.c_void_p]
     lib.evg_allocator_report_device.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8
@@ -84,11 +82,8 @@ def load_library() -> C.CDLL:
         lib.evg_host_alloc.restype = C.c_void_p
         lib.evg_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
         lib.evg_host_free.argtypes = [C.c_void_p, C.c_void_p]
-    if hasattr(lib, "evg_plan_allocate_range_device"):
-        lib.evg_plan_allocate_range_device.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.POINTER(abi.AllocInput),
-                                                       C.POINTER(abi.AllocOutput), C.c_int32, C.c_int32, C.c_void_p]
     if hasattr(lib, "evg_plan_launch_hints"):
-        lib.evg_plan_launch_hints.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.evg_plan_launch_hints.argtypes = [C.POINTER(abi.PlanInput), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     if hasattr(lib, "evg_profile_plan_kernel"):
         lib.evg_profile_plan_kernel.argtypes = [C.c_void_p, C.c_int]
         lib.evg_last_plan_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -111,17 +106,15 @@ def load_library() -> C.CDLL:
 
 
 def launch_hints(batch: abi.PlanBatch):
-    """evg_plan_launch_hints on the HOST batch: (max_distro_tasks, promises) for the evg_plan_input of a *_device call. Host
-    work only (no context, no GPU); (0, 0) -- "unknown, nothing promised" -- from a build that does not export the call."""
+    """evg_plan_launch_hints on the HOST batch: (max_distro_tasks, promises, n_big_tier_distros) for the evg_plan_input of a
+    *_device call. Host work only (no context, no GPU)."""
     lib = load_library()
-    if not hasattr(lib, "evg_plan_launch_hints"):
-        return 0, 0
     inp = abi.make_plan_input(batch)
-    mx, pr = C.c_int32(0), C.c_int32(0)
-    rc = lib.evg_plan_launch_hints(C.byref(inp), C.byref(mx), C.byref(pr))
+    mx, pr, nb = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    rc = lib.evg_plan_launch_hints(C.byref(inp), C.byref(mx), C.byref(pr), C.byref(nb))
     if rc != abi.EVG_OK:
         raise NativeError("evg_plan_launch_hints failed (%d)" % rc)
-    return int(mx.value), int(pr.value)
+    return int(mx.value), int(pr.value), int(nb.value)
 
 
 class Context:
@@ -327,21 +320,9 @@ class Context:
         self._check(self.lib.evg_plan_distro_range_device(self.h, C.byref(inp), C.byref(out), d_begin, d_end, stream),
                     "evg_plan_distro_range_device")
 
-    def plan_allocate_range_device(self, inp: abi.PlanInput, out: abi.PlanOutput, ainp: abi.AllocInput, aout: abi.AllocOutput,
-                                   d_begin: int, d_end: int, stream: Optional[int] = None) -> None:
-        """Plan + host allocation of distros [d_begin, d_end) in ONE launch (the allocator runs as the tail of each distro's
-        planner workgroup)."""
-        self._check(self.lib.evg_plan_allocate_range_device(self.h, C.byref(inp), C.byref(out), C.byref(ainp), C.byref(aout), d_begin, d_end, stream),
-                    "evg_plan_allocate_range_device")
-
     def allocate_range_device(self, inp: abi.AllocInput, out: abi.AllocOutput, d_begin: int, d_end: int, stream: Optional[int] = None) -> None:
         self._check(self.lib.evg_allocate_host_range_device(self.h, C.byref(inp), C.byref(out), d_begin, d_end, stream),
                     "evg_allocate_host_range_device")
-
-    def plan_allocate_device(self, inp: abi.PlanInput, out: abi.PlanOutput, ainp: abi.AllocInput, aout: abi.AllocOutput,
-                             stream: Optional[int] = None) -> None:
-        self._check(self.lib.evg_plan_allocate_device(self.h, C.byref(inp), C.byref(out), C.byref(ainp), C.byref(aout), stream),
-                    "evg_plan_allocate_device")
 
     def materialize_queue_device(self, inp: abi.PlanInput, out: abi.PlanOutput, tg_name_key: int, max_scheduled: int,
                                  items: abi.QueueItems, stream: Optional[int] = None) -> None:

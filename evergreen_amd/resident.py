@@ -34,7 +34,7 @@ class ResidentPool:
         self.o_ubd = z(max(nslots * abi.BREAKDOWN_FIELDS, 1), dt=torch.int64) if units else None
         self.inp = abi.make_plan_input(batch, self.t)
         # what the host knows about the batch it uploaded: the launch hint and the promises (evg_plan_launch_hints)
-        self.inp.max_distro_tasks, self.inp.promises = native.launch_hints(batch)
+        self.inp.max_distro_tasks, self.inp.promises, self.inp.n_big_tier_distros = native.launch_hints(batch)
         self.out = abi.PlanOutput()
         self.out.order, self.out.deps_met, self.out.wait_ns = self.o_order.data_ptr(), self.o_met.data_ptr(), self.o_wait.data_ptr()
         self.out.breakdown = self.o_bd.data_ptr() if breakdown else None
@@ -59,13 +59,10 @@ class ResidentPool:
     def allocate(self, stream: Optional[int] = None) -> None:
         self.ctx.allocate_device(self.ainp, self.aout, self.stream() if stream is None else stream)
 
-    def step(self, stream: Optional[int] = None, fused: bool = True) -> None:
-        """One pass of the hot path over the resident pool: plan + queue info [+ host allocation]. `fused` uses the
-        single-launch entry point (evg_plan_allocate_device); otherwise the two separate calls."""
+    def step(self, stream: Optional[int] = None) -> None:
+        """One pass of the hot path over the resident pool: plan + queue info [+ host allocation] -- the reference's two jobs,
+        two calls."""
         s = self.stream() if stream is None else stream
-        if self.has_hosts and fused:
-            self.ctx.plan_allocate_device(self.inp, self.out, self.ainp, self.aout, s)
-            return
         self.ctx.plan_device(self.inp, self.out, s)
         if self.has_hosts:
             self.ctx.allocate_device(self.ainp, self.aout, s)

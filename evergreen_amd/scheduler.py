@@ -528,10 +528,13 @@ def pack_hosts(batch: abi.PlanBatch, datas: Sequence[HostAllocatorData], tg_key_
 
 
 def AllocateHosts(backend: Backend, datas: Sequence[HostAllocatorData], now_ns: int,
-                  running: Optional[RunningTaskLookup] = None) -> List[Tuple[int, int, Optional[str]]]:
+                  running: Optional[RunningTaskLookup] = None, large_parser: Tuple[int, int] = (0, 0)) -> List[Tuple[int, int, Optional[str]]]:
     """Batched UtilizationBasedHostAllocator: one HostAllocatorData per distro -> (newHostsNeeded,
     estimatedFreeHosts, error-or-None). Writes CountFree/CountRequired back into
-    data.DistroQueueInfo.TaskGroupInfos IN PLACE like the reference (...allocator.go:106-109)."""
+    data.DistroQueueInfo.TaskGroupInfos IN PLACE like the reference (...allocator.go:106-109).
+    large_parser = (MaxConcurrentLargeParserProjectTasks, running large-parser tasks): the allocator JOB's
+    adjustForLargeParserProjectLimit (units/host_allocator.go:150,479-520) for a batch whose queue infos are the planner's own
+    (not yet adjusted); (0, 0) = no limit = the infos are used as they are."""
     D = len(datas)
     tg_names: List[str] = []
     tg_key_of: List[Dict[str, int]] = []
@@ -553,6 +556,7 @@ def AllocateHosts(backend: Backend, datas: Sequence[HostAllocatorData], now_ns: 
         distro_info[d]["length"] = q.Length
         distro_info[d]["length_with_dependencies_met"] = q.LengthWithDependenciesMet
         distro_info[d]["max_duration_threshold_ns"] = q.MaxDurationThreshold
+        distro_info[d]["num_queued_large_parser_project_tasks"] = q.NumQueuedLargeParserProjectTasks
         for gi in q.TaskGroupInfos:
             # groupByTaskGroup builds a name->info map (:228-231): a later duplicate name wins
             g = group_info[d if gi.Name == "" else D + tg_key_of[d][gi.Name]]
@@ -567,6 +571,7 @@ def AllocateHosts(backend: Backend, datas: Sequence[HostAllocatorData], now_ns: 
                           dep_off=np.zeros(1, np.int32), edges={k: np.zeros(0, dt) for k, dt in abi.EDGE_COLUMNS.items()},
                           distros=np.zeros(D, abi.DISTRO_PARAMS_DTYPE), task_off=zeros, tg_off=tg_off, ver_off=zeros)
     pack_hosts(batch, datas, tg_key_of, running, now_ns)
+    batch.large_parser_limit, batch.large_parser_running = large_parser
     res = backend.allocate(batch, distro_info, group_info)
     out = []
     for d, data in enumerate(datas):

@@ -175,7 +175,12 @@ typedef struct evg_plan_input {
                                          reports it). The host-pointer entry points work them out themselves and ignore
                                          this field; a *_device caller takes them from evg_plan_launch_hints on its host
                                          copy of the batch                                                             */
-  int32_t reserved0;
+  int32_t n_big_tier_distros;         /* how many distros the 4096-task tier of the one-workgroup kernel takes (2049..4096
+                                         tasks, or fewer with more unit slots / edges than the 2048-task tier holds), or
+                                         0 = unknown / none. A hint like max_distro_tasks (ABI 3.0; from
+                                         evg_plan_launch_hints): it sizes that tier's launch -- every one of its workgroups
+                                         needs a whole CU -- and without it those distros take the large-distro pipeline,
+                                         with the same result                                                           */
 } evg_plan_input;
 
 /* Every distro of the batch can be planned by the one-workgroup kernel: at most 2048 tasks, unit slots + dependency
@@ -183,6 +188,10 @@ typedef struct evg_plan_input {
  * kernels that pick up what that kernel leaves (one empty launch, ~4.5 us of a ~70 us tick on BASELINE config 3). A false
  * promise is detected on the device and reported by evg_take_device_status: the plan of such a batch must not be used. */
 #define EVG_PROMISE_ALL_ON_LDS_PATH 0x1
+/* Every distro can be planned by one of the two tiers of the one-workgroup kernel (the above, or at most 4096 tasks with unit
+ * slots + edges inside the whole CU's LDS; every |priority| below 2^31) and n_big_tier_distros counts the second kind (ABI 3.0).
+ * Nothing is enqueued behind the two tiers then. A false promise is reported the same way. */
+#define EVG_PROMISE_ALL_ON_LDS_TIERS 0x2
 
 /* ---- outputs -------------------------------------------------------------------------------- */
 
@@ -292,6 +301,16 @@ typedef struct evg_alloc_input {
                                            back from Mongo, units/host_allocator.go:144)         */
   evg_group_info* group_info;           /* D + n_task_groups, in/out: count_free/count_required  */
   int64_t now_ns;
+  /* adjustForLargeParserProjectLimit (units/host_allocator.go:150,479-520; ABI 3.0): the allocator JOB lowers
+   * DistroQueueInfo.LengthWithDependenciesMet by the queued large-parser-project (S3 storage) tasks the global limit blocks,
+   * between reading the planner's queue info and calling the HostAllocator -- and the allocator clamps on exactly that field
+   * (utilization_based_host_allocator.go:113-115). A batched tick hands the planner's device-resident info rows straight to
+   * the allocator, so the adjustment is applied here, per distro, to the value the clamp uses (distro_info is not modified):
+   *     limit <= 0 or num_queued_large_parser_project_tasks == 0      -> no change            (:481-488)
+   *     blocked = num_queued - max(0, limit - running);  blocked > 0  -> length_with_dependencies_met - blocked   (:500-507)
+   * A caller whose DistroQueueInfo was already adjusted by the Go job (the per-distro shim) passes limit 0. */
+  int32_t max_concurrent_large_parser_project_tasks; /* model.GetMaxConcurrentLargeParserProjTasks(config); <= 0 = no limit */
+  int32_t running_large_parser_project_tasks;        /* task.CountLargeParserProjectTasks(ctx)                              */
 } evg_alloc_input;
 
 typedef struct evg_alloc_output {
@@ -320,7 +339,7 @@ void* evg_host_alloc(evg_ctx* ctx, size_t bytes);
 void evg_host_free(evg_ctx* ctx, void* p);
 
 /* Measurement hook (ABI 1.2): when enabled, every plan call on `ctx` records a HIP event right before and right after the
- * planner kernel (k_plan_distros; k_plan_allocate for the fused entry points) on the stream it is launched on; evg_last_plan_kernel_ms waits for the last call's stop
+ * planner kernel (k_plan_distros) on the stream it is launched on; evg_last_plan_kernel_ms waits for the last call's stop
  * event and returns the interval -- that kernel alone, without the large-distro kernels enqueued behind it. bench.py's
  * roofline block is measured with it. */
 int evg_profile_plan_kernel(evg_ctx* ctx, int enable);
@@ -329,10 +348,12 @@ int evg_last_plan_kernel_ms(evg_ctx* ctx, float* ms);
 /* Last error message of `ctx` (or of the failed evg_create when ctx == NULL). */
 const char* evg_last_error(const evg_ctx* ctx);
 
-/* Library/ABI version: (major << 16) | minor. MAJOR changes whenever a struct of this header changes size or layout (2.0:
- * evg_plan_input / evg_plan_output as they have been since 1.2 -- growing them under a MINOR bump was a mistake, a shim built
- * against 1.0 would have passed shorter structs); MINOR adds entry points only. */
-#define EVG_ABI_MAJOR 2
+/* Library/ABI version: (major << 16) | minor. MAJOR changes whenever a struct of this header changes size or layout, or an
+ * entry point changes or goes (2.0: evg_plan_input / evg_plan_output as they have been since 1.2; 3.0: evg_alloc_input grew the
+ * two large-parser-project fields, evg_plan_input.reserved0 became n_big_tier_distros, evg_plan_launch_hints returns that count,
+ * and the one-launch evg_plan_allocate[_range]_device entry points are gone -- measured no faster than the two calls for three
+ * rounds); MINOR adds entry points only. */
+#define EVG_ABI_MAJOR 3
 #define EVG_ABI_MINOR 0
 int32_t evg_abi_version(void);
 /* What a binding calls once at start-up with ITS compile-time view of the header: EVG_OK iff the library's major equals
@@ -352,9 +373,10 @@ int evg_take_device_status(evg_ctx* ctx);
 /* Host-side check of the layout contract; no GPU work. */
 int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len);
 
-/* Host side, no GPU work: the launch hint and the promises that hold for a batch whose pointers are HOST pointers -- what a
- * *_device caller copies into the evg_plan_input it passes with device pointers (max_distro_tasks, promises). ABI 1.2. */
-int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, int32_t* promises);
+/* Host side, no GPU work: the launch hints and the promises that hold for a batch whose pointers are HOST pointers -- what a
+ * *_device caller copies into the evg_plan_input it passes with device pointers (max_distro_tasks, promises,
+ * n_big_tier_distros). ABI 3.0. */
+int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, int32_t* promises, int32_t* n_big_tier_distros);
 
 /* Device self-test of the planner's scoring arithmetic: runs unitInfo.value() (planner.go:209-300) over `n_cases`
  * generated inputs twice -- the kernels' fast exact form and a statement that follows the Go code step by step (IEEE fp64
@@ -397,20 +419,6 @@ int evg_allocate_hosts_device(evg_ctx* ctx, const evg_alloc_input* in, const evg
 /* The allocator for distros [d_begin, d_end) of the batch only (see evg_plan_distro_range_device). ABI 1.1. */
 int evg_allocate_host_range_device(evg_ctx* ctx, const evg_alloc_input* in, const evg_alloc_output* out,
                                    int32_t d_begin, int32_t d_end, void* hip_stream);
-
-/* The batched tick in one launch: evg_plan_distros_device followed by evg_allocate_hosts_device for the same batch,
- * fused -- every distro's planning workgroup finishes with that distro's UtilizationBasedHostAllocator pass, so the
- * queue info never round-trips through a second kernel and the host rows are fetched behind the planner's compute.
- * `ain->distro_info`, `ain->group_info`, `ain->tg_off` and `ain->now_ns` are ignored: the allocator consumes
- * out->distro_info / out->group_info of this very call (what units/host_allocator.go:144 reads back from the
- * task_queues document the planner persisted) and writes count_free / count_required into out->group_info.
- * Results are identical to the two separate calls. Device pointers; enqueued on hip_stream. */
-int evg_plan_allocate_device(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out,
-                             const evg_alloc_input* ain, const evg_alloc_output* aout, void* hip_stream);
-/* The same for distros [d_begin, d_end) of a batch that is resident as a whole (see evg_plan_distro_range_device). ABI 1.2. */
-int evg_plan_allocate_range_device(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_output* out,
-                                   const evg_alloc_input* alloc_in, const evg_alloc_output* alloc_out, int32_t d_begin,
-                                   int32_t d_end, void* hip_stream);
 
 /* capTaskQueueLength (scheduler/task_queue_persister.go:66-83) for all D distros: cut[d] = number of
  * leading queue positions of distro d to persist for limit max_scheduled (<= 0 disables). The

@@ -980,6 +980,28 @@ int evg_oracle_plan_distro_range(const evg_plan_input* in, const evg_plan_output
 }
 
 // Distros [d_lo, d_hi) only (d_hi < 0: all): the allocator job is per distro too (units/host_allocator.go:56-62).
+// adjustForLargeParserProjectLimit  units/host_allocator.go:479-520: reduces the effective queue length when the max concurrent
+// large parser project task limit is hit. limit = model.GetMaxConcurrentLargeParserProjTasks(config), currentlyRunning =
+// task.CountLargeParserProjectTasks(ctx) -- both global, fetched by the allocator job; the DB error branch (:492-499) returns
+// info unchanged and has no counterpart here.
+static DistroQueueInfo adjustForLargeParserProjectLimit(DistroQueueInfo info, int NumQueuedLargeParserProjectTasks, int limit,
+                                                        int currentlyRunning) {
+  if (NumQueuedLargeParserProjectTasks == 0) return info;  // :481-483
+  if (limit <= 0) return info;                             // :485-488
+  const int remainingCapacity = std::max(0, limit - currentlyRunning);  // :501
+  const int blocked = NumQueuedLargeParserProjectTasks - remainingCapacity;
+  if (blocked <= 0) return info;                           // :503-506
+  info.LengthWithDependenciesMet -= blocked;               // :508
+  return info;
+}
+// The reference's own two vectors (units/host_allocator_test.go:245-300) through the function above; returns the adjusted
+// LengthWithDependenciesMet.
+int evg_oracle_adjust_large_parser(int length_with_dependencies_met, int num_queued, int limit, int running) {
+  DistroQueueInfo info;
+  info.LengthWithDependenciesMet = length_with_dependencies_met;
+  return adjustForLargeParserProjectLimit(info, num_queued, limit, running).LengthWithDependenciesMet;
+}
+
 int evg_oracle_allocate_host_range(const evg_alloc_input* in, const evg_alloc_output* out, int d_lo, int d_hi);
 int evg_oracle_allocate_hosts(const evg_alloc_input* in, const evg_alloc_output* out) { return evg_oracle_allocate_host_range(in, out, 0, -1); }
 int evg_oracle_allocate_host_range(const evg_alloc_input* in, const evg_alloc_output* out, int d_lo, int d_hi) {
@@ -1010,6 +1032,9 @@ int evg_oracle_allocate_host_range(const evg_alloc_input* in, const evg_alloc_ou
     for (int32_t k = in->tg_off[d]; k < in->tg_off[d + 1]; k++)
       if (in->group_info[in->n_distros + k].present)
         dqi.TaskGroupInfos.push_back(load_group(in->group_info[in->n_distros + k], k));
+    // units/host_allocator.go:150: the job adjusts the info it read back before it calls the allocator (:183-188)
+    dqi = adjustForLargeParserProjectLimit(dqi, di.num_queued_large_parser_project_tasks, in->max_concurrent_large_parser_project_tasks,
+                                           in->running_large_parser_project_tasks);
     int nNew = 0, nFree = 0, err = 0;
     UtilizationBasedHostAllocator(distro, hosts, &dqi, in->now_ns, &nNew, &nFree, &err);
     out->new_hosts[d] = nNew;

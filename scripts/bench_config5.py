@@ -11,11 +11,11 @@ D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 b = gen.generate(gen.config(5, n_tasks=n, n_distros=D))
 ctx = native.Context(0)
 pool = resident.ResidentPool(ctx, b, torch.device("cuda:0"))
-pool.step(fused=False); torch.cuda.synchronize()
+pool.step(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 K = int(sys.argv[sys.argv.index('--steps') + 1]) if '--steps' in sys.argv else 3
 for _ in range(K):
-    pool.step(fused=False)
+    pool.step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 print("config-5 share: %d tasks x %d distros (%d edges): %.3f ms per step = %.1f M tasks/s on one GPU" % (b.n_tasks, b.n_distros, b.n_edges, dt * 1e3, b.n_tasks / dt / 1e6))

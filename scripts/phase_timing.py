@@ -40,12 +40,12 @@ def main():
     ts = torch.zeros(batch.n_distros * 16, dtype=torch.int64, device=dev)
     lib.evg_dbg_phase_buffer(ctx.h, ts.data_ptr())
     pool = resident.ResidentPool(ctx, batch, dev, breakdown=False, n_units=False)
-    fused = os.environ.get("FUSED", "0") == "1" and pool.has_hosts
+    fused = False  # (the one-launch plan + allocate kernel is gone: ABI 3.0)
     ts2 = torch.zeros(batch.n_distros * 16, dtype=torch.int64, device=dev)
     lib.evg_dbg_alloc_phase_buffer.argtypes = [C.c_void_p, C.c_void_p]
     lib.evg_dbg_alloc_phase_buffer(ctx.h, ts2.data_ptr())
     for _ in range(5):
-        pool.step(fused=True) if fused else pool.plan()
+        pool.plan()
     torch.cuda.synchronize()
     if fused:
         tt = ts.cpu().numpy().reshape(-1, 16)

@@ -16,7 +16,7 @@ cases += [gen.GenConfig(1_000_000, 512, gen.SEED_BASE + 200, dag_depth=8, tg_fra
 for cfg in cases:
     b = gen.generate(cfg)
     pool = resident.ResidentPool(ctx, b, dev, breakdown=False, n_units=False, units=True)  # the drop-in configuration: unit rows
-    pool.step(fused=False)
+    pool.step()
     got, ga = pool.plan_result(), pool.alloc_result()
     t0 = time.perf_counter()
     want = o.plan(b, breakdown=True, n_units=False)

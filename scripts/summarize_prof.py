@@ -51,9 +51,6 @@ def main():
         if "k_plan_distros<false, false>" in k and "hbm_bytes_per_launch_corrected" in v:
             out["k_plan_distros_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch_corrected"]
             out["k_plan_distros_hbm_bytes_per_launch_raw"] = v["hbm_bytes_per_launch_raw"]
-        if "k_plan_allocate<false, false>" in k and "hbm_bytes_per_launch_corrected" in v:  # the fused tick's kernel
-            out["k_plan_allocate_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch_corrected"]
-            out["k_plan_allocate_hbm_bytes_per_launch_raw"] = v["hbm_bytes_per_launch_raw"]
     json.dump(out, open(os.path.join(d, tag + "-pmc.json"), "w"), indent=1)
 
 

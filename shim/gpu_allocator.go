@@ -166,7 +166,9 @@ func allocateBatch(ctx context.Context, datas []*HostAllocatorData) ([]allocResu
 				if t := running[eh.RunningTask]; t != nil {
 					f |= C.EVG_HF_RUNNING_FOUND
 					st := t.FetchExpectedDuration(ctx) // :342-344
-					hStart[h], hExp[h], hDev[h] = C.int64_t(t.StartTime.UnixNano()), C.int64_t(st.Average), C.int64_t(st.StdDev)
+					// unixNS: a Go-zero StartTime (dispatched, not started; a field lost in decoding) is EVG_TIME_GO_ZERO, so that the
+					// library's saturating time_sub gives what time.Since(t.StartTime) gives (:345); UnixNano() of it is undefined
+					hStart[h], hExp[h], hDev[h] = unixNS(t.StartTime), C.int64_t(st.Average), C.int64_t(st.StdDev)
 				}
 			}
 			hFlags[h] = C.uint8_t(f)
@@ -175,11 +177,15 @@ func allocateBatch(ctx context.Context, datas []*HostAllocatorData) ([]allocResu
 	}
 	hostOff[D], tgOff[D] = C.int32_t(h), C.int32_t(key)
 
-	in := C.evg_alloc_input{n_distros: C.int32_t(D), n_task_groups: C.int32_t(key), params: &params[0], host_off: &hostOff[0], tg_off: &tgOff[0],
-		distro_info: &distroInfo[0], group_info: &groupInfo[0], now_ns: C.int64_t(now.UnixNano())}
-	in.hosts = C.evg_host_soa{n_hosts: C.int32_t(nHosts), flags: &hFlags[0], tg_key: &hKey[0], start_ts_ns: &hStart[0],
-		expected_duration_ns: &hExp[0], duration_stddev_ns: &hDev[0]}
-	out := C.evg_alloc_output{new_hosts: &newHosts[0], free_hosts: &freeHosts[0], status: &status[0]}
+	// ptr() (gpu_planner.go), not &col[0]: the host columns are EMPTY for a distro without hosts -- the case in which the
+	// allocator has to spawn some (NoExistingHosts, utilization_based_host_allocator_test.go:226-250).
+	// max_concurrent_large_parser_project_tasks stays 0 (no limit): units/host_allocator.go:150 has already run
+	// adjustForLargeParserProjectLimit on data.DistroQueueInfo before it calls the HostAllocator.
+	in := C.evg_alloc_input{n_distros: C.int32_t(D), n_task_groups: C.int32_t(key), params: ptr(params), host_off: ptr(hostOff), tg_off: ptr(tgOff),
+		distro_info: ptr(distroInfo), group_info: ptr(groupInfo), now_ns: C.int64_t(now.UnixNano())}
+	in.hosts = C.evg_host_soa{n_hosts: C.int32_t(nHosts), flags: ptr(hFlags), tg_key: ptr(hKey), start_ts_ns: ptr(hStart),
+		expected_duration_ns: ptr(hExp), duration_stddev_ns: ptr(hDev)}
+	out := C.evg_alloc_output{new_hosts: ptr(newHosts), free_hosts: ptr(freeHosts), status: ptr(status)}
 	if rc := C.evg_allocate_hosts(g.c, &in, &out); rc != C.EVG_OK {
 		return nil, errors.Errorf("evg_allocate_hosts: %s (%d)", C.GoString(C.evg_last_error(g.c)), int(rc))
 	}

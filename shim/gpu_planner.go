@@ -133,6 +133,11 @@ func carveSlice[T any](g *gpuCtx, n int) []T {
 	return unsafe.Slice((*T)(g.carve(n, unsafe.Sizeof(z))), n)
 }
 
+// ptr is the address a C struct field gets for a carved column: the slice's data pointer, valid (and inside the arena) even
+// when the slice is EMPTY -- a queue without dependencies, a distro without hosts, an empty queue. Never &s[0]: Go
+// bounds-checks the index under the & and panics on a zero-length slice (the spare element carve() adds lies past len).
+func ptr[T any](s []T) *T { return unsafe.SliceData(s) }
+
 // ---- small conversions ----------------------------------------------------------------------------------------------
 
 // unixNS maps a time.Time onto the ABI's clock: Go's zero Time (Time.IsZero) is EVG_TIME_GO_ZERO, everything else Unix
@@ -339,17 +344,18 @@ func planBatch(ctx context.Context, ds []*distro.Distro, queues [][]task.Task) (
 			e += len(q[i].DependsOn)
 		}
 	}
-	// dependencies that are in none of the queues: fetched once, before packing
+	// Dependencies that are not in the SAME distro's queue: fetched once, before packing. "In the queue" is per distro (the
+	// planner's cache and GetDistroQueueInfo's depCache hold one distro's tasks, planner.go:453, scheduler.go:62-65): a
+	// dependency that sits only in ANOTHER distro's queue of this batch is an out-of-queue dependency here and needs its
+	// fetched state like any other.
 	var outside []string
 	{
-		inQueue := make(map[string]struct{}, n)
+		seen := map[string]struct{}{}
 		for _, q := range queues {
+			inQueue := make(map[string]struct{}, len(q))
 			for i := range q {
 				inQueue[q[i].Id] = struct{}{}
 			}
-		}
-		seen := map[string]struct{}{}
-		for _, q := range queues {
 			for i := range q {
 				for _, dep := range q[i].DependsOn {
 					if _, ok := inQueue[dep.TaskId]; ok {
@@ -457,14 +463,16 @@ func planBatch(ctx context.Context, ds []*distro.Distro, queues [][]task.Task) (
 	distroInfo, groupInfo := carveSlice[C.evg_distro_info](g, D), carveSlice[C.evg_group_info](g, D+nTG)
 
 	in := C.evg_plan_input{n_distros: C.int32_t(D), n_task_groups: C.int32_t(nTG), n_versions: C.int32_t(nVer),
-		distros: &params[0], task_off: &taskOff[0], tg_off: &tgOff[0], ver_off: &verOff[0], now_ns: C.int64_t(now.UnixNano())}
+		distros: ptr(params), task_off: ptr(taskOff), tg_off: ptr(tgOff), ver_off: ptr(verOff), now_ns: C.int64_t(now.UnixNano())}
+	// ptr(), not &col[0]: any of these columns can be empty (e == 0 for a queue without DependsOn -- most of planner_test.go --
+	// and n == 0 for an empty queue, which scheduler/wrapper.go:107 still hands to PrioritizeTasks)
 	in.tasks = C.evg_task_soa{n_tasks: C.int32_t(n), n_edges: C.int32_t(e),
-		priority: &priority[0], expected_duration_ns: &expDur[0], queue_ts_ns: &queueTS[0], scheduled_ts_ns: &schedTS[0],
-		deps_met_ts_ns: &metTS[0], num_dependents: &numDep[0], task_group_order: &tgOrder[0], task_group_max_hosts: &tgMaxHosts[0],
-		tg_key: &tgKey[0], version_key: &verKey[0], flags: &flags[0], dep_off: &depOff[0], dep_idx: &depIdx[0], dep_info: &depInfo[0],
-		dep_finished_ts_ns: &depFin[0]}
-	out := C.evg_plan_output{order: &order[0], deps_met: &met[0], wait_ns: &wait[0], distro_info: &distroInfo[0], group_info: &groupInfo[0],
-		unit_of_task: &unitOf[0], unit_breakdown: &unitRows[0]} // breakdown (rows by task) and n_units stay NULL
+		priority: ptr(priority), expected_duration_ns: ptr(expDur), queue_ts_ns: ptr(queueTS), scheduled_ts_ns: ptr(schedTS),
+		deps_met_ts_ns: ptr(metTS), num_dependents: ptr(numDep), task_group_order: ptr(tgOrder), task_group_max_hosts: ptr(tgMaxHosts),
+		tg_key: ptr(tgKey), version_key: ptr(verKey), flags: ptr(flags), dep_off: ptr(depOff), dep_idx: ptr(depIdx), dep_info: ptr(depInfo),
+		dep_finished_ts_ns: ptr(depFin)}
+	out := C.evg_plan_output{order: ptr(order), deps_met: ptr(met), wait_ns: ptr(wait), distro_info: ptr(distroInfo), group_info: ptr(groupInfo),
+		unit_of_task: ptr(unitOf), unit_breakdown: ptr(unitRows)} // breakdown (rows by task) and n_units stay NULL
 	// Everything the structs point at is C memory (the arena): nothing to pin. (With Go slices instead:
 	// var pin runtime.Pinner; pin.Pin(&col[0]) for every column; defer pin.Unpin().)
 	var pin runtime.Pinner

@@ -65,6 +65,21 @@ static F sym(void* h, const char* name) {
   return f;
 }
 
+// A Go slice as the shim sees it: indexing is bounds-checked against LEN (Go panics on s[i] with i >= len(s) -- also under
+// an &, and also when capacity or the arena would allow it), and the only way to the data pointer is ptr() == unsafe.SliceData.
+// With raw pointers the twin could not see the shim taking &col[0] of an empty column (zero hosts, zero edges, an empty queue).
+template <class T>
+struct GoSlice {
+  T* p = nullptr;
+  size_t n = 0;
+  T& operator[](size_t i) const {
+    if (i >= n) throw std::out_of_range("runtime error: index out of range [" + std::to_string(i) + "] with length " + std::to_string(n));
+    return p[i];
+  }
+};
+template <class T>
+static T* ptr(const GoSlice<T>& s) { return s.p; }  // unsafe.SliceData(s): valid for an empty slice too
+
 // ---- gpuCtx / gpuCtxPool (gpu_planner.go) -----------------------------------------------------------------------------
 struct gpuCtx {
   evg_ctx* c = nullptr;
@@ -91,7 +106,7 @@ struct gpuCtx {
     return p;
   }
   template <class T>
-  T* carveSlice(size_t n) { return (T*)carve(n, sizeof(T)); }
+  GoSlice<T> carveSlice(size_t n) { return GoSlice<T>{(T*)carve(n, sizeof(T)), n}; }
 };
 static gpuCtx g_ctx;  // the pool hands out one context; one goroutine here
 static bool g_abi_checked = false;
@@ -142,7 +157,7 @@ static uint8_t depRequired(const Task& t, const std::string& id) {
   }
   return 3;
 }
-static SortingValueBreakdown breakdownOfUnit(const int64_t* ub, int u, int nSlots) {
+static SortingValueBreakdown breakdownOfUnit(const GoSlice<int64_t>& ub, int u, int nSlots) {
   auto f = [&](int k) { return ub[(size_t)k * nSlots + u]; };
   SortingValueBreakdown b;
   b.TaskGroupLength = f(EVG_BD_TASK_GROUP_LENGTH); b.TotalValue = f(EVG_BD_TOTAL_VALUE);
@@ -160,7 +175,7 @@ static Time depsMetTime(const Task& t, Time now) {  // Task.setDependenciesMetTi
     if (!IsZeroTime(dep.FinishedAt) && dep.FinishedAt > met) met = dep.FinishedAt;
   return IsZeroTime(met) ? now : met;
 }
-static DistroQueueInfo queueInfoFromRows(const evg_distro_info* di, const evg_group_info* gi, int d, int D, const int32_t* tgOff,
+static DistroQueueInfo queueInfoFromRows(const GoSlice<evg_distro_info>& di, const GoSlice<evg_group_info>& gi, int d, int D, const GoSlice<int32_t>& tgOff,
                                          const std::vector<std::string>& tgNames) {
   const evg_distro_info& i = di[d];
   DistroQueueInfo info;
@@ -204,17 +219,17 @@ static PlanOut planBatch(const std::vector<const Distro*>& ds, const std::vector
                        3 * (size_t)(D + 1) * 4 + (size_t)n * (4 + 1 + 8 + 4) + maxSlots * EVG_BREAKDOWN_FIELDS * 8 + (size_t)D * sizeof(evg_distro_info) +
                        (size_t)(D + n) * sizeof(evg_group_info) + 64 * 40 + 32 * 16;
   g->reserve(bytes);
-  int64_t *priority = g->carveSlice<int64_t>(n), *expDur = g->carveSlice<int64_t>(n), *queueTS = g->carveSlice<int64_t>(n);
-  int64_t *schedTS = g->carveSlice<int64_t>(n), *metTS = g->carveSlice<int64_t>(n);
-  int32_t *numDep = g->carveSlice<int32_t>(n), *tgOrder = g->carveSlice<int32_t>(n), *tgMaxHosts = g->carveSlice<int32_t>(n);
-  int32_t *tgKey = g->carveSlice<int32_t>(n), *verKey = g->carveSlice<int32_t>(n);
-  uint16_t* flags = g->carveSlice<uint16_t>(n);
-  int32_t* depOff = g->carveSlice<int32_t>(n + 1);
-  int32_t* depIdx = g->carveSlice<int32_t>(e);
-  uint8_t* depInfo = g->carveSlice<uint8_t>(e);
-  int64_t* depFin = g->carveSlice<int64_t>(e);
-  evg_distro_params* params = g->carveSlice<evg_distro_params>(D);
-  int32_t *taskOff = g->carveSlice<int32_t>(D + 1), *tgOff = g->carveSlice<int32_t>(D + 1), *verOff = g->carveSlice<int32_t>(D + 1);
+  auto priority = g->carveSlice<int64_t>(n), expDur = g->carveSlice<int64_t>(n), queueTS = g->carveSlice<int64_t>(n);
+  auto schedTS = g->carveSlice<int64_t>(n), metTS = g->carveSlice<int64_t>(n);
+  auto numDep = g->carveSlice<int32_t>(n), tgOrder = g->carveSlice<int32_t>(n), tgMaxHosts = g->carveSlice<int32_t>(n);
+  auto tgKey = g->carveSlice<int32_t>(n), verKey = g->carveSlice<int32_t>(n);
+  auto flags = g->carveSlice<uint16_t>(n);
+  auto depOff = g->carveSlice<int32_t>(n + 1);
+  auto depIdx = g->carveSlice<int32_t>(e);
+  auto depInfo = g->carveSlice<uint8_t>(e);
+  auto depFin = g->carveSlice<int64_t>(e);
+  auto params = g->carveSlice<evg_distro_params>(D);
+  auto taskOff = g->carveSlice<int32_t>(D + 1), tgOff = g->carveSlice<int32_t>(D + 1), verOff = g->carveSlice<int32_t>(D + 1);
 
   std::vector<std::string> tgNames;
   int nTG = 0, nVer = 0, row = 0, edge = 0;
@@ -271,24 +286,25 @@ static PlanOut planBatch(const std::vector<const Distro*>& ds, const std::vector
   taskOff[D] = row; tgOff[D] = nTG; verOff[D] = nVer;
 
   const int nSlots = n + nTG + nVer;
-  int32_t *order = g->carveSlice<int32_t>(n), *unitOf = g->carveSlice<int32_t>(n);
-  uint8_t* met = g->carveSlice<uint8_t>(n);
-  int64_t* wait = g->carveSlice<int64_t>(n);
-  int64_t* unitRows = g->carveSlice<int64_t>((size_t)nSlots * EVG_BREAKDOWN_FIELDS);
-  evg_distro_info* distroInfo = g->carveSlice<evg_distro_info>(D);
-  evg_group_info* groupInfo = g->carveSlice<evg_group_info>(D + nTG);
+  auto order = g->carveSlice<int32_t>(n), unitOf = g->carveSlice<int32_t>(n);
+  auto met = g->carveSlice<uint8_t>(n);
+  auto wait = g->carveSlice<int64_t>(n);
+  auto unitRows = g->carveSlice<int64_t>((size_t)nSlots * EVG_BREAKDOWN_FIELDS);
+  auto distroInfo = g->carveSlice<evg_distro_info>(D);
+  auto groupInfo = g->carveSlice<evg_group_info>(D + nTG);
 
   evg_plan_input in{};
   in.n_distros = D; in.n_task_groups = nTG; in.n_versions = nVer;
-  in.distros = params; in.task_off = taskOff; in.tg_off = tgOff; in.ver_off = verOff; in.now_ns = now;
+  // ptr(), not &col[0]: any of these columns can be empty (e == 0: no DependsOn anywhere; n == 0: an empty queue)
+  in.distros = ptr(params); in.task_off = ptr(taskOff); in.tg_off = ptr(tgOff); in.ver_off = ptr(verOff); in.now_ns = now;
   in.tasks.n_tasks = n; in.tasks.n_edges = e;
-  in.tasks.priority = priority; in.tasks.expected_duration_ns = expDur; in.tasks.queue_ts_ns = queueTS; in.tasks.scheduled_ts_ns = schedTS;
-  in.tasks.deps_met_ts_ns = metTS; in.tasks.num_dependents = numDep; in.tasks.task_group_order = tgOrder; in.tasks.task_group_max_hosts = tgMaxHosts;
-  in.tasks.tg_key = tgKey; in.tasks.version_key = verKey; in.tasks.flags = flags; in.tasks.dep_off = depOff; in.tasks.dep_idx = depIdx;
-  in.tasks.dep_info = depInfo; in.tasks.dep_finished_ts_ns = depFin;
+  in.tasks.priority = ptr(priority); in.tasks.expected_duration_ns = ptr(expDur); in.tasks.queue_ts_ns = ptr(queueTS); in.tasks.scheduled_ts_ns = ptr(schedTS);
+  in.tasks.deps_met_ts_ns = ptr(metTS); in.tasks.num_dependents = ptr(numDep); in.tasks.task_group_order = ptr(tgOrder); in.tasks.task_group_max_hosts = ptr(tgMaxHosts);
+  in.tasks.tg_key = ptr(tgKey); in.tasks.version_key = ptr(verKey); in.tasks.flags = ptr(flags); in.tasks.dep_off = ptr(depOff); in.tasks.dep_idx = ptr(depIdx);
+  in.tasks.dep_info = ptr(depInfo); in.tasks.dep_finished_ts_ns = ptr(depFin);
   evg_plan_output out{};
-  out.order = order; out.deps_met = met; out.wait_ns = wait; out.distro_info = distroInfo; out.group_info = groupInfo;
-  out.unit_of_task = unitOf; out.unit_breakdown = unitRows;  // breakdown (rows by task) and n_units stay NULL
+  out.order = ptr(order); out.deps_met = ptr(met); out.wait_ns = ptr(wait); out.distro_info = ptr(distroInfo); out.group_info = ptr(groupInfo);
+  out.unit_of_task = ptr(unitOf); out.unit_breakdown = ptr(unitRows);  // breakdown (rows by task) and n_units stay NULL
 
   const int rc = L.hip ? L.plan_distros(g->c, &in, &out) : L.o_plan(&in, &out);
   L.calls_plan++;
@@ -326,15 +342,15 @@ static std::vector<allocResult> allocateBatch(std::vector<HostAllocatorData*>& d
   const size_t bytes = (size_t)D * (sizeof(evg_alloc_params) + sizeof(evg_distro_info) + 3 * 4) + 2 * (size_t)(D + 1) * 4 + (size_t)nHosts * (1 + 4 + 3 * 8) +
                        (size_t)(D + nGroups) * sizeof(evg_group_info) + 64 * 20 + 48 * 16;
   g->reserve(bytes);
-  evg_alloc_params* params = g->carveSlice<evg_alloc_params>(D);
-  int32_t *hostOff = g->carveSlice<int32_t>(D + 1), *tgOff = g->carveSlice<int32_t>(D + 1);
-  uint8_t* hFlags = g->carveSlice<uint8_t>(nHosts);
-  int32_t* hKey = g->carveSlice<int32_t>(nHosts);
-  int64_t *hStart = g->carveSlice<int64_t>(nHosts), *hExp = g->carveSlice<int64_t>(nHosts), *hDev = g->carveSlice<int64_t>(nHosts);
-  evg_distro_info* distroInfo = g->carveSlice<evg_distro_info>(D);
-  evg_group_info* groupInfo = g->carveSlice<evg_group_info>(D + nGroups);
-  std::memset(groupInfo, 0, sizeof(evg_group_info) * (size_t)(D + nGroups));
-  int32_t *newHosts = g->carveSlice<int32_t>(D), *freeHosts = g->carveSlice<int32_t>(D), *status = g->carveSlice<int32_t>(D);
+  auto params = g->carveSlice<evg_alloc_params>(D);
+  auto hostOff = g->carveSlice<int32_t>(D + 1), tgOff = g->carveSlice<int32_t>(D + 1);
+  auto hFlags = g->carveSlice<uint8_t>(nHosts);
+  auto hKey = g->carveSlice<int32_t>(nHosts);
+  auto hStart = g->carveSlice<int64_t>(nHosts), hExp = g->carveSlice<int64_t>(nHosts), hDev = g->carveSlice<int64_t>(nHosts);
+  auto distroInfo = g->carveSlice<evg_distro_info>(D);
+  auto groupInfo = g->carveSlice<evg_group_info>(D + nGroups);
+  for (size_t i = 0; i < groupInfo.n; i++) groupInfo[i] = evg_group_info{};
+  auto newHosts = g->carveSlice<int32_t>(D), freeHosts = g->carveSlice<int32_t>(D), status = g->carveSlice<int32_t>(D);
 
   std::vector<std::vector<int>> groupRow((size_t)D);
   int h = 0, key = 0;
@@ -390,7 +406,7 @@ static std::vector<allocResult> allocateBatch(std::vector<HostAllocatorData*>& d
         if (rt != running.end()) {
           f |= EVG_HF_RUNNING_FOUND;
           const auto st = FetchExpectedDuration(rt->second, now);
-          hStart[h] = rt->second.StartTime; hExp[h] = st.first; hDev[h] = st.second;
+          hStart[h] = rt->second.StartTime; hExp[h] = st.first; hDev[h] = st.second;  // unixNS(t.StartTime): the structs hold it already
         }
       }
       hFlags[h] = f;
@@ -400,11 +416,13 @@ static std::vector<allocResult> allocateBatch(std::vector<HostAllocatorData*>& d
   hostOff[D] = h; tgOff[D] = key;
 
   evg_alloc_input in{};
-  in.n_distros = D; in.n_task_groups = key; in.params = params; in.host_off = hostOff; in.tg_off = tgOff;
-  in.distro_info = distroInfo; in.group_info = groupInfo; in.now_ns = now;
-  in.hosts.n_hosts = nHosts; in.hosts.flags = hFlags; in.hosts.tg_key = hKey; in.hosts.start_ts_ns = hStart;
-  in.hosts.expected_duration_ns = hExp; in.hosts.duration_stddev_ns = hDev;
-  evg_alloc_output out{newHosts, freeHosts, status};
+  // ptr(), not &col[0]: the host columns are empty for a distro without hosts. max_concurrent_large_parser_project_tasks stays
+  // 0: the allocator job has already adjusted data.DistroQueueInfo (units/host_allocator.go:150)
+  in.n_distros = D; in.n_task_groups = key; in.params = ptr(params); in.host_off = ptr(hostOff); in.tg_off = ptr(tgOff);
+  in.distro_info = ptr(distroInfo); in.group_info = ptr(groupInfo); in.now_ns = now;
+  in.hosts.n_hosts = nHosts; in.hosts.flags = ptr(hFlags); in.hosts.tg_key = ptr(hKey); in.hosts.start_ts_ns = ptr(hStart);
+  in.hosts.expected_duration_ns = ptr(hExp); in.hosts.duration_stddev_ns = ptr(hDev);
+  evg_alloc_output out{ptr(newHosts), ptr(freeHosts), ptr(status)};
   const int rc = L.hip ? L.allocate_hosts(g->c, &in, &out) : L.o_alloc(&in, &out);
   L.calls_alloc++;
   if (rc != EVG_OK) throw std::runtime_error(std::string("evg_allocate_hosts: ") + (L.hip ? L.last_error(g->c) : "oracle"));
@@ -551,6 +569,73 @@ static void run_twin_specifics() {
          d3.DistroQueueInfo.TaskGroupInfos[0].CountRequired, r3.newHosts);
 }
 
+// The cases the reviewer of round 3 found the Go files panicking on, by name: every column that can be EMPTY.
+static void run_empty_column_cases() {
+  Distro d;
+  d.Id = "d";
+  {  // ZeroEdges: no task has DependsOn (most of planner_test.go): depIdx / depInfo / depFin are empty
+    std::vector<Task> q(2);
+    q[0].Id = "a"; q[1].Id = "b"; q[1].Priority = 5;
+    const PlanOut po = planBatch({&d}, {&q}, NOW);
+    EXPECT(po.plans[0].size() == 2 && po.plans[0][0].Id == "b", "ZeroEdges: planned, the priority-5 task first");
+  }
+  {  // EmptyQueue: scheduler/wrapper.go:107 calls PrioritizeTasks even with no tasks; runTunablePlanner plans nothing and
+     // GetDistroQueueInfo of an empty plan is a zero info with the default 30 min threshold (scheduler.go:57-178, distro.go:448-475)
+    std::vector<Task> q;
+    const PlanOut po = planBatch({&d}, {&q}, NOW);
+    EXPECT(po.plans[0].empty(), "EmptyQueue: an empty plan");
+    EXPECT(po.infos[0].Length == 0 && po.infos[0].LengthWithDependenciesMet == 0 && po.infos[0].TaskGroupInfos.empty(), "EmptyQueue: a zero queue info");
+    EXPECT(po.infos[0].MaxDurationThreshold == 30 * Minute, "EmptyQueue: MaxDurationThreshold = MaxDurationPerDistroHost (%lld)",
+           (long long)po.infos[0].MaxDurationThreshold);
+  }
+  {  // EmptyQueue next to a full one in ONE batch
+    std::vector<Task> q0, q1(1);
+    q1[0].Id = "only";
+    Distro d2;
+    d2.Id = "d2";
+    const PlanOut po = planBatch({&d, &d2}, {&q0, &q1}, NOW);
+    EXPECT(po.plans[0].empty() && po.plans[1].size() == 1 && po.infos[1].Length == 1, "an empty and a one-task queue in one call");
+  }
+  {  // ZeroHosts: ExistingHosts == []host.Host{} -- NoExistingHosts (utilization_based_host_allocator_test.go:226-250): (2, 0)
+    HostAllocatorData data;
+    data.Distro.Id = "testDistro"; data.Distro.Provider = ProviderNameEc2Fleet;
+    data.Distro.HostAllocatorSettings.MinimumHosts = 0; data.Distro.HostAllocatorSettings.MaximumHosts = 50;
+    data.Distro.HostAllocatorSettings.FutureHostFraction = 0.5;
+    TaskGroupInfo gi; gi.Count = 5; gi.ExpectedDuration = 60 * Minute;  // one hour of queued work at a 30 min threshold = 2 hosts
+    data.DistroQueueInfo.Length = 5; data.DistroQueueInfo.LengthWithDependenciesMet = 5; data.DistroQueueInfo.MaxDurationThreshold = 30 * Minute;
+    data.DistroQueueInfo.ExpectedDuration = gi.ExpectedDuration;
+    data.DistroQueueInfo.TaskGroupInfos.push_back(gi);
+    std::vector<HostAllocatorData*> one{&data};
+    const allocResult r = allocateBatch(one, NOW, {})[0];
+    EXPECT(r.err.empty() && r.newHosts == 2 && r.freeHosts == 0, "ZeroHosts: (%d, %d) %s, want (2, 0)", r.newHosts, r.freeHosts, r.err.c_str());
+  }
+  {  // ZeroHosts and ZeroGroups: nothing queued, nothing running
+    HostAllocatorData data;
+    data.Distro.Id = "idle"; data.Distro.Provider = ProviderNameEc2Fleet; data.Distro.HostAllocatorSettings.MaximumHosts = 10;
+    data.Distro.HostAllocatorSettings.FutureHostFraction = 0.5;
+    data.DistroQueueInfo.MaxDurationThreshold = 30 * Minute;
+    std::vector<HostAllocatorData*> one{&data};
+    const allocResult r = allocateBatch(one, NOW, {})[0];
+    EXPECT(r.err.empty() && r.newHosts == 0 && r.freeHosts == 0, "an idle distro: (%d, %d) %s", r.newHosts, r.freeHosts, r.err.c_str());
+  }
+  {  // a dependency that sits only in ANOTHER distro's queue of the batch is out-of-queue for this distro: its fetched state counts
+    Distro d1, d2;
+    d1.Id = "d1"; d2.Id = "d2";
+    std::vector<Task> q1(1), q2(1);
+    q1[0].Id = "dep"; q1[0].DistroId = "d1"; q1[0].Status = "undispatched";
+    q2[0].Id = "t"; q2[0].DistroId = "d2";
+    Dependency dep; dep.TaskId = "dep"; dep.Status = AllStatuses;  // "*": met only if the dependency finished or is blocked
+    q2[0].DependsOn.push_back(dep);
+    const std::unordered_map<std::string, uint8_t> blocked{{"dep", (uint8_t)EVG_DEP_BLOCKED}};
+    std::vector<bool> inc{true, true};
+    const PlanOut po = planBatch({&d1, &d2}, {&q1, &q2}, NOW, blocked, &inc);
+    EXPECT(po.infos[1].LengthWithDependenciesMet == 1, "cross-distro dependency: its Blocked() state is fetched and satisfies \"*\" (%d)",
+           po.infos[1].LengthWithDependenciesMet);
+    const PlanOut po2 = planBatch({&d1, &d2}, {&q1, &q2}, NOW, {}, &inc);
+    EXPECT(po2.infos[1].LengthWithDependenciesMet == 0, "cross-distro dependency without a fetched state is MISSING: unmet");
+  }
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) {
     std::fprintf(stderr, "usage: %s oracle|hip <library path>\n", argv[0]);
@@ -575,6 +660,7 @@ int main(int argc, char** argv) {
     run_queue_info_cases(none);
     run_allocator_cases(none);
     run_twin_specifics();
+    run_empty_column_cases();
     if (L.hip && g_ctx.c) {
       if (g_ctx.arena) L.host_free(g_ctx.c, g_ctx.arena);
       L.destroy(g_ctx.c);

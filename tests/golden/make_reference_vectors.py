@@ -23,7 +23,7 @@ from tests.golden import fixture_io as F  # noqa: E402
 def main():
     out = {"source": "transcribed from /root/reference/scheduler/*_test.go; see tests/golden_cases.py for file:line",
            "now_ns": G.NOW, "unit_values": [], "queue_info": [], "calc_new_hosts": [list(map(int, c)) for c in G.CALC_NEW_HOSTS],
-           "allocator": [], "cap": []}
+           "allocator": [], "cap": [], "adjust_large_parser": [list(map(int, c)) for c in G.ADJUST_LARGE_PARSER]}
     for name, d, tasks, want, line in G.unit_value_cases():
         packed = S.pack_queues([(d, tasks)], G.NOW)
         out["unit_values"].append({"name": name, "ref": "scheduler/planner_test.go:%d" % line, "batch": F.batch_to_json(packed.batch),

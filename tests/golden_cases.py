@@ -147,6 +147,11 @@ CALC_NEW_HOSTS = [
     (80 * HOUR, 30 * MIN, 150, 0, 1, 1, True, 12),
 ]
 
+# ---- units/host_allocator_test.go:245-300  TestAdjustForLargeParserProjectLimit ---------------------------------------
+# (LengthWithDependenciesMet, NumQueuedLargeParserProjectTasks, MaxConcurrentLargeParserProjectTasks, running S3 tasks in the DB)
+#   -> result.LengthWithDependenciesMet;  :253-274 NoAdjustmentWhenLimitNotSaturated, :276-298 ReducesQueueLengthWhenLimitSaturated
+ADJUST_LARGE_PARSER = [(10, 5, 10, 2, 10), (10, 5, 5, 3, 7)]
+
 PROJECT = "testProject"
 
 

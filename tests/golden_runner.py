@@ -157,6 +157,23 @@ def check_in_place_group_counts(backend):
         assert by[""].CountFree == 0 and by[""].CountRequired == 0  # never written for ""
 
 
+def check_large_parser_limit(backend):
+    # units/host_allocator_test.go:245-300: adjustForLargeParserProjectLimit's two vectors, END TO END through the batched allocator
+    # -- a queue that wants far more hosts than it is long, so that the clamp of utilization_based_host_allocator.go:113-115 is
+    # what decides: newHostsNeeded == the (adjusted) LengthWithDependenciesMet
+    for length, queued, limit, running, want in G.ADJUST_LARGE_PARSER:
+        datas = []
+        for _ in range(3):  # a batch of three: the adjustment is per distro
+            q = S.DistroQueueInfo(Length=length, LengthWithDependenciesMet=length, NumQueuedLargeParserProjectTasks=queued,
+                                  MaxDurationThreshold=30 * S.MINUTE, ExpectedDuration=100 * 60 * S.MINUTE,
+                                  TaskGroupInfos=[S.TaskGroupInfo(Name="", Count=length, ExpectedDuration=100 * 60 * S.MINUTE)])
+            datas.append(S.HostAllocatorData(Distro=G.suite_distro(MaximumHosts=500), ExistingHosts=[], DistroQueueInfo=q))
+        datas[1].DistroQueueInfo.NumQueuedLargeParserProjectTasks = 0  # :481: nothing queued -> untouched
+        got = S.AllocateHosts(backend, datas, G.NOW, None, large_parser=(limit, running))
+        assert [g[0] for g in got] == [want, length, want], (got, want)
+        assert [g[0] for g in S.AllocateHosts(backend, datas, G.NOW, None)] == [length] * 3  # no limit configured (:486)
+
+
 def check_fuzz_invariants(backend, seed=1234, iters=200):
     # host_allocator_fuzzer_test.go:154-172: 0 <= newHosts <= queue length
     rng = np.random.default_rng(seed)

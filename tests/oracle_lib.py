@@ -101,10 +101,6 @@ class OracleRangeBackend:
         rc = lib().evg_oracle_allocate_host_range(C.byref(inp), C.byref(out), d_begin, d_end)
         assert rc == 0, rc
 
-    def plan_allocate_range_device(self, inp, out, ainp, aout, d_begin, d_end, stream=None):
-        self.plan_range_device(inp, out, d_begin, d_end)
-        self.allocate_range_device(ainp, aout, d_begin, d_end)
-
 
 class OracleBackend:
     """scheduler.Backend over the CPU oracle."""

@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-from evergreen_amd import gen, resident
+from evergreen_amd import abi, gen, resident
 from tests import compare
 
 PER_DISTRO = [3, 60, 500, 1500, 2040, 2047, 2048, 2049, 2100, 4096, 4100, 9000, 20000, 70000]
@@ -32,16 +32,19 @@ def run(ctx, oracle, device, seed, n_pools=None, seconds=None, max_tasks=400_000
         cfg = draw(rng, k, max_tasks, large_only)
         b = gen.generate(cfg)
         units = bool(rng.random() < 0.6)
-        fused = bool(rng.random() < 0.5)
+        hinted = bool(rng.random() < 0.6)  # without the tier hint the 2049..4096-task distros take the large-distro pipeline instead
         pool = resident.ResidentPool(ctx, b, device, breakdown=False, n_units=False, units=units)
-        pool.step(fused=fused)
+        if not hinted:
+            pool.inp.n_big_tier_distros = 0
+            pool.inp.promises &= ~abi.EVG_PROMISE_ALL_ON_LDS_TIERS
+        pool.step()
         got, ga = pool.plan_result(), pool.alloc_result()
         want = oracle.plan(b, breakdown=units, n_units=False)
         want.n_units = None
         if units:
             got.breakdown = got.expand_breakdown()  # rows by task from the rows by unit: compared field by field
         wa = oracle.allocate(b, want.distro_info, want.group_info)
-        tag = "%r units=%s one_launch=%s" % (cfg, units, fused)
+        tag = "%r units=%s big_tier_hint=%s" % (cfg, units, hinted)
         compare.assert_plan_equal(got, want, b, tag)
         compare.assert_alloc_equal(ga, wa, tag)
         compare.reference_validity(b, got)

@@ -149,22 +149,31 @@ def test_product_never_imports_the_oracle():
 def test_plan_launch_hints_on_host(lib):
     """evg_plan_launch_hints: host work only. EVG_PROMISE_ALL_ON_LDS_PATH holds exactly when every distro passes the planner
     kernel's own shape test (<= 2048 tasks, slots + edges inside the LDS budget, <= 1023 task groups) and no priority needs
-    more than 32 bits."""
+    more than 32 bits; EVG_PROMISE_ALL_ON_LDS_TIERS when every distro passes that or the 4096-task tier's, and
+    n_big_tier_distros counts the distros of the second kind."""
+    BOTH = abi.EVG_PROMISE_ALL_ON_LDS_PATH | abi.EVG_PROMISE_ALL_ON_LDS_TIERS
+
     def hints(b):
         inp = abi.make_plan_input(b)
-        mx, pr = C.c_int32(-1), C.c_int32(-1)
-        assert lib.evg_plan_launch_hints(C.byref(inp), C.byref(mx), C.byref(pr)) == abi.EVG_OK
-        return mx.value, pr.value
+        mx, pr, nb = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        assert lib.evg_plan_launch_hints(C.byref(inp), C.byref(mx), C.byref(pr), C.byref(nb)) == abi.EVG_OK
+        return mx.value, pr.value, nb.value
     b = gen.generate(gen.config(2))
-    assert hints(b) == (int(np.diff(b.task_off).max()), abi.EVG_PROMISE_ALL_ON_LDS_PATH)
-    b.cols["priority"][int(b.task_off[7]) + 5] = 2**31                       # one priority beyond int32: that distro leaves the path
-    assert hints(b)[1] == 0
+    assert hints(b) == (int(np.diff(b.task_off).max()), BOTH, 0)
+    b.cols["priority"][int(b.task_off[7]) + 5] = 2**31                       # one priority beyond int32: that distro leaves both tiers
+    assert hints(b)[1:] == (0, 0)
     b.cols["priority"][int(b.task_off[7]) + 5] = -(2**31)                    # the most negative int32 still fits
-    assert hints(b)[1] == abi.EVG_PROMISE_ALL_ON_LDS_PATH
-    big = gen.generate(gen.GenConfig(6000, 2, 5, with_hosts=False))          # 3000 tasks per distro: more than 2048
-    assert hints(big) == (3000, 0)
+    assert hints(b)[1] == BOTH
+    big = gen.generate(gen.GenConfig(6000, 2, 5, with_hosts=False))          # 3000 tasks per distro: the 4096-task tier's
+    assert hints(big) == (3000, abi.EVG_PROMISE_ALL_ON_LDS_TIERS, 2)
+    huge = gen.generate(gen.GenConfig(12_000, 2, 5, with_hosts=False))       # 6000 per distro: neither tier
+    assert hints(huge) == (6000, 0, 0)
+    mixed = gen.generate(gen.GenConfig(12_000, 4, 4243, skew=True, with_hosts=False))
+    n = np.diff(mixed.task_off)
+    assert hints(mixed)[2] <= int(((n > 2048) & (n <= 4096)).sum()) + int((n <= 2048).sum())
     edges = gen.generate(gen.GenConfig(4000, 2, 6, dag_depth=8, with_hosts=False))
     n_e = np.diff(edges.dep_off[edges.task_off])                             # 2000 tasks + many edges: the LDS budget decides
     S = np.diff(edges.task_off) + np.diff(edges.tg_off)
     fits = all(max(32 * ((s + 1) & ~1), 57344) + 2 * ((e + 7) & ~7) <= 79872 - 4096 for s, e in zip(S, n_e))
-    assert hints(edges)[1] == (abi.EVG_PROMISE_ALL_ON_LDS_PATH if fits else 0)
+    assert hints(edges)[1] == (BOTH if fits else abi.EVG_PROMISE_ALL_ON_LDS_TIERS)  # 2000 tasks always fit the CU's whole LDS
+    assert hints(edges)[2] == (0 if fits else sum(1 for s, e in zip(S, n_e) if max(32 * ((s + 1) & ~1), 57344) + 2 * ((e + 7) & ~7) > 79872 - 4096))

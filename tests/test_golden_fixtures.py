@@ -49,6 +49,14 @@ def test_oracle_reproduces_reference_vectors(oracle):
     _check_reference_vectors(oracle)
 
 
+def test_oracle_adjust_large_parser_vectors():
+    """units/host_allocator_test.go:245-300 from the committed fixture."""
+    L = oracle_lib.lib()
+    assert len(REF["adjust_large_parser"]) == 2
+    for length, queued, limit, running, want in REF["adjust_large_parser"]:
+        assert L.evg_oracle_adjust_large_parser(length, queued, limit, running) == want
+
+
 def test_oracle_calc_new_hosts_needed_vectors():
     L = oracle_lib.lib()
     for short, maxd, free, nlong, over, merge, down, want in REF["calc_new_hosts"]:

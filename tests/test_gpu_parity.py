@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("check", [
     R.check_unit_values, R.check_grouped_unit, R.check_dependency_first, R.check_task_plan_order, R.check_task_list,
     R.check_prepare, R.check_queue_info, R.check_distro_alias_order, R.check_allocator, R.check_calc_existing_free,
-    R.check_allocator_errors, R.check_in_place_group_counts], ids=lambda f: f.__name__)
+    R.check_allocator_errors, R.check_in_place_group_counts, R.check_large_parser_limit], ids=lambda f: f.__name__)
 def test_reference_golden_vectors(native_ctx, check):
     check(native_ctx)
 
@@ -231,28 +231,23 @@ def test_contract_violation_is_rejected(native_ctx):
                                   lambda: gen.generate(gen.GenConfig(60_000, 24, gen.SEED_BASE + 31, skew=True)),
                                   lambda: gen.generate(gen.GenConfig(3_000, 40, 321))], ids=["config2", "skewed-generic", "small"])
 @pytest.mark.parametrize("rich", [False, True], ids=["lean", "rich"])
-def test_fused_plan_allocate_entry_point(native_ctx, oracle, make, rich):
-    """evg_plan_allocate_device (one launch: planner + host allocator per distro) == the two separate calls == oracle."""
+def test_resident_tick_plan_then_allocate(native_ctx, oracle, make, rich):
+    """The device-resident tick -- evg_plan_distros_device, then evg_allocate_hosts_device on the info rows that never left the
+    device -- == oracle, CountFree / CountRequired written into the group rows included."""
     import torch
     from evergreen_amd import resident
     b = make()
     pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=rich, n_units=rich)
-    pool.step(fused=True)
+    pool.step()
     got, got_alloc = pool.plan_result(), pool.alloc_result()
     want = oracle.plan(b)
     want_alloc = oracle.allocate(b, want.distro_info, want.group_info)
     if not rich:
         want.breakdown, want.n_units = None, None
-    compare.assert_plan_equal(got, want, b, "fused")
-    compare.assert_alloc_equal(got_alloc, want_alloc, "fused")
+    compare.assert_plan_equal(got, want, b, "resident tick")
+    compare.assert_alloc_equal(got_alloc, want_alloc, "resident tick")
     for name in ("count_free", "count_required"):
         assert np.array_equal(got.group_info[name], want.group_info[name]), name
-    # and the unfused pair of calls on the same pool gives the same bytes
-    pool2 = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=rich, n_units=rich)
-    pool2.step(fused=False)
-    g2, a2 = pool2.plan_result(), pool2.alloc_result()
-    assert np.array_equal(g2.order, got.order) and np.array_equal(g2.group_info, got.group_info)
-    assert np.array_equal(a2.new_hosts, got_alloc.new_hosts) and np.array_equal(a2.free_hosts, got_alloc.free_hosts)
 
 
 def test_big_distros_generic_fast_sort(native_ctx, oracle):
@@ -271,7 +266,7 @@ def test_config5_per_gpu_share(native_ctx, oracle):
     from evergreen_amd import resident
     b = gen.generate(gen.config(5, n_tasks=1_250_000, n_distros=64))
     pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=False, n_units=False)
-    pool.step(fused=False)
+    pool.step()
     got, got_alloc = pool.plan_result(), pool.alloc_result()
     want = oracle.plan(b, breakdown=False, n_units=False)
     want.breakdown, want.n_units = None, None
@@ -291,7 +286,7 @@ def test_config5_full_10m_tasks_512_distros(native_ctx):
     b = gen.generate(gen.config(5))
     assert b.n_tasks == 10_000_000 and b.n_distros == 512
     pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=False, n_units=False, units=True)
-    pool.step(fused=False)
+    pool.step()
     got, got_alloc = pool.plan_result(), pool.alloc_result()
     del pool
     torch.cuda.empty_cache()
@@ -465,7 +460,7 @@ def test_promise_all_on_lds_path(native_ctx, oracle):
     for cfg, promised in ((gen.config(2), True), (gen.GenConfig(30_000, 6, 41, skew=True), False),
                           (gen.GenConfig(9_000, 5, 42, dag_depth=9, tg_fraction=0.5), None)):
         b = gen.generate(cfg)
-        mx, pr = native.launch_hints(b)
+        mx, pr, nb = native.launch_hints(b)
         if promised is not None:
             assert bool(pr & abi.EVG_PROMISE_ALL_ON_LDS_PATH) == promised, cfg
         pool = resident.ResidentPool(native_ctx, b, dev, breakdown=True)
@@ -474,10 +469,10 @@ def test_promise_all_on_lds_path(native_ctx, oracle):
         want = oracle.plan(b, n_units=False)
         want.n_units = None
         compare.assert_plan_equal(pool.plan_result(), want, b, "promise %r" % (cfg,))
-        pool.step(fused=True)  # plan + allocate in one launch: the allocator writes CountFree / CountRequired into the group rows
+        pool.step()  # plan + allocate: the allocator writes CountFree / CountRequired into the group rows
         want_alloc = oracle.allocate(b, want.distro_info, want.group_info)
-        compare.assert_plan_equal(pool.plan_result(), want, b, "promise, fused %r" % (cfg,))
-        compare.assert_alloc_equal(pool.alloc_result(), want_alloc, "promise, fused %r" % (cfg,))
+        compare.assert_plan_equal(pool.plan_result(), want, b, "promise, tick %r" % (cfg,))
+        compare.assert_alloc_equal(pool.alloc_result(), want_alloc, "promise, tick %r" % (cfg,))
     # a batch with a 2^31 priority: the host-pointer path works the promise out itself and must not skip the fallback
     b = gen.generate(gen.config(1))
     b.cols["priority"][3] = 2**40
@@ -590,3 +585,103 @@ def test_large_host_pointer_batch(native_ctx, oracle):
     got = native_ctx.plan(b, breakdown=False, n_units=False)  # pageable memory, no unit rows
     want.breakdown = None
     compare.assert_plan_equal(got, want, b, "large host batch, pageable")
+
+
+# ---- the 4096-task tier of the one-workgroup kernel (k_plan_distros_big) -----------------------------------------------------
+@pytest.mark.parametrize("n", [2049, 2050, 3000, 4095, 4096, 4097])
+def test_big_tier_boundaries(native_ctx, oracle, n):
+    """Distros of exactly n tasks either side of both tiers' limits (2048 | 2049 .. 4096 | 4097), plain and grouped-version
+    (every 4th distro), shallow and deep DAGs, few and many task groups: the host-pointer call (hints worked out by the library)
+    with TaskPlan.Len() (the big tier is off: RICH kernel + pipeline) and without (the big tier plans them) against the oracle."""
+    for k, (depth, tg) in enumerate(((3, 0.1), (8, 0.2), (2, 0.6), (1, 0.0))):
+        b = gen.generate(gen.GenConfig(n * 5, 5, 7100 + n + k, dag_depth=depth, tg_fraction=tg))
+        assert (np.diff(b.task_off) == n).all()
+        _full_compare(native_ctx, oracle, b, "big tier n=%d depth=%d tg=%.1f" % (n, depth, tg))
+
+
+def test_big_tier_beside_the_small_tier(native_ctx, oracle):
+    """BASELINE config 3 with eight distros grown to 4096 tasks and with one grown to 2049 (bench.py's `cliff` workloads), through the
+    device-resident tick: with the hints of evg_plan_launch_hints (both tiers, nothing behind them: EVG_PROMISE_ALL_ON_LDS_TIERS),
+    with the count but no promise (the pipeline is enqueued behind and finds nothing), and without the count (the grown distros
+    take the large-distro pipeline) -- one plan."""
+    import torch
+    from evergreen_amd import native, resident
+    dev = torch.device("cuda:0")
+    for k, size in ((8, 4096), (1, 2049)):
+        b = gen.generate(gen.cliff_config(k, size))
+        mx, pr, nb = native.launch_hints(b)
+        assert (mx, pr, nb) == (size, abi.EVG_PROMISE_ALL_ON_LDS_TIERS, k)
+        want = oracle.plan(b, breakdown=False, n_units=False)
+        want.breakdown, want.n_units = None, None
+        want_alloc = oracle.allocate(b, want.distro_info, want.group_info)
+        for promises, count in ((pr, nb), (0, nb), (0, 0), (0, nb + 3), (0, max(nb - 1, 0))):
+            pool = resident.ResidentPool(native_ctx, b, dev, breakdown=False, n_units=False)
+            pool.inp.promises, pool.inp.n_big_tier_distros = promises, count
+            pool.step()
+            torch.cuda.synchronize()
+            assert native_ctx.take_device_status() == abi.EVG_OK
+            tag = "cliff %d x %d, promises %d, n_big_tier_distros %d" % (k, size, promises, count)
+            compare.assert_plan_equal(pool.plan_result(), want, b, tag)
+            compare.assert_alloc_equal(pool.alloc_result(), want_alloc, tag)
+            del pool
+
+
+def test_false_tiers_promise_is_reported(native_ctx, oracle):
+    """EVG_PROMISE_ALL_ON_LDS_TIERS on a batch whose 3000-task distro holds a priority beyond int32 (the hints never promise that):
+    the big tier's workgroup cannot plan it and nothing was enqueued behind -- reported through the status word, like a false
+    EVG_PROMISE_ALL_ON_LDS_PATH; and an understated n_big_tier_distros under the promise is reported too."""
+    import torch
+    from evergreen_amd import native, resident
+    b = gen.generate(gen.GenConfig(9_000, 3, 9911))
+    b.cols["priority"][int(b.task_off[1]) + 17] = 2**40
+    mx, pr, nb = native.launch_hints(b)
+    assert pr == 0 and nb == 2
+    pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=False, n_units=False)
+    pool.inp.promises, pool.inp.n_big_tier_distros = abi.EVG_PROMISE_ALL_ON_LDS_TIERS, 3
+    pool.plan()
+    torch.cuda.synchronize()
+    assert native_ctx.take_device_status() == abi.EVG_E_CONTRACT
+    b2 = gen.generate(gen.GenConfig(9_000, 3, 9912))
+    pool2 = resident.ResidentPool(native_ctx, b2, torch.device("cuda:0"), breakdown=False, n_units=False)
+    assert pool2.inp.promises == abi.EVG_PROMISE_ALL_ON_LDS_TIERS and pool2.inp.n_big_tier_distros == 3
+    pool2.inp.n_big_tier_distros = 2
+    pool2.plan()
+    torch.cuda.synchronize()
+    assert native_ctx.take_device_status() == abi.EVG_E_CONTRACT
+    pool2.inp.n_big_tier_distros = 3
+    pool2.plan()
+    torch.cuda.synchronize()
+    assert native_ctx.take_device_status() == abi.EVG_OK
+    want = oracle.plan(b2, breakdown=False, n_units=False)
+    want.breakdown, want.n_units = None, None
+    compare.assert_plan_equal(pool2.plan_result(), want, b2, "after the false promises")
+
+
+# ---- adjustForLargeParserProjectLimit inside the batched allocator (units/host_allocator.go:150,479-520) -------------------------
+def test_large_parser_project_limit_in_the_batched_allocator(native_ctx, oracle):
+    """The allocator job lowers LengthWithDependenciesMet by the queued large-parser-project tasks the global limit blocks before it
+    calls the HostAllocator; the batched tick hands the planner's device-resident rows straight to the allocator, so
+    evg_alloc_input carries the limit and the running count. Against the oracle (whose adjustForLargeParserProjectLimit is pinned
+    to the reference's two vectors, tests/test_oracle_golden.py), host-pointer and device-resident; a limit that blocks queued
+    tasks must lower some distro's host count (the clamp of utilization_based_host_allocator.go:113-115 is what it feeds)."""
+    import torch
+    from evergreen_amd import resident
+    b = gen.generate(gen.config(2))
+    b.cols["flags"] = b.cols["flags"] | np.where(np.arange(b.n_tasks) % 3 == 0, abi.TF_S3_STORAGE, 0).astype(np.uint16)  # a third of the queue
+    plan = native_ctx.plan(b, breakdown=False, n_units=False)
+    assert int(plan.distro_info["num_queued_large_parser_project_tasks"].sum()) > 0
+    base = native_ctx.allocate(b, plan.distro_info, plan.group_info.copy())
+    changed = 0
+    for limit, running in ((0, 0), (-5, 10), (10**6, 3), (50, 20), (50, 49), (50, 50), (50, 80), (1, 0)):
+        b.large_parser_limit, b.large_parser_running = limit, running
+        got = native_ctx.allocate(b, plan.distro_info, plan.group_info.copy())
+        want = oracle.allocate(b, plan.distro_info, plan.group_info.copy())
+        compare.assert_alloc_equal(got, want, "large parser limit %d running %d" % (limit, running))
+        if limit <= 0 or limit >= 10**6:
+            assert np.array_equal(got.new_hosts, base.new_hosts)
+        changed += int((got.new_hosts != base.new_hosts).sum())
+        pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=False, n_units=False)
+        pool.step()
+        compare.assert_alloc_equal(pool.alloc_result(), want, "resident tick, large parser limit %d running %d" % (limit, running))
+    assert changed > 0, "no limit ever lowered a host count: the adjustment does not reach the clamp"
+

@@ -46,7 +46,7 @@ def test_emulated_ranks_cover_the_pool(native_ctx, oracle, cfg, world):
         pool.rank = r
         d0, d1 = pool.my_range
         if r % 2 == 0:
-            pool.plan_allocate()  # one launch for the range when the batch promises it stays on the one-workgroup path
+            pool.plan_allocate()
         else:
             pool.plan()
             pool.allocate()

@@ -103,3 +103,33 @@ def test_go_shim_files_are_complete():
                    "queueInfoFromRows", "providerClass", "unixNS", "boolToC", "statusClass", "carveSlice", "runGPUPlanner"):
         assert helper in defined, "shim helper %s is named but not defined" % helper
     assert "var GPUTaskPlanner TaskPlanner" in src and "var GPUHostAllocator HostAllocator" in src
+
+
+def _go_code_lines(text):
+    """The Go source without // comments (string literals of the shim hold no slashes)."""
+    return [ln.split("//", 1)[0] for ln in text.splitlines()]
+
+
+def test_go_shim_never_takes_the_address_of_element_zero():
+    """Go bounds-checks s[0] under an & too: &col[0] of a carved column panics whenever the column is empty -- zero hosts
+    (NoExistingHosts, the reference's first allocator case), zero dependency edges (most of planner_test.go), an empty queue
+    (scheduler/wrapper.go:107 plans those too). Round 3's files did exactly that; the C++ twin, on raw pointers, could not see it.
+    A column's address for a C struct is ptr(col) == unsafe.SliceData(col); the twin now indexes through a bounds-checked
+    GoSlice, so a regression fails there as well (run_empty_column_cases)."""
+    import re
+    shim = os.path.join(ROOT, "shim")
+    for f in sorted(os.listdir(shim)):
+        if not f.endswith(".go"):
+            continue
+        for i, ln in enumerate(_go_code_lines(open(os.path.join(shim, f)).read()), 1):
+            m = re.search(r"&\s*[A-Za-z_][A-Za-z0-9_.]*\[0\]", ln)
+            assert not m, "%s:%d takes %s: panics on an empty slice; use ptr()" % (f, i, m.group(0))
+    src = "".join(open(os.path.join(shim, f)).read() for f in sorted(os.listdir(shim)) if f.endswith(".go"))
+    assert "func ptr[T any](s []T) *T { return unsafe.SliceData(s) }" in src
+    # every pointer field of the C structs the shim fills is a ptr(...) of a carved slice
+    for field in re.findall(r"\b([a-z_]+): (&?[A-Za-z_]+\(?[A-Za-z_]*\)?)[,}]", "\n".join(_go_code_lines(src))):
+        name, value = field
+        if name in ("priority", "expected_duration_ns", "dep_idx", "dep_info", "flags", "tg_key", "start_ts_ns", "new_hosts", "order", "distro_info"):
+            assert value.startswith("ptr("), (name, value)
+    twin = open(os.path.join(CPP, "test_shim_twin.cpp")).read()
+    assert "struct GoSlice" in twin and "run_empty_column_cases" in twin and "index out of range" in twin

@@ -153,3 +153,41 @@ def test_rank_caches_value(cache):
     assert L.evg_oracle_cache_unit_value(h, FOO) == 18080
     L.evg_oracle_cache_create(h, FOO, BAR, 0, 1)
     assert L.evg_oracle_cache_unit_value(h, FOO) == 18080
+
+
+def test_large_parser_limit_through_the_batched_allocator(oracle):
+    R.check_large_parser_limit(oracle)
+
+
+def test_adjust_for_large_parser_project_limit(oracle):
+    """units/host_allocator_test.go:245-300 (TestAdjustForLargeParserProjectLimit): LengthWithDependenciesMet 10,
+    NumQueuedLargeParserProjectTasks 5 -- limit 10 with 2 running leaves 10 (NoAdjustmentWhenLimitNotSaturated :253-274); limit 5
+    with 3 running leaves 7 (ReducesQueueLengthWhenLimitSaturated :276-298). Plus the guards of :481-488 / :503-506. The oracle's
+    restatement of units/host_allocator.go:479-520 -- and through it the batched allocator entry point, which applies it ahead of
+    the clamp of utilization_based_host_allocator.go:113-115."""
+    import numpy as np
+    from evergreen_amd import abi, gen
+    adj = oracle_lib.lib().evg_oracle_adjust_large_parser
+    for length, queued, limit, running, want in G.ADJUST_LARGE_PARSER:  # the reference's two vectors
+        assert adj(length, queued, limit, running) == want
+    assert G.ADJUST_LARGE_PARSER == [(10, 5, 10, 2, 10), (10, 5, 5, 3, 7)]
+    assert adj(10, 0, 5, 99) == 10    # no queued large-parser tasks (:481)
+    assert adj(10, 5, 0, 99) == 10 and adj(10, 5, -1, 99) == 10  # limit <= 0 (:486)
+    assert adj(10, 5, 5, 9) == 5      # remaining capacity max(0, 5 - 9) = 0: all five blocked
+    assert adj(10, 5, 100, 95) == 10  # blocked = 5 - 5 = 0 (:504)
+    # end to end through the batched allocator: the distro's host count follows the adjusted length
+    b = gen.generate(gen.config(1))
+    plan = oracle.plan(b, breakdown=False, n_units=False)
+    d = int(np.argmax(plan.distro_info["length_with_dependencies_met"]))
+    plan.distro_info["num_queued_large_parser_project_tasks"][:] = 0
+    plan.distro_info["num_queued_large_parser_project_tasks"][d] = plan.distro_info["length_with_dependencies_met"][d]
+    base = oracle.allocate(b, plan.distro_info, plan.group_info.copy())
+    b.large_parser_limit, b.large_parser_running = 4, 4  # every queued large-parser task of distro d is blocked: effective length 0
+    got = oracle.allocate(b, plan.distro_info, plan.group_info.copy())
+    others = np.arange(b.n_distros) != d
+    assert np.array_equal(got.new_hosts[others], base.new_hosts[others])
+    minimum = int(b.alloc_params["minimum_hosts"][d])
+    n_hosts = int(b.host_off[d + 1] - b.host_off[d])
+    if base.status[d] == 0 and not b.alloc_params["disabled"][d] and (b.alloc_params["provider"][d] == 2 or n_hosts < b.alloc_params["maximum_hosts"][d]):
+        assert got.new_hosts[d] == max(0, minimum - n_hosts), (got.new_hosts[d], base.new_hosts[d])
+
