@@ -577,7 +577,11 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const int d, 
       k[e] = i < n ? K128{vmax - ub(bv[e]), ((uint64_t)bm[e] << (LG + SB)) | ((uint64_t)bs[e] << LG) | (uint64_t)i} : K128{~0ull, ~0ull};
     }
     EVG_STAMP(6); EVG_STOP(6);
-    bitonic_sort4<K128>(k, P, tid, (K128*)(smem + TR::X_BUF0), (K128*)(smem + TR::X_BUF0));
+    // The big tier has three value bits fewer in a 64-bit key (its tie-break is 37 bits, not 34): ranges of 28..30 bits are not
+    // rare there, so its wide sort is the unrolled network too (the runtime-dispatched one took 110 k ticks against 31.6 k for the
+    // 64-bit keys of the same distro size); the small tier keeps the compact loop -- its code size is the headline kernel's.
+    if (LG == 12 && P == TR::N) bitonic_sort4_fixed<TR::N, K128, 11>(k, tid, (K128*)(smem + TR::X_BUF0), (K128*)(smem + TR::X_BUF0));
+    else bitonic_sort4<K128>(k, P, tid, (K128*)(smem + TR::X_BUF0), (K128*)(smem + TR::X_BUF0));
 #pragma unroll
     for (int e = 0; e < E; e++) srt[e] = (uint32_t)k[e].lo & SRT_MASK;
   }

@@ -408,9 +408,14 @@ struct evg_ctx {
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
-  // the one-per-CU tier (k_plan_distros_big): 2 = beside the small tier's launch on the context's side stream (default),
-  // 1 = behind it on the caller's stream, 0 = off (tier-12 distros take the large-distro pipeline). EVG_BIG_TIER, for A/B runs.
-  int big_mode = 2;
+  // the one-per-CU tier (k_plan_distros_big): 1 = behind the small tier's launch on the caller's stream (default), 2 = on the
+  // context's high-priority side stream, forked before that launch and joined after it, 0 = off (tier-12 distros take the
+  // large-distro pipeline). EVG_BIG_TIER, for A/B runs. Measured (scripts/bench_cliff.py, config 3 with 1 / 8 / 64 distros grown to
+  // 4096 tasks): 0.118 / 0.117 / 0.153 ms per tick behind, 0.130 / 0.132 / 0.165 beside, 0.158 / 0.164 / 0.170 off: the 512
+  // workgroups of the small tier fill every CU the moment they are dispatched (the cross-queue wait of the fork delays the side
+  // stream by ~7 us), so the big tier's workgroups -- which need a CU to themselves -- start when the small tier ends either way,
+  // and the two event hand-overs cost ~15 us on top.
+  int big_mode = 1;
   hipStream_t side = nullptr;               // high-priority stream of the big tier's launch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // evg_profile_plan_kernel: HIP events around the LDS planner kernel alone, on the stream it is launched on

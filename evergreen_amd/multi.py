@@ -41,16 +41,20 @@ HEADER_WORDS = 32            # int64 words = 256 bytes
 H_MAGIC, H_TOTAL, H_NOW, H_D, H_N, H_E, H_TG, H_VER, H_H, H_HAS_HOSTS, H_HAS_NAME, H_MAX_DISTRO, H_PROMISES, H_NBIG, H_LP_LIMIT, H_LP_RUNNING = range(16)
 
 
-# Cost of one task of a distro that takes the many-workgroups-per-distro pipeline (more than LDS_PATH_TASKS tasks), in
-# tasks of a distro on the one-workgroup path: measured on MI355X (round 3: 0.21 ns against 0.056 ns per task).
+# Cost of one task of a distro that takes the many-workgroups-per-distro pipeline (more than BIG_TIER_TASKS tasks), in
+# tasks of a distro on the two-per-CU tier of the one-workgroup kernel: measured on MI355X (round 3: 0.21 ns against 0.056 ns per
+# task). A distro of the one-per-CU tier (2049..4096 tasks) holds a whole CU for about as long as two small distros hold half of
+# one each (round 4: 54 us for 4096 tasks against 53 us for two 2048-task distros sharing a CU): twice the cost per task.
 LDS_PATH_TASKS = 2048
+BIG_TIER_TASKS = 4096
+BIG_TIER_COST = 2.0
 LARGE_PATH_COST = 4.0
 
 
 def distro_costs(task_off: Sequence[int]) -> np.ndarray:
     """Planning cost of every distro in LDS-path task units (what balanced_ranges balances)."""
     n = np.diff(np.asarray(task_off, np.int64)).astype(np.float64)
-    return np.where(n > LDS_PATH_TASKS, n * LARGE_PATH_COST, n)
+    return np.where(n > BIG_TIER_TASKS, n * LARGE_PATH_COST, np.where(n > LDS_PATH_TASKS, n * BIG_TIER_COST, n))
 
 
 def balanced_ranges(task_off: Sequence[int], world: int, costs: Optional[Sequence[float]] = None) -> List[Tuple[int, int]]:

@@ -131,8 +131,9 @@ def test_balanced_ranges_cover_and_balance():
 def test_ranges_balance_cost_not_task_count_on_the_skewed_pool():
     """BASELINE config 3's skewed variant (Zipf sizes in [64, 65536]): a task of a distro beyond the one-workgroup path costs
     LARGE_PATH_COST tasks of one inside it, so ranges cut at equal TASK counts leave the rank that holds the head distros
-    with most of the work. The cost-weighted cut keeps max / mean rank cost within 15 % at 8 ranks (the head distro alone is
-    less than the mean) and is never worse than the count-weighted one."""
+    with most of the work (a distro of the 4096-task tier: BIG_TIER_COST). The cost-weighted cut keeps max / mean rank cost within
+    20 % at 8 ranks (it is the optimal contiguous partition; the head distro alone is 0.9 of the mean) and is never worse than the
+    count-weighted one."""
     b_off = gen._distro_sizes(gen.config(3, skew=True), None)
     off = np.concatenate([[0], np.cumsum(b_off)])
     cost = multi.distro_costs(off)
@@ -145,7 +146,7 @@ def test_ranges_balance_cost_not_task_count_on_the_skewed_pool():
         by_cost = imbalance(multi.balanced_ranges(off, world))
         by_count = imbalance(multi.balanced_ranges(off, world, costs=np.diff(off)))
         assert by_cost <= by_count + 1e-9, (world, by_cost, by_count)
-        assert by_cost <= 1.15, (world, by_cost)
+        assert by_cost <= 1.20, (world, by_cost)
     assert imbalance(multi.balanced_ranges(off, 8, costs=np.diff(off))) > 1.25  # ranges cut by task count (round 2)
 
 
