@@ -363,6 +363,64 @@ def sharded_workload(make_batch, what, ctx, dev, dist, rank, world, mode, steps,
     return obj
 
 
+def multi_abi_tick(batch, native, devices, steps, warmup, scatter=False, want=None, want_alloc=None):
+    """The sharded tick through the C ABI's evg_multi_* (one process, one context + RCCL communicator per device): ms per tick (wall
+    clock around `steps` ticks; a tick returns when every device is done), its phases by the library's HIP events, parity flags."""
+    import numpy as np
+    m = native.MultiContext(devices, scatter=scatter)
+    try:
+        m.load(batch)
+        for _ in range(warmup):
+            m.tick()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.tick()
+        dt = (time.perf_counter() - t0) / steps
+        m.profile(True)
+        m.tick()
+        phases = m.last_tick_ms()
+        m.profile(False)
+        got, got_alloc = m.results()
+        obj = {"value": batch.n_tasks / dt, "unit": "tasks/s", "ms_per_tick": dt * 1e3, "devices": list(devices), "pool_in": "scatter" if scatter else "broadcast",
+               "distro_ranges": m.ranges(), "phases_ms": phases,
+               "what": "evg_multi_load once, then evg_multi_tick per step: ONE process drives every device through the C ABI (what shim/gpu_multi.go "
+                       "binds) -- ncclBroadcast of the packed pool (or grouped ncclSend/ncclRecv of each rank's slices), evg_plan_distro_range_device + "
+                       "evg_allocate_host_range_device per device, grouped ncclSend/ncclRecv gather to device 0; host wall clock, the call returns "
+                       "when every device has finished"}
+        if want is not None:
+            obj["identical_to_the_torch_distributed_tick"] = bool(np.array_equal(got.order, want.order) and np.array_equal(got.distro_info, want.distro_info) and
+                                                                  (want_alloc is None or np.array_equal(got_alloc.new_hosts, want_alloc.new_hosts)))
+        return obj, got, got_alloc
+    finally:
+        m.close()
+
+
+def single_process(args, gen, native, np, torch):
+    """bench.py --gpus N --single-process: BASELINE config 3 / 4 from one process over N devices (see multi_abi_tick)."""
+    n = args.gpus
+    cfg_num = args.config or (3 if n == 1 else 4)
+    over = {}
+    if args.tasks:
+        over["n_tasks"] = args.tasks
+    if args.distros:
+        over["n_distros"] = args.distros
+    cfg = gen.config(cfg_num, **over)
+    batch = gen.generate(cfg)
+    obj, got, got_alloc = multi_abi_tick(batch, native, list(range(n)), args.steps, args.warmup, scatter=args.scatter)
+    line = {"metric": METRIC, "value": obj["value"], "unit": "tasks/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": obj["ms_per_tick"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": "BASELINE config %d: %d tasks x %d distros over %d device(s) of ONE process (C ABI evg_multi_*, RCCL %s + grouped gather)" % (
+                cfg_num, batch.n_tasks, batch.n_distros, n, obj["pool_in"]), "tasks": batch.n_tasks, "distros": batch.n_distros, "parallelism": "single process, %d devices" % n},
+            "single_process": obj}
+    if not args.no_cpu_baseline:
+        want, want_alloc, t1s, tn, tmed, nt = cpu_baseline(batch, os.cpu_count() or 1)
+        line["queue_order_match"] = order_match(batch, got, want)
+        line["host_counts_match"] = bool(np.array_equal(got_alloc.new_hosts, want_alloc.new_hosts) and np.array_equal(got_alloc.free_hosts, want_alloc.free_hosts))
+        line["cpu_baseline"] = {"value": batch.n_tasks / tn, "unit": "tasks/s", "cores": nt, "kind": "port", "median_value": batch.n_tasks / tmed,
+                                "sample": "the whole workload, 5 passes with %d worker threads (best = value)" % nt}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -375,6 +433,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / skewed / config5_share / pipelined (profiling runs)")
     ap.add_argument("--no-config5", action="store_true", help="skip BASELINE config 5 at full size (10M tasks: ~90 s of generation and checking)")
+    ap.add_argument("--single-process", action="store_true", help="N > 1 from ONE process through the C ABI (evg_multi_*: one context, stream and RCCL "
+                                                                  "communicator per device) instead of one torch.distributed process per GPU; not "
+                                                                  "launched under torchrun")
+    ap.add_argument("--scatter", action="store_true", help="with --single-process: the pool moves in as per-rank slices (EVG_MULTI_SCATTER)")
     ap.add_argument("--in-flight", type=int, default=3, help="also report the sustained rate with this many independent pools in flight "
                                                              "on their own streams (the `pipelined` object; 1 = skip)")
     args = ap.parse_args()
@@ -383,6 +445,8 @@ def main():
     import torch
     from evergreen_amd import gen, multi, native, resident
 
+    if args.single_process:
+        return single_process(args, gen, native, np, torch)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -669,6 +733,7 @@ def main():
                                              "vs_all_small": ms / base_ms, "parity_vs_oracle": ok})
                 return out
             guarded("cliff", cliff)
+            guarded("single_process_abi", lambda: multi_abi_tick(batch, native, [dev.index or 0], 20, 3, want=got, want_alloc=got_alloc)[0])
             if args.in_flight > 1:
                 guarded("pipelined", lambda: pipelined_rate(batch, dev, args.in_flight, min(args.steps, 60), native, resident, torch))
         for k, v in extra_objs.items():

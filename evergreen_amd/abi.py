@@ -69,7 +69,7 @@ class EdgeUpdate(C.Structure):  # evg_edge_update
     _fields_ = [("n_edges", C.c_int32), ("reserved", C.c_int32), ("edges", _p), ("dep_info", _p), ("dep_finished_ts_ns", _p)]
 
 
-EVG_ABI_MAJOR, EVG_ABI_MINOR = 3, 0
+EVG_ABI_MAJOR, EVG_ABI_MINOR = 3, 1
 
 
 class HostSoa(C.Structure):

@@ -1,0 +1,628 @@
+// evg_multi.hip.h -- several MI355X driven from ONE process through the C ABI (BASELINE configs 4 and 5).
+//
+// north_star: "Distros shard naturally across the 8 GPUs of one node with a single RCCL broadcast of the shared runnable-task
+// pool over xGMI and a gather of the per-distro TaskQueue back to rank 0." A Go scheduler is ONE process
+// (units/crons.go:303-332 enqueues every distro's job from it), so the natural shape is one process, eight devices: one
+// evg_ctx + one stream per device, one RCCL communicator per device from ncclCommInitAll, and per tick
+//
+//   move-in   ONE ncclBroadcast of the packed pool (root = rank 0's device), or -- EVG_MULTI_SCATTER, SURVEY 8e's cheaper form --
+//             one group of ncclSend / ncclRecv that hands every rank only the slices its distro range reads
+//   plan      evg_plan_distro_range_device + evg_allocate_host_range_device on every rank's own contiguous distro range
+//             (balanced by cost, evg_balanced_ranges); every output keeps the full batch's numbering
+//   gather    one group of ncclSend / ncclRecv: each rank's result slices land at their final place in rank 0's arrays
+//
+// -- the logic of evergreen_amd/multi.py (one process PER GPU on torch.distributed) inside the library, for a caller that has
+// no torch: shim/gpu_multi.go. The packed pool has multi.py's layout (a 256-byte header, then every column at the next multiple of
+// 256 bytes), so both drivers can be checked against each other byte for byte.
+//
+// RCCL is loaded on first use (dlopen of librccl.so.1): a single-GPU caller never pays for it, and the library has no link-time
+// dependency on it. EVG_MULTI_LOOPBACK replaces the collectives by device copies and lets `devices` repeat an ordinal: the
+// ranks of an N-GPU world run one after the other on ONE GPU -- the test transport of the one-GPU boxes this is developed on
+// (RCCL refuses a communicator with the same device twice). It is a test mode, not a fallback: nothing selects it implicitly.
+//
+// Included by evg_sched.hip (it needs launch_plan / launch_alloc and the context internals).
+#pragma once
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace evgm {
+
+constexpr size_t kAlign = 256;
+constexpr int kHeaderWords = 32;  // int64 words
+constexpr int64_t kMagic = 0x455647504F4F4C31LL;  // "EVGPOOL1" (evergreen_amd/multi.py)
+enum { H_MAGIC, H_TOTAL, H_NOW, H_D, H_N, H_E, H_TG, H_VER, H_H, H_HAS_HOSTS, H_HAS_NAME, H_MAX_DISTRO, H_PROMISES, H_NBIG, H_LP_LIMIT, H_LP_RUNNING };
+
+// what a section is sliced by when only a distro range travels
+enum Kind { K_ROW, K_ROW1, K_EDGE, K_HOST, K_WHOLE };
+struct Section {
+  const char* name;
+  size_t pos, isz, count;
+  Kind kind;
+};
+
+struct Layout {
+  size_t D = 0, N = 0, E = 0, TG = 0, V = 0, H = 0;
+  bool has_hosts = false;
+  std::vector<Section> sec;
+  size_t total = 0;
+  const Section& at(const char* name) const {
+    for (const Section& s : sec)
+      if (!strcmp(s.name, name)) return s;
+    static const Section none{"", 0, 0, 0, K_WHOLE};
+    return none;
+  }
+  void build() {
+    sec.clear();
+    auto add = [&](const char* n, size_t isz, size_t count, Kind k) { sec.push_back(Section{n, 0, isz, count, k}); };
+    add("priority", 8, N, K_ROW); add("expected_duration_ns", 8, N, K_ROW); add("queue_ts_ns", 8, N, K_ROW); add("scheduled_ts_ns", 8, N, K_ROW);
+    add("deps_met_ts_ns", 8, N, K_ROW); add("num_dependents", 4, N, K_ROW); add("task_group_order", 4, N, K_ROW);
+    add("task_group_max_hosts", 4, N, K_ROW); add("tg_key", 4, N, K_ROW); add("version_key", 4, N, K_ROW); add("flags", 2, N, K_ROW);
+    add("dep_off", 4, N + 1, K_ROW1);
+    add("dep_idx", 4, E, K_EDGE); add("dep_info", 1, E, K_EDGE); add("dep_finished_ts_ns", 8, E, K_EDGE);
+    add("distros", 1, D * sizeof(evg_distro_params), K_WHOLE);
+    add("task_off", 4, D + 1, K_WHOLE); add("tg_off", 4, D + 1, K_WHOLE); add("ver_off", 4, D + 1, K_WHOLE);
+    if (has_hosts) {
+      add("alloc_params", 1, D * sizeof(evg_alloc_params), K_WHOLE);
+      add("host_off", 4, D + 1, K_WHOLE);
+      add("host_flags", 1, H, K_HOST); add("host_tg_key", 4, H, K_HOST); add("host_start_ts_ns", 8, H, K_HOST);
+      add("host_expected_duration_ns", 8, H, K_HOST); add("host_duration_stddev_ns", 8, H, K_HOST);
+    }
+    size_t pos = kHeaderWords * 8;
+    for (Section& s : sec) {
+      pos = (pos + kAlign - 1) / kAlign * kAlign;
+      s.pos = pos;
+      pos += s.isz * s.count;
+    }
+    total = (pos + kAlign - 1) / kAlign * kAlign;
+  }
+};
+
+// ---- RCCL, loaded on first use -----------------------------------------------------------------------------------------
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+  bool load() {
+    if (lib) return true;
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) { err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?"); return false; }
+    auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("RCCL lacks ") + n; return p; };
+    CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+    Broadcast = (decltype(Broadcast))sym("ncclBroadcast"); Send = (decltype(Send))sym("ncclSend"); Recv = (decltype(Recv))sym("ncclRecv");
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast || !Send || !Recv || !GetErrorString) { lib = nullptr; return false; }
+    return true;
+  }
+};
+static Rccl g_rccl;
+static std::mutex g_rccl_mu;
+
+struct Slice { size_t off, bytes; };  // of a rank's byte buffer
+
+struct Rank {
+  int device = 0;
+  evg_ctx* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  ncclComm_t comm = nullptr;
+  unsigned char* buf = nullptr;  // the packed pool
+  unsigned char* out = nullptr;  // every output array, full-size, one block (Outs below gives the offsets)
+  evg_plan_input inp{};
+  evg_plan_output pout{};
+  evg_alloc_input ainp{};
+  evg_alloc_output aout{};
+  int d0 = 0, d1 = 0;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // around move-in | plan | allocate | gather
+};
+
+// offsets of the output arrays inside a rank's output block
+struct Outs {
+  size_t order, met, wait, di, gi, uot, ubd, alloc, total;
+};
+
+}  // namespace evgm
+
+struct evg_multi {
+  int n = 0, flags = 0;
+  bool loopback = false;
+  std::vector<evgm::Rank> r;
+  std::string err;
+  std::mutex mu;
+  // the pool of the last evg_multi_load
+  bool loaded = false;
+  evgm::Layout lay;
+  evgm::Outs o{};
+  unsigned char* packed_h = nullptr;  // page-locked: the packed pool on the host
+  size_t packed_cap = 0, buf_cap = 0, out_cap = 0;
+  std::vector<int32_t> task_off, tg_off, ver_off, host_off;
+  std::vector<int64_t> edge_cut;
+  size_t n_slots = 0;
+  bool timed = false;
+};
+
+namespace evgm {
+
+static thread_local std::string g_multi_err;
+
+static int merr(evg_multi* m, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (m) m->err = buf; else g_multi_err = buf;
+  return code;
+}
+#define EVGM_HIP(m, expr)                                                                                             \
+  do {                                                                                                                \
+    hipError_t e_ = (expr);                                                                                           \
+    if (e_ != hipSuccess) return evgm::merr((m), e_ == hipErrorOutOfMemory ? EVG_E_NOMEM : EVG_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define EVGM_NCCL(m, expr)                                                                                            \
+  do {                                                                                                                \
+    ncclResult_t e_ = (expr);                                                                                         \
+    if (e_ != ncclSuccess) return evgm::merr((m), EVG_E_HIP, "%s: %s", #expr, evgm::g_rccl.GetErrorString(e_));       \
+  } while (0)
+
+// Cost of a distro in quarter-tasks of the two-per-CU tier of the one-workgroup kernel (evergreen_amd/multi.py:distro_costs --
+// the same integers, so that a Go caller and the Python driver cut the same ranges): a distro of the one-per-CU tier holds a whole
+// CU for as long as two small ones share it (x2 per task), one on the large-distro pipeline costs x4.
+static inline int64_t distro_cost4(int64_t n) { return n > 4096 ? 16 * n : n > 2048 ? 8 * n : 4 * n; }
+
+// Contiguous distro ranges that minimise the largest rank cost: the smallest bound L such that a left-to-right fill with ranges
+// of cost <= L needs at most `world` ranges (binary search over L), then that fill. cuts: world + 1 entries.
+static void balanced_cuts(const int32_t* task_off, int D, int world, std::vector<int>& cuts) {
+  std::vector<int64_t> pre(D + 1, 0);
+  int64_t cmax = 0;
+  for (int d = 0; d < D; d++) {
+    const int64_t c = distro_cost4((int64_t)task_off[d + 1] - task_off[d]);
+    pre[d + 1] = pre[d] + c;
+    cmax = std::max(cmax, c);
+  }
+  auto fill = [&](int64_t limit, std::vector<int>& cu) {
+    cu.assign(1, 0);
+    int d = 0;
+    while (d < D && (int)cu.size() <= world) {
+      // the furthest boundary whose range cost stays within the limit (at least one distro)
+      const int k = (int)(std::upper_bound(pre.begin(), pre.end(), pre[d] + limit) - pre.begin()) - 1;
+      d = std::min(std::max(k, d + 1), D);
+      cu.push_back(d);
+    }
+  };
+  int64_t lo = D ? cmax : 0, hi = pre[D];
+  std::vector<int> cu;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) / 2;
+    fill(mid, cu);
+    if (cu.back() == D && (int)cu.size() - 1 <= world) hi = mid; else lo = mid + 1;
+  }
+  if (D) fill(lo, cuts); else cuts.assign(1, 0);
+  while ((int)cuts.size() < world + 1) cuts.push_back(D);
+}
+
+// What rank k's distro range reads of the packed pool, as slices of the buffer at their own offsets (multi.py:_in_slices).
+static void in_slices(const evg_multi* m, int k, std::vector<Slice>& out) {
+  const Layout& L = m->lay;
+  const Rank& r = m->r[k];
+  const size_t r0 = m->task_off[r.d0], r1 = m->task_off[r.d1], e0 = (size_t)m->edge_cut[k], e1 = (size_t)m->edge_cut[k + 1];
+  const size_t h0 = L.has_hosts ? m->host_off[r.d0] : 0, h1 = L.has_hosts ? m->host_off[r.d1] : 0;
+  out.clear();
+  out.push_back(Slice{0, (size_t)kHeaderWords * 8});
+  for (const Section& s : L.sec) {
+    size_t lo = 0, hi = s.count;
+    switch (s.kind) {
+      case K_ROW: lo = r0; hi = r1; break;
+      case K_ROW1: lo = r0; hi = r1 + 1; break;
+      case K_EDGE: lo = e0; hi = e1; break;
+      case K_HOST: lo = h0; hi = h1; break;
+      case K_WHOLE: break;
+    }
+    if (hi > lo) out.push_back(Slice{s.pos + lo * s.isz, (hi - lo) * s.isz});
+  }
+}
+
+// The contiguous slices of the full-size outputs that rank k's distro range fills (multi.py:_slices).
+static void out_slices(const evg_multi* m, int k, std::vector<Slice>& out) {
+  const Layout& L = m->lay;
+  const Rank& r = m->r[k];
+  const Outs& o = m->o;
+  const size_t r0 = m->task_off[r.d0], r1 = m->task_off[r.d1];
+  const size_t g0 = L.D + m->tg_off[r.d0], g1 = L.D + m->tg_off[r.d1];
+  out.clear();
+  auto add = [&](size_t base, size_t isz, size_t lo, size_t hi) { if (hi > lo) out.push_back(Slice{base + lo * isz, (hi - lo) * isz}); };
+  add(o.order, 4, r0, r1); add(o.met, 1, r0, r1); add(o.wait, 8, r0, r1);
+  add(o.di, sizeof(evg_distro_info), r.d0, r.d1);
+  add(o.gi, sizeof(evg_group_info), r.d0, r.d1);  // the stand-alone rows
+  add(o.gi, sizeof(evg_group_info), g0, g1);      // the task-group rows
+  if (m->flags & EVG_MULTI_UNIT_ROWS) {
+    const size_t u0 = (size_t)m->task_off[r.d0] + m->tg_off[r.d0] + m->ver_off[r.d0], u1 = (size_t)m->task_off[r.d1] + m->tg_off[r.d1] + m->ver_off[r.d1];
+    add(o.uot, 4, r0, r1);
+    for (int f = 0; f < EVG_BREAKDOWN_FIELDS; f++) add(o.ubd, 8, f * m->n_slots + u0, f * m->n_slots + u1);  // field-major
+  }
+  if (L.has_hosts)
+    for (int q = 0; q < 3; q++) add(o.alloc, 4, q * L.D + r.d0, q * L.D + r.d1);
+}
+
+static void free_rank(Rank& r) {
+  (void)hipSetDevice(r.device);
+  if (r.comm) (void)g_rccl.CommDestroy(r.comm);
+  if (r.buf) (void)hipFree(r.buf);
+  if (r.out) (void)hipFree(r.out);
+  for (hipEvent_t& e : r.ev) if (e) (void)hipEventDestroy(e);
+  if (r.stream) (void)hipStreamDestroy(r.stream);
+  if (r.ctx) evg_destroy(r.ctx);
+  r = Rank{};
+}
+
+}  // namespace evgm
+
+extern "C" {
+
+const char* evg_multi_last_error(const evg_multi* m) { return m ? m->err.c_str() : evgm::g_multi_err.c_str(); }
+
+int evg_balanced_ranges(const int32_t* task_off, int32_t n_distros, int32_t world, int32_t* d_begin, int32_t* d_end) {
+  if (!task_off || n_distros < 0 || world <= 0 || !d_begin || !d_end) return EVG_E_INVALID;
+  std::vector<int> cuts;
+  evgm::balanced_cuts(task_off, n_distros, world, cuts);
+  for (int k = 0; k < world; k++) { d_begin[k] = cuts[k]; d_end[k] = cuts[k + 1]; }
+  return EVG_OK;
+}
+
+evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t flags) {
+  using namespace evgm;
+  if (!devices || n_devices <= 0 || n_devices > 64) { merr(nullptr, EVG_E_INVALID, "evg_multi_create: 1..64 devices"); return nullptr; }
+  const bool loopback = (flags & EVG_MULTI_LOOPBACK) != 0;
+  if (!loopback)
+    for (int i = 0; i < n_devices; i++)
+      for (int j = 0; j < i; j++)
+        if (devices[i] == devices[j]) { merr(nullptr, EVG_E_INVALID, "evg_multi_create: device %d listed twice (RCCL wants distinct devices; EVG_MULTI_LOOPBACK emulates ranks on one)", devices[i]); return nullptr; }
+  evg_multi* m = new evg_multi();
+  m->n = n_devices; m->flags = flags; m->loopback = loopback;
+  m->r.resize(n_devices);
+  auto fail = [&]() -> evg_multi* {
+    g_multi_err = m->err;
+    for (Rank& r : m->r) free_rank(r);
+    delete m;
+    return nullptr;
+  };
+  for (int k = 0; k < n_devices; k++) {
+    Rank& r = m->r[k];
+    r.device = devices[k];
+    r.ctx = evg_create(devices[k]);
+    if (!r.ctx) { m->err = evg_last_error(nullptr); return fail(); }
+    if (hipSetDevice(r.device) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess) { m->err = "cannot create a stream"; return fail(); }
+    for (hipEvent_t& e : r.ev)
+      if (hipEventCreate(&e) != hipSuccess) { m->err = "cannot create an event"; return fail(); }
+  }
+  if (!loopback) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (!g_rccl.load()) { m->err = g_rccl.err; return fail(); }
+    std::vector<ncclComm_t> comms(n_devices);
+    std::vector<int> devs(devices, devices + n_devices);
+    const ncclResult_t e = g_rccl.CommInitAll(comms.data(), n_devices, devs.data());
+    if (e != ncclSuccess) { m->err = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(e); return fail(); }
+    for (int k = 0; k < n_devices; k++) m->r[k].comm = comms[k];
+  }
+  return m;
+}
+
+void evg_multi_destroy(evg_multi* m) {
+  if (!m) return;
+  for (evgm::Rank& r : m->r) evgm::free_rank(r);
+  if (m->packed_h) (void)hipHostFree(m->packed_h);
+  delete m;
+}
+
+int evg_multi_ranges(const evg_multi* m, int32_t* d_begin, int32_t* d_end) {
+  if (!m || !m->loaded || !d_begin || !d_end) return EVG_E_INVALID;
+  for (int k = 0; k < m->n; k++) { d_begin[k] = m->r[k].d0; d_end[k] = m->r[k].d1; }
+  return EVG_OK;
+}
+
+// Validates the batch, packs it ONCE into a page-locked block in the pool layout, uploads it to rank 0's device and cuts the
+// distro ranges. `alloc` (or NULL: plan only) brings the allocator's per-distro settings and host columns; its distro_info /
+// group_info pointers are ignored -- every rank's allocator reads the rows its own planner left on the device.
+int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input* alloc) {
+  using namespace evgm;
+  if (!m || !in) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  m->loaded = false;
+  char msg[256];
+  int rc = evg_validate_plan_input(in, msg, sizeof msg);
+  if (rc) return merr(m, rc, "%s", rc == EVG_E_CONTRACT ? msg : "invalid plan input");
+  if (alloc && (alloc->n_distros != in->n_distros || alloc->n_task_groups != in->n_task_groups || !alloc->params || !alloc->host_off ||
+                alloc->hosts.n_hosts < 0 || alloc->host_off[0] != 0 || alloc->host_off[in->n_distros] != alloc->hosts.n_hosts))
+    return merr(m, EVG_E_INVALID, "evg_multi_load: the allocator input does not describe the same batch");
+  int32_t max_distro = 0, promises = 0, n_big = 0;
+  rc = evg_plan_launch_hints(in, &max_distro, &promises, &n_big);
+  if (rc) return merr(m, rc, "invalid plan input");
+  Layout& L = m->lay;
+  L.D = in->n_distros; L.N = in->tasks.n_tasks; L.E = in->tasks.n_edges; L.TG = in->n_task_groups; L.V = in->n_versions;
+  L.has_hosts = alloc != nullptr; L.H = alloc ? alloc->hosts.n_hosts : 0;
+  L.build();
+  const size_t D = L.D, N = L.N, G = D + L.TG;
+  // ---- the packed pool on the host ----
+  if (L.total > m->packed_cap) {
+    if (m->packed_h) (void)hipHostFree(m->packed_h);
+    m->packed_h = nullptr; m->packed_cap = 0;
+    EVGM_HIP(m, hipSetDevice(m->r[0].device));
+    EVGM_HIP(m, hipHostMalloc((void**)&m->packed_h, L.total + L.total / 8, hipHostMallocDefault));
+    m->packed_cap = L.total + L.total / 8;
+  }
+  memset(m->packed_h, 0, (size_t)kHeaderWords * 8);
+  int64_t* h = (int64_t*)m->packed_h;
+  h[H_MAGIC] = kMagic; h[H_TOTAL] = (int64_t)L.total; h[H_NOW] = in->now_ns; h[H_D] = (int64_t)D; h[H_N] = (int64_t)N; h[H_E] = (int64_t)L.E;
+  h[H_TG] = (int64_t)L.TG; h[H_VER] = (int64_t)L.V; h[H_H] = (int64_t)L.H; h[H_HAS_HOSTS] = L.has_hosts; h[H_HAS_NAME] = 0;
+  h[H_MAX_DISTRO] = max_distro; h[H_PROMISES] = promises; h[H_NBIG] = n_big;
+  h[H_LP_LIMIT] = alloc ? alloc->max_concurrent_large_parser_project_tasks : 0; h[H_LP_RUNNING] = alloc ? alloc->running_large_parser_project_tasks : 0;
+  const evg_task_soa& t = in->tasks;
+  auto put = [&](const char* name, const void* src) {
+    const Section& s = L.at(name);
+    const size_t bytes = s.isz * s.count;
+    if (!bytes) return;
+    if (src) memcpy(m->packed_h + s.pos, src, bytes); else memset(m->packed_h + s.pos, 0, bytes);
+  };
+  put("priority", t.priority); put("expected_duration_ns", t.expected_duration_ns); put("queue_ts_ns", t.queue_ts_ns);
+  put("scheduled_ts_ns", t.scheduled_ts_ns); put("deps_met_ts_ns", t.deps_met_ts_ns); put("num_dependents", t.num_dependents);
+  put("task_group_order", t.task_group_order); put("task_group_max_hosts", t.task_group_max_hosts); put("tg_key", t.tg_key);
+  put("version_key", t.version_key); put("flags", t.flags); put("dep_off", t.dep_off); put("dep_idx", t.dep_idx); put("dep_info", t.dep_info);
+  put("dep_finished_ts_ns", t.dep_finished_ts_ns);  // NULL = all zero
+  put("distros", in->distros); put("task_off", in->task_off); put("tg_off", in->tg_off); put("ver_off", in->ver_off);
+  if (alloc) {
+    put("alloc_params", alloc->params); put("host_off", alloc->host_off); put("host_flags", alloc->hosts.flags); put("host_tg_key", alloc->hosts.tg_key);
+    put("host_start_ts_ns", alloc->hosts.start_ts_ns); put("host_expected_duration_ns", alloc->hosts.expected_duration_ns);
+    put("host_duration_stddev_ns", alloc->hosts.duration_stddev_ns);
+  }
+  if (N && !t.dep_off) return merr(m, EVG_E_INVALID, "dep_off is required");
+  // ---- ranges, slice bounds ----
+  m->task_off.assign(in->task_off, in->task_off + D + 1); m->tg_off.assign(in->tg_off, in->tg_off + D + 1); m->ver_off.assign(in->ver_off, in->ver_off + D + 1);
+  if (alloc) m->host_off.assign(alloc->host_off, alloc->host_off + D + 1); else m->host_off.assign(D + 1, 0);
+  std::vector<int> cuts;
+  balanced_cuts(in->task_off, (int)D, m->n, cuts);
+  m->edge_cut.resize(m->n + 1);
+  for (int k = 0; k <= m->n; k++) m->edge_cut[k] = N ? t.dep_off[in->task_off[cuts[k]]] : 0;
+  m->n_slots = N + L.TG + L.V;
+  // ---- output block ----
+  Outs& o = m->o;
+  size_t pos = 0;
+  auto carve = [&](size_t bytes) { const size_t at = pos; pos = (pos + bytes + kAlign - 1) / kAlign * kAlign; return at; };
+  o.order = carve(4 * (N + 1)); o.met = carve(N + 1); o.wait = carve(8 * (N + 1)); o.di = carve(sizeof(evg_distro_info) * D);
+  o.gi = carve(sizeof(evg_group_info) * G);
+  const bool units = (m->flags & EVG_MULTI_UNIT_ROWS) != 0;
+  o.uot = carve(units ? 4 * (N + 1) : 0); o.ubd = carve(units ? 8 * EVG_BREAKDOWN_FIELDS * (m->n_slots + 1) : 0);
+  o.alloc = carve(alloc ? 12 * D : 0);
+  o.total = pos + kAlign;
+  for (int k = 0; k < m->n; k++) {
+    Rank& r = m->r[k];
+    r.d0 = cuts[k]; r.d1 = cuts[k + 1];
+    EVGM_HIP(m, hipSetDevice(r.device));
+    if (L.total > m->buf_cap || !r.buf) {
+      if (r.buf) EVGM_HIP(m, hipFree(r.buf));
+      r.buf = nullptr;
+      EVGM_HIP(m, hipMalloc((void**)&r.buf, L.total + L.total / 8));
+    }
+    if (o.total > m->out_cap || !r.out) {
+      if (r.out) EVGM_HIP(m, hipFree(r.out));
+      r.out = nullptr;
+      EVGM_HIP(m, hipMalloc((void**)&r.out, o.total + o.total / 8));
+    }
+    // argument blocks: the columns in place, through the layout
+    auto at = [&](const char* name) -> const void* { const Section& s = L.at(name); return s.count ? (const void*)(r.buf + s.pos) : nullptr; };
+    evg_plan_input& pi = r.inp;
+    pi = evg_plan_input{};
+    pi.n_distros = (int32_t)D; pi.n_task_groups = (int32_t)L.TG; pi.n_versions = (int32_t)L.V; pi.max_distro_tasks = max_distro;
+    pi.promises = promises; pi.n_big_tier_distros = n_big; pi.now_ns = in->now_ns;
+    pi.tasks.n_tasks = (int32_t)N; pi.tasks.n_edges = (int32_t)L.E;
+    pi.tasks.priority = (const int64_t*)at("priority"); pi.tasks.expected_duration_ns = (const int64_t*)at("expected_duration_ns");
+    pi.tasks.queue_ts_ns = (const int64_t*)at("queue_ts_ns"); pi.tasks.scheduled_ts_ns = (const int64_t*)at("scheduled_ts_ns");
+    pi.tasks.deps_met_ts_ns = (const int64_t*)at("deps_met_ts_ns"); pi.tasks.num_dependents = (const int32_t*)at("num_dependents");
+    pi.tasks.task_group_order = (const int32_t*)at("task_group_order"); pi.tasks.task_group_max_hosts = (const int32_t*)at("task_group_max_hosts");
+    pi.tasks.tg_key = (const int32_t*)at("tg_key"); pi.tasks.version_key = (const int32_t*)at("version_key"); pi.tasks.flags = (const uint16_t*)at("flags");
+    pi.tasks.dep_off = (const int32_t*)at("dep_off"); pi.tasks.dep_idx = (const int32_t*)at("dep_idx"); pi.tasks.dep_info = (const uint8_t*)at("dep_info");
+    pi.tasks.dep_finished_ts_ns = (const int64_t*)at("dep_finished_ts_ns");
+    pi.distros = (const evg_distro_params*)at("distros"); pi.task_off = (const int32_t*)at("task_off"); pi.tg_off = (const int32_t*)at("tg_off");
+    pi.ver_off = (const int32_t*)at("ver_off");
+    evg_plan_output& po = r.pout;
+    po = evg_plan_output{};
+    po.order = (int32_t*)(r.out + o.order); po.deps_met = r.out + o.met; po.wait_ns = (int64_t*)(r.out + o.wait);
+    po.distro_info = (evg_distro_info*)(r.out + o.di); po.group_info = (evg_group_info*)(r.out + o.gi);
+    if (units) { po.unit_of_task = (int32_t*)(r.out + o.uot); po.unit_breakdown = (int64_t*)(r.out + o.ubd); }
+    if (alloc) {
+      evg_alloc_input& ai = r.ainp;
+      ai = evg_alloc_input{};
+      ai.n_distros = (int32_t)D; ai.n_task_groups = (int32_t)L.TG; ai.now_ns = in->now_ns;
+      ai.params = (const evg_alloc_params*)at("alloc_params"); ai.host_off = (const int32_t*)at("host_off"); ai.tg_off = pi.tg_off;
+      ai.hosts.n_hosts = (int32_t)L.H; ai.hosts.flags = (const uint8_t*)at("host_flags"); ai.hosts.tg_key = (const int32_t*)at("host_tg_key");
+      ai.hosts.start_ts_ns = (const int64_t*)at("host_start_ts_ns"); ai.hosts.expected_duration_ns = (const int64_t*)at("host_expected_duration_ns");
+      ai.hosts.duration_stddev_ns = (const int64_t*)at("host_duration_stddev_ns");
+      ai.distro_info = po.distro_info; ai.group_info = po.group_info;
+      ai.max_concurrent_large_parser_project_tasks = alloc->max_concurrent_large_parser_project_tasks;
+      ai.running_large_parser_project_tasks = alloc->running_large_parser_project_tasks;
+      r.aout.new_hosts = (int32_t*)(r.out + o.alloc); r.aout.free_hosts = r.aout.new_hosts + D; r.aout.status = r.aout.new_hosts + 2 * D;
+    }
+  }
+  m->buf_cap = std::max(m->buf_cap, L.total); m->out_cap = std::max(m->out_cap, o.total);
+  // the pool of this tick lives on rank 0's device: one copy of the packed bytes
+  evgm::Rank& root = m->r[0];
+  EVGM_HIP(m, hipSetDevice(root.device));
+  EVGM_HIP(m, hipMemcpyAsync(root.buf, m->packed_h, L.total, hipMemcpyHostToDevice, root.stream));
+  EVGM_HIP(m, hipStreamSynchronize(root.stream));
+  m->loaded = true;
+  return EVG_OK;
+}
+
+// One tick over the loaded pool: move-in (broadcast or scatter from rank 0) -> every rank plans + allocates its range -> gather to
+// rank 0; returns when every device is done. Results stay on rank 0's device (evg_multi_results downloads them).
+int evg_multi_tick(evg_multi* m, int64_t now_ns) {
+  using namespace evgm;
+  if (!m) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (!m->loaded) return merr(m, EVG_E_INVALID, "evg_multi_tick: no pool is loaded");
+  const Layout& L = m->lay;
+  if (L.D == 0) return EVG_OK;
+  const int n = m->n;
+  std::vector<Slice> sl;
+  auto mark = [&](int k, int e) -> int {
+    if (!m->timed) return EVG_OK;
+    EVGM_HIP(m, hipSetDevice(m->r[k].device));
+    EVGM_HIP(m, hipEventRecord(m->r[k].ev[e], m->r[k].stream));
+    return EVG_OK;
+  };
+  for (int k = 0; k < n; k++) if (int rc = mark(k, 0)) return rc;
+  // ---- move-in ----
+  if (m->loopback) {
+    for (int k = 1; k < n; k++) {
+      Rank& r = m->r[k];
+      EVGM_HIP(m, hipSetDevice(r.device));
+      if (m->flags & EVG_MULTI_SCATTER) {
+        in_slices(m, k, sl);
+        for (const Slice& s : sl) EVGM_HIP(m, hipMemcpyAsync(r.buf + s.off, m->r[0].buf + s.off, s.bytes, hipMemcpyDeviceToDevice, r.stream));
+      } else {
+        EVGM_HIP(m, hipMemcpyAsync(r.buf, m->r[0].buf, L.total, hipMemcpyDeviceToDevice, r.stream));
+      }
+    }
+  } else if (m->flags & EVG_MULTI_SCATTER) {
+    EVGM_NCCL(m, g_rccl.GroupStart());
+    for (int k = 1; k < n; k++) {
+      in_slices(m, k, sl);
+      for (const Slice& s : sl) {
+        EVGM_NCCL(m, g_rccl.Send(m->r[0].buf + s.off, s.bytes, ncclUint8, k, m->r[0].comm, m->r[0].stream));
+        EVGM_NCCL(m, g_rccl.Recv(m->r[k].buf + s.off, s.bytes, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
+      }
+    }
+    EVGM_NCCL(m, g_rccl.GroupEnd());
+  } else {
+    EVGM_NCCL(m, g_rccl.GroupStart());
+    for (int k = 0; k < n; k++) EVGM_NCCL(m, g_rccl.Broadcast(m->r[k].buf, m->r[k].buf, L.total, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
+    EVGM_NCCL(m, g_rccl.GroupEnd());
+  }
+  for (int k = 0; k < n; k++) if (int rc = mark(k, 1)) return rc;
+  // ---- plan + allocate, every rank its own range (the reference's two jobs: two calls) ----
+  for (int k = 0; k < n; k++) {
+    Rank& r = m->r[k];
+    r.inp.now_ns = now_ns;
+    int rc = evg_plan_distro_range_device(r.ctx, &r.inp, &r.pout, r.d0, r.d1, r.stream);
+    if (rc) return merr(m, rc, "rank %d: %s", k, evg_last_error(r.ctx));
+    if (int rc2 = mark(k, 2)) return rc2;
+    if (L.has_hosts) {
+      r.ainp.now_ns = now_ns;
+      rc = evg_allocate_host_range_device(r.ctx, &r.ainp, &r.aout, r.d0, r.d1, r.stream);
+      if (rc) return merr(m, rc, "rank %d: %s", k, evg_last_error(r.ctx));
+    }
+    if (int rc2 = mark(k, 3)) return rc2;
+  }
+  // ---- gather ----
+  if (m->loopback) {
+    for (int k = 1; k < n; k++) {
+      Rank& r = m->r[k];
+      EVGM_HIP(m, hipSetDevice(r.device));
+      out_slices(m, k, sl);
+      for (const Slice& s : sl) EVGM_HIP(m, hipMemcpyAsync(m->r[0].out + s.off, r.out + s.off, s.bytes, hipMemcpyDeviceToDevice, r.stream));
+    }
+  } else if (n > 1) {
+    EVGM_NCCL(m, g_rccl.GroupStart());
+    for (int k = 1; k < n; k++) {
+      out_slices(m, k, sl);
+      for (const Slice& s : sl) {
+        EVGM_NCCL(m, g_rccl.Send(m->r[k].out + s.off, s.bytes, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
+        EVGM_NCCL(m, g_rccl.Recv(m->r[0].out + s.off, s.bytes, ncclUint8, k, m->r[0].comm, m->r[0].stream));
+      }
+    }
+    EVGM_NCCL(m, g_rccl.GroupEnd());
+  }
+  for (int k = 0; k < n; k++) if (int rc = mark(k, 4)) return rc;
+  for (int k = 0; k < n; k++) {
+    EVGM_HIP(m, hipSetDevice(m->r[k].device));
+    EVGM_HIP(m, hipStreamSynchronize(m->r[k].stream));
+  }
+  for (int k = 0; k < n; k++)
+    if (int rc = evg_take_device_status(m->r[k].ctx)) return merr(m, rc, "rank %d: %s", k, evg_last_error(m->r[k].ctx));
+  return EVG_OK;
+}
+
+// Per-phase HIP-event times of the last tick, the maximum over the ranks (ms): move-in | plan | allocate | gather. Enable first
+// (the events cost stream time at these step lengths, like bench.py's).
+int evg_multi_profile(evg_multi* m, int enable) {
+  if (!m) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  m->timed = enable != 0;
+  return EVG_OK;
+}
+int evg_multi_last_tick_ms(evg_multi* m, float* ms4) {
+  if (!m || !ms4) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (!m->timed) return evgm::merr(m, EVG_E_INVALID, "evg_multi_last_tick_ms: evg_multi_profile was not enabled");
+  for (int q = 0; q < 4; q++) ms4[q] = 0.f;
+  for (evgm::Rank& r : m->r)
+    for (int q = 0; q < 4; q++) {
+      float t = 0.f;
+      EVGM_HIP(m, hipSetDevice(r.device));
+      EVGM_HIP(m, hipEventElapsedTime(&t, r.ev[q], r.ev[q + 1]));
+      ms4[q] = std::max(ms4[q], t);
+    }
+  return EVG_OK;
+}
+
+// Downloads rank 0's full-size results into the caller's host buffers (NULL pointers / structs are skipped); `breakdown` by task
+// is not produced here (ask for EVG_MULTI_UNIT_ROWS: unit_of_task + unit_breakdown).
+int evg_multi_results(evg_multi* m, const evg_plan_output* out, const evg_alloc_output* aout) {
+  using namespace evgm;
+  if (!m) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (!m->loaded) return merr(m, EVG_E_INVALID, "evg_multi_results: no pool is loaded");
+  const Layout& L = m->lay;
+  const Outs& o = m->o;
+  Rank& root = m->r[0];
+  EVGM_HIP(m, hipSetDevice(root.device));
+  auto down = [&](void* h, size_t off, size_t bytes) -> int {
+    if (!h || !bytes) return EVG_OK;
+    EVGM_HIP(m, hipMemcpyAsync(h, root.out + off, bytes, hipMemcpyDeviceToHost, root.stream));
+    return EVG_OK;
+  };
+  int rc = EVG_OK;
+  if (out) {
+    if (out->breakdown) return merr(m, EVG_E_INVALID, "rows by task are not gathered: ask for unit_of_task + unit_breakdown (EVG_MULTI_UNIT_ROWS)");
+    if ((out->unit_of_task || out->unit_breakdown) && !(m->flags & EVG_MULTI_UNIT_ROWS)) return merr(m, EVG_E_INVALID, "created without EVG_MULTI_UNIT_ROWS");
+    if (!rc) rc = down(out->order, o.order, 4 * L.N);
+    if (!rc) rc = down(out->deps_met, o.met, L.N);
+    if (!rc) rc = down(out->wait_ns, o.wait, 8 * L.N);
+    if (!rc) rc = down(out->distro_info, o.di, sizeof(evg_distro_info) * L.D);
+    if (!rc) rc = down(out->group_info, o.gi, sizeof(evg_group_info) * (L.D + L.TG));
+    if (!rc) rc = down(out->unit_of_task, o.uot, 4 * L.N);
+    if (!rc) rc = down(out->unit_breakdown, o.ubd, 8 * EVG_BREAKDOWN_FIELDS * m->n_slots);
+  }
+  if (aout && L.has_hosts) {
+    if (!rc) rc = down(aout->new_hosts, o.alloc, 4 * L.D);
+    if (!rc) rc = down(aout->free_hosts, o.alloc + 4 * L.D, 4 * L.D);
+    if (!rc) rc = down(aout->status, o.alloc + 8 * L.D, 4 * L.D);
+  }
+  (void)hipStreamSynchronize(root.stream);  // nothing of the caller's is touched after the return, error or not
+  return rc;
+}
+
+// Test hook: fills rank 0's output block with a byte pattern (a rank that wrote outside its slices, or a slice that never
+// arrived, shows in the gathered result).
+int evg_multi_poison_outputs(evg_multi* m, int32_t byte) {
+  if (!m) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (!m->loaded) return EVG_E_INVALID;
+  for (evgm::Rank& r : m->r) {
+    EVGM_HIP(m, hipSetDevice(r.device));
+    EVGM_HIP(m, hipMemsetAsync(r.out, byte, m->o.total, r.stream));
+    EVGM_HIP(m, hipStreamSynchronize(r.stream));
+  }
+  return EVG_OK;
+}
+
+}  // extern "C"

@@ -1769,3 +1769,5 @@ int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_ou
 }
 
 }  // extern "C"
+
+#include "evg_multi.hip.h"

@@ -25,6 +25,8 @@ EXPORTS = [
     "evg_plan_distro_range_device", "evg_allocate_host_range_device", "evg_selftest_unit_value",
     "evg_host_alloc", "evg_host_free", "evg_profile_plan_kernel", "evg_last_plan_kernel_ms", "evg_plan_launch_hints",
     "evg_check_abi", "evg_take_device_status", "evg_pool_load", "evg_pool_update", "evg_pool_plan",
+    "evg_multi_create", "evg_multi_destroy", "evg_multi_last_error", "evg_multi_load", "evg_multi_tick", "evg_multi_results",
+    "evg_multi_ranges", "evg_multi_profile", "evg_multi_last_tick_ms", "evg_multi_poison_outputs", "evg_balanced_ranges",
 ]
 
 _lib = None
@@ -99,6 +101,20 @@ def load_library() -> C.CDLL:
         if rc != abi.EVG_OK:
             raise NativeError("%s: ABI %#x does not match this binding (%d.%d, struct sizes)" % (LIB_PATH, lib.evg_abi_version(), abi.EVG_ABI_MAJOR,
                                                                                              abi.EVG_ABI_MINOR))
+    if hasattr(lib, "evg_multi_create"):  # ABI 3.1
+        lib.evg_multi_create.restype = C.c_void_p
+        lib.evg_multi_create.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32]
+        lib.evg_multi_destroy.argtypes = [C.c_void_p]
+        lib.evg_multi_last_error.restype = C.c_char_p
+        lib.evg_multi_last_error.argtypes = [C.c_void_p]
+        lib.evg_multi_load.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.AllocInput)]
+        lib.evg_multi_tick.argtypes = [C.c_void_p, C.c_int64]
+        lib.evg_multi_results.argtypes = [C.c_void_p, C.POINTER(abi.PlanOutput), C.POINTER(abi.AllocOutput)]
+        lib.evg_multi_ranges.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.evg_multi_profile.argtypes = [C.c_void_p, C.c_int]
+        lib.evg_multi_last_tick_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        lib.evg_multi_poison_outputs.argtypes = [C.c_void_p, C.c_int32]
+        lib.evg_balanced_ranges.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     if hasattr(lib, "evg_selftest_unit_value"):  # absent from older builds loaded through EVG_SCHED_LIB (A/B runs)
         lib.evg_selftest_unit_value.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
@@ -115,6 +131,96 @@ def launch_hints(batch: abi.PlanBatch):
     if rc != abi.EVG_OK:
         raise NativeError("evg_plan_launch_hints failed (%d)" % rc)
     return int(mx.value), int(pr.value), int(nb.value)
+
+
+def balanced_ranges(task_off, world: int):
+    """evg_balanced_ranges: the contiguous distro ranges `world` ranks plan, as the LIBRARY cuts them (host only; the Python driver's
+    own multi.balanced_ranges must agree, tests/test_abi.py)."""
+    lib = load_library()
+    off = np.ascontiguousarray(task_off, np.int32)
+    b, e = (C.c_int32 * world)(), (C.c_int32 * world)()
+    rc = lib.evg_balanced_ranges(off.ctypes.data_as(C.POINTER(C.c_int32)), len(off) - 1, world, b, e)
+    if rc != abi.EVG_OK:
+        raise NativeError("evg_balanced_ranges failed (%d)" % rc)
+    return [(int(b[k]), int(e[k])) for k in range(world)]
+
+
+MULTI_SCATTER, MULTI_UNIT_ROWS, MULTI_LOOPBACK = 0x1, 0x2, 0x100
+
+
+class MultiContext:
+    """evg_multi wrapper: several devices driven from THIS process through the C ABI (include/evg_sched.h, ABI 3.1) -- what
+    shim/gpu_multi.go calls. rank k = devices[k]; rank 0 holds the pool and receives the gathered results."""
+
+    def __init__(self, devices, scatter: bool = False, units: bool = False, loopback: bool = False):
+        self.lib = load_library()
+        self.devices = list(devices)
+        self.units = units
+        flags = (MULTI_SCATTER if scatter else 0) | (MULTI_UNIT_ROWS if units else 0) | (MULTI_LOOPBACK if loopback else 0)
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        self.h = self.lib.evg_multi_create(arr, len(self.devices), flags)
+        if not self.h:
+            raise NativeError("evg_multi_create(%s) failed: %s" % (self.devices, (self.lib.evg_multi_last_error(None) or b"?").decode()))
+        self.batch = None
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.evg_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != abi.EVG_OK:
+            raise NativeError("%s failed (%d): %s" % (what, rc, (self.lib.evg_multi_last_error(self.h) or b"?").decode()))
+
+    def load(self, batch: abi.PlanBatch) -> None:
+        inp = abi.make_plan_input(batch)
+        ainp = None
+        if batch.alloc_params is not None:
+            # distro_info / group_info are ignored by evg_multi_load (each rank's allocator reads its planner's device rows)
+            ainp = abi.make_alloc_input(batch, np.zeros(max(batch.n_distros, 1), abi.DISTRO_INFO_DTYPE),
+                                        np.zeros(batch.n_distros + batch.n_task_groups + 1, abi.GROUP_INFO_DTYPE))
+        self._check(self.lib.evg_multi_load(self.h, C.byref(inp), C.byref(ainp) if ainp is not None else None), "evg_multi_load")
+        self.batch = batch
+
+    def ranges(self):
+        n = len(self.devices)
+        b, e = (C.c_int32 * n)(), (C.c_int32 * n)()
+        self._check(self.lib.evg_multi_ranges(self.h, b, e), "evg_multi_ranges")
+        return [(int(b[k]), int(e[k])) for k in range(n)]
+
+    def tick(self, now_ns: Optional[int] = None) -> None:
+        self._check(self.lib.evg_multi_tick(self.h, self.batch.now_ns if now_ns is None else now_ns), "evg_multi_tick")
+
+    def profile(self, enable: bool = True) -> None:
+        self._check(self.lib.evg_multi_profile(self.h, 1 if enable else 0), "evg_multi_profile")
+
+    def last_tick_ms(self):
+        ms = (C.c_float * 4)()
+        self._check(self.lib.evg_multi_last_tick_ms(self.h, ms), "evg_multi_last_tick_ms")
+        return {"pool-move-in": float(ms[0]), "planning-distro": float(ms[1]), "host-allocation": float(ms[2]), "queue-gather": float(ms[3])}
+
+    def poison_outputs(self, byte: int = 0xA5) -> None:
+        self._check(self.lib.evg_multi_poison_outputs(self.h, byte), "evg_multi_poison_outputs")
+
+    def results(self):
+        """(PlanResult, AllocResult or None) downloaded from rank 0."""
+        b = self.batch
+        res = abi.PlanResult.alloc_host(b, breakdown=False, n_units=False, units=self.units)
+        out = res.c_output()
+        ares, aout = None, None
+        if b.alloc_params is not None:
+            ares = abi.AllocResult.alloc_host(b.n_distros)
+            aout = ares.c_output()
+        self._check(self.lib.evg_multi_results(self.h, C.byref(out), C.byref(aout) if aout is not None else None), "evg_multi_results")
+        if self.units and res.unit_breakdown is not None:
+            res.breakdown = np.ascontiguousarray(res.unit_breakdown[:, res.unit_of_task].T)
+        return res, ares
 
 
 class Context:

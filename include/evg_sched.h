@@ -354,7 +354,7 @@ const char* evg_last_error(const evg_ctx* ctx);
  * and the one-launch evg_plan_allocate[_range]_device entry points are gone -- measured no faster than the two calls for three
  * rounds); MINOR adds entry points only. */
 #define EVG_ABI_MAJOR 3
-#define EVG_ABI_MINOR 0
+#define EVG_ABI_MINOR 1 /* 3.1: the evg_multi_* entry points (several devices from one process) and evg_balanced_ranges */
 int32_t evg_abi_version(void);
 /* What a binding calls once at start-up with ITS compile-time view of the header: EVG_OK iff the library's major equals
  * `major`, its minor is at least `minor`, and the four struct sizes are the library's. A binding must refuse the library
@@ -585,6 +585,54 @@ int evg_allocator_report_device(evg_ctx* ctx, int32_t n_distros, const int32_t* 
 int evg_allocator_report(evg_ctx* ctx, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
                          const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
                          const evg_report_params* params, evg_alloc_report* report);
+
+/* ---- several MI355X from ONE process (ABI 3.1; SURVEY.md 8e, BASELINE configs 4 and 5) ----------------------------------------
+ * north_star: "Distros shard naturally across the 8 GPUs of one node with a single RCCL broadcast of the shared runnable-task pool
+ * over xGMI and a gather of the per-distro TaskQueue back to rank 0". The reference plans every distro from ONE scheduler process
+ * (units/crons.go:303-332: one job per distro, all enqueued by the same process), so this is the shape a Go caller needs: one
+ * evg_multi owns one context + stream per device and one RCCL communicator per device (ncclCommInitAll; RCCL is loaded on first
+ * use, a single-GPU caller never touches it). Rank k = devices[k]; rank 0 holds the tick's pool and receives the results.
+ *
+ *   evg_multi_load     host pointers; validates the batch, packs it ONCE (page-locked) into one buffer -- a 256-byte header, then
+ *                      every column at the next multiple of 256 bytes, the layout of evergreen_amd/multi.py -- uploads it to rank
+ *                      0's device and cuts the contiguous distro ranges (evg_balanced_ranges). `alloc` may be NULL (plan only);
+ *                      its distro_info / group_info pointers are ignored: each rank's allocator reads the rows its planner left
+ *                      on the device
+ *   evg_multi_tick     move-in: ONE ncclBroadcast of the packed pool from rank 0 -- or, created with EVG_MULTI_SCATTER, one group
+ *                      of ncclSend / ncclRecv that hands every rank only the slices its range reads (SURVEY 8e's cheaper form);
+ *                      every rank: evg_plan_distro_range_device + evg_allocate_host_range_device over its range (the reference's
+ *                      two jobs, scheduler/wrapper.go:107 and units/host_allocator.go:183-188), outputs in the FULL batch's
+ *                      numbering; gather: one group of ncclSend / ncclRecv, every result slice straight to its final place in
+ *                      rank 0's arrays. Returns when every device has finished; a false promise on any rank is EVG_E_CONTRACT
+ *   evg_multi_results  downloads rank 0's arrays into host buffers (NULL pointers are skipped). Rows by task (`breakdown`) are not
+ *                      gathered: create with EVG_MULTI_UNIT_ROWS and ask for unit_of_task + unit_breakdown
+ *
+ * EVG_MULTI_LOOPBACK is the test transport of a one-GPU box: device copies instead of RCCL, and `devices` may repeat an ordinal
+ * (RCCL refuses that), so the ranks of an N-GPU world run one after the other on one GPU. Never selected implicitly. */
+typedef struct evg_multi evg_multi;
+#define EVG_MULTI_SCATTER 0x1
+#define EVG_MULTI_UNIT_ROWS 0x2
+#define EVG_MULTI_LOOPBACK 0x100
+evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t flags);
+void evg_multi_destroy(evg_multi* m);
+const char* evg_multi_last_error(const evg_multi* m); /* m == NULL: of the failed evg_multi_create */
+int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input* alloc);
+int evg_multi_tick(evg_multi* m, int64_t now_ns);
+int evg_multi_results(evg_multi* m, const evg_plan_output* out, const evg_alloc_output* aout);
+int evg_multi_ranges(const evg_multi* m, int32_t* d_begin, int32_t* d_end); /* n_devices entries each: rank k plans [d_begin[k], d_end[k]) */
+/* Measurement: HIP events on every rank's stream around the four phases of a tick; ms4 = move-in | plan | allocate | gather, each
+ * the maximum over the ranks. */
+int evg_multi_profile(evg_multi* m, int enable);
+int evg_multi_last_tick_ms(evg_multi* m, float* ms4);
+/* Test hook: fills every rank's output block with `byte` (a slice that never arrived shows in the gathered result). */
+int evg_multi_poison_outputs(evg_multi* m, int32_t byte);
+
+/* Host only: the contiguous distro ranges `world` ranks plan, minimising the largest rank COST (a distro is never split: a rank's
+ * results must be contiguous slices of the full-size outputs). Cost of a distro = tasks on the two-per-CU tier of the one-workgroup
+ * kernel, x2 on its one-per-CU tier (2049..4096 tasks), x4 on the large-distro pipeline (measured); the
+ * same integers as evergreen_amd/multi.py:balanced_ranges, so every driver cuts the same ranges. Ranks past the last range get
+ * empty ranges. */
+int evg_balanced_ranges(const int32_t* task_off, int32_t n_distros, int32_t world, int32_t* d_begin, int32_t* d_end);
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,12 @@
 #!/bin/bash
-# round 4, first GPU call: the new paths' parity tests, the cliff A/B over the big tier's modes, per-kernel stats of one cliff case
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R; export PYTHONPATH=$R
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "big_tier or tiers_promise or large_parser or golden_vectors or ragged or promise or resident_tick or size_hint or config_small" 2>&1 | tail -15 | tee $OUT/r04a_pytest_new.log
-timeout 300 python -m pytest tests/test_host_shim_cpp.py tests/test_gpu_sharded.py -m gpu -x -q 2>&1 | tail -5 | tee -a $OUT/r04a_pytest_new.log
-timeout 600 python scripts/bench_cliff.py 2,1,0 2>&1 | tee $OUT/r04a_cliff.log
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof/r04a-cliff -o r04a -- python $R/scripts/bench_cliff.py 2 --cases 1:2049,8:4096,64:4096 --steps 20 > $OUT/r04a_cliff_prof.log 2>&1
-find $OUT/prof/r04a-cliff -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -12 {}' | cut -c1-200
+# round 4, GPU call A: the whole GPU suite, the driver's bench line, per-kernel stats + FETCH/WRITE + SQ counters of the headline
+# tick and of the config-5 share (every k_tiled_* kernel), the cliff sweep over the big tier's modes
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT/prof; cd $R; export PYTHONPATH=$R
+TAG=${1:-r04a}
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $OUT/${TAG}_pytest.log
+timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -3 > $OUT/${TAG}_bench.log; tail -c 600 $OUT/${TAG}_bench.log
+timeout 600 python scripts/bench_cliff.py 1,0 --steps 20 2>&1 | tee $OUT/${TAG}_cliff.log
+PROFILE_ONLY=1 C5=1 bash scripts/gpu_round.sh $TAG 2>&1 | tail -60 > $OUT/${TAG}_round.log
+bash scripts/pmc_sq.sh $TAG > $OUT/${TAG}_sq_counters.txt 2>&1
+bash scripts/pmc_sq.sh ${TAG}_c5 python $R/scripts/bench_config5.py 1250000 64 --steps 5 > $OUT/${TAG}_c5_sq_counters.txt 2>&1
+tail -40 $OUT/${TAG}_c5_sq_counters.txt

@@ -1,0 +1,116 @@
+//go:build cgo && evg_mi355x
+
+// gpu_multi.go -- several MI355X behind the BATCHED planner of gpu_planner.go (include/evg_sched.h, ABI 3.1: evg_multi_*).
+//
+// north_star / SURVEY.md 8e: "Distros shard naturally across the 8 GPUs of one node with a single RCCL broadcast of the shared
+// runnable-task pool over xGMI and a gather of the per-distro TaskQueue back to rank 0." The scheduler is ONE Go process that
+// enqueues a job per distro (units/crons.go:303-332), so the sharding lives behind the C ABI: the library owns one context and
+// one RCCL communicator per device, cuts the contiguous distro ranges (evg_balanced_ranges) and runs the tick; this file only
+// decides WHEN a batch is worth spreading and hands the library the same two structs planBatch fills for one device.
+//
+// NEVER COMPILED HERE (no Go toolchain in the build image), like the rest of shim/. The library side is exercised by
+// tests/test_gpu_multi_abi.py: a world of one through RCCL, and 3 / 4 / 5 / 8 emulated ranks on one device.
+package scheduler
+
+/*
+#include <stdint.h>
+#include "evg_sched.h"
+*/
+import "C"
+
+import (
+	"context"
+	"sync"
+
+	"github.com/evergreen-ci/evergreen/model"
+	"github.com/evergreen-ci/evergreen/model/distro"
+	"github.com/evergreen-ci/evergreen/model/task"
+	"github.com/pkg/errors"
+)
+
+// gpuDevices is what SetGPUDevices last stored: the HIP ordinals the batched planner may use. One device (the default) keeps
+// every call on gpuPool's per-goroutine contexts.
+var (
+	gpuDevices   = []int{0}
+	gpuDevicesMu sync.Mutex
+	gpuShard     *gpuMulti
+)
+
+// minTasksPerDevice: below this a batch stays on one device -- the broadcast of the pool costs more than the kernels it
+// spreads (DESIGN.md section 4: 84.6 MB over xGMI against ~60 us of kernels for 1 M tasks on ONE MI355X; BASELINE config 5's
+// 10 M tasks are where eight devices pay).
+const minTasksPerDevice = 1 << 20
+
+type gpuMulti struct {
+	mu sync.Mutex // one tick at a time: the evg_multi owns one pool
+	m  *C.evg_multi
+	n  int
+}
+
+// SetGPUDevices selects the devices of the batched planner; an existing multi-device context is torn down. Call it at start-up
+// (units/crons.go populates its queue from one goroutine).
+func SetGPUDevices(devs []int) {
+	gpuDevicesMu.Lock()
+	defer gpuDevicesMu.Unlock()
+	if gpuShard != nil {
+		gpuShard.mu.Lock()
+		C.evg_multi_destroy(gpuShard.m)
+		gpuShard.mu.Unlock()
+		gpuShard = nil
+	}
+	gpuDevices = append([]int(nil), devs...)
+	if len(gpuDevices) == 0 {
+		gpuDevices = []int{0}
+	}
+	gpuPool.dev = C.int(gpuDevices[0])
+}
+
+// shardFor returns the multi-device context when a batch of n tasks over D distros should be spread, nil otherwise.
+func shardFor(n, D int) (*gpuMulti, error) {
+	gpuDevicesMu.Lock()
+	defer gpuDevicesMu.Unlock()
+	k := len(gpuDevices)
+	if k < 2 || D < k || n < k*minTasksPerDevice {
+		return nil, nil
+	}
+	if gpuShard == nil {
+		devs := make([]C.int32_t, k)
+		for i, d := range gpuDevices {
+			devs[i] = C.int32_t(d)
+		}
+		// unit rows: planBatch stamps SortingValueBreakdown from unit_of_task + unit_breakdown (planner.go:475)
+		m := C.evg_multi_create(ptr(devs), C.int32_t(k), C.EVG_MULTI_UNIT_ROWS)
+		if m == nil {
+			return nil, errors.Errorf("evg_multi_create: %s", C.GoString(C.evg_multi_last_error(nil)))
+		}
+		gpuShard = &gpuMulti{m: m, n: k}
+	}
+	return gpuShard, nil
+}
+
+// plan is evg_plan_distros spread over the devices: the same input and output structs (host memory of the caller's arena),
+// the same results bit for bit. The pool is packed once, broadcast, every device plans its distro range, the slices come back.
+func (s *gpuMulti) plan(in *C.evg_plan_input, out *C.evg_plan_output) error {
+	s.mu.Lock()
+	defer s.mu.Unlock()
+	if rc := C.evg_multi_load(s.m, in, nil); rc != C.EVG_OK {
+		return errors.Errorf("evg_multi_load: %s (%d)", C.GoString(C.evg_multi_last_error(s.m)), int(rc))
+	}
+	if rc := C.evg_multi_tick(s.m, in.now_ns); rc != C.EVG_OK {
+		return errors.Errorf("evg_multi_tick: %s (%d)", C.GoString(C.evg_multi_last_error(s.m)), int(rc))
+	}
+	if rc := C.evg_multi_results(s.m, out, nil); rc != C.EVG_OK {
+		return errors.Errorf("evg_multi_results: %s (%d)", C.GoString(C.evg_multi_last_error(s.m)), int(rc))
+	}
+	return nil
+}
+
+// PlanAllDistros is the batched cron's body: every (distro, queue) pair of a tick in ONE call -- on one device, or sharded by
+// distro over the devices of SetGPUDevices when the tick is large enough. Per distro it returns what runTunablePlanner would
+// have produced (scheduler/scheduler.go:35-52): the re-ordered, stamped tasks and the DistroQueueInfo.
+func PlanAllDistros(ctx context.Context, ds []*distro.Distro, queues [][]task.Task) ([][]task.Task, []model.DistroQueueInfo, error) {
+	if len(ds) != len(queues) {
+		return nil, nil, errors.New("PlanAllDistros: one queue per distro")
+	}
+	return planBatch(ctx, ds, queues)
+}

@@ -478,7 +478,17 @@ func planBatch(ctx context.Context, ds []*distro.Distro, queues [][]task.Task) (
 	var pin runtime.Pinner
 	defer pin.Unpin()
 
-	if rc := C.evg_plan_distros(g.c, &in, &out); rc != C.EVG_OK {
+	// One device, or -- a tick large enough to pay for the broadcast, gpu_multi.go -- the same two structs spread over the
+	// devices of SetGPUDevices by the library (evg_multi_*): identical results either way.
+	shard, err := shardFor(n, D)
+	if err != nil {
+		return nil, nil, err
+	}
+	if shard != nil {
+		if err := shard.plan(&in, &out); err != nil {
+			return nil, nil, err
+		}
+	} else if rc := C.evg_plan_distros(g.c, &in, &out); rc != C.EVG_OK {
 		return nil, nil, errors.Errorf("evg_plan_distros: %s (%d)", C.GoString(C.evg_last_error(g.c)), int(rc))
 	}
 

@@ -177,3 +177,19 @@ def test_plan_launch_hints_on_host(lib):
     fits = all(max(32 * ((s + 1) & ~1), 57344) + 2 * ((e + 7) & ~7) <= 79872 - 4096 for s, e in zip(S, n_e))
     assert hints(edges)[1] == (BOTH if fits else abi.EVG_PROMISE_ALL_ON_LDS_TIERS)  # 2000 tasks always fit the CU's whole LDS
     assert hints(edges)[2] == (0 if fits else sum(1 for s, e in zip(S, n_e) if max(32 * ((s + 1) & ~1), 57344) + 2 * ((e + 7) & ~7) > 79872 - 4096))
+
+
+def test_library_cuts_the_same_ranges_as_the_python_driver():
+    """evg_balanced_ranges (what evg_multi_load and a Go caller use) == evergreen_amd/multi.py:balanced_ranges, on uniform, Zipf and
+    degenerate offset tables: the one-process and the one-process-per-GPU drivers shard a pool identically."""
+    from evergreen_amd import multi, native
+    rng = np.random.default_rng(5)
+    tables = [np.arange(0, 513) * 1953, np.array([0]), np.array([0, 0, 0, 7]), np.array([0, 5000])]
+    for _ in range(40):
+        D = int(rng.integers(1, 300))
+        sizes = np.minimum((rng.zipf(1.3, D) * rng.integers(1, 400)).astype(np.int64), 70_000)
+        sizes[rng.random(D) < 0.05] = 0
+        tables.append(np.concatenate([[0], np.cumsum(sizes)]))
+    for off in tables:
+        for world in (1, 2, 3, 4, 8, 13):
+            assert native.balanced_ranges(off.astype(np.int32), world) == multi.balanced_ranges(off, world), (off[:8], world)

@@ -1,0 +1,97 @@
+"""-m gpu: several devices from ONE process through the C ABI (include/evg_sched.h, evg_multi_*) on a one-GPU box:
+a world of one through RCCL itself (ncclCommInitAll, the in-place ncclBroadcast of the packed pool), and the ranks of 3 / 4 / 5-GPU
+worlds emulated one after the other on the same device over the loopback transport (device copies where RCCL's collectives go) --
+poisoned outputs first, so a slice that never arrived or a rank that wrote outside its range shows in the gathered result."""
+import numpy as np
+import pytest
+
+from evergreen_amd import gen, multi, native
+from tests import compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _want(oracle, b):
+    want = oracle.plan(b, breakdown=True, n_units=False)
+    want.n_units = None
+    return want, (oracle.allocate(b, want.distro_info, want.group_info) if b.alloc_params is not None else None)
+
+
+def _check(m, b, want, want_alloc, what):
+    got, got_alloc = m.results()
+    compare.assert_plan_equal(got, want, b, what)
+    if m.units:
+        compare.reference_validity(b, got)
+    if want_alloc is not None:
+        compare.assert_alloc_equal(got_alloc, want_alloc, what)
+        for name in ("count_free", "count_required"):
+            assert np.array_equal(got.group_info[name], want.group_info[name]), what + " " + name
+
+
+@pytest.mark.parametrize("scatter", [False, True], ids=["broadcast", "scatter"])
+def test_world_of_one_through_rccl(oracle, scatter):
+    """evg_multi_create([0]) builds a real RCCL communicator; the tick's broadcast goes through ncclBroadcast."""
+    b = gen.generate(gen.config(2))
+    m = native.MultiContext([0], scatter=scatter, units=True)
+    try:
+        m.load(b)
+        assert m.ranges() == [(0, b.n_distros)]
+        m.poison_outputs()
+        m.tick()
+        m.tick()  # a second tick over the resident pool gives the same result
+        want, want_alloc = _want(oracle, b)
+        _check(m, b, want, want_alloc, "multi x1 rccl")
+        m.profile(True)
+        m.tick()
+        ms = m.last_tick_ms()
+        assert set(ms) == {"pool-move-in", "planning-distro", "host-allocation", "queue-gather"} and ms["planning-distro"] > 0
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("scatter", [False, True], ids=["broadcast", "scatter"])
+@pytest.mark.parametrize("cfg,world", [(gen.config(2), 4), (gen.GenConfig(60_000, 24, gen.SEED_BASE + 31, skew=True), 3),
+                                       (gen.config(5, n_tasks=150_000, n_distros=12), 5), (gen.config(1), 8)],
+                         ids=["config2x4", "skewed-x3", "config5-shape-x5", "config1x8"])
+def test_emulated_ranks_gather_the_whole_plan(oracle, cfg, world, scatter):
+    b = gen.generate(cfg)
+    m = native.MultiContext([0] * world, scatter=scatter, units=True, loopback=True)
+    try:
+        m.load(b)
+        rg = m.ranges()
+        assert rg == multi.balanced_ranges(b.task_off, world) and rg[0][0] == 0 and rg[-1][1] == b.n_distros
+        m.poison_outputs()
+        m.tick()
+        want, want_alloc = _want(oracle, b)
+        _check(m, b, want, want_alloc, "multi loopback x%d" % world)
+        # a second pool into the same evg_multi (other sizes: every buffer and range is rebuilt)
+        b2 = gen.generate(gen.GenConfig(20_000, 9, gen.SEED_BASE + 77))
+        m.load(b2)
+        m.poison_outputs()
+        m.tick(b2.now_ns)
+        want2, want_alloc2 = _want(oracle, b2)
+        _check(m, b2, want2, want_alloc2, "multi loopback x%d, second pool" % world)
+    finally:
+        m.close()
+
+
+def test_plan_only_pool_and_errors(oracle):
+    import dataclasses
+    b = gen.generate(gen.config(1))
+    nb = dataclasses.replace(b, alloc_params=None, host_off=None, hosts={})
+    m = native.MultiContext([0, 0], loopback=True)
+    try:
+        with pytest.raises(native.NativeError):
+            m.tick(0)  # nothing loaded
+        m.load(nb)
+        m.tick()
+        got, got_alloc = m.results()
+        assert got_alloc is None
+        want = oracle.plan(nb, breakdown=False, n_units=False)
+        assert np.array_equal(got.order, want.order) and np.array_equal(got.distro_info, want.distro_info)
+    finally:
+        m.close()
+    with pytest.raises(native.NativeError):
+        native.MultiContext([0, 0])  # RCCL wants distinct devices: refused before any communicator is built
+    with pytest.raises(native.NativeError):
+        native.MultiContext([99])

@@ -100,7 +100,8 @@ def test_go_shim_files_are_complete():
         assert re.search(r"\b%s\b" % name, header), "shim names C.%s, which include/evg_sched.h does not declare" % name
     defined = set(re.findall(r"^func (?:\([^)]*\) )?([A-Za-z_][A-Za-z0-9_]*)", src, flags=re.M))
     for helper in ("planBatch", "allocateBatch", "intern", "taskFlags", "depRequired", "fetchedDepStates", "breakdownOfUnit", "depsMetTime",
-                   "queueInfoFromRows", "providerClass", "unixNS", "boolToC", "statusClass", "carveSlice", "runGPUPlanner"):
+                   "queueInfoFromRows", "providerClass", "unixNS", "boolToC", "statusClass", "carveSlice", "runGPUPlanner", "shardFor", "SetGPUDevices",
+                   "PlanAllDistros"):
         assert helper in defined, "shim helper %s is named but not defined" % helper
     assert "var GPUTaskPlanner TaskPlanner" in src and "var GPUHostAllocator HostAllocator" in src
 
