@@ -65,14 +65,16 @@ struct PlanArgs {
   // the many-workgroups-per-distro path for large distros (evg_tiled.hip.h)
   struct TState* w_ts;         // [D]
   int32_t *w_rtile, *w_stile;  // (distro, tile) of every row tile / slot tile
-  int32_t* w_ntile;            // [2] their numbers
+  int32_t* w_ntile;            // [3] their numbers; [2]: the sort buckets of the sample-sorted distros
+  int32_t* w_btile;            // (distro, bucket) of every sort bucket
+  uint32_t* w_bcur;            // keys placed in every sort bucket so far (k_ss_partition), then its size
+  void* w_split;               // 192-bit splitters: splitter b of a distro at index ss_base + b
   void* w_bucket;              // int2 (offset, count) per (row tile, slot tile) pair
   void* w_rec;                 // [2N + E] membership records (TRec)
   int32_t* w_eslot;            // [E] unit slot a dependency edge adds a membership to, or -1
   void *w_keyA, *w_keyB;       // 192-bit sort keys, ping-pong
   unsigned long long* w_gfirst;  // [D + n_tg] (first queue position << 32) | TaskGroupMaxHosts of that task
   unsigned long long* w_tgbit;   // one bit per row of every row tile: the row is a task-group task
-  uint32_t* w_srank;             // [row tiles x 64] rank of every sample key of a sorted tile among ALL keys of its distro
   int32_t tiled_mode;            // TM_* bits (EVG_TILED_MODE; 0 = default)
   uint32_t* w_status;            // host-visible status word of the context (evg_take_device_status), or nullptr: set to 1 by a
                                  // planner workgroup that cannot plan its distro although the batch promised it could

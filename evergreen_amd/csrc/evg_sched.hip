@@ -915,7 +915,7 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.w_key = c->scratch[21].p;
   a.w_ts = nullptr; a.w_rtile = nullptr; a.w_stile = nullptr; a.w_ntile = nullptr; a.w_bucket = nullptr; a.w_rec = nullptr;
   a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr; a.w_tgbit = nullptr;
-  a.w_srank = nullptr;
+  a.w_btile = nullptr; a.w_bcur = nullptr; a.w_split = nullptr;
   a.tiled_mode = c->tiled_mode;
   a.big_tier = 0;
   a.w_status = (in->promises & EVG_PROMISE_ALL_ON_LDS_PATH) ? c->status_word : nullptr;  // launch_plan arms it for ALL_ON_LDS_TIERS
@@ -997,18 +997,31 @@ static size_t tiled_max_slot_tiles(const evg_plan_input* in) {
   return std::min(Stot / evg::kST + D + 1, 5 * N / (2 * evg::kST) + 1);
 }
 
+// Fine buckets / coarse (sort) bucket slots the sample-sorted distros of a batch can have: a distro of n rows has at most
+// n / 256 + 2 fine buckets (ss_buckets) and n / 1024 + 1 coarse slots (ss_coarse_slots), and only distros of more than kRT rows are tiled.
+static size_t tiled_max_fine_buckets(const evg_plan_input* in) {
+  const size_t N = (size_t)in->tasks.n_tasks, D = (size_t)in->n_distros;
+  return N / 256 + 2 * std::min(D, N / evg::kRT + 1) + 1;
+}
+static size_t tiled_max_buckets(const evg_plan_input* in) {
+  const size_t N = (size_t)in->tasks.n_tasks, D = (size_t)in->n_distros;
+  return N / (evg::kRT / 2) + std::min(D, N / evg::kRT + 1) + 1;
+}
+
 // Scratch of the tiled large-distro path (evg_tiled.hip.h); sized from host-known totals, allocated on first need.
-static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, bool pairwise) {
+static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, bool pairwise, bool sample_sort) {
   using namespace evg;
   const size_t N = (size_t)in->tasks.n_tasks, E = (size_t)in->tasks.n_edges, D = (size_t)in->n_distros;
   const size_t G = D + (size_t)in->n_task_groups;
-  const size_t max_rt = tiled_max_row_tiles(in), max_st = tiled_max_slot_tiles(in);
+  const size_t max_rt = tiled_max_row_tiles(in), max_st = tiled_max_slot_tiles(in), max_bt = sample_sort ? tiled_max_buckets(in) : 1,
+               max_ft = sample_sort ? tiled_max_fine_buckets(in) : 1;
   const size_t st_cap = std::min<size_t>(max_st, kMaxST);  // slot tiles of ONE distro
-  // keyB is the pairwise merge passes' second buffer: only distros of more than kMaxWay tiles use it
-  const size_t sz[12] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
-                         4 * (E + 1), sizeof(K192) * max_rt * kRT, pairwise ? sizeof(K192) * max_rt * kRT : 16, 8 * G, 8 * max_rt * (kRT / 64),
-                         4 * max_rt * kSmpPerTile};
-  for (int i = 0; i < 12; i++) {
+  // keyB: the pairwise merge passes' second buffer (distros beyond the sample sort) and the sample sort's fine buckets (1024 slots each)
+  const size_t keyB = std::max<size_t>(pairwise ? sizeof(K192) * max_rt * kRT : 16, sample_sort ? sizeof(K192) * max_ft * kSSFineCap : 16);
+  const size_t sz[14] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
+                         4 * (E + 1), sizeof(K192) * max_rt * kRT, keyB, 8 * G, 8 * max_rt * (kRT / 64),
+                         8 * max_bt, 4 * max_ft, sizeof(K192) * max_ft};
+  for (int i = 0; i < 14; i++) {
     int rc = ensure(c, c->scratch[32 + i], sz[i]);
     if (rc) return rc;
   }
@@ -1017,13 +1030,13 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in,
   a.w_eslot = (int32_t*)c->scratch[38].p; a.w_keyA = c->scratch[39].p; a.w_keyB = c->scratch[40].p;
   a.w_gfirst = (unsigned long long*)c->scratch[41].p;
   a.w_tgbit = (unsigned long long*)c->scratch[42].p;
-  a.w_srank = (uint32_t*)c->scratch[43].p;
+  a.w_btile = (int32_t*)c->scratch[43].p; a.w_bcur = (uint32_t*)c->scratch[44].p; a.w_split = c->scratch[45].p;
   if (!c->tiled_attr_set) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledReduceLds));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_elect, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_merge, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_srank, hipFuncAttributeMaxDynamicSharedMemorySize, kSrankLds));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_mmerge, hipFuncAttributeMaxDynamicSharedMemorySize, kMmergeLds));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_ss_split, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)k_ss_sort, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
     c->tiled_attr_set = true;
   }
   return EVG_OK;
@@ -1033,10 +1046,11 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in,
 // unconditionally and exits at once where there is no work). evg_plan_input.max_distro_tasks (0 = unknown) only shapes
 // the launch, never the result:
 //   hint <= 2048  only data-dependent fallbacks can be flagged: ONE kernel, one workgroup per flagged distro (k_plan_generic);
-//   otherwise     the tiled pipeline (evg_tiled.hip.h, many workgroups per distro): distros of up to kMaxWay row tiles
-//                 (65,536 rows) are merged by ONE multiway pass; for larger ones the pairwise merge passes the hint (or,
-//                 without a hint, the task count) allows are enqueued too. Then k_plan_generic for whatever the pipeline
-//                 left: small flagged distros, distros it cannot take, and distros larger than the hint promised.
+//   otherwise     the tiled pipeline (evg_tiled.hip.h, many workgroups per distro): distros of up to kSSMaxRows rows are
+//                 sample-sorted (split, partition, bucket sort: three launches whatever their size); only when the hint (or,
+//                 without a hint, the task count) allows larger ones are the pairwise merge passes they need enqueued too.
+//                 Then k_plan_generic for whatever the pipeline left: small flagged distros, distros it cannot take, and
+//                 distros larger than the hint promised.
 // TaskPlan.Len() (out->n_units) needs the set-equality pass that only the one-workgroup kernel has.
 static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st) {
   using namespace evg;
@@ -1049,20 +1063,22 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
     return EVG_OK;
   }
   const long long cap = hint < kTiledMaxRows ? hint : kTiledMaxRows - 1;
+  const bool ss = !(a.tiled_mode & TM_NO_SAMPLE_SORT);
   int passes = 0;
-  if (cap > (long long)kMaxWay * kRT || !(a.tiled_mode & TM_MULTIWAY_MERGE))
+  if (!ss || cap > kSSMaxRows)
     while (((long long)kRT << passes) < cap) passes++;
-  int rc = prepare_tiled(c, a, in, passes > 0);
+  int rc = prepare_tiled(c, a, in, passes > 0, ss);
   if (rc) return rc;
   // + 8: the XCD-aware tile mapping (xcd_tile) rounds the tile count up to a multiple of the 8 XCDs
   const dim3 rt((unsigned)tiled_max_row_tiles(in) + 8), stl((unsigned)tiled_max_slot_tiles(in) + 8), tb(kTiledBlock);
-  hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, st, a, passes);
+  hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, st, a, passes, ss ? 1 : 0);
   hipLaunchKernelGGL(k_tiled_scatter, rt, tb, 0, st, a);
   hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, st, a);
   hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, st, a);
-  if (a.tiled_mode & TM_MULTIWAY_MERGE) {
-    hipLaunchKernelGGL(k_tiled_srank, rt, tb, kSrankLds, st, a);
-    hipLaunchKernelGGL(k_tiled_mmerge, rt, tb, kMmergeLds, st, a);
+  if (ss) {
+    hipLaunchKernelGGL(k_ss_split, dim3((unsigned)D), tb, kTiledSortLds, st, a);
+    hipLaunchKernelGGL(k_ss_partition, rt, tb, 0, st, a);
+    hipLaunchKernelGGL(k_ss_sort, dim3((unsigned)tiled_max_buckets(in) + 8), tb, kTiledSortLds, st, a);
   }
   for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, st, a, p);
   hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 1);  // its head writes the info rows of the distros the pipeline finished

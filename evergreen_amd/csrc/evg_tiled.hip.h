@@ -21,10 +21,12 @@
 //   T4 k_tiled_merge    log2(tiles) passes of merge path: every workgroup produces 2048 consecutive outputs of the merge of
 //                       two sorted runs (wave-wide 64-ary diagonal searches in global memory, the window's two key ranges
 //                       staged into LDS as consecutive words, one merge-path round there)
-//      k_tiled_srank    (EVG_TILED_MODE bit 4 only: measured equal, off by default) ONE multiway pass for distros of up to 32
-//      k_tiled_mmerge   tiles: every 32nd key of every sorted tile is a sample with its exact rank in the distro; the workgroup
-//                       of an output window finds the window's split of every tile from the samples + <= 33 candidates per
-//                       tile, loads its <= 32 segments and merges them by rank searches in LDS
+//   -- round 4: distros of up to kSSMaxRows rows are SAMPLE-sorted instead (T3 leaves their keys unsorted; no merge pass):
+//   S1 k_ss_split       per distro: <= 2048 sample keys (one row of every block of `stride` rows, at a hashed offset) sorted in LDS;
+//                       every (ns / B)-th is a splitter; B buckets so that a bucket overflows its 2048 slots at six sigma
+//   S2 k_ss_partition   per row tile: the tile's keys searched against the distro's splitters in LDS, counted per bucket with LDS
+//                       atomics, ONE device atomic per (tile, bucket) reserves the keys' places in the bucket
+//   S3 k_ss_sort        per bucket: <= 2048 keys sorted in LDS (the tile sort), emitted at the bucket's place in the queue (T5)
 //   T5 (tail of T4)     queue order out; first queue position of every task group (TaskGroupInfo.MaxHosts,
 //                       scheduler.go:103-106) -- the merged keys never go back to memory
 //   T6 k_tiled_rows     model.DistroQueueInfo / the standalone TaskGroupInfo row
@@ -50,14 +52,21 @@ constexpr int kTiledMaxRows = 1 << 20;
 constexpr int kTiledMaxSlots = 1 << 21;
 constexpr int kMaxST = (kTiledMaxSlots / kST + 511) / 512 * 512;  // slot tiles of one distro: the scatter kernel buckets them in LDS
 constexpr int kTiledBlock = 512;
-constexpr int kMaxWay = 32;           // sorted tiles one multiway pass merges; larger distros take the pairwise passes
-constexpr int kSmpStride = 32, kSmpPerTile = kRT / kSmpStride;  // sample = the last key of every 32-key block of a sorted tile
-constexpr int kCandWin = kSmpStride + 1;  // candidates per tile at a window boundary
+// Sample sort (S1-S3): a distro of n <= kSSMaxRows rows is cut into B FINE buckets by B - 1 splitters taken from ns <=
+// kSSMaxSamples sampled keys. A fine bucket is the rows between two consecutive chosen order statistics of the sample, (ns / B)
+// sample spacings apart: its size has mean n / B and relative standard deviation 1 / sqrt(ns / B). B is the smallest count for
+// which mean x (1 + 6 / sqrt(ns / B)) stays under the kSSFineCap slots of a fine bucket (ss_buckets): an overflow is a six-sigma
+// event, and when it happens the distro is left, flagged, to the one-workgroup generic kernel like every other misfit -- the plan
+// never changes. The SORT then runs over COARSE buckets: maximal runs of consecutive fine buckets that hold at most 2048 keys
+// together, cut greedily from the exact fine counts -- a sort workgroup is ~88 % full whatever the sample said (sorting the
+// sampled buckets themselves needs them ~64 % full to keep six sigma: half as many workgroups again, and a second wave of them).
+constexpr int kSSMaxSamples = 2048, kSSMaxB = 1024, kSSFineCap = 1024;
+constexpr int kSSMaxRows = 98304;     // the bound holds up to ~100 k rows with B <= n / 256 + 2; beyond: tile sort + merge passes
 constexpr int kTileEdges = 6144;      // dependency edges of one row tile resolved edge-parallel in LDS (more: per row, from memory)
 // PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs; every variant is bit-exact, scripts/r03_modes.sh): 1, 2 = the per-row forms of
-// round 2; 4 = the one-pass multiway merge instead of the pairwise passes; 8 = the rank-merge tile sort (both measured equal or
-// slower: DESIGN.md 3.1); 32 = every thread stores its own keys; 64 = the full networks instead of the merge-path rounds
-constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2, TM_MULTIWAY_MERGE = 4, TM_RANK_MERGE_SORT = 8;  // 16: linear tile mapping (xcd_tile)
+// round 2; 4 = no sample sort (round 3's tile sort + log2(tiles) merge passes for every distro); 32 = every thread stores its own
+// keys
+constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2, TM_NO_SAMPLE_SORT = 4;  // 16: linear tile mapping (xcd_tile)
 
 // blockIdx -> tile, XCD-aware: workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; tile
 // (b % 8) * ceil(T / 8) + b / 8 gives every XCD a contiguous eighth of the tile list, i.e. whole distros. -1: no tile.
@@ -125,7 +134,9 @@ constexpr uint32_t RW_QI = 1u << 16, RW_COUNT = 1u << 17, RW_MQ = 1u << 18, RW_W
 struct TState {
   int32_t on;       // the tiled path plans this distro
   int32_t unfit;    // set on the way: leave it to k_plan_generic after all
-  int32_t n_rt, n_st, rt_base, st_base, passes, way;  // way: one multiway merge pass (n_rt <= kMaxWay) instead of `passes`
+  int32_t n_rt, n_st, rt_base, st_base, passes;
+  int32_t ss_B, ss_base, ss_stride, ss_ns;  // sample sort: fine buckets (0: the merge passes sort this distro), first fine bucket id, sample stride, samples
+  int32_t ss_C, ss_cbase;                   //   slots of coarse (sort) buckets reserved in the launch, the first one's id
   long long bucket_base;
   unsigned long long vmin, vmax;                 // biased range of the valid units' TotalValue (k_tiled_reduce)
   unsigned long long dmin, dmax;                 // biased ranges of the TaskList.Less columns
@@ -190,13 +201,27 @@ __device__ __forceinline__ long long wave_scan_sum(long long v, int lane) {
   return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
 }
 
-__global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passes_launched) {
-  __shared__ int s_rt[1024], s_st[1024];  // exclusive prefixes: row tiles / slot tiles before thread t's distros
-  __shared__ long long s_w[3][16];
+// Fine buckets of the sample sort of a distro of n rows sampled ns times, or 0 when no count within n / 256 + 2 keeps a
+// bucket's six-sigma size under its kSSFineCap slots (see kSSMaxSamples).
+__device__ __forceinline__ int ss_buckets(int n, int ns) {
+  const int bmax = n / 256 + 2 < kSSMaxB ? n / 256 + 2 : kSSMaxB;
+  int B = (n + kSSFineCap - 1) / kSSFineCap;
+  for (B = B < 2 ? 2 : B; B <= bmax && B <= ns; B++) {
+    const float mean = (float)n / (float)B, spb = (float)ns / (float)B;
+    if (mean * (1.f + 6.f / sqrtf(spb)) <= 1000.f) return B;
+  }
+  return 0;
+}
+// Coarse (sort) buckets a distro of n rows can have: two consecutive greedy runs hold more than 2048 keys together.
+__device__ __host__ __forceinline__ int ss_coarse_slots(int n) { return n / (kRT / 2) + 1; }
+
+__global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passes_launched, int ss_on) {
+  __shared__ int s_rt[1024], s_st[1024], s_bt[1024];  // exclusive prefixes: row tiles / slot tiles / sort buckets before thread t's distros
+  __shared__ long long s_w[5][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int d0 = a.d0, D = a.d1 - a.d0;
   const int per = (D + 1023) / 1024;
-  int rt = 0, st = 0;
+  int rt = 0, st = 0, bt = 0, ft = 0;  // bt: coarse (sort) bucket slots, ft: fine buckets
   long long bk = 0;
   for (int k = 0; k < per; k++) {
     const int d = d0 + tid * per + k;
@@ -209,10 +234,16 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
       const int n_rt = (n + kRT - 1) / kRT, n_st = (S + kST - 1) / kST;
       int passes = 0;
       while ((1 << passes) < n_rt) passes++;
-      const bool way = n_rt <= kMaxWay && (a.tiled_mode & TM_MULTIWAY_MERGE);  // one multiway pass instead of `passes`
-      if (S < kTiledMaxSlots && n_st <= kMaxST && (way || passes <= passes_launched)) {
-        t.on = 1; t.n_rt = n_rt; t.n_st = n_st; t.passes = way ? 0 : passes; t.way = way ? 1 : 0;
-        rt += n_rt; st += n_st; bk += (long long)n_rt * n_st;
+      int B = 0, stride = 1, ns = 0;
+      if (ss_on && n <= kSSMaxRows) {
+        stride = (n + kSSMaxSamples - 1) / kSSMaxSamples;
+        ns = (n + stride - 1) / stride;
+        B = ss_buckets(n, ns);
+      }
+      if (S < kTiledMaxSlots && n_st <= kMaxST && (B > 0 || passes <= passes_launched)) {
+        t.on = 1; t.n_rt = n_rt; t.n_st = n_st; t.passes = B > 0 ? 0 : passes;
+        t.ss_B = B; t.ss_stride = stride; t.ss_ns = ns; t.ss_C = B > 0 ? ss_coarse_slots(n) : 0;
+        rt += n_rt; st += n_st; bt += t.ss_C; ft += B; bk += (long long)n_rt * n_st;
       }
     }
     t.dmin = ~0ull; t.tmin = t.nmin = t.pmin = ~0u;
@@ -221,29 +252,30 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
     a.w_ts[d] = t;
   }
   // three inclusive scans over the 1024 threads: inside the wave by DPP, the 16 wave totals through LDS
-  long long irt = wave_scan_sum(rt, lane), ist = wave_scan_sum(st, lane), ibk = wave_scan_sum(bk, lane);
-  if (lane == 63) { s_w[0][wv] = irt; s_w[1][wv] = ist; s_w[2][wv] = ibk; }
+  long long irt = wave_scan_sum(rt, lane), ist = wave_scan_sum(st, lane), ibk = wave_scan_sum(bk, lane), ibt = wave_scan_sum(bt, lane),
+            ift = wave_scan_sum(ft, lane);
+  if (lane == 63) { s_w[0][wv] = irt; s_w[1][wv] = ist; s_w[2][wv] = ibk; s_w[3][wv] = ibt; s_w[4][wv] = ift; }
   __syncthreads();
-  long long trt = 0, tst = 0;
+  long long trt = 0, tst = 0, tbt = 0;
   for (int w = 0; w < 16; w++) {
-    if (w < wv) { irt += s_w[0][w]; ist += s_w[1][w]; ibk += s_w[2][w]; }
-    trt += s_w[0][w]; tst += s_w[1][w];
+    if (w < wv) { irt += s_w[0][w]; ist += s_w[1][w]; ibk += s_w[2][w]; ibt += s_w[3][w]; ift += s_w[4][w]; }
+    trt += s_w[0][w]; tst += s_w[1][w]; tbt += s_w[3][w];
   }
-  int rb = (int)irt - rt, sb = (int)ist - st;
+  int rb = (int)irt - rt, sb = (int)ist - st, qb = (int)ibt - bt, fb = (int)ift - ft;
   long long bb = ibk - bk;
-  s_rt[tid] = rb; s_st[tid] = sb;
+  s_rt[tid] = rb; s_st[tid] = sb; s_bt[tid] = qb;
   for (int k = 0; k < per; k++) {
     const int d = d0 + tid * per + k;
     if (d >= a.d1) break;
     TState* t = &a.w_ts[d];
     if (!t->on) continue;
-    t->rt_base = rb; t->st_base = sb; t->bucket_base = bb;
-    rb += t->n_rt; sb += t->n_st; bb += (long long)t->n_rt * t->n_st;
+    t->rt_base = rb; t->st_base = sb; t->bucket_base = bb; t->ss_cbase = qb; t->ss_base = fb;
+    rb += t->n_rt; sb += t->n_st; bb += (long long)t->n_rt * t->n_st; qb += t->ss_C; fb += t->ss_B;
   }
-  if (tid == 0) { a.w_ntile[0] = (int)trt; a.w_ntile[1] = (int)tst; }
+  if (tid == 0) { a.w_ntile[0] = (int)trt; a.w_ntile[1] = (int)tst; a.w_ntile[2] = (int)tbt; }
   __syncthreads();  // the TState rows (same workgroup: visible after the barrier) and the prefixes
   // the two directories, every thread a share: tile x belongs to the last thread whose prefix is <= x, then to one of its distros
-  auto fill = [&](int total, const int* pre, int32_t* dir, bool rows) {
+  auto fill = [&](int total, const int* pre, int32_t* dir, int what) {
     for (int x = tid; x < total; x += 1024) {
       int lo = 0, hi = 1024;  // last t with pre[t] <= x
       while (hi - lo > 1) {
@@ -255,13 +287,14 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
         if (d >= a.d1) break;
         const TState* t = &a.w_ts[d];
         if (!t->on) continue;
-        const int base = rows ? t->rt_base : t->st_base, cnt = rows ? t->n_rt : t->n_st;
+        const int base = what == 0 ? t->rt_base : what == 1 ? t->st_base : t->ss_cbase, cnt = what == 0 ? t->n_rt : what == 1 ? t->n_st : t->ss_C;
         if (x >= base && x < base + cnt) { dir[2 * x] = d; dir[2 * x + 1] = x - base; break; }
       }
     }
   };
-  fill((int)trt, s_rt, a.w_rtile, true);
-  fill((int)tst, s_st, a.w_stile, false);
+  fill((int)trt, s_rt, a.w_rtile, 0);
+  fill((int)tst, s_st, a.w_stile, 1);
+  fill((int)tbt, s_bt, a.w_btile, 2);
 }
 
 // ---- T1: rows -> records ---------------------------------------------------------------------------------------
@@ -737,134 +770,8 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
   TT_MARK(19);
 }
 
-// ---- sorting by rank searches in LDS ---------------------------------------------------------------------------------
-// Keys live in LDS as three arrays of 64-bit words (s_hi | s_mid | s_lo, `cap` entries each) and, four per thread, in
-// registers. One search step for the thread's four keys: the four probes are issued side by side (independent LDS reads),
-// the first word decides unless the probed key belongs to the same unit (or, in the wide-value key layout, has the same
-// value): only then are the other two words read.
-//   z[e]  index of the probe (any valid index when !ok[e])     ok[e]  the step applies to key e
-// Returns, per key, "the probed key is below mine".
-// Position i of a key array lives at word lpad(i): one spare word after every 32, so that the probes of a round -- which sit
-// at equal offsets of runs that start at multiples of a power of two -- spread over the LDS banks instead of piling on one.
-__device__ __forceinline__ int lpad(int i) { return i + (i >> 5); }
-constexpr int kPadRT = kRT + kRT / 32;  // words per padded key array of one tile
-__device__ __forceinline__ void probe4(const K192 (&key)[4], const int (&zi)[4], const bool (&ok)[4], const uint64_t* s_hi, const uint64_t* s_mid,
-                                       const uint64_t* s_lo, bool (&lt)[4]) {
-  uint64_t h[4];
-  int z[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) { z[e] = lpad(zi[e]); h[e] = s_hi[z[e]]; }
-  bool tie = false;
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    lt[e] = ok[e] && h[e] < key[e].hi;
-    tie |= ok[e] && h[e] == key[e].hi;
-  }
-  if (tie) {
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-      if (ok[e] && h[e] == key[e].hi) {
-        const uint64_t m = s_mid[z[e]];
-        lt[e] = m != key[e].mid ? m < key[e].mid : s_lo[z[e]] < key[e].lo;
-      }
-  }
-}
-
-// Sort of P = 2^m keys by one 512-thread workgroup, ascending; thread t holds positions 4t..4t+3 before and after. The
-// thread's four keys are sorted in registers (five compare-exchanges), then log2(P) - 2 rounds of pairwise RANK merges of
-// runs of L = 4, 8, .. P/2 keys: every key counts the keys of the partner run that are below it (log2(L) + 1 uniform steps
-// of four side-by-side probes) and moves to its place in the merged run. 63 probe steps for P = 2048 against the 66
-// compare-exchange stages of the bitonic network -- each of which moves and compares all six words of a key across lanes.
-// Keys must be distinct. smem: 3 * (P + P / 32) * 8 bytes (lpad).
-template <int P>
-__device__ __forceinline__ void lds_merge_sort4(K192 (&k)[4], int tid, uint64_t* smem64) {
-  uint64_t *s_hi = smem64, *s_mid = s_hi + (P + P / 32), *s_lo = s_mid + (P + P / 32);
-  cmpx(k[0], k[1], true); cmpx(k[2], k[3], true); cmpx(k[0], k[2], true); cmpx(k[1], k[3], true); cmpx(k[1], k[2], true);
-  int place[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) { place[e] = tid * 4 + e; const int q = lpad(place[e]); s_hi[q] = k[e].hi; s_mid[q] = k[e].mid; s_lo[q] = k[e].lo; }
-  __syncthreads();
-  // (rolled loops on purpose: unrolled, the 63 probe steps are ~100 KB of code and the waves of a CU thrash its instruction cache)
-#pragma clang loop unroll(disable)
-  for (int L = 4; L < P; L <<= 1) {
-    int base[4], cnt[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int e = 0; e < 4; e++) base[e] = (place[e] & ~(L - 1)) ^ L;  // start of the partner run
-#pragma clang loop unroll(disable)
-    for (int step = L; step > 0; step >>= 1) {
-      int z[4];
-      bool ok[4], lt[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) { ok[e] = cnt[e] + step <= L; z[e] = base[e] + (ok[e] ? cnt[e] + step - 1 : 0); }
-      probe4(k, z, ok, s_hi, s_mid, s_lo, lt);
-#pragma unroll
-      for (int e = 0; e < 4; e++) cnt[e] += lt[e] ? step : 0;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++) place[e] = (place[e] & L) ? place[e] - (L - cnt[e]) : place[e] + cnt[e];
-    __syncthreads();  // every search of this round is done
-#pragma unroll
-    for (int e = 0; e < 4; e++) { const int q = lpad(place[e]); s_hi[q] = k[e].hi; s_mid[q] = k[e].mid; s_lo[q] = k[e].lo; }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int e = 0; e < 4; e++) { const int q = lpad(tid * 4 + e); k[e] = K192{s_hi[q], s_mid[q], s_lo[q]}; }
-}
-
-// The same rank merges over SEGMENTS of any length: segment g is the sorted keys at [s_seg[g], s_seg[g + 1]). Round r merges
-// the runs of 2^r segments pairwise; s_maxrun[r] = the longest run of round r (the uniform search depth). On entry key[e]
-// sits at place[e] inside segment seg[e] (seg[e] < 0: no key); on return place[e] is its position in its merged run of
-// 2^rounds segments. The arrays are rewritten in place every round.
-__device__ __forceinline__ void seg_merge_tree(const K192 (&key)[4], const int (&seg)[4], int (&place)[4], const int* s_seg, int nseg, int rounds,
-                                               const int* s_maxrun, uint64_t* s_hi, uint64_t* s_mid, uint64_t* s_lo) {
-#pragma clang loop unroll(disable)
-  for (int r = 0; r < rounds; r++) {
-    const int mx = s_maxrun[r];
-    int b0[4], nv[4], cnt[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int pr = (seg[e] >> r) ^ 1;  // the partner run of my run of 2^r segments
-      const int q0 = pr << r < nseg ? pr << r : nseg, q1 = (pr + 1) << r < nseg ? (pr + 1) << r : nseg;
-      b0[e] = seg[e] >= 0 ? s_seg[q0] : 0;
-      nv[e] = seg[e] >= 0 ? s_seg[q1] - b0[e] : 0;
-    }
-#pragma clang loop unroll(disable)
-    for (int step = mx ? 1 << (31 - __builtin_clz(mx)) : 0; step > 0; step >>= 1) {
-      int z[4];
-      bool ok[4], lt[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) { ok[e] = cnt[e] + step <= nv[e]; z[e] = ok[e] ? b0[e] + cnt[e] + step - 1 : 0; }
-      probe4(key, z, ok, s_hi, s_mid, s_lo, lt);
-#pragma unroll
-      for (int e = 0; e < 4; e++) cnt[e] += lt[e] ? step : 0;
-    }
-    // a key of the left run moves right by the partner keys below it; a key of the right run moves left by the partner
-    // keys that are NOT below it (keys are distinct)
-#pragma unroll
-    for (int e = 0; e < 4; e++) place[e] = ((seg[e] >> r) & 1) ? place[e] - (nv[e] - cnt[e]) : place[e] + cnt[e];
-    __syncthreads();  // every search of this round is done
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-      if (seg[e] >= 0) { const int q = lpad(place[e]); s_hi[q] = key[e].hi; s_mid[q] = key[e].mid; s_lo[q] = key[e].lo; }
-    __syncthreads();
-  }
-}
-// s_maxrun[r], r < rounds, for seg_merge_tree; called by one thread.
-__device__ __forceinline__ void seg_max_runs(const int* s_seg, int nseg, int rounds, int* s_maxrun) {
-#pragma clang loop unroll(disable)
-  for (int r = 0; r < rounds; r++) {
-    int mx = 0;
-#pragma clang loop unroll(disable)
-    for (int q = 0; q < nseg; q += 1 << r) {
-      const int q1 = q + (1 << r) < nseg ? q + (1 << r) : nseg;
-      mx = s_seg[q1] - s_seg[q] > mx ? s_seg[q1] - s_seg[q] : mx;
-    }
-    s_maxrun[r] = mx;
-  }
-}
-
 // ---- T3: elect, keys, tile sort ----------------------------------------------------------------------------------
-constexpr int kTiledSortLds = 3 * 8 * (kRT + kRT / 32);  // three padded arrays of 64-bit words (lpad)
+constexpr int kTiledSortLds = 3 * 8 * (kRT + kRT / 32);  // three arrays of 64-bit words, 22 entries apart modulo the banks (k_tiled_merge)
 
 // ---- merge path on 192-bit keys in LDS ----------------------------------------------------------------------------------
 // Keys by position in three arrays of 64-bit words (s_hi | s_mid | s_lo, kRT entries each). Two sorted ranges, A = [a0, a0 +
@@ -872,8 +779,6 @@ constexpr int kTiledSortLds = 3 * 8 * (kRT + kRT / 32);  // three padded arrays 
 // outputs diag .. diag + 3 of their merge. A binary search along the diagonal (ITER >= log2(max(la, lb)) + 1 uniform rounds;
 // the first word decides unless both keys belong to the same unit) finds where they begin, then they are merged one after the
 // other -- ~30 LDS reads and ~150 VALU instructions where the network spends 4 keys x 9..11 stages x ~18. Keys are distinct.
-// TM_NETWORK_MERGE (EVG_TILED_MODE bit 64) keeps the networks for A/B runs.
-constexpr int TM_NETWORK_MERGE = 64;
 // field by field: a ?: on the structs makes the compiler park both in scratch memory and load through a selected pointer
 __device__ __forceinline__ K192 key_sel(bool c, const K192& x, const K192& y) { return K192{c ? x.hi : y.hi, c ? x.mid : y.mid, c ? x.lo : y.lo}; }
 template <int ITER>
@@ -1071,9 +976,19 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
   // inside each unit's run by counting: k_tiled_elect 96 -> 76 us on the config-5 share, but the runs of ~50 rows of
   // grouped-version distros cost more than the network saves on the skewed pool (+7 %), and without them few distros qualify.)
   K192* const tile_out = (K192*)a.w_keyA + ((size_t)ts->rt_base + tile) * kRT;
-  if (a.tiled_mode & TM_RANK_MERGE_SORT) lds_merge_sort4<kRT>(k, tid, (uint64_t*)smem);
-  else if (a.tiled_mode & TM_NETWORK_MERGE) bitonic_sort4_fixed<kRT, K192>(k, tid, (K192*)smem, (K192*)smem);
-  else tile_sort_merge_path(k, tid, smem);
+  if (ts->ss_B > 0) {
+    // sample-sorted distro: the keys leave UNSORTED, word-major inside the tile's 6144 words (hi[2048] | mid[2048] | lo[2048]) -- every
+    // store here and every load of S1 / S2 is one 8-byte word per lane, consecutive lanes consecutive words
+    uint64_t* g = (uint64_t*)tile_out;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; e4++) {
+      const int x = e4 * kTiledBlock + tid;
+      g[x] = k[e4].hi; g[kRT + x] = k[e4].mid; g[2 * kRT + x] = k[e4].lo;
+    }
+    TT_MARK(11);
+    return;
+  }
+  tile_sort_merge_path(k, tid, smem);
   TT_MARK(10);
   if (a.tiled_mode & 32) {  // A/B: every thread stores its own four keys
     K192* out = tile_out + tid * 4;
@@ -1087,7 +1002,8 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
 
 // ---- T5 (the tail of the merge): queue order out; first queue position per task group ----------------------------------
 // i4[e] = the (local) row at queue position q0 + e of distro d. Called by every thread of the workgroup.
-__device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, int d, long long q0, const uint32_t (&i4)[4]) {
+// Positions at or beyond qlimit (the end of a sort bucket; the distro's length for a merge window) hold no row.
+__device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, int d, long long q0, const uint32_t (&i4)[4], long long qlimit) {
   __shared__ unsigned long long s_first;
   const int tid = threadIdx.x, lane = tid & 63;
   const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo, D = a.in.n_distros;
@@ -1100,7 +1016,7 @@ __device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, 
   for (int e = 0; e < 4; e++) {
     const long long q = q0 + e;
     o4[e] = 0;
-    if (q >= n) continue;
+    if (q >= qlimit) continue;
     const int i = (int)i4[e];
     const int r = lo + i;
     o4[e] = r;
@@ -1121,7 +1037,7 @@ __device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, 
   }
 #pragma unroll
   for (int e = 0; e < 4; e++)
-    if (q0 + e < n) a.out.order[lo + q0 + e] = o4[e];
+    if (q0 + e < qlimit) a.out.order[lo + q0 + e] = o4[e];
   first = wave_min((uint64_t)first);
   if (lane == 0 && first != ~0ull) atomicMin(&s_first, first);
   __syncthreads();
@@ -1131,201 +1047,54 @@ __device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, 
   }
 }
 
-// ---- T4 (distros of up to kMaxWay sorted tiles): sample ranks, then ONE multiway merge pass -----------------------------
-// Number of keys below `key` among the n sorted keys at(0..n-1): the same number of steps for every lane (n is uniform).
-template <class At, class K>
-__device__ __forceinline__ int count_below(int n, const K& key, At at) {
-  int pos = 0;
-  for (int step = n ? 1 << (31 - __builtin_clz(n)) : 0; step > 0; step >>= 1)
-    if (pos + step <= n && key_lt(at(pos + step - 1), key)) pos += step;
-  return pos;
-}
-
-// k_tiled_srank: the workgroup of sorted tile `tile` ranks the tile's 64 samples (the key at the end of every 32-key block)
-// in the whole distro: G[sample] = the sum over the distro's tiles of the keys below the sample -- for another tile, a search
-// over that tile's samples in LDS, then inside ONE 32-key block in memory: two rounds of side-by-side probes (every 5th
-// key, then the 4 keys in between) instead of five dependent steps.
-constexpr int kSrankLds = kMaxWay * kSmpPerTile * (int)sizeof(K192);
-__global__ void __launch_bounds__(kTiledBlock) k_tiled_srank(const PlanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t s_G[kSmpPerTile];
-  const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);
-  if (w < 0) return;
-  const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
-  const TState* ts = &a.w_ts[d];
-  if (!tiled_live(ts) || !ts->way) return;
-  const int k = ts->n_rt, tid = threadIdx.x;
-  const K192* keys = (const K192*)a.w_keyA + (size_t)ts->rt_base * kRT;
-  TT_BEGIN();
-  K192* smp = (K192*)smem;
-  for (int x = tid; x < k * kSmpPerTile; x += kTiledBlock)
-    smp[x] = keys[(size_t)(x / kSmpPerTile) * kRT + (x % kSmpPerTile) * kSmpStride + kSmpStride - 1];
-  if (tid < kSmpPerTile) s_G[tid] = 0;
+// The same for a sort bucket (k_ss_sort), with the four positions' loads issued side by side -- the table words, then the task-group
+// rows' columns, then the reads of the groups' current minima -- instead of row after row: four dependent round trips per thread
+// instead of up to sixteen. (In k_tiled_merge, which sits at its 80-register limit, this form measured 3 % slower; here there is room.)
+__device__ __forceinline__ void tiled_emit_order4(const PlanArgs& a, TState* ts, int d, long long q0, const uint32_t (&i4)[4], long long qlimit) {
+  __shared__ unsigned long long s_first;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lo = a.in.task_off[d], D = a.in.n_distros;
+  if (tid == 0) s_first = ~0ull;
   __syncthreads();
-  TT_MARK(20);
-  for (int pair = tid; pair < k * kSmpPerTile; pair += kTiledBlock) {
-    const int m = pair % kSmpPerTile, j = pair / kSmpPerTile;  // a wave: 64 samples against one tile
-    int below;
-    if (j == tile) {
-      below = m * kSmpStride + kSmpStride - 1;  // the sample's own position
-    } else {
-      const K192 key = smp[tile * kSmpPerTile + m];
-      const K192* sj = smp + j * kSmpPerTile;
-      const int blk = count_below(kSmpPerTile, key, [&](int q) { return sj[q]; });  // tile j's samples below the key
-      below = kRT;
-      if (blk < kSmpPerTile) {  // inside block `blk`: its last key (the sample) is above, the 31 before it are undecided
-        const K192* kb = keys + (size_t)j * kRT + blk * kSmpStride;
-        int c5 = 0;  // keys 4, 9, 14, 19, 24, 29 of the block, probed together
-#pragma unroll
-        for (int q = 0; q < 6; q++) c5 += key_lt(kb[5 * q + 4], key) ? 1 : 0;
-        int c1 = 0;  // the (at most) four keys before the first probe that is not below
-#pragma unroll
-        for (int q = 0; q < 4; q++) c1 += (5 * c5 + q < kSmpStride - 1) && key_lt(kb[5 * c5 + q], key) ? 1 : 0;
-        below = blk * kSmpStride + 5 * c5 + c1;
-      }
-    }
-    atomicAdd(&s_G[m], (uint32_t)below);
-  }
-  __syncthreads();
-  if (tid < kSmpPerTile) a.w_srank[(size_t)(ts->rt_base + tile) * kSmpPerTile + tid] = s_G[tid];
-  TT_MARK(21);
-}
-
-// k_tiled_mmerge: the workgroup of output window [R0, R1) = [2048 w, 2048 (w + 1)) of the distro's queue.
-//  (1) The window's split of every tile at both boundaries (side by side). For boundary R and tile j: m = the tile's samples
-//      of rank below R. The 32 m keys up to the last of them are among the R smallest; the next sample (rank >= R) and
-//      everything after it are not; the 31 keys in between are CANDIDATES. The R smallest keys are those certain ones plus
-//      the R - sum(32 m) smallest candidates (a down-set), so: the candidates of every tile into LDS (at most 31 per tile
-//      and boundary, 1,984 in all), merged per boundary by the rank-merge tree, and the ones of rank below that number taken.
-//  (2) The window's <= 32 segments (exactly 2048 keys, four per thread, in registers and in LDS) merged by the same TREE of
-//      pairwise rank merges: in round r every key counts the keys below it in the partner run of its run of 2^r segments
-//      (one uniform-step search, four keys side by side) and moves to its place in the merged run -- ceil(log2 k) rounds of
-//      one search each. The rows in queue order go to tiled_emit_order.
-constexpr int kMmergeLds = 3 * 8 * kPadRT;
-constexpr int kCandPer = kSmpStride - 1;  // candidates per tile and boundary
-static_assert(2 * kMaxWay * kCandPer <= kRT, "both boundaries' candidates fit the segment buffer, four per thread");
-__global__ void __launch_bounds__(kTiledBlock) k_tiled_mmerge(const PlanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_split[2][kMaxWay], s_m[2][kMaxWay], s_take[2][kMaxWay], s_seg[2 * kMaxWay + 1], s_maxrun[8];
-  const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);
-  if (w < 0) return;
-  const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
-  TState* ts = &a.w_ts[d];
-  if (!tiled_live(ts) || !ts->way) return;
-  const int k = ts->n_rt, tid = threadIdx.x;
-  const K192* keys = (const K192*)a.w_keyA + (size_t)ts->rt_base * kRT;
-  const uint32_t* G = a.w_srank + (size_t)ts->rt_base * kSmpPerTile;
-  uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kPadRT, *s_lo = s_mid + kPadRT;
-  // boundary b: rank R = 2048 (tile + b); the first boundary of the first window and the last of the last are trivial
-  const bool open0 = tile > 0, open1 = tile + 1 < k;
-  const uint32_t R0 = (uint32_t)tile * kRT, R1 = R0 + kRT;
-  int k2 = 1, lg2 = 0;  // the tiles rounded up to a power of two: boundary 1's windows start at segment k2
-  while (k2 < k) { k2 <<= 1; lg2++; }
-  TT_BEGIN();
-  if (tid < k) { s_m[0][tid] = 0; s_m[1][tid] = 0; s_take[0][tid] = 0; s_take[1][tid] = 0; }
-  __syncthreads();
-  for (int x = tid; x < k * kSmpPerTile; x += kTiledBlock) {  // samples of rank below the boundary, per tile
-    const uint32_t g = G[x];
-    const int j = x / kSmpPerTile;
-    if (open0 && g < R0) atomicAdd(&s_m[0][j], 1);
-    if (open1 && g < R1) atomicAdd(&s_m[1][j], 1);
-  }
-  __syncthreads();
-  TT_MARK(0);
-  if (tid == 0) {  // candidate windows as segments: boundary 0's tiles at [0, k), boundary 1's at [k2, k2 + k)
-    int o = 0;
-#pragma clang loop unroll(disable)
-    for (int g = 0; g < 2 * k2; g++) {
-      const int b = g >= k2, j = g - b * k2;
-      s_seg[g] = o;
-      if (j < k && (b ? open1 : open0) && s_m[b][j] < kSmpPerTile) o += kCandPer;
-    }
-    s_seg[2 * k2] = o;
-    seg_max_runs(s_seg, 2 * k2, lg2, s_maxrun);
-  }
-  __syncthreads();
-  TT_MARK(1);
-  {
-    const int ncand = s_seg[2 * k2];
-    K192 key[4];
-    int seg[4], place[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int x = e * kTiledBlock + tid;
-      seg[e] = -1; place[e] = x; key[e] = K192{0, 0, 0};
-      if (x < ncand) {
-        int g = 0;
-#pragma clang loop unroll(disable)
-        for (int q = 1; q < 2 * k2; q++) g += s_seg[q] <= x ? 1 : 0;  // the last segment that starts at or before x
-        const int b = g >= k2, j = g - b * k2;
-        seg[e] = g;
-        key[e] = keys[(size_t)j * kRT + s_m[b][j] * kSmpStride + (x - s_seg[g])];
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-      if (seg[e] >= 0) { const int q = lpad(place[e]); s_hi[q] = key[e].hi; s_mid[q] = key[e].mid; s_lo[q] = key[e].lo; }
-    __syncthreads();
-    TT_MARK(2);
-    seg_merge_tree(key, seg, place, s_seg, 2 * k2, lg2, s_maxrun, s_hi, s_mid, s_lo);
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      if (seg[e] < 0) continue;
-      const int b = seg[e] >= k2, j = seg[e] - b * k2;
-      int certain = 0;  // keys of the boundary that are certainly among its R smallest
-#pragma clang loop unroll(disable)
-      for (int q = 0; q < k; q++) certain += s_m[b][q] * kSmpStride;
-      const int need = (int)(b ? R1 : R0) - certain;
-      const int rank = place[e] - s_seg[b * k2];  // among the boundary's candidates
-      if (rank < need) atomicMax(&s_take[b][j], (e * kTiledBlock + tid) - s_seg[seg[e]] + 1);
-    }
-    __syncthreads();
-  }
-  TT_MARK(3);
-  if (tid < 2 * k) {
-    const int b = tid >= k, j = tid - b * k;
-    s_split[b][j] = (b ? open1 : open0) ? s_m[b][j] * kSmpStride + s_take[b][j] : (b ? kRT : 0);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-#pragma clang loop unroll(disable)
-    for (int j = 0; j < k; j++) { s_seg[j] = o; o += s_split[1][j] - s_split[0][j]; }
-    s_seg[k] = o;
-    seg_max_runs(s_seg, k, lg2, s_maxrun);
-  }
-  __syncthreads();
-  if (s_seg[k] != kRT) {  // cannot happen; if it ever did, the one-workgroup kernel plans the distro instead
-    if (tid == 0) atomicOr((unsigned*)&ts->unfit, 1u);
-    return;
-  }
-  TT_MARK(4);
-  K192 key[4];
-  int seg[4], place[4];
+  const unsigned long long* tgbit = a.w_tgbit + (size_t)ts->rt_base * (kRT / 64);
+  bool live[4], tg[4];
+  unsigned long long word[4];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
-    const int x = e * kTiledBlock + tid;
-    int j = 0;
-#pragma clang loop unroll(disable)
-    for (int q = 1; q < k; q++) j += s_seg[q] <= x ? 1 : 0;  // the last segment that starts at or before x
-    seg[e] = j; place[e] = x;
-    key[e] = keys[(size_t)j * kRT + s_split[0][j] + (x - s_seg[j])];
+    live[e] = q0 + e < qlimit;
+    word[e] = live[e] ? tgbit[i4[e] >> 6] : 0ull;
   }
+  int tgk[4], mh[4];
 #pragma unroll
-  for (int e = 0; e < 4; e++) { const int q = lpad(place[e]); s_hi[q] = key[e].hi; s_mid[q] = key[e].mid; s_lo[q] = key[e].lo; }
+  for (int e = 0; e < 4; e++) {
+    tg[e] = live[e] && ((word[e] >> (i4[e] & 63)) & 1ull);
+    tgk[e] = tg[e] ? a.in.tasks.tg_key[lo + (int)i4[e]] : 0;
+    mh[e] = tg[e] ? a.in.tasks.task_group_max_hosts[lo + (int)i4[e]] : 0;
+  }
+  unsigned long long seen[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) seen[e] = tg[e] ? __hip_atomic_load(&a.w_gfirst[D + tgk[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  unsigned long long first = ~0ull;  // (queue position << 32) | row of the first stand-alone task this thread met
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    if (!live[e]) continue;
+    const unsigned long long q = (unsigned long long)(q0 + e);
+    if (tg[e]) {
+      const unsigned long long packed = (q << 32) | (uint32_t)mh[e];
+      if (seen[e] > packed) atomicMin(&a.w_gfirst[D + tgk[e]], packed);
+    } else {
+      const unsigned long long packed = (q << 32) | i4[e];
+      first = packed < first ? packed : first;
+    }
+    a.out.order[lo + q0 + e] = lo + (int)i4[e];
+  }
+  first = wave_min((uint64_t)first);
+  if (lane == 0 && first != ~0ull) atomicMin(&s_first, first);
   __syncthreads();
-  TT_MARK(5);
-  seg_merge_tree(key, seg, place, s_seg, k, lg2, s_maxrun, s_hi, s_mid, s_lo);
-  TT_MARK(6);
-  uint32_t* s_row = (uint32_t*)smem;
-#pragma unroll
-  for (int e = 0; e < 4; e++) s_row[place[e]] = (uint32_t)(key[e].lo & 0xFFFFFu);
-  __syncthreads();
-  uint32_t i4[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) i4[e] = s_row[tid * 4 + e];
-  tiled_emit_order(a, ts, d, (long long)tile * kRT + tid * 4, i4);
-  TT_MARK(7);
+  if (tid == 0 && s_first != ~0ull) {  // MaxHosts of the stand-alone row = TaskGroupMaxHosts of its first task in queue order
+    const unsigned long long packed = (s_first & 0xFFFFFFFF00000000ull) | (uint32_t)a.in.tasks.task_group_max_hosts[lo + (int)(s_first & 0xFFFFFFFFu)];
+    atomicMin(&ts->s_first, packed);
+  }
 }
 
 // ---- T4: one merge-path pass ---------------------------------------------------------------------------------------
@@ -1380,18 +1149,7 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a
     TT_MARK(22);
     const int a0 = s_split[0], a1 = s_split[1];
     const int b1 = diag0 + kRT - a1, cnt_a = a1 - a0;
-    // positions [0, cnt_a): A ascending; [cnt_a, 2048): B descending -- a bitonic sequence. (Measured: bringing the two
-    // contiguous key ranges in as 6144 consecutive 64-bit words through LDS -- 8 requests per load instruction instead of 64
-    // -- is SLOWER, 0.347 -> 0.372 ms per config-5-share plan: the 96-byte-stride reads that take the keys back out of LDS
-    // conflict eight ways, and the loads were latency, not request rate.)
-    const bool net = (a.tiled_mode & TM_NETWORK_MERGE) != 0;
-    if (net) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int x = tid * 4 + e;
-        k[e] = x < cnt_a ? A[a0 + x] : B[b1 - 1 - (x - cnt_a)];
-      }
-    } else {
+    {
       // Both ranges ascending into LDS, one merge-path round. The two ranges are contiguous 24-byte keys: they come in as 6144
       // consecutive 64-bit words, twelve per thread (a wave's load is 512 contiguous bytes: 8 requests, where a thread fetching
       // its own four keys is a 96-byte stride between lanes, 64 requests), straight into the three word arrays the merge reads;
@@ -1415,18 +1173,13 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a
       merge_path4_k192<12>(k, s_hi, s_mid, s_lo, 0, cnt_a, cnt_a, kRT - cnt_a, false, tid * 4);
       __syncthreads();  // the arrays are re-used below
     }
-#ifdef EVG_PHASE_TIMING
-    if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     TT_MARK(23);
-#endif
-    if (net) bitonic_merge4_fixed<kRT, K192>(k, tid, (K192*)smem, true);
-    TT_MARK(24);
   }
   if (pass == ts->passes - 1) {  // the distro's last pass: the merged keys ARE the queue -- nothing is written back
     uint32_t i4[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) i4[e] = (uint32_t)(k[e].lo & 0xFFFFFu);
-    tiled_emit_order(a, ts, d, pos0 + tid * 4, i4);
+    tiled_emit_order(a, ts, d, pos0 + tid * 4, i4, a.in.task_off[d + 1] - a.in.task_off[d]);
     return;
   }
   if (a.tiled_mode & 32) {
@@ -1435,6 +1188,190 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a
   } else {
     store_tile_keys(k, dst + pos0, tid, smem);
   }
+}
+
+// ---- S1-S3: sample sort of the distros k_tiled_list gave buckets (ss_B > 0) -------------------------------------------------
+// Key i of row tile T of a sample-sorted distro (k_tiled_elect's word-major layout).
+__device__ __forceinline__ K192 ss_key(const uint64_t* keys, int i) {
+  const uint64_t* g = keys + (size_t)(i / kRT) * (3 * kRT) + (i % kRT);
+  return K192{g[0], g[kRT], g[2 * kRT]};
+}
+// S1: one workgroup per distro of the call's range. Sample x is one row of block [x stride, (x + 1) stride), at an offset hashed
+// from x (a periodic arrangement of the rows cannot line up with a fixed offset); the ns samples are sorted with the tile sort
+// (padded to 2048 with keys above every row's) and splitter b = the sample of rank floor((b + 1) ns / B), b < B - 1: bucket b
+// takes the keys k with splitter[b - 1] < k <= splitter[b]. The distro's bucket cursors are zeroed here.
+__global__ void __launch_bounds__(kTiledBlock, 6) k_ss_split(const PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int d = a.d0 + blockIdx.x;
+  if (d >= a.d1) return;
+  TState* ts = &a.w_ts[d];
+  if (!tiled_live(ts) || ts->ss_B <= 0) return;
+  const int tid = threadIdx.x;
+  const int n = a.in.task_off[d + 1] - a.in.task_off[d], B = ts->ss_B, stride = ts->ss_stride, ns = ts->ss_ns;
+  const uint64_t* keys = (const uint64_t*)a.w_keyA + (size_t)ts->rt_base * (3 * kRT);
+  for (int b = tid; b < B; b += kTiledBlock) a.w_bcur[ts->ss_base + b] = 0;
+  TT_BEGIN();
+  K192 k[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int x = e * kTiledBlock + tid;
+    k[e] = K192{~0ull, ~0ull, 0xFFFFFFFFFFF00000ull | (uint64_t)x};
+    if (x < ns) {
+      uint32_t h = (uint32_t)x * 0x9E3779B1u;
+      h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+      int row = x * stride + (int)(h % (uint32_t)stride);
+      if (row >= n) row = x * stride;  // the last, partial block
+      k[e] = ss_key(keys, row);
+    }
+  }
+  TT_MARK(0);
+  tile_sort_merge_path(k, tid, smem);
+  TT_MARK(1);
+  uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kRT, *s_lo = s_mid + kRT;
+  __syncthreads();  // the last round's reads of the arrays
+  lds_put4_soa(s_hi, s_mid, s_lo, tid * 4, k);
+  __syncthreads();
+  uint64_t* sp = (uint64_t*)a.w_split + (size_t)ts->ss_base * 3;
+  for (int b = tid; b < B - 1; b += kTiledBlock) {
+    const int r = (int)(((long long)(b + 1) * ns) / B);  // < ns
+    sp[3 * b] = s_hi[r]; sp[3 * b + 1] = s_mid[r]; sp[3 * b + 2] = s_lo[r];
+  }
+}
+
+// S2: one workgroup per row tile.
+__global__ void __launch_bounds__(kTiledBlock, 6) k_ss_partition(const PlanArgs a) {
+  __shared__ uint64_t s_hi[kSSMaxB], s_mid[kSSMaxB], s_lo[kSSMaxB];
+  __shared__ int s_cnt[kSSMaxB];
+  const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);
+  if (w < 0) return;
+  const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
+  TState* ts = &a.w_ts[d];
+  if (!tiled_live(ts) || ts->ss_B <= 0) return;
+  const int tid = threadIdx.x;
+  const int n = a.in.task_off[d + 1] - a.in.task_off[d], B = ts->ss_B, nsp = B - 1;
+  const uint64_t* sp = (const uint64_t*)a.w_split + (size_t)ts->ss_base * 3;
+  const uint64_t* g = (const uint64_t*)a.w_keyA + ((size_t)ts->rt_base + tile) * (3 * kRT);
+  TT_BEGIN();
+  K192 k[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int x = e * kTiledBlock + tid;
+    k[e] = K192{g[x], g[kRT + x], g[2 * kRT + x]};
+  }
+  for (int x = tid; x < 3 * nsp; x += kTiledBlock) {  // consecutive words in, three arrays
+    const int b = x / 3, c = x - 3 * b;
+    (c == 0 ? s_hi : c == 1 ? s_mid : s_lo)[b] = sp[x];
+  }
+  for (int b = tid; b < B; b += kTiledBlock) s_cnt[b] = 0;
+  __syncthreads();
+  TT_MARK(2);
+  // bucket = the splitters strictly below the key: one uniform binary search, four keys side by side
+  int bkt[4] = {0, 0, 0, 0};
+  for (int step = nsp ? 1 << (31 - __builtin_clz(nsp)) : 0; step > 0; step >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int z = bkt[e] + step - 1;
+      if (bkt[e] + step <= nsp) {
+        const uint64_t h = s_hi[z];
+        bool lt = h < k[e].hi;
+        if (h == k[e].hi) { const uint64_t m = s_mid[z]; lt = m != k[e].mid ? m < k[e].mid : s_lo[z] < k[e].lo; }
+        bkt[e] += lt ? step : 0;
+      }
+    }
+  }
+  int lr[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const bool valid = tile * kRT + e * kTiledBlock + tid < n;
+    lr[e] = valid ? atomicAdd(&s_cnt[bkt[e]], 1) : -1;
+  }
+  __syncthreads();
+  TT_MARK(3);
+  for (int b = tid; b < B; b += kTiledBlock) {
+    const int c = s_cnt[b];
+    int base = 0;
+    if (c > 0) {
+      base = (int)atomicAdd(&a.w_bcur[ts->ss_base + b], (uint32_t)c);
+      if (base + c > kSSFineCap) atomicOr((unsigned*)&ts->unfit, 1u);  // a six-sigma bucket: the generic kernel plans this distro
+    }
+    s_cnt[b] = base;
+  }
+  __syncthreads();
+  TT_MARK(4);
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    if (lr[e] < 0) continue;
+    const int pos = s_cnt[bkt[e]] + lr[e];
+    if (pos >= kSSFineCap) continue;
+    uint64_t* out = (uint64_t*)a.w_keyB + (size_t)(ts->ss_base + bkt[e]) * (3 * kSSFineCap) + pos;
+    out[0] = k[e].hi; out[kSSFineCap] = k[e].mid; out[2 * kSSFineCap] = k[e].lo;
+  }
+  TT_MARK(5);
+}
+
+// S3: one workgroup per COARSE bucket slot: coarse bucket c of a distro is the c-th maximal run of consecutive fine buckets with at
+// most 2048 keys together (greedy over the exact counts k_ss_partition left; every workgroup of the distro cuts the same runs).
+// Its keys are sorted in LDS and the rows go out at the run's place in the distro's queue.
+__global__ void __launch_bounds__(kTiledBlock, 6) k_ss_sort(const PlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_pre[kSSMaxB + 1];  // keys in the distro's fine buckets below f
+  __shared__ int s_w8[8], s_run[2];
+  const int w = xcd_tile(blockIdx.x, a.w_ntile[2], a.tiled_mode);
+  if (w < 0) return;
+  const int d = a.w_btile[2 * w], c = a.w_btile[2 * w + 1];
+  TState* ts = &a.w_ts[d];
+  if (!tiled_live(ts)) return;
+  const int tid = threadIdx.x;
+  const int B = ts->ss_B;
+  const uint32_t* cur = a.w_bcur + ts->ss_base;
+  TT_BEGIN();
+  // prefix sums of the fine counts (B <= 1024: two per thread)
+  const int c0 = 2 * tid < B ? (int)cur[2 * tid] : 0, c1 = 2 * tid + 1 < B ? (int)cur[2 * tid + 1] : 0;
+  const int incl = block_scan_sum(c0 + c1, tid, s_w8);
+  if (2 * tid < B) s_pre[2 * tid] = incl - c0 - c1;
+  if (2 * tid + 1 < B) s_pre[2 * tid + 1] = incl - c1;
+  if (tid == kTiledBlock - 1) s_pre[B] = incl;  // (B == 1024: thread 511 owns the last pair)
+  __syncthreads();
+  if (tid == 0) {  // the c-th greedy run [f0, f1): a handful of steps per run
+    int f0 = 0, f1 = 0;
+    for (int g = 0; g <= c && f0 < B; g++) {
+      f0 = f1;
+      if (f0 >= B) break;
+      f1 = f0 + 1;
+      while (f1 < B && s_pre[f1 + 1] - s_pre[f0] <= kRT) f1++;
+    }
+    s_run[0] = f0; s_run[1] = f0 < B ? f1 : f0;
+  }
+  __syncthreads();
+  const int f0 = s_run[0], f1 = s_run[1];
+  if (f0 >= f1) return;  // fewer runs than slots
+  const int q_start = s_pre[f0], cnt = s_pre[f1] - q_start;  // cnt <= 2048 unless one fine bucket overflowed (then the distro is unfit)
+  if (cnt <= 0 || cnt > kRT) return;
+  const uint64_t* keys = (const uint64_t*)a.w_keyB + (size_t)ts->ss_base * (3 * kSSFineCap);
+  K192 k[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int x = e * kTiledBlock + tid;
+    k[e] = K192{~0ull, ~0ull, 0xFFFFFFFFFFF00000ull | (uint64_t)x};  // past the end: distinct keys above every row's
+    if (x < cnt) {
+      int lo = f0, hi = f1;  // the fine bucket of the run's x-th key: last f with s_pre[f] - q_start <= x
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_pre[mid] - q_start <= x) lo = mid; else hi = mid;
+      }
+      const uint64_t* g = keys + (size_t)lo * (3 * kSSFineCap) + (x - (s_pre[lo] - q_start));
+      k[e] = K192{g[0], g[kSSFineCap], g[2 * kSSFineCap]};
+    }
+  }
+  TT_MARK(6);
+  tile_sort_merge_path(k, tid, smem);
+  __syncthreads();
+  TT_MARK(7);
+  uint32_t i4[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) i4[e] = (uint32_t)(k[e].lo & 0xFFFFFu);
+  tiled_emit_order4(a, ts, d, (long long)q_start + tid * 4, i4, (long long)q_start + cnt);
+  TT_MARK(20);
 }
 
 // ---- T6: model.DistroQueueInfo, the standalone row, MaxHosts of the task-group rows ---------------------------------------

@@ -312,6 +312,37 @@ def generate(cfg: GenConfig, now_ns: int = NOW_NS) -> abi.PlanBatch:
     return batch
 
 
+def sparsify_keys(batch: abi.PlanBatch, seed: int = 1, spread: float = 1.5) -> abi.PlanBatch:
+    """The same pool with every distro's task-group and version keys renumbered by a random injection into a key range `spread`
+    times as large: keys are no longer in first-appearance order and their ranges have holes (keys without a task) -- what a
+    resident pool looks like after evg_pool_apply_delta removed the last task of a group and appended tasks of new ones. The plan
+    must not depend on how the keys are numbered (include/evg_sched.h: any one-to-one interning into the distro's range)."""
+    import dataclasses
+    rng = np.random.default_rng(seed)
+    D = batch.n_distros
+
+    def remap(keys, off, host_keys=None):
+        new_off = np.zeros(D + 1, np.int64)
+        table = np.zeros(int(off[-1]) + 1, np.int64)
+        for d in range(D):
+            lo, hi = int(off[d]), int(off[d + 1])
+            n_old = hi - lo
+            n_new = int(np.ceil(n_old * spread)) + (1 if d % 3 == 0 else 0)  # some ranges grow although they hold no key
+            table[lo:hi] = new_off[d] + rng.permutation(n_new)[:n_old]
+            new_off[d + 1] = new_off[d] + n_new
+        out = np.where(keys >= 0, table[np.maximum(keys, 0)], keys).astype(np.int32)
+        hk = None if host_keys is None else np.where(host_keys >= 0, table[np.maximum(host_keys, 0)], host_keys).astype(np.int32)
+        return out, new_off.astype(np.int32), hk
+
+    cols = dict(batch.cols)
+    hosts = dict(batch.hosts)
+    cols["tg_key"], tg_off, hk = remap(batch.cols["tg_key"], batch.tg_off, hosts.get("tg_key"))
+    cols["version_key"], ver_off, _ = remap(batch.cols["version_key"], batch.ver_off)
+    if hk is not None:
+        hosts["tg_key"] = hk
+    return dataclasses.replace(batch, cols=cols, tg_off=tg_off, ver_off=ver_off, hosts=hosts)
+
+
 def _gen_hosts(batch: abi.PlanBatch, rs: Streams, now_ns: int, dur_pool: np.ndarray) -> None:
     D = batch.n_distros
     nh = rs.randint("hosts.n", D, 0, 200)

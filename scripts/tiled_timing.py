@@ -31,11 +31,11 @@ for _ in range(K):
     pool.plan()
 torch.cuda.synchronize()
 v = buf.cpu().numpy()
-names = {0: "mmerge: samples below the boundaries", 1: "mmerge: candidate segments", 2: "mmerge: candidates loaded", 3: "mmerge: candidates ranked", 4: "mmerge: splits + segments",
-         5: "mmerge: keys loaded", 6: "mmerge: merge tree", 7: "mmerge: emit order", 8: "elect: edges staged", 9: "elect: rows -> keys", 10: "elect: tile sort",
+names = {0: "ss split: samples gathered", 1: "ss split: samples sorted", 2: "ss partition: keys + splitters loaded", 3: "ss partition: search + LDS counts",
+         4: "ss partition: places reserved", 5: "ss partition: keys out", 6: "ss sort: start + keys loaded", 7: "ss sort: bucket sorted", 8: "elect: edges staged", 9: "elect: rows -> keys", 10: "elect: tile sort",
          11: "elect: keys out", 12: "scatter: edges staged", 13: "scatter: row sweep", 14: "scatter: reductions + bucket scan", 15: "scatter: records out",
-         16: "reduce: init", 17: "reduce: bucket table", 18: "reduce: records applied", 19: "reduce: score + rows out", 20: "srank: samples staged", 21: "srank: pairs ranked",
-         22: "merge pass: diagonal searches", 23: "merge pass: keys loaded (thread 0)", 24: "merge pass: 11-stage merge"}
+         16: "reduce: init", 17: "reduce: bucket table", 18: "reduce: records applied", 19: "reduce: score + rows out", 20: "ss sort: order out",
+         22: "merge pass: diagonal searches", 23: "merge pass: keys loaded (thread 0)", }
 for k in range(25):
     if v[64 + k]:
         print("%-40s %9.0f ticks = %6.2f us per workgroup, %d workgroups per plan" % (names[k], v[k] / v[64 + k], v[k] / v[64 + k] / 2100.0, v[64 + k] // K))
