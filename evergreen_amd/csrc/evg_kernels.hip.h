@@ -65,10 +65,7 @@ struct PlanArgs {
   // the many-workgroups-per-distro path for large distros (evg_tiled.hip.h)
   struct TState* w_ts;         // [D]
   int32_t *w_rtile, *w_stile;  // (distro, tile) of every row tile / slot tile
-  int32_t* w_ntile;            // [3] their numbers; [2]: the sort buckets of the sample-sorted distros
-  int32_t* w_btile;            // (distro, bucket) of every sort bucket
-  uint32_t* w_bcur;            // keys placed in every sort bucket so far (k_ss_partition), then its size
-  void* w_split;               // 192-bit splitters: splitter b of a distro at index ss_base + b
+  int32_t* w_ntile;            // [2] their numbers
   void* w_bucket;              // int2 (offset, count) per (row tile, slot tile) pair
   void* w_rec;                 // [2N + E] membership records (TRec)
   int32_t* w_eslot;            // [E] unit slot a dependency edge adds a membership to, or -1

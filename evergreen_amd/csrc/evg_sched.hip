@@ -784,15 +784,14 @@ static int validate_distro(const evg_plan_input* in, int d, char* err, size_t er
   const int lo = in->task_off[d], hi = in->task_off[d + 1];
   if (hi < lo) return fail("task_off not monotone at distro %ld (%ld)", d, hi);
   if (hi - lo >= (1 << 24)) return fail("distro %ld has %ld tasks; the limit is 2^24-1", d, hi - lo);
-  int next_tg = in->tg_off[d], next_ver = in->ver_off[d];
+  const int tg_lo = in->tg_off[d], tg_hi = in->tg_off[d + 1], ver_lo = in->ver_off[d], ver_hi = in->ver_off[d + 1];
+  if (tg_hi < tg_lo || ver_hi < ver_lo) return fail("key offsets not monotone at distro %ld (%ld)", d, tg_hi);
   for (int r = lo; r < hi; r++) {
+    // keys: any one-to-one interning of the strings into the distro's range (ABI 3.1: neither first-appearance order nor
+    // density is required -- a resident pool that lost the last task of a group keeps the key, with no row behind it)
     const int g = t.tg_key[r], v = t.version_key[r];
-    if (g >= 0) {
-      if (g > next_tg || g < in->tg_off[d]) return fail("row %ld: tg_key %ld is not in first-appearance order", r, g);
-      if (g == next_tg) next_tg++;
-    } else if (g != -1) return fail("row %ld: tg_key %ld (use -1 for no task group)", r, g);
-    if (v > next_ver || v < in->ver_off[d]) return fail("row %ld: version_key %ld is not in first-appearance order", r, v);
-    if (v == next_ver) next_ver++;
+    if (g != -1 && (g < tg_lo || g >= tg_hi)) return fail("row %ld: tg_key %ld is neither -1 nor in the distro's key range", r, g);
+    if (v < ver_lo || v >= ver_hi) return fail("row %ld: version_key %ld is outside the distro's key range", r, v);
     const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
     if (e1 < e0) return fail("dep_off not monotone at row %ld (%ld)", r, e1);
     if (e0 < 0 || e1 > t.n_edges) return fail("row %ld: dep_off %ld outside [0, n_edges]", r, e1);
@@ -803,8 +802,6 @@ static int validate_distro(const evg_plan_input* in, int d, char* err, size_t er
       if (j != -1 && (j < lo || j >= hi)) return fail("edge %ld: dep_idx %ld is neither -1 nor a row of the same distro", e, j);
     }
   }
-  if (next_tg != in->tg_off[d + 1]) return fail("distro %ld: tg keys do not fill [tg_off[d], tg_off[d+1]) (%ld)", d, next_tg);
-  if (next_ver != in->ver_off[d + 1]) return fail("distro %ld: version keys do not fill their range (%ld)", d, next_ver);
   return EVG_OK;
 }
 
@@ -915,7 +912,6 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.w_key = c->scratch[21].p;
   a.w_ts = nullptr; a.w_rtile = nullptr; a.w_stile = nullptr; a.w_ntile = nullptr; a.w_bucket = nullptr; a.w_rec = nullptr;
   a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr; a.w_tgbit = nullptr;
-  a.w_btile = nullptr; a.w_bcur = nullptr; a.w_split = nullptr;
   a.tiled_mode = c->tiled_mode;
   a.big_tier = 0;
   a.w_status = (in->promises & EVG_PROMISE_ALL_ON_LDS_PATH) ? c->status_word : nullptr;  // launch_plan arms it for ALL_ON_LDS_TIERS
@@ -997,31 +993,16 @@ static size_t tiled_max_slot_tiles(const evg_plan_input* in) {
   return std::min(Stot / evg::kST + D + 1, 5 * N / (2 * evg::kST) + 1);
 }
 
-// Fine buckets / coarse (sort) bucket slots the sample-sorted distros of a batch can have: a distro of n rows has at most
-// n / 256 + 2 fine buckets (ss_buckets) and n / 1024 + 1 coarse slots (ss_coarse_slots), and only distros of more than kRT rows are tiled.
-static size_t tiled_max_fine_buckets(const evg_plan_input* in) {
-  const size_t N = (size_t)in->tasks.n_tasks, D = (size_t)in->n_distros;
-  return N / 256 + 2 * std::min(D, N / evg::kRT + 1) + 1;
-}
-static size_t tiled_max_buckets(const evg_plan_input* in) {
-  const size_t N = (size_t)in->tasks.n_tasks, D = (size_t)in->n_distros;
-  return N / (evg::kRT / 2) + std::min(D, N / evg::kRT + 1) + 1;
-}
-
 // Scratch of the tiled large-distro path (evg_tiled.hip.h); sized from host-known totals, allocated on first need.
-static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, bool pairwise, bool sample_sort) {
+static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in) {
   using namespace evg;
   const size_t N = (size_t)in->tasks.n_tasks, E = (size_t)in->tasks.n_edges, D = (size_t)in->n_distros;
   const size_t G = D + (size_t)in->n_task_groups;
-  const size_t max_rt = tiled_max_row_tiles(in), max_st = tiled_max_slot_tiles(in), max_bt = sample_sort ? tiled_max_buckets(in) : 1,
-               max_ft = sample_sort ? tiled_max_fine_buckets(in) : 1;
+  const size_t max_rt = tiled_max_row_tiles(in), max_st = tiled_max_slot_tiles(in);
   const size_t st_cap = std::min<size_t>(max_st, kMaxST);  // slot tiles of ONE distro
-  // keyB: the pairwise merge passes' second buffer (distros beyond the sample sort) and the sample sort's fine buckets (1024 slots each)
-  const size_t keyB = std::max<size_t>(pairwise ? sizeof(K192) * max_rt * kRT : 16, sample_sort ? sizeof(K192) * max_ft * kSSFineCap : 16);
-  const size_t sz[14] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
-                         4 * (E + 1), sizeof(K192) * max_rt * kRT, keyB, 8 * G, 8 * max_rt * (kRT / 64),
-                         8 * max_bt, 4 * max_ft, sizeof(K192) * max_ft};
-  for (int i = 0; i < 14; i++) {
+  const size_t sz[11] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
+                         4 * (E + 1), sizeof(K192) * max_rt * kRT, sizeof(K192) * max_rt * kRT, 8 * G, 8 * max_rt * (kRT / 64)};
+  for (int i = 0; i < 11; i++) {
     int rc = ensure(c, c->scratch[32 + i], sz[i]);
     if (rc) return rc;
   }
@@ -1030,13 +1011,10 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in,
   a.w_eslot = (int32_t*)c->scratch[38].p; a.w_keyA = c->scratch[39].p; a.w_keyB = c->scratch[40].p;
   a.w_gfirst = (unsigned long long*)c->scratch[41].p;
   a.w_tgbit = (unsigned long long*)c->scratch[42].p;
-  a.w_btile = (int32_t*)c->scratch[43].p; a.w_bcur = (uint32_t*)c->scratch[44].p; a.w_split = c->scratch[45].p;
   if (!c->tiled_attr_set) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledReduceLds));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_elect, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_merge, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_ss_split, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)k_ss_sort, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
     c->tiled_attr_set = true;
   }
   return EVG_OK;
@@ -1046,11 +1024,9 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in,
 // unconditionally and exits at once where there is no work). evg_plan_input.max_distro_tasks (0 = unknown) only shapes
 // the launch, never the result:
 //   hint <= 2048  only data-dependent fallbacks can be flagged: ONE kernel, one workgroup per flagged distro (k_plan_generic);
-//   otherwise     the tiled pipeline (evg_tiled.hip.h, many workgroups per distro): distros of up to kSSMaxRows rows are
-//                 sample-sorted (split, partition, bucket sort: three launches whatever their size); only when the hint (or,
-//                 without a hint, the task count) allows larger ones are the pairwise merge passes they need enqueued too.
-//                 Then k_plan_generic for whatever the pipeline left: small flagged distros, distros it cannot take, and
-//                 distros larger than the hint promised.
+//   otherwise     the tiled pipeline (evg_tiled.hip.h, many workgroups per distro) with the pairwise merge passes the hint (or,
+//                 without a hint, the task count) allows. Then k_plan_generic for whatever the pipeline left: small flagged
+//                 distros, distros it cannot take, and distros larger than the hint promised.
 // TaskPlan.Len() (out->n_units) needs the set-equality pass that only the one-workgroup kernel has.
 static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st) {
   using namespace evg;
@@ -1063,23 +1039,16 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
     return EVG_OK;
   }
   const long long cap = hint < kTiledMaxRows ? hint : kTiledMaxRows - 1;
-  const bool ss = !(a.tiled_mode & TM_NO_SAMPLE_SORT);
   int passes = 0;
-  if (!ss || cap > kSSMaxRows)
-    while (((long long)kRT << passes) < cap) passes++;
-  int rc = prepare_tiled(c, a, in, passes > 0, ss);
+  while (((long long)kRT << passes) < cap) passes++;
+  int rc = prepare_tiled(c, a, in);
   if (rc) return rc;
   // + 8: the XCD-aware tile mapping (xcd_tile) rounds the tile count up to a multiple of the 8 XCDs
   const dim3 rt((unsigned)tiled_max_row_tiles(in) + 8), stl((unsigned)tiled_max_slot_tiles(in) + 8), tb(kTiledBlock);
-  hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, st, a, passes, ss ? 1 : 0);
+  hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, st, a, passes);
   hipLaunchKernelGGL(k_tiled_scatter, rt, tb, 0, st, a);
   hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, st, a);
   hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, st, a);
-  if (ss) {
-    hipLaunchKernelGGL(k_ss_split, dim3((unsigned)D), tb, kTiledSortLds, st, a);
-    hipLaunchKernelGGL(k_ss_partition, rt, tb, 0, st, a);
-    hipLaunchKernelGGL(k_ss_sort, dim3((unsigned)tiled_max_buckets(in) + 8), tb, kTiledSortLds, st, a);
-  }
   for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, st, a, p);
   hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 1);  // its head writes the info rows of the distros the pipeline finished
   HIP_TRY(c, hipGetLastError());

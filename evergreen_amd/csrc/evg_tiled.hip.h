@@ -21,12 +21,6 @@
 //   T4 k_tiled_merge    log2(tiles) passes of merge path: every workgroup produces 2048 consecutive outputs of the merge of
 //                       two sorted runs (wave-wide 64-ary diagonal searches in global memory, the window's two key ranges
 //                       staged into LDS as consecutive words, one merge-path round there)
-//   -- round 4: distros of up to kSSMaxRows rows are SAMPLE-sorted instead (T3 leaves their keys unsorted; no merge pass):
-//   S1 k_ss_split       per distro: <= 2048 sample keys (one row of every block of `stride` rows, at a hashed offset) sorted in LDS;
-//                       every (ns / B)-th is a splitter; B buckets so that a bucket overflows its 2048 slots at six sigma
-//   S2 k_ss_partition   per row tile: the tile's keys searched against the distro's splitters in LDS, counted per bucket with LDS
-//                       atomics, ONE device atomic per (tile, bucket) reserves the keys' places in the bucket
-//   S3 k_ss_sort        per bucket: <= 2048 keys sorted in LDS (the tile sort), emitted at the bucket's place in the queue (T5)
 //   T5 (tail of T4)     queue order out; first queue position of every task group (TaskGroupInfo.MaxHosts,
 //                       scheduler.go:103-106) -- the merged keys never go back to memory
 //   T6 k_tiled_rows     model.DistroQueueInfo / the standalone TaskGroupInfo row
@@ -52,21 +46,10 @@ constexpr int kTiledMaxRows = 1 << 20;
 constexpr int kTiledMaxSlots = 1 << 21;
 constexpr int kMaxST = (kTiledMaxSlots / kST + 511) / 512 * 512;  // slot tiles of one distro: the scatter kernel buckets them in LDS
 constexpr int kTiledBlock = 512;
-// Sample sort (S1-S3): a distro of n <= kSSMaxRows rows is cut into B FINE buckets by B - 1 splitters taken from ns <=
-// kSSMaxSamples sampled keys. A fine bucket is the rows between two consecutive chosen order statistics of the sample, (ns / B)
-// sample spacings apart: its size has mean n / B and relative standard deviation 1 / sqrt(ns / B). B is the smallest count for
-// which mean x (1 + 6 / sqrt(ns / B)) stays under the kSSFineCap slots of a fine bucket (ss_buckets): an overflow is a six-sigma
-// event, and when it happens the distro is left, flagged, to the one-workgroup generic kernel like every other misfit -- the plan
-// never changes. The SORT then runs over COARSE buckets: maximal runs of consecutive fine buckets that hold at most 2048 keys
-// together, cut greedily from the exact fine counts -- a sort workgroup is ~88 % full whatever the sample said (sorting the
-// sampled buckets themselves needs them ~64 % full to keep six sigma: half as many workgroups again, and a second wave of them).
-constexpr int kSSMaxSamples = 2048, kSSMaxB = 1024, kSSFineCap = 1024;
-constexpr int kSSMaxRows = 98304;     // the bound holds up to ~100 k rows with B <= n / 256 + 2; beyond: tile sort + merge passes
 constexpr int kTileEdges = 6144;      // dependency edges of one row tile resolved edge-parallel in LDS (more: per row, from memory)
 // PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs; every variant is bit-exact, scripts/r03_modes.sh): 1, 2 = the per-row forms of
-// round 2; 4 = no sample sort (round 3's tile sort + log2(tiles) merge passes for every distro); 32 = every thread stores its own
-// keys
-constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2, TM_NO_SAMPLE_SORT = 4;  // 16: linear tile mapping (xcd_tile)
+// round 2; 32 = every thread stores its own keys
+constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2;  // 16: linear tile mapping (xcd_tile)
 
 // blockIdx -> tile, XCD-aware: workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; tile
 // (b % 8) * ceil(T / 8) + b / 8 gives every XCD a contiguous eighth of the tile list, i.e. whole distros. -1: no tile.
@@ -135,8 +118,6 @@ struct TState {
   int32_t on;       // the tiled path plans this distro
   int32_t unfit;    // set on the way: leave it to k_plan_generic after all
   int32_t n_rt, n_st, rt_base, st_base, passes;
-  int32_t ss_B, ss_base, ss_stride, ss_ns;  // sample sort: fine buckets (0: the merge passes sort this distro), first fine bucket id, sample stride, samples
-  int32_t ss_C, ss_cbase;                   //   slots of coarse (sort) buckets reserved in the launch, the first one's id
   long long bucket_base;
   unsigned long long vmin, vmax;                 // biased range of the valid units' TotalValue (k_tiled_reduce)
   unsigned long long dmin, dmax;                 // biased ranges of the TaskList.Less columns
@@ -145,7 +126,7 @@ struct TState {
   uint32_t s_cnt, s_mq, s_cover[2], s_wait[2];   // the standalone ("") row; [0] against the plain target time, [1] against
   unsigned long long s_dur, s_dover[2];          //   min(target, merge-queue target)
   unsigned long long s_first;                    // (queue position << 32) | TaskGroupMaxHosts of the first standalone task
-  uint32_t t_cover, t_wait, pad1;                // sums over the task-group rows
+  uint32_t t_cover, t_wait, t_rows;              // sums over the task-group rows; t_rows: how many of them exist (a key may have no task)
   unsigned long long t_dur, t_dover;
 };
 
@@ -201,27 +182,13 @@ __device__ __forceinline__ long long wave_scan_sum(long long v, int lane) {
   return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
 }
 
-// Fine buckets of the sample sort of a distro of n rows sampled ns times, or 0 when no count within n / 256 + 2 keeps a
-// bucket's six-sigma size under its kSSFineCap slots (see kSSMaxSamples).
-__device__ __forceinline__ int ss_buckets(int n, int ns) {
-  const int bmax = n / 256 + 2 < kSSMaxB ? n / 256 + 2 : kSSMaxB;
-  int B = (n + kSSFineCap - 1) / kSSFineCap;
-  for (B = B < 2 ? 2 : B; B <= bmax && B <= ns; B++) {
-    const float mean = (float)n / (float)B, spb = (float)ns / (float)B;
-    if (mean * (1.f + 6.f / sqrtf(spb)) <= 1000.f) return B;
-  }
-  return 0;
-}
-// Coarse (sort) buckets a distro of n rows can have: two consecutive greedy runs hold more than 2048 keys together.
-__device__ __host__ __forceinline__ int ss_coarse_slots(int n) { return n / (kRT / 2) + 1; }
-
-__global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passes_launched, int ss_on) {
-  __shared__ int s_rt[1024], s_st[1024], s_bt[1024];  // exclusive prefixes: row tiles / slot tiles / sort buckets before thread t's distros
-  __shared__ long long s_w[5][16];
+__global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passes_launched) {
+  __shared__ int s_rt[1024], s_st[1024];  // exclusive prefixes: row tiles / slot tiles before thread t's distros
+  __shared__ long long s_w[3][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int d0 = a.d0, D = a.d1 - a.d0;
   const int per = (D + 1023) / 1024;
-  int rt = 0, st = 0, bt = 0, ft = 0;  // bt: coarse (sort) bucket slots, ft: fine buckets
+  int rt = 0, st = 0;
   long long bk = 0;
   for (int k = 0; k < per; k++) {
     const int d = d0 + tid * per + k;
@@ -234,16 +201,9 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
       const int n_rt = (n + kRT - 1) / kRT, n_st = (S + kST - 1) / kST;
       int passes = 0;
       while ((1 << passes) < n_rt) passes++;
-      int B = 0, stride = 1, ns = 0;
-      if (ss_on && n <= kSSMaxRows) {
-        stride = (n + kSSMaxSamples - 1) / kSSMaxSamples;
-        ns = (n + stride - 1) / stride;
-        B = ss_buckets(n, ns);
-      }
-      if (S < kTiledMaxSlots && n_st <= kMaxST && (B > 0 || passes <= passes_launched)) {
-        t.on = 1; t.n_rt = n_rt; t.n_st = n_st; t.passes = B > 0 ? 0 : passes;
-        t.ss_B = B; t.ss_stride = stride; t.ss_ns = ns; t.ss_C = B > 0 ? ss_coarse_slots(n) : 0;
-        rt += n_rt; st += n_st; bt += t.ss_C; ft += B; bk += (long long)n_rt * n_st;
+      if (S < kTiledMaxSlots && n_st <= kMaxST && passes <= passes_launched) {
+        t.on = 1; t.n_rt = n_rt; t.n_st = n_st; t.passes = passes;
+        rt += n_rt; st += n_st; bk += (long long)n_rt * n_st;
       }
     }
     t.dmin = ~0ull; t.tmin = t.nmin = t.pmin = ~0u;
@@ -252,30 +212,29 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
     a.w_ts[d] = t;
   }
   // three inclusive scans over the 1024 threads: inside the wave by DPP, the 16 wave totals through LDS
-  long long irt = wave_scan_sum(rt, lane), ist = wave_scan_sum(st, lane), ibk = wave_scan_sum(bk, lane), ibt = wave_scan_sum(bt, lane),
-            ift = wave_scan_sum(ft, lane);
-  if (lane == 63) { s_w[0][wv] = irt; s_w[1][wv] = ist; s_w[2][wv] = ibk; s_w[3][wv] = ibt; s_w[4][wv] = ift; }
+  long long irt = wave_scan_sum(rt, lane), ist = wave_scan_sum(st, lane), ibk = wave_scan_sum(bk, lane);
+  if (lane == 63) { s_w[0][wv] = irt; s_w[1][wv] = ist; s_w[2][wv] = ibk; }
   __syncthreads();
-  long long trt = 0, tst = 0, tbt = 0;
+  long long trt = 0, tst = 0;
   for (int w = 0; w < 16; w++) {
-    if (w < wv) { irt += s_w[0][w]; ist += s_w[1][w]; ibk += s_w[2][w]; ibt += s_w[3][w]; ift += s_w[4][w]; }
-    trt += s_w[0][w]; tst += s_w[1][w]; tbt += s_w[3][w];
+    if (w < wv) { irt += s_w[0][w]; ist += s_w[1][w]; ibk += s_w[2][w]; }
+    trt += s_w[0][w]; tst += s_w[1][w];
   }
-  int rb = (int)irt - rt, sb = (int)ist - st, qb = (int)ibt - bt, fb = (int)ift - ft;
+  int rb = (int)irt - rt, sb = (int)ist - st;
   long long bb = ibk - bk;
-  s_rt[tid] = rb; s_st[tid] = sb; s_bt[tid] = qb;
+  s_rt[tid] = rb; s_st[tid] = sb;
   for (int k = 0; k < per; k++) {
     const int d = d0 + tid * per + k;
     if (d >= a.d1) break;
     TState* t = &a.w_ts[d];
     if (!t->on) continue;
-    t->rt_base = rb; t->st_base = sb; t->bucket_base = bb; t->ss_cbase = qb; t->ss_base = fb;
-    rb += t->n_rt; sb += t->n_st; bb += (long long)t->n_rt * t->n_st; qb += t->ss_C; fb += t->ss_B;
+    t->rt_base = rb; t->st_base = sb; t->bucket_base = bb;
+    rb += t->n_rt; sb += t->n_st; bb += (long long)t->n_rt * t->n_st;
   }
-  if (tid == 0) { a.w_ntile[0] = (int)trt; a.w_ntile[1] = (int)tst; a.w_ntile[2] = (int)tbt; }
+  if (tid == 0) { a.w_ntile[0] = (int)trt; a.w_ntile[1] = (int)tst; }
   __syncthreads();  // the TState rows (same workgroup: visible after the barrier) and the prefixes
   // the two directories, every thread a share: tile x belongs to the last thread whose prefix is <= x, then to one of its distros
-  auto fill = [&](int total, const int* pre, int32_t* dir, int what) {
+  auto fill = [&](int total, const int* pre, int32_t* dir, bool rows) {
     for (int x = tid; x < total; x += 1024) {
       int lo = 0, hi = 1024;  // last t with pre[t] <= x
       while (hi - lo > 1) {
@@ -287,14 +246,13 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
         if (d >= a.d1) break;
         const TState* t = &a.w_ts[d];
         if (!t->on) continue;
-        const int base = what == 0 ? t->rt_base : what == 1 ? t->st_base : t->ss_cbase, cnt = what == 0 ? t->n_rt : what == 1 ? t->n_st : t->ss_C;
+        const int base = rows ? t->rt_base : t->st_base, cnt = rows ? t->n_rt : t->n_st;
         if (x >= base && x < base + cnt) { dir[2 * x] = d; dir[2 * x + 1] = x - base; break; }
       }
     }
   };
-  fill((int)trt, s_rt, a.w_rtile, 0);
-  fill((int)tst, s_st, a.w_stile, 1);
-  fill((int)tbt, s_bt, a.w_btile, 2);
+  fill((int)trt, s_rt, a.w_rtile, true);
+  fill((int)tst, s_st, a.w_stile, false);
 }
 
 // ---- T1: rows -> records ---------------------------------------------------------------------------------------
@@ -611,7 +569,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
   __shared__ int s_pref[kTiledBlock + 1], s_w8[8];
   __shared__ long long s_base[kTiledBlock];
   __shared__ unsigned long long s_t64[4];  // 0 t_dur 1 t_dover 2 vmin 3 vmax
-  __shared__ uint32_t s_t32[2];
+  __shared__ uint32_t s_t32[3];
   const int w = xcd_tile(blockIdx.x, a.w_ntile[1], a.tiled_mode);
   if (w < 0) return;
   const int d = a.w_stile[2 * w], j = a.w_stile[2 * w + 1];
@@ -673,7 +631,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
   }
   TT_MARK(16);
   if (tid < n_rt) s_base[tid] = my_base;
-  if (tid == 0) { s_pref[0] = 0; s_t64[0] = 0; s_t64[1] = 0; s_t64[2] = ~0ull; s_t64[3] = 0; s_t32[0] = 0; s_t32[1] = 0; }
+  if (tid == 0) { s_pref[0] = 0; s_t64[0] = 0; s_t64[1] = 0; s_t64[2] = ~0ull; s_t64[3] = 0; s_t32[0] = 0; s_t32[1] = 0; s_t32[2] = 0; }
   s_pref[tid + 1] = block_scan_sum(mine, tid, s_w8);
   __syncthreads();
   TT_MARK(17);
@@ -705,6 +663,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     atomicOr(&m_cnt[u], ((r.w0 >> 10) & 0x3Fu) << 24);
     atomicMin(&m_minrow[u], r.row);
     if (r.w0 & RW_QI) {
+      atomicOr(&g_wait[u], 0x80000000u);  // the group has a task in this queue: its TaskGroupInfo row exists (scheduler.go:98-112)
       if (r.w0 & RW_COUNT) {
         atomicAdd(&g_cnt[u], 1u);
         atomicAdd((unsigned long long*)&g_dur[u], (unsigned long long)r.dur);
@@ -720,7 +679,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
   // ---- score; rows out ----
   const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // the distro's slot range in the global slot arrays
   uint64_t t_dur = 0, t_dover = 0, r_vmin = ~0ull, r_vmax = 0;
-  uint32_t t_cover = 0, t_wait = 0;
+  uint32_t t_cover = 0, t_wait = 0, t_rows = 0;
   for (int u = tid; u < ns; u += kTiledBlock) {
     const int su = s0 + u;
     const uint32_t cw = m_cnt[u];
@@ -741,23 +700,25 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
       gi.duration_over_threshold_ns = (int64_t)g_dover[u];
       gi.count = (int32_t)g_cnt[u];
       gi.max_hosts = 0;
+      const uint32_t gw = g_wait[u] & 0x7FFFFFFFu;
       gi.count_duration_over_threshold = (int32_t)g_cover[u];
-      gi.count_wait_over_threshold = (int32_t)g_wait[u];
+      gi.count_wait_over_threshold = (int32_t)gw;
       gi.count_dep_filled_merge_queue_tasks = (int32_t)g_mq[u];
-      gi.present = 1;  // a key of this distro has at least one task (keys are dense by first appearance)
+      gi.present = (int32_t)(g_wait[u] >> 31);  // a key WITHOUT a task (a hole in the distro's key range) has no row in the reference's map
+      t_rows += g_wait[u] >> 31;
       gi.count_free = 0;
       gi.count_required = 0;
       a.out.group_info[c.D + c.tg_lo + k] = gi;
       a.w_gfirst[c.D + c.tg_lo + k] = ~0ull;
-      t_dur += g_dur[u]; t_dover += g_dover[u]; t_cover += g_cover[u]; t_wait += g_wait[u];
+      t_dur += g_dur[u]; t_dover += g_dover[u]; t_cover += g_cover[u]; t_wait += gw;
     }
   }
-  t_dur = wave_sum(t_dur); t_dover = wave_sum(t_dover); t_cover = wave_sum(t_cover); t_wait = wave_sum(t_wait);
+  t_dur = wave_sum(t_dur); t_dover = wave_sum(t_dover); t_cover = wave_sum(t_cover); t_wait = wave_sum(t_wait); t_rows = wave_sum(t_rows);
   r_vmin = wave_min(r_vmin); r_vmax = wave_max(r_vmax);
   if (lane == 0) {
     atomicAdd(&s_t64[0], (unsigned long long)t_dur); atomicAdd(&s_t64[1], (unsigned long long)t_dover);
     atomicMin(&s_t64[2], (unsigned long long)r_vmin); atomicMax(&s_t64[3], (unsigned long long)r_vmax);
-    atomicAdd(&s_t32[0], t_cover); atomicAdd(&s_t32[1], t_wait);
+    atomicAdd(&s_t32[0], t_cover); atomicAdd(&s_t32[1], t_wait); atomicAdd(&s_t32[2], t_rows);
   }
   __syncthreads();
   if (tid == 0) {
@@ -766,6 +727,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     if (s_t64[1]) atomicAdd(&ts->t_dover, s_t64[1]);
     if (s_t32[0]) atomicAdd(&ts->t_cover, s_t32[0]);
     if (s_t32[1]) atomicAdd(&ts->t_wait, s_t32[1]);
+    if (s_t32[2]) atomicAdd(&ts->t_rows, s_t32[2]);
   }
   TT_MARK(19);
 }
@@ -976,18 +938,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
   // inside each unit's run by counting: k_tiled_elect 96 -> 76 us on the config-5 share, but the runs of ~50 rows of
   // grouped-version distros cost more than the network saves on the skewed pool (+7 %), and without them few distros qualify.)
   K192* const tile_out = (K192*)a.w_keyA + ((size_t)ts->rt_base + tile) * kRT;
-  if (ts->ss_B > 0) {
-    // sample-sorted distro: the keys leave UNSORTED, word-major inside the tile's 6144 words (hi[2048] | mid[2048] | lo[2048]) -- every
-    // store here and every load of S1 / S2 is one 8-byte word per lane, consecutive lanes consecutive words
-    uint64_t* g = (uint64_t*)tile_out;
-#pragma unroll
-    for (int e4 = 0; e4 < 4; e4++) {
-      const int x = e4 * kTiledBlock + tid;
-      g[x] = k[e4].hi; g[kRT + x] = k[e4].mid; g[2 * kRT + x] = k[e4].lo;
-    }
-    TT_MARK(11);
-    return;
-  }
   tile_sort_merge_path(k, tid, smem);
   TT_MARK(10);
   if (a.tiled_mode & 32) {  // A/B: every thread stores its own four keys
@@ -1001,62 +951,25 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
 }
 
 // ---- T5 (the tail of the merge): queue order out; first queue position per task group ----------------------------------
-// i4[e] = the (local) row at queue position q0 + e of distro d. Called by every thread of the workgroup.
-// Positions at or beyond qlimit (the end of a sort bucket; the distro's length for a merge window) hold no row.
+// i4[e] = the (local) row at queue position q0 + e of distro d, q0 = 4 x (the thread's place in the window). Called by every
+// thread of the workgroup. Positions at or beyond qlimit (the distro's length) hold no row.
+//
+// A task group's MaxHosts is the TaskGroupMaxHosts of its FIRST task in queue order (scheduler.go:103-106): a device-scope
+// atomicMin of (position << 32 | max hosts) per task-group row. Those atomics execute in the memory-side cache at ~20 G/s --
+// a quarter million of them per config-5-share plan were 17 us of the last pass. Round 4: (1) a row whose predecessor in the queue
+// belongs to the same group cannot be the group's first, and the rows of a group mostly sit side by side (one unit): the
+// predecessor's key is the previous position's in the thread's own registers, or the previous lane's last one (one ds_bpermute);
+// lane 0 of a wave has no lane to ask and always issues. ~80 % of the atomics go. (2) What is left is one atomic per run, so the
+// read-before-write that kept a large group's rows from serialising on one address is no longer needed: the atomicMin goes out
+// without a returned value, nothing waits for it. (3) The loads of the four positions are issued side by side (the merge kernel
+// has the registers since the network variant left it: 54 of 80).
 __device__ __forceinline__ void tiled_emit_order(const PlanArgs& a, TState* ts, int d, long long q0, const uint32_t (&i4)[4], long long qlimit) {
-  __shared__ unsigned long long s_first;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int lo = a.in.task_off[d], n = a.in.task_off[d + 1] - lo, D = a.in.n_distros;
-  if (tid == 0) s_first = ~0ull;
-  __syncthreads();
-  const unsigned long long* tgbit = a.w_tgbit + (size_t)ts->rt_base * (kRT / 64);
-  unsigned long long first = ~0ull;  // (queue position << 32) | row of the first stand-alone task this thread met
-  int32_t o4[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const long long q = q0 + e;
-    o4[e] = 0;
-    if (q >= qlimit) continue;
-    const int i = (int)i4[e];
-    const int r = lo + i;
-    o4[e] = r;
-    // (Measured: the atomics of the task-group rows below are 17 us of the last pass -- with them compiled out the plan is 0.285 ->
-    // 0.268 ms, the gathers are free. Skipping every row whose predecessor in the queue is a task of the same group, which
-    // cannot be the group's first, is nevertheless SLOWER, 0.289 -> 0.293 ms, skewed pool 0.295 -> 0.311.)
-    // (Measured: issuing the task-group rows' gathers and the reads of the current minimum for all four rows before any is used --
-    // +3 % per plan, the merge kernels sit at their 80-register limit; the atomic without the read first -- the rows of a large
-    // group serialise on one address, skewed pool 0.314 -> 0.364 ms.)
-    if (!((tgbit[i >> 6] >> (i & 63)) & 1ull)) {  // row tiles are 2048 rows: bit i of the distro's table
-      const unsigned long long packed = ((unsigned long long)q << 32) | (uint32_t)i;
-      first = packed < first ? packed : first;
-    } else {
-      const int tgk = a.in.tasks.tg_key[r];
-      const unsigned long long packed = ((unsigned long long)q << 32) | (uint32_t)a.in.tasks.task_group_max_hosts[r];
-      if (__hip_atomic_load(&a.w_gfirst[D + tgk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > packed) atomicMin(&a.w_gfirst[D + tgk], packed);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 4; e++)
-    if (q0 + e < qlimit) a.out.order[lo + q0 + e] = o4[e];
-  first = wave_min((uint64_t)first);
-  if (lane == 0 && first != ~0ull) atomicMin(&s_first, first);
-  __syncthreads();
-  if (tid == 0 && s_first != ~0ull) {  // MaxHosts of the stand-alone row = TaskGroupMaxHosts of its first task in queue order
-    const unsigned long long packed = (s_first & 0xFFFFFFFF00000000ull) | (uint32_t)a.in.tasks.task_group_max_hosts[lo + (int)(s_first & 0xFFFFFFFFu)];
-    atomicMin(&ts->s_first, packed);
-  }
-}
-
-// The same for a sort bucket (k_ss_sort), with the four positions' loads issued side by side -- the table words, then the task-group
-// rows' columns, then the reads of the groups' current minima -- instead of row after row: four dependent round trips per thread
-// instead of up to sixteen. (In k_tiled_merge, which sits at its 80-register limit, this form measured 3 % slower; here there is room.)
-__device__ __forceinline__ void tiled_emit_order4(const PlanArgs& a, TState* ts, int d, long long q0, const uint32_t (&i4)[4], long long qlimit) {
   __shared__ unsigned long long s_first;
   const int tid = threadIdx.x, lane = tid & 63;
   const int lo = a.in.task_off[d], D = a.in.n_distros;
   if (tid == 0) s_first = ~0ull;
   __syncthreads();
-  const unsigned long long* tgbit = a.w_tgbit + (size_t)ts->rt_base * (kRT / 64);
+  const unsigned long long* tgbit = a.w_tgbit + (size_t)ts->rt_base * (kRT / 64);  // row tiles are 2048 rows: bit i of the distro's table
   bool live[4], tg[4];
   unsigned long long word[4];
 #pragma unroll
@@ -1068,25 +981,26 @@ __device__ __forceinline__ void tiled_emit_order4(const PlanArgs& a, TState* ts,
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     tg[e] = live[e] && ((word[e] >> (i4[e] & 63)) & 1ull);
-    tgk[e] = tg[e] ? a.in.tasks.tg_key[lo + (int)i4[e]] : 0;
+    tgk[e] = tg[e] ? a.in.tasks.tg_key[lo + (int)i4[e]] : -1;
     mh[e] = tg[e] ? a.in.tasks.task_group_max_hosts[lo + (int)i4[e]] : 0;
   }
-  unsigned long long seen[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) seen[e] = tg[e] ? __hip_atomic_load(&a.w_gfirst[D + tgk[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  // the group of the position before this thread's first: the previous lane's last (lane 0: none, -2 never matches)
+  int prev = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, tgk[3]);
+  prev = lane == 0 ? -2 : prev;
   unsigned long long first = ~0ull;  // (queue position << 32) | row of the first stand-alone task this thread met
 #pragma unroll
   for (int e = 0; e < 4; e++) {
-    if (!live[e]) continue;
-    const unsigned long long q = (unsigned long long)(q0 + e);
-    if (tg[e]) {
-      const unsigned long long packed = (q << 32) | (uint32_t)mh[e];
-      if (seen[e] > packed) atomicMin(&a.w_gfirst[D + tgk[e]], packed);
-    } else {
-      const unsigned long long packed = (q << 32) | i4[e];
-      first = packed < first ? packed : first;
+    if (live[e]) {
+      const unsigned long long q = (unsigned long long)(q0 + e);
+      if (tg[e]) {
+        if (tgk[e] != prev) atomicMin(&a.w_gfirst[D + tgk[e]], (q << 32) | (uint32_t)mh[e]);
+      } else {
+        const unsigned long long packed = (q << 32) | i4[e];
+        first = packed < first ? packed : first;
+      }
+      a.out.order[lo + q0 + e] = lo + (int)i4[e];
     }
-    a.out.order[lo + q0 + e] = lo + (int)i4[e];
+    prev = tgk[e];
   }
   first = wave_min((uint64_t)first);
   if (lane == 0 && first != ~0ull) atomicMin(&s_first, first);
@@ -1190,190 +1104,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a
   }
 }
 
-// ---- S1-S3: sample sort of the distros k_tiled_list gave buckets (ss_B > 0) -------------------------------------------------
-// Key i of row tile T of a sample-sorted distro (k_tiled_elect's word-major layout).
-__device__ __forceinline__ K192 ss_key(const uint64_t* keys, int i) {
-  const uint64_t* g = keys + (size_t)(i / kRT) * (3 * kRT) + (i % kRT);
-  return K192{g[0], g[kRT], g[2 * kRT]};
-}
-// S1: one workgroup per distro of the call's range. Sample x is one row of block [x stride, (x + 1) stride), at an offset hashed
-// from x (a periodic arrangement of the rows cannot line up with a fixed offset); the ns samples are sorted with the tile sort
-// (padded to 2048 with keys above every row's) and splitter b = the sample of rank floor((b + 1) ns / B), b < B - 1: bucket b
-// takes the keys k with splitter[b - 1] < k <= splitter[b]. The distro's bucket cursors are zeroed here.
-__global__ void __launch_bounds__(kTiledBlock, 6) k_ss_split(const PlanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int d = a.d0 + blockIdx.x;
-  if (d >= a.d1) return;
-  TState* ts = &a.w_ts[d];
-  if (!tiled_live(ts) || ts->ss_B <= 0) return;
-  const int tid = threadIdx.x;
-  const int n = a.in.task_off[d + 1] - a.in.task_off[d], B = ts->ss_B, stride = ts->ss_stride, ns = ts->ss_ns;
-  const uint64_t* keys = (const uint64_t*)a.w_keyA + (size_t)ts->rt_base * (3 * kRT);
-  for (int b = tid; b < B; b += kTiledBlock) a.w_bcur[ts->ss_base + b] = 0;
-  TT_BEGIN();
-  K192 k[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const int x = e * kTiledBlock + tid;
-    k[e] = K192{~0ull, ~0ull, 0xFFFFFFFFFFF00000ull | (uint64_t)x};
-    if (x < ns) {
-      uint32_t h = (uint32_t)x * 0x9E3779B1u;
-      h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
-      int row = x * stride + (int)(h % (uint32_t)stride);
-      if (row >= n) row = x * stride;  // the last, partial block
-      k[e] = ss_key(keys, row);
-    }
-  }
-  TT_MARK(0);
-  tile_sort_merge_path(k, tid, smem);
-  TT_MARK(1);
-  uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kRT, *s_lo = s_mid + kRT;
-  __syncthreads();  // the last round's reads of the arrays
-  lds_put4_soa(s_hi, s_mid, s_lo, tid * 4, k);
-  __syncthreads();
-  uint64_t* sp = (uint64_t*)a.w_split + (size_t)ts->ss_base * 3;
-  for (int b = tid; b < B - 1; b += kTiledBlock) {
-    const int r = (int)(((long long)(b + 1) * ns) / B);  // < ns
-    sp[3 * b] = s_hi[r]; sp[3 * b + 1] = s_mid[r]; sp[3 * b + 2] = s_lo[r];
-  }
-}
-
-// S2: one workgroup per row tile.
-__global__ void __launch_bounds__(kTiledBlock, 6) k_ss_partition(const PlanArgs a) {
-  __shared__ uint64_t s_hi[kSSMaxB], s_mid[kSSMaxB], s_lo[kSSMaxB];
-  __shared__ int s_cnt[kSSMaxB];
-  const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);
-  if (w < 0) return;
-  const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
-  TState* ts = &a.w_ts[d];
-  if (!tiled_live(ts) || ts->ss_B <= 0) return;
-  const int tid = threadIdx.x;
-  const int n = a.in.task_off[d + 1] - a.in.task_off[d], B = ts->ss_B, nsp = B - 1;
-  const uint64_t* sp = (const uint64_t*)a.w_split + (size_t)ts->ss_base * 3;
-  const uint64_t* g = (const uint64_t*)a.w_keyA + ((size_t)ts->rt_base + tile) * (3 * kRT);
-  TT_BEGIN();
-  K192 k[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const int x = e * kTiledBlock + tid;
-    k[e] = K192{g[x], g[kRT + x], g[2 * kRT + x]};
-  }
-  for (int x = tid; x < 3 * nsp; x += kTiledBlock) {  // consecutive words in, three arrays
-    const int b = x / 3, c = x - 3 * b;
-    (c == 0 ? s_hi : c == 1 ? s_mid : s_lo)[b] = sp[x];
-  }
-  for (int b = tid; b < B; b += kTiledBlock) s_cnt[b] = 0;
-  __syncthreads();
-  TT_MARK(2);
-  // bucket = the splitters strictly below the key: one uniform binary search, four keys side by side
-  int bkt[4] = {0, 0, 0, 0};
-  for (int step = nsp ? 1 << (31 - __builtin_clz(nsp)) : 0; step > 0; step >>= 1) {
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int z = bkt[e] + step - 1;
-      if (bkt[e] + step <= nsp) {
-        const uint64_t h = s_hi[z];
-        bool lt = h < k[e].hi;
-        if (h == k[e].hi) { const uint64_t m = s_mid[z]; lt = m != k[e].mid ? m < k[e].mid : s_lo[z] < k[e].lo; }
-        bkt[e] += lt ? step : 0;
-      }
-    }
-  }
-  int lr[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const bool valid = tile * kRT + e * kTiledBlock + tid < n;
-    lr[e] = valid ? atomicAdd(&s_cnt[bkt[e]], 1) : -1;
-  }
-  __syncthreads();
-  TT_MARK(3);
-  for (int b = tid; b < B; b += kTiledBlock) {
-    const int c = s_cnt[b];
-    int base = 0;
-    if (c > 0) {
-      base = (int)atomicAdd(&a.w_bcur[ts->ss_base + b], (uint32_t)c);
-      if (base + c > kSSFineCap) atomicOr((unsigned*)&ts->unfit, 1u);  // a six-sigma bucket: the generic kernel plans this distro
-    }
-    s_cnt[b] = base;
-  }
-  __syncthreads();
-  TT_MARK(4);
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    if (lr[e] < 0) continue;
-    const int pos = s_cnt[bkt[e]] + lr[e];
-    if (pos >= kSSFineCap) continue;
-    uint64_t* out = (uint64_t*)a.w_keyB + (size_t)(ts->ss_base + bkt[e]) * (3 * kSSFineCap) + pos;
-    out[0] = k[e].hi; out[kSSFineCap] = k[e].mid; out[2 * kSSFineCap] = k[e].lo;
-  }
-  TT_MARK(5);
-}
-
-// S3: one workgroup per COARSE bucket slot: coarse bucket c of a distro is the c-th maximal run of consecutive fine buckets with at
-// most 2048 keys together (greedy over the exact counts k_ss_partition left; every workgroup of the distro cuts the same runs).
-// Its keys are sorted in LDS and the rows go out at the run's place in the distro's queue.
-__global__ void __launch_bounds__(kTiledBlock, 6) k_ss_sort(const PlanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_pre[kSSMaxB + 1];  // keys in the distro's fine buckets below f
-  __shared__ int s_w8[8], s_run[2];
-  const int w = xcd_tile(blockIdx.x, a.w_ntile[2], a.tiled_mode);
-  if (w < 0) return;
-  const int d = a.w_btile[2 * w], c = a.w_btile[2 * w + 1];
-  TState* ts = &a.w_ts[d];
-  if (!tiled_live(ts)) return;
-  const int tid = threadIdx.x;
-  const int B = ts->ss_B;
-  const uint32_t* cur = a.w_bcur + ts->ss_base;
-  TT_BEGIN();
-  // prefix sums of the fine counts (B <= 1024: two per thread)
-  const int c0 = 2 * tid < B ? (int)cur[2 * tid] : 0, c1 = 2 * tid + 1 < B ? (int)cur[2 * tid + 1] : 0;
-  const int incl = block_scan_sum(c0 + c1, tid, s_w8);
-  if (2 * tid < B) s_pre[2 * tid] = incl - c0 - c1;
-  if (2 * tid + 1 < B) s_pre[2 * tid + 1] = incl - c1;
-  if (tid == kTiledBlock - 1) s_pre[B] = incl;  // (B == 1024: thread 511 owns the last pair)
-  __syncthreads();
-  if (tid == 0) {  // the c-th greedy run [f0, f1): a handful of steps per run
-    int f0 = 0, f1 = 0;
-    for (int g = 0; g <= c && f0 < B; g++) {
-      f0 = f1;
-      if (f0 >= B) break;
-      f1 = f0 + 1;
-      while (f1 < B && s_pre[f1 + 1] - s_pre[f0] <= kRT) f1++;
-    }
-    s_run[0] = f0; s_run[1] = f0 < B ? f1 : f0;
-  }
-  __syncthreads();
-  const int f0 = s_run[0], f1 = s_run[1];
-  if (f0 >= f1) return;  // fewer runs than slots
-  const int q_start = s_pre[f0], cnt = s_pre[f1] - q_start;  // cnt <= 2048 unless one fine bucket overflowed (then the distro is unfit)
-  if (cnt <= 0 || cnt > kRT) return;
-  const uint64_t* keys = (const uint64_t*)a.w_keyB + (size_t)ts->ss_base * (3 * kSSFineCap);
-  K192 k[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const int x = e * kTiledBlock + tid;
-    k[e] = K192{~0ull, ~0ull, 0xFFFFFFFFFFF00000ull | (uint64_t)x};  // past the end: distinct keys above every row's
-    if (x < cnt) {
-      int lo = f0, hi = f1;  // the fine bucket of the run's x-th key: last f with s_pre[f] - q_start <= x
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (s_pre[mid] - q_start <= x) lo = mid; else hi = mid;
-      }
-      const uint64_t* g = keys + (size_t)lo * (3 * kSSFineCap) + (x - (s_pre[lo] - q_start));
-      k[e] = K192{g[0], g[kSSFineCap], g[2 * kSSFineCap]};
-    }
-  }
-  TT_MARK(6);
-  tile_sort_merge_path(k, tid, smem);
-  __syncthreads();
-  TT_MARK(7);
-  uint32_t i4[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) i4[e] = (uint32_t)(k[e].lo & 0xFFFFFu);
-  tiled_emit_order4(a, ts, d, (long long)q_start + tid * 4, i4, (long long)q_start + cnt);
-  TT_MARK(20);
-}
-
 // ---- T6: model.DistroQueueInfo, the standalone row, MaxHosts of the task-group rows ---------------------------------------
 // Runs at the head of k_plan_generic's launch behind the pipeline (one launch instead of two): the workgroup that strides
 // over distro d writes d's rows when the pipeline finished d. nthreads = blockDim.x.
@@ -1383,7 +1113,10 @@ __device__ __forceinline__ void tiled_rows(const PlanArgs& a) {
     const TState* ts = &a.w_ts[d];
     if (!tiled_live(ts)) continue;
     const int D = a.in.n_distros, tg_lo = a.in.tg_off[d], ntg = a.in.tg_off[d + 1] - tg_lo;
-    for (int k = tid; k < ntg; k += nthreads) a.out.group_info[D + tg_lo + k].max_hosts = (int32_t)(uint32_t)(a.w_gfirst[D + tg_lo + k] & 0xFFFFFFFFu);
+    for (int k = tid; k < ntg; k += nthreads) {
+      const unsigned long long gf = a.w_gfirst[D + tg_lo + k];  // ~0: a key without a task (its row is all zero, present == 0)
+      a.out.group_info[D + tg_lo + k].max_hosts = gf == ~0ull ? 0 : (int32_t)(uint32_t)(gf & 0xFFFFFFFFu);
+    }
     if (tid == 0) {
       const evg_distro_params p = a.in.distros[d];
       const int v = ts->any_mq ? 1 : 0;
@@ -1411,7 +1144,7 @@ __device__ __forceinline__ void tiled_rows(const PlanArgs& a) {
       di.count_wait_over_threshold = (int32_t)(ts->s_wait[v] + ts->t_wait);
       di.num_queued_large_parser_project_tasks = (int32_t)ts->n_s3;
       di.secondary_queue = (int32_t)ts->sec;
-      di.n_task_group_infos = ntg + (present ? 1 : 0);
+      di.n_task_group_infos = (int32_t)ts->t_rows + (present ? 1 : 0);
       a.out.distro_info[d] = di;
     }
   }

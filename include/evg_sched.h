@@ -20,8 +20,11 @@
  *     model/task/task.go:436-438) and version ids are interned by the caller into dense int32 keys:
  *       tg_key      : -1 when Task.TaskGroup == "", else in [tg_off[d], tg_off[d+1])
  *       version_key : in [ver_off[d], ver_off[d+1])
- *     Keys of one distro are numbered in order of FIRST APPEARANCE in that distro's rows (key k first
- *     occurs after every key < k has occurred). One string maps to one key per distro.
+ *     One string maps to one key per distro, one key to one string; which key, and whether every key of the
+ *     range has a task, is the caller's business (ABI 3.1; until 3.0 keys had to be dense, in order of first
+ *     appearance -- what a shim that interns while it packs produces anyway). A key without a task costs one
+ *     idle unit slot and a group_info row with present == 0: what a resident pool keeps when
+ *     evg_pool_apply_delta removes the last task of a group.
  *   - A dependency edge stores the ROW of the dependency when that task is in the SAME distro's
  *     segment (the planner's cache.Exists(dep.TaskId), scheduler/planner.go:453, and
  *     GetDistroQueueInfo's depCache, scheduler/scheduler.go:62-65), else -1 plus the resolved state

@@ -31,10 +31,9 @@ for _ in range(K):
     pool.plan()
 torch.cuda.synchronize()
 v = buf.cpu().numpy()
-names = {0: "ss split: samples gathered", 1: "ss split: samples sorted", 2: "ss partition: keys + splitters loaded", 3: "ss partition: search + LDS counts",
-         4: "ss partition: places reserved", 5: "ss partition: keys out", 6: "ss sort: start + keys loaded", 7: "ss sort: bucket sorted", 8: "elect: edges staged", 9: "elect: rows -> keys", 10: "elect: tile sort",
+names = {8: "elect: edges staged", 9: "elect: rows -> keys", 10: "elect: tile sort",
          11: "elect: keys out", 12: "scatter: edges staged", 13: "scatter: row sweep", 14: "scatter: reductions + bucket scan", 15: "scatter: records out",
-         16: "reduce: init", 17: "reduce: bucket table", 18: "reduce: records applied", 19: "reduce: score + rows out", 20: "ss sort: order out",
+         16: "reduce: init", 17: "reduce: bucket table", 18: "reduce: records applied", 19: "reduce: score + rows out", 20: "merge pass: order out (last pass)",
          22: "merge pass: diagonal searches", 23: "merge pass: keys loaded (thread 0)", }
 for k in range(25):
     if v[64 + k]:
