@@ -69,6 +69,12 @@ class EdgeUpdate(C.Structure):  # evg_edge_update
     _fields_ = [("n_edges", C.c_int32), ("reserved", C.c_int32), ("edges", _p), ("dep_info", _p), ("dep_finished_ts_ns", _p)]
 
 
+class PoolDelta(C.Structure):  # evg_pool_delta
+    _fields_ = [("n_removed", C.c_int32), ("n_added", C.c_int32), ("removed_rows", _p), ("removed_dep_state", _p), ("removed_finished_ts_ns", _p),
+                ("added_distro", _p), ("added", TaskSoa), ("tg_off", _p), ("ver_off", _p), ("n_relinked", C.c_int32), ("reserved", C.c_int32),
+                ("relinked_edges", _p), ("relinked_to", _p)]
+
+
 EVG_ABI_MAJOR, EVG_ABI_MINOR = 3, 1
 
 

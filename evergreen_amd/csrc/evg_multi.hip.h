@@ -255,6 +255,10 @@ static void out_slices(const evg_multi* m, int k, std::vector<Slice>& out) {
 }
 
 static void free_rank(Rank& r) {
+  if (!r.ctx) {  // evg_create refused the device (a bad ordinal): nothing was allocated on it, and hipSetDevice on it would leave a
+    r = Rank{};  // sticky "invalid device ordinal" behind for the next hipGetLastError of this thread
+    return;
+  }
   (void)hipSetDevice(r.device);
   if (r.comm) (void)g_rccl.CommDestroy(r.comm);
   if (r.buf) (void)hipFree(r.buf);

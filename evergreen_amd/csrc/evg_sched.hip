@@ -20,6 +20,7 @@
 #include "evg_alloc.hip.h"
 #include "evg_plan_lds.hip.h"
 #include "evg_dispatch.hip.h"
+#include "evg_pool_delta.hip.h"
 
 namespace evg {
 
@@ -431,6 +432,11 @@ struct evg_ctx {
   std::vector<DevBuf> pool = std::vector<DevBuf>(20);
   evg_plan_input pool_in{};  // device pointers into `pool`
   bool pool_loaded = false;
+  // evg_pool_apply_delta re-packs into the second set and swaps; what the host must remember of the pool to cut a delta
+  std::vector<DevBuf> pool_alt = std::vector<DevBuf>(20);
+  std::vector<int32_t> pool_task_off, pool_tg_off, pool_ver_off;
+  std::vector<uint8_t> pool_gv;   // PlannerSettings.ShouldGroupVersions() per distro (the shape test of the launch hints)
+  bool pool_pri_wide = false;     // some priority does not fit int32: no distro-shape promise holds
   int tiled_mode = 0;  // EVG_TILED_MODE: TM_* bits (evg_tiled.hip.h), A/B runs of the large-distro pipeline's per-row / pairwise forms
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts = nullptr;
@@ -690,6 +696,7 @@ void evg_destroy(evg_ctx* c) {
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->stage) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->pool) if (b.p) (void)hipFree(b.p);
+  for (auto& b : c->pool_alt) if (b.p) (void)hipFree(b.p);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -878,6 +885,7 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   using namespace evg;
   if (!c || !in || !out) return EVG_E_INVALID;
   if (int rc = pending_status(c)) return rc;
+  (void)hipGetLastError();  // a stale error some other HIP user of this thread left behind is not this call's
   const int D = in->n_distros;
   if (D < 0 || in->tasks.n_tasks < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
   if (D == 0) return EVG_OK;
@@ -960,6 +968,7 @@ static int prepare_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_
   using namespace evg;
   if (!c || !in || !out) return EVG_E_INVALID;
   if (int rc = pending_status(c)) return rc;
+  (void)hipGetLastError();  // (see prepare_plan)
   if (in->n_distros < 0) return set_err(c, EVG_E_INVALID, "negative sizes");
   if (in->n_distros == 0) return EVG_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1526,6 +1535,13 @@ int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
   dt.dep_finished_ts_ns = up(t.dep_finished_ts_ns, E);
   di.distros = up(in->distros, D); di.task_off = up(in->task_off, D + 1); di.tg_off = up(in->tg_off, D + 1); di.ver_off = up(in->ver_off, D + 1);
   if (rc) return rc;
+  c->pool_task_off.assign(in->task_off, in->task_off + D + 1);
+  c->pool_tg_off.assign(in->tg_off, in->tg_off + D + 1);
+  c->pool_ver_off.assign(in->ver_off, in->ver_off + D + 1);
+  c->pool_gv.resize(D);
+  for (size_t d = 0; d < D; d++) c->pool_gv[d] = in->distros[d].group_versions != 0;
+  c->pool_pri_wide = false;
+  for (size_t r = 0; r < N && !c->pool_pri_wide; r++) c->pool_pri_wide = t.priority[r] != (int64_t)(int32_t)t.priority[r];
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->pool_in = di;
   c->pool_loaded = true;
@@ -1544,7 +1560,10 @@ int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update*
   for (int i = 0; i < nr; i++) {
     if (ru->rows[i] < 0 || ru->rows[i] >= p.tasks.n_tasks) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: row %d is outside the pool", ru->rows[i]);
     // a priority beyond int32 takes the distro off the one-workgroup path: the promise made at load time no longer holds
-    if (ru->priority && ru->priority[i] != (int64_t)(int32_t)ru->priority[i]) c->pool_in.promises &= ~EVG_PROMISE_ALL_ON_LDS_PATH;  // (n_big_tier_distros is a hint: it may overstate)
+    if (ru->priority && ru->priority[i] != (int64_t)(int32_t)ru->priority[i]) {  // (n_big_tier_distros is a hint: it may overstate)
+      c->pool_in.promises &= ~(EVG_PROMISE_ALL_ON_LDS_PATH | EVG_PROMISE_ALL_ON_LDS_TIERS);
+      c->pool_pri_wide = true;
+    }
   }
   for (int i = 0; i < ne; i++)
     if (eu->edges[i] < 0 || eu->edges[i] >= p.tasks.n_edges) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: edge %d is outside the pool", eu->edges[i]);
@@ -1646,6 +1665,222 @@ int evg_pool_plan(evg_ctx* c, int64_t now_ns, const evg_plan_output* out) {
   s.down(out->unit_of_task, dout.unit_of_task, N);
   s.down(out->unit_breakdown, dout.unit_breakdown, Stot * EVG_BREAKDOWN_FIELDS);
   return s.finish();
+}
+
+// A tick's structural change applied to the resident pool on the device (evg_pool_delta.hip.h): see include/evg_sched.h.
+int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
+  using namespace evg;
+  if (!c || !dl) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = pending_status(c)) return rc;
+  if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: no pool is loaded on this context");
+  const evg_plan_input& p = c->pool_in;
+  const int D = p.n_distros, N = p.tasks.n_tasks, E = p.tasks.n_edges;
+  const int nr = dl->n_removed, na = dl->n_added;
+  if (nr < 0 || na < 0 || (nr > 0 && (!dl->removed_rows || !dl->removed_dep_state)) || (na > 0 && !dl->added_distro))
+    return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: null or negative");
+  const int nl = dl->n_relinked;
+  if (nl < 0 || (nl > 0 && (!dl->relinked_edges || !dl->relinked_to))) return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: null or negative");
+  if (nr == 0 && na == 0 && nl == 0 && !dl->tg_off && !dl->ver_off) return EVG_OK;
+  const evg_task_soa& ad = dl->added;
+  if (na > 0 && (ad.n_tasks != na || !ad.priority || !ad.expected_duration_ns || !ad.queue_ts_ns || !ad.scheduled_ts_ns || !ad.deps_met_ts_ns ||
+                 !ad.num_dependents || !ad.task_group_order || !ad.task_group_max_hosts || !ad.tg_key || !ad.version_key || !ad.flags || !ad.dep_off ||
+                 ad.dep_off[0] != 0 || ad.dep_off[na] != ad.n_edges || (ad.n_edges > 0 && (!ad.dep_idx || !ad.dep_info))))
+    return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: the added rows' columns are incomplete");
+  const int EA = na > 0 ? ad.n_edges : 0;
+  const std::vector<int32_t>& toff = c->pool_task_off;
+  // ---- the delta against the pool's layout: per-distro counts, the new offset tables, where every added row goes ----
+  const int32_t* n_tg = dl->tg_off ? dl->tg_off : c->pool_tg_off.data();
+  const int32_t* n_ver = dl->ver_off ? dl->ver_off : c->pool_ver_off.data();
+  std::vector<int32_t> tg_shift(D + 1), ver_shift(D + 1);
+  if (n_tg[0] != 0 || n_ver[0] != 0) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: key offsets start at 0");
+  for (int d = 0; d < D; d++) {  // a distro's key range may only grow, at its end: an existing key keeps its place in the range
+    if (n_tg[d + 1] - n_tg[d] < c->pool_tg_off[d + 1] - c->pool_tg_off[d] || n_ver[d + 1] - n_ver[d] < c->pool_ver_off[d + 1] - c->pool_ver_off[d])
+      return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: the key range of distro %d shrinks", d);
+    tg_shift[d] = n_tg[d] - c->pool_tg_off[d];
+    ver_shift[d] = n_ver[d] - c->pool_ver_off[d];
+  }
+  auto distro_of = [&](int r) { return (int)(std::upper_bound(toff.begin(), toff.end(), r) - toff.begin()) - 1; };
+  std::vector<int32_t> rem(D, 0), add(D, 0);
+  {
+    std::vector<int32_t> seen(dl->removed_rows, dl->removed_rows + nr);
+    std::sort(seen.begin(), seen.end());
+    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: a row is removed twice");
+    if (nr > 0 && (seen.front() < 0 || seen.back() >= N)) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: a removed row is outside the pool");
+    for (int i = 0; i < nr; i++) {
+      rem[distro_of(dl->removed_rows[i])]++;
+      if (dl->removed_dep_state[i] & ~(EVG_DEP_STATE_MASK | EVG_DEP_BLOCKED | EVG_DEP_MISSING))
+        return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: removed_dep_state[%d] holds bits outside EVG_DEP_STATE / BLOCKED / MISSING", i);
+    }
+  }
+  bool pri_wide = c->pool_pri_wide;
+  for (int i = 0; i < na; i++) {
+    const int d = dl->added_distro[i];
+    if (d < 0 || d >= D || (i > 0 && d < dl->added_distro[i - 1])) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added_distro must be non-decreasing in [0, D) (row %d)", i);
+    add[d]++;
+    const int g = ad.tg_key[i], v = ad.version_key[i];
+    if ((g != -1 && (g < n_tg[d] || g >= n_tg[d + 1])) || v < n_ver[d] || v >= n_ver[d + 1])
+      return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added row %d: a key outside the distro's (new) key range", i);
+    if (ad.dep_off[i + 1] < ad.dep_off[i]) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added dep_off not monotone at row %d", i);
+    for (int e = ad.dep_off[i]; e < ad.dep_off[i + 1]; e++) {
+      const int j = ad.dep_idx[e];
+      const bool ok = j == -1 || (j >= 0 && j < N && distro_of(j) == d) || (j <= -2 && -(j + 2) < na && dl->added_distro[-(j + 2)] == d);
+      if (!ok) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added edge %d: %d is neither -1, a current row of the same distro, nor -(k + 2) for an added row k of it", e, j);
+    }
+    pri_wide |= ad.priority[i] != (int64_t)(int32_t)ad.priority[i];
+  }
+  {
+    std::vector<int32_t> seen(dl->relinked_edges, dl->relinked_edges + nl);
+    std::sort(seen.begin(), seen.end());
+    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: an edge is relinked twice");
+    if (nl > 0 && (seen.front() < 0 || seen.back() >= E)) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: a relinked edge is outside the pool");
+    for (int i = 0; i < nl; i++)
+      if (dl->relinked_to[i] < 0 || dl->relinked_to[i] >= na) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: relinked_to[%d] is not an added row", i);
+  }
+  std::vector<int32_t> new_toff(D + 1, 0), add_before(D + 1, 0), added_dst(std::max(na, 1));
+  for (int d = 0; d < D; d++) {
+    new_toff[d + 1] = new_toff[d] + (toff[d + 1] - toff[d]) - rem[d] + add[d];
+    add_before[d + 1] = add_before[d] + add[d];
+    if (new_toff[d + 1] - new_toff[d] >= (1 << 24)) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: distro %d would have 2^24 tasks or more", d);
+  }
+  {
+    int i = 0;
+    for (int d = 0; d < D; d++) {
+      const int first = new_toff[d + 1] - add[d];  // behind the distro's kept rows
+      for (int k = 0; k < add[d]; k++, i++) added_dst[i] = first + k;
+    }
+  }
+  const int NN = new_toff[D];
+  const size_t EN_cap = (size_t)E + (size_t)EA;  // edges only go (with their rows) or come (with the added rows)
+  StreamDrain drain{c};
+  hipStream_t st = c->stream;
+  // ---- scratch (the staging slots are free between host-pointer calls: 32 of the 48 are used) + the delta's arrays up ----
+  int slot = 0;
+  int rc = EVG_OK;
+  auto dev = [&](size_t bytes) -> void* {
+    DevBuf& b = c->stage[slot++];
+    if (rc) return nullptr;
+    rc = ensure(c, b, std::max<size_t>(bytes, 16));
+    return rc ? nullptr : b.p;
+  };
+  auto up = [&](const void* h, size_t bytes) -> void* {
+    void* d = dev(bytes);
+    if (!rc && h && bytes && hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = set_err(c, EVG_E_HIP, "H2D copy failed");
+    return h && bytes ? d : nullptr;
+  };
+  const int nb_old = (N + kScanTile - 1) / kScanTile, nb_new = (NN + kScanTile - 1) / kScanTile;
+  int32_t* d_rmi = (int32_t*)dev(4 * ((size_t)N + 1));
+  int32_t* d_kept = (int32_t*)dev(4 * ((size_t)N + 1));
+  int32_t* d_newrow = (int32_t*)dev(4 * ((size_t)N + 1));
+  int32_t* d_src = (int32_t*)dev(4 * ((size_t)NN + 1));
+  int32_t* d_bsum = (int32_t*)dev(4 * ((size_t)std::max(nb_old, nb_new) + 2));
+  int32_t* d_removed = (int32_t*)up(dl->removed_rows, 4 * (size_t)nr);
+  uint8_t* d_rm_state = (uint8_t*)up(dl->removed_dep_state, (size_t)nr);
+  int64_t* d_rm_fin = (int64_t*)up(dl->removed_finished_ts_ns, 8 * (size_t)nr);
+  int32_t* d_added_dst = (int32_t*)up(added_dst.data(), 4 * (size_t)na);
+  int32_t* d_add_before = (int32_t*)up(add_before.data(), 4 * (size_t)(D + 1));
+  int32_t* d_tg_shift = (int32_t*)up(tg_shift.data(), 4 * (size_t)(D + 1));
+  int32_t* d_ver_shift = (int32_t*)up(ver_shift.data(), 4 * (size_t)(D + 1));
+  int32_t* d_new_toff_idx = (int32_t*)up(new_toff.data(), 4 * (size_t)(D + 1));
+  int32_t* d_ecut = (int32_t*)dev(4 * (size_t)(D + 1));
+  int32_t* d_rl_edges = (int32_t*)up(dl->relinked_edges, 4 * (size_t)nl);
+  int32_t* d_rl_to = (int32_t*)up(dl->relinked_to, 4 * (size_t)nl);
+  int32_t* d_relink = nl > 0 ? (int32_t*)dev(4 * ((size_t)E + 1)) : nullptr;
+  TaskCols a_cols{(int64_t*)up(ad.priority, 8 * (size_t)na), (int64_t*)up(ad.expected_duration_ns, 8 * (size_t)na), (int64_t*)up(ad.queue_ts_ns, 8 * (size_t)na),
+                  (int64_t*)up(ad.scheduled_ts_ns, 8 * (size_t)na), (int64_t*)up(ad.deps_met_ts_ns, 8 * (size_t)na), (int32_t*)up(ad.num_dependents, 4 * (size_t)na),
+                  (int32_t*)up(ad.task_group_order, 4 * (size_t)na), (int32_t*)up(ad.task_group_max_hosts, 4 * (size_t)na), (int32_t*)up(ad.tg_key, 4 * (size_t)na),
+                  (int32_t*)up(ad.version_key, 4 * (size_t)na), (uint16_t*)up(ad.flags, 2 * (size_t)na)};
+  int32_t* d_add_dep_off = (int32_t*)up(na > 0 ? ad.dep_off : nullptr, 4 * ((size_t)na + 1));
+  EdgeCols a_edges{(int32_t*)up(ad.dep_idx, 4 * (size_t)EA), (uint8_t*)up(ad.dep_info, (size_t)EA), (int64_t*)up(ad.dep_finished_ts_ns, 8 * (size_t)EA)};
+  if (rc) return rc;
+  // ---- the second set of pool buffers ----
+  std::vector<DevBuf>& nw = c->pool_alt;
+  const size_t n1 = (size_t)NN + 1;
+  const size_t colsz[11] = {8, 8, 8, 8, 8, 4, 4, 4, 4, 4, 2};
+  for (int k = 0; k < 11 && !rc; k++) rc = ensure(c, nw[k], colsz[k] * n1);
+  if (!rc) rc = ensure(c, nw[11], 4 * (n1 + 1));
+  if (!rc) rc = ensure(c, nw[12], 4 * (EN_cap + 1));
+  if (!rc) rc = ensure(c, nw[13], EN_cap + 1);
+  if (!rc) rc = ensure(c, nw[14], 8 * (EN_cap + 1));
+  for (int k = 16; k < 19 && !rc; k++) rc = ensure(c, nw[k], 4 * ((size_t)D + 1));
+  if (rc) return rc;
+  TaskCols n_cols{(int64_t*)nw[0].p, (int64_t*)nw[1].p, (int64_t*)nw[2].p, (int64_t*)nw[3].p, (int64_t*)nw[4].p, (int32_t*)nw[5].p, (int32_t*)nw[6].p,
+                  (int32_t*)nw[7].p, (int32_t*)nw[8].p, (int32_t*)nw[9].p, (uint16_t*)nw[10].p};
+  const evg_task_soa& t = p.tasks;
+  TaskCols o_cols{(int64_t*)t.priority, (int64_t*)t.expected_duration_ns, (int64_t*)t.queue_ts_ns, (int64_t*)t.scheduled_ts_ns, (int64_t*)t.deps_met_ts_ns,
+                  (int32_t*)t.num_dependents, (int32_t*)t.task_group_order, (int32_t*)t.task_group_max_hosts, (int32_t*)t.tg_key, (int32_t*)t.version_key,
+                  (uint16_t*)t.flags};
+  int32_t* n_dep_off = (int32_t*)nw[11].p;
+  EdgeCols n_edges{(int32_t*)nw[12].p, (uint8_t*)nw[13].p, (int64_t*)nw[14].p}, o_edges{(int32_t*)t.dep_idx, (uint8_t*)t.dep_info, (int64_t*)t.dep_finished_ts_ns};
+  auto grid = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  // ---- kept rows, their new numbers ----
+  if (N > 0) {
+    HIP_TRY(c, hipMemsetAsync(d_rmi, 0xFF, 4 * (size_t)N, st));
+    if (nr > 0) hipLaunchKernelGGL(k_delta_mark, grid(nr), dim3(256), 0, st, nr, d_removed, d_rmi);
+    hipLaunchKernelGGL(k_scan_block_sums<true>, dim3(nb_old), dim3(kScanBlock), 0, st, d_rmi, N, d_bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb_old);
+    hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb_old), dim3(kScanBlock), 0, st, d_rmi, N, d_bsum, nb_old, d_kept);
+    hipLaunchKernelGGL(k_delta_place, grid(N), dim3(256), 0, st, N, D, d_rmi, d_kept, p.task_off, d_add_before, d_newrow, d_src);
+  }
+  if (na > 0) hipLaunchKernelGGL(k_delta_src_added, grid(na), dim3(256), 0, st, na, d_added_dst, d_src);
+  if (nl > 0) {
+    HIP_TRY(c, hipMemsetAsync(d_relink, 0xFF, 4 * (size_t)E, st));
+    hipLaunchKernelGGL(k_delta_relink, grid(nl), dim3(256), 0, st, nl, d_rl_edges, d_rl_to, d_relink);
+  }
+  if (NN > 0) {
+    hipLaunchKernelGGL(k_delta_rows, grid(NN), dim3(256), 0, st, NN, D, d_src, n_cols, o_cols, a_cols, t.dep_off, d_add_dep_off, d_new_toff_idx, d_tg_shift,
+                       d_ver_shift, n_dep_off);
+    hipLaunchKernelGGL(k_scan_block_sums<false>, dim3(nb_new), dim3(kScanBlock), 0, st, n_dep_off, NN, d_bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb_new);
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb_new), dim3(kScanBlock), 0, st, n_dep_off, NN, d_bsum, nb_new, n_dep_off);
+    hipLaunchKernelGGL(k_delta_edges, grid(NN), dim3(256), 0, st, NN, d_src, n_dep_off, n_edges, o_edges, a_edges, t.dep_off, d_add_dep_off, d_newrow, d_rmi,
+                       d_rm_state, d_rm_fin, d_added_dst, d_relink);
+    hipLaunchKernelGGL(k_gather_i32, grid(D + 1), dim3(256), 0, st, D + 1, d_new_toff_idx, n_dep_off, d_ecut);
+  } else {
+    HIP_TRY(c, hipMemsetAsync(n_dep_off, 0, 8, st));
+    HIP_TRY(c, hipMemsetAsync(d_ecut, 0, 4 * (size_t)(D + 1), st));
+  }
+  HIP_TRY(c, hipGetLastError());
+  // the small tables of the new pool; the edge offset at every distro boundary comes back for the launch hints
+  HIP_TRY(c, hipMemcpyAsync(nw[16].p, new_toff.data(), 4 * (size_t)(D + 1), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(nw[17].p, n_tg, 4 * (size_t)(D + 1), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(nw[18].p, n_ver, 4 * (size_t)(D + 1), hipMemcpyHostToDevice, st));
+  std::vector<int32_t> ecut(D + 1, 0);
+  HIP_TRY(c, hipMemcpyAsync(ecut.data(), d_ecut, 4 * (size_t)(D + 1), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  // ---- swap: the new buffers ARE the pool (the distro settings are not re-packed: their buffer moves over) ----
+  std::swap(nw[15], c->pool[15]);
+  std::swap(c->pool, c->pool_alt);
+  evg_plan_input& q = c->pool_in;
+  const std::vector<DevBuf>& pb = c->pool;
+  q.tasks.n_tasks = NN; q.tasks.n_edges = ecut[D];
+  q.tasks.priority = (const int64_t*)pb[0].p; q.tasks.expected_duration_ns = (const int64_t*)pb[1].p; q.tasks.queue_ts_ns = (const int64_t*)pb[2].p;
+  q.tasks.scheduled_ts_ns = (const int64_t*)pb[3].p; q.tasks.deps_met_ts_ns = (const int64_t*)pb[4].p; q.tasks.num_dependents = (const int32_t*)pb[5].p;
+  q.tasks.task_group_order = (const int32_t*)pb[6].p; q.tasks.task_group_max_hosts = (const int32_t*)pb[7].p; q.tasks.tg_key = (const int32_t*)pb[8].p;
+  q.tasks.version_key = (const int32_t*)pb[9].p; q.tasks.flags = (const uint16_t*)pb[10].p; q.tasks.dep_off = (const int32_t*)pb[11].p;
+  q.tasks.dep_idx = (const int32_t*)pb[12].p; q.tasks.dep_info = (const uint8_t*)pb[13].p; q.tasks.dep_finished_ts_ns = (const int64_t*)pb[14].p;
+  q.distros = (const evg_distro_params*)pb[15].p; q.task_off = (const int32_t*)pb[16].p; q.tg_off = (const int32_t*)pb[17].p; q.ver_off = (const int32_t*)pb[18].p;
+  q.n_task_groups = n_tg[D]; q.n_versions = n_ver[D];
+  // Careful: n_tg / n_ver may point into the vectors assigned next
+  std::vector<int32_t> tgv(n_tg, n_tg + D + 1), verv(n_ver, n_ver + D + 1);
+  c->pool_task_off = new_toff; c->pool_tg_off = tgv; c->pool_ver_off = verv;
+  c->pool_pri_wide = pri_wide;
+  // ---- the launch hints of the new pool, from its shape (evg_plan_launch_hints's test without the columns) ----
+  q.max_distro_tasks = 0; q.promises = 0; q.n_big_tier_distros = 0;
+  bool all11 = !pri_wide, all_tiers = !pri_wide;
+  for (int d = 0; d < D; d++) {
+    const int n = new_toff[d + 1] - new_toff[d], ntg = tgv[d + 1] - tgv[d], nver = verv[d + 1] - verv[d];
+    q.max_distro_tasks = std::max(q.max_distro_tasks, n);
+    const int S = c->pool_gv[d] ? ntg + nver : n + ntg;
+    const int tier = lds_tier_of_shape(n, S, ntg, ecut[d + 1] - ecut[d]);
+    if (tier != 11) all11 = false;
+    if (tier == 0) all_tiers = false;
+    if (tier == 12 && !pri_wide) q.n_big_tier_distros++;
+  }
+  if (all11) q.promises |= EVG_PROMISE_ALL_ON_LDS_PATH;
+  if (all_tiers) q.promises |= EVG_PROMISE_ALL_ON_LDS_TIERS;
+  return EVG_OK;
 }
 
 int evg_filter_runnable(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,

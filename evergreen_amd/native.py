@@ -24,7 +24,7 @@ EXPORTS = [
     "evg_schedule_distros", "evg_filter_runnable", "evg_allocator_report", "evg_rebuild_dispatchers",
     "evg_plan_distro_range_device", "evg_allocate_host_range_device", "evg_selftest_unit_value",
     "evg_host_alloc", "evg_host_free", "evg_profile_plan_kernel", "evg_last_plan_kernel_ms", "evg_plan_launch_hints",
-    "evg_check_abi", "evg_take_device_status", "evg_pool_load", "evg_pool_update", "evg_pool_plan",
+    "evg_check_abi", "evg_take_device_status", "evg_pool_load", "evg_pool_update", "evg_pool_plan", "evg_pool_apply_delta",
     "evg_multi_create", "evg_multi_destroy", "evg_multi_last_error", "evg_multi_load", "evg_multi_tick", "evg_multi_results",
     "evg_multi_ranges", "evg_multi_profile", "evg_multi_last_tick_ms", "evg_multi_poison_outputs", "evg_balanced_ranges",
 ]
@@ -95,6 +95,8 @@ def load_library() -> C.CDLL:
         lib.evg_pool_load.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput)]
         lib.evg_pool_update.argtypes = [C.c_void_p, C.POINTER(abi.RowUpdate), C.POINTER(abi.EdgeUpdate)]
         lib.evg_pool_plan.argtypes = [C.c_void_p, C.c_int64, C.POINTER(abi.PlanOutput)]
+        if hasattr(lib, "evg_pool_apply_delta"):
+            lib.evg_pool_apply_delta.argtypes = [C.c_void_p, C.POINTER(abi.PoolDelta)]
         # what a binding does once at start-up: refuse a library whose structs are not the ones it was written against
         rc = lib.evg_check_abi(abi.EVG_ABI_MAJOR, abi.EVG_ABI_MINOR, C.sizeof(abi.PlanInput), C.sizeof(abi.PlanOutput), C.sizeof(abi.AllocInput),
                                abi.GROUP_INFO_DTYPE.itemsize)
@@ -353,6 +355,42 @@ class Context:
                 eu.dep_finished_ts_ns = a.ctypes.data
         self._check(self.lib.evg_pool_update(self.h, C.byref(ru) if ru is not None else None, C.byref(eu) if eu is not None else None),
                     "evg_pool_update")
+
+    def pool_apply_delta(self, removed_rows=None, removed_dep_state=None, removed_finished_ts_ns=None, added_distro=None, added_cols=None,
+                         added_dep_off=None, added_edges=None, tg_off=None, ver_off=None, relinked_edges=None, relinked_to=None) -> None:
+        """evg_pool_apply_delta: see include/evg_sched.h. added_cols: {column: values} of TASK_COLUMNS for the added rows, added_edges:
+        {dep_idx, dep_info, dep_finished_ts_ns} over added_dep_off (dep_idx: -1, a current row, or -(k + 2) for added row k)."""
+        d, keep = abi.PoolDelta(), []
+
+        def arr(a, dt):
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return a.ctypes.data if a.size else None
+        nr = 0 if removed_rows is None else len(removed_rows)
+        na = 0 if added_distro is None else len(added_distro)
+        d.n_removed, d.n_added = nr, na
+        if nr:
+            d.removed_rows, d.removed_dep_state = arr(removed_rows, np.int32), arr(removed_dep_state, np.uint8)
+            if removed_finished_ts_ns is not None:
+                d.removed_finished_ts_ns = arr(removed_finished_ts_ns, np.int64)
+        if na:
+            d.added_distro = arr(added_distro, np.int32)
+            t = d.added
+            off = np.ascontiguousarray(added_dep_off, np.int32)
+            keep.append(off)
+            t.n_tasks, t.n_edges, t.dep_off = na, int(off[-1]), off.ctypes.data
+            for k, dt in abi.TASK_COLUMNS.items():
+                setattr(t, k, arr(added_cols[k], dt))
+            for k, dt in abi.EDGE_COLUMNS.items():
+                if added_edges is not None and added_edges.get(k) is not None:
+                    setattr(t, k, arr(added_edges[k], dt))
+        if tg_off is not None:
+            d.tg_off = arr(tg_off, np.int32)
+        if ver_off is not None:
+            d.ver_off = arr(ver_off, np.int32)
+        if relinked_edges is not None and len(relinked_edges):
+            d.n_relinked, d.relinked_edges, d.relinked_to = len(relinked_edges), arr(relinked_edges, np.int32), arr(relinked_to, np.int32)
+        self._check(self.lib.evg_pool_apply_delta(self.h, C.byref(d)), "evg_pool_apply_delta")
 
     def pool_plan(self, batch: abi.PlanBatch, now_ns: int, breakdown: bool = False, n_units: bool = False, units: bool = False,
                   into: Optional[abi.PlanResult] = None) -> abi.PlanResult:

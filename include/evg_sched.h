@@ -526,8 +526,8 @@ int evg_schedule_distros(evg_ctx* ctx, const evg_plan_input* in, const evg_plan_
  * context); evg_pool_update overwrites the listed rows' per-task VALUE columns and the listed dependency edges' state, so a
  * tick that changes 5 % of the pool moves 5 % of the bytes; evg_pool_plan plans the resident pool for a new `now_ns` and
  * downloads the outputs (exactly evg_plan_distros's, bit for bit, on the updated batch). The pool's STRUCTURE -- the row set,
- * the distro / key / CSR layout -- is what evg_pool_load saw: a tick that adds or removes tasks loads again. Host pointers;
- * synchronous; nothing of the caller's is retained. */
+ * the distro / key / CSR layout -- changes with evg_pool_apply_delta (below). Host pointers; synchronous; nothing of the caller's
+ * is retained. */
 typedef struct evg_row_update {
   int32_t n_rows;
   int32_t reserved;
@@ -548,7 +548,47 @@ typedef struct evg_edge_update {
   const uint8_t* dep_info;              /* EVG_DEP_* of the edge (a dependency outside the queue finished, became blocked ...), or NULL */
   const int64_t* dep_finished_ts_ns;    /* Dependency.FinishedAt, or NULL */
 } evg_edge_update;
+/* A tick's STRUCTURAL change (ABI 3.1). Every real 15 s tick removes the tasks that were dispatched, finished or deactivated and
+ * adds the newly activated ones (units/crons_remote_fifteen_second.go:21,58-60); with evg_pool_update alone such a tick had to load
+ * the whole pool again. evg_pool_apply_delta re-packs the resident pool ON THE DEVICE from the delta alone (kernels in
+ * csrc/evg_pool_delta.hip.h; a few per cent of the pool's bytes cross the link): removed rows go, the kept rows of a distro keep their
+ * relative order, the added rows of a distro follow them in the order given. The result is bit for bit the batch a caller would
+ * have uploaded for the same rows in that order with the same keys -- evg_pool_plan plans it like any other.
+ *   removed_rows            CURRENT row numbers, distinct
+ *   removed_dep_state       per removed row: what the task now looks like to a dependent -- EVG_DEP_STATE_* | EVG_DEP_BLOCKED |
+ *                           EVG_DEP_MISSING, what fetchedDepStates (shim/gpu_planner.go) reports for a dependency that is not in
+ *                           the queue. Every edge that pointed at the row becomes an out-of-queue edge (dep_idx -1) with these
+ *                           bits next to ITS OWN required-status bits, and removed_finished_ts_ns (or 0) as Dependency.FinishedAt
+ *   added_distro, added     n_added rows: the distro of each (non-decreasing) and its columns; added.dep_off is the CSR over the
+ *                           added rows; added.dep_idx: -1 = not in the queue (state in dep_info), j >= 0 = CURRENT row j of the
+ *                           same distro (if j is being removed in this delta the edge takes j's removed state), -(k + 2) = added
+ *                           row k of the same distro
+ *   tg_off, ver_off         the NEW key ranges (D + 1 each), or NULL = unchanged: a distro's range may only GROW, at its end
+ *                           (new keys for new groups / versions; an existing key k of distro d becomes k + tg_off[d] - old
+ *                           tg_off[d]); the added rows' keys are in the new numbering. Keys whose last task left stay, unused
+ *                           (the note on keys at the top: present == 0 rows); a full evg_pool_load compacts them away
+ *   relinked_edges,         a KEPT row's edge (CURRENT edge number, distinct) whose dependency was not in the queue and now enters it:
+ *   relinked_to             the edge points at added row relinked_to[i] (same distro) from now on, an in-queue edge with its own
+ *                           required-status bits and nothing else (planner.go:451-455: the dependent joins that task's unit)
+ * The caller keeps its own id -> row map current the same way: row numbers after the call = kept rows in order, then added rows,
+ * distro by distro. Host pointers; synchronous; nothing of the caller's is retained. */
+typedef struct evg_pool_delta {
+  int32_t n_removed;
+  int32_t n_added;
+  const int32_t* removed_rows;
+  const uint8_t* removed_dep_state;
+  const int64_t* removed_finished_ts_ns; /* or NULL: all zero */
+  const int32_t* added_distro;
+  evg_task_soa added;                    /* n_tasks == n_added */
+  const int32_t* tg_off;                 /* D + 1 or NULL */
+  const int32_t* ver_off;                /* D + 1 or NULL */
+  int32_t n_relinked;
+  int32_t reserved;
+  const int32_t* relinked_edges;
+  const int32_t* relinked_to;
+} evg_pool_delta;
 int evg_pool_load(evg_ctx* ctx, const evg_plan_input* in);
+int evg_pool_apply_delta(evg_ctx* ctx, const evg_pool_delta* delta);
 int evg_pool_update(evg_ctx* ctx, const evg_row_update* rows, const evg_edge_update* edges); /* either may be NULL */
 int evg_pool_plan(evg_ctx* ctx, int64_t now_ns, const evg_plan_output* out);
 

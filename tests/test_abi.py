@@ -43,7 +43,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     structs = {"evg_task_soa": abi.TaskSoa, "evg_plan_input": abi.PlanInput, "evg_plan_output": abi.PlanOutput,
                "evg_host_soa": abi.HostSoa, "evg_alloc_input": abi.AllocInput, "evg_alloc_output": abi.AllocOutput,
                "evg_queue_items": abi.QueueItems, "evg_dispatch_order": abi.DispatchOrder, "evg_row_update": abi.RowUpdate,
-               "evg_edge_update": abi.EdgeUpdate}
+               "evg_edge_update": abi.EdgeUpdate, "evg_pool_delta": abi.PoolDelta}
     dtypes = {"evg_distro_params": abi.DISTRO_PARAMS_DTYPE, "evg_group_info": abi.GROUP_INFO_DTYPE,
               "evg_distro_info": abi.DISTRO_INFO_DTYPE, "evg_alloc_params": abi.ALLOC_PARAMS_DTYPE,
               "evg_report_params": abi.REPORT_PARAMS_DTYPE, "evg_alloc_report": abi.ALLOC_REPORT_DTYPE}

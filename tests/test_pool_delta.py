@@ -1,0 +1,115 @@
+"""evg_pool_apply_delta: a tick that removes and adds tasks, re-packed on the device from the delta alone (ABI 3.1).
+
+CPU: the host restatement of the re-pack (tests/pool_delta.py) is itself checked -- pool0 + delta must be `full` minus the removed
+rows, reordered (kept rows, then the late ones, per distro): the oracle plans both to the same queue, task for task.
+GPU: evg_pool_load(pool0) -> evg_pool_apply_delta(delta) -> evg_pool_plan == a full upload of apply_delta(pool0, delta) == the
+oracle; then value updates and a SECOND structural delta on top (the buffers swap back), and the error exits."""
+import numpy as np
+import pytest
+
+from evergreen_amd import abi, gen
+from tests import compare, pool_delta
+
+
+def _tick(cfg, seed=7, late=0.025, gone=0.025, grow=True):
+    full = gen.generate(cfg)
+    pool0, delta, late_rows, gone_rows = pool_delta.split_tick(full, late, gone, seed=seed, grow_keys=grow)
+    return full, pool0, delta, late_rows, gone_rows
+
+
+@pytest.mark.parametrize("cfg", [gen.config(1), gen.GenConfig(20_000, 9, gen.SEED_BASE + 61, tg_fraction=0.3)], ids=["config1", "groups"])
+def test_restated_delta_is_a_reordering_of_the_full_pool(oracle, cfg):
+    full, pool0, delta, late_rows, gone_rows = _tick(cfg, grow=False)
+    pool1 = pool_delta.apply_delta(pool0, delta)
+    pool1.check()
+    assert pool1.n_tasks == full.n_tasks - len(gone_rows)
+    # the same rows as `full` minus the gone ones: map pool1's rows back to full's
+    N, D = full.n_tasks, full.n_distros
+    distro_of = np.searchsorted(full.task_off, np.arange(N), side="right") - 1
+    is_late = np.zeros(N, bool); is_late[late_rows] = True
+    is_gone = np.zeros(N, bool); is_gone[gone_rows] = True
+    back = np.concatenate([np.concatenate([np.nonzero((distro_of == d) & ~is_late & ~is_gone)[0], np.nonzero((distro_of == d) & is_late)[0]]) for d in range(D)])
+    for k in ("priority", "expected_duration_ns", "flags", "tg_key", "version_key"):
+        assert np.array_equal(pool1.cols[k], full.cols[k][back]), k
+    # and the plans agree task for task: queue position p of pool1 holds the task that `full` minus gone has there, wherever the
+    # tie-breaks do not depend on the row numbers (the canonical order breaks ties by row: compare the stamped values instead)
+    want = oracle.plan(pool1, breakdown=True, n_units=False)
+    compare.reference_validity(pool1, want)
+    for d in range(D):  # in-queue edges of kept rows to late rows were relinked: the dependents are in the late tasks' units again
+        lo, hi = int(pool1.task_off[d]), int(pool1.task_off[d + 1])
+        assert sorted(want.order[lo:hi]) == list(range(lo, hi))
+    e_in_full = int(((full.edges["dep_idx"] >= 0) & ~is_gone[np.maximum(full.edges["dep_idx"], 0)] & ~is_gone[np.repeat(np.arange(N), np.diff(full.dep_off))]).sum())
+    assert int((pool1.edges["dep_idx"] >= 0).sum()) == e_in_full, "every in-queue edge of `full` between surviving tasks is in-queue again"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [gen.config(2), gen.GenConfig(60_000, 24, gen.SEED_BASE + 31, skew=True), gen.config(5, n_tasks=150_000, n_distros=12),
+                                 gen.GenConfig(3_000, 40, 321)], ids=["config2", "skewed", "config5-shape", "small"])
+def test_device_repack_plans_like_a_full_upload(native_ctx, oracle, cfg):
+    full, pool0, delta, _, _ = _tick(cfg)
+    native_ctx.pool_load(pool0)
+    native_ctx.pool_apply_delta(**delta.kwargs())
+    pool1 = pool_delta.apply_delta(pool0, delta)
+    got = native_ctx.pool_plan(pool1, pool1.now_ns, breakdown=True, n_units=True)
+    want = oracle.plan(pool1, breakdown=True, n_units=True)
+    compare.assert_plan_equal(got, want, pool1, "pool after a structural delta")
+    up = native_ctx.plan(pool1, breakdown=True, n_units=True)  # the full upload of the same batch
+    compare.assert_plan_equal(got, up, pool1, "resident vs full upload")
+    # value updates on top of the new numbering, then a second delta (the buffers swap back)
+    rng = np.random.default_rng(3)
+    rows = rng.choice(pool1.n_tasks, size=max(pool1.n_tasks // 20, 1), replace=False).astype(np.int32)
+    newpri = rng.integers(0, 100, len(rows)).astype(np.int64)
+    native_ctx.pool_update(rows=rows, cols={"priority": newpri})
+    pool1.cols["priority"][rows] = newpri
+    # second tick: remove 2 % more, add nothing; then add rows back from a fresh split of pool1 itself
+    p2_0, d2, _, _ = pool_delta.split_tick(pool1, 0.0, 0.02, seed=11, grow_keys=False)
+    assert p2_0.n_tasks == pool1.n_tasks
+    native_ctx.pool_apply_delta(**d2.kwargs())
+    pool2 = pool_delta.apply_delta(pool1, d2)
+    got2 = native_ctx.pool_plan(pool2, pool2.now_ns + 15_000_000_000, breakdown=True, n_units=False)
+    import dataclasses
+    want2 = oracle.plan(dataclasses.replace(pool2, now_ns=pool2.now_ns + 15_000_000_000), breakdown=True, n_units=False)
+    compare.assert_plan_equal(got2, want2, pool2, "second delta")
+
+
+@pytest.mark.gpu
+def test_delta_can_empty_and_refill_distros(native_ctx, oracle):
+    full = gen.generate(gen.GenConfig(4_000, 10, 99))
+    # everything of distros 2 and 5 arrives late; everything of distro 7 leaves
+    N = full.n_tasks
+    distro_of = np.searchsorted(full.task_off, np.arange(N), side="right") - 1
+    u = np.where(np.isin(distro_of, (2, 5)), 0.0, np.where(distro_of == 7, 0.5, 0.99))
+    pool0, delta, late_rows, gone_rows = pool_delta.split_tick(full, 0.25, 0.5, seed=1, u=u)
+    assert pool0.task_off[3] == pool0.task_off[2] and len(gone_rows) == int((distro_of == 7).sum())
+    native_ctx.pool_load(pool0)
+    native_ctx.pool_apply_delta(**delta.kwargs())
+    pool1 = pool_delta.apply_delta(pool0, delta)
+    assert pool1.task_off[8] == pool1.task_off[7]
+    got = native_ctx.pool_plan(pool1, pool1.now_ns, breakdown=True, n_units=True)
+    compare.assert_plan_equal(got, oracle.plan(pool1, breakdown=True, n_units=True), pool1, "emptied and refilled distros")
+
+
+@pytest.mark.gpu
+def test_delta_contract_violations_are_refused(native_ctx):
+    from evergreen_amd import native
+    full, pool0, delta, _, _ = _tick(gen.config(1))
+    native_ctx.pool_load(pool0)
+    bad = dict(delta.kwargs())
+    bad["removed_rows"] = np.concatenate([delta.removed_rows, delta.removed_rows[:1]])
+    bad["removed_dep_state"] = np.concatenate([delta.removed_dep_state, delta.removed_dep_state[:1]])
+    bad["removed_finished_ts_ns"] = None
+    with pytest.raises(native.NativeError, match="twice"):
+        native_ctx.pool_apply_delta(**bad)
+    bad = dict(delta.kwargs())
+    bad["added_distro"] = delta.added_distro[::-1].copy()
+    with pytest.raises(native.NativeError):
+        native_ctx.pool_apply_delta(**bad)
+    bad = dict(delta.kwargs())
+    shr = delta.tg_off.copy(); shr[1:] -= 1
+    bad["tg_off"] = shr
+    with pytest.raises(native.NativeError, match="shrinks|key"):
+        native_ctx.pool_apply_delta(**bad)
+    # the pool is untouched by the refused calls
+    got = native_ctx.pool_plan(pool0, pool0.now_ns, breakdown=False, n_units=False)
+    up = native_ctx.plan(pool0, breakdown=False, n_units=False)
+    assert np.array_equal(got.order, up.order)

@@ -61,9 +61,11 @@ def test_hip_plan_with_sparse_unordered_keys(native_ctx, oracle, cfg):
     got = native_ctx.plan(sb, breakdown=True, n_units=True)
     compare.assert_plan_equal(got, want, sb, "sparse keys")
     compare.reference_validity(sb, got)
+    # the same queue as with the dense keys (before the allocator writes count_free / count_required into the rows)
+    base = native_ctx.plan(b, breakdown=True, n_units=True)
+    _same_plan(b, sb, base, got, "hip")
     wa = oracle.allocate(sb, want.distro_info, want.group_info)
     ga = native_ctx.allocate(sb, got.distro_info, got.group_info)
     compare.assert_alloc_equal(ga, wa, "sparse keys")
-    # and the same queue as with the dense keys
-    base = native_ctx.plan(b, breakdown=True, n_units=True)
-    _same_plan(b, sb, base, got, "hip")
+    ba = native_ctx.allocate(b, base.distro_info, base.group_info)
+    compare.assert_alloc_equal(ga, ba, "sparse vs dense keys")
