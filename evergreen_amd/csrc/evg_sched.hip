@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -437,6 +438,7 @@ struct evg_ctx {
   std::vector<int32_t> pool_task_off, pool_tg_off, pool_ver_off;
   std::vector<uint8_t> pool_gv;   // PlannerSettings.ShouldGroupVersions() per distro (the shape test of the launch hints)
   bool pool_pri_wide = false;     // some priority does not fit int32: no distro-shape promise holds
+  std::vector<uint64_t> seen_bits;  // evg_pool_update's duplicate check: one bit per row / edge
   int tiled_mode = 0;  // EVG_TILED_MODE: TM_* bits (evg_tiled.hip.h), A/B runs of the large-distro pipeline's per-row / pairwise forms
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts = nullptr;
@@ -1571,15 +1573,20 @@ int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update*
     return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_finished_ts_ns");
   if (ne > 0 && eu->dep_info && !p.tasks.dep_info)  // (k_update_edges would write through a null device pointer)
     return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_info");
-  {  // `distinct`: a row / edge listed twice would take whichever of its two values the device wrote last
-    std::vector<int32_t> seen;
-    auto dup = [&](const int32_t* v, int n) {
-      seen.assign(v, v + n);
-      std::sort(seen.begin(), seen.end());
-      return std::adjacent_find(seen.begin(), seen.end()) != seen.end();
+  {  // `distinct`: a row / edge listed twice would take whichever of its two values the device wrote last. One bit per row / edge
+     // of the pool (125 KB for a million rows; sorting the 50,000 rows of a 5 % update cost 0.2 ms of the tick's 0.7)
+    auto dup = [&](const int32_t* v, int n, int range) {
+      c->seen_bits.assign((size_t)range / 64 + 1, 0ull);
+      for (int i = 0; i < n; i++) {
+        uint64_t& w = c->seen_bits[(size_t)v[i] >> 6];
+        const uint64_t bit = 1ull << (v[i] & 63);
+        if (w & bit) return true;
+        w |= bit;
+      }
+      return false;
     };
-    if (nr > 1 && dup(ru->rows, nr)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: a row is listed twice");
-    if (ne > 1 && dup(eu->edges, ne)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: an edge is listed twice");
+    if (nr > 1 && dup(ru->rows, nr, p.tasks.n_tasks)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: a row is listed twice");
+    if (ne > 1 && dup(eu->edges, ne, p.tasks.n_edges)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: an edge is listed twice");
   }
   if (nr == 0 && ne == 0) return EVG_OK;
   StreamDrain drain{c};
@@ -1689,6 +1696,16 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
                  ad.dep_off[0] != 0 || ad.dep_off[na] != ad.n_edges || (ad.n_edges > 0 && (!ad.dep_idx || !ad.dep_info))))
     return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: the added rows' columns are incomplete");
   const int EA = na > 0 ? ad.n_edges : 0;
+#ifdef EVG_DELTA_TIMING
+  auto tt0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[delta] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - tt0).count());
+    tt0 = t;
+  };
+#else
+  auto lap = [](const char*) {};
+#endif
   const std::vector<int32_t>& toff = c->pool_task_off;
   // ---- the delta against the pool's layout: per-distro counts, the new offset tables, where every added row goes ----
   const int32_t* n_tg = dl->tg_off ? dl->tg_off : c->pool_tg_off.data();
@@ -1701,19 +1718,37 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
     tg_shift[d] = n_tg[d] - c->pool_tg_off[d];
     ver_shift[d] = n_ver[d] - c->pool_ver_off[d];
   }
-  auto distro_of = [&](int r) { return (int)(std::upper_bound(toff.begin(), toff.end(), r) - toff.begin()) - 1; };
   std::vector<int32_t> rem(D, 0), add(D, 0);
-  {
-    std::vector<int32_t> seen(dl->removed_rows, dl->removed_rows + nr);
-    std::sort(seen.begin(), seen.end());
-    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: a row is removed twice");
-    if (nr > 0 && (seen.front() < 0 || seen.back() >= N)) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: a removed row is outside the pool");
-    for (int i = 0; i < nr; i++) {
-      rem[distro_of(dl->removed_rows[i])]++;
-      if (dl->removed_dep_state[i] & ~(EVG_DEP_STATE_MASK | EVG_DEP_BLOCKED | EVG_DEP_MISSING))
-        return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: removed_dep_state[%d] holds bits outside EVG_DEP_STATE / BLOCKED / MISSING", i);
+  // distinct + in range: one bit per row (sorting the 25,000 removed rows and relinked edges of a 5 % tick was 0.8 ms of the call)
+  auto mark_all = [&](const int32_t* v, int n, int range, const char* what) -> int {
+    c->seen_bits.assign((size_t)range / 64 + 1, 0ull);
+    for (int i = 0; i < n; i++) {
+      if (v[i] < 0 || v[i] >= range) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: %s %d is outside the pool", what, v[i]);
+      uint64_t& w = c->seen_bits[(size_t)v[i] >> 6];
+      const uint64_t bit = 1ull << (v[i] & 63);
+      if (w & bit) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: %s %d is listed twice", what, v[i]);
+      w |= bit;
     }
-  }
+    return EVG_OK;
+  };
+  if (int rcm = mark_all(dl->removed_rows, nr, N, "removed row")) return rcm;
+  // removed rows per distro = the bits of the distro's row range (a binary search per removed row was 0.4 ms of mispredicted branches)
+  if (nr > 0)
+    for (int d = 0; d < D; d++) {
+      const int lo = toff[d], hi = toff[d + 1];
+      if (hi <= lo) continue;
+      int cnt = 0;
+      for (int wd = lo >> 6; wd <= (hi - 1) >> 6; wd++) {
+        uint64_t w = c->seen_bits[wd];
+        if (wd == lo >> 6) w &= ~0ull << (lo & 63);
+        if (wd == (hi - 1) >> 6 && ((hi - 1) & 63) != 63) w &= (1ull << (((hi - 1) & 63) + 1)) - 1ull;
+        cnt += __builtin_popcountll(w);
+      }
+      rem[d] = cnt;
+    }
+  for (int i = 0; i < nr; i++)
+    if (dl->removed_dep_state[i] & ~(EVG_DEP_STATE_MASK | EVG_DEP_BLOCKED | EVG_DEP_MISSING))
+      return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: removed_dep_state[%d] holds bits outside EVG_DEP_STATE / BLOCKED / MISSING", i);
   bool pri_wide = c->pool_pri_wide;
   for (int i = 0; i < na; i++) {
     const int d = dl->added_distro[i];
@@ -1725,19 +1760,14 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
     if (ad.dep_off[i + 1] < ad.dep_off[i]) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added dep_off not monotone at row %d", i);
     for (int e = ad.dep_off[i]; e < ad.dep_off[i + 1]; e++) {
       const int j = ad.dep_idx[e];
-      const bool ok = j == -1 || (j >= 0 && j < N && distro_of(j) == d) || (j <= -2 && -(j + 2) < na && dl->added_distro[-(j + 2)] == d);
+      const bool ok = j == -1 || (j >= toff[d] && j < toff[d + 1]) || (j <= -2 && -(j + 2) < na && dl->added_distro[-(j + 2)] == d);
       if (!ok) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added edge %d: %d is neither -1, a current row of the same distro, nor -(k + 2) for an added row k of it", e, j);
     }
     pri_wide |= ad.priority[i] != (int64_t)(int32_t)ad.priority[i];
   }
-  {
-    std::vector<int32_t> seen(dl->relinked_edges, dl->relinked_edges + nl);
-    std::sort(seen.begin(), seen.end());
-    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: an edge is relinked twice");
-    if (nl > 0 && (seen.front() < 0 || seen.back() >= E)) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: a relinked edge is outside the pool");
-    for (int i = 0; i < nl; i++)
-      if (dl->relinked_to[i] < 0 || dl->relinked_to[i] >= na) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: relinked_to[%d] is not an added row", i);
-  }
+  if (int rcm = mark_all(dl->relinked_edges, nl, E, "relinked edge")) return rcm;
+  for (int i = 0; i < nl; i++)
+    if (dl->relinked_to[i] < 0 || dl->relinked_to[i] >= na) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: relinked_to[%d] is not an added row", i);
   std::vector<int32_t> new_toff(D + 1, 0), add_before(D + 1, 0), added_dst(std::max(na, 1));
   for (int d = 0; d < D; d++) {
     new_toff[d + 1] = new_toff[d] + (toff[d + 1] - toff[d]) - rem[d] + add[d];
@@ -1753,21 +1783,25 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   }
   const int NN = new_toff[D];
   const size_t EN_cap = (size_t)E + (size_t)EA;  // edges only go (with their rows) or come (with the added rows)
+  lap("validated, tables cut");
   StreamDrain drain{c};
   hipStream_t st = c->stream;
-  // ---- scratch (the staging slots are free between host-pointer calls: 32 of the 48 are used) + the delta's arrays up ----
-  int slot = 0;
+  // ---- the delta's arrays up: ONE page-locked block, ONE copy (a 5 % tick is ~4 MB in ~30 arrays: from pageable memory every
+  // array is a staged copy of its own and the call was 1.5 ms, most of it those); scratch in the staging slots behind ----
+  Stager sg{c};
+  {
+    const size_t in_bytes = (size_t)nr * (4 + 1 + 8) + (size_t)na * (4 + 5 * 8 + 5 * 4 + 2 + 4) + 4 + (size_t)EA * (4 + 1 + 8) + (size_t)nl * 8 +
+                            5 * 4 * ((size_t)D + 1) + 40 * 256;
+    if (in_bytes <= kPackLimit)
+      if (int rc0 = sg.begin_packed(in_bytes, 256)) return rc0;
+  }
   int rc = EVG_OK;
+  int slot = 32;  // the scratch arrays' staging slots (the Stager's unpacked path uses 0..31)
   auto dev = [&](size_t bytes) -> void* {
     DevBuf& b = c->stage[slot++];
     if (rc) return nullptr;
     rc = ensure(c, b, std::max<size_t>(bytes, 16));
     return rc ? nullptr : b.p;
-  };
-  auto up = [&](const void* h, size_t bytes) -> void* {
-    void* d = dev(bytes);
-    if (!rc && h && bytes && hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = set_err(c, EVG_E_HIP, "H2D copy failed");
-    return h && bytes ? d : nullptr;
   };
   const int nb_old = (N + kScanTile - 1) / kScanTile, nb_new = (NN + kScanTile - 1) / kScanTile;
   int32_t* d_rmi = (int32_t*)dev(4 * ((size_t)N + 1));
@@ -1775,25 +1809,28 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   int32_t* d_newrow = (int32_t*)dev(4 * ((size_t)N + 1));
   int32_t* d_src = (int32_t*)dev(4 * ((size_t)NN + 1));
   int32_t* d_bsum = (int32_t*)dev(4 * ((size_t)std::max(nb_old, nb_new) + 2));
-  int32_t* d_removed = (int32_t*)up(dl->removed_rows, 4 * (size_t)nr);
-  uint8_t* d_rm_state = (uint8_t*)up(dl->removed_dep_state, (size_t)nr);
-  int64_t* d_rm_fin = (int64_t*)up(dl->removed_finished_ts_ns, 8 * (size_t)nr);
-  int32_t* d_added_dst = (int32_t*)up(added_dst.data(), 4 * (size_t)na);
-  int32_t* d_add_before = (int32_t*)up(add_before.data(), 4 * (size_t)(D + 1));
-  int32_t* d_tg_shift = (int32_t*)up(tg_shift.data(), 4 * (size_t)(D + 1));
-  int32_t* d_ver_shift = (int32_t*)up(ver_shift.data(), 4 * (size_t)(D + 1));
-  int32_t* d_new_toff_idx = (int32_t*)up(new_toff.data(), 4 * (size_t)(D + 1));
   int32_t* d_ecut = (int32_t*)dev(4 * (size_t)(D + 1));
-  int32_t* d_rl_edges = (int32_t*)up(dl->relinked_edges, 4 * (size_t)nl);
-  int32_t* d_rl_to = (int32_t*)up(dl->relinked_to, 4 * (size_t)nl);
   int32_t* d_relink = nl > 0 ? (int32_t*)dev(4 * ((size_t)E + 1)) : nullptr;
-  TaskCols a_cols{(int64_t*)up(ad.priority, 8 * (size_t)na), (int64_t*)up(ad.expected_duration_ns, 8 * (size_t)na), (int64_t*)up(ad.queue_ts_ns, 8 * (size_t)na),
-                  (int64_t*)up(ad.scheduled_ts_ns, 8 * (size_t)na), (int64_t*)up(ad.deps_met_ts_ns, 8 * (size_t)na), (int32_t*)up(ad.num_dependents, 4 * (size_t)na),
-                  (int32_t*)up(ad.task_group_order, 4 * (size_t)na), (int32_t*)up(ad.task_group_max_hosts, 4 * (size_t)na), (int32_t*)up(ad.tg_key, 4 * (size_t)na),
-                  (int32_t*)up(ad.version_key, 4 * (size_t)na), (uint16_t*)up(ad.flags, 2 * (size_t)na)};
-  int32_t* d_add_dep_off = (int32_t*)up(na > 0 ? ad.dep_off : nullptr, 4 * ((size_t)na + 1));
-  EdgeCols a_edges{(int32_t*)up(ad.dep_idx, 4 * (size_t)EA), (uint8_t*)up(ad.dep_info, (size_t)EA), (int64_t*)up(ad.dep_finished_ts_ns, 8 * (size_t)EA)};
   if (rc) return rc;
+  const int32_t* d_removed = sg.up(dl->removed_rows, (size_t)nr);
+  const uint8_t* d_rm_state = sg.up(dl->removed_dep_state, (size_t)nr);
+  const int64_t* d_rm_fin = sg.up(dl->removed_finished_ts_ns, (size_t)nr);
+  const int32_t* d_added_dst = sg.up((const int32_t*)added_dst.data(), (size_t)na);
+  const int32_t* d_add_before = sg.up((const int32_t*)add_before.data(), (size_t)(D + 1));
+  const int32_t* d_tg_shift = sg.up((const int32_t*)tg_shift.data(), (size_t)(D + 1));
+  const int32_t* d_ver_shift = sg.up((const int32_t*)ver_shift.data(), (size_t)(D + 1));
+  const int32_t* d_new_toff_idx = sg.up((const int32_t*)new_toff.data(), (size_t)(D + 1));
+  const int32_t* d_rl_edges = sg.up(dl->relinked_edges, (size_t)nl);
+  const int32_t* d_rl_to = sg.up(dl->relinked_to, (size_t)nl);
+  TaskCols a_cols{(int64_t*)sg.up(ad.priority, (size_t)na), (int64_t*)sg.up(ad.expected_duration_ns, (size_t)na), (int64_t*)sg.up(ad.queue_ts_ns, (size_t)na),
+                  (int64_t*)sg.up(ad.scheduled_ts_ns, (size_t)na), (int64_t*)sg.up(ad.deps_met_ts_ns, (size_t)na), (int32_t*)sg.up(ad.num_dependents, (size_t)na),
+                  (int32_t*)sg.up(ad.task_group_order, (size_t)na), (int32_t*)sg.up(ad.task_group_max_hosts, (size_t)na), (int32_t*)sg.up(ad.tg_key, (size_t)na),
+                  (int32_t*)sg.up(ad.version_key, (size_t)na), (uint16_t*)sg.up(ad.flags, (size_t)na)};
+  const int32_t* d_add_dep_off = sg.up(na > 0 ? ad.dep_off : (const int32_t*)nullptr, (size_t)na + 1);
+  EdgeCols a_edges{(int32_t*)sg.up(ad.dep_idx, (size_t)EA), (uint8_t*)sg.up(ad.dep_info, (size_t)EA), (int64_t*)sg.up(ad.dep_finished_ts_ns, (size_t)EA)};
+  if (sg.rc) return sg.rc;
+  lap("delta packed (page-locked)");
+  if (sg.flush_in()) return sg.rc;
   // ---- the second set of pool buffers ----
   std::vector<DevBuf>& nw = c->pool_alt;
   const size_t n1 = (size_t)NN + 1;
@@ -1842,6 +1879,7 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
     HIP_TRY(c, hipMemsetAsync(d_ecut, 0, 4 * (size_t)(D + 1), st));
   }
   HIP_TRY(c, hipGetLastError());
+  lap("buffers + kernels enqueued");
   // the small tables of the new pool; the edge offset at every distro boundary comes back for the launch hints
   HIP_TRY(c, hipMemcpyAsync(nw[16].p, new_toff.data(), 4 * (size_t)(D + 1), hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync(nw[17].p, n_tg, 4 * (size_t)(D + 1), hipMemcpyHostToDevice, st));
@@ -1849,6 +1887,7 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   std::vector<int32_t> ecut(D + 1, 0);
   HIP_TRY(c, hipMemcpyAsync(ecut.data(), d_ecut, 4 * (size_t)(D + 1), hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipStreamSynchronize(st));
+  lap("tables up, cuts back, synced");
   // ---- swap: the new buffers ARE the pool (the distro settings are not re-packed: their buffer moves over) ----
   std::swap(nw[15], c->pool[15]);
   std::swap(c->pool, c->pool_alt);

@@ -46,6 +46,9 @@ constexpr int kTiledMaxRows = 1 << 20;
 constexpr int kTiledMaxSlots = 1 << 21;
 constexpr int kMaxST = (kTiledMaxSlots / kST + 511) / 512 * 512;  // slot tiles of one distro: the scatter kernel buckets them in LDS
 constexpr int kTiledBlock = 512;
+#ifndef EVG_STAGE_BATCH
+#define EVG_STAGE_BATCH 7  // edges per thread whose loads the staging loops of T1 / T3 issue together
+#endif
 constexpr int kTileEdges = 6144;      // dependency edges of one row tile resolved edge-parallel in LDS (more: per row, from memory)
 // PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs; every variant is bit-exact, scripts/r03_modes.sh): 1, 2 = the per-row forms of
 // round 2; 32 = every thread stores its own keys
@@ -328,7 +331,7 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
   if (eL) {
     // six edges per thread at a time: their index loads together, then the gathers of the dependencies' rows together (edge
     // after edge the loop was two dependent round trips per trip, ~7 trips: 16.8 us of a workgroup's 51)
-    constexpr int kB = 6;
+    constexpr int kB = EVG_STAGE_BATCH;
     for (int x0 = tid; x0 < E1 - E0; x0 += kB * kTiledBlock) {
       EdgeIn in[kB];
       EdgeDep dep[kB];
@@ -860,7 +863,7 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
   // (Fetching the four rows' columns ahead of this loop was measured: 85 VGPRs, one workgroup less per CU, slower.)
   uint64_t* s_uk = (uint64_t*)smem;
   if (stage) {
-    constexpr int kB = 6;  // batched like the scatter kernel's staging: slots together, then the units' (value, min row) together
+    constexpr int kB = EVG_STAGE_BATCH;  // batched like the scatter kernel's staging: slots together, then the units' (value, min row) together
     for (int x0 = tid; x0 < E1 - E0; x0 += kB * kTiledBlock) {
       int sl[kB];
       int64_t v[kB];

@@ -356,10 +356,12 @@ class Context:
         self._check(self.lib.evg_pool_update(self.h, C.byref(ru) if ru is not None else None, C.byref(eu) if eu is not None else None),
                     "evg_pool_update")
 
-    def pool_apply_delta(self, removed_rows=None, removed_dep_state=None, removed_finished_ts_ns=None, added_distro=None, added_cols=None,
-                         added_dep_off=None, added_edges=None, tg_off=None, ver_off=None, relinked_edges=None, relinked_to=None) -> None:
-        """evg_pool_apply_delta: see include/evg_sched.h. added_cols: {column: values} of TASK_COLUMNS for the added rows, added_edges:
-        {dep_idx, dep_info, dep_finished_ts_ns} over added_dep_off (dep_idx: -1, a current row, or -(k + 2) for added row k)."""
+    @staticmethod
+    def make_pool_delta(removed_rows=None, removed_dep_state=None, removed_finished_ts_ns=None, added_distro=None, added_cols=None,
+                        added_dep_off=None, added_edges=None, tg_off=None, ver_off=None, relinked_edges=None, relinked_to=None):
+        """The evg_pool_delta argument block (see include/evg_sched.h) + the arrays it points into (keep both alive for the call).
+        added_cols: {column: values} of TASK_COLUMNS for the added rows, added_edges: {dep_idx, dep_info, dep_finished_ts_ns} over
+        added_dep_off (dep_idx: -1, a current row, or -(k + 2) for added row k)."""
         d, keep = abi.PoolDelta(), []
 
         def arr(a, dt):
@@ -390,7 +392,15 @@ class Context:
             d.ver_off = arr(ver_off, np.int32)
         if relinked_edges is not None and len(relinked_edges):
             d.n_relinked, d.relinked_edges, d.relinked_to = len(relinked_edges), arr(relinked_edges, np.int32), arr(relinked_to, np.int32)
-        self._check(self.lib.evg_pool_apply_delta(self.h, C.byref(d)), "evg_pool_apply_delta")
+        return d, keep
+
+    def pool_apply_delta(self, delta=None, **kw) -> None:
+        """evg_pool_apply_delta with a block from make_pool_delta, or with make_pool_delta's keyword arguments."""
+        keep = None
+        if delta is None:
+            delta, keep = self.make_pool_delta(**kw)
+        self._check(self.lib.evg_pool_apply_delta(self.h, C.byref(delta)), "evg_pool_apply_delta")
+        del keep
 
     def pool_plan(self, batch: abi.PlanBatch, now_ns: int, breakdown: bool = False, n_units: bool = False, units: bool = False,
                   into: Optional[abi.PlanResult] = None) -> abi.PlanResult:

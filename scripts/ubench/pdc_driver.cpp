@@ -1,0 +1,39 @@
+// pdc_driver.cpp -- the timed loop of bench.py's `per_distro_calls` in native threads.
+//
+// The reference calls its TaskPlanner and its HostAllocator once per distro from concurrent amboy jobs (units/crons.go:303-332,
+// units/scheduler.go:48-49): goroutines on OS threads, no interpreter lock between them. Measured from Python threads, a worker that
+// returns from its C call waits for the GIL behind whichever thread is doing bookkeeping (switch interval 5 ms): with 32 threads the
+// p99 of a 150 us call pair read 15.9 ms, an artefact of the harness. Here every worker is a std::thread that owns one context
+// and makes the same two C-ABI calls per distro -- evg_plan_distros + evg_allocate_hosts on a batch of one -- through the function
+// pointers bench.py hands over (this file links nothing: no HIP, no libevg_sched).
+//   g++ -O2 -shared -fPIC -pthread pdc_driver.cpp -o libpdc.so
+#include <chrono>
+#include <cstddef>
+#include <thread>
+#include <vector>
+
+typedef int (*call2_fn)(void* ctx, const void* in, const void* out);
+
+extern "C" int pdc_run(void* fn_plan, void* fn_alloc, void** ctxs, int n_threads, int n_distros, const char* pin, size_t pin_stride, const char* pout,
+                       size_t pout_stride, const char* ain, size_t ain_stride, const char* aout, size_t aout_stride, double* lat_us, double* wall_ms) {
+  const call2_fn plan = (call2_fn)fn_plan, alloc = (call2_fn)fn_alloc;
+  std::vector<int> bad(n_threads, 0);
+  auto work = [&](int w) {
+    for (int d = w; d < n_distros; d += n_threads) {
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rc = plan(ctxs[w], pin + (size_t)d * pin_stride, pout + (size_t)d * pout_stride);
+      const int rc2 = alloc(ctxs[w], ain + (size_t)d * ain_stride, aout + (size_t)d * aout_stride);
+      lat_us[d] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      bad[w] += (rc != 0) + (rc2 != 0);
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int w = 1; w < n_threads; w++) th.emplace_back(work, w);
+  work(0);
+  for (auto& t : th) t.join();
+  *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  int errors = 0;
+  for (int b : bad) errors += b;
+  return errors;
+}
