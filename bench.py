@@ -718,9 +718,15 @@ def main():
                 out = {"all_small_tick_ms": base_ms, "all_small_plan_ms": base_plan, "cases": [],
                        "what": "ms per device-resident tick (plan + allocate) of BASELINE config 3 with n_grown distros grown to grown_size tasks, "
                                "next to the all-small tick; vs_all_small = tick / all-small tick"}
-                for size in (2049, 4096, 10_000):
-                    for k in (1, 8, 64):
-                        b = gen.generate(gen.cliff_config(k, size))
+                # ... and on a pool that leaves CUs free (the first 384 distros of config 3): there the one-per-CU tier is launched FIRST
+                # and runs beside the small tier; on config 3 itself 512 small workgroups are exactly one wave of the chip (two per CU)
+                # and anything more is a second round, whatever the order
+                b384 = gen.generate(gen.cliff_config(0, 0, n_distros=384))
+                ms384, plan384, _, _, _ = resident_rate(b384, dev, native, resident, torch, steps=20, warmup=3)
+                out["all_small_384_distros_tick_ms"] = ms384
+                for size, k, nd in [(s_, k_, 0) for s_ in (2049, 4096, 10_000) for k_ in (1, 8, 64)] + [(2049, 1, 384), (4096, 8, 384), (4096, 64, 384)]:
+                    if True:
+                        b = gen.generate(gen.cliff_config(k, size, n_distros=nd))
                         ms, p_ms, a_ms, r, ra = resident_rate(b, dev, native, resident, torch, steps=20, warmup=3)
                         want, want_alloc, _, _ = oracle_threads(b, os.cpu_count() or 1, reps=1)
                         want.n_units = None
@@ -730,8 +736,8 @@ def main():
                             compare.assert_alloc_equal(ra, want_alloc, "cliff %d x %d" % (k, size))
                         except AssertionError as e:
                             ok = str(e)[:200]
-                        out["cases"].append({"n_grown": k, "grown_size": size, "tasks": b.n_tasks, "ms_per_tick": ms, "planning-distro_ms": p_ms,
-                                             "vs_all_small": ms / base_ms, "parity_vs_oracle": ok})
+                        out["cases"].append({"n_grown": k, "grown_size": size, "distros": b.n_distros, "tasks": b.n_tasks, "ms_per_tick": ms,
+                                             "planning-distro_ms": p_ms, "vs_all_small": ms / (ms384 if nd else base_ms), "parity_vs_oracle": ok})
                 return out
             guarded("cliff", cliff)
             guarded("single_process_abi", lambda: multi_abi_tick(batch, native, [dev.index or 0], 20, 3, want=got, want_alloc=got_alloc)[0])

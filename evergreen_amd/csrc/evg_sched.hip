@@ -410,14 +410,15 @@ struct evg_ctx {
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
-  // the one-per-CU tier (k_plan_distros_big): 1 = behind the small tier's launch on the caller's stream (default), 2 = on the
-  // context's high-priority side stream, forked before that launch and joined after it, 0 = off (tier-12 distros take the
-  // large-distro pipeline). EVG_BIG_TIER, for A/B runs. Measured (scripts/bench_cliff.py, config 3 with 1 / 8 / 64 distros grown to
-  // 4096 tasks): 0.118 / 0.117 / 0.153 ms per tick behind, 0.130 / 0.132 / 0.165 beside, 0.158 / 0.164 / 0.170 off: the 512
-  // workgroups of the small tier fill every CU the moment they are dispatched (the cross-queue wait of the fork delays the side
-  // stream by ~7 us), so the big tier's workgroups -- which need a CU to themselves -- start when the small tier ends either way,
-  // and the two event hand-overs cost ~15 us on top.
-  int big_mode = 1;
+  // the one-per-CU tier (k_plan_distros_big), EVG_BIG_TIER: 3 (default) = beside the small tier when the launch's workgroups leave CUs
+  // free, behind it when they fill the chip (launch_plan); 1 = always behind the small tier's launch on the caller's stream; 2 = always
+  // on the context's high-priority side stream, forked before that launch and joined after it; 0 = off (tier-12 distros take the
+  // large-distro pipeline). Measured (scripts/bench_cliff.py, config 3 = 512 distros with 1 / 8 / 64 of them grown to 4096 tasks):
+  // 0.118 / 0.117 / 0.153 ms per tick behind, 0.130 / 0.132 / 0.165 beside, 0.158 / 0.164 / 0.170 off: the 512 workgroups of the
+  // small tier fill every CU the moment they are dispatched, so the big tier's workgroups -- which need a CU to themselves -- start
+  // when the small tier ends either way, and the two event hand-overs cost ~15 us on top.
+  int big_mode = 3;
+  int n_cus = 256;
   hipStream_t side = nullptr;               // high-priority stream of the big tier's launch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // evg_profile_plan_kernel: HIP events around the LDS planner kernel alone, on the stream it is launched on
@@ -679,6 +680,7 @@ evg_ctx* evg_create(int device_ordinal) {
   }
   evg_ctx* c = new evg_ctx();
   c->device = device_ordinal;
+  c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* m = getenv("EVG_BIG_TIER")) c->big_mode = atoi(m);
   if (const char* m = getenv("EVG_TILED_MODE")) c->tiled_mode = atoi(m);
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1096,7 +1098,12 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
       promise = true;
       a.w_status = c->status_word;
     }
-    big_beside = c->big_mode == 2;
+    // Beside or behind? A big-tier workgroup needs a CU to itself, a small-tier one half a CU. When the launch's workgroups do not
+    // fill the chip (D - n_big small ones + two half-CUs per big one within the 512 half-CU slots of 256 CUs) the big tier runs
+    // BESIDE the small tier on the context's side stream and costs the tick nothing but the two event hand-overs; when they do
+    // (BASELINE config 3: 512 small distros are exactly one wave) the side stream only queues behind the small tier's wave and
+    // the hand-overs are pure loss (EVG_BIG_TIER=3: this choice, the default; 1 / 2 force behind / beside).
+    big_beside = c->big_mode == 2 || (c->big_mode == 3 && (D - n_big) + 2 * n_big <= 2 * c->n_cus);
     if (big_beside && !c->side) {
       int lo_pri = 0, hi_pri = 0;
       HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
@@ -1106,24 +1113,30 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
     }
     const dim3 bg((unsigned)n_big), bb(Tier<12>::BLK);
     if (big_beside) {
-      HIP_TRY(c, hipEventRecord(c->ev_fork, st));  // after whatever produced the batch on the caller's stream
+      // The big tier goes FIRST, on the caller's stream, so that its workgroups find whole CUs; the small tier follows on the side
+      // stream (it waits for whatever produced the batch on the caller's stream) and fills what is left, two workgroups per CU.
+      // (Round 4, first form: the big tier on the side stream -- it arrived ~7 us after the small tier, whose workgroups the
+      // dispatcher spreads over ALL CUs, and found no empty CU until the small tier drained: no better than behind.)
+      HIP_TRY(c, hipEventRecord(c->ev_fork, st));
       HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-      if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros_big<true>), bg, bb, kLdsBig, c->side, a);
-      else hipLaunchKernelGGL((k_plan_distros_big<false>), bg, bb, kLdsBig, c->side, a);
+      if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros_big<true>), bg, bb, kLdsBig, st, a);
+      else hipLaunchKernelGGL((k_plan_distros_big<false>), bg, bb, kLdsBig, st, a);
       HIP_TRY(c, hipGetLastError());
-      HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
     }
   }
-  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st));
+  hipStream_t st_small = big_beside ? c->side : st;
+  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st_small));
   // TaskPlan.Len() needs 18 KiB more LDS per workgroup (one workgroup per CU instead of two); the breakdown rows do not
-  if (out->n_units) hipLaunchKernelGGL((k_plan_distros<true, true>), dim3(D), dim3(kBlock), kLdsRich, st, a);
-  else if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros<false, true>), dim3(D), dim3(kBlock), kLdsLean, st, a);
-  else hipLaunchKernelGGL((k_plan_distros<false, false>), dim3(D), dim3(kBlock), kLdsLean, st, a);
+  if (out->n_units) hipLaunchKernelGGL((k_plan_distros<true, true>), dim3(D), dim3(kBlock), kLdsRich, st_small, a);
+  else if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros<false, true>), dim3(D), dim3(kBlock), kLdsLean, st_small, a);
+  else hipLaunchKernelGGL((k_plan_distros<false, false>), dim3(D), dim3(kBlock), kLdsLean, st_small, a);
   HIP_TRY(c, hipGetLastError());
-  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_stop, st));
+  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_stop, st_small));
   if (n_big > 0) {
-    if (big_beside) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-    else {
+    if (big_beside) {
+      HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+      HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    } else {
       const dim3 bg((unsigned)n_big), bb(Tier<12>::BLK);
       if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros_big<true>), bg, bb, kLdsBig, st, a);
       else hipLaunchKernelGGL((k_plan_distros_big<false>), bg, bb, kLdsBig, st, a);

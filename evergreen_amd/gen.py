@@ -90,10 +90,13 @@ def config(num: int, **over) -> GenConfig:
     return GenConfig(**{**c.__dict__, **over})
 
 
-def cliff_config(n_grown: int, grown_size: int, base: int = 3) -> GenConfig:
+def cliff_config(n_grown: int, grown_size: int, base: int = 3, n_distros: int = 0) -> GenConfig:
     """BASELINE config `base` with `n_grown` of its distros (evenly spaced) grown to `grown_size` tasks: how much one / a few /
     many distros beyond the 2048-task tier cost a tick that is otherwise all small."""
     c = config(base)
+    if n_distros:  # the first n_distros distros of the base config only: a pool that does not fill the chip
+        per = c.n_tasks // c.n_distros
+        c = GenConfig(**{**c.__dict__, "n_tasks": per * n_distros, "n_distros": n_distros})
     s = np.full(c.n_distros, c.n_tasks // c.n_distros, np.int64)
     s[: c.n_tasks % c.n_distros] += 1
     if n_grown:

@@ -1,7 +1,8 @@
 """The 2048-task cliff: BASELINE config 3 with n_grown distros grown to grown_size tasks, device-resident
 plan + allocate, for every mode of the 4096-task tier (EVG_BIG_TIER: 2 = beside the small tier's launch on the context's side
 stream, 1 = behind it on the caller's stream, 0 = off: the large-distro pipeline). GPU box only.
-usage: bench_cliff.py [modes, default 2,1,0] [--cases k:size,k:size,...] [--steps N]"""
+usage: bench_cliff.py [modes, default 2,1,0] [--cases k:size,k:size,...] [--steps N] [--distros D]  (D: the first D distros of config 3 only --
+a pool that leaves CUs free, where the big tier can run BESIDE the small one; mode 3 = the library's own choice)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,13 +12,16 @@ from evergreen_amd import gen, native, resident
 modes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "2,1,0").split(",")]
 cases = [(0, 0), (1, 2049), (8, 2049), (64, 2049), (1, 4096), (8, 4096), (64, 4096), (1, 10000), (8, 10000)]
 steps = 30
+n_distros = 0
 for i, a in enumerate(sys.argv):
+    if a == "--distros":
+        n_distros = int(sys.argv[i + 1])
     if a == "--cases":
         cases = [tuple(int(v) for v in c.split(":")) for c in sys.argv[i + 1].split(",")]
     if a == "--steps":
         steps = int(sys.argv[i + 1])
 dev = torch.device("cuda:0")
-batches = {c: gen.generate(gen.cliff_config(*c) if c[0] else gen.config(3)) for c in cases}
+batches = {c: gen.generate(gen.cliff_config(c[0], c[1], n_distros=n_distros) if (c[0] or n_distros) else gen.config(3)) for c in cases}
 ref = {}
 for mode in modes:
     os.environ["EVG_BIG_TIER"] = str(mode)
