@@ -364,6 +364,16 @@ def sharded_workload(make_batch, what, ctx, dev, dist, rank, world, mode, steps,
     return obj
 
 
+def flush_c_stdio():
+    """RCCL prints its version banner with C stdio when a communicator is created; into a pipe that is buffered until the process
+    exits, i.e. AFTER the JSON line. Flushed here so that the JSON line stays the last line of the output."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def multi_abi_tick(batch, native, devices, steps, warmup, scatter=False, want=None, want_alloc=None):
     """The sharded tick through the C ABI's evg_multi_* (one process, one context + RCCL communicator per device): ms per tick (wall
     clock around `steps` ticks; a tick returns when every device is done), its phases by the library's HIP events, parity flags."""
@@ -419,6 +429,7 @@ def single_process(args, gen, native, np, torch):
         line["host_counts_match"] = bool(np.array_equal(got_alloc.new_hosts, want_alloc.new_hosts) and np.array_equal(got_alloc.free_hosts, want_alloc.free_hosts))
         line["cpu_baseline"] = {"value": batch.n_tasks / tn, "unit": "tasks/s", "cores": nt, "kind": "port", "median_value": batch.n_tasks / tmed,
                                 "sample": "the whole workload, 5 passes with %d worker threads (best = value)" % nt}
+    flush_c_stdio()
     print(json.dumps(line), flush=True)
 
 
@@ -746,6 +757,7 @@ def main():
         for k, v in extra_objs.items():
             if v is not None:
                 line[k] = v
+        flush_c_stdio()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

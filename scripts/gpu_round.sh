@@ -11,7 +11,7 @@ if [ -z "${PROFILE_ONLY:-}" ]; then
 echo "== pytest -m gpu" | tee $OUT/pytest_$TAG.log
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee -a $OUT/pytest_$TAG.log
 echo "== bench" | tee $OUT/bench_$TAG.log
-timeout 600 python bench.py --steps 50 --warmup 5 2>&1 | tail -5 | tee -a $OUT/bench_$TAG.log
+timeout 900 python bench.py --steps 50 --warmup 5 2>&1 | grep "^{\"metric" | tee -a $OUT/bench_$TAG.log | tail -c 300
 fi
 # the profiled runs keep ONE batch in flight: with several, concurrent launches stretch each other's durations and the
 # per-kernel averages no longer describe a launch on its own (bench.py's roofline block is the one-at-a-time figure too)
