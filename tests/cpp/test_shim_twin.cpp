@@ -51,6 +51,14 @@ struct Lib {
   void (*host_free)(evg_ctx*, void*) = nullptr;
   int (*plan_distros)(evg_ctx*, const evg_plan_input*, const evg_plan_output*) = nullptr;
   int (*allocate_hosts)(evg_ctx*, const evg_alloc_input*, const evg_alloc_output*) = nullptr;
+  // gpu_multi.go: the batched planner spread over several devices of this process
+  evg_multi* (*multi_create)(const int32_t*, int32_t, int32_t) = nullptr;
+  void (*multi_destroy)(evg_multi*) = nullptr;
+  const char* (*multi_last_error)(const evg_multi*) = nullptr;
+  int (*multi_load)(evg_multi*, const evg_plan_input*, const evg_alloc_input*) = nullptr;
+  int (*multi_tick)(evg_multi*, int64_t) = nullptr;
+  int (*multi_results)(evg_multi*, const evg_plan_output*, const evg_alloc_output*) = nullptr;
+  int calls_multi = 0;
   // oracle mode: the two batched calls without a context
   int (*o_plan)(const evg_plan_input*, const evg_plan_output*) = nullptr;
   int (*o_alloc)(const evg_alloc_input*, const evg_alloc_output*) = nullptr;
@@ -205,6 +213,21 @@ struct PlanOut {
 };
 // depState: fetchedDepStates' result (what task.FindWithFields would return for the dependencies outside the queues);
 // includesDeps: the test cases set opts.IncludesDependencies directly where the Go test does.
+// ---- gpuMulti / shardFor (gpu_multi.go) ------------------------------------------------------------------------------------
+// The Go file creates the evg_multi over the devices of SetGPUDevices with EVG_MULTI_UNIT_ROWS; a one-GPU box has one device, so the
+// twin lists it twice over the loopback transport (RCCL refuses the same device twice): the three calls and their arguments are the
+// shim's, the two ranks' ranges and the gather are real.
+struct gpuMulti {
+  evg_multi* m = nullptr;
+  void plan(const evg_plan_input* in, const evg_plan_output* out) {
+    if (L.multi_load(m, in, nullptr) != EVG_OK) throw std::runtime_error(std::string("evg_multi_load: ") + L.multi_last_error(m));
+    if (L.multi_tick(m, in->now_ns) != EVG_OK) throw std::runtime_error(std::string("evg_multi_tick: ") + L.multi_last_error(m));
+    if (L.multi_results(m, out, nullptr) != EVG_OK) throw std::runtime_error(std::string("evg_multi_results: ") + L.multi_last_error(m));
+    L.calls_multi++;
+  }
+};
+static gpuMulti* g_shard = nullptr;  // what shardFor(n, D) returned for the batch being planned (nullptr: one device)
+
 static PlanOut planBatch(const std::vector<const Distro*>& ds, const std::vector<const std::vector<Task>*>& queues, Time now,
                          const std::unordered_map<std::string, uint8_t>& depState = {}, const std::vector<bool>* includesDeps = nullptr) {
   gpuCtx* g = pool_get();
@@ -306,7 +329,9 @@ static PlanOut planBatch(const std::vector<const Distro*>& ds, const std::vector
   out.order = ptr(order); out.deps_met = ptr(met); out.wait_ns = ptr(wait); out.distro_info = ptr(distroInfo); out.group_info = ptr(groupInfo);
   out.unit_of_task = ptr(unitOf); out.unit_breakdown = ptr(unitRows);  // breakdown (rows by task) and n_units stay NULL
 
-  const int rc = L.hip ? L.plan_distros(g->c, &in, &out) : L.o_plan(&in, &out);
+  int rc = EVG_OK;
+  if (g_shard) g_shard->plan(&in, &out);  // shard.plan(&in, &out): the same two structs, spread over the devices by the library
+  else rc = L.hip ? L.plan_distros(g->c, &in, &out) : L.o_plan(&in, &out);
   L.calls_plan++;
   if (rc != EVG_OK) throw std::runtime_error(std::string("evg_plan_distros: ") + (L.hip ? L.last_error(g->c) : "oracle") + " (" + std::to_string(rc) + ")");
 
@@ -521,6 +546,45 @@ static void check_allocator(const Backend&, const char* name, int line, HostAllo
          want_hosts, want_free);
 }
 
+// gpu_multi.go's path: the two-distro batch of run_twin_specifics through evg_multi_load / _tick / _results (two ranks, one distro
+// each) must be the plan evg_plan_distros gives.
+static void run_multi_cases() {
+  if (!L.hip) return;
+  const int32_t devs[2] = {0, 0};
+  gpuMulti shard;
+  shard.m = L.multi_create(devs, 2, EVG_MULTI_UNIT_ROWS | EVG_MULTI_LOOPBACK);
+  if (!shard.m) throw std::runtime_error(std::string("evg_multi_create: ") + L.multi_last_error(nullptr));
+  Distro d1, d2;
+  d1.Id = "d1"; d2.Id = "d2"; d2.PlannerSettings.GroupVersions = true;
+  std::vector<Task> q1(40), q2(25);
+  for (size_t i = 0; i < q1.size(); i++) {
+    q1[i].Id = "a" + std::to_string(i); q1[i].DistroId = "d1"; q1[i].Priority = (int64_t)((i * 7) % 5); q1[i].Version = "v" + std::to_string(i / 8);
+    if (i % 9 == 4) { q1[i].TaskGroup = "tg" + std::to_string(i / 18); q1[i].BuildVariant = "bv"; q1[i].Project = "p"; q1[i].TaskGroupMaxHosts = 2; q1[i].TaskGroupOrder = (int)(i % 3) + 1; }
+    if (i >= 8) { Dependency dep; dep.TaskId = "a" + std::to_string(i - 8); q1[i].DependsOn.push_back(dep); }
+  }
+  for (size_t i = 0; i < q2.size(); i++) { q2[i].Id = "x" + std::to_string(i); q2[i].DistroId = "d2"; q2[i].Version = "w" + std::to_string(i / 5); q2[i].NumDependents = (int)(i % 4); }
+  const PlanOut one = planBatch({&d1, &d2}, {&q1, &q2}, NOW);
+  g_shard = &shard;
+  const PlanOut two = planBatch({&d1, &d2}, {&q1, &q2}, NOW);
+  const PlanOut again = planBatch({&d2, &d1}, {&q2, &q1}, NOW);  // a second pool into the same evg_multi, other sizes per rank
+  g_shard = nullptr;
+  for (int d = 0; d < 2; d++) {
+    EXPECT(one.plans[(size_t)d].size() == two.plans[(size_t)d].size(), "multi: distro %d keeps its tasks", d);
+    bool same = true, same2 = true;
+    for (size_t p = 0; p < one.plans[(size_t)d].size(); p++) {
+      same &= one.plans[(size_t)d][p].Id == two.plans[(size_t)d][p].Id &&
+              one.plans[(size_t)d][p].SortingValueBreakdown.TotalValue == two.plans[(size_t)d][p].SortingValueBreakdown.TotalValue;
+      same2 &= one.plans[(size_t)d][p].Id == again.plans[(size_t)(1 - d)][p].Id;
+    }
+    EXPECT(same, "multi: distro %d planned over two ranks == planned on one device (order + stamped TotalValue)", d);
+    EXPECT(same2, "multi: distro %d in a second pool with the distros swapped", d);
+    EXPECT(one.infos[(size_t)d].Length == two.infos[(size_t)d].Length && one.infos[(size_t)d].ExpectedDuration == two.infos[(size_t)d].ExpectedDuration &&
+           one.infos[(size_t)d].TaskGroupInfos.size() == two.infos[(size_t)d].TaskGroupInfos.size(), "multi: queue info of distro %d", d);
+  }
+  EXPECT(L.calls_multi == 2, "two ticks went through evg_multi_* (%d)", L.calls_multi);
+  L.multi_destroy(shard.m);
+}
+
 static void run_twin_specifics() {
   // a batch of SEVERAL distros in one call (the batched cron's shape): first-appearance interning is per distro, rows re-based
   Distro d1, d2;
@@ -650,6 +714,9 @@ int main(int argc, char** argv) {
       L.last_error = sym<decltype(L.last_error)>(h, "evg_last_error"); L.check_abi = sym<decltype(L.check_abi)>(h, "evg_check_abi");
       L.host_alloc = sym<decltype(L.host_alloc)>(h, "evg_host_alloc"); L.host_free = sym<decltype(L.host_free)>(h, "evg_host_free");
       L.plan_distros = sym<decltype(L.plan_distros)>(h, "evg_plan_distros"); L.allocate_hosts = sym<decltype(L.allocate_hosts)>(h, "evg_allocate_hosts");
+      L.multi_create = sym<decltype(L.multi_create)>(h, "evg_multi_create"); L.multi_destroy = sym<decltype(L.multi_destroy)>(h, "evg_multi_destroy");
+      L.multi_last_error = sym<decltype(L.multi_last_error)>(h, "evg_multi_last_error"); L.multi_load = sym<decltype(L.multi_load)>(h, "evg_multi_load");
+      L.multi_tick = sym<decltype(L.multi_tick)>(h, "evg_multi_tick"); L.multi_results = sym<decltype(L.multi_results)>(h, "evg_multi_results");
     } else {
       L.o_plan = sym<decltype(L.o_plan)>(h, "evg_oracle_plan_distros"); L.o_alloc = sym<decltype(L.o_alloc)>(h, "evg_oracle_allocate_hosts");
     }
@@ -661,6 +728,7 @@ int main(int argc, char** argv) {
     run_allocator_cases(none);
     run_twin_specifics();
     run_empty_column_cases();
+    run_multi_cases();
     if (L.hip && g_ctx.c) {
       if (g_ctx.arena) L.host_free(g_ctx.c, g_ctx.arena);
       L.destroy(g_ctx.c);
