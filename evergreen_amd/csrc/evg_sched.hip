@@ -420,6 +420,9 @@ struct evg_ctx {
   int big_mode = 3;
   int n_cus = 256;
   hipStream_t side = nullptr;               // high-priority stream of the big tier's launch
+  hipStream_t side2 = nullptr;              // the large-distro pipeline beside the tiers (launch_plan)
+  hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+  int overlap = 1;                          // EVG_OVERLAP: 1 = beside the tiers when the batch carries EVG_HINT_MIXED_POOL, 0 never, 2 always
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // evg_profile_plan_kernel: HIP events around the LDS planner kernel alone, on the stream it is launched on
   bool profile = false;
@@ -683,6 +686,7 @@ evg_ctx* evg_create(int device_ordinal) {
   c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* m = getenv("EVG_BIG_TIER")) c->big_mode = atoi(m);
   if (const char* m = getenv("EVG_TILED_MODE")) c->tiled_mode = atoi(m);
+  if (const char* m = getenv("EVG_OVERLAP")) c->overlap = atoi(m);
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void**)&c->status_word, 64, hipHostMallocDefault) != hipSuccess) {
     set_err(nullptr, EVG_E_HIP, "cannot create a stream / the status word on device %d", device_ordinal);
@@ -705,6 +709,9 @@ void evg_destroy(evg_ctx* c) {
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->side2) (void)hipStreamDestroy(c->side2);
+  if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
+  if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->status_word) (void)hipHostFree(c->status_word);
@@ -827,17 +834,22 @@ int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, i
   if (in->tasks.n_tasks > 0 && (!in->tasks.priority || !in->tasks.dep_off)) return EVG_E_INVALID;
   for (int d = 0; d < D; d++) *max_distro_tasks = std::max(*max_distro_tasks, in->task_off[d + 1] - in->task_off[d]);
   int off_path[8] = {0, 0, 0, 0, 0, 0, 0, 0}, off_tiers[8] = {0, 0, 0, 0, 0, 0, 0, 0}, big[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long on_tiers[8] = {0, 0, 0, 0, 0, 0, 0, 0}, on_pipe[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tasks the tiers / the large-distro pipeline plan
   for_distros_parallel(in, [&](int d, int w) {
     const int tier = distro_lds_tier(in, d);
+    const int n = in->task_off[d + 1] - in->task_off[d];
     if (tier != 11) off_path[w] = 1;
     if (tier == 12) big[w]++;
     if (tier == 0) off_tiers[w] = 1;
+    if (tier != 0) on_tiers[w] += n; else if (n > evg::kRT) on_pipe[w] += n;
     return true;
   });
   int any = 0, any_none = 0;
-  for (int w = 0; w < 8; w++) { any |= off_path[w]; *n_big_tier_distros += big[w]; any_none |= off_tiers[w]; }
+  long long nt = 0, np = 0;
+  for (int w = 0; w < 8; w++) { any |= off_path[w]; *n_big_tier_distros += big[w]; any_none |= off_tiers[w]; nt += on_tiers[w]; np += on_pipe[w]; }
   if (!any) *promises |= EVG_PROMISE_ALL_ON_LDS_PATH;
   if (!any_none) *promises |= EVG_PROMISE_ALL_ON_LDS_TIERS;
+  if (std::min(nt, np) * 8 >= (long long)in->tasks.n_tasks && in->tasks.n_tasks > 0) *promises |= EVG_HINT_MIXED_POOL;
   return EVG_OK;
 }
 
@@ -1041,7 +1053,10 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
 //                 without a hint, the task count) allows. Then k_plan_generic for whatever the pipeline left: small flagged
 //                 distros, distros it cannot take, and distros larger than the hint promised.
 // TaskPlan.Len() (out->n_units) needs the set-equality pass that only the one-workgroup kernel has.
-static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st) {
+// st_tiled: the stream of the pipeline's own kernels (list .. merge passes). When it is not `st`, the pipeline runs BESIDE the
+// one-workgroup tiers: the caller forked st_tiled before it launched them, k_tiled_list decides by shape, and k_plan_generic -- on
+// `st`, which by then carries the tiers -- waits for the pipeline through ev_join2.
+static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st, hipStream_t st_tiled) {
   using namespace evg;
   const int D = a.d1 - a.d0;
   const dim3 gg(D < kGenericGrid ? D : kGenericGrid), bb(kBlock);
@@ -1054,15 +1069,19 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
   const long long cap = hint < kTiledMaxRows ? hint : kTiledMaxRows - 1;
   int passes = 0;
   while (((long long)kRT << passes) < cap) passes++;
-  int rc = prepare_tiled(c, a, in);
-  if (rc) return rc;
   // + 8: the XCD-aware tile mapping (xcd_tile) rounds the tile count up to a multiple of the 8 XCDs
   const dim3 rt((unsigned)tiled_max_row_tiles(in) + 8), stl((unsigned)tiled_max_slot_tiles(in) + 8), tb(kTiledBlock);
-  hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, st, a, passes);
-  hipLaunchKernelGGL(k_tiled_scatter, rt, tb, 0, st, a);
-  hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, st, a);
-  hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, st, a);
-  for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, st, a, p);
+  const hipStream_t t = st_tiled;
+  hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, t, a, passes, t != st ? 1 : 0);
+  hipLaunchKernelGGL(k_tiled_scatter, rt, tb, 0, t, a);
+  hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, t, a);
+  hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, t, a);
+  for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, t, a, p);
+  HIP_TRY(c, hipGetLastError());
+  if (t != st) {
+    HIP_TRY(c, hipEventRecord(c->ev_join2, t));
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join2, 0));
+  }
   hipLaunchKernelGGL(k_plan_generic, gg, bb, kGenericLds, st, a, 1);  // its head writes the info rows of the distros the pipeline finished
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
@@ -1084,6 +1103,30 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
     if (d_begin == d_end) return EVG_OK;
   }
   const int D = a.d1 - a.d0;
+  // The large-distro pipeline BESIDE the tiers (round 4). Its first kernel used to read the flags the tier kernels leave, so
+  // its eight launches queued behind them: ~57 us of a mixed pool's plan in which the chip mostly idles (the tiers' workgroups of
+  // the LARGE distros exit at once, and small distros finish early). With k_tiled_list deciding by shape the two chains are
+  // independent until k_plan_generic: the pipeline goes to a second side stream, forked here -- when the batch is a MIX (the
+  // host's EVG_HINT_MIXED_POOL: both chains have at least an eighth of the tasks): 0.333 -> 0.300 ms per plan on the skewed pool. On
+  // config 5's share (nothing for the tiers) and on config 3 with one 10,000-task distro (a full chip) the two event hand-overs
+  // only cost: +8 %. EVG_OVERLAP=0 never, 2 always (A/B runs).
+  const long long hint0 = in->max_distro_tasks > 0 ? in->max_distro_tasks : in->tasks.n_tasks;
+  const bool tiled = !(in->promises & (EVG_PROMISE_ALL_ON_LDS_PATH | EVG_PROMISE_ALL_ON_LDS_TIERS)) && hint0 > kRT && !out->n_units;
+  hipStream_t st_tiled = st;
+  if (tiled) {
+    rc = prepare_tiled(c, a, in);
+    if (rc) return rc;
+    if (c->overlap == 2 || (c->overlap == 1 && (in->promises & EVG_HINT_MIXED_POOL))) {
+      if (!c->side2) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
+      }
+      HIP_TRY(c, hipEventRecord(c->ev_fork2, st));  // after whatever produced the batch on the caller's stream
+      HIP_TRY(c, hipStreamWaitEvent(c->side2, c->ev_fork2, 0));
+      st_tiled = c->side2;
+    }
+  }
   // The one-per-CU tier (distros of 2049..4096 tasks): its workgroups are the launch's critical path -- twice the rows of a small
   // distro -- so they are enqueued FIRST, on the context's high-priority side stream, and run beside the small tier's launch;
   // the large-distro pipeline behind waits for both. Only when the caller's hint says there are such distros (a hint: without it
@@ -1149,7 +1192,7 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   // distros the LDS path could not take (flagged on the device); the workgroups exit at once otherwise. Not enqueued at all
   // when the caller promises (evg_plan_launch_hints; the host-pointer entry points work it out themselves) that there are none.
   if (!promise) {
-    rc = launch_generic(c, a, in, st);
+    rc = launch_generic(c, a, in, st, st_tiled);
     if (rc) return rc;
   }
   return finish_breakdown(c, a, out, st, d_end < 0 || (d_begin == 0 && d_end == in->n_distros));
@@ -1924,6 +1967,7 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   // ---- the launch hints of the new pool, from its shape (evg_plan_launch_hints's test without the columns) ----
   q.max_distro_tasks = 0; q.promises = 0; q.n_big_tier_distros = 0;
   bool all11 = !pri_wide, all_tiers = !pri_wide;
+  long long nt_tiers = 0, nt_pipe = 0;
   for (int d = 0; d < D; d++) {
     const int n = new_toff[d + 1] - new_toff[d], ntg = tgv[d + 1] - tgv[d], nver = verv[d + 1] - verv[d];
     q.max_distro_tasks = std::max(q.max_distro_tasks, n);
@@ -1932,9 +1976,11 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
     if (tier != 11) all11 = false;
     if (tier == 0) all_tiers = false;
     if (tier == 12 && !pri_wide) q.n_big_tier_distros++;
+    if (tier != 0 && !pri_wide) nt_tiers += n; else if (n > kRT) nt_pipe += n;
   }
   if (all11) q.promises |= EVG_PROMISE_ALL_ON_LDS_PATH;
   if (all_tiers) q.promises |= EVG_PROMISE_ALL_ON_LDS_TIERS;
+  if (std::min(nt_tiers, nt_pipe) * 8 >= (long long)NN && NN > 0) q.promises |= EVG_HINT_MIXED_POOL;
   return EVG_OK;
 }
 

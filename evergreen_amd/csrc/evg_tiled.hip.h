@@ -185,7 +185,12 @@ __device__ __forceinline__ long long wave_scan_sum(long long v, int lane) {
   return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
 }
 
-__global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passes_launched) {
+__device__ __forceinline__ int lds_tier_of(const PlanArgs& a, int d);  // evg_plan_lds.hip.h: the tier that plans distro d, from its shape
+
+// by_shape: the pipeline runs BESIDE the one-workgroup tiers (launch_plan): which distros are its own is then decided from the
+// distro's shape -- the tiers' own test -- instead of from the flags the tier kernels leave. A distro a tier rejects for its DATA
+// (a priority beyond int32) is then nobody's here and falls to k_plan_generic, like a distro the pipeline itself finds unfit.
+__global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passes_launched, int by_shape) {
   __shared__ int s_rt[1024], s_st[1024];  // exclusive prefixes: row tiles / slot tiles before thread t's distros
   __shared__ long long s_w[3][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -198,7 +203,14 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
     if (d >= a.d1) break;
     TState t{};
     const int n = a.in.task_off[d + 1] - a.in.task_off[d];
-    if (a.w_generic[d] && n > kRT && n < kTiledMaxRows) {
+    bool mine;
+    if (by_shape) {
+      const int tier = n > kRT ? lds_tier_of(a, d) : 11;
+      mine = tier == 0 || (tier == 12 && !a.big_tier);
+    } else {
+      mine = a.w_generic[d] != 0;
+    }
+    if (mine && n > kRT && n < kTiledMaxRows) {
       const int ntg = a.in.tg_off[d + 1] - a.in.tg_off[d], nver = a.in.ver_off[d + 1] - a.in.ver_off[d];
       const int S = a.in.distros[d].group_versions ? ntg + nver : n + ntg;
       const int n_rt = (n + kRT - 1) / kRT, n_st = (S + kST - 1) / kST;

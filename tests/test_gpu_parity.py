@@ -479,6 +479,32 @@ def test_promise_all_on_lds_path(native_ctx, oracle):
     _full_compare(native_ctx, oracle, b, "wide priority", validity=False)
 
 
+def test_mixed_pool_hint_never_changes_the_plan(native_ctx, oracle):
+    """EVG_HINT_MIXED_POOL (evg_plan_launch_hints: both the one-workgroup tiers and the large-distro pipeline have an eighth of the
+    tasks or more) makes the library run the pipeline's launches BESIDE the tiers' on a second stream, deciding the pipeline's
+    distros by shape instead of by the tier kernels' flags. Same plan with the bit, without it, and on a pool that gets it wrongly."""
+    import torch
+    from evergreen_amd import native, resident
+    dev = torch.device("cuda:0")
+    for cfg, mixed in ((gen.GenConfig(60_000, 24, gen.SEED_BASE + 31, skew=True), True), (gen.config(5, n_tasks=150_000, n_distros=12), False),
+                       (gen.cliff_config(8, 4096, base=2), False), (gen.GenConfig(40_000, 30, 77, sizes=tuple([9_000, 3_000] + [1_000] * 28)), True)):
+        b = gen.generate(cfg)
+        if cfg.sizes is not None and mixed:  # a wide priority in a LARGE distro and in a small one: rejected for their data, not their shape
+            b.cols["priority"][5] = 2**40
+            b.cols["priority"][int(b.task_off[3]) + 1] = 2**41
+        mx, pr, nb = native.launch_hints(b)
+        assert bool(pr & abi.EVG_HINT_MIXED_POOL) == mixed, (cfg, pr)
+        want = oracle.plan(b, breakdown=True, n_units=False)
+        want.n_units = None
+        for bits in (pr, pr & ~abi.EVG_HINT_MIXED_POOL, pr | abi.EVG_HINT_MIXED_POOL):
+            pool = resident.ResidentPool(native_ctx, b, dev, breakdown=True)
+            pool.inp.promises = bits
+            pool.plan()
+            pool.plan()
+            compare.assert_plan_equal(pool.plan_result(), want, b, "mixed-pool hint %#x on %r" % (bits, cfg))
+        assert native_ctx.take_device_status() == abi.EVG_OK
+
+
 def test_false_promise_is_reported_not_silently_wrong(native_ctx, oracle):
     """A batch passed to a *_device entry point with EVG_PROMISE_ALL_ON_LDS_PATH although one distro holds more than 2048 tasks
     (a false promise used to give a wrong plan with EVG_OK): the planner workgroup of that distro records it in the
@@ -635,7 +661,7 @@ def test_false_tiers_promise_is_reported(native_ctx, oracle):
     b = gen.generate(gen.GenConfig(9_000, 3, 9911))
     b.cols["priority"][int(b.task_off[1]) + 17] = 2**40
     mx, pr, nb = native.launch_hints(b)
-    assert pr == 0 and nb == 2
+    assert (pr & ~abi.EVG_HINT_MIXED_POOL) == 0 and nb == 2  # (no promise; the hint bit says a third of the tasks left the tiers)
     pool = resident.ResidentPool(native_ctx, b, torch.device("cuda:0"), breakdown=False, n_units=False)
     pool.inp.promises, pool.inp.n_big_tier_distros = abi.EVG_PROMISE_ALL_ON_LDS_TIERS, 3
     pool.plan()
