@@ -75,6 +75,7 @@ class PoolDelta(C.Structure):  # evg_pool_delta
                 ("relinked_edges", _p), ("relinked_to", _p)]
 
 
+EVG_HINT_NO_TIER_DISTROS = 0x200
 EVG_HINT_MIXED_POOL = 0x100  # travels in evg_plan_input.promises; never changes a plan (include/evg_sched.h)
 EVG_ABI_MAJOR, EVG_ABI_MINOR = 3, 1
 

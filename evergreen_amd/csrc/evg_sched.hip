@@ -850,6 +850,7 @@ int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, i
   if (!any) *promises |= EVG_PROMISE_ALL_ON_LDS_PATH;
   if (!any_none) *promises |= EVG_PROMISE_ALL_ON_LDS_TIERS;
   if (std::min(nt, np) * 8 >= (long long)in->tasks.n_tasks && in->tasks.n_tasks > 0) *promises |= EVG_HINT_MIXED_POOL;
+  if (nt == 0 && np > 0 && np == (long long)in->tasks.n_tasks) *promises |= EVG_HINT_NO_TIER_DISTROS;
   return EVG_OK;
 }
 
@@ -1056,7 +1057,7 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
 // st_tiled: the stream of the pipeline's own kernels (list .. merge passes). When it is not `st`, the pipeline runs BESIDE the
 // one-workgroup tiers: the caller forked st_tiled before it launched them, k_tiled_list decides by shape, and k_plan_generic -- on
 // `st`, which by then carries the tiers -- waits for the pipeline through ev_join2.
-static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st, hipStream_t st_tiled) {
+static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in, hipStream_t st, hipStream_t st_tiled, int by_shape = -1) {
   using namespace evg;
   const int D = a.d1 - a.d0;
   const dim3 gg(D < kGenericGrid ? D : kGenericGrid), bb(kBlock);
@@ -1072,7 +1073,7 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
   // + 8: the XCD-aware tile mapping (xcd_tile) rounds the tile count up to a multiple of the 8 XCDs
   const dim3 rt((unsigned)tiled_max_row_tiles(in) + 8), stl((unsigned)tiled_max_slot_tiles(in) + 8), tb(kTiledBlock);
   const hipStream_t t = st_tiled;
-  hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, t, a, passes, t != st ? 1 : 0);
+  hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, t, a, passes, by_shape >= 0 ? by_shape : t != st ? 1 : 0);
   hipLaunchKernelGGL(k_tiled_scatter, rt, tb, 0, t, a);
   hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, t, a);
   hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, t, a);
@@ -1131,6 +1132,14 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   // distro -- so they are enqueued FIRST, on the context's high-priority side stream, and run beside the small tier's launch;
   // the large-distro pipeline behind waits for both. Only when the caller's hint says there are such distros (a hint: without it
   // they take the pipeline, with the same result); TaskPlan.Len() needs the small tier's RICH kernel or the generic one.
+  // EVG_HINT_NO_TIER_DISTROS: nothing for the tiers to do -- their launches are skipped and k_tiled_list marks every distro as
+  // left to the kernels behind (w_generic), which is all the tier kernels would have done
+  const bool skip_tiers = tiled && (in->promises & EVG_HINT_NO_TIER_DISTROS) && !c->profile;
+  if (skip_tiers) {
+    rc = launch_generic(c, a, in, st, st, 2);
+    if (rc) return rc;
+    return finish_breakdown(c, a, out, st, d_end < 0 || (d_begin == 0 && d_end == in->n_distros));
+  }
   bool promise = (in->promises & EVG_PROMISE_ALL_ON_LDS_PATH) != 0;
   int n_big = promise || out->n_units || c->big_mode == 0 ? 0 : in->n_big_tier_distros;
   if (n_big > D) n_big = D;
@@ -1981,6 +1990,7 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   if (all11) q.promises |= EVG_PROMISE_ALL_ON_LDS_PATH;
   if (all_tiers) q.promises |= EVG_PROMISE_ALL_ON_LDS_TIERS;
   if (std::min(nt_tiers, nt_pipe) * 8 >= (long long)NN && NN > 0) q.promises |= EVG_HINT_MIXED_POOL;
+  if (nt_tiers == 0 && nt_pipe > 0 && nt_pipe == (long long)NN) q.promises |= EVG_HINT_NO_TIER_DISTROS;
   return EVG_OK;
 }
 

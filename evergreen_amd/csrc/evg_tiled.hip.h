@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
     if (d >= a.d1) break;
     TState t{};
     const int n = a.in.task_off[d + 1] - a.in.task_off[d];
+    if (by_shape == 2) a.w_generic[d] = 1;  // the tier kernels were not launched (EVG_HINT_NO_TIER_DISTROS): every distro is left to what follows
     bool mine;
     if (by_shape) {
       const int tier = n > kRT ? lds_tier_of(a, d) : 11;

@@ -202,6 +202,10 @@ typedef struct evg_plan_input {
  * tiers have nothing to do, and on a pool of small distros with one large one, where the chip is full). Set by
  * evg_plan_launch_hints. */
 #define EVG_HINT_MIXED_POOL 0x100
+/* Another hint in the same word (ABI 3.1): NO distro of the batch fits a one-workgroup tier (BASELINE config 5: every distro has
+ * 19.5 k tasks). The tiers' launches -- workgroups that would all exit at once -- are then not enqueued and the large-distro
+ * pipeline starts at once; a distro that does fit after all is planned by the generic kernel (slowly, correctly). */
+#define EVG_HINT_NO_TIER_DISTROS 0x200
 
 /* ---- outputs -------------------------------------------------------------------------------- */
 

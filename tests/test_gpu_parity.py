@@ -494,9 +494,13 @@ def test_mixed_pool_hint_never_changes_the_plan(native_ctx, oracle):
             b.cols["priority"][int(b.task_off[3]) + 1] = 2**41
         mx, pr, nb = native.launch_hints(b)
         assert bool(pr & abi.EVG_HINT_MIXED_POOL) == mixed, (cfg, pr)
+        # EVG_HINT_NO_TIER_DISTROS (the tiers' launches are skipped): only the pool whose distros are all large gets it; set wrongly,
+        # the distros that would have fit a tier are planned by the generic kernel -- slowly, identically
+        assert bool(pr & abi.EVG_HINT_NO_TIER_DISTROS) == (cfg.n_distros == 12), (cfg, pr)
         want = oracle.plan(b, breakdown=True, n_units=False)
         want.n_units = None
-        for bits in (pr, pr & ~abi.EVG_HINT_MIXED_POOL, pr | abi.EVG_HINT_MIXED_POOL):
+        for bits in (pr, pr & ~(abi.EVG_HINT_MIXED_POOL | abi.EVG_HINT_NO_TIER_DISTROS), pr | abi.EVG_HINT_MIXED_POOL,
+                     (pr | abi.EVG_HINT_NO_TIER_DISTROS) & ~abi.EVG_PROMISE_ALL_ON_LDS_TIERS):
             pool = resident.ResidentPool(native_ctx, b, dev, breakdown=True)
             pool.inp.promises = bits
             pool.plan()
