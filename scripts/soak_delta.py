@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Randomised soak of the resident pool's structural deltas: pools of random shape (tests/random_shapes.py), optionally with sparse,
+unordered keys (gen.sparsify_keys); each is cut into (pool0, delta) with random late / gone fractions (tests/pool_delta.py), loaded,
+brought forward by evg_pool_apply_delta -- then by a value update and a SECOND structural delta (the buffers swap back) -- and
+planned; every plan against the oracle on the host restatement's batch. GPU box only.
+usage: scripts/soak_delta.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from evergreen_amd import gen, native
+from tests import compare, oracle_lib, pool_delta, random_shapes
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260923
+rng = np.random.default_rng(seed)
+ctx, oracle = native.Context(0), oracle_lib.OracleBackend()
+t_end, k, tasks = time.time() + budget, 0, 0
+while time.time() < t_end:
+    cfg = random_shapes.draw(rng, k, max_tasks=250_000)
+    full = gen.generate(cfg)
+    if rng.random() < 0.4:
+        full = gen.sparsify_keys(full, seed=int(rng.integers(1, 1 << 30)))
+    late, gone = float(rng.choice([0.0, 0.01, 0.05, 0.3])), float(rng.choice([0.0, 0.01, 0.05, 0.3]))
+    pool0, d1, _, _ = pool_delta.split_tick(full, late, gone, seed=int(rng.integers(1, 1 << 30)), grow_keys=bool(rng.random() < 0.5))
+    tag = "%r late %.2f gone %.2f" % (cfg, late, gone)
+    ctx.pool_load(pool0)
+    ctx.pool_apply_delta(**d1.kwargs())
+    pool1 = pool_delta.apply_delta(pool0, d1)
+    got = ctx.pool_plan(pool1, pool1.now_ns, breakdown=False, n_units=False, units=True)
+    want = oracle.plan(pool1, breakdown=True, n_units=False)
+    want.n_units = None
+    got.breakdown = got.expand_breakdown()
+    compare.assert_plan_equal(got, want, pool1, tag)
+    # a value update, then a second delta that only removes
+    if pool1.n_tasks > 20:
+        rows = rng.choice(pool1.n_tasks, size=max(pool1.n_tasks // 10, 1), replace=False).astype(np.int32)
+        pri = rng.integers(0, 100, len(rows)).astype(np.int64)
+        ctx.pool_update(rows=rows, cols={"priority": pri})
+        pool1.cols["priority"][rows] = pri
+        _, d2, _, _ = pool_delta.split_tick(pool1, 0.0, float(rng.choice([0.02, 0.2])), seed=int(rng.integers(1, 1 << 30)), grow_keys=False)
+        ctx.pool_apply_delta(**d2.kwargs())
+        pool2 = pool_delta.apply_delta(pool1, d2)
+        got2 = ctx.pool_plan(pool2, pool2.now_ns + 15 * 10**9, breakdown=False, n_units=False)
+        import dataclasses
+        want2 = oracle.plan(dataclasses.replace(pool2, now_ns=pool2.now_ns + 15 * 10**9), breakdown=False, n_units=False)
+        want2.breakdown, want2.n_units = None, None
+        compare.assert_plan_equal(got2, want2, pool2, tag + " (second delta)")
+    k += 1
+    tasks += full.n_tasks
+print("soak_delta: %d pools, %d tasks, every plan after a structural delta equal to the oracle on the restated batch" % (k, tasks))
