@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Randomised soak: pools of random shape (tests/random_shapes.py) through the resident tick -- two calls or the one-launch
-entry point, unit rows on or off -- against the oracle and the reference-validity checker, for a time budget. GPU box only.
+"""Randomised soak: pools of random shape (tests/random_shapes.py) through the resident tick (plan + allocate, with and without the
+big-tier hint, unit rows on or off) -- against the oracle and the reference-validity checker, for a time budget. GPU box only.
 usage: scripts/soak_random.py [seconds] [seed] [large]   (large: only distros beyond the LDS path, up to 1.5 M tasks per pool)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

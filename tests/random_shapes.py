@@ -2,8 +2,8 @@
 
 Shared by tests/test_gpu_parity.py (a fixed number of pools) and scripts/soak_random.py (a time budget). Shapes: 3 to 70,000
 tasks per distro with the sizes either side of the LDS path's 2048-task limit and of the large-distro pipeline's tile sizes,
-DAG depth 1-20, 0-100 % task-group tasks, 0-100 % grouped-version distros, Zipf sizes, unshuffled rows; the two calls or the
-one-launch entry point; unit rows on or off."""
+DAG depth 1-20, 0-100 % task-group tasks, 0-100 % grouped-version distros, Zipf sizes, unshuffled rows; with and without the
+big-tier hint; unit rows on or off."""
 import time
 
 import numpy as np
