@@ -155,7 +155,11 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
   }
   // per bucket: evalHostUtilization (:134-205)
   const bool ephemeral = p.provider != 0;
-  int r_new = 0, r_free = 0, r_err = -1;  // results of this thread's first bucket (b == tid) stay in registers
+  // results of this thread's first kReg buckets (b == tid + k BLOCK) stay in registers: the two loops below re-read a bucket's
+  // result, and through the global scratch each re-read is a round trip nothing hides (a 19.5 k-task distro has ~1,100 task
+  // groups: two buckets per thread of the 1024-thread workgroup)
+  constexpr int kReg = 2;
+  int r_new[kReg] = {0, 0}, r_free[kReg] = {0, 0}, r_err[kReg] = {-1, -1};
   for (int b = tid; b < ntg + 1; b += kAllocBlock) {
     const int row = b == 0 ? d : D + tg_lo + (b - 1);
     const evg_group_info gi = a.in.group_info[row];
@@ -164,14 +168,25 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
     double soon = 0.0;
     if (staged && hs.filter) {
       // no counter words for this many buckets: walk the records only if the filter says the bucket may have hosts
-      if (hs.filter[(b & (kAllocFilterBits - 1)) >> 5] >> (b & 31) & 1u)
-        for (int i = 0; i < nh; i++) {
-          const HostRec r = hs.rec[i];
+      if (hs.filter[(b & (kAllocFilterBits - 1)) >> 5] >> (b & 31) & 1u) {
+        // four independent LDS reads per trip (one record after the other the walk of the "" bucket -- every host of the distro --
+        // was a chain of ~200 dependent round trips); the sum stays in host order
+        auto take = [&](const HostRec& r) {
           const bool mine = r.key == want_key;
           n_hosts_b += mine ? 1 : 0;
           n_free_b += mine && (r.flags & EVG_HF_FREE) ? 1 : 0;
           soon += mine ? r.term : 0.0;
+        };
+        int i = 0;
+        for (; i + 4 <= nh; i += 4) {
+          HostRec r[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) r[k] = hs.rec[i + k];
+#pragma unroll
+          for (int k = 0; k < 4; k++) take(r[k]);
         }
+        for (; i < nh; i++) take(hs.rec[i]);
+      }
     } else if (staged) {
       // counts were taken while staging; the fp64 sum must follow host order (the canonical order), so the one
       // thread of the bucket walks the 16-byte records -- 4 independent LDS reads per trip, +0.0 for other buckets
@@ -236,7 +251,8 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
       }
       if (err > 0) atomicMin(&s_i[4], b);
     }
-    if (b == tid) { r_new = n_new; r_free = n_free; r_err = err; }
+    if (b == tid) { r_new[0] = n_new; r_free[0] = n_free; r_err[0] = err; }
+    else if (b == tid + kAllocBlock) { r_new[1] = n_new; r_free[1] = n_free; r_err[1] = err; }
     else { a.w_new[row] = n_new; a.w_free[row] = n_free; a.w_err[row] = err; }  // re-read by this same thread below
   }
   __syncthreads();
@@ -247,11 +263,12 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
   int t_new = 0, t_free = 0;
   for (int b = tid; b < ntg + 1; b += kAllocBlock) {
     const int row = b == 0 ? d : D + tg_lo + (b - 1);
-    const int err = b == tid ? r_err : a.w_err[row];
+    const int kk = b == tid ? 0 : b == tid + kAllocBlock ? 1 : -1;
+    const int err = kk == 0 ? r_err[0] : kk == 1 ? r_err[1] : a.w_err[row];
     if (b == first_err) s_i[5] = err;
     if (err != 0 || b > first_err) continue;
-    t_new += b == tid ? r_new : a.w_new[row];
-    t_free += b == tid ? r_free : a.w_free[row];
+    t_new += kk == 0 ? r_new[0] : kk == 1 ? r_new[1] : a.w_new[row];
+    t_free += kk == 0 ? r_free[0] : kk == 1 ? r_free[1] : a.w_free[row];
   }
   ALLOC_STAMP(4);
   if (t_new) atomicAdd(&s_i[1], t_new);
@@ -261,10 +278,11 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
   for (int b = tid; b < ntg + 1; b += kAllocBlock) {
     if (b == 0) continue;
     const int row = D + tg_lo + (b - 1);
-    const int err = b == tid ? r_err : a.w_err[row];
+    const int kk = b == tid ? 0 : b == tid + kAllocBlock ? 1 : -1;
+    const int err = kk == 0 ? r_err[0] : kk == 1 ? r_err[1] : a.w_err[row];
     if (err != 0 || b > first_err) continue;
-    a.in.group_info[row].count_free = b == tid ? r_free : a.w_free[row];
-    a.in.group_info[row].count_required = b == tid ? r_new : a.w_new[row];
+    a.in.group_info[row].count_free = kk == 0 ? r_free[0] : kk == 1 ? r_free[1] : a.w_free[row];
+    a.in.group_info[row].count_required = kk == 0 ? r_new[0] : kk == 1 ? r_new[1] : a.w_new[row];
   }
   if (tid == 0) {
     if (first_err != 0x7FFFFFFF) {
