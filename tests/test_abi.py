@@ -167,7 +167,11 @@ def test_plan_launch_hints_on_host(lib):
     big = gen.generate(gen.GenConfig(6000, 2, 5, with_hosts=False))          # 3000 tasks per distro: the 4096-task tier's
     assert hints(big) == (3000, abi.EVG_PROMISE_ALL_ON_LDS_TIERS, 2)
     huge = gen.generate(gen.GenConfig(12_000, 2, 5, with_hosts=False))       # 6000 per distro: neither tier
-    assert hints(huge) == (6000, 0, 0)
+    assert hints(huge) == (6000, abi.EVG_HINT_NO_TIER_DISTROS, 0)            # no promise; the hint: nothing for the tiers to do
+    two = gen.generate(gen.GenConfig(12_000, 4, 5, with_hosts=False, sizes=(6000, 2000, 2000, 2000)))
+    assert hints(two) == (6000, abi.EVG_HINT_MIXED_POOL, 0)                  # the tiers and the pipeline both hold an eighth of the tasks
+    lone = gen.generate(gen.GenConfig(60_000, 28, 5, with_hosts=False, sizes=tuple([6000] + [2000] * 27)))
+    assert hints(lone) == (6000, 0, 0)                                       # one large distro in 60,000 tasks: a tenth, not a mix
     mixed = gen.generate(gen.GenConfig(12_000, 4, 4243, skew=True, with_hosts=False))
     n = np.diff(mixed.task_off)
     assert hints(mixed)[2] <= int(((n > 2048) & (n <= 4096)).sum()) + int((n <= 2048).sum())
