@@ -531,14 +531,27 @@ def main():
     barrier()
     elapsed_k = time.perf_counter() - t1
 
+    # resident shards (N > 1): every rank keeps its distro range's columns from the last broadcast and the tick is plan + allocate +
+    # the gather to rank 0 -- the shape a scheduler would run that moves only deltas between ticks (evg_pool_update /
+    # evg_pool_apply_delta per rank) instead of the whole pool
+    elapsed_r = 0.0
+    if dist is not None and not args.weak:
+        barrier()
+        t2 = time.perf_counter()
+        for k in range(args.steps):
+            pool.plan_allocate()
+            pool.gather()
+        barrier()
+        elapsed_r = time.perf_counter() - t2
+
     my_tasks = float(pool.layout.N if args.weak else 0)
-    red = torch.tensor([elapsed, elapsed_k, my_tasks], dtype=torch.float64, device=dev)
+    red = torch.tensor([elapsed, elapsed_k, my_tasks, elapsed_r], dtype=torch.float64, device=dev)
     if dist is not None:
         mx = red.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = red.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, elapsed_k, sum_tasks = float(mx[0]), float(mx[1]), float(sm[2])
+        elapsed, elapsed_k, sum_tasks, elapsed_r = float(mx[0]), float(mx[1]), float(sm[2]), float(mx[3])
     else:
         sum_tasks = my_tasks
     total_tasks = sum_tasks if args.weak else float(pool.layout.N)
@@ -599,6 +612,10 @@ def main():
             "kernel_only": {"value": total_tasks * args.steps / elapsed_k, "unit": "tasks/s", "ms_per_step": elapsed_k / args.steps * 1e3,
                             "what": "the same steps without the broadcast and the gather (every rank plans + allocates its range), max over ranks"},
         }
+        if elapsed_r > 0:
+            line["resident_shards"] = {"value": total_tasks * args.steps / elapsed_r, "unit": "tasks/s", "ms_per_step": elapsed_r / args.steps * 1e3,
+                                       "what": "the same steps without the broadcast: every rank's distro range stays resident in its HBM (only deltas "
+                                               "would move between ticks), plan + allocate + the grouped gather to rank 0, max over ranks"}
         # roofline of the dominant kernel (k_plan_distros) over rank 0's distro range, from the HIP events of the timed region
         try:
             full = ctx.plan(batch, breakdown=True, n_units=True)  # host-pointer call: n_units + breakdown for the checks below

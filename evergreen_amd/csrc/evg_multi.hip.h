@@ -348,6 +348,11 @@ int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input
   if (alloc && (alloc->n_distros != in->n_distros || alloc->n_task_groups != in->n_task_groups || !alloc->params || !alloc->host_off ||
                 alloc->hosts.n_hosts < 0 || alloc->host_off[0] != 0 || alloc->host_off[in->n_distros] != alloc->hosts.n_hosts))
     return merr(m, EVG_E_INVALID, "evg_multi_load: the allocator input does not describe the same batch");
+  if (in->n_distros == 0) {  // nothing to plan: a tick is a no-op, the results are empty (the offset tables may be NULL)
+    m->lay = Layout{};
+    m->loaded = true;
+    return EVG_OK;
+  }
   int32_t max_distro = 0, promises = 0, n_big = 0;
   rc = evg_plan_launch_hints(in, &max_distro, &promises, &n_big);
   if (rc) return merr(m, rc, "invalid plan input");

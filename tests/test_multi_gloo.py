@@ -57,6 +57,11 @@ def _worker(rank, world, port, cfg, mode, out_path):
         pool.tick()  # a second tick over the resident buffer gives the same result
         if rank == 0:
             _check_rank0(pool, batch, cfg.with_hosts, "sharded x%d %s" % (world, mode))
+        # resident shards (bench.py's `resident_shards`): no pool move-in, every rank plans the range it already holds, then the gather
+        pool.plan_allocate()
+        pool.gather()
+        if rank == 0:
+            _check_rank0(pool, batch, cfg.with_hosts, "resident shards x%d %s" % (world, mode))
         # ---- a NEW pool of the SAME sizes whose content moved: one distro grows past the one-workgroup path's 2048 tasks,
         # so the first pool's EVG_PROMISE_ALL_ON_LDS_PATH, launch hint, ranges and slice bounds are all stale. setup() must
         # refresh them from the new pool's header and tables on every rank.
