@@ -96,7 +96,11 @@ struct Rccl {
       lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (lib) break;
     }
-    if (!lib) { err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?"); return false; }
+    if (!lib) {
+      const char* why = dlerror();  // once: the call clears the message
+      err = std::string("cannot load RCCL: ") + (why ? why : "?");
+      return false;
+    }
     auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("RCCL lacks ") + n; return p; };
     CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
@@ -350,6 +354,8 @@ int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input
     return merr(m, EVG_E_INVALID, "evg_multi_load: the allocator input does not describe the same batch");
   if (in->n_distros == 0) {  // nothing to plan: a tick is a no-op, the results are empty (the offset tables may be NULL)
     m->lay = Layout{};
+    m->o = Outs{};
+    for (Rank& r : m->r) r.d0 = r.d1 = 0;
     m->loaded = true;
     return EVG_OK;
   }
@@ -627,6 +633,7 @@ int evg_multi_poison_outputs(evg_multi* m, int32_t byte) {
   std::lock_guard<std::mutex> lk(m->mu);
   if (!m->loaded) return EVG_E_INVALID;
   for (evgm::Rank& r : m->r) {
+    if (!r.out || !m->o.total) continue;  // an empty batch has no outputs
     EVGM_HIP(m, hipSetDevice(r.device));
     EVGM_HIP(m, hipMemsetAsync(r.out, byte, m->o.total, r.stream));
     EVGM_HIP(m, hipStreamSynchronize(r.stream));

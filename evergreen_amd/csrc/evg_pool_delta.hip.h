@@ -190,8 +190,8 @@ __global__ void __launch_bounds__(256) k_delta_edges(int n_new, const int32_t* s
       j = added_dst[rl];
       info &= EVG_DEP_REQ_MASK;
       fin = 0;
-    } else if (j <= -2) {
-      j = added_dst[-(j + 2)];  // another added row
+    } else if (!kept && j <= -2) {
+      j = added_dst[-(j + 2)];  // another added row (a pool row's edge is -1 or a row: evg_validate_plan_input)
     } else if (j >= 0) {
       const int nj = newrow[j];
       if (nj >= 0) {

@@ -1067,6 +1067,10 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
     HIP_TRY(c, hipGetLastError());
     return EVG_OK;
   }
+  // launch_plan prepares the pipeline's scratch when it expects the pipeline; a caller that keeps EVG_PROMISE_ALL_ON_LDS_TIERS but
+  // names no big-tier distro (or EVG_BIG_TIER=0) arrives here without it: the promise is then not armed and the pipeline plans them
+  if (!a.w_ts)
+    if (int rc = prepare_tiled(c, a, in)) return rc;
   const long long cap = hint < kTiledMaxRows ? hint : kTiledMaxRows - 1;
   int passes = 0;
   while (((long long)kRT << passes) < cap) passes++;

@@ -95,3 +95,22 @@ def test_plan_only_pool_and_errors(oracle):
         native.MultiContext([0, 0])  # RCCL wants distinct devices: refused before any communicator is built
     with pytest.raises(native.NativeError):
         native.MultiContext([99])
+
+
+@pytest.mark.parametrize("n,d,world", [(3_000, 3, 5), (3, 5, 4), (0, 3, 2)], ids=["3-distros-x5", "empty-distros-x4", "no-tasks-x2"])
+def test_more_ranks_than_work(oracle, n, d, world):
+    """Ranks whose distro range is empty (more devices than distros), distros without tasks, a pool without tasks: an empty range
+    plans nothing, sends nothing and the gathered result is still the whole plan."""
+    b = gen.generate(gen.GenConfig(n, d, gen.SEED_BASE + 900 + n + d, with_hosts=True))
+    for scatter in (False, True):
+        m = native.MultiContext([0] * world, scatter=scatter, units=True, loopback=True)
+        try:
+            m.load(b)
+            rg = m.ranges()
+            assert rg[0][0] == 0 and rg[-1][1] == d and all(a[1] == c[0] for a, c in zip(rg, rg[1:]))
+            m.poison_outputs()
+            m.tick()
+            want, want_alloc = _want(oracle, b)
+            _check(m, b, want, want_alloc, "multi loopback x%d over %d tasks in %d distros" % (world, n, d))
+        finally:
+            m.close()

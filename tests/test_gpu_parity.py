@@ -644,7 +644,9 @@ def test_big_tier_beside_the_small_tier(native_ctx, oracle):
         want = oracle.plan(b, breakdown=False, n_units=False)
         want.breakdown, want.n_units = None, None
         want_alloc = oracle.allocate(b, want.distro_info, want.group_info)
-        for promises, count in ((pr, nb), (0, nb), (0, 0), (0, nb + 3), (0, max(nb - 1, 0))):
+        # (pr, 0): the promise without a count is not armed -- the grown distros take the pipeline, whose scratch launch_plan did not
+        # expect to need
+        for promises, count in ((pr, nb), (0, nb), (0, 0), (0, nb + 3), (0, max(nb - 1, 0)), (pr, 0)):
             pool = resident.ResidentPool(native_ctx, b, dev, breakdown=False, n_units=False)
             pool.inp.promises, pool.inp.n_big_tier_distros = promises, count
             pool.step()
@@ -654,6 +656,28 @@ def test_big_tier_beside_the_small_tier(native_ctx, oracle):
             compare.assert_plan_equal(pool.plan_result(), want, b, tag)
             compare.assert_alloc_equal(pool.alloc_result(), want_alloc, tag)
             del pool
+
+
+def test_big_tier_switched_off(oracle, monkeypatch):
+    """EVG_BIG_TIER=0 (the A/B knob of scripts/bench_cliff.py): a context that never launches the 4096-task tier plans the same pool
+    through the small tier + the large-distro pipeline, whatever the hints promise."""
+    import torch
+    from evergreen_amd import native, resident
+    monkeypatch.setenv("EVG_BIG_TIER", "0")
+    ctx = native.Context(0)
+    try:
+        b = gen.generate(gen.cliff_config(8, 4096, n_distros=64))
+        want = oracle.plan(b, breakdown=False, n_units=False)
+        want.breakdown, want.n_units = None, None
+        pool = resident.ResidentPool(ctx, b, torch.device("cuda:0"), breakdown=False, n_units=False)
+        assert pool.inp.promises & abi.EVG_PROMISE_ALL_ON_LDS_TIERS and pool.inp.n_big_tier_distros == 8
+        pool.plan()
+        torch.cuda.synchronize()
+        assert ctx.take_device_status() == abi.EVG_OK
+        compare.assert_plan_equal(pool.plan_result(), want, b, "EVG_BIG_TIER=0")
+        del pool
+    finally:
+        ctx.close()
 
 
 def test_false_tiers_promise_is_reported(native_ctx, oracle):
