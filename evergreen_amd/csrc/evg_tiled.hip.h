@@ -9,11 +9,13 @@
 //   T0 k_tiled_list     which flagged distros take this path; their row tiles (2048 rows) and slot tiles (1024 unit slots)
 //   T1 k_tiled_scatter  per row tile: columns in (coalesced), checkDependenciesMet per row (deps_met / wait_ns out), the
 //                       standalone row of GetDistroQueueInfo reduced per workgroup; every unit membership (row -> unit,
-//                       planner.go:434-456) becomes a 32-byte RECORD appended to the bucket of the slot tile that owns the
-//                       unit. Buckets are counted and placed with LDS atomics only; the bucket table goes to memory.
+//                       planner.go:434-456) becomes a 4-byte RECORD (slot in the tile, flags, row in the source tile)
+//                       appended to the bucket of the slot tile that owns the unit. Buckets are counted and placed with LDS
+//                       atomics only; the bucket table goes to memory.
 //   T2 k_tiled_reduce   per slot tile: its 1024 unit slots' Unit.info accumulators (planner.go:302-337) and, for task-group
-//                       slots, the TaskGroupInfo sums (scheduler.go:78-160) live in 64 KB of LDS; the records of every
-//                       source tile are streamed in and applied with LDS atomics; unitInfo.value() per slot
+//                       slots, the TaskGroupInfo sums (scheduler.go:78-160) live in 44 KB of LDS; the records of every
+//                       source tile are streamed in, each one's four accumulands gathered by row from the source tile's
+//                       columns (16 KB a column: cache hits) and applied with LDS atomics; unitInfo.value() per slot
 //   T3 k_tiled_elect    per row tile: each row's emitting unit (TaskPlan.Export's first-occurrence dedup, planner.go:462-481),
 //                       ONE 192-bit key [value desc | unit min row | unit slot | TaskList.Less key | row] per row -- the
 //                       final queue order is the plain ascending order of these keys -- and the tile sorted in LDS: the
@@ -105,16 +107,16 @@ __device__ __forceinline__ K192 lds_get(const K192* buf, int t, int e) {
 }
 
 // ---- membership record -----------------------------------------------------------------------------------------
-// w0: bits 0-9 slot inside the destination tile | 10-15 unit flags (UF_* >> 24) | 16 carries queue info (the row's own
-// task-group slot) | 17 counted (!IncludesDependencies || depsMet) | 18 depsMet && merge-queue task | 19 wait over the
-// plain target time | 20 wait over min(target, merge-queue target)
-struct __attribute__((aligned(16))) TRec {
-  int64_t tiq, dur;
-  uint32_t w0, row;
-  int32_t pri, nd;
-};
-static_assert(sizeof(TRec) == 32, "record layout");
+// One 32-bit word: bits 0-9 slot inside the destination tile | 10-15 unit flags (UF_* >> 24) | 16 carries queue info (the row's
+// own task-group slot) | 17 counted (!IncludesDependencies || depsMet) | 18 depsMet && merge-queue task | 19 wait over the plain
+// target time | 20 wait over min(target, merge-queue target) | 21-31 the row inside its row tile (the bucket says which tile).
+// (Rounds 2-4 carried the row's four accumulands in the record -- 32 bytes, 74 MB written and read back per config-5-share plan,
+// a quarter of the pipeline's traffic; the reducer now gathers them from the source tile's columns, which the scatter workgroup
+// of the same XCD has just read.)
+typedef uint32_t TRec;
 constexpr uint32_t RW_QI = 1u << 16, RW_COUNT = 1u << 17, RW_MQ = 1u << 18, RW_WAIT_HI = 1u << 19, RW_WAIT_LO = 1u << 20;
+constexpr int RW_ROW_SHIFT = 21;
+static_assert(kST <= (1 << 10) && kRT <= (1 << (32 - RW_ROW_SHIFT)), "record layout");
 
 // What the kernels of the pipeline keep per distro. Zeroed / initialised by k_tiled_list.
 struct TState {
@@ -272,8 +274,7 @@ __global__ void __launch_bounds__(1024) k_tiled_list(const PlanArgs a, int passe
 }
 
 // ---- T1: rows -> records ---------------------------------------------------------------------------------------
-struct RowMem {  // what pass 2 keeps of a row in registers (it re-reads the four accumuland columns: 20 registers instead of 44
-                 // for the thread's four rows, which is what lets three workgroups share a CU)
+struct RowMem {  // what pass 2 keeps of a row in registers
   int32_t t0, t1, e0, e1;
   uint32_t bits;  // unit flags (UF_* >> 24) << 10 | RW_* of the row's own task-group record | RM_LIVE | RM_OWN
 };
@@ -557,16 +558,11 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
     const int i = tile * kRT + k * kTiledBlock + tid;
     const bool any = !(m.bits & RM_OWN) || m.e1 > m.e0;  // a stand-alone row without dependencies emits nothing
     if (!any) continue;
-    // the row's Unit.info contribution (planner.go:302-337), from its columns again
-    const int r = lo + i;
-    const int64_t qts = t.queue_ts_ns[r], dur = t.expected_duration_ns[r], pri64 = t.priority[r];
-    const int32_t nd0 = t.num_dependents[r];
-    const int64_t tiq = qts == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, qts);
-    const int32_t pri = pri64 > 0 ? (int32_t)pri64 : 0, nd = nd0 > 0 ? nd0 : 0;
     const uint32_t uf10 = m.bits & (0x3Fu << 10), qi = m.bits & (RW_QI | RW_COUNT | RW_MQ | RW_WAIT_HI | RW_WAIT_LO);
+    const uint32_t rbits = (uint32_t)(i - tile * kRT) << RW_ROW_SHIFT;
     auto emit = [&](int sl, uint32_t bits) {
       const int pos = atomicAdd(&s_cnt[sl / kST], 1);
-      rec[pos] = TRec{tiq, dur, (uint32_t)(sl % kST) | bits, (uint32_t)i, pri, nd};
+      rec[pos] = (uint32_t)(sl % kST) | bits | rbits;
     };
     if (!(m.bits & RM_OWN)) emit(m.t0, uf10 | ((UF_DISTRO >> 24) << 10) | qi);  // SetDistro only via the primary key (planner.go:447)
     if (m.t1 >= 0) emit(m.t1, uf10);
@@ -620,30 +616,43 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     mine = b.y;
     my_base = rec_region(a, c, tid) + b.x;
   }
-  // ---- init: a stand-alone row's own unit starts with that row (plain stores); everything else empty ----
-  for (int u = tid; u < ns; u += kTiledBlock) {
-    const int su = s0 + u;
-    int64_t tq = 0, du = 0;
-    int32_t mp = 0, mn = 0;
-    uint32_t cw = 0, mr = 0xFFFFFFFFu;
-    if (!c.gv && su < c.n) {
-      const int r = c.lo + su;
-      if (t.tg_key[r] < 0) {
-        const uint32_t f = t.flags[r];
-        const int64_t qts = t.queue_ts_ns[r], pri = t.priority[r];
-        const int32_t nd = t.num_dependents[r];
-        const uint32_t rc = f & EVG_TF_REQ_MASK;
-        tq = qts == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, qts);
-        du = t.expected_duration_ns[r];
-        mp = pri > 0 ? (int32_t)pri : 0;
-        mn = nd > 0 ? nd : 0;
-        mr = (uint32_t)su;
+  // ---- init: a stand-alone row's own unit starts with that row (plain stores); everything else empty. The columns of both of
+  // a thread's slots are fetched at once and whether or not the row turns out to be a task-group task (two dependent round trips
+  // per slot before, in a workgroup whose life is a chain of seven) ----
+  constexpr int kIU = (kST + kTiledBlock - 1) / kTiledBlock;
+  {
+    int32_t i_tg[kIU], i_nd[kIU];
+    uint32_t i_f[kIU];
+    int64_t i_q[kIU], i_p[kIU], i_d[kIU];
+    bool i_row[kIU];
+#pragma unroll
+    for (int q = 0; q < kIU; q++) {
+      const int su = s0 + tid + q * kTiledBlock;
+      i_row[q] = tid + q * kTiledBlock < ns && !c.gv && su < c.n;
+      const int r = c.lo + (i_row[q] ? su : 0);
+      i_tg[q] = t.tg_key[r]; i_f[q] = t.flags[r]; i_q[q] = t.queue_ts_ns[r]; i_p[q] = t.priority[r]; i_nd[q] = t.num_dependents[r];
+      i_d[q] = t.expected_duration_ns[r];
+    }
+#pragma unroll
+    for (int q = 0; q < kIU; q++) {
+      const int u = tid + q * kTiledBlock;
+      if (u >= ns) continue;
+      int64_t tq = 0, du = 0;
+      int32_t mp = 0, mn = 0;
+      uint32_t cw = 0, mr = 0xFFFFFFFFu;
+      if (i_row[q] && i_tg[q] < 0) {
+        const uint32_t f = i_f[q], rc = f & EVG_TF_REQ_MASK;
+        tq = i_q[q] == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, i_q[q]);
+        du = i_d[q];
+        mp = i_p[q] > 0 ? (int32_t)i_p[q] : 0;
+        mn = i_nd[q] > 0 ? i_nd[q] : 0;
+        mr = (uint32_t)(s0 + u);
         cw = 1u | UF_DISTRO | UF_NONGROUP | (rc == EVG_TF_REQ_MERGE ? UF_MERGE : rc == EVG_TF_REQ_PATCH ? UF_PATCH : 0u) |
              ((f & EVG_TF_GENERATE) ? UF_GENERATE : 0u) | ((f & EVG_TF_STEPBACK) ? UF_STEPBACK : 0u);
       }
+      m_tiq[u] = tq; m_dur[u] = du; m_maxpri[u] = mp; m_cnt[u] = cw; m_maxnd[u] = mn; m_minrow[u] = mr;
+      g_dur[u] = 0; g_dover[u] = 0; g_cnt[u] = 0; g_cover[u] = 0; g_wait[u] = 0; g_mq[u] = 0;
     }
-    m_tiq[u] = tq; m_dur[u] = du; m_maxpri[u] = mp; m_cnt[u] = cw; m_maxnd[u] = mn; m_minrow[u] = mr;
-    g_dur[u] = 0; g_dover[u] = 0; g_cnt[u] = 0; g_cover[u] = 0; g_wait[u] = 0; g_mq[u] = 0;
   }
   TT_MARK(16);
   if (tid < n_rt) s_base[tid] = my_base;
@@ -653,9 +662,10 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
   TT_MARK(17);
   const int total = s_pref[n_rt];
   const TRec* recs = (const TRec*)a.w_rec;
-  constexpr int kRB = 3;  // records per thread in flight: their loads are issued together
+  constexpr int kRB = 3;  // records per thread in flight: their loads are issued together, then their rows' gathers
   for (int x0 = tid; x0 < total; x0 += kRB * kTiledBlock) {
    TRec rb[kRB];
+   int rrow[kRB];  // the record's row in the distro (-1: past the end)
 #pragma unroll
    for (int q = 0; q < kRB; q++) {
     const int x = x0 + q * kTiledBlock;
@@ -664,29 +674,41 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
       const int mid = (l + h) >> 1;
       if (s_pref[mid] <= x) l = mid; else h = mid;
     }
-    if (x < total) rb[q] = recs[s_base[l] + (x - s_pref[l])];
+    rb[q] = 0; rrow[q] = -1;
+    if (x < total) { rb[q] = recs[s_base[l] + (x - s_pref[l])]; rrow[q] = l * kRT; }
+   }
+   // the row's Unit.info contribution (planner.go:302-337) from its columns
+   int64_t c_qts[kRB], c_dur[kRB], c_pri[kRB];
+   int32_t c_nd[kRB];
+#pragma unroll
+   for (int q = 0; q < kRB; q++) {
+    if (rrow[q] >= 0) rrow[q] += (int)(rb[q] >> RW_ROW_SHIFT);
+    const int r = c.lo + (rrow[q] >= 0 ? rrow[q] : 0);
+    c_qts[q] = t.queue_ts_ns[r]; c_dur[q] = t.expected_duration_ns[r]; c_pri[q] = t.priority[r]; c_nd[q] = t.num_dependents[r];
    }
 #pragma unroll
    for (int q = 0; q < kRB; q++) {
-    if (x0 + q * kTiledBlock >= total) continue;
-    const TRec r = rb[q];
-    const int u = (int)(r.w0 & 0x3FFu);
-    atomicAdd((unsigned long long*)&m_tiq[u], (unsigned long long)r.tiq);
-    atomicAdd((unsigned long long*)&m_dur[u], (unsigned long long)r.dur);
-    atomicMax(&m_maxpri[u], r.pri);
-    atomicMax(&m_maxnd[u], r.nd);
+    if (rrow[q] < 0) continue;
+    const uint32_t w0 = rb[q];
+    const int64_t tiq = c_qts[q] == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, c_qts[q]), dur = c_dur[q];
+    const int32_t pri = c_pri[q] > 0 ? (int32_t)c_pri[q] : 0, nd = c_nd[q] > 0 ? c_nd[q] : 0;
+    const int u = (int)(w0 & 0x3FFu);
+    atomicAdd((unsigned long long*)&m_tiq[u], (unsigned long long)tiq);
+    atomicAdd((unsigned long long*)&m_dur[u], (unsigned long long)dur);
+    atomicMax(&m_maxpri[u], pri);
+    atomicMax(&m_maxnd[u], nd);
     atomicAdd(&m_cnt[u], 1u);
-    atomicOr(&m_cnt[u], ((r.w0 >> 10) & 0x3Fu) << 24);
-    atomicMin(&m_minrow[u], r.row);
-    if (r.w0 & RW_QI) {
+    atomicOr(&m_cnt[u], ((w0 >> 10) & 0x3Fu) << 24);
+    atomicMin(&m_minrow[u], (uint32_t)rrow[q]);
+    if (w0 & RW_QI) {
       atomicOr(&g_wait[u], 0x80000000u);  // the group has a task in this queue: its TaskGroupInfo row exists (scheduler.go:98-112)
-      if (r.w0 & RW_COUNT) {
+      if (w0 & RW_COUNT) {
         atomicAdd(&g_cnt[u], 1u);
-        atomicAdd((unsigned long long*)&g_dur[u], (unsigned long long)r.dur);
-        if (r.dur > T) { atomicAdd(&g_cover[u], 1u); atomicAdd((unsigned long long*)&g_dover[u], (unsigned long long)r.dur); }
+        atomicAdd((unsigned long long*)&g_dur[u], (unsigned long long)dur);
+        if (dur > T) { atomicAdd(&g_cover[u], 1u); atomicAdd((unsigned long long*)&g_dover[u], (unsigned long long)dur); }
       }
-      if (r.w0 & wait_bit) atomicAdd(&g_wait[u], 1u);
-      if (r.w0 & RW_MQ) atomicAdd(&g_mq[u], 1u);
+      if (w0 & wait_bit) atomicAdd(&g_wait[u], 1u);
+      if (w0 & RW_MQ) atomicAdd(&g_mq[u], 1u);
     }
    }
   }
