@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
     const int r = lo + i;
     const int tgk = t.tg_key[r], verk = t.version_key[r];
     const uint32_t f = t.flags[r];
-    const int64_t pri = t.priority[r], dur = t.expected_duration_ns[r], qts = t.queue_ts_ns[r];
+    const int64_t pri = t.priority[r], dur = t.expected_duration_ns[r];
     const int32_t nd = t.num_dependents[r], tgo = t.task_group_order[r];
     const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
     const int64_t dmt = t.deps_met_ts_ns[r], sched = t.scheduled_ts_ns[r];
