@@ -52,7 +52,7 @@ constexpr int kTiledBlock = 512;
 #define EVG_STAGE_BATCH 7  // edges per thread whose loads the staging loops of T1 / T3 issue together
 #endif
 constexpr int kTileEdges = 6144;      // dependency edges of one row tile resolved edge-parallel in LDS (more: per row, from memory)
-// PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs; every variant is bit-exact, scripts/r03_modes.sh): 1, 2 = the per-row forms of
+// PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs; every variant is bit-exact through the GPU suite): 1, 2 = the per-row forms of
 // round 2; 32 = every thread stores its own keys
 constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2;  // 16: linear tile mapping (xcd_tile)
 
