@@ -92,6 +92,29 @@ def test_self_edge_and_cycle_vectors(oracle):
     _check_against_object(packed, res, [items])
 
 
+NEW_VECTORS = ("outside_dependency_in_queue", "dependency_without_a_node", "root_tasks_keep_queue_order")
+
+
+@pytest.mark.parametrize("name", NEW_VECTORS)
+def test_missing_node_and_root_order_vectors(oracle, name):
+    """TestAddingEdgeWithMissingNodes (:716-881): two tasks of one task group (TaskGroupOrder 2 and 1) that depend on a third task --
+    in the queue, then finished and gone from it (a dependency without a node adds no edge, addEdge :854-856): the order holds every
+    queued task, the group's unit is ordered by GroupIndex ("3" is handed out before "2", :818-824).
+    TestFindNextTaskRespectsQueueOrderForRootTasks (:1267-1337): root tasks keep the queue's order."""
+    v = VEC[name]
+    items = _items(v["items"])
+    disp = H.basicCachedDAGDispatcherImpl("distro_0")
+    disp.rebuild(items)
+    assert [it.Id for it in disp.sorted] == v["sorted"] and disp.cycles == 0
+    packed, res = _oracle_rebuild(oracle, [items])
+    assert [items[int(q)].Id for q in res.distro_sorted(packed.batch.task_off, 0)] == v["sorted"] and int(res.n_cycles[0]) == 0
+    if "group_tasks" in v:
+        (su,) = disp.taskGroups.values()
+        assert [t.Id for t in su.tasks] == v["group_tasks"]
+        assert [items[int(q)].Id for q in res.group_tasks(0)] == v["group_tasks"]
+    _check_against_object(packed, res, [items])
+
+
 def _random_queue(rng, d, n, cyclic):
     items = []
     for i in range(n):
@@ -210,13 +233,19 @@ def test_hip_rebuild_host_pointer_form(native_ctx, oracle):
     """evg_rebuild_dispatchers: rebuild(items) from host memory -- the reference's vectors and random graphs with cycles."""
     rng = np.random.default_rng(3)
     queues = [_items(VEC["constructor"]["items"]), _items(VEC["single_host_group_ordering"]["items"]), _items(VEC["self_edge"]["items"]),
-              _items(VEC["dependency_cycle"]["items"]), [], _random_queue(rng, 20, 300, True), _random_queue(rng, 21, 700, False)]
+              _items(VEC["dependency_cycle"]["items"]), [], _random_queue(rng, 20, 300, True), _random_queue(rng, 21, 700, False)] + \
+             [_items(VEC[k]["items"]) for k in NEW_VECTORS]
     packed, want = _oracle_rebuild(oracle, queues)
     b = packed.batch
     got = native_ctx.dispatch_order(b)
     _assert_same(got, want, b.task_off, b.n_distros, int(b.tg_off[-1]))
     assert [queues[0][int(q)].Id for q in got.distro_sorted(b.task_off, 0)] == VEC["constructor"]["sorted"]
     assert [queues[1][int(q)].Id for q in got.group_tasks(int(b.tg_off[1]))] == VEC["single_host_group_ordering"]["group_tasks"]
+    for k, name in enumerate(NEW_VECTORS):
+        d = 7 + k
+        assert [queues[d][int(q)].Id for q in got.distro_sorted(b.task_off, d)] == VEC[name]["sorted"], name
+        if "group_tasks" in VEC[name]:
+            assert [queues[d][int(q)].Id for q in got.group_tasks(int(b.tg_off[d]))] == VEC[name]["group_tasks"], name
 
 
 @pytest.mark.gpu
