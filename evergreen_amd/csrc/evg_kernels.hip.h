@@ -72,6 +72,8 @@ struct PlanArgs {
   void *w_keyA, *w_keyB;       // 192-bit sort keys, ping-pong
   unsigned long long* w_gfirst;  // [D + n_tg] (first queue position << 32) | TaskGroupMaxHosts of that task
   unsigned long long* w_tgbit;   // one bit per row of every row tile: the row is a task-group task
+  void* w_unit;                  // [slots] TUnit {TotalValue, unit min row}: what k_tiled_elect gathers per candidate unit, one 16-byte load
+  void* w_acc;                   // [N] TAcc: a row's four Unit.info accumulands side by side, what k_tiled_reduce gathers per record
   int32_t tiled_mode;            // TM_* bits (EVG_TILED_MODE; 0 = default)
   uint32_t* w_status;            // host-visible status word of the context (evg_take_device_status), or nullptr: set to 1 by a
                                  // planner workgroup that cannot plan its distro although the batch promised it could

@@ -406,7 +406,7 @@ struct evg_ctx {
   std::mutex mu;
   hipStream_t stream = nullptr;  // used by the host-pointer entry points
   // scratch of the large-distro path + allocator
-  std::vector<DevBuf> scratch = std::vector<DevBuf>(48);  // 0-23 planner, 24-27 allocator, 28 dispatcher, 32-41 tiled path
+  std::vector<DevBuf> scratch = std::vector<DevBuf>(48);  // 0-23 planner, 24-27 allocator, 28 dispatcher, 32-44 tiled path
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
@@ -937,6 +937,7 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.w_key = c->scratch[21].p;
   a.w_ts = nullptr; a.w_rtile = nullptr; a.w_stile = nullptr; a.w_ntile = nullptr; a.w_bucket = nullptr; a.w_rec = nullptr;
   a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr; a.w_tgbit = nullptr;
+  a.w_unit = nullptr; a.w_acc = nullptr;
   a.tiled_mode = c->tiled_mode;
   a.big_tier = 0;
   a.w_status = (in->promises & EVG_PROMISE_ALL_ON_LDS_PATH) ? c->status_word : nullptr;  // launch_plan arms it for ALL_ON_LDS_TIERS
@@ -1026,9 +1027,11 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
   const size_t G = D + (size_t)in->n_task_groups;
   const size_t max_rt = tiled_max_row_tiles(in), max_st = tiled_max_slot_tiles(in);
   const size_t st_cap = std::min<size_t>(max_st, kMaxST);  // slot tiles of ONE distro
-  const size_t sz[11] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
-                         4 * (E + 1), sizeof(K192) * max_rt * kRT, sizeof(K192) * max_rt * kRT, 8 * G, 8 * max_rt * (kRT / 64)};
-  for (int i = 0; i < 11; i++) {
+  const size_t Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions + 1;
+  const size_t sz[13] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
+                         4 * (E + 1), sizeof(K192) * max_rt * kRT, sizeof(K192) * max_rt * kRT, 8 * G, 8 * max_rt * (kRT / 64),
+                         sizeof(TUnit) * Stot, sizeof(TAcc) * (N + 1)};
+  for (int i = 0; i < 13; i++) {
     int rc = ensure(c, c->scratch[32 + i], sz[i]);
     if (rc) return rc;
   }
@@ -1037,6 +1040,7 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
   a.w_eslot = (int32_t*)c->scratch[38].p; a.w_keyA = c->scratch[39].p; a.w_keyB = c->scratch[40].p;
   a.w_gfirst = (unsigned long long*)c->scratch[41].p;
   a.w_tgbit = (unsigned long long*)c->scratch[42].p;
+  a.w_unit = c->scratch[43].p; a.w_acc = c->scratch[44].p;
   if (!c->tiled_attr_set) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledReduceLds));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_elect, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
@@ -1078,6 +1082,7 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
   const dim3 rt((unsigned)tiled_max_row_tiles(in) + 8), stl((unsigned)tiled_max_slot_tiles(in) + 8), tb(kTiledBlock);
   const hipStream_t t = st_tiled;
   hipLaunchKernelGGL(k_tiled_list, dim3(1), dim3(1024), 0, t, a, passes, by_shape >= 0 ? by_shape : t != st ? 1 : 0);
+  hipLaunchKernelGGL(k_tiled_rowkey, rt, tb, 0, t, a);
   hipLaunchKernelGGL(k_tiled_scatter, rt, tb, 0, t, a);
   hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, t, a);
   hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, t, a);

@@ -118,6 +118,27 @@ constexpr uint32_t RW_QI = 1u << 16, RW_COUNT = 1u << 17, RW_MQ = 1u << 18, RW_W
 constexpr int RW_ROW_SHIFT = 21;
 static_assert(kST <= (1 << 10) && kRT <= (1 << (32 - RW_ROW_SHIFT)), "record layout");
 
+// A unit as k_tiled_elect meets it: TotalValue (INT64_MIN: dropped, planner.go:81) and the unit's smallest member row, side by
+// side -- one 16-byte gather per candidate unit where two arrays were two L1 misses (round 4's L1 counters: the elect kernel is
+// bound by the NUMBER of its gather requests, 2.70 M per config-5-share plan, not by their bytes).
+struct __attribute__((aligned(16))) TUnit {
+  int64_t value;
+  uint32_t minrow, pad;
+};
+// A row's contribution to the Unit.info of every unit it is a member of (planner.go:302-337), side by side: one 32-byte gather
+// per membership record in k_tiled_reduce where the four task columns were four L1 misses. Written by k_tiled_scatter, which has
+// the columns in registers.
+struct __attribute__((aligned(32))) TAcc {
+  int64_t tiq, dur;  // time in queue (0 for a task never activated), expected duration
+  int32_t pri, nd;   // max(priority, 0), max(num dependents, 0)
+  uint32_t pad[2];
+};
+// The unit slot of a row and what a dependent's edge needs to know about the row, in ONE word (k_tiled_rowkey writes
+// PlanArgs.w_pslot so): bits 0-20 primary unit slot | 21-22 Task.Status class (EVG_TF_STATUS_*) | 23 Task.Blocked().
+constexpr uint32_t RK_SLOT = 0x1FFFFFu, RK_BLOCKED = 1u << 23;
+constexpr int RK_STATUS_SHIFT = 21;
+static_assert(kTiledMaxSlots <= (int)RK_SLOT + 1, "row key layout");
+
 // What the kernels of the pipeline keep per distro. Zeroed / initialised by k_tiled_list.
 struct TState {
   int32_t on;       // the tiled path plans this distro
@@ -287,24 +308,24 @@ constexpr uint32_t SE_SLOT = 0x1FFFFFu, SE_INQ = 1u << 29, SE_SAT = 1u << 30;
 // What tiled_edge reads about the dependency: two dependent rounds of loads (the edge, then the dependency's row). The
 // edge-parallel staging loops issue each round for a batch of edges before they use any of it.
 struct EdgeIn { int j; uint32_t info; };
-struct EdgeDep { uint32_t fj; int tgj; };
+// The dependency's row key (k_tiled_rowkey): ONE gather per edge. (Rounds 2-4 gathered the dependency's flags and tg_key --
+// and its version_key under GroupVersions -- from the task columns: two or three L1 misses per edge, 3.39 M requests per
+// config-5-share plan in a kernel that waits on exactly those.)
+struct EdgeDep { uint32_t rk; };
 __device__ __forceinline__ EdgeIn edge_fetch(const evg_task_soa& t, const DC& c, int e) { return EdgeIn{t.dep_idx[e] - c.lo, (uint32_t)t.dep_info[e]}; }
-__device__ __forceinline__ EdgeDep edge_gather(const evg_task_soa& t, const DC& c, const EdgeIn& in) {
+__device__ __forceinline__ EdgeDep edge_gather(const uint32_t* rowkey, const DC& c, const EdgeIn& in) {
   const bool inq = (unsigned)in.j < (unsigned)c.n;
-  return EdgeDep{inq ? (uint32_t)t.flags[c.lo + in.j] : 0u, inq ? t.tg_key[c.lo + in.j] : -1};
+  return EdgeDep{inq ? rowkey[c.lo + in.j] : 0u};
 }
-__device__ __forceinline__ uint32_t edge_resolve(const evg_task_soa& t, const DC& c, const EdgeIn& in, const EdgeDep& dep) {
+__device__ __forceinline__ uint32_t edge_resolve(const DC& c, const EdgeIn& in, const EdgeDep& dep) {
   const int j = in.j;
   const uint32_t info = in.info;
   uint32_t st, rec = 0;
   bool blk, known = true;
   if ((unsigned)j < (unsigned)c.n) {
-    const uint32_t fj = dep.fj;
-    const int tgj = dep.tgj;
-    const int verj = c.gv && tgj < 0 ? t.version_key[c.lo + j] : c.ver_lo;
-    st = (fj & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT;
-    blk = fj & EVG_TF_BLOCKED;
-    rec = SE_INQ | (uint32_t)(tgj >= 0 ? c.tg_base + (tgj - c.tg_lo) : c.gv ? c.ver_base + (verj - c.ver_lo) : j);
+    st = (dep.rk >> RK_STATUS_SHIFT) & 3u;
+    blk = dep.rk & RK_BLOCKED;
+    rec = SE_INQ | (dep.rk & RK_SLOT);
   } else {
     st = (info & EVG_DEP_STATE_MASK) >> EVG_DEP_STATE_SHIFT;
     blk = info & EVG_DEP_BLOCKED;
@@ -314,9 +335,32 @@ __device__ __forceinline__ uint32_t edge_resolve(const evg_task_soa& t, const DC
   const bool sat = req == 0 ? st == 1 : req == 1 ? st == 2 : req == 2 ? (st == 1 || st == 2 || blk) : false;
   return rec | (sat && known ? SE_SAT : 0u);
 }
-__device__ __forceinline__ uint32_t tiled_edge(const evg_task_soa& t, const DC& c, int e) {
+__device__ __forceinline__ uint32_t tiled_edge(const evg_task_soa& t, const uint32_t* rowkey, const DC& c, int e) {
   const EdgeIn in = edge_fetch(t, c, e);
-  return edge_resolve(t, c, in, edge_gather(t, c, in));
+  return edge_resolve(c, in, edge_gather(rowkey, c, in));
+}
+
+// ---- T0b: row keys ------------------------------------------------------------------------------------------------
+// A streaming pass over the rows of the pipeline's distros (flags, tg_key and -- under GroupVersions -- version_key in, one
+// word out): 14 B a row, ~5 us for the 1.25 M rows of a config-5 share, for which every dependency edge of the scatter kernel
+// becomes one gather instead of two or three and k_tiled_elect reads a row's primary unit from the same word.
+__global__ void __launch_bounds__(kTiledBlock) k_tiled_rowkey(const PlanArgs a) {
+  const int w = xcd_tile(blockIdx.x, a.w_ntile[0], a.tiled_mode);  // the scatter kernel's mapping: a distro's keys land in the L2 that gathers them
+  if (w < 0) return;
+  const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
+  const DC c = tiled_context(a, d);
+  const evg_task_soa& t = a.in.tasks;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = tile * kRT + k * kTiledBlock + (int)threadIdx.x;
+    if (i >= c.n) continue;
+    const int r = c.lo + i;
+    const int tgk = t.tg_key[r];
+    const uint32_t f = t.flags[r];
+    const int verk = c.gv ? t.version_key[r] : 0;
+    a.w_pslot[r] = (uint32_t)pslot_of(i, tgk, verk, c) | (((f & EVG_TF_STATUS_MASK) >> EVG_TF_STATUS_SHIFT) << RK_STATUS_SHIFT) |
+                   ((f & EVG_TF_BLOCKED) ? RK_BLOCKED : 0u);
+  }
 }
 
 __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs a) {
@@ -355,11 +399,11 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
         in[q] = x < E1 - E0 ? edge_fetch(t, c, E0 + x) : EdgeIn{-1, 0u};
       }
 #pragma unroll
-      for (int q = 0; q < kB; q++) dep[q] = edge_gather(t, c, in[q]);
+      for (int q = 0; q < kB; q++) dep[q] = edge_gather(a.w_pslot, c, in[q]);
 #pragma unroll
       for (int q = 0; q < kB; q++) {
         const int x = x0 + q * kTiledBlock;
-        if (x < E1 - E0) s_edge[x] = edge_resolve(t, c, in[q], dep[q]);
+        if (x < E1 - E0) s_edge[x] = edge_resolve(c, in[q], dep[q]);
       }
     }
   }
@@ -400,7 +444,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
     m.t0 = pslot_of(i, tgk, verk, c);
     m.t1 = c.gv && tgk >= 0 ? c.ver_base + (verk - c.ver_lo) : -1;
     const bool own = !c.gv && tgk < 0;  // its own unit: initialised by the slot tile that holds it (k_tiled_reduce), no record
-    a.w_pslot[r] = (uint32_t)m.t0;
     // ranges of the TaskList.Less columns (planner.go:386-405)
     {
       const uint64_t ud = ub(dur);
@@ -416,7 +459,7 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
     bool all = true;
     int prev0 = -1, prev1 = -1, prev2 = -1, prev3 = -1;  // unit slots the row's last four edges named (-1: none)
     for (int e = e0; e < e1; e++) {
-      const uint32_t rec = eL ? s_edge[e - E0] : tiled_edge(t, c, e);
+      const uint32_t rec = eL ? s_edge[e - E0] : tiled_edge(t, a.w_pslot, c, e);
       all &= (rec & SE_SAT) != 0;
       int sl = (rec & SE_INQ) ? (int)(rec & SE_SLOT) : -1;
       if (sl >= 0) {
@@ -427,8 +470,8 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
         for (int e2 = e0; sl >= 0 && e2 < e - 4; e2++)
           if ((eL ? (int)s_edge[e2 - E0] : a.w_eslot[e2]) == sl) sl = -1;
       }
-      a.w_eslot[e] = sl;
-      if (eL) s_edge[e - E0] = (uint32_t)sl;
+      if (eL) s_edge[e - E0] = (uint32_t)sl;  // out to w_eslot by the sweep behind the row loop: whole lines instead of a word per lane
+      else a.w_eslot[e] = sl;
       prev3 = prev2; prev2 = prev1; prev1 = prev0; prev0 = sl;
       if (sl >= 0) atomicAdd(&s_cnt[sl / kST], 1);
     }
@@ -478,6 +521,10 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
     if (m.t1 >= 0) atomicAdd(&s_cnt[m.t1 / kST], 1);
   }
   TT_MARK(13);
+  if (eL) {  // every row's FINAL slots are in LDS after the barrier below; k_tiled_elect reads them back edge-parallel
+    __syncthreads();
+    for (int x = tid; x < E1 - E0; x += kTiledBlock) a.w_eslot[E0 + x] = (int32_t)s_edge[x];
+  }
   // one bit per row: is it a task-group task? (the tail of the merge classifies the rows it meets in QUEUE order with this -- a
   // 2.4 KB table per 19.5k-row distro that stays in cache -- instead of gathering tg_key by row)
 #pragma unroll
@@ -729,8 +776,7 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
       const uint64_t uv = ub(v);  // range of the valid units' values: k_tiled_elect packs (value, min row, slot) into 64 bits with it
       r_vmin = uv < r_vmin ? uv : r_vmin; r_vmax = uv > r_vmax ? uv : r_vmax;
     }
-    a.w_val[sb + su] = v;
-    a.w_minrow[sb + su] = m_minrow[u];
+    ((TUnit*)a.w_unit)[sb + su] = TUnit{v, m_minrow[u], 0u};
     const int k = su - c.tg_base;
     if (k >= 0 && k < c.ntg) {  // model.TaskGroupInfo of task group k; MaxHosts comes with the queue order (tiled_emit_order)
       evg_group_info gi;
@@ -888,10 +934,10 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
   const int E0 = t.dep_off[c.lo + tile * kRT], E1 = t.dep_off[c.lo + i_end];
   const bool ukl = vb + bmr + bsl <= 63 && !(a.tiled_mode & TM_ROW_ELECT);
   const bool stage = ukl && E1 - E0 <= kTileEdges;
+  const TUnit* units = (const TUnit*)a.w_unit + sb;
   auto ukey = [&](int u) -> uint64_t {
-    const int64_t v = a.w_val[sb + u];
-    const uint32_t mr = a.w_minrow[sb + u];
-    return v == INT64_MIN ? ~0ull : (shl64(vmaxu - ub(v), bmr + bsl) | ((uint64_t)mr << bsl) | (uint64_t)u);
+    const TUnit un = units[u];
+    return un.value == INT64_MIN ? ~0ull : (shl64(vmaxu - ub(un.value), bmr + bsl) | ((uint64_t)un.minrow << bsl) | (uint64_t)u);
   };
   TT_BEGIN();
   // The units the tile's dependency edges name, edge-parallel into LDS (the slots come coalesced, one gather per edge).
@@ -901,23 +947,19 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
     constexpr int kB = EVG_STAGE_BATCH;  // batched like the scatter kernel's staging: slots together, then the units' (value, min row) together
     for (int x0 = tid; x0 < E1 - E0; x0 += kB * kTiledBlock) {
       int sl[kB];
-      int64_t v[kB];
-      uint32_t mr[kB];
+      TUnit un[kB];
 #pragma unroll
       for (int q = 0; q < kB; q++) {
         const int x = x0 + q * kTiledBlock;
         sl[q] = x < E1 - E0 ? a.w_eslot[E0 + x] : -1;
       }
 #pragma unroll
-      for (int q = 0; q < kB; q++) {
-        v[q] = sl[q] >= 0 ? a.w_val[sb + sl[q]] : INT64_MIN;
-        mr[q] = sl[q] >= 0 ? a.w_minrow[sb + sl[q]] : 0u;
-      }
+      for (int q = 0; q < kB; q++) un[q] = sl[q] >= 0 ? units[sl[q]] : TUnit{INT64_MIN, 0u, 0u};
 #pragma unroll
       for (int q = 0; q < kB; q++) {
         const int x = x0 + q * kTiledBlock;
         if (x < E1 - E0)
-          s_uk[x] = v[q] == INT64_MIN ? ~0ull : (shl64(vmaxu - ub(v[q]), bmr + bsl) | ((uint64_t)mr[q] << bsl) | (uint64_t)sl[q]);
+          s_uk[x] = un[q].value == INT64_MIN ? ~0ull : (shl64(vmaxu - ub(un[q].value), bmr + bsl) | ((uint64_t)un[q].minrow << bsl) | (uint64_t)sl[q]);
       }
     }
     __syncthreads();
@@ -937,7 +979,7 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
                         shl64((uint64_t)(pmax - ub((int32_t)t.priority[r])), bd) | (dmax - ub(t.expected_duration_ns[r]));
     int best;
     if (ukl) {
-      uint64_t bk = ukey((int)a.w_pslot[r]);  // the primary unit is always valid: it got its distro from this row
+      uint64_t bk = ukey((int)(a.w_pslot[r] & RK_SLOT));  // the primary unit is always valid: it got its distro from this row
       if (c.gv && tgk >= 0) { const uint64_t x = ukey(c.ver_base + (t.version_key[r] - c.ver_lo)); bk = x < bk ? x : bk; }
       if (stage) {
         for (int e = e0; e < e1; e++) { const uint64_t x = s_uk[e - E0]; bk = x < bk ? x : bk; }
@@ -950,12 +992,13 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
       best = (int)(bk & ((1ull << bsl) - 1ull));
       k[e4] = K192{bk, ik, (uint64_t)i};
     } else {
-      best = (int)a.w_pslot[r];
-      int64_t bv = a.w_val[sb + best];
-      uint32_t bm = a.w_minrow[sb + best];
+      best = (int)(a.w_pslot[r] & RK_SLOT);
+      int64_t bv = units[best].value;
+      uint32_t bm = units[best].minrow;
       auto consider = [&](int u) {
-        const int64_t v = a.w_val[sb + u];  // INT64_MIN for a dropped unit: never better
-        const uint32_t mr = a.w_minrow[sb + u];
+        const TUnit un = units[u];
+        const int64_t v = un.value;  // INT64_MIN for a dropped unit: never better
+        const uint32_t mr = un.minrow;
         const bool better = v > bv || (v == bv && (mr < bm || (mr == bm && u < best)));
         best = better ? u : best; bv = better ? v : bv; bm = better ? mr : bm;
       };
