@@ -55,6 +55,7 @@ constexpr int kTileEdges = 6144;      // dependency edges of one row tile resolv
 // PlanArgs.tiled_mode (EVG_TILED_MODE, A/B runs; every variant is bit-exact through the GPU suite): 1, 2 = the per-row forms of
 // round 2; 32 = every thread stores its own keys
 constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2;  // 16: linear tile mapping (xcd_tile)
+constexpr int TM_KEY192 = 64;                        // keys always travel as 24 bytes (the 20-byte form off)
 
 // blockIdx -> tile, XCD-aware: workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; tile
 // (b % 8) * ceil(T / 8) + b / 8 gives every XCD a contiguous eighth of the tile list, i.e. whole distros. -1: no tile.
@@ -144,6 +145,7 @@ struct TState {
   int32_t on;       // the tiled path plans this distro
   int32_t unfit;    // set on the way: leave it to k_plan_generic after all
   int32_t n_rt, n_st, rt_base, st_base, passes;
+  int32_t key20;    // the distro's sort keys travel in the 20-byte form (k_tiled_elect decides, the merge passes follow)
   long long bucket_base;
   unsigned long long vmin, vmax;                 // biased range of the valid units' TotalValue (k_tiled_reduce)
   unsigned long long dmin, dmax;                 // biased ranges of the TaskList.Less columns
@@ -436,6 +438,10 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
     const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
     const int64_t dmt = t.deps_met_ts_ns[r], sched = t.scheduled_ts_ns[r];
     if (pri != (int64_t)(int32_t)pri) pk |= 1ull << F_WIDE;
+    {  // the row's accumulands for the reducer (a wide priority: the distro goes to k_plan_generic, nobody reads this)
+      const int64_t qts = t.queue_ts_ns[r];
+      ((TAcc*)a.w_acc)[r] = TAcc{qts == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, qts), dur, pri > 0 ? (int32_t)pri : 0, nd > 0 ? nd : 0, {0u, 0u}};
+    }
     const uint32_t rc = f & EVG_TF_REQ_MASK;
     uint32_t uf = rc == EVG_TF_REQ_MERGE ? UF_MERGE : rc == EVG_TF_REQ_PATCH ? UF_PATCH : 0u;
     uf |= tgk < 0 ? UF_NONGROUP : 0u;
@@ -724,21 +730,21 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     rb[q] = 0; rrow[q] = -1;
     if (x < total) { rb[q] = recs[s_base[l] + (x - s_pref[l])]; rrow[q] = l * kRT; }
    }
-   // the row's Unit.info contribution (planner.go:302-337) from its columns
-   int64_t c_qts[kRB], c_dur[kRB], c_pri[kRB];
-   int32_t c_nd[kRB];
+   // the row's Unit.info contribution (planner.go:302-337): its TAcc row, one gather (two 16-byte loads of one 32-byte line)
+   int64_t c_tiq[kRB], c_dur[kRB];
+   int32_t c_pri[kRB], c_nd[kRB];
 #pragma unroll
    for (int q = 0; q < kRB; q++) {
     if (rrow[q] >= 0) rrow[q] += (int)(rb[q] >> RW_ROW_SHIFT);
-    const int r = c.lo + (rrow[q] >= 0 ? rrow[q] : 0);
-    c_qts[q] = t.queue_ts_ns[r]; c_dur[q] = t.expected_duration_ns[r]; c_pri[q] = t.priority[r]; c_nd[q] = t.num_dependents[r];
+    const TAcc* ac = (const TAcc*)a.w_acc + (c.lo + (rrow[q] >= 0 ? rrow[q] : 0));
+    c_tiq[q] = ac->tiq; c_dur[q] = ac->dur; c_pri[q] = ac->pri; c_nd[q] = ac->nd;
    }
 #pragma unroll
    for (int q = 0; q < kRB; q++) {
     if (rrow[q] < 0) continue;
     const uint32_t w0 = rb[q];
-    const int64_t tiq = c_qts[q] == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, c_qts[q]), dur = c_dur[q];
-    const int32_t pri = c_pri[q] > 0 ? (int32_t)c_pri[q] : 0, nd = c_nd[q] > 0 ? c_nd[q] : 0;
+    const int64_t tiq = c_tiq[q], dur = c_dur[q];
+    const int32_t pri = c_pri[q], nd = c_nd[q];
     const int u = (int)(w0 & 0x3FFu);
     atomicAdd((unsigned long long*)&m_tiq[u], (unsigned long long)tiq);
     atomicAdd((unsigned long long*)&m_dur[u], (unsigned long long)dur);
@@ -827,8 +833,8 @@ constexpr int kTiledSortLds = 3 * 8 * (kRT + kRT / 32);  // three arrays of 64-b
 // other -- ~30 LDS reads and ~150 VALU instructions where the network spends 4 keys x 9..11 stages x ~18. Keys are distinct.
 // field by field: a ?: on the structs makes the compiler park both in scratch memory and load through a selected pointer
 __device__ __forceinline__ K192 key_sel(bool c, const K192& x, const K192& y) { return K192{c ? x.hi : y.hi, c ? x.mid : y.mid, c ? x.lo : y.lo}; }
-template <int ITER>
-__device__ __forceinline__ void merge_path4_k192(K192 (&k)[4], const uint64_t* s_hi, const uint64_t* s_mid, const uint64_t* s_lo, int a0, int la,
+template <int ITER, class LoT = uint64_t>
+__device__ __forceinline__ void merge_path4_k192(K192 (&k)[4], const uint64_t* s_hi, const uint64_t* s_mid, const LoT* s_lo, int a0, int la,
                                                  int b0, int lb, bool b_rev, int diag) {
   auto bi = [&](int j) { return b_rev ? b0 + lb - 1 - j : b0 + j; };
   auto lt = [&](int x, int y) -> bool {  // key at x < key at y
@@ -847,7 +853,7 @@ __device__ __forceinline__ void merge_path4_k192(K192 (&k)[4], const uint64_t* s
     hi = go && !a_first ? mid : hi;
   }
   int ia = lo, ib = diag - lo;
-  auto ld = [&](int x) { return K192{s_hi[x], s_mid[x], s_lo[x]}; };
+  auto ld = [&](int x) { return K192{s_hi[x], s_mid[x], (uint64_t)s_lo[x]}; };
   K192 ka = ld(ia < la ? a0 + ia : a0), kb = ld(ib < lb ? bi(ib) : a0);
 #pragma unroll
   for (int e = 0; e < 4; e++) {
@@ -899,6 +905,32 @@ __device__ __forceinline__ void store_tile_keys(const K192 (&k)[4], K192* dst, i
 #pragma unroll
   for (int q = 0; q < 12; q++) g[q * kTiledBlock + tid] = sw[q * kTiledBlock + tid];
 }
+// ---- the 20-byte key form -------------------------------------------------------------------------------------------
+// With the packed unit word the third key word is just the row (< 2^20), so the keys of such a distro travel between the sort
+// kernels as 8 + 8 + 4 bytes: its share of a key buffer (24 bytes x the distro's padded length P) holds P {unit word, Less key}
+// pairs and, behind them, P 32-bit rows. A merge pass reads and writes 40 bytes per key instead of 48 -- the passes are bound
+// by bytes (round 4: 78.5 MB per pass at 4.2 TB/s). Inside a workgroup (registers, LDS of the tile sort) a key stays a K192.
+struct Keys20 {
+  ulonglong2* hm;   // [P] {hi, mid}
+  uint32_t* row;    // [P]
+};
+__device__ __forceinline__ Keys20 keys20_of(void* buf, const TState* ts) {
+  char* base = (char*)buf + (size_t)ts->rt_base * kRT * sizeof(K192);
+  return Keys20{(ulonglong2*)base, (uint32_t*)(base + (size_t)ts->n_rt * kRT * 16)};
+}
+// A tile's sorted keys (positions 4 tid .. 4 tid + 3 of the 2048 from key `pos0` of the distro on) out: the pairs through LDS as
+// consecutive 64-bit words, the rows as one 16-byte store per thread. smem: 32 KB; barriers inside.
+__device__ __forceinline__ void store_tile_keys20(const K192 (&k)[4], const Keys20& dst, long long pos0, int tid, unsigned char* smem) {
+  __syncthreads();  // whoever still reads the exchange buffer of the last LDS stage
+#pragma unroll
+  for (int e = 0; e < 4; e++) ((ulonglong2*)smem)[tid * 4 + e] = make_ulonglong2(k[e].hi, k[e].mid);
+  __syncthreads();
+  const uint64_t* sw = (const uint64_t*)smem;
+  uint64_t* g = (uint64_t*)(dst.hm + pos0);
+#pragma unroll
+  for (int q = 0; q < 8; q++) g[q * kTiledBlock + tid] = sw[q * kTiledBlock + tid];
+  ((uint4*)(dst.row + pos0))[tid] = make_uint4((uint32_t)k[0].lo, (uint32_t)k[1].lo, (uint32_t)k[2].lo, (uint32_t)k[3].lo);
+}
 static_assert(kTileEdges * 8 <= kTiledSortLds && kRT * (int)sizeof(K192) <= kTiledSortLds, "the staged candidates and the network's exchange buffer share the bytes");
 __device__ __forceinline__ bool tiled_key_bits(const TState* ts, int& bn, int& bp, int& bd) {
   const int bt = bits_of((uint64_t)(ts->tmax - ts->tmin));
@@ -933,6 +965,8 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
   const int i_end = (tile + 1) * kRT < c.n ? (tile + 1) * kRT : c.n;
   const int E0 = t.dep_off[c.lo + tile * kRT], E1 = t.dep_off[c.lo + i_end];
   const bool ukl = vb + bmr + bsl <= 63 && !(a.tiled_mode & TM_ROW_ELECT);
+  const bool key20 = ukl && !(a.tiled_mode & TM_KEY192);  // every workgroup of the distro decides the same
+  if (tile == 0 && tid == 0) ts->key20 = key20 ? 1 : 0;    // for the merge passes (later kernels)
   const bool stage = ukl && E1 - E0 <= kTileEdges;
   const TUnit* units = (const TUnit*)a.w_unit + sb;
   auto ukey = [&](int u) -> uint64_t {
@@ -1021,7 +1055,9 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
   K192* const tile_out = (K192*)a.w_keyA + ((size_t)ts->rt_base + tile) * kRT;
   tile_sort_merge_path(k, tid, smem);
   TT_MARK(10);
-  if (a.tiled_mode & 32) {  // A/B: every thread stores its own four keys
+  if (key20) {
+    store_tile_keys20(k, keys20_of(a.w_keyA, ts), (long long)tile * kRT, tid, smem);
+  } else if (a.tiled_mode & 32) {  // A/B: every thread stores its own four keys
     K192* out = tile_out + tid * 4;
 #pragma unroll
     for (int e4 = 0; e4 < 4; e4++) out[e4] = k[e4];
@@ -1112,6 +1148,89 @@ __device__ __forceinline__ int merge_split(const K192* A, const K192* B, int na,
   return lo < hi ? lo : hi;
 }
 
+// merge_split on the 20-byte form: run A = keys [0, na) of (hmA, rowA), run B likewise.
+__device__ __forceinline__ int merge_split20(const ulonglong2* hmA, const uint32_t* rowA, const ulonglong2* hmB, const uint32_t* rowB, int na, int nb,
+                                             int diag, int lane) {
+  int lo = diag - nb > 0 ? diag - nb : 0, hi = diag < na ? diag : na;
+  while (lo < hi) {
+    const int width = hi - lo, chunk = (width + 63) >> 6;
+    const int idx = lo + lane * chunk + chunk - 1;
+    bool before = false;
+    if (idx < hi) {
+      const ulonglong2 ka = hmA[idx], kb = hmB[diag - 1 - idx];
+      const uint32_t ra = rowA[idx], rb = rowB[diag - 1 - idx];
+      before = !key_lt(K192{kb.x, kb.y, (uint64_t)rb}, K192{ka.x, ka.y, (uint64_t)ra});
+    }
+    const int cnt = __popcll(__ballot(before));
+    const int nlo = lo + cnt * chunk;
+    const int nhi = nlo + chunk - 1 < hi ? nlo + chunk - 1 : hi;
+    lo = nlo < hi ? nlo : hi;
+    hi = nhi;
+    if (chunk == 1) break;
+  }
+  return lo < hi ? lo : hi;
+}
+
+// One window of one pass over a distro whose keys are in the 20-byte form. Same steps as the 24-byte body of k_tiled_merge below.
+__device__ __forceinline__ void tiled_merge20(const PlanArgs& a, TState* ts, int d, int tile, int pass, unsigned char* smem, int* s_split) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const Keys20 src = keys20_of((pass & 1) ? a.w_keyB : a.w_keyA, ts), dst = keys20_of((pass & 1) ? a.w_keyA : a.w_keyB, ts);
+  const long long P = (long long)ts->n_rt * kRT, L = (long long)kRT << pass;
+  const long long pos0 = (long long)tile * kRT;
+  const long long pair_lo = pos0 / (2 * L) * (2 * L);
+  const long long a_hi = pair_lo + L < P ? pair_lo + L : P, b_hi = pair_lo + 2 * L < P ? pair_lo + 2 * L : P;
+  const int na = (int)(a_hi - pair_lo), nb = (int)(b_hi - a_hi);
+  K192 k[4];
+  if (nb <= 0) {  // a run without a partner: carried over
+    const uint4 r4 = ((const uint4*)(src.row + pos0))[tid];
+    const uint32_t rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const ulonglong2 p = src.hm[pos0 + tid * 4 + e];
+      k[e] = K192{p.x, p.y, (uint64_t)rr[e]};
+    }
+  } else {
+    const ulonglong2 *hmA = src.hm + pair_lo, *hmB = src.hm + a_hi;
+    const uint32_t *rowA = src.row + pair_lo, *rowB = src.row + a_hi;
+    const int diag0 = (int)(pos0 - pair_lo);
+    if (tid < 128) {
+      const int s = merge_split20(hmA, rowA, hmB, rowB, na, nb, diag0 + (tid >> 6) * kRT, lane);
+      if (lane == 0) s_split[tid >> 6] = s;
+    }
+    __syncthreads();
+    const int a0 = s_split[0], a1 = s_split[1];
+    const int b1 = diag0 + kRT - a1, cnt_a = a1 - a0;
+    const int bs = b1 - (kRT - cnt_a);  // the window's first key of run B
+    // the window's two key ranges into LDS by position: a wave's load is 1 KB of consecutive pairs / 256 B of consecutive rows
+    uint64_t *s_hi = (uint64_t*)smem, *s_mid = s_hi + kRT;
+    uint32_t* s_row = (uint32_t*)(s_mid + kRT);
+    ulonglong2 v[4];
+    uint32_t r[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int x = q * kTiledBlock + tid;
+      v[q] = x < cnt_a ? hmA[a0 + x] : hmB[bs + x - cnt_a];
+      r[q] = x < cnt_a ? rowA[a0 + x] : rowB[bs + x - cnt_a];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int x = q * kTiledBlock + tid;
+      s_hi[x] = v[q].x; s_mid[x] = v[q].y; s_row[x] = r[q];
+    }
+    __syncthreads();
+    merge_path4_k192<12, uint32_t>(k, s_hi, s_mid, s_row, 0, cnt_a, cnt_a, kRT - cnt_a, false, tid * 4);
+    __syncthreads();  // the arrays are re-used below
+  }
+  if (pass == ts->passes - 1) {  // the distro's last pass: the merged keys ARE the queue -- nothing is written back
+    uint32_t i4[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) i4[e] = (uint32_t)(k[e].lo & 0xFFFFFu);
+    tiled_emit_order(a, ts, d, pos0 + tid * 4, i4, a.in.task_off[d + 1] - a.in.task_off[d]);
+    return;
+  }
+  store_tile_keys20(k, dst, pos0, tid, smem);
+}
+
 __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a, int pass) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_split[2];
@@ -1120,6 +1239,10 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a
   const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
   TState* ts = &a.w_ts[d];
   if (!tiled_live(ts) || pass >= ts->passes) return;
+  if (ts->key20) {
+    tiled_merge20(a, ts, d, tile, pass, smem, s_split);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const K192* src = (const K192*)((pass & 1) ? a.w_keyB : a.w_keyA) + (size_t)ts->rt_base * kRT;
   K192* dst = (K192*)((pass & 1) ? a.w_keyA : a.w_keyB) + (size_t)ts->rt_base * kRT;

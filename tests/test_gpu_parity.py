@@ -680,6 +680,34 @@ def test_big_tier_switched_off(oracle, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("mode", [64, 1, 2, 3, 16, 32 | 64], ids=["keys-24-bytes", "per-row-scatter", "per-row-elect", "per-row-both", "linear-tiles",
+                                                                  "own-key-stores"])
+def test_large_distro_pipeline_forms(oracle, monkeypatch, mode):
+    """EVG_TILED_MODE (the A/B knob of scripts/ab_tiled.py) selects forms of the large-distro pipeline that are otherwise taken only by
+    distros of unusual shape: sort keys travelling as 24 bytes instead of 20 (the form of a distro whose unit values do not pack into
+    one word), dependency edges resolved per row instead of staged edge-parallel in LDS (the form of a row tile with more than 6,144
+    edges). Every one plans the same pools bit for bit: a config-5 shape with ragged tile counts, and a grouped-versions Zipf pool."""
+    import torch
+    from evergreen_amd import native, resident
+    monkeypatch.setenv("EVG_TILED_MODE", str(mode))
+    ctx = native.Context(0)
+    try:
+        for cfg, tag in ((gen.config(5, n_tasks=130_000, n_distros=7), "config 5 shape"),
+                         (gen.GenConfig(70_000, 5, 611, skew=True, dag_depth=6, all_tg_version_fraction=0.4), "zipf, grouped versions")):
+            b = gen.generate(cfg)
+            assert int(np.diff(b.task_off).max()) > 4096
+            want = oracle.plan(b, breakdown=False, n_units=False)
+            want.breakdown, want.n_units = None, None
+            pool = resident.ResidentPool(ctx, b, torch.device("cuda:0"), breakdown=False, n_units=False)
+            pool.plan()
+            torch.cuda.synchronize()
+            assert ctx.take_device_status() == abi.EVG_OK
+            compare.assert_plan_equal(pool.plan_result(), want, b, "EVG_TILED_MODE=%d, %s" % (mode, tag))
+            del pool
+    finally:
+        ctx.close()
+
+
 def test_false_tiers_promise_is_reported(native_ctx, oracle):
     """EVG_PROMISE_ALL_ON_LDS_TIERS on a batch whose 3000-task distro holds a priority beyond int32 (the hints never promise that):
     the big tier's workgroup cannot plan it and nothing was enqueued behind -- reported through the status word, like a false
