@@ -132,6 +132,33 @@ def per_distro_calls(batch, native, got, got_alloc, dev_index):
                 c.close()
         out["threads_%d" % nt] = {"wall_ms": wall * 1e3, "tasks_per_s": batch.n_tasks / wall, "us_per_call_pair_p50": float(xs[len(xs) // 2]) * 1e6,
                                   "us_per_call_pair_p99": float(xs[int(len(xs) * 0.99)]) * 1e6, "errors": len(bad)}
+    # ---- the same call shape through the micro-batching front (evg_batcher_*, ABI 3.2): ONE shared batcher, every thread calls
+    # evg_batcher_plan + evg_batcher_allocate per distro; requests that arrive together are planned by one launch sequence ----
+    if hasattr(lib, "evg_batcher_create"):
+        drv.pdc_run_batcher.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p, C.c_size_t] * 4 + [C.c_void_p, C.c_void_p]
+        fb_plan, fb_alloc = C.cast(lib.evg_batcher_plan, C.c_void_p), C.cast(lib.evg_batcher_allocate, C.c_void_p)
+        for r in res:  # the batched results must be produced by the batched calls, not left over from the loops above
+            r.order[:] = -1
+        for nt in (8, 32, 64, 128):
+            bt = native.Batcher(dev_index, max_wait_us=200, max_requests=64)
+            try:
+                def run_b():
+                    lat = np.zeros(D, np.float64)
+                    wall = C.c_double(0)
+                    errs = drv.pdc_run_batcher(fb_plan, fb_alloc, bt.h, nt, D, C.addressof(a_pin), C.sizeof(abi.PlanInput), C.addressof(a_pout),
+                                               C.sizeof(abi.PlanOutput), C.addressof(a_ain), C.sizeof(abi.AllocInput), C.addressof(a_aout),
+                                               C.sizeof(abi.AllocOutput), lat.ctypes.data, C.byref(wall))
+                    return wall.value * 1e-3, np.sort(lat) * 1e-6, errs
+                run_b()
+                walls = [run_b() for _ in range(3)]
+                wall, xs, errs = sorted(walls, key=lambda w: w[0])[1]
+                st = bt.stats()
+            finally:
+                bt.close()
+            out["batcher_threads_%d" % nt] = {"wall_ms": wall * 1e3, "tasks_per_s": batch.n_tasks / wall, "us_per_call_pair_p50": float(xs[len(xs) // 2]) * 1e6,
+                                              "us_per_call_pair_p99": float(xs[int(len(xs) * 0.99)]) * 1e6, "errors": int(errs),
+                                              "requests_per_batch": st["requests"] / max(1, st["batches"]), "largest_batch": st["largest_batch"]}
+        out["batcher"] = "evg_batcher_plan + evg_batcher_allocate on one shared batcher (max_wait_us 200, max_requests 64), median wall of 3 runs"
     try:
         os.unlink(so)
     except OSError:

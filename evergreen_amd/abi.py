@@ -77,7 +77,7 @@ class PoolDelta(C.Structure):  # evg_pool_delta
 
 EVG_HINT_NO_TIER_DISTROS = 0x200
 EVG_HINT_MIXED_POOL = 0x100  # travels in evg_plan_input.promises; never changes a plan (include/evg_sched.h)
-EVG_ABI_MAJOR, EVG_ABI_MINOR = 3, 1
+EVG_ABI_MAJOR, EVG_ABI_MINOR = 3, 2
 
 
 class HostSoa(C.Structure):
@@ -230,7 +230,11 @@ class PlanBatch:
     def one_distro(self, d: int) -> "PlanBatch":
         """Distro d alone as a batch of one: what the reference's per-distro jobs hand to a TaskPlanner / HostAllocator value
         (scheduler.go:26, host_allocator.go:15). Rows, keys, edges and hosts are re-based to start at 0."""
-        r0, r1 = int(self.task_off[d]), int(self.task_off[d + 1])
+        return self.distro_range(d, d + 1)
+
+    def distro_range(self, d: int, d1: int) -> "PlanBatch":
+        """Distros [d, d1) as a batch of their own, re-based to start at 0."""
+        r0, r1 = int(self.task_off[d]), int(self.task_off[d1])
         e0, e1 = int(self.dep_off[r0]), int(self.dep_off[r1])
         g0, v0 = int(self.tg_off[d]), int(self.ver_off[d])
         cols = {k: np.ascontiguousarray(v[r0:r1]) for k, v in self.cols.items()}
@@ -238,15 +242,15 @@ class PlanBatch:
         cols["version_key"] = (cols["version_key"] - v0).astype(np.int32)
         edges = {k: np.ascontiguousarray(v[e0:e1]) for k, v in self.edges.items()}
         edges["dep_idx"] = np.where(edges["dep_idx"] >= 0, edges["dep_idx"] - r0, -1).astype(np.int32)
-        one = lambda a, b: np.array([0, b - a], np.int32)  # noqa: E731
-        b = PlanBatch(n_distros=1, now_ns=self.now_ns, cols=cols, dep_off=(self.dep_off[r0:r1 + 1] - e0).astype(np.int32), edges=edges,
-                      distros=np.ascontiguousarray(self.distros[d:d + 1]), task_off=one(r0, r1), tg_off=one(g0, int(self.tg_off[d + 1])),
-                      ver_off=one(v0, int(self.ver_off[d + 1])),
+        cut = lambda off: (off[d:d1 + 1] - off[d]).astype(np.int32)  # noqa: E731
+        b = PlanBatch(n_distros=d1 - d, now_ns=self.now_ns, cols=cols, dep_off=(self.dep_off[r0:r1 + 1] - e0).astype(np.int32), edges=edges,
+                      distros=np.ascontiguousarray(self.distros[d:d1]), task_off=cut(self.task_off), tg_off=cut(self.tg_off),
+                      ver_off=cut(self.ver_off),
                       tg_name_key=np.ascontiguousarray(self.tg_name_key[r0:r1]) if self.tg_name_key is not None else None)
         if self.alloc_params is not None:
-            h0, h1 = int(self.host_off[d]), int(self.host_off[d + 1])
-            b.alloc_params = np.ascontiguousarray(self.alloc_params[d:d + 1])
-            b.host_off = one(h0, h1)
+            h0, h1 = int(self.host_off[d]), int(self.host_off[d1])
+            b.alloc_params = np.ascontiguousarray(self.alloc_params[d:d1])
+            b.host_off = cut(self.host_off)
             b.hosts = {k: np.ascontiguousarray(v[h0:h1]) for k, v in self.hosts.items()}
             b.hosts["tg_key"] = np.where(b.hosts["tg_key"] >= 0, b.hosts["tg_key"] - g0, b.hosts["tg_key"]).astype(np.int32)
         return b

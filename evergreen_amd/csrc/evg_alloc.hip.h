@@ -12,9 +12,16 @@ namespace evg {
 constexpr int kAllocBlock = 256;
 constexpr int kAllocLdsHosts = 2048;  // hosts of one distro staged in LDS (more: the bucket loop reads global memory)
 
+// What evg_alloc_input holds once per CALL, per distro: a batch of the micro-batching front (evg_batcher.hip.h) is made of several
+// callers' requests, each with its own clock reading and its own large-parser-project figures.
+struct AllocTick {
+  int64_t now_ns;
+  int32_t lpp_limit, lpp_running;
+};
 struct AllocArgs {
   evg_alloc_input in;
   evg_alloc_output out;
+  const AllocTick* tick_d;  // [D] or nullptr (then in.now_ns and the two large-parser-project fields hold for every distro)
   double* w_term;  // [n_hosts] fractional-free term of each running host
   int32_t *w_new, *w_free, *w_err;  // [D + n_tg] per-bucket results; w_err: -1 not evaluated, 0 ok, >0 EVG_ALLOC_E_*
   int32_t d0;  // first distro of this call (evg_allocate_host_range_device; else 0): workgroup b allocates distro d0 + b
@@ -291,10 +298,10 @@ __device__ __forceinline__ void allocate_distro(const AllocArgs& a, int d, const
       int required = s_i[1];
       // adjustForLargeParserProjectLimit (units/host_allocator.go:479-520): what the allocator job does to
       // LengthWithDependenciesMet between reading the queue info and this clamp
-      const int limit = a.in.max_concurrent_large_parser_project_tasks;
+      const int limit = a.tick_d ? a.tick_d[d].lpp_limit : a.in.max_concurrent_large_parser_project_tasks;
       if (limit > 0) {
         const int queued = a.in.distro_info[d].num_queued_large_parser_project_tasks;
-        const int room = limit - a.in.running_large_parser_project_tasks;
+        const int room = limit - (a.tick_d ? a.tick_d[d].lpp_running : a.in.running_large_parser_project_tasks);
         const int blocked = queued - (room > 0 ? room : 0);
         if (queued != 0 && blocked > 0) len_met -= blocked;
       }

@@ -73,11 +73,12 @@ struct PlanArgs {
   unsigned long long* w_gfirst;  // [D + n_tg] (first queue position << 32) | TaskGroupMaxHosts of that task
   unsigned long long* w_tgbit;   // one bit per row of every row tile: the row is a task-group task
   void* w_unit;                  // [slots] TUnit {TotalValue, unit min row}: what k_tiled_elect gathers per candidate unit, one 16-byte load
-  void* w_acc;                   // [N] TAcc: a row's four Unit.info accumulands side by side, what k_tiled_reduce gathers per record
   int32_t tiled_mode;            // TM_* bits (EVG_TILED_MODE; 0 = default)
   uint32_t* w_status;            // host-visible status word of the context (evg_take_device_status), or nullptr: set to 1 by a
                                  // planner workgroup that cannot plan its distro although the batch promised it could
   int32_t big_tier;    // 1: k_plan_distros_big runs beside k_plan_distros and owns w_generic[d] of the tier-12 distros (evg_plan_lds.hip.h)
+  const int64_t* now_d;  // [D] a `now` per distro in place of in.now_ns, or nullptr: the micro-batching front (evg_batcher.hip.h) plans
+                         // requests of several callers in one batch, each with its caller's own clock reading
   int32_t d0, d1;      // the distros this call plans: [d0, d1) of the batch (evg_plan_distro_range_device; else 0, D).
                        // Outputs keep the FULL batch's row / info-row numbering.
 #ifdef EVG_PHASE_TIMING

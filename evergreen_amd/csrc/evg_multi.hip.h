@@ -83,6 +83,7 @@ struct Rccl {
   void* lib = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -106,6 +107,7 @@ struct Rccl {
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     Broadcast = (decltype(Broadcast))sym("ncclBroadcast"); Send = (decltype(Send))sym("ncclSend"); Recv = (decltype(Recv))sym("ncclRecv");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    CommAbort = (decltype(CommAbort))dlsym(lib, "ncclCommAbort");
     if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast || !Send || !Recv || !GetErrorString) { lib = nullptr; return false; }
     return true;
   }
@@ -153,6 +155,8 @@ struct evg_multi {
   std::vector<int64_t> edge_cut;
   size_t n_slots = 0;
   bool timed = false;
+  bool aborted = false;          // evg_multi_abort: the communicators are gone; only evg_multi_destroy is left
+  int inject_rank = -1, inject_phase = -1;  // evg_multi_inject_failure: the next tick fails there (test hook, one shot)
 };
 
 namespace evgm {
@@ -479,15 +483,25 @@ int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input
 
 // One tick over the loaded pool: move-in (broadcast or scatter from rank 0) -> every rank plans + allocates its range -> gather to
 // rank 0; returns when every device is done. Results stay on rank 0's device (evg_multi_results downloads them).
-int evg_multi_tick(evg_multi* m, int64_t now_ns) {
+// The tick proper. Every exit of this function -- the error exits included -- is followed by tick_epilogue: an open RCCL group is
+// closed, every rank's stream is drained and every rank's device status is taken, so that the evg_multi can be used again (round
+// 4's form returned from the middle of ncclGroupStart .. ncclGroupEnd, left ranks below the failing one with work in flight and the
+// ranks above it with a stale status word: the first real failure on eight devices would have wedged it).
+// `group_open` tells the epilogue whether a return happened inside a group, `group_whole` whether everything enqueued in it so far has
+// its counterpart (every send its receive, the broadcast all its ranks): only then can the streams be drained -- a half-issued
+// collective never completes, and the epilogue aborts the communicators instead (the object then needs re-creating). Failure
+// injection (evg_multi_inject_failure) returns an error at the chosen (rank, phase) AFTER that rank's share of the phase was
+// enqueued -- for the move-in and the gather that is inside the open group, at a point where the group is whole.
+static int tick_body(evg_multi* m, int64_t now_ns, bool& group_open, bool& group_whole) {
   using namespace evgm;
-  if (!m) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(m->mu);
-  if (!m->loaded) return merr(m, EVG_E_INVALID, "evg_multi_tick: no pool is loaded");
   const Layout& L = m->lay;
-  if (L.D == 0) return EVG_OK;
   const int n = m->n;
   std::vector<Slice> sl;
+  auto inject = [&](int k, int phase) -> int {
+    if (m->inject_rank != k || m->inject_phase != phase) return EVG_OK;
+    m->inject_rank = m->inject_phase = -1;
+    return merr(m, EVG_E_HIP, "injected failure on rank %d in phase %d (evg_multi_inject_failure)", k, phase);
+  };
   auto mark = [&](int k, int e) -> int {
     if (!m->timed) return EVG_OK;
     EVGM_HIP(m, hipSetDevice(m->r[k].device));
@@ -506,20 +520,33 @@ int evg_multi_tick(evg_multi* m, int64_t now_ns) {
       } else {
         EVGM_HIP(m, hipMemcpyAsync(r.buf, m->r[0].buf, L.total, hipMemcpyDeviceToDevice, r.stream));
       }
+      if (int rc = inject(k, 0)) return rc;
     }
+    if (int rc = inject(0, 0)) return rc;
   } else if (m->flags & EVG_MULTI_SCATTER) {
     EVGM_NCCL(m, g_rccl.GroupStart());
+    group_open = true;
     for (int k = 1; k < n; k++) {
       in_slices(m, k, sl);
       for (const Slice& s : sl) {
+        group_whole = false;
         EVGM_NCCL(m, g_rccl.Send(m->r[0].buf + s.off, s.bytes, ncclUint8, k, m->r[0].comm, m->r[0].stream));
         EVGM_NCCL(m, g_rccl.Recv(m->r[k].buf + s.off, s.bytes, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
+        group_whole = true;
       }
+      if (int rc = inject(k, 0)) return rc;
     }
+    if (int rc = inject(0, 0)) return rc;
+    group_open = false;
     EVGM_NCCL(m, g_rccl.GroupEnd());
   } else {
     EVGM_NCCL(m, g_rccl.GroupStart());
+    group_open = true;
+    group_whole = false;
     for (int k = 0; k < n; k++) EVGM_NCCL(m, g_rccl.Broadcast(m->r[k].buf, m->r[k].buf, L.total, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
+    group_whole = true;
+    for (int k = 0; k < n; k++) if (int rc = inject(k, 0)) return rc;
+    group_open = false;
     EVGM_NCCL(m, g_rccl.GroupEnd());
   }
   for (int k = 0; k < n; k++) if (int rc = mark(k, 1)) return rc;
@@ -529,11 +556,13 @@ int evg_multi_tick(evg_multi* m, int64_t now_ns) {
     r.inp.now_ns = now_ns;
     int rc = evg_plan_distro_range_device(r.ctx, &r.inp, &r.pout, r.d0, r.d1, r.stream);
     if (rc) return merr(m, rc, "rank %d: %s", k, evg_last_error(r.ctx));
+    if (int rci = inject(k, 1)) return rci;
     if (int rc2 = mark(k, 2)) return rc2;
     if (L.has_hosts) {
       r.ainp.now_ns = now_ns;
       rc = evg_allocate_host_range_device(r.ctx, &r.ainp, &r.aout, r.d0, r.d1, r.stream);
       if (rc) return merr(m, rc, "rank %d: %s", k, evg_last_error(r.ctx));
+      if (int rci = inject(k, 2)) return rci;
     }
     if (int rc2 = mark(k, 3)) return rc2;
   }
@@ -544,25 +573,235 @@ int evg_multi_tick(evg_multi* m, int64_t now_ns) {
       EVGM_HIP(m, hipSetDevice(r.device));
       out_slices(m, k, sl);
       for (const Slice& s : sl) EVGM_HIP(m, hipMemcpyAsync(m->r[0].out + s.off, r.out + s.off, s.bytes, hipMemcpyDeviceToDevice, r.stream));
+      if (int rc = inject(k, 3)) return rc;
     }
+    if (int rc = inject(0, 3)) return rc;
   } else if (n > 1) {
     EVGM_NCCL(m, g_rccl.GroupStart());
+    group_open = true;
     for (int k = 1; k < n; k++) {
       out_slices(m, k, sl);
       for (const Slice& s : sl) {
+        group_whole = false;
         EVGM_NCCL(m, g_rccl.Send(m->r[k].out + s.off, s.bytes, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
         EVGM_NCCL(m, g_rccl.Recv(m->r[0].out + s.off, s.bytes, ncclUint8, k, m->r[0].comm, m->r[0].stream));
+        group_whole = true;
       }
+      if (int rc = inject(k, 3)) return rc;  // pairs are matched rank by rank: what was enqueued so far completes
     }
+    if (int rc = inject(0, 3)) return rc;
+    group_open = false;
     EVGM_NCCL(m, g_rccl.GroupEnd());
+  } else if (int rc = inject(0, 3)) {
+    return rc;
   }
   for (int k = 0; k < n; k++) if (int rc = mark(k, 4)) return rc;
-  for (int k = 0; k < n; k++) {
-    EVGM_HIP(m, hipSetDevice(m->r[k].device));
-    EVGM_HIP(m, hipStreamSynchronize(m->r[k].stream));
+  return EVG_OK;
+}
+
+extern "C" int evg_multi_tick(evg_multi* m, int64_t now_ns) {
+  using namespace evgm;
+  if (!m) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (m->aborted) return merr(m, EVG_E_INVALID, "evg_multi_tick: the communicators were aborted (evg_multi_abort): destroy this evg_multi and create a new one");
+  if (!m->loaded) return merr(m, EVG_E_INVALID, "evg_multi_tick: no pool is loaded");
+  if (m->lay.D == 0) return EVG_OK;
+  bool group_open = false, group_whole = true;
+  int first = tick_body(m, now_ns, group_open, group_whole);  // its message is in m->err; the epilogue reports its own failures only when the body had none
+  // ---- epilogue, on every path ----
+  if (group_open) {  // an error inside ncclGroupStart .. ncclGroupEnd: an open group would swallow every later RCCL call of this thread
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (e != ncclSuccess && !first) first = merr(m, EVG_E_HIP, "ncclGroupEnd: %s", g_rccl.GetErrorString(e));
+    if (!group_whole) {  // a send without its receive, a broadcast without all its ranks: it never completes -- the communicators go
+      const std::string why = m->err;
+      m->aborted = true;
+      for (Rank& r : m->r)
+        if (r.comm) {
+          (void)hipSetDevice(r.device);
+          if (g_rccl.CommAbort) (void)g_rccl.CommAbort(r.comm); else (void)g_rccl.CommDestroy(r.comm);
+          r.comm = nullptr;
+        }
+      merr(m, first ? first : EVG_E_HIP, "%s; the RCCL group was left half-issued, the communicators were aborted: destroy this evg_multi and create a new one", why.c_str());
+      if (!first) first = EVG_E_HIP;
+    }
   }
-  for (int k = 0; k < n; k++)
-    if (int rc = evg_take_device_status(m->r[k].ctx)) return merr(m, rc, "rank %d: %s", k, evg_last_error(m->r[k].ctx));
+  for (int k = 0; k < m->n; k++) {  // nothing of this tick is in flight after the return, error or not
+    hipError_t e = hipSetDevice(m->r[k].device);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->r[k].stream);
+    if (e != hipSuccess && !first) first = merr(m, EVG_E_HIP, "rank %d: hipStreamSynchronize: %s", k, hipGetErrorString(e));
+  }
+  for (int k = 0; k < m->n; k++) {  // ALL ranks: a status word left set would fail every later tick with a stale EVG_E_CONTRACT
+    const int rc = evg_take_device_status(m->r[k].ctx);
+    if (rc && !first) first = merr(m, rc, "rank %d: %s", k, evg_last_error(m->r[k].ctx));
+  }
+  return first;
+}
+
+// Test hook: the NEXT evg_multi_tick fails on `rank` in `phase` (0 move-in, 1 plan, 2 allocate, 3 gather) after that rank's share of
+// the phase was enqueued -- inside the open RCCL group for the move-in and the gather. One shot. rank < 0 clears it.
+int evg_multi_inject_failure(evg_multi* m, int32_t rank, int32_t phase) {
+  if (!m || rank >= m->n || phase > 3) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  m->inject_rank = rank < 0 ? -1 : rank;
+  m->inject_phase = rank < 0 ? -1 : phase;
+  return EVG_OK;
+}
+
+// After a tick that did not come back (a peer device lost, a hung collective -- called from another thread) or an RCCL error the
+// caller does not trust: ncclCommAbort on every communicator, so that blocked collectives return, and the object refuses further
+// ticks. The caller destroys it and creates a new one (or goes on with one device). Takes no lock: the thread inside evg_multi_tick
+// holds it.
+int evg_multi_abort(evg_multi* m) {
+  if (!m) return EVG_E_INVALID;
+  m->aborted = true;
+  for (evgm::Rank& r : m->r)
+    if (r.comm) {
+      (void)hipSetDevice(r.device);
+      if (evgm::g_rccl.CommAbort) (void)evgm::g_rccl.CommAbort(r.comm); else (void)evgm::g_rccl.CommDestroy(r.comm);
+      r.comm = nullptr;
+    }
+  return EVG_OK;
+}
+
+// Start-up self-check (the N > 1 path has never met hardware, and a Go scheduler that routes its only planning path
+// through it should know before the first tick): a small generated pool of mixed shape -- small distros, one for the 4096-task
+// tier, one for the large-distro pipeline; task groups, grouped versions, dependencies, hosts -- planned + allocated once on rank 0's
+// device alone (evg_plan_distros / evg_allocate_hosts) and once through evg_multi_load / _tick / _results over all the ranks: every
+// output array must be the same, byte for byte. EVG_OK, or EVG_E_CONTRACT with the first difference in the message (any other code:
+// that call failed). Replaces the loaded pool. shim/gpu_multi.go calls it from SetGPUDevices and stays on one device unless it passes.
+int evg_multi_selftest(evg_multi* m) {
+  using namespace evgm;
+  if (!m) return EVG_E_INVALID;
+  const int n_small = 3 * m->n + 2;
+  std::vector<int32_t> sizes;
+  for (int k = 0; k < n_small; k++) sizes.push_back(150 + 37 * (k % 7));
+  sizes.insert(sizes.begin() + 1, 2600);   // the one-per-CU tier
+  sizes.insert(sizes.begin() + 4, 5200);   // the large-distro pipeline
+  sizes.push_back(0);                      // an empty queue
+  const int D = (int)sizes.size();
+  uint64_t sm = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { sm += 0x9E3779B97F4A7C15ull; uint64_t z = sm; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+  std::vector<int32_t> task_off(D + 1, 0), tg_off(D + 1, 0), ver_off(D + 1, 0), host_off(D + 1, 0);
+  for (int d = 0; d < D; d++) task_off[d + 1] = task_off[d] + sizes[d];
+  const int N = task_off[D];
+  const int64_t now = 1790000000LL * 1000000000LL;
+  std::vector<int64_t> pri(N), dur(N), qts(N), sched(N), dmt(N);
+  std::vector<int32_t> nd(N), tgo(N), tgmh(N), tgk(N), verk(N), dep_off(N + 1, 0), dep_idx;
+  std::vector<uint16_t> flags(N);
+  std::vector<uint8_t> dep_info;
+  std::vector<evg_distro_params> dp(D);
+  std::vector<evg_alloc_params> ap(D);
+  std::vector<uint8_t> hflags;
+  std::vector<int32_t> htgk;
+  std::vector<int64_t> hstart, hexp, hsd;
+  for (int d = 0; d < D; d++) {
+    const int lo = task_off[d], n = sizes[d];
+    const int ntg = n / 40, nver = n / 25 + 1;
+    tg_off[d + 1] = tg_off[d] + ntg; ver_off[d + 1] = ver_off[d] + nver;
+    evg_distro_params& p = dp[d];
+    p = evg_distro_params{};
+    p.patch_factor = 1 + d % 3; p.patch_time_in_queue_factor = 2; p.commit_queue_factor = 3; p.mainline_time_in_queue_factor = 1 + d % 2;
+    p.expected_runtime_factor = 1; p.generate_task_factor = 5; p.stepback_task_factor = 2; p.num_dependents_factor = 0.5 + d % 4;
+    p.target_time_ns = d % 2 ? 0 : 20LL * 60 * 1000000000LL; p.merge_queue_target_time_ns = d % 3 == 0 ? 10LL * 60 * 1000000000LL : 0;
+    p.group_versions = d % 5 == 2; p.includes_dependencies = d % 4 != 1;
+    for (int i = 0; i < n; i++) {
+      const int r = lo + i;
+      const uint64_t x = rnd();
+      pri[r] = (int64_t)(x % 100); dur[r] = (int64_t)(60 + (x >> 8) % 7000) * 1000000000LL;
+      qts[r] = (x >> 20) % 50 == 0 ? EVG_TIME_GO_ZERO : now - (int64_t)((x >> 24) % 90000) * 1000000000LL;
+      sched[r] = now - (int64_t)((x >> 40) % 5000) * 1000000000LL; dmt[r] = (x >> 52) % 3 ? 0 : now - (int64_t)((x >> 44) % 4000) * 1000000000LL;
+      nd[r] = (int32_t)((x >> 12) % 9); tgk[r] = ntg && (x >> 16) % 10 == 0 ? tg_off[d] + (int32_t)((x >> 30) % ntg) : -1;
+      tgo[r] = tgk[r] >= 0 ? 1 + (int32_t)((x >> 36) % 6) : 0; tgmh[r] = tgk[r] >= 0 ? 1 + (int32_t)((x >> 33) % 3) : 0;
+      verk[r] = ver_off[d] + (int32_t)((x >> 48) % nver);
+      flags[r] = (uint16_t)(((x >> 4) % 3) | (((x >> 6) % 17 == 0) ? EVG_TF_GENERATE : 0) | (((x >> 7) % 19 == 0) ? EVG_TF_STEPBACK : 0) |
+                            (((x >> 9) % 23 == 0) ? EVG_TF_S3_STORAGE : 0) | (((x >> 10) % 3) << EVG_TF_STATUS_SHIFT));
+      const int deps = i ? (int)((x >> 56) % 3) : 0;
+      for (int q = 0; q < deps; q++) {
+        const uint64_t y = rnd();
+        const bool inq = y % 4 != 0;
+        dep_idx.push_back(inq ? lo + (int32_t)((y >> 8) % i) : -1);
+        dep_info.push_back((uint8_t)(((y >> 40) % 3) | (inq ? 0 : (((y >> 44) % 3) << EVG_DEP_STATE_SHIFT))));
+      }
+      dep_off[r + 1] = (int32_t)dep_idx.size();
+    }
+    evg_alloc_params& a = ap[d];
+    a = evg_alloc_params{};
+    a.future_host_fraction = 0.5; a.minimum_hosts = d % 3; a.maximum_hosts = 40 + d; a.provider = 1; a.round_up = d % 2; a.feedback_waits_over_thresh = d % 3 == 1;
+    const int nh = 3 + d % 6;
+    for (int h = 0; h < nh; h++) {
+      const uint64_t y = rnd();
+      const bool running = y % 3 != 0;
+      hflags.push_back((uint8_t)(running ? (EVG_HF_RUNNING | EVG_HF_RUNNING_FOUND) : EVG_HF_FREE));
+      htgk.push_back(running && ntg && (y >> 8) % 3 == 0 ? tg_off[d] + (int32_t)((y >> 16) % ntg) : -1);
+      hstart.push_back(now - (int64_t)((y >> 24) % 3000) * 1000000000LL); hexp.push_back((int64_t)(300 + (y >> 36) % 3000) * 1000000000LL);
+      hsd.push_back((int64_t)((y >> 50) % 300) * 1000000000LL);
+    }
+    host_off[d + 1] = (int32_t)hflags.size();
+  }
+  const int E = (int)dep_idx.size(), TG = tg_off[D], V = ver_off[D], G = D + TG, H = (int)hflags.size();
+  if (dep_idx.empty()) { dep_idx.push_back(-1); dep_info.push_back(0); }
+  evg_plan_input in{};
+  in.n_distros = D; in.n_task_groups = TG; in.n_versions = V; in.now_ns = now;
+  in.tasks.n_tasks = N; in.tasks.n_edges = E;
+  in.tasks.priority = pri.data(); in.tasks.expected_duration_ns = dur.data(); in.tasks.queue_ts_ns = qts.data(); in.tasks.scheduled_ts_ns = sched.data();
+  in.tasks.deps_met_ts_ns = dmt.data(); in.tasks.num_dependents = nd.data(); in.tasks.task_group_order = tgo.data(); in.tasks.task_group_max_hosts = tgmh.data();
+  in.tasks.tg_key = tgk.data(); in.tasks.version_key = verk.data(); in.tasks.flags = flags.data(); in.tasks.dep_off = dep_off.data();
+  in.tasks.dep_idx = dep_idx.data(); in.tasks.dep_info = dep_info.data(); in.tasks.dep_finished_ts_ns = nullptr;
+  in.distros = dp.data(); in.task_off = task_off.data(); in.tg_off = tg_off.data(); in.ver_off = ver_off.data();
+  struct Res {
+    std::vector<int32_t> order, uot, nh, fh, st;
+    std::vector<uint8_t> met;
+    std::vector<int64_t> wait, ub;
+    std::vector<evg_distro_info> di;
+    std::vector<evg_group_info> gi;
+  } a, b;
+  const size_t slots = (size_t)N + TG + V;
+  const bool units = (m->flags & EVG_MULTI_UNIT_ROWS) != 0;
+  for (Res* r : {&a, &b}) {
+    r->order.assign(N, -7); r->uot.assign(N, -7); r->met.assign(N, 9); r->wait.assign(N, -7); r->ub.assign(slots * EVG_BREAKDOWN_FIELDS, 0);
+    r->di.assign(D, evg_distro_info{}); r->gi.assign(G, evg_group_info{}); r->nh.assign(D, -7); r->fh.assign(D, -7); r->st.assign(D, -7);
+  }
+  auto outs = [&](Res& r) {
+    evg_plan_output o{};
+    o.order = r.order.data(); o.deps_met = r.met.data(); o.wait_ns = r.wait.data(); o.distro_info = r.di.data(); o.group_info = r.gi.data();
+    if (units) { o.unit_of_task = r.uot.data(); o.unit_breakdown = r.ub.data(); }
+    return o;
+  };
+  evg_alloc_input ai{};
+  ai.n_distros = D; ai.n_task_groups = TG; ai.params = ap.data(); ai.host_off = host_off.data(); ai.tg_off = tg_off.data(); ai.now_ns = now;
+  ai.hosts.n_hosts = H; ai.hosts.flags = hflags.data(); ai.hosts.tg_key = htgk.data(); ai.hosts.start_ts_ns = hstart.data();
+  ai.hosts.expected_duration_ns = hexp.data(); ai.hosts.duration_stddev_ns = hsd.data();
+  // one device
+  evg_plan_output oa = outs(a);
+  int rc = evg_plan_distros(m->r[0].ctx, &in, &oa);
+  if (rc) return merr(m, rc, "evg_multi_selftest: evg_plan_distros on device %d: %s", m->r[0].device, evg_last_error(m->r[0].ctx));
+  ai.distro_info = a.di.data(); ai.group_info = a.gi.data();
+  evg_alloc_output aoa{a.nh.data(), a.fh.data(), a.st.data()};
+  rc = evg_allocate_hosts(m->r[0].ctx, &ai, &aoa);
+  if (rc) return merr(m, rc, "evg_multi_selftest: evg_allocate_hosts on device %d: %s", m->r[0].device, evg_last_error(m->r[0].ctx));
+  // all the ranks
+  rc = evg_multi_load(m, &in, &ai);
+  if (!rc) rc = evg_multi_tick(m, now);
+  evg_plan_output ob = outs(b);
+  evg_alloc_output aob{b.nh.data(), b.fh.data(), b.st.data()};
+  if (!rc) rc = evg_multi_results(m, &ob, &aob);
+  if (rc) return rc;  // the message is the failing call's
+  auto differ = [&](const char* what, const void* x, const void* y, size_t bytes) -> bool {
+    if (!bytes || !memcmp(x, y, bytes)) return false;
+    merr(m, EVG_E_CONTRACT, "evg_multi_selftest: %s planned over %d ranks differs from the plan of one device (%d tasks, %d distros)", what, m->n, N, D);
+    return true;
+  };
+  if (differ("the queue order", a.order.data(), b.order.data(), 4 * (size_t)N) || differ("deps_met", a.met.data(), b.met.data(), (size_t)N) ||
+      differ("wait_ns", a.wait.data(), b.wait.data(), 8 * (size_t)N) || differ("distro_info", a.di.data(), b.di.data(), sizeof(evg_distro_info) * (size_t)D) ||
+      differ("group_info", a.gi.data(), b.gi.data(), sizeof(evg_group_info) * (size_t)G) || differ("new_hosts", a.nh.data(), b.nh.data(), 4 * (size_t)D) ||
+      differ("free_hosts", a.fh.data(), b.fh.data(), 4 * (size_t)D) || differ("the allocator status", a.st.data(), b.st.data(), 4 * (size_t)D) ||
+      (units && differ("unit_of_task", a.uot.data(), b.uot.data(), 4 * (size_t)N)))
+    return EVG_E_CONTRACT;
+  if (units)  // rows of slots that emit no task are unspecified: compare the rows tasks are emitted from
+    for (int r = 0; r < N; r++)
+      for (int f = 0; f < EVG_BREAKDOWN_FIELDS; f++)
+        if (a.ub[(size_t)f * slots + a.uot[r]] != b.ub[(size_t)f * slots + b.uot[r]])
+          return merr(m, EVG_E_CONTRACT, "evg_multi_selftest: the SortingValueBreakdown of row %d (field %d) differs between %d ranks and one device", r, f, m->n);
   return EVG_OK;
 }
 

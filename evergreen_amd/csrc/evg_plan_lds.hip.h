@@ -207,7 +207,7 @@ __device__ __forceinline__ DC distro_context(const PlanArgs& a, int d, int lo, i
   c.ver_lo = a.in.ver_off[d];
   c.nver = a.in.ver_off[d + 1] - c.ver_lo;
   c.gv = a.in.distros[d].group_versions != 0;
-  c.now = a.in.now_ns;
+  c.now = a.now_d ? a.now_d[d] : a.in.now_ns;
   // slot map: !gv: own task units [0,n) then task groups; gv: task groups then versions (no own units)
   if (c.gv) { c.tg_base = 0; c.ver_base = c.ntg; c.S = c.ntg + c.nver; }
   else { c.tg_base = c.n; c.ver_base = c.n + c.ntg; c.S = c.n + c.ntg; }

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(BLOCK) k_allocate_hosts(const AllocArgs a) {
   const int tg_lo = a.in.tg_off[d], ntg = a.in.tg_off[d + 1] - tg_lo;
   const int64_t T = a.in.distro_info[d].max_duration_threshold_ns;
   const int len_met = a.in.distro_info[d].length_with_dependencies_met;
-  const int64_t now = a.in.now_ns;
+  const int64_t now = a.tick_d ? a.tick_d[d].now_ns : a.in.now_ns;
   ALLOC_STAMP(0);
   if (tid < 8) s_i[tid] = tid == 4 ? 0x7FFFFFFF : 0;
   // free hosts of the distro (:33-37) and every running host's fractional-free term (:340-368); the host columns
@@ -406,7 +406,7 @@ struct evg_ctx {
   std::mutex mu;
   hipStream_t stream = nullptr;  // used by the host-pointer entry points
   // scratch of the large-distro path + allocator
-  std::vector<DevBuf> scratch = std::vector<DevBuf>(48);  // 0-23 planner, 24-27 allocator, 28 dispatcher, 32-44 tiled path
+  std::vector<DevBuf> scratch = std::vector<DevBuf>(48);  // 0-23 planner, 24-27 allocator, 28 dispatcher, 32-43 tiled path
   // staging for the host-pointer entry points
   std::vector<DevBuf> stage = std::vector<DevBuf>(48);
   bool lds_attr_set = false;
@@ -443,6 +443,9 @@ struct evg_ctx {
   std::vector<uint8_t> pool_gv;   // PlannerSettings.ShouldGroupVersions() per distro (the shape test of the launch hints)
   bool pool_pri_wide = false;     // some priority does not fit int32: no distro-shape promise holds
   std::vector<uint64_t> seen_bits;  // evg_pool_update's duplicate check: one bit per row / edge
+  // set by the micro-batching front around its own launches (evg_batcher.hip.h): per-distro clock readings / allocator tick rows
+  const int64_t* now_d = nullptr;
+  const void* tick_d = nullptr;
   int tiled_mode = 0;  // EVG_TILED_MODE: TM_* bits (evg_tiled.hip.h), A/B runs of the large-distro pipeline's per-row / pairwise forms
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts = nullptr;
@@ -917,6 +920,7 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.out = *out;
   a.d0 = 0;
   a.d1 = D;
+  a.now_d = c->now_d;
   // scratch of the generic path (untouched pages cost nothing; small distros never use it)
   size_t sz[22] = {8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 8 * Stot, 4 * Stot, 4 * Stot, 4 * Stot,
                    4 * (N + 1), 8 * (N + 1), 8 * (N + 1), 8 * (N + 1), 4 * (N + 1),
@@ -937,7 +941,7 @@ static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_out
   a.w_key = c->scratch[21].p;
   a.w_ts = nullptr; a.w_rtile = nullptr; a.w_stile = nullptr; a.w_ntile = nullptr; a.w_bucket = nullptr; a.w_rec = nullptr;
   a.w_eslot = nullptr; a.w_keyA = nullptr; a.w_keyB = nullptr; a.w_gfirst = nullptr; a.w_tgbit = nullptr;
-  a.w_unit = nullptr; a.w_acc = nullptr;
+  a.w_unit = nullptr;
   a.tiled_mode = c->tiled_mode;
   a.big_tier = 0;
   a.w_status = (in->promises & EVG_PROMISE_ALL_ON_LDS_PATH) ? c->status_word : nullptr;  // launch_plan arms it for ALL_ON_LDS_TIERS
@@ -994,6 +998,7 @@ static int prepare_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_
   a.in = *in;
   a.out = *out;
   a.d0 = 0;
+  a.tick_d = (const AllocTick*)c->tick_d;
   const size_t G = (size_t)in->n_distros + (size_t)in->n_task_groups;
   size_t sz[4] = {8 * ((size_t)in->hosts.n_hosts + 1), 4 * G, 4 * G, 4 * G};
   for (int i = 0; i < 4; i++) {
@@ -1028,10 +1033,10 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
   const size_t max_rt = tiled_max_row_tiles(in), max_st = tiled_max_slot_tiles(in);
   const size_t st_cap = std::min<size_t>(max_st, kMaxST);  // slot tiles of ONE distro
   const size_t Stot = N + (size_t)in->n_task_groups + (size_t)in->n_versions + 1;
-  const size_t sz[13] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
+  const size_t sz[12] = {sizeof(TState) * D, 8 * max_rt, 8 * max_st, 16, 8 * (max_rt * st_cap + 1), sizeof(TRec) * (2 * N + E + 1),
                          4 * (E + 1), sizeof(K192) * max_rt * kRT, sizeof(K192) * max_rt * kRT, 8 * G, 8 * max_rt * (kRT / 64),
-                         sizeof(TUnit) * Stot, sizeof(TAcc) * (N + 1)};
-  for (int i = 0; i < 13; i++) {
+                         sizeof(TUnit) * Stot};
+  for (int i = 0; i < 12; i++) {
     int rc = ensure(c, c->scratch[32 + i], sz[i]);
     if (rc) return rc;
   }
@@ -1040,7 +1045,7 @@ static int prepare_tiled(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in)
   a.w_eslot = (int32_t*)c->scratch[38].p; a.w_keyA = c->scratch[39].p; a.w_keyB = c->scratch[40].p;
   a.w_gfirst = (unsigned long long*)c->scratch[41].p;
   a.w_tgbit = (unsigned long long*)c->scratch[42].p;
-  a.w_unit = c->scratch[43].p; a.w_acc = c->scratch[44].p;
+  a.w_unit = c->scratch[43].p;
   if (!c->tiled_attr_set) {
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledReduceLds));
     HIP_TRY(c, hipFuncSetAttribute((const void*)k_tiled_elect, hipFuncAttributeMaxDynamicSharedMemorySize, kTiledSortLds));
@@ -2111,3 +2116,4 @@ int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_ou
 }  // extern "C"
 
 #include "evg_multi.hip.h"
+#include "evg_batcher.hip.h"

@@ -126,14 +126,6 @@ struct __attribute__((aligned(16))) TUnit {
   int64_t value;
   uint32_t minrow, pad;
 };
-// A row's contribution to the Unit.info of every unit it is a member of (planner.go:302-337), side by side: one 32-byte gather
-// per membership record in k_tiled_reduce where the four task columns were four L1 misses. Written by k_tiled_scatter, which has
-// the columns in registers.
-struct __attribute__((aligned(32))) TAcc {
-  int64_t tiq, dur;  // time in queue (0 for a task never activated), expected duration
-  int32_t pri, nd;   // max(priority, 0), max(num dependents, 0)
-  uint32_t pad[2];
-};
 // The unit slot of a row and what a dependent's edge needs to know about the row, in ONE word (k_tiled_rowkey writes
 // PlanArgs.w_pslot so): bits 0-20 primary unit slot | 21-22 Task.Status class (EVG_TF_STATUS_*) | 23 Task.Blocked().
 constexpr uint32_t RK_SLOT = 0x1FFFFFu, RK_BLOCKED = 1u << 23;
@@ -165,7 +157,7 @@ __device__ __forceinline__ DC tiled_context(const PlanArgs& a, int d) {  // dist
   c.tg_lo = a.in.tg_off[d]; c.ntg = a.in.tg_off[d + 1] - c.tg_lo;
   c.ver_lo = a.in.ver_off[d]; c.nver = a.in.ver_off[d + 1] - c.ver_lo;
   c.gv = a.in.distros[d].group_versions != 0;
-  c.now = a.in.now_ns;
+  c.now = a.now_d ? a.now_d[d] : a.in.now_ns;
   if (c.gv) { c.tg_base = 0; c.ver_base = c.ntg; c.S = c.ntg + c.nver; }
   else { c.tg_base = c.n; c.ver_base = c.n + c.ntg; c.S = c.n + c.ntg; }
   c.P = 0; c.eb = 0; c.ne = 0; c.eL = false;
@@ -438,10 +430,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
     const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
     const int64_t dmt = t.deps_met_ts_ns[r], sched = t.scheduled_ts_ns[r];
     if (pri != (int64_t)(int32_t)pri) pk |= 1ull << F_WIDE;
-    {  // the row's accumulands for the reducer (a wide priority: the distro goes to k_plan_generic, nobody reads this)
-      const int64_t qts = t.queue_ts_ns[r];
-      ((TAcc*)a.w_acc)[r] = TAcc{qts == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, qts), dur, pri > 0 ? (int32_t)pri : 0, nd > 0 ? nd : 0, {0u, 0u}};
-    }
     const uint32_t rc = f & EVG_TF_REQ_MASK;
     uint32_t uf = rc == EVG_TF_REQ_MERGE ? UF_MERGE : rc == EVG_TF_REQ_PATCH ? UF_PATCH : 0u;
     uf |= tgk < 0 ? UF_NONGROUP : 0u;
@@ -730,21 +718,23 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     rb[q] = 0; rrow[q] = -1;
     if (x < total) { rb[q] = recs[s_base[l] + (x - s_pref[l])]; rrow[q] = l * kRT; }
    }
-   // the row's Unit.info contribution (planner.go:302-337): its TAcc row, one gather (two 16-byte loads of one 32-byte line)
-   int64_t c_tiq[kRB], c_dur[kRB];
-   int32_t c_pri[kRB], c_nd[kRB];
+   // the row's Unit.info contribution (planner.go:302-337) from its columns. (Round 5 measured the four accumulands side by side
+   // in a 32-byte row written by the scatter kernel -- one gather per record instead of four: the reducer 55.5 -> 51.5 us per
+   // config-5-share plan, the scatter kernel 40.5 -> 52.8 us for the 40 MB it has to write; dropped, profiles/r05a_*.)
+   int64_t c_qts[kRB], c_dur[kRB], c_pri[kRB];
+   int32_t c_nd[kRB];
 #pragma unroll
    for (int q = 0; q < kRB; q++) {
     if (rrow[q] >= 0) rrow[q] += (int)(rb[q] >> RW_ROW_SHIFT);
-    const TAcc* ac = (const TAcc*)a.w_acc + (c.lo + (rrow[q] >= 0 ? rrow[q] : 0));
-    c_tiq[q] = ac->tiq; c_dur[q] = ac->dur; c_pri[q] = ac->pri; c_nd[q] = ac->nd;
+    const int r = c.lo + (rrow[q] >= 0 ? rrow[q] : 0);
+    c_qts[q] = t.queue_ts_ns[r]; c_dur[q] = t.expected_duration_ns[r]; c_pri[q] = t.priority[r]; c_nd[q] = t.num_dependents[r];
    }
 #pragma unroll
    for (int q = 0; q < kRB; q++) {
     if (rrow[q] < 0) continue;
     const uint32_t w0 = rb[q];
-    const int64_t tiq = c_tiq[q], dur = c_dur[q];
-    const int32_t pri = c_pri[q], nd = c_nd[q];
+    const int64_t tiq = c_qts[q] == EVG_TIME_GO_ZERO ? 0 : time_sub(c.now, c_qts[q]), dur = c_dur[q];
+    const int32_t pri = c_pri[q] > 0 ? (int32_t)c_pri[q] : 0, nd = c_nd[q] > 0 ? c_nd[q] : 0;
     const int u = (int)(w0 & 0x3FFu);
     atomicAdd((unsigned long long*)&m_tiq[u], (unsigned long long)tiq);
     atomicAdd((unsigned long long*)&m_dur[u], (unsigned long long)dur);

@@ -27,6 +27,8 @@ EXPORTS = [
     "evg_check_abi", "evg_take_device_status", "evg_pool_load", "evg_pool_update", "evg_pool_plan", "evg_pool_apply_delta",
     "evg_multi_create", "evg_multi_destroy", "evg_multi_last_error", "evg_multi_load", "evg_multi_tick", "evg_multi_results",
     "evg_multi_ranges", "evg_multi_profile", "evg_multi_last_tick_ms", "evg_multi_poison_outputs", "evg_balanced_ranges",
+    "evg_multi_inject_failure", "evg_multi_abort", "evg_multi_selftest",
+    "evg_batcher_create", "evg_batcher_destroy", "evg_batcher_plan", "evg_batcher_allocate", "evg_batcher_get_stats",
 ]
 
 _lib = None
@@ -116,7 +118,18 @@ def load_library() -> C.CDLL:
         lib.evg_multi_profile.argtypes = [C.c_void_p, C.c_int]
         lib.evg_multi_last_tick_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         lib.evg_multi_poison_outputs.argtypes = [C.c_void_p, C.c_int32]
+        if hasattr(lib, "evg_multi_selftest"):  # ABI 3.2
+            lib.evg_multi_inject_failure.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+            lib.evg_multi_abort.argtypes = [C.c_void_p]
+            lib.evg_multi_selftest.argtypes = [C.c_void_p]
         lib.evg_balanced_ranges.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    if hasattr(lib, "evg_batcher_create"):  # ABI 3.2
+        lib.evg_batcher_create.restype = C.c_void_p
+        lib.evg_batcher_create.argtypes = [C.c_int, C.c_int32, C.c_int32]
+        lib.evg_batcher_destroy.argtypes = [C.c_void_p]
+        lib.evg_batcher_plan.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_char_p, C.c_int32]
+        lib.evg_batcher_allocate.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_char_p, C.c_int32]
+        lib.evg_batcher_get_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 4)]
     if hasattr(lib, "evg_selftest_unit_value"):  # absent from older builds loaded through EVG_SCHED_LIB (A/B runs)
         lib.evg_selftest_unit_value.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
@@ -210,6 +223,17 @@ class MultiContext:
     def poison_outputs(self, byte: int = 0xA5) -> None:
         self._check(self.lib.evg_multi_poison_outputs(self.h, byte), "evg_multi_poison_outputs")
 
+    def inject_failure(self, rank: int, phase: int) -> None:
+        """Test hook: the next tick fails on `rank` in `phase` (0 move-in, 1 plan, 2 allocate, 3 gather)."""
+        self._check(self.lib.evg_multi_inject_failure(self.h, rank, phase), "evg_multi_inject_failure")
+
+    def abort(self) -> None:
+        self._check(self.lib.evg_multi_abort(self.h), "evg_multi_abort")
+
+    def selftest(self) -> None:
+        """A generated mixed pool planned on rank 0's device alone and over all the ranks: raises unless the outputs are identical."""
+        self._check(self.lib.evg_multi_selftest(self.h), "evg_multi_selftest")
+
     def results(self):
         """(PlanResult, AllocResult or None) downloaded from rank 0."""
         b = self.batch
@@ -223,6 +247,53 @@ class MultiContext:
         if self.units and res.unit_breakdown is not None:
             res.breakdown = np.ascontiguousarray(res.unit_breakdown[:, res.unit_of_task].T)
         return res, ares
+
+
+class Batcher:
+    """evg_batcher wrapper: the micro-batching front for per-distro callers (include/evg_sched.h, ABI 3.2). plan() / allocate() are
+    called from many threads at once with one-distro batches -- the reference's call shape (scheduler/scheduler.go:28-52,
+    units/host_allocator.go:183-188); ctypes drops the GIL for the duration of the C call."""
+
+    def __init__(self, device_ordinal: int = 0, max_wait_us: int = -1, max_requests: int = 0):
+        self.lib = load_library()
+        self.h = self.lib.evg_batcher_create(device_ordinal, max_wait_us, max_requests)
+        if not self.h:
+            msg = self.lib.evg_last_error(None)
+            raise NativeError("evg_batcher_create(%d) failed: %s" % (device_ordinal, msg.decode() if msg else "?"))
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.evg_batcher_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def plan(self, batch: abi.PlanBatch, breakdown: bool = True, n_units: bool = True, units: bool = False,
+             into: Optional[abi.PlanResult] = None) -> abi.PlanResult:
+        res = into if into is not None else abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=n_units, units=units)
+        inp, out, err = abi.make_plan_input(batch), res.c_output(), C.create_string_buffer(256)
+        rc = self.lib.evg_batcher_plan(self.h, C.byref(inp), C.byref(out), err, 256)
+        if rc != abi.EVG_OK:
+            raise NativeError("evg_batcher_plan failed (%d): %s" % (rc, err.value.decode()))
+        return res
+
+    def allocate(self, batch: abi.PlanBatch, distro_info: np.ndarray, group_info: np.ndarray,
+                 into: Optional[abi.AllocResult] = None) -> abi.AllocResult:
+        res = into if into is not None else abi.AllocResult.alloc_host(batch.n_distros)
+        inp, out, err = abi.make_alloc_input(batch, distro_info, group_info), res.c_output(), C.create_string_buffer(256)
+        rc = self.lib.evg_batcher_allocate(self.h, C.byref(inp), C.byref(out), err, 256)
+        if rc != abi.EVG_OK:
+            raise NativeError("evg_batcher_allocate failed (%d): %s" % (rc, err.value.decode()))
+        return res
+
+    def stats(self) -> dict:
+        v = (C.c_uint64 * 4)()
+        self.lib.evg_batcher_get_stats(self.h, C.byref(v))
+        return {"batches": int(v[0]), "requests": int(v[1]), "direct_requests": int(v[2]), "largest_batch": int(v[3])}
 
 
 class Context:

@@ -368,7 +368,8 @@ const char* evg_last_error(const evg_ctx* ctx);
  * and the one-launch evg_plan_allocate[_range]_device entry points are gone -- measured no faster than the two calls for three
  * rounds); MINOR adds entry points only. */
 #define EVG_ABI_MAJOR 3
-#define EVG_ABI_MINOR 1 /* 3.1: the evg_multi_* entry points (several devices from one process) and evg_balanced_ranges */
+#define EVG_ABI_MINOR 2 /* 3.1: the evg_multi_* entry points (several devices from one process) and evg_balanced_ranges;
+                           3.2: the evg_batcher_* entry points (micro-batching front for per-distro callers) */
 int32_t evg_abi_version(void);
 /* What a binding calls once at start-up with ITS compile-time view of the header: EVG_OK iff the library's major equals
  * `major`, its minor is at least `minor`, and the four struct sizes are the library's. A binding must refuse the library
@@ -680,6 +681,21 @@ int evg_multi_profile(evg_multi* m, int enable);
 int evg_multi_last_tick_ms(evg_multi* m, float* ms4);
 /* Test hook: fills every rank's output block with `byte` (a slice that never arrived shows in the gathered result). */
 int evg_multi_poison_outputs(evg_multi* m, int32_t byte);
+/* Error behaviour of evg_multi_tick (ABI 3.2). Whatever fails -- a HIP or RCCL call, a rank's planner or allocator, a false promise
+ * seen on a device -- the tick closes an RCCL group it had open, waits for every rank's stream and takes every rank's device status
+ * before it returns the FIRST error: nothing of the tick is in flight after the return and the next tick starts clean. One case
+ * cannot be waited for: an RCCL call that failed with its group half-issued (a send without its receive, a broadcast without all its
+ * ranks). The tick then aborts the communicators and every later tick is refused: destroy the evg_multi and create a new one.
+ *   evg_multi_inject_failure  test hook: the NEXT tick fails on `rank` in `phase` (0 move-in, 1 plan, 2 allocate, 3 gather) after that
+ *                             rank's share of the phase was enqueued (inside the open RCCL group for 0 and 3). One shot; rank < 0 clears
+ *   evg_multi_abort           for a tick that does not come back (called from ANOTHER thread) or communicators the caller no longer
+ *                             trusts: ncclCommAbort on every rank; the object only accepts evg_multi_destroy afterwards
+ *   evg_multi_selftest        start-up check before a scheduler routes its planning through several devices: a generated pool of mixed
+ *                             shape planned + allocated on rank 0's device alone and over all the ranks must give identical outputs.
+ *                             EVG_OK, EVG_E_CONTRACT (first difference in the message) or the failing call's code. Replaces the loaded pool */
+int evg_multi_inject_failure(evg_multi* m, int32_t rank, int32_t phase);
+int evg_multi_abort(evg_multi* m);
+int evg_multi_selftest(evg_multi* m);
 
 /* Host only: the contiguous distro ranges `world` ranks plan, minimising the largest rank COST (a distro is never split: a rank's
  * results must be contiguous slices of the full-size outputs). Cost of a distro = tasks on the two-per-CU tier of the one-workgroup
@@ -687,6 +703,33 @@ int evg_multi_poison_outputs(evg_multi* m, int32_t byte);
  * same integers as evergreen_amd/multi.py:balanced_ranges, so every driver cuts the same ranges. Ranks past the last range get
  * empty ranges. */
 int evg_balanced_ranges(const int32_t* task_off, int32_t n_distros, int32_t world, int32_t* d_begin, int32_t* d_end);
+
+/* ---- a micro-batching front for PER-DISTRO callers (ABI 3.2) ---------------------------------------------------------------------
+ * The reference calls the planner once per distro from concurrent jobs (units/crons.go:303-332 enqueues one distro-scheduler job
+ * per distro; units/scheduler.go:48-49 -> scheduler.PlanDistro -> runTunablePlanner, scheduler/scheduler.go:28-52) and the host
+ * allocator likewise (units/host_allocator.go:183-188). Through that call shape the host-pointer entry points above serve ONE distro
+ * per call and the device's command path saturates at ~25 ms for 512 of them, whatever the number of threads. A batcher keeps the
+ * call shape and issues batches: concurrent evg_batcher_plan (evg_batcher_allocate) calls are collected -- until `max_requests`
+ * joined, nobody new has joined for a quarter of `max_wait_us`, or `max_wait_us` passed since the first -- and planned (allocated) by
+ * ONE launch sequence over all of them; every caller packs its own columns and cuts out its own results on its own thread. Each
+ * request keeps its own now_ns (and the allocator's large-parser-project figures), so its results are bit for bit those of
+ * evg_plan_distros / evg_allocate_hosts on the request alone; inputs, outputs and return codes are theirs too. Errors stay per
+ * request: one that fails the layout contract is refused before it joins a batch (EVG_E_CONTRACT, message in `err`); a failure of a
+ * batch's own device work is returned to every caller of that batch. Thread-safe; the calls block. Up to four batches can be in flight.
+ * evg_batcher_create: device ordinal; max_wait_us < 0 / max_requests <= 0 = the defaults (200 us, 64). NULL + evg_last_error(NULL)
+ * on failure. evg_batcher_destroy waits for the batches in flight; calls that arrive after it began are refused. */
+typedef struct evg_batcher evg_batcher;
+typedef struct evg_batcher_stats {
+  uint64_t batches;          /* launch sequences issued                                  */
+  uint64_t requests;         /* requests they carried                                    */
+  uint64_t direct_requests;  /* requests too large for a batch: passed straight through  */
+  uint64_t largest_batch;    /* most requests in one batch                               */
+} evg_batcher_stats;
+evg_batcher* evg_batcher_create(int device_ordinal, int32_t max_wait_us, int32_t max_requests);
+void evg_batcher_destroy(evg_batcher* b);
+int evg_batcher_plan(evg_batcher* b, const evg_plan_input* in, const evg_plan_output* out, char* err, int32_t err_len);
+int evg_batcher_allocate(evg_batcher* b, const evg_alloc_input* in, const evg_alloc_output* out, char* err, int32_t err_len);
+int evg_batcher_get_stats(evg_batcher* b, evg_batcher_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@
 #include <vector>
 
 typedef int (*call2_fn)(void* ctx, const void* in, const void* out);
+typedef int (*call4_fn)(void* batcher, const void* in, const void* out, char* err, int err_len);  // evg_batcher_plan / evg_batcher_allocate
 
 extern "C" int pdc_run(void* fn_plan, void* fn_alloc, void** ctxs, int n_threads, int n_distros, const char* pin, size_t pin_stride, const char* pout,
                        size_t pout_stride, const char* ain, size_t ain_stride, const char* aout, size_t aout_stride, double* lat_us, double* wall_ms) {
@@ -23,6 +24,34 @@ extern "C" int pdc_run(void* fn_plan, void* fn_alloc, void** ctxs, int n_threads
       const auto t0 = std::chrono::steady_clock::now();
       const int rc = plan(ctxs[w], pin + (size_t)d * pin_stride, pout + (size_t)d * pout_stride);
       const int rc2 = alloc(ctxs[w], ain + (size_t)d * ain_stride, aout + (size_t)d * aout_stride);
+      lat_us[d] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      bad[w] += (rc != 0) + (rc2 != 0);
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int w = 1; w < n_threads; w++) th.emplace_back(work, w);
+  work(0);
+  for (auto& t : th) t.join();
+  *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  int errors = 0;
+  for (int b : bad) errors += b;
+  return errors;
+}
+
+// The same loop through the micro-batching front (ABI 3.2): every worker calls evg_batcher_plan + evg_batcher_allocate on the ONE shared
+// batcher -- what shim/gpu_planner.go's runGPUPlanner / GPUHostAllocator do from the reference's concurrent per-distro jobs.
+extern "C" int pdc_run_batcher(void* fn_plan, void* fn_alloc, void* batcher, int n_threads, int n_distros, const char* pin, size_t pin_stride,
+                               const char* pout, size_t pout_stride, const char* ain, size_t ain_stride, const char* aout, size_t aout_stride,
+                               double* lat_us, double* wall_ms) {
+  const call4_fn plan = (call4_fn)fn_plan, alloc = (call4_fn)fn_alloc;
+  std::vector<int> bad(n_threads, 0);
+  auto work = [&](int w) {
+    char err[256];
+    for (int d = w; d < n_distros; d += n_threads) {
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rc = plan(batcher, pin + (size_t)d * pin_stride, pout + (size_t)d * pout_stride, err, (int)sizeof err);
+      const int rc2 = alloc(batcher, ain + (size_t)d * ain_stride, aout + (size_t)d * aout_stride, err, (int)sizeof err);
       lat_us[d] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       bad[w] += (rc != 0) + (rc2 != 0);
     }

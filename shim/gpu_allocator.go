@@ -186,7 +186,15 @@ func allocateBatch(ctx context.Context, datas []*HostAllocatorData) ([]allocResu
 	in.hosts = C.evg_host_soa{n_hosts: C.int32_t(nHosts), flags: ptr(hFlags), tg_key: ptr(hKey), start_ts_ns: ptr(hStart),
 		expected_duration_ns: ptr(hExp), duration_stddev_ns: ptr(hDev)}
 	out := C.evg_alloc_output{new_hosts: ptr(newHosts), free_hosts: ptr(freeHosts), status: ptr(status)}
-	if rc := C.evg_allocate_hosts(g.c, &in, &out); rc != C.EVG_OK {
+	batcher, err := batcherFor(nHosts, D) // one HostAllocator call = one distro (units/host_allocator.go:183-188): batched with its peers
+	if err != nil {
+		return nil, err
+	}
+	if batcher != nil {
+		if err := batchedAllocate(batcher, &in, &out); err != nil {
+			return nil, err
+		}
+	} else if rc := C.evg_allocate_hosts(g.c, &in, &out); rc != C.EVG_OK {
 		return nil, errors.Errorf("evg_allocate_hosts: %s (%d)", C.GoString(C.evg_last_error(g.c)), int(rc))
 	}
 

@@ -484,8 +484,18 @@ func planBatch(ctx context.Context, ds []*distro.Distro, queues [][]task.Task) (
 	if err != nil {
 		return nil, nil, err
 	}
+	// A batch of ONE distro -- the reference's own call shape (scheduler/scheduler.go:28-52) -- joins whatever other goroutines
+	// are planning at this moment (gpu_batcher.go): one launch sequence for all of them, the same result for each.
+	batcher, err := batcherFor(n, D)
+	if err != nil {
+		return nil, nil, err
+	}
 	if shard != nil {
 		if err := shard.plan(&in, &out); err != nil {
+			return nil, nil, err
+		}
+	} else if batcher != nil {
+		if err := batchedPlan(batcher, &in, &out); err != nil {
 			return nil, nil, err
 		}
 	} else if rc := C.evg_plan_distros(g.c, &in, &out); rc != C.EVG_OK {

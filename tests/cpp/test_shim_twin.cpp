@@ -23,6 +23,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <set>
+#include <atomic>
+#include <mutex>
+#include <thread>
 
 #include "evg_host.hpp"  // the reference's struct shapes (Task, Distro, Host, ...) and constants; its packing code is NOT used
 
@@ -58,11 +61,18 @@ struct Lib {
   int (*multi_load)(evg_multi*, const evg_plan_input*, const evg_alloc_input*) = nullptr;
   int (*multi_tick)(evg_multi*, int64_t) = nullptr;
   int (*multi_results)(evg_multi*, const evg_plan_output*, const evg_alloc_output*) = nullptr;
-  int calls_multi = 0;
+  std::atomic<int> calls_multi{0};
+  // gpu_batcher.go: the one-distro calls through the process-wide micro-batching front
+  evg_batcher* (*batcher_create)(int, int32_t, int32_t) = nullptr;
+  void (*batcher_destroy)(evg_batcher*) = nullptr;
+  int (*batcher_plan)(evg_batcher*, const evg_plan_input*, const evg_plan_output*, char*, int32_t) = nullptr;
+  int (*batcher_allocate)(evg_batcher*, const evg_alloc_input*, const evg_alloc_output*, char*, int32_t) = nullptr;
+  int (*batcher_get_stats)(evg_batcher*, evg_batcher_stats*) = nullptr;
+  std::atomic<int> calls_batched{0};
   // oracle mode: the two batched calls without a context
   int (*o_plan)(const evg_plan_input*, const evg_plan_output*) = nullptr;
   int (*o_alloc)(const evg_alloc_input*, const evg_alloc_output*) = nullptr;
-  int calls_host_alloc = 0, calls_plan = 0, calls_alloc = 0;
+  std::atomic<int> calls_host_alloc{0}, calls_plan{0}, calls_alloc{0};
 };
 static Lib L;
 
@@ -116,20 +126,44 @@ struct gpuCtx {
   template <class T>
   GoSlice<T> carveSlice(size_t n) { return GoSlice<T>{(T*)carve(n, sizeof(T)), n}; }
 };
-static gpuCtx g_ctx;  // the pool hands out one context; one goroutine here
-static bool g_abi_checked = false;
+// The pool hands every goroutine (here: every std::thread) a context of its own and keeps them for the next call.
+static std::mutex g_pool_mu;
+static std::vector<gpuCtx*> g_all_ctx;
+static thread_local gpuCtx* t_ctx = nullptr;
+static std::once_flag g_abi_once;
 
 static gpuCtx* pool_get() {
-  if (L.hip && !g_abi_checked) {  // p.once.Do(...)
-    if (L.check_abi(EVG_ABI_MAJOR, EVG_ABI_MINOR, sizeof(evg_plan_input), sizeof(evg_plan_output), sizeof(evg_alloc_input), sizeof(evg_group_info)) != EVG_OK)
-      throw std::runtime_error("libevg_sched ABI does not match this binding");
-    g_abi_checked = true;
+  if (L.hip)
+    std::call_once(g_abi_once, [] {  // p.once.Do(...)
+      if (L.check_abi(EVG_ABI_MAJOR, EVG_ABI_MINOR, sizeof(evg_plan_input), sizeof(evg_plan_output), sizeof(evg_alloc_input), sizeof(evg_group_info)) != EVG_OK)
+        throw std::runtime_error("libevg_sched ABI does not match this binding");
+    });
+  if (!t_ctx) {
+    gpuCtx* g = new gpuCtx();
+    if (L.hip) {
+      g->c = L.create(0);
+      if (!g->c) { delete g; throw std::runtime_error(std::string("evg_create: ") + L.last_error(nullptr)); }
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_all_ctx.push_back(g);
+    t_ctx = g;
   }
-  if (L.hip && !g_ctx.c) {
-    g_ctx.c = L.create(0);
-    if (!g_ctx.c) throw std::runtime_error(std::string("evg_create: ") + L.last_error(nullptr));
+  return t_ctx;
+}
+
+// ---- gpu_batcher.go -----------------------------------------------------------------------------------------------------
+static std::mutex g_batcher_mu;
+static evg_batcher* g_batcher = nullptr;
+static bool g_batch_off = true;  // the known-answer cases run one call at a time; run_batcher_cases switches it on (SetGPUBatching)
+static const int kBatchMaxTasks = 1 << 16;
+static evg_batcher* batcherFor(int n, int D) {
+  std::lock_guard<std::mutex> lk(g_batcher_mu);
+  if (!L.hip || g_batch_off || D != 1 || n > kBatchMaxTasks) return nullptr;
+  if (!g_batcher) {
+    g_batcher = L.batcher_create(0, 2000, 64);
+    if (!g_batcher) throw std::runtime_error(std::string("evg_batcher_create: ") + L.last_error(nullptr));
   }
-  return &g_ctx;
+  return g_batcher;
 }
 
 // ---- small conversions ----------------------------------------------------------------------------------------------
@@ -330,8 +364,14 @@ static PlanOut planBatch(const std::vector<const Distro*>& ds, const std::vector
   out.unit_of_task = ptr(unitOf); out.unit_breakdown = ptr(unitRows);  // breakdown (rows by task) and n_units stay NULL
 
   int rc = EVG_OK;
+  evg_batcher* batcher = batcherFor(n, D);  // a batch of ONE distro joins whatever other threads are planning at this moment
   if (g_shard) g_shard->plan(&in, &out);  // shard.plan(&in, &out): the same two structs, spread over the devices by the library
-  else rc = L.hip ? L.plan_distros(g->c, &in, &out) : L.o_plan(&in, &out);
+  else if (batcher) {
+    char msg[256];
+    rc = L.batcher_plan(batcher, &in, &out, msg, (int32_t)sizeof msg);
+    L.calls_batched++;
+    if (rc != EVG_OK) throw std::runtime_error(std::string("evg_batcher_plan: ") + msg + " (" + std::to_string(rc) + ")");
+  } else rc = L.hip ? L.plan_distros(g->c, &in, &out) : L.o_plan(&in, &out);
   L.calls_plan++;
   if (rc != EVG_OK) throw std::runtime_error(std::string("evg_plan_distros: ") + (L.hip ? L.last_error(g->c) : "oracle") + " (" + std::to_string(rc) + ")");
 
@@ -448,7 +488,13 @@ static std::vector<allocResult> allocateBatch(std::vector<HostAllocatorData*>& d
   in.hosts.n_hosts = nHosts; in.hosts.flags = ptr(hFlags); in.hosts.tg_key = ptr(hKey); in.hosts.start_ts_ns = ptr(hStart);
   in.hosts.expected_duration_ns = ptr(hExp); in.hosts.duration_stddev_ns = ptr(hDev);
   evg_alloc_output out{ptr(newHosts), ptr(freeHosts), ptr(status)};
-  const int rc = L.hip ? L.allocate_hosts(g->c, &in, &out) : L.o_alloc(&in, &out);
+  int rc;
+  if (evg_batcher* batcher = batcherFor(nHosts, D)) {  // one HostAllocator call = one distro: batched with its peers
+    char msg[256];
+    rc = L.batcher_allocate(batcher, &in, &out, msg, (int32_t)sizeof msg);
+    L.calls_batched++;
+    if (rc != EVG_OK) throw std::runtime_error(std::string("evg_batcher_allocate: ") + msg);
+  } else rc = L.hip ? L.allocate_hosts(g->c, &in, &out) : L.o_alloc(&in, &out);
   L.calls_alloc++;
   if (rc != EVG_OK) throw std::runtime_error(std::string("evg_allocate_hosts: ") + (L.hip ? L.last_error(g->c) : "oracle"));
 
@@ -581,8 +627,78 @@ static void run_multi_cases() {
     EXPECT(one.infos[(size_t)d].Length == two.infos[(size_t)d].Length && one.infos[(size_t)d].ExpectedDuration == two.infos[(size_t)d].ExpectedDuration &&
            one.infos[(size_t)d].TaskGroupInfos.size() == two.infos[(size_t)d].TaskGroupInfos.size(), "multi: queue info of distro %d", d);
   }
-  EXPECT(L.calls_multi == 2, "two ticks went through evg_multi_* (%d)", L.calls_multi);
+  EXPECT(L.calls_multi == 2, "two ticks went through evg_multi_* (%d)", (int)L.calls_multi);
   L.multi_destroy(shard.m);
+}
+
+// gpu_batcher.go's path: the reference's call shape -- GPUTaskPlanner / GPUHostAllocator on ONE distro, from concurrent jobs
+// (units/scheduler.go:48-49) -- through the process-wide batcher must give every caller what the same call gives alone.
+static void run_batcher_cases() {
+  if (!L.hip) return;
+  const int K = 24;
+  std::vector<Distro> ds((size_t)K);
+  std::vector<std::vector<Task>> qs((size_t)K);
+  std::vector<HostAllocatorData> hd((size_t)K);
+  for (int k = 0; k < K; k++) {
+    Distro& d = ds[(size_t)k];
+    d.Id = "bd" + std::to_string(k);
+    d.PlannerSettings.GroupVersions = k % 5 == 3;
+    d.HostAllocatorSettings.MaximumHosts = 50; d.Provider = "ec2-fleet";
+    std::vector<Task>& q = qs[(size_t)k];
+    q.resize((size_t)(30 + 17 * k));
+    for (size_t i = 0; i < q.size(); i++) {
+      Task& t = q[i];
+      t.Id = d.Id + "-t" + std::to_string(i); t.DistroId = d.Id; t.Priority = (int64_t)((i * 11 + (size_t)k) % 7); t.Version = "v" + std::to_string(i / 9);
+      t.NumDependents = (int)((i + (size_t)k) % 5);
+      t.ExpectedDuration = (int64_t)(60 + (i * 37 + (size_t)k * 13) % 900) * 1000000000LL;
+      if (i % 7 == 2) { t.TaskGroup = "tg" + std::to_string(i / 21); t.BuildVariant = "bv"; t.Project = "p"; t.TaskGroupMaxHosts = 1 + (int)(i % 3); t.TaskGroupOrder = (int)(i % 4) + 1; }
+      if (i >= 5 && i % 3 == 0) { Dependency dep; dep.TaskId = d.Id + "-t" + std::to_string(i - 5); t.DependsOn.push_back(dep); }
+    }
+  }
+  // alone, one after the other, straight through evg_plan_distros / evg_allocate_hosts
+  std::vector<PlanOut> alone((size_t)K), together((size_t)K);
+  std::vector<allocResult> a_alone((size_t)K), a_together((size_t)K);
+  const std::map<std::string, Task> running;
+  auto one = [&](int k, PlanOut& po, allocResult& ar) {
+    po = planBatch({&ds[(size_t)k]}, {&qs[(size_t)k]}, NOW + k);  // every caller has its own clock reading
+    HostAllocatorData data;
+    data.Distro = ds[(size_t)k];
+    data.DistroQueueInfo = po.infos[0];
+    std::vector<HostAllocatorData*> v{&data};
+    ar = allocateBatch(v, NOW + k, running)[0];
+  };
+  for (int k = 0; k < K; k++) one(k, alone[(size_t)k], a_alone[(size_t)k]);
+  // together: K threads at once, batching on
+  { std::lock_guard<std::mutex> lk(g_batcher_mu); g_batch_off = false; }
+  std::vector<std::thread> th;
+  std::vector<std::string> errs((size_t)K);
+  for (int k = 0; k < K; k++)
+    th.emplace_back([&, k] {
+      try { one(k, together[(size_t)k], a_together[(size_t)k]); } catch (const std::exception& e) { errs[(size_t)k] = e.what(); }
+    });
+  for (auto& t : th) t.join();
+  { std::lock_guard<std::mutex> lk(g_batcher_mu); g_batch_off = true; }
+  for (int k = 0; k < K; k++) {
+    EXPECT(errs[(size_t)k].empty(), "batcher: request %d failed: %s", k, errs[(size_t)k].c_str());
+    if (!errs[(size_t)k].empty()) continue;
+    const auto &x = alone[(size_t)k].plans[0], &y = together[(size_t)k].plans[0];
+    bool same = x.size() == y.size();
+    for (size_t p = 0; same && p < x.size(); p++)
+      same = x[p].Id == y[p].Id && x[p].SortingValueBreakdown.TotalValue == y[p].SortingValueBreakdown.TotalValue &&
+             x[p].WaitSinceDependenciesMet == y[p].WaitSinceDependenciesMet;
+    EXPECT(same, "batcher: distro %d planned in a batch == planned alone (order, stamped TotalValue, wait)", k);
+    const DistroQueueInfo &ix = alone[(size_t)k].infos[0], &iy = together[(size_t)k].infos[0];
+    EXPECT(ix.Length == iy.Length && ix.ExpectedDuration == iy.ExpectedDuration && ix.TaskGroupInfos.size() == iy.TaskGroupInfos.size() &&
+           ix.LengthWithDependenciesMet == iy.LengthWithDependenciesMet, "batcher: queue info of distro %d", k);
+    EXPECT(a_alone[(size_t)k].newHosts == a_together[(size_t)k].newHosts && a_alone[(size_t)k].freeHosts == a_together[(size_t)k].freeHosts,
+           "batcher: host counts of distro %d (%d, %d) vs alone (%d, %d)", k, a_together[(size_t)k].newHosts, a_together[(size_t)k].freeHosts,
+           a_alone[(size_t)k].newHosts, a_alone[(size_t)k].freeHosts);
+  }
+  evg_batcher_stats st{};
+  EXPECT(g_batcher && L.batcher_get_stats(g_batcher, &st) == EVG_OK && st.requests == 2u * K && st.batches < st.requests,
+         "batcher: %d requests went out in fewer launch sequences (%llu requests, %llu batches)", 2 * K, (unsigned long long)st.requests,
+         (unsigned long long)st.batches);
+  EXPECT(L.calls_batched == 2 * K, "every one-distro call of the concurrent phase went through evg_batcher_* (%d)", (int)L.calls_batched);
 }
 
 static void run_twin_specifics() {
@@ -717,6 +833,9 @@ int main(int argc, char** argv) {
       L.multi_create = sym<decltype(L.multi_create)>(h, "evg_multi_create"); L.multi_destroy = sym<decltype(L.multi_destroy)>(h, "evg_multi_destroy");
       L.multi_last_error = sym<decltype(L.multi_last_error)>(h, "evg_multi_last_error"); L.multi_load = sym<decltype(L.multi_load)>(h, "evg_multi_load");
       L.multi_tick = sym<decltype(L.multi_tick)>(h, "evg_multi_tick"); L.multi_results = sym<decltype(L.multi_results)>(h, "evg_multi_results");
+      L.batcher_create = sym<decltype(L.batcher_create)>(h, "evg_batcher_create"); L.batcher_destroy = sym<decltype(L.batcher_destroy)>(h, "evg_batcher_destroy");
+      L.batcher_plan = sym<decltype(L.batcher_plan)>(h, "evg_batcher_plan"); L.batcher_allocate = sym<decltype(L.batcher_allocate)>(h, "evg_batcher_allocate");
+      L.batcher_get_stats = sym<decltype(L.batcher_get_stats)>(h, "evg_batcher_get_stats");
     } else {
       L.o_plan = sym<decltype(L.o_plan)>(h, "evg_oracle_plan_distros"); L.o_alloc = sym<decltype(L.o_alloc)>(h, "evg_oracle_allocate_hosts");
     }
@@ -729,15 +848,20 @@ int main(int argc, char** argv) {
     run_twin_specifics();
     run_empty_column_cases();
     run_multi_cases();
-    if (L.hip && g_ctx.c) {
-      if (g_ctx.arena) L.host_free(g_ctx.c, g_ctx.arena);
-      L.destroy(g_ctx.c);
+    run_batcher_cases();
+    if (g_batcher) L.batcher_destroy(g_batcher);
+    for (gpuCtx* g : g_all_ctx) {
+      if (L.hip && g->c) {
+        if (g->arena) L.host_free(g->c, g->arena);
+        L.destroy(g->c);
+      } else if (g->arena) std::free(g->arena);
+      delete g;
     }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 1;
   }
   std::printf("shim twin, %s backend: %d checks, %d failed; %d evg_plan_distros, %d evg_allocate_hosts, %d arena (re)allocations\n", argv[1], g_checks, g_fail,
-              L.calls_plan, L.calls_alloc, L.calls_host_alloc);
+              (int)L.calls_plan, (int)L.calls_alloc, (int)L.calls_host_alloc);
   return g_fail ? 1 : 0;
 }

@@ -114,3 +114,55 @@ def test_more_ranks_than_work(oracle, n, d, world):
             _check(m, b, want, want_alloc, "multi loopback x%d over %d tasks in %d distros" % (world, n, d))
         finally:
             m.close()
+
+
+@pytest.mark.parametrize("world,loopback,scatter", [(1, False, False), (1, False, True), (3, True, False), (4, True, True), (8, True, False)],
+                         ids=["rccl-x1", "rccl-x1-scatter", "loopback-x3", "loopback-x4-scatter", "loopback-x8"])
+def test_selftest(world, loopback, scatter):
+    """evg_multi_selftest -- what shim/gpu_multi.go runs in SetGPUDevices before it routes planning over several devices: a generated
+    mixed pool (small distros, a 4096-task-tier distro, a pipeline distro, an empty queue) over all the ranks == on one device."""
+    for units in (False, True):
+        m = native.MultiContext([0] * world, scatter=scatter, units=units, loopback=loopback)
+        try:
+            m.selftest()
+        finally:
+            m.close()
+
+
+@pytest.mark.parametrize("world,loopback,scatter", [(1, False, False), (1, False, True), (3, True, False), (3, True, True)],
+                         ids=["rccl-x1", "rccl-x1-scatter", "loopback-x3", "loopback-x3-scatter"])
+def test_a_failed_tick_leaves_the_object_usable(oracle, world, loopback, scatter):
+    """Round 4's evg_multi_tick returned from the middle of an open ncclGroupStart and left work enqueued on the ranks below the
+    failing one; the first real failure would have wedged the object. Every (rank, phase) failure is injected -- after that rank's
+    share of the phase was enqueued, inside the open RCCL group for the move-in and the gather -- and reported; the tick after it
+    gives the whole plan again."""
+    b = gen.generate(gen.GenConfig(30_000, 14, gen.SEED_BASE + 41, skew=True))
+    want, want_alloc = _want(oracle, b)
+    m = native.MultiContext([0] * world, scatter=scatter, units=True, loopback=loopback)
+    try:
+        m.load(b)
+        m.tick()
+        for phase in range(4):
+            for rank in sorted({0, world - 1}):
+                m.inject_failure(rank, phase)
+                m.poison_outputs()
+                with pytest.raises(native.NativeError, match="injected failure on rank %d in phase %d" % (rank, phase)):
+                    m.tick()
+                m.poison_outputs()
+                m.tick()  # nothing of the failed tick is in flight, no status word is left set, no RCCL group is open
+                _check(m, b, want, want_alloc, "after a failure on rank %d in phase %d" % (rank, phase))
+    finally:
+        m.close()
+
+
+def test_abort_refuses_further_ticks():
+    b = gen.generate(gen.config(1))
+    m = native.MultiContext([0], units=True)  # a real RCCL communicator
+    try:
+        m.load(b)
+        m.tick()
+        m.abort()
+        with pytest.raises(native.NativeError, match="aborted"):
+            m.tick()
+    finally:
+        m.close()  # destroying an aborted object is fine

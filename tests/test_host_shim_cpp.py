@@ -65,7 +65,7 @@ def _build_twin():
     srcs = [os.path.join(CPP, "test_shim_twin.cpp"), os.path.join(CPP, "golden_cases.inc"), os.path.join(ROOT, "include", "evg_host.hpp"),
             os.path.join(ROOT, "include", "evg_sched.h")]
     if not os.path.exists(TWIN) or any(os.path.getmtime(s) > os.path.getmtime(TWIN) for s in srcs):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), srcs[0], "-o", TWIN, "-ldl"])
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), srcs[0], "-o", TWIN, "-ldl", "-pthread"])
     return TWIN
 
 
@@ -101,7 +101,7 @@ def test_go_shim_files_are_complete():
     defined = set(re.findall(r"^func (?:\([^)]*\) )?([A-Za-z_][A-Za-z0-9_]*)", src, flags=re.M))
     for helper in ("planBatch", "allocateBatch", "intern", "taskFlags", "depRequired", "fetchedDepStates", "breakdownOfUnit", "depsMetTime",
                    "queueInfoFromRows", "providerClass", "unixNS", "boolToC", "statusClass", "carveSlice", "runGPUPlanner", "shardFor", "SetGPUDevices",
-                   "PlanAllDistros"):
+                   "PlanAllDistros", "batcherFor", "batchedPlan", "batchedAllocate", "SetGPUBatching"):
         assert helper in defined, "shim helper %s is named but not defined" % helper
     assert "var GPUTaskPlanner TaskPlanner" in src and "var GPUHostAllocator HostAllocator" in src
 
