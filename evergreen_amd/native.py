@@ -100,7 +100,10 @@ def load_library() -> C.CDLL:
         if hasattr(lib, "evg_pool_apply_delta"):
             lib.evg_pool_apply_delta.argtypes = [C.c_void_p, C.POINTER(abi.PoolDelta)]
         # what a binding does once at start-up: refuse a library whose structs are not the ones it was written against
-        rc = lib.evg_check_abi(abi.EVG_ABI_MAJOR, abi.EVG_ABI_MINOR, C.sizeof(abi.PlanInput), C.sizeof(abi.PlanOutput), C.sizeof(abi.AllocInput),
+        # (an older build named by EVG_SCHED_LIB -- the A/B runs of scripts/ab_libs.sh -- is held to ITS minor: the newer entry points are
+        # then simply absent, and everything above is guarded by hasattr)
+        minor = min(abi.EVG_ABI_MINOR, lib.evg_abi_version() & 0xFFFF) if os.environ.get("EVG_SCHED_LIB") else abi.EVG_ABI_MINOR
+        rc = lib.evg_check_abi(abi.EVG_ABI_MAJOR, minor, C.sizeof(abi.PlanInput), C.sizeof(abi.PlanOutput), C.sizeof(abi.AllocInput),
                                abi.GROUP_INFO_DTYPE.itemsize)
         if rc != abi.EVG_OK:
             raise NativeError("%s: ABI %#x does not match this binding (%d.%d, struct sizes)" % (LIB_PATH, lib.evg_abi_version(), abi.EVG_ABI_MAJOR,

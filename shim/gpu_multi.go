@@ -42,27 +42,55 @@ var (
 const minTasksPerDevice = 1 << 20
 
 type gpuMulti struct {
-	mu sync.Mutex // one tick at a time: the evg_multi owns one pool
-	m  *C.evg_multi
-	n  int
+	mu     sync.Mutex // one tick at a time: the evg_multi owns one pool
+	m      *C.evg_multi
+	n      int
+	closed bool // SetGPUDevices replaced this object: a planBatch that still holds it falls back to one device
 }
 
-// SetGPUDevices selects the devices of the batched planner; an existing multi-device context is torn down. Call it at start-up
-// (units/crons.go populates its queue from one goroutine).
-func SetGPUDevices(devs []int) {
+// SetGPUDevices is the EXPLICIT opt-in to multi-device planning, called once at start-up (one device is the default and needs no
+// call). With more than one device it builds the evg_multi -- contexts, streams, RCCL communicators -- right here and runs the
+// library's self-check (evg_multi_selftest: a generated pool of mixed shape planned on the first device alone and over all of them
+// must give identical outputs) BEFORE any tick depends on it: the N > 1 RCCL path had never met hardware when this file was
+// written, and a hang or a mismatch there would stall the scheduler's only planning path. On any failure the error is returned and
+// planning stays on one device.
+func SetGPUDevices(devs []int) error {
 	gpuDevicesMu.Lock()
 	defer gpuDevicesMu.Unlock()
-	if gpuShard != nil {
-		gpuShard.mu.Lock()
-		C.evg_multi_destroy(gpuShard.m)
-		gpuShard.mu.Unlock()
+	if old := gpuShard; old != nil {
+		old.mu.Lock() // waits for a tick in flight; a planBatch that took the pointer earlier sees `closed` under the same lock
+		old.closed = true
+		C.evg_multi_destroy(old.m)
+		old.m = nil
+		old.mu.Unlock()
 		gpuShard = nil
 	}
-	gpuDevices = append([]int(nil), devs...)
-	if len(gpuDevices) == 0 {
-		gpuDevices = []int{0}
+	gpuDevices = []int{0}
+	if len(devs) > 0 {
+		gpuDevices = []int{devs[0]}
 	}
 	gpuPool.dev = C.int(gpuDevices[0])
+	if len(devs) < 2 {
+		return nil
+	}
+	cdevs := make([]C.int32_t, len(devs))
+	for i, d := range devs {
+		cdevs[i] = C.int32_t(d)
+	}
+	// unit rows: planBatch stamps SortingValueBreakdown from unit_of_task + unit_breakdown (planner.go:475)
+	m := C.evg_multi_create(ptr(cdevs), C.int32_t(len(devs)), C.EVG_MULTI_UNIT_ROWS)
+	if m == nil {
+		return errors.Errorf("evg_multi_create: %s; planning stays on device %d", C.GoString(C.evg_multi_last_error(nil)), gpuDevices[0])
+	}
+	if rc := C.evg_multi_selftest(m); rc != C.EVG_OK {
+		err := errors.Errorf("evg_multi_selftest over %d devices: %s (%d); planning stays on device %d", len(devs),
+			C.GoString(C.evg_multi_last_error(m)), int(rc), gpuDevices[0])
+		C.evg_multi_destroy(m)
+		return err
+	}
+	gpuDevices = append([]int(nil), devs...)
+	gpuShard = &gpuMulti{m: m, n: len(devs)}
+	return nil
 }
 
 // shardFor returns the multi-device context when a batch of n tasks over D distros should be spread, nil otherwise.
@@ -70,20 +98,8 @@ func shardFor(n, D int) (*gpuMulti, error) {
 	gpuDevicesMu.Lock()
 	defer gpuDevicesMu.Unlock()
 	k := len(gpuDevices)
-	if k < 2 || D < k || n < k*minTasksPerDevice {
+	if gpuShard == nil || k < 2 || D < k || n < k*minTasksPerDevice {
 		return nil, nil
-	}
-	if gpuShard == nil {
-		devs := make([]C.int32_t, k)
-		for i, d := range gpuDevices {
-			devs[i] = C.int32_t(d)
-		}
-		// unit rows: planBatch stamps SortingValueBreakdown from unit_of_task + unit_breakdown (planner.go:475)
-		m := C.evg_multi_create(ptr(devs), C.int32_t(k), C.EVG_MULTI_UNIT_ROWS)
-		if m == nil {
-			return nil, errors.Errorf("evg_multi_create: %s", C.GoString(C.evg_multi_last_error(nil)))
-		}
-		gpuShard = &gpuMulti{m: m, n: k}
 	}
 	return gpuShard, nil
 }
@@ -93,6 +109,9 @@ func shardFor(n, D int) (*gpuMulti, error) {
 func (s *gpuMulti) plan(in *C.evg_plan_input, out *C.evg_plan_output) error {
 	s.mu.Lock()
 	defer s.mu.Unlock()
+	if s.closed { // SetGPUDevices ran between shardFor and here: the handle is gone, never touch it
+		return errGPUShardClosed
+	}
 	if rc := C.evg_multi_load(s.m, in, nil); rc != C.EVG_OK {
 		return errors.Errorf("evg_multi_load: %s (%d)", C.GoString(C.evg_multi_last_error(s.m)), int(rc))
 	}
@@ -104,6 +123,8 @@ func (s *gpuMulti) plan(in *C.evg_plan_input, out *C.evg_plan_output) error {
 	}
 	return nil
 }
+
+var errGPUShardClosed = errors.New("the multi-device context was replaced by SetGPUDevices")
 
 // PlanAllDistros is the batched cron's body: every (distro, queue) pair of a tick in ONE call -- on one device, or sharded by
 // distro over the devices of SetGPUDevices when the tick is large enough. Per distro it returns what runTunablePlanner would

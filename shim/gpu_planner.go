@@ -491,7 +491,14 @@ func planBatch(ctx context.Context, ds []*distro.Distro, queues [][]task.Task) (
 		return nil, nil, err
 	}
 	if shard != nil {
-		if err := shard.plan(&in, &out); err != nil {
+		err := shard.plan(&in, &out)
+		if err == errGPUShardClosed { // replaced while this batch was being packed: one device plans it, same result
+			err = nil
+			if rc := C.evg_plan_distros(g.c, &in, &out); rc != C.EVG_OK {
+				return nil, nil, errors.Errorf("evg_plan_distros: %s (%d)", C.GoString(C.evg_last_error(g.c)), int(rc))
+			}
+		}
+		if err != nil {
 			return nil, nil, err
 		}
 	} else if batcher != nil {
