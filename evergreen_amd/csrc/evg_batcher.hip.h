@@ -10,8 +10,12 @@
 //   * a caller's request JOINS the open batch (a mutex-protected reservation: where its rows, edges, keys and distros go in
 //     the batch's numbering), packs its columns -- re-based into that numbering -- into its own stretch of the batch's
 //     page-locked block ON ITS OWN THREAD (the packing of a batch runs on as many cores as it has callers), and sleeps;
-//   * the first caller of a batch is its leader: it closes the batch when `max_requests` joined, when nobody new has joined
-//     for a quarter of `max_wait_us`, or after `max_wait_us`; waits for the members' packing; then ONE copy to the device,
+//   * the first caller of a batch is its leader: it closes the batch when `max_requests` joined, when every caller the batcher
+//     currently EXPECTS has joined (the recent peak of threads inside the batcher, less those blocked in other batches: threads
+//     in lockstep -- the callers of the batch that has just come back -- fill the next batch within microseconds and never wait
+//     out the window; a lone caller expects nobody and leaves at once), or after `max_wait_us`; waits for the members' packing
+//     (condition variables throughout: first form polled under the one mutex and 128 callers took 93 ms for what 64 did in 13);
+//     then ONE copy to the device,
 //     one kernel that moves every member's column stretches to their place in the batch's columns (a table of segments), the
 //     ordinary planner (or allocator) launches over the whole batch, ONE copy back;
 //   * every member cuts its own results out of the batch's output block on its own thread, back in its own numbering.
@@ -88,6 +92,8 @@ struct Slot {
   std::chrono::steady_clock::time_point opened, last_join;
   std::atomic<int> packed{0};
   int unpacked = 0;
+  std::condition_variable cv_lead;  // the leader's: a join, the last member's packing
+  std::condition_variable cv_done;  // the members': the batch's results are in h_out
   // results of the batch (valid in DONE)
   int rc = EVG_OK;
   std::string err;
@@ -104,8 +110,11 @@ struct evg_batcher {
   int32_t max_wait_us = 200, max_requests = 64;
   size_t max_batch_bytes = 32u << 20;  // of packed inputs per batch (EVG_BATCHER_MAX_BYTES); a request above half of it goes straight through
   std::mutex mu;
-  std::condition_variable cv;
+  std::condition_variable cv_free;  // callers waiting for a slot to join
   evgb::Slot slot[4];
+  std::atomic<int> inside{0};  // threads between entry and return of evg_batcher_plan / evg_batcher_allocate
+  int expect = 1;              // how many callers a batch waits for before its window ends: the recent peak of `inside`, decayed
+                               // whenever a window ran out short of it
   evg_ctx* direct = nullptr;  // requests too large for a batch go straight through (serialised by the context's mutex)
   // counters (evg_batcher_get_stats)
   uint64_t n_batches = 0, n_requests = 0, n_direct = 0, max_batch = 0;
@@ -158,7 +167,7 @@ static Slot* join_slot(evg_batcher* b, std::unique_lock<std::mutex>& lk, int kin
       *leader = true;
       return &s;
     }
-    b->cv.wait(lk);
+    b->cv_free.wait(lk);
   }
 }
 
@@ -344,31 +353,45 @@ static int run_alloc_batch(evg_batcher* b, Slot& s) {
 // The leader's part between its own packing and the results: close, wait for the members' packing, run, publish.
 static void lead(evg_batcher* b, Slot& s) {
   using clk = std::chrono::steady_clock;
-  const auto max_wait = std::chrono::microseconds(b->max_wait_us), idle = std::chrono::microseconds(std::max(5, b->max_wait_us / 4));
-  for (;;) {  // short waits: poll (a condition variable's timed wait is no finer than the kernel's timer slack, ~50 us)
+  int members;
+  {
     std::unique_lock<std::mutex> lk(b->mu);
-    const auto now = clk::now();
-    if ((int)s.members.size() >= b->max_requests || s.in_used >= b->max_batch_bytes / 2 || now - s.opened >= max_wait || now - s.last_join >= idle ||
-        b->closing) {
-      s.state = Slot::CLOSED;
-      break;
+    const auto deadline = s.opened + std::chrono::microseconds(b->max_wait_us);
+    for (;;) {
+      int elsewhere = 0;  // callers blocked in other batches that are still filling or on the device: they cannot join this one
+      for (const Slot& o : b->slot)  // (the members of a batch that is DONE are about to return and call again: they are expected here)
+        if (&o != &s && (o.state == Slot::OPEN || o.state == Slot::CLOSED)) elsewhere += (int)o.members.size();
+      const int target = std::max(1, std::min<int>(b->max_requests, b->expect - elsewhere));
+      members = (int)s.members.size();
+      const bool timed_out = clk::now() >= deadline;
+      if (members >= b->max_requests || members >= target || s.in_used >= b->max_batch_bytes / 2 || b->closing || timed_out) {
+        if (timed_out && members < target) b->expect = std::max(members + elsewhere, b->expect / 2);  // fewer callers than it thought
+        break;
+      }
+      s.cv_lead.wait_until(lk, deadline);
     }
-    lk.unlock();
-    std::this_thread::yield();
+    s.state = Slot::CLOSED;  // membership is final
+    b->cv_free.notify_all();  // whoever waits for an open slot may open another one now
+    s.cv_lead.wait(lk, [&] { return s.packed.load(std::memory_order_acquire) >= members; });
   }
-  b->cv.notify_all();  // whoever waits for an open slot may open the other one now
-  const int members = (int)s.members.size();  // fixed once CLOSED
-  while (s.packed.load(std::memory_order_acquire) < members) std::this_thread::yield();
   int rc = s.kind == 0 ? run_plan_batch(b, s) : run_alloc_batch(b, s);
-  std::unique_lock<std::mutex> lk(b->mu);
-  s.rc = rc;
-  if (rc) s.err = s.ctx->err;
-  s.state = Slot::DONE;
-  b->n_batches++;
-  b->n_requests += (uint64_t)members;
-  b->max_batch = std::max<uint64_t>(b->max_batch, (uint64_t)members);
-  lk.unlock();
-  b->cv.notify_all();
+  {
+    std::lock_guard<std::mutex> lk(b->mu);
+    s.rc = rc;
+    if (rc) s.err = s.ctx->err;
+    s.state = Slot::DONE;
+    b->n_batches++;
+    b->n_requests += (uint64_t)members;
+    b->max_batch = std::max<uint64_t>(b->max_batch, (uint64_t)members);
+  }
+  s.cv_done.notify_all();
+}
+
+// A member has packed its columns.
+static void packed_one(evg_batcher* b, Slot& s) {
+  s.packed.fetch_add(1, std::memory_order_release);
+  std::lock_guard<std::mutex> lk(b->mu);  // (the leader checks the counter under the mutex: no lost wake-up)
+  if (s.state == Slot::CLOSED) s.cv_lead.notify_one();
 }
 
 // Every member after it has cut its results out: the last one frees the slot.
@@ -377,9 +400,15 @@ static void leave(evg_batcher* b, Slot& s) {
   if (++s.unpacked == (int)s.members.size()) {
     s.state = Slot::FREE;
     lk.unlock();
-    b->cv.notify_all();
+    b->cv_free.notify_all();
   }
 }
+
+struct Inside {  // counts the calling thread as inside the batcher for the length of a call
+  evg_batcher* b;
+  explicit Inside(evg_batcher* b_) : b(b_) { b->inside.fetch_add(1, std::memory_order_relaxed); }
+  ~Inside() { b->inside.fetch_sub(1, std::memory_order_relaxed); }
+};
 
 }  // namespace evgb
 
@@ -412,9 +441,10 @@ void evg_batcher_destroy(evg_batcher* b) {
   {
     std::unique_lock<std::mutex> lk(b->mu);
     b->closing = true;
-    b->cv.notify_all();
+    b->cv_free.notify_all();
+    for (evgb::Slot& s : b->slot) s.cv_lead.notify_all();
     // batches in flight finish; nobody new joins
-    b->cv.wait(lk, [&] { for (const evgb::Slot& s : b->slot) if (s.state != evgb::Slot::FREE) return false; return true; });
+    b->cv_free.wait(lk, [&] { for (const evgb::Slot& s : b->slot) if (s.state != evgb::Slot::FREE) return false; return true; });
   }
   for (evgb::Slot& s : b->slot) {
     if (s.ctx) {
@@ -440,6 +470,7 @@ int evg_batcher_plan(evg_batcher* b, const evg_plan_input* in, const evg_plan_ou
   using namespace evgb;
   if (!b || !in || !out) return EVG_E_INVALID;
   if (err && err_len > 0) err[0] = 0;
+  Inside in_call(b);
   // ---- the request alone: contract, hints, sizes (on the caller's thread, outside every lock) ----
   char msg[256];
   int rc = evg_validate_plan_input(in, msg, sizeof msg);
@@ -481,6 +512,8 @@ int evg_batcher_plan(evg_batcher* b, const evg_plan_input* in, const evg_plan_ou
     s.want |= m.want; s.any_fin |= m.has_fin;
     s.members.push_back(m);
     s.last_join = std::chrono::steady_clock::now();
+    b->expect = std::max(b->expect, b->inside.load(std::memory_order_relaxed));
+    if (!leader) s.cv_lead.notify_one();
   }
   Slot& s = *sp;
   // ---- pack: the request's columns, re-based into the batch's numbering ----
@@ -510,12 +543,12 @@ int evg_batcher_plan(evg_batcher* b, const evg_plan_input* in, const evg_plan_ou
     int64_t* now = at<int64_t>(p, m.col[PC_NOW]);
     for (size_t d = 0; d < nd; d++) { to[d] = in->task_off[d] + m.r0; go[d] = in->tg_off[d] + m.g0; vo[d] = in->ver_off[d] + m.v0; now[d] = in->now_ns; }
   }
-  s.packed.fetch_add(1, std::memory_order_release);
+  packed_one(b, s);
   // ---- run / wait ----
   if (leader) lead(b, s);
   else {
     std::unique_lock<std::mutex> lk(b->mu);
-    b->cv.wait(lk, [&] { return s.state == Slot::DONE; });
+    s.cv_done.wait(lk, [&] { return s.state == Slot::DONE; });
   }
   // ---- cut the results out (the slot stays DONE until every member left) ----
   rc = s.rc;
@@ -547,6 +580,7 @@ int evg_batcher_allocate(evg_batcher* b, const evg_alloc_input* in, const evg_al
   using namespace evgb;
   if (!b || !in || !out) return EVG_E_INVALID;
   if (err && err_len > 0) err[0] = 0;
+  Inside in_call(b);
   if (in->n_distros < 0 || in->n_task_groups < 0 || in->hosts.n_hosts < 0) return fail(err, err_len, EVG_E_INVALID, "negative sizes");
   if (in->n_distros == 0) return EVG_OK;
   if (!in->params || !in->host_off || !in->tg_off || !in->distro_info || !in->group_info || !out->new_hosts || !out->free_hosts || !out->status)
@@ -580,6 +614,8 @@ int evg_batcher_allocate(evg_batcher* b, const evg_alloc_input* in, const evg_al
     s.D += m.nd; s.TG += m.ntg; s.H += m.nh;
     s.members.push_back(m);
     s.last_join = std::chrono::steady_clock::now();
+    b->expect = std::max(b->expect, b->inside.load(std::memory_order_relaxed));
+    if (!leader) s.cv_lead.notify_one();
   }
   Slot& s = *sp;
   {
@@ -603,11 +639,11 @@ int evg_batcher_allocate(evg_batcher* b, const evg_alloc_input* in, const evg_al
     memcpy(p + m.col[AC_GSTAND], in->group_info, colb[AC_GSTAND]);
     if (ntg) memcpy(p + m.col[AC_GGROUPS], in->group_info + nd, colb[AC_GGROUPS]);
   }
-  s.packed.fetch_add(1, std::memory_order_release);
+  packed_one(b, s);
   if (leader) lead(b, s);
   else {
     std::unique_lock<std::mutex> lk(b->mu);
-    b->cv.wait(lk, [&] { return s.state == Slot::DONE; });
+    s.cv_done.wait(lk, [&] { return s.state == Slot::DONE; });
   }
   int rc = s.rc;
   if (rc) fail(err, err_len, rc, "%s", s.err.c_str());

@@ -64,7 +64,7 @@ def test_sixty_four_threads_one_distro_each(native, oracle):
         def job(s):
             def run():
                 p = b.plan(s, breakdown=True, n_units=False, units=True)
-                a = b.allocate(s, p.distro_info, p.group_info)
+                a = b.allocate(s, p.distro_info, p.group_info.copy())  # in/out: CountFree / CountRequired are written back
                 return p, a
             return run
         res = _run_threads([job(s) for s in subs])
@@ -134,7 +134,7 @@ def test_one_caller_alone_and_reuse(native, oracle):
         for d in range(batch.n_distros):
             s = batch.one_distro(d)
             p = b.plan(s, breakdown=True, n_units=True)
-            a = b.allocate(s, p.distro_info, p.group_info)
+            a = b.allocate(s, p.distro_info, p.group_info.copy())  # in/out: CountFree / CountRequired are written back
             _check_request(s, p, a, oracle, "alone %d" % d, n_units=True)
         subs = [batch.one_distro(d) for d in range(batch.n_distros)] * 4  # 32 requests, at most 8 per batch
         res = _run_threads([lambda s=s: b.plan(s, breakdown=False, n_units=False) for s in subs])
