@@ -341,6 +341,8 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const int d, 
   // ---- B: resolve the edge records; segmented reduce of Unit.info (planner.go:302-337) -------------------------
   const int n_own = c.gv ? 0 : n;  // slots below n_own were initialised by their owner (NONGROUP | DISTRO, min row = slot)
   int tv[E];                       // version unit of a task-group row when versions are grouped, else -1
+  uint32_t unsat4 = 0;             // bit e: some dependency edge of row i0 + e is not satisfied (what checkDependenciesMet asks in
+                                   // phase G: this loop sees every edge of the row anyway -- the deps-met pass re-read them all)
 #pragma unroll
   for (int e = 0; e < E; e++) {
     EVG_PRIO4(1, e);
@@ -390,6 +392,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const int d, 
       recent = (recent << 16) | (out ? 0xFFFFu : s16);
       const uint32_t rec = out ? (ED_OUT | (sat ? ER_SAT : 0u)) : ((sat ? ER_SAT : 0u) | (skip ? ER_SKIP : 0u) | (uint32_t)sl);
       if (!skip) join(sl, sl < n_own ? ufe & ~UF_NONGROUP : ufe);
+      unsat4 |= sat ? 0u : 1u << e;
       m.edge[x] = (uint16_t)rec;
     }
   }
@@ -877,8 +880,7 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const int d, 
     bool mt = (x1 == x0) || (f & EVG_TF_OVERRIDE_DEPS) || !is_zero_time(dmt[e]);  // HasDependenciesMet task.go:3406
     int64_t mtime = dmt[e];
     if (!mt) {
-      bool all = true;
-      for (int x = x0; x < x1; x++) all &= (m.edge[x] & ER_SAT) != 0;
+      const bool all = !((unsat4 >> e) & 1u);  // from phase B's walk over the row's edges
       if (all) {
         mt = true;  // setDependenciesMetTime task.go:690-701
         int64_t mx = 0;

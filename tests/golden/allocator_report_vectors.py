@@ -6,6 +6,38 @@ with the arithmetic written next to each (T = MaxDurationThreshold, MIN = 60e9 n
 the host-object restatement and the HIP kernel to ONE reading of the code -- the author's; a misreading shared by all
 three would not be caught here.
 
+What each statement computes, line by line of the reference (units/host_allocator.go), and where each of the three
+statements does it -- oracle/evg_oracle.cpp (evg_oracle_allocator_report), tests/host_restatements.py (HostAllocatorReport, the
+host-object form; allocator_report_rows, the vectorised form used for the 10^6-row fuzz) and csrc/evg_sched.hip (k_allocator_report):
+
+  Go line   quantity                                               formula (all int64 unless said)
+  :267-277  sums over TaskGroupInfos with Name != ""               over, durOver, dur, free, required  (CountWaitOverThreshold is summed
+                                                                   at :269 and only logged: not part of any decision)
+  :280      correctedExpectedDuration                              info.ExpectedDuration - dur
+  :282      correctedDurationOverThreshold                         info.DurationOverThreshold - durOver
+  :284      scheduledDuration                                      :280 - :282
+  :286      durationOverThreshNoTaskGroups                         info.CountDurationOverThreshold - over
+  :289      correctedHostsSpawned                                  len(hostsSpawned) - required
+  :291      hostsAvail                                             (nHostsFree - free) + :289 - :286
+  :299-301  scheduledDuration <= 0                                 timeToEmpty = timeToEmptyNoSpawns = 0
+  :304      hostsAvailNoSpawns                                     hostsAvail - :289
+  :305-308  hostsAvail <= 0                                        both = 2532000 * time.Hour (maxPossibleHours)
+  :309-311  hostsAvailNoSpawns <= 0                                timeToEmpty = scheduled / hostsAvail (Go int64 division), the other = max
+  :312-315  otherwise                                              scheduled / hostsAvail, scheduled / hostsAvailNoSpawns
+  :319      hostQueueRatio   (float32)                             float32(timeToEmpty) / float32(MaxDurationThreshold): x/0 = +Inf, 0/0 = NaN
+  :321      noSpawnsRatio    (float32)                             float32(timeToEmptyNoSpawns) / float32(MaxDurationThreshold)
+  :324-333  the drawdown gate                                      terminate rule && spawnable provider && ratio < float32(.25) && len(upHosts) > 0
+                                                                   && !hourly billing; the three host-side facts travel as drawdown_allowed
+  :395-396  hostQueueRatio == 0                                    killableHosts = numUpHosts, newCapTarget stays 0
+  :397-399  otherwise                                              killableHosts = int(float32(numUpHosts) * (1 - hostQueueRatio)) (float32 product,
+                                                                   truncated), newCapTarget = numUpHosts - killableHosts
+  :402-404  newCapTarget < MinimumHosts                            newCapTarget = MinimumHosts
+  :407      killableHosts > 0                                      a drawdown job with NewCapTarget is enqueued (drawdown = 1)
+
+The fuzz tests (tests/test_allocator_report.py: test_parity_unpinned_*) aim rows at the float32 neighbourhood of the 0.25 line, at both
+maxPossibleHours branches, at scheduledDuration <= 0 and at a zero threshold, and require the three statements to agree bit for bit
+(float32 included) -- 300,000 rows on the CPU, 1,000,000 through the HIP kernel. That is agreement of readings, not a pin.
+
 Each vector: (name, lines, info, groups, hosts_spawned, n_hosts_free, n_up_hosts, minimum_hosts, drawdown_allowed, want)
   info   = (ExpectedDuration, DurationOverThreshold, CountDurationOverThreshold, MaxDurationThreshold)
   groups = [(Name, ExpectedDuration, DurationOverThreshold, CountDurationOverThreshold, CountFree, CountRequired)]

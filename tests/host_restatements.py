@@ -255,3 +255,54 @@ def HostAllocatorReport(info: DistroQueueInfo, hostsSpawned: int, nHostsFree: in
 def _go_div(a: int, b: int) -> int:                # Go's integer division truncates toward zero
     q = abs(a) // abs(b)
     return q if (a >= 0) == (b >= 0) else -q
+
+
+def allocator_report_rows(tg_off, di, gi, spawned, free, params):
+    """The same report math as ONE vectorised statement over the ABI's rows (a third statement beside the oracle's C++ and
+    HostAllocatorReport above, written from the Go source, for fuzzing at device scale): units/host_allocator.go
+      :262-281  sums over the NAMED task groups (the "" row is skipped)          -> np.add.reduceat over rows D + key
+      :284-291  scheduledDuration, durationOverThreshNoTaskGroups, correctedHostsSpawned, hostsAvail
+      :300-316  timeToEmpty / timeToEmptyNoSpawns (Go's truncating int64 division; maxPossibleHours = 2532000)
+      :319-321  the two float32 ratios (float32(int64) / float32(int64): IEEE single, round to nearest even)
+      :327      hostQueueRatio < float32(.25) && len(upHosts) > 0 (terminationOn && terminatableDistro && !hourly = drawdown_allowed)
+      :393-407  setTargetAndTerminate: killable = int(float32(up) * (1 - ratio)) (all float32), cap target floored at MinimumHosts,
+                a drawdown job only when killableHosts > 0
+    Returns a dict of columns named like evg_alloc_report's fields."""
+    D = len(di)
+    tg_off = np.asarray(tg_off, np.int64)
+    g = gi[D:]
+    named = g["present"] != 0
+
+    def seg(col):
+        v = np.where(named, g[col].astype(np.int64), 0)
+        c = np.concatenate([[0], np.cumsum(v)])
+        return c[tg_off[1:]] - c[tg_off[:-1]]
+    durTG, durOverTG, overTG = seg("expected_duration_ns"), seg("duration_over_threshold_ns"), seg("count_duration_over_threshold")
+    freeTG, reqTG = seg("count_free"), seg("count_required")
+    scheduled = (di["expected_duration_ns"].astype(np.int64) - durTG) - (di["duration_over_threshold_ns"].astype(np.int64) - durOverTG)
+    overNoTG = di["count_duration_over_threshold"].astype(np.int64) - overTG
+    correctedSpawned = np.asarray(spawned, np.int64) - reqTG
+    hostsAvail = (np.asarray(free, np.int64) - freeTG) + correctedSpawned - overNoTG
+    noSpawns = hostsAvail - correctedSpawned
+    maxD = np.int64(2532000) * HOUR
+    pos = scheduled > 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q1 = np.where(hostsAvail > 0, scheduled // np.where(hostsAvail > 0, hostsAvail, 1), 0)   # both operands positive where used: // == Go's /
+        q2 = np.where(noSpawns > 0, scheduled // np.where(noSpawns > 0, noSpawns, 1), 0)
+    tte = np.where(pos, np.where(hostsAvail <= 0, maxD, q1), 0).astype(np.int64)
+    tteNS = np.where(pos, np.where((hostsAvail <= 0) | (noSpawns <= 0), maxD, q2), 0).astype(np.int64)
+    T = di["max_duration_threshold_ns"].astype(np.int64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = tte.astype(np.float32) / T.astype(np.float32)
+        ratioNS = tteNS.astype(np.float32) / T.astype(np.float32)
+    up = params["n_up_hosts"].astype(np.int64)
+    enter = (params["drawdown_allowed"] != 0) & (ratio < np.float32(0.25)) & (up > 0)
+    with np.errstate(invalid="ignore"):
+        kill_f = up.astype(np.float32) * (np.float32(1) - ratio)
+    kill = np.where(enter, np.where(ratio == 0, up, np.where(enter, kill_f, 0).astype(np.int64)), 0)
+    target = np.where(enter & (ratio != 0), up - kill, 0)
+    target = np.maximum(target, params["minimum_hosts"].astype(np.int64))
+    draw = enter & (kill > 0)
+    return {"time_to_empty_ns": tte, "time_to_empty_no_spawns_ns": tteNS, "host_queue_ratio": ratio, "no_spawns_ratio": ratioNS,
+            "hosts_avail": hostsAvail.astype(np.int32), "drawdown": draw.astype(np.int32), "new_cap_target": np.where(draw, target, 0).astype(np.int32),
+            "killable_hosts": kill.astype(np.int32)}

@@ -165,3 +165,74 @@ def test_hip_report_host_pointer_form(native_ctx, oracle):
     got = native_ctx.allocator_report(len(di_rows), tg_off, di_rows, gi, spawned, free, params)
     for name in abi.ALLOC_REPORT_DTYPE.names:
         assert np.array_equal(got[name], want[name], equal_nan=got[name].dtype.kind == "f"), name
+
+
+def _boundary_rows(seed, D):
+    """Rows aimed at the edges of the report math: hostQueueRatio within a few float32 ulps of the 0.25 drawdown line (timeToEmpty =
+    T / 4 +- k x the float32 spacing at that magnitude, on both sides, through the integer division), hosts available <= 0 and hosts
+    available without the spawned ones <= 0 (maxPossibleHours = 2532000 h), nothing short queued, a zero threshold (NaN / +Inf ratios),
+    up-host counts whose float32 product with (1 - ratio) sits next to an integer."""
+    rng = np.random.default_rng(seed)
+    tg_off, di, gi, spawned, free, params = _random_rows(seed, D)
+    T = rng.choice([30 * S.MINUTE, 5 * S.MINUTE, S.HOUR, 7 * S.MINUTE + 1, 0], D, p=[0.4, 0.2, 0.2, 0.19, 0.01]).astype(np.int64)
+    di["max_duration_threshold_ns"] = T
+    kind = rng.integers(0, 10, D)
+    h = rng.integers(1, 50, D).astype(np.int64)                     # hosts available for the short standalone tasks
+    ulp = np.maximum(np.spacing((T / 4).astype(np.float32)).astype(np.int64), 1)
+    tte = T // 4 + rng.integers(-3, 4, D) * ulp + rng.integers(-2, 3, D)
+    sched = np.where(kind < 6, tte * h + rng.integers(0, 2, D) * (h - 1), rng.integers(-5, 6, D) * S.MINUTE)
+    # fold the targets back into the rows: standalone durations = distro totals - the named groups' (present rows only)
+    g = gi[D:]
+    named = g["present"] != 0
+
+    def seg(col):
+        c = np.concatenate([[0], np.cumsum(np.where(named, g[col].astype(np.int64), 0))])
+        return c[tg_off[1:].astype(np.int64)] - c[tg_off[:-1].astype(np.int64)]
+    di["duration_over_threshold_ns"] = seg("duration_over_threshold_ns") + rng.integers(0, 3, D) * 45 * S.MINUTE
+    di["expected_duration_ns"] = seg("expected_duration_ns") + (di["duration_over_threshold_ns"] - seg("duration_over_threshold_ns")) + sched
+    over_no_tg = rng.integers(0, 3, D)
+    di["count_duration_over_threshold"] = seg("count_duration_over_threshold") + over_no_tg
+    corrected_spawned = rng.integers(0, 6, D) * (kind != 7)          # kind 7: nothing spawned -> hostsAvailNoSpawns == hostsAvail
+    spawned = (corrected_spawned + seg("count_required")).astype(np.int32)
+    avail = np.where(kind == 8, rng.integers(-3, 1, D), h)           # kind 8: no hosts available at all
+    avail = np.where(kind == 9, corrected_spawned - rng.integers(0, 2, D) * 0, avail)  # kind 9: only the spawned hosts (no-spawns <= 0)
+    free = (avail - corrected_spawned + over_no_tg + seg("count_free")).astype(np.int32)
+    params["n_up_hosts"] = rng.integers(0, 4000, D)
+    params["drawdown_allowed"] = rng.random(D) < 0.85
+    return tg_off, di, gi, spawned, free, params
+
+
+def _assert_reports_equal(got, want, what):
+    for name in abi.ALLOC_REPORT_DTYPE.names:
+        a, b = np.asarray(got[name]), np.asarray(want[name])
+        assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), "%s: %s differs in %d rows (first %d: %r vs %r)" % (
+            what, name, int((a != b).sum()), int(np.nonzero(a != b)[0][0]), a[np.nonzero(a != b)[0][0]], b[np.nonzero(a != b)[0][0]])
+
+
+def test_parity_unpinned_report_fuzz_oracle_vs_vectorised_statement(oracle):
+    """PARITY UNPINNED (the reference holds no expected values for units/host_allocator.go:250-334,393-424; see the fixture's header): what
+    can be done instead is agreement between independent statements of the Go source, at scale and on the edges. 300,000 rows here."""
+    for seed, D in ((21, 200_000), (22, 100_000)):
+        rows = _boundary_rows(seed, D) if seed == 21 else _random_rows(seed, D)
+        want = H.allocator_report_rows(*rows)
+        got = oracle.allocator_report(D, *rows)
+        _assert_reports_equal(got, want, "oracle vs vectorised statement, seed %d" % seed)
+        if seed == 21:  # the generator really sits on the edges
+            r = want["host_queue_ratio"]
+            near = np.abs(r - np.float32(0.25)) <= np.float32(4e-7)
+            assert near.sum() > D // 20 and (r[near] < np.float32(0.25)).any() and (r[near] >= np.float32(0.25)).any()
+            mx = 2532000 * S.HOUR
+            assert (want["time_to_empty_ns"] == mx).sum() > D // 50 and ((want["time_to_empty_no_spawns_ns"] == mx) & (want["time_to_empty_ns"] != mx)).sum() > D // 50
+            assert np.isnan(r).any() or np.isinf(r).any()
+            assert want["drawdown"].sum() > D // 20
+
+
+@pytest.mark.gpu
+def test_parity_unpinned_report_fuzz_one_million_rows_hip(native_ctx, oracle):
+    """PARITY UNPINNED, strengthened as far as it goes: 10^6 rows on the float32 / maxPossibleHours edges through k_allocator_report,
+    bit for bit (float32 included) against the oracle AND against the vectorised statement of the Go source."""
+    D = 1_000_000
+    rows = _boundary_rows(31, D)
+    got = native_ctx.allocator_report(D, *rows)
+    _assert_reports_equal(got, oracle.allocator_report(D, *rows), "HIP vs oracle")
+    _assert_reports_equal(got, H.allocator_report_rows(*rows), "HIP vs vectorised statement")
