@@ -685,18 +685,22 @@ def main():
             ctx.profile_plan_kernel(False)
             kernel_ms = kms[len(kms) // 2]
             achieved = abytes / (kernel_ms * 1e-3) / 1e9
-            traffic, traffic_source = None, None
+            traffic, traffic_source, traffic_stale = None, None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc) and world == 1:
                 try:
                     j = json.load(open(pmc))
                     traffic = j.get("k_plan_distros_hbm_bytes_per_launch")
-                    traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this workload, NOT measured in this run)" % j.get("source", "pmc_latest.json")
+                    # the counters are a committed file: say so, and say when the kernels have changed since they were taken
+                    have, now_hash = j.get("kernel_sources_sha16"), native.kernel_sources_hash()
+                    traffic_stale = have != now_hash
+                    traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this workload, NOT measured in this run; kernel sources %s, this tree %s)" % (
+                        j.get("source", "pmc_latest.json"), have or "unstamped", now_hash)
                 except Exception:
                     traffic = None
             line["roofline"] = {"bound": "hbm", "kernel": "k_plan_distros",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                                 "algorithmic_bytes_per_launch": abytes, "kernel_ms": kernel_ms, "kernel_ms_min": kms[0], "kernel_ms_mean": sum(kms) / len(kms),
                                 "plan_entry_point_ms": plan_ms[0], "allocator_ms": alloc_ms[0],
                                 "kernel_ms_scope": "median HIP-event interval around the dominant kernel of the timed tick alone, events recorded by the library on "

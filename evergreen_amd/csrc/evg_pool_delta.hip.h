@@ -100,9 +100,48 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int32_t* v, int
   if (blockIdx.x == 0 && tid == 0) out[n] = bsum[nb];
 }
 
-__global__ void __launch_bounds__(256) k_delta_mark(int n_removed, const int32_t* removed, int32_t* rmi) {
+// ---- the delta's contract, checked where the data is ---------------------------------------------------------------------------
+// Round 4 validated a delta on the HOST before anything was enqueued: a bitmap pass over the removed rows, a popcount per distro,
+// a loop over every added row and edge, a bitmap pass over the relinked edges -- ~0.3 ms of the call's 0.7 for a 5 % tick of a 1 M
+// pool. The kernels below walk the same arrays anyway: they check as they go and record the FIRST violation (lowest code, then the
+// index the code speaks of) in a small status block that comes back with the tables the host needs; the re-packed pool is swapped
+// in only when the block is clean, so a refused delta leaves the pool exactly as it was.
+//   st[0] code (DS_*), st[1] index, st[2] 1: an added row's priority does not fit int32 (the launch promises depend on it)
+enum { DS_OK = 0, DS_REMOVED_RANGE, DS_REMOVED_TWICE, DS_REMOVED_STATE, DS_ADDED_KEY, DS_ADDED_DEP_OFF, DS_ADDED_EDGE, DS_RELINK_RANGE, DS_RELINK_TWICE,
+       DS_RELINK_TO, DS_RELINK_DISTRO, DS_RELINK_IN_QUEUE, DS_DISTRO_SIZE };
+__device__ __forceinline__ void delta_fail(int32_t* st, int code, int index) {
+  // the first violation reported is the one with the lowest (code, index): what the host's sequential checks used to find first
+  const unsigned long long mine = ((unsigned long long)(uint32_t)code << 32) | (uint32_t)index;
+  atomicMin((unsigned long long*)(st + 4), mine);  // st[4..5]: packed (code, index), ~0 when clean
+}
+__device__ __forceinline__ int distro_of_row(const int32_t* task_off, int D, int r) {  // last d with task_off[d] <= r
+  int lo = 0, hi = D;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (task_off[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// removed rows -> rmi[row] = index in the removed list (-1 elsewhere: memset before); rows removed per distro counted
+__global__ void __launch_bounds__(256) k_delta_mark(int n_removed, const int32_t* removed, const uint8_t* rm_state, int N, int D,
+                                                    const int32_t* old_task_off, int32_t* rmi, int32_t* rem_cnt, int32_t* st) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_removed) rmi[removed[i]] = i;
+  if (i >= n_removed) return;
+  const int r = removed[i];
+  if ((unsigned)r >= (unsigned)N) { delta_fail(st, DS_REMOVED_RANGE, i); return; }
+  if (atomicExch(&rmi[r], i) >= 0) { delta_fail(st, DS_REMOVED_TWICE, i); return; }
+  if (rm_state[i] & ~(EVG_DEP_STATE_MASK | EVG_DEP_BLOCKED | EVG_DEP_MISSING)) delta_fail(st, DS_REMOVED_STATE, i);
+  atomicAdd(&rem_cnt[distro_of_row(old_task_off, D, r)], 1);
+}
+// rows of every distro after the delta (the scan kernels turn them into the new task_off)
+__global__ void __launch_bounds__(256) k_delta_counts(int D, const int32_t* old_task_off, const int32_t* rem_cnt, const int32_t* add_before, int32_t* cnt,
+                                                      int32_t* st) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const int n = (old_task_off[d + 1] - old_task_off[d]) - rem_cnt[d] + (add_before[d + 1] - add_before[d]);
+  if (n >= (1 << 24)) delta_fail(st, DS_DISTRO_SIZE, d);
+  cnt[d] = n;
 }
 
 struct TaskCols {  // the eleven per-task columns of evg_task_soa, mutable
@@ -114,24 +153,20 @@ struct TaskCols {  // the eleven per-task columns of evg_task_soa, mutable
 // kept[r] (exclusive count of kept rows before r) -> newrow[r] (-1: removed), src[new row] = r. add_before[d] = rows added to the
 // distros before d; old_task_off: the OLD offsets (D + 1).
 __global__ void __launch_bounds__(256) k_delta_place(int n, int D, const int32_t* rmi, const int32_t* kept, const int32_t* old_task_off,
-                                                     const int32_t* add_before, int32_t* newrow, int32_t* src) {
+                                                     const int32_t* add_before, int32_t* newrow, int32_t* src, int n_new) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
   if (rmi[r] >= 0) { newrow[r] = -1; return; }
-  int lo = 0, hi = D;  // the distro of row r: last d with old_task_off[d] <= r
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (old_task_off[mid] <= r) lo = mid; else hi = mid;
-  }
-  const int q = kept[r] + add_before[lo];
+  const int q = kept[r] + add_before[distro_of_row(old_task_off, D, r)];
   newrow[r] = q;
-  src[q] = r;
+  if (q < n_new) src[q] = r;  // (a delta whose removed rows are not distinct rows of the pool keeps more rows than the host sized for: refused later)
 }
 
 // New row q of the re-packed pool: a kept row (src[q] >= 0) or the added row -(src[q] + 1). Columns over; edge count into cnt[q].
 __global__ void __launch_bounds__(256) k_delta_rows(int n_new, int D, const int32_t* src, TaskCols dst, TaskCols old, TaskCols add,
                                                     const int32_t* old_dep_off, const int32_t* add_dep_off, const int32_t* new_task_off,
-                                                    const int32_t* tg_shift, const int32_t* ver_shift, int32_t* cnt) {
+                                                    const int32_t* tg_shift, const int32_t* ver_shift, int32_t* cnt, const int32_t* added_distro,
+                                                    const int32_t* new_tg_off, const int32_t* new_ver_off, int32_t* st) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= n_new) return;
   const int s = src[q];
@@ -151,16 +186,30 @@ __global__ void __launch_bounds__(256) k_delta_rows(int n_new, int D, const int3
     cnt[q] = old_dep_off[s + 1] - old_dep_off[s];
   } else {
     const int i = -(s + 1);  // keys of an added row are already in the new numbering
+    {
+      const int d = added_distro[i], g = add.tg_key[i], v = add.version_key[i];
+      if ((g != -1 && (g < new_tg_off[d] || g >= new_tg_off[d + 1])) || v < new_ver_off[d] || v >= new_ver_off[d + 1]) delta_fail(st, DS_ADDED_KEY, i);
+      if (add_dep_off[i + 1] < add_dep_off[i]) delta_fail(st, DS_ADDED_DEP_OFF, i);
+      const int64_t pv = add.priority[i];
+      if (pv != (int64_t)(int32_t)pv) st[2] = 1;
+    }
     dst.priority[q] = add.priority[i]; dst.expected_duration_ns[q] = add.expected_duration_ns[i]; dst.queue_ts_ns[q] = add.queue_ts_ns[i];
     dst.scheduled_ts_ns[q] = add.scheduled_ts_ns[i]; dst.deps_met_ts_ns[q] = add.deps_met_ts_ns[i]; dst.num_dependents[q] = add.num_dependents[i];
     dst.task_group_order[q] = add.task_group_order[i]; dst.task_group_max_hosts[q] = add.task_group_max_hosts[i];
     dst.tg_key[q] = add.tg_key[i]; dst.version_key[q] = add.version_key[i]; dst.flags[q] = add.flags[i];
-    cnt[q] = add_dep_off[i + 1] - add_dep_off[i];
+    const int c = add_dep_off[i + 1] - add_dep_off[i];
+    cnt[q] = c < 0 ? 0 : c;
   }
 }
-__global__ void __launch_bounds__(256) k_delta_src_added(int n_added, const int32_t* added_dst, int32_t* src) {
+// Where every added row goes: behind the kept rows of its distro, in the order given. added_dst[i] for the edge kernel, src[] for the rows.
+__global__ void __launch_bounds__(256) k_delta_src_added(int n_added, const int32_t* added_distro, const int32_t* add_before, const int32_t* new_task_off,
+                                                         int32_t* added_dst, int32_t* src, int n_new) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_added) src[added_dst[i]] = -(i + 1);
+  if (i >= n_added) return;
+  const int d = added_distro[i];
+  const int q = new_task_off[d + 1] - (add_before[d + 1] - add_before[d]) + (i - add_before[d]);
+  added_dst[i] = q < n_new ? q : 0;
+  if (q < n_new) src[q] = -(i + 1);
 }
 
 struct EdgeCols {
@@ -173,7 +222,8 @@ struct EdgeCols {
 __global__ void __launch_bounds__(256) k_delta_edges(int n_new, const int32_t* src, const int32_t* new_dep_off, EdgeCols dst, EdgeCols old,
                                                      EdgeCols add, const int32_t* old_dep_off, const int32_t* add_dep_off, const int32_t* newrow,
                                                      const int32_t* rmi, const uint8_t* rm_state, const int64_t* rm_fin, const int32_t* added_dst,
-                                                     const int32_t* relink) {
+                                                     const int32_t* relink, int n_added, const int32_t* added_distro, const int32_t* old_task_off,
+                                                     const int32_t* new_task_off, int D, int32_t* st, int edge_cap) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= n_new) return;
   const int s = src[q];
@@ -181,17 +231,40 @@ __global__ void __launch_bounds__(256) k_delta_edges(int n_new, const int32_t* s
   const int i = kept ? s : -(s + 1);
   const int e0 = kept ? old_dep_off[i] : add_dep_off[i], e1 = kept ? old_dep_off[i + 1] : add_dep_off[i + 1];
   int o = new_dep_off[q];
+  if (o < 0 || e1 < e0 || o + (e1 - e0) > edge_cap) return;  // only behind a violation already recorded: nothing is written out of bounds
   for (int e = e0; e < e1; e++, o++) {
     int j = kept ? old.dep_idx[e] : add.dep_idx[e];
     uint32_t info = kept ? (old.dep_info ? old.dep_info[e] : 0u) : add.dep_info[e];
     int64_t fin = kept ? (old.dep_finished_ts_ns ? old.dep_finished_ts_ns[e] : 0) : (add.dep_finished_ts_ns ? add.dep_finished_ts_ns[e] : 0);
     const int rl = kept && relink ? relink[e] : -1;
     if (rl >= 0) {  // the dependency enters the queue with this delta: an in-queue edge from now on
+      // only an edge whose dependency was NOT in the queue can be pointed at a row that now enters it, and only inside its own distro:
+      // a cross-distro relink would put a row outside the distro's range into dep_idx (the plan kernels index LDS with it)
+      if (j != -1) delta_fail(st, DS_RELINK_IN_QUEUE, e);
+      if (added_distro[rl] != distro_of_row(new_task_off, D, q)) delta_fail(st, DS_RELINK_DISTRO, e);
       j = added_dst[rl];
       info &= EVG_DEP_REQ_MASK;
       fin = 0;
-    } else if (!kept && j <= -2) {
-      j = added_dst[-(j + 2)];  // another added row (a pool row's edge is -1 or a row: evg_validate_plan_input)
+    } else if (!kept) {
+      // an added row's dependency: -1, a CURRENT row of the same distro, or -(k + 2) = added row k of the same distro
+      const int d = added_distro[i];
+      if (j <= -2) {
+        const int k = -(j + 2);
+        if (k >= n_added || added_distro[k] != d) { delta_fail(st, DS_ADDED_EDGE, e); j = -1; }
+        else j = added_dst[k];
+      } else if (j >= 0) {
+        if (j < old_task_off[d] || j >= old_task_off[d + 1]) { delta_fail(st, DS_ADDED_EDGE, e); j = -1; }
+        else {
+          const int nj = newrow[j];
+          if (nj >= 0) j = nj;
+          else {  // the dependency leaves the queue in this very delta
+            const int k = rmi[j];
+            info = (info & EVG_DEP_REQ_MASK) | rm_state[k];
+            fin = rm_fin ? rm_fin[k] : 0;
+            j = -1;
+          }
+        }
+      }
     } else if (j >= 0) {
       const int nj = newrow[j];
       if (nj >= 0) {
@@ -210,13 +283,17 @@ __global__ void __launch_bounds__(256) k_delta_edges(int n_new, const int32_t* s
 }
 
 // relink[edge] = the added row a kept row's edge points at from now on (-1 elsewhere: memset before)
-__global__ void __launch_bounds__(256) k_delta_relink(int n, const int32_t* edges, const int32_t* to, int32_t* relink) {
+__global__ void __launch_bounds__(256) k_delta_relink(int n, const int32_t* edges, const int32_t* to, int32_t* relink, int E, int n_added, int32_t* st) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) relink[edges[i]] = to[i];
+  if (i >= n) return;
+  const int e = edges[i], k = to[i];
+  if ((unsigned)e >= (unsigned)E) { delta_fail(st, DS_RELINK_RANGE, i); return; }
+  if ((unsigned)k >= (unsigned)n_added) { delta_fail(st, DS_RELINK_TO, i); return; }
+  if (atomicExch(&relink[e], k) >= 0) delta_fail(st, DS_RELINK_TWICE, i);
 }
-__global__ void __launch_bounds__(256) k_gather_i32(int n, const int32_t* idx, const int32_t* v, int32_t* out) {
+__global__ void __launch_bounds__(256) k_gather_i32(int n, const int32_t* idx, const int32_t* v, int32_t* out, int idx_max) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = v[idx[i]];
+  if (i < n) out[i] = (unsigned)idx[i] <= (unsigned)idx_max ? v[idx[i]] : 0;
 }
 
 }  // namespace evg

@@ -1619,6 +1619,15 @@ int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
   dt.dep_finished_ts_ns = up(t.dep_finished_ts_ns, E);
   di.distros = up(in->distros, D); di.task_off = up(in->task_off, D + 1); di.tg_off = up(in->tg_off, D + 1); di.ver_off = up(in->ver_off, D + 1);
   if (rc) return rc;
+  if (D == 0) {  // an empty pool: evg_validate_plan_input accepts NULL offset tables for it (so does evg_multi_load); nothing to remember
+    c->pool_task_off.assign(1, 0); c->pool_tg_off.assign(1, 0); c->pool_ver_off.assign(1, 0);
+    c->pool_gv.clear();
+    c->pool_pri_wide = false;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pool_in = di;
+    c->pool_loaded = true;
+    return EVG_OK;
+  }
   c->pool_task_off.assign(in->task_off, in->task_off + D + 1);
   c->pool_tg_off.assign(in->tg_off, in->tg_off + D + 1);
   c->pool_ver_off.assign(in->ver_off, in->ver_off + D + 1);
@@ -1772,6 +1781,7 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   const int nl = dl->n_relinked;
   if (nl < 0 || (nl > 0 && (!dl->relinked_edges || !dl->relinked_to))) return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: null or negative");
   if (nr == 0 && na == 0 && nl == 0 && !dl->tg_off && !dl->ver_off) return EVG_OK;
+  if (D == 0) return nr || na || nl ? set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: the pool has no distros") : EVG_OK;
   const evg_task_soa& ad = dl->added;
   if (na > 0 && (ad.n_tasks != na || !ad.priority || !ad.expected_duration_ns || !ad.queue_ts_ns || !ad.scheduled_ts_ns || !ad.deps_met_ts_ns ||
                  !ad.num_dependents || !ad.task_group_order || !ad.task_group_max_hosts || !ad.tg_key || !ad.version_key || !ad.flags || !ad.dep_off ||
@@ -1789,7 +1799,9 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   auto lap = [](const char*) {};
 #endif
   const std::vector<int32_t>& toff = c->pool_task_off;
-  // ---- the delta against the pool's layout: per-distro counts, the new offset tables, where every added row goes ----
+  // ---- what the HOST still checks: O(D) tables and one pass over the added rows' distro numbers and edge offsets (they size the
+  // launches and bound every index the kernels form). Everything per row / per edge -- ranges, duplicates, keys, dependency
+  // targets, relinks -- is checked by the kernels while they move the data (evg_pool_delta.hip.h: the status block) ----
   const int32_t* n_tg = dl->tg_off ? dl->tg_off : c->pool_tg_off.data();
   const int32_t* n_ver = dl->ver_off ? dl->ver_off : c->pool_ver_off.data();
   std::vector<int32_t> tg_shift(D + 1), ver_shift(D + 1);
@@ -1800,72 +1812,18 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
     tg_shift[d] = n_tg[d] - c->pool_tg_off[d];
     ver_shift[d] = n_ver[d] - c->pool_ver_off[d];
   }
-  std::vector<int32_t> rem(D, 0), add(D, 0);
-  // distinct + in range: one bit per row (sorting the 25,000 removed rows and relinked edges of a 5 % tick was 0.8 ms of the call)
-  auto mark_all = [&](const int32_t* v, int n, int range, const char* what) -> int {
-    c->seen_bits.assign((size_t)range / 64 + 1, 0ull);
-    for (int i = 0; i < n; i++) {
-      if (v[i] < 0 || v[i] >= range) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: %s %d is outside the pool", what, v[i]);
-      uint64_t& w = c->seen_bits[(size_t)v[i] >> 6];
-      const uint64_t bit = 1ull << (v[i] & 63);
-      if (w & bit) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: %s %d is listed twice", what, v[i]);
-      w |= bit;
-    }
-    return EVG_OK;
-  };
-  if (int rcm = mark_all(dl->removed_rows, nr, N, "removed row")) return rcm;
-  // removed rows per distro = the bits of the distro's row range (a binary search per removed row was 0.4 ms of mispredicted branches)
-  if (nr > 0)
-    for (int d = 0; d < D; d++) {
-      const int lo = toff[d], hi = toff[d + 1];
-      if (hi <= lo) continue;
-      int cnt = 0;
-      for (int wd = lo >> 6; wd <= (hi - 1) >> 6; wd++) {
-        uint64_t w = c->seen_bits[wd];
-        if (wd == lo >> 6) w &= ~0ull << (lo & 63);
-        if (wd == (hi - 1) >> 6 && ((hi - 1) & 63) != 63) w &= (1ull << (((hi - 1) & 63) + 1)) - 1ull;
-        cnt += __builtin_popcountll(w);
-      }
-      rem[d] = cnt;
-    }
-  for (int i = 0; i < nr; i++)
-    if (dl->removed_dep_state[i] & ~(EVG_DEP_STATE_MASK | EVG_DEP_BLOCKED | EVG_DEP_MISSING))
-      return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: removed_dep_state[%d] holds bits outside EVG_DEP_STATE / BLOCKED / MISSING", i);
-  bool pri_wide = c->pool_pri_wide;
+  std::vector<int32_t> add_before(D + 1, 0);
   for (int i = 0; i < na; i++) {
     const int d = dl->added_distro[i];
     if (d < 0 || d >= D || (i > 0 && d < dl->added_distro[i - 1])) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added_distro must be non-decreasing in [0, D) (row %d)", i);
-    add[d]++;
-    const int g = ad.tg_key[i], v = ad.version_key[i];
-    if ((g != -1 && (g < n_tg[d] || g >= n_tg[d + 1])) || v < n_ver[d] || v >= n_ver[d + 1])
-      return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added row %d: a key outside the distro's (new) key range", i);
+    add_before[d + 1]++;
     if (ad.dep_off[i + 1] < ad.dep_off[i]) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added dep_off not monotone at row %d", i);
-    for (int e = ad.dep_off[i]; e < ad.dep_off[i + 1]; e++) {
-      const int j = ad.dep_idx[e];
-      const bool ok = j == -1 || (j >= toff[d] && j < toff[d + 1]) || (j <= -2 && -(j + 2) < na && dl->added_distro[-(j + 2)] == d);
-      if (!ok) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added edge %d: %d is neither -1, a current row of the same distro, nor -(k + 2) for an added row k of it", e, j);
-    }
-    pri_wide |= ad.priority[i] != (int64_t)(int32_t)ad.priority[i];
   }
-  if (int rcm = mark_all(dl->relinked_edges, nl, E, "relinked edge")) return rcm;
-  for (int i = 0; i < nl; i++)
-    if (dl->relinked_to[i] < 0 || dl->relinked_to[i] >= na) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: relinked_to[%d] is not an added row", i);
-  std::vector<int32_t> new_toff(D + 1, 0), add_before(D + 1, 0), added_dst(std::max(na, 1));
-  for (int d = 0; d < D; d++) {
-    new_toff[d + 1] = new_toff[d] + (toff[d + 1] - toff[d]) - rem[d] + add[d];
-    add_before[d + 1] = add_before[d] + add[d];
-    if (new_toff[d + 1] - new_toff[d] >= (1 << 24)) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: distro %d would have 2^24 tasks or more", d);
-  }
-  {
-    int i = 0;
-    for (int d = 0; d < D; d++) {
-      const int first = new_toff[d + 1] - add[d];  // behind the distro's kept rows
-      for (int k = 0; k < add[d]; k++, i++) added_dst[i] = first + k;
-    }
-  }
-  const int NN = new_toff[D];
+  for (int d = 0; d < D; d++) add_before[d + 1] += add_before[d];
+  if (nr > N) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: %d removed rows in a pool of %d", nr, N);
+  const int NN = N - nr + na;  // when the removed rows are distinct rows of the pool (the kernels check; the guards below hold otherwise)
   const size_t EN_cap = (size_t)E + (size_t)EA;  // edges only go (with their rows) or come (with the added rows)
-  lap("validated, tables cut");
+  lap("tables cut");
   StreamDrain drain{c};
   hipStream_t st = c->stream;
   // ---- the delta's arrays up: ONE page-locked block, ONE copy (a 5 % tick is ~4 MB in ~30 arrays: from pageable memory every
@@ -1873,7 +1831,7 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   Stager sg{c};
   {
     const size_t in_bytes = (size_t)nr * (4 + 1 + 8) + (size_t)na * (4 + 5 * 8 + 5 * 4 + 2 + 4) + 4 + (size_t)EA * (4 + 1 + 8) + (size_t)nl * 8 +
-                            5 * 4 * ((size_t)D + 1) + 40 * 256;
+                            7 * 4 * ((size_t)D + 1) + 40 * 256;
     if (in_bytes <= kPackLimit)
       if (int rc0 = sg.begin_packed(in_bytes, 256)) return rc0;
   }
@@ -1885,23 +1843,28 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
     rc = ensure(c, b, std::max<size_t>(bytes, 16));
     return rc ? nullptr : b.p;
   };
-  const int nb_old = (N + kScanTile - 1) / kScanTile, nb_new = (NN + kScanTile - 1) / kScanTile;
+  const int nb_old = (N + kScanTile - 1) / kScanTile, nb_new = (NN + kScanTile - 1) / kScanTile, nb_d = (D + kScanTile - 1) / kScanTile;
   int32_t* d_rmi = (int32_t*)dev(4 * ((size_t)N + 1));
   int32_t* d_kept = (int32_t*)dev(4 * ((size_t)N + 1));
   int32_t* d_newrow = (int32_t*)dev(4 * ((size_t)N + 1));
   int32_t* d_src = (int32_t*)dev(4 * ((size_t)NN + 1));
-  int32_t* d_bsum = (int32_t*)dev(4 * ((size_t)std::max(nb_old, nb_new) + 2));
-  int32_t* d_ecut = (int32_t*)dev(4 * (size_t)(D + 1));
-  int32_t* d_relink = nl > 0 ? (int32_t*)dev(4 * ((size_t)E + 1)) : nullptr;
+  int32_t* d_bsum = (int32_t*)dev(4 * ((size_t)std::max(std::max(nb_old, nb_new), nb_d) + 2));
+  int32_t* d_relink = nl > 0 ? (int32_t*)dev(4 * ((size_t)E + 1)) : (slot++, nullptr);
+  int32_t* d_added_dst = (int32_t*)dev(4 * ((size_t)na + 1));
+  int32_t* d_rem = (int32_t*)dev(4 * ((size_t)D + 1));
+  // what comes back in ONE copy: [status: 8 words][edge offset at every distro boundary: D + 1][the new task_off: D + 1]
+  int32_t* d_back = (int32_t*)dev(4 * (8 + 2 * ((size_t)D + 1)));
   if (rc) return rc;
+  int32_t *d_st = d_back, *d_ecut = d_back + 8, *d_ntoff = d_ecut + (D + 1);
   const int32_t* d_removed = sg.up(dl->removed_rows, (size_t)nr);
   const uint8_t* d_rm_state = sg.up(dl->removed_dep_state, (size_t)nr);
   const int64_t* d_rm_fin = sg.up(dl->removed_finished_ts_ns, (size_t)nr);
-  const int32_t* d_added_dst = sg.up((const int32_t*)added_dst.data(), (size_t)na);
+  const int32_t* d_added_distro = sg.up(dl->added_distro, (size_t)na);
   const int32_t* d_add_before = sg.up((const int32_t*)add_before.data(), (size_t)(D + 1));
   const int32_t* d_tg_shift = sg.up((const int32_t*)tg_shift.data(), (size_t)(D + 1));
   const int32_t* d_ver_shift = sg.up((const int32_t*)ver_shift.data(), (size_t)(D + 1));
-  const int32_t* d_new_toff_idx = sg.up((const int32_t*)new_toff.data(), (size_t)(D + 1));
+  const int32_t* d_ntg = sg.up(n_tg, (size_t)(D + 1));
+  const int32_t* d_nver = sg.up(n_ver, (size_t)(D + 1));
   const int32_t* d_rl_edges = sg.up(dl->relinked_edges, (size_t)nl);
   const int32_t* d_rl_to = sg.up(dl->relinked_to, (size_t)nl);
   TaskCols a_cols{(int64_t*)sg.up(ad.priority, (size_t)na), (int64_t*)sg.up(ad.expected_duration_ns, (size_t)na), (int64_t*)sg.up(ad.queue_ts_ns, (size_t)na),
@@ -1933,43 +1896,77 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   int32_t* n_dep_off = (int32_t*)nw[11].p;
   EdgeCols n_edges{(int32_t*)nw[12].p, (uint8_t*)nw[13].p, (int64_t*)nw[14].p}, o_edges{(int32_t*)t.dep_idx, (uint8_t*)t.dep_info, (int64_t*)t.dep_finished_ts_ns};
   auto grid = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  // ---- status block; removed rows; rows per distro; the new task_off ----
+  HIP_TRY(c, hipMemsetAsync(d_st, 0, 16, st));
+  HIP_TRY(c, hipMemsetAsync(d_st + 4, 0xFF, 8, st));  // packed (code, index) of the first violation: ~0 = clean
+  HIP_TRY(c, hipMemsetAsync(d_rem, 0, 4 * ((size_t)D + 1), st));
+  HIP_TRY(c, hipMemsetAsync(d_src, 0, 4 * ((size_t)NN + 1), st));  // a refused delta leaves entries unset: they must still be rows of the pool
+  if (N > 0) HIP_TRY(c, hipMemsetAsync(d_rmi, 0xFF, 4 * (size_t)N, st));
+  if (nr > 0) hipLaunchKernelGGL(k_delta_mark, grid(nr), dim3(256), 0, st, nr, d_removed, d_rm_state, N, D, p.task_off, d_rmi, d_rem, d_st);
+  hipLaunchKernelGGL(k_delta_counts, grid(D), dim3(256), 0, st, D, p.task_off, d_rem, d_add_before, d_ntoff, d_st);
+  hipLaunchKernelGGL(k_scan_block_sums<false>, dim3(nb_d), dim3(kScanBlock), 0, st, d_ntoff, D, d_bsum);
+  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb_d);
+  hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb_d), dim3(kScanBlock), 0, st, d_ntoff, D, d_bsum, nb_d, d_ntoff);
   // ---- kept rows, their new numbers ----
   if (N > 0) {
-    HIP_TRY(c, hipMemsetAsync(d_rmi, 0xFF, 4 * (size_t)N, st));
-    if (nr > 0) hipLaunchKernelGGL(k_delta_mark, grid(nr), dim3(256), 0, st, nr, d_removed, d_rmi);
     hipLaunchKernelGGL(k_scan_block_sums<true>, dim3(nb_old), dim3(kScanBlock), 0, st, d_rmi, N, d_bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb_old);
     hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb_old), dim3(kScanBlock), 0, st, d_rmi, N, d_bsum, nb_old, d_kept);
-    hipLaunchKernelGGL(k_delta_place, grid(N), dim3(256), 0, st, N, D, d_rmi, d_kept, p.task_off, d_add_before, d_newrow, d_src);
+    hipLaunchKernelGGL(k_delta_place, grid(N), dim3(256), 0, st, N, D, d_rmi, d_kept, p.task_off, d_add_before, d_newrow, d_src, NN);
   }
-  if (na > 0) hipLaunchKernelGGL(k_delta_src_added, grid(na), dim3(256), 0, st, na, d_added_dst, d_src);
+  if (na > 0) hipLaunchKernelGGL(k_delta_src_added, grid(na), dim3(256), 0, st, na, d_added_distro, d_add_before, d_ntoff, d_added_dst, d_src, NN);
   if (nl > 0) {
     HIP_TRY(c, hipMemsetAsync(d_relink, 0xFF, 4 * (size_t)E, st));
-    hipLaunchKernelGGL(k_delta_relink, grid(nl), dim3(256), 0, st, nl, d_rl_edges, d_rl_to, d_relink);
+    hipLaunchKernelGGL(k_delta_relink, grid(nl), dim3(256), 0, st, nl, d_rl_edges, d_rl_to, d_relink, E, na, d_st);
   }
   if (NN > 0) {
-    hipLaunchKernelGGL(k_delta_rows, grid(NN), dim3(256), 0, st, NN, D, d_src, n_cols, o_cols, a_cols, t.dep_off, d_add_dep_off, d_new_toff_idx, d_tg_shift,
-                       d_ver_shift, n_dep_off);
+    hipLaunchKernelGGL(k_delta_rows, grid(NN), dim3(256), 0, st, NN, D, d_src, n_cols, o_cols, a_cols, t.dep_off, d_add_dep_off, d_ntoff, d_tg_shift,
+                       d_ver_shift, n_dep_off, d_added_distro, d_ntg, d_nver, d_st);
     hipLaunchKernelGGL(k_scan_block_sums<false>, dim3(nb_new), dim3(kScanBlock), 0, st, n_dep_off, NN, d_bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb_new);
     hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb_new), dim3(kScanBlock), 0, st, n_dep_off, NN, d_bsum, nb_new, n_dep_off);
     hipLaunchKernelGGL(k_delta_edges, grid(NN), dim3(256), 0, st, NN, d_src, n_dep_off, n_edges, o_edges, a_edges, t.dep_off, d_add_dep_off, d_newrow, d_rmi,
-                       d_rm_state, d_rm_fin, d_added_dst, d_relink);
-    hipLaunchKernelGGL(k_gather_i32, grid(D + 1), dim3(256), 0, st, D + 1, d_new_toff_idx, n_dep_off, d_ecut);
+                       d_rm_state, d_rm_fin, d_added_dst, d_relink, na, d_added_distro, p.task_off, d_ntoff, D, d_st, (int)EN_cap);
+    hipLaunchKernelGGL(k_gather_i32, grid(D + 1), dim3(256), 0, st, D + 1, d_ntoff, n_dep_off, d_ecut, NN);
   } else {
     HIP_TRY(c, hipMemsetAsync(n_dep_off, 0, 8, st));
     HIP_TRY(c, hipMemsetAsync(d_ecut, 0, 4 * (size_t)(D + 1), st));
   }
   HIP_TRY(c, hipGetLastError());
   lap("buffers + kernels enqueued");
-  // the small tables of the new pool; the edge offset at every distro boundary comes back for the launch hints
-  HIP_TRY(c, hipMemcpyAsync(nw[16].p, new_toff.data(), 4 * (size_t)(D + 1), hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(nw[17].p, n_tg, 4 * (size_t)(D + 1), hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(nw[18].p, n_ver, 4 * (size_t)(D + 1), hipMemcpyHostToDevice, st));
-  std::vector<int32_t> ecut(D + 1, 0);
-  HIP_TRY(c, hipMemcpyAsync(ecut.data(), d_ecut, 4 * (size_t)(D + 1), hipMemcpyDeviceToHost, st));
+  // the small tables of the new pool; status, edge cuts and the new task_off come back in one copy
+  HIP_TRY(c, hipMemcpyAsync(nw[16].p, d_ntoff, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(nw[17].p, d_ntg, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(nw[18].p, d_nver, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
+  std::vector<int32_t> back(8 + 2 * ((size_t)D + 1), 0);
+  HIP_TRY(c, hipMemcpyAsync(back.data(), d_back, 4 * back.size(), hipMemcpyDeviceToHost, st));
   HIP_TRY(c, hipStreamSynchronize(st));
   lap("tables up, cuts back, synced");
+  {  // the kernels' verdict: the first violation in the order the host used to look for them
+    const unsigned long long first = ((unsigned long long)(uint32_t)back[5] << 32) | (uint32_t)back[4];
+    if (first != ~0ull) {
+      const int code = (int)(first >> 32), idx = (int)(uint32_t)first;
+      switch (code) {
+        case DS_REMOVED_RANGE: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: removed row %d is outside the pool", dl->removed_rows[idx]);
+        case DS_REMOVED_TWICE: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: removed row %d is listed twice", dl->removed_rows[idx]);
+        case DS_REMOVED_STATE: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: removed_dep_state[%d] holds bits outside EVG_DEP_STATE / BLOCKED / MISSING", idx);
+        case DS_ADDED_KEY: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added row %d: a key outside the distro's (new) key range", idx);
+        case DS_ADDED_DEP_OFF: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added dep_off not monotone at row %d", idx);
+        case DS_ADDED_EDGE: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added edge %d: %d is neither -1, a current row of the same distro, nor -(k + 2) for an added row k of it", idx, ad.dep_idx[idx]);
+        case DS_RELINK_RANGE: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: relinked edge %d is outside the pool", dl->relinked_edges[idx]);
+        case DS_RELINK_TWICE: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: relinked edge %d is listed twice", dl->relinked_edges[idx]);
+        case DS_RELINK_TO: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: relinked_to[%d] is not an added row", idx);
+        case DS_RELINK_DISTRO: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: relinked edge %d belongs to a row of another distro than the added row it is pointed at", idx);
+        case DS_RELINK_IN_QUEUE: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: relinked edge %d already names a row of the queue (only an out-of-queue edge can be relinked)", idx);
+        case DS_DISTRO_SIZE: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: distro %d would have 2^24 tasks or more", idx);
+        default: return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: the delta violates the contract (code %d at %d)", code, idx);
+      }
+    }
+  }
+  const int32_t* ecut = back.data() + 8;
+  std::vector<int32_t> new_toff(back.begin() + 8 + (D + 1), back.begin() + 8 + 2 * (D + 1));
+  if (new_toff[D] != NN) return set_err(c, EVG_E_HIP, "evg_pool_apply_delta: internal: the re-packed pool has %d rows, %d expected", new_toff[D], NN);
+  const bool pri_wide = c->pool_pri_wide || back[2] != 0;
   // ---- swap: the new buffers ARE the pool (the distro settings are not re-packed: their buffer moves over) ----
   std::swap(nw[15], c->pool[15]);
   std::swap(c->pool, c->pool_alt);

@@ -34,6 +34,19 @@ EXPORTS = [
 _lib = None
 
 
+def kernel_sources_hash() -> str:
+    """sha256 (first 16 hex digits) over the device sources of the library, in name order: what a committed rocprofv3 counter summary
+    (profiles/pmc_latest.json) is stamped with, so that bench.py can tell when the kernels changed after the counters were taken."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hip.h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 class NativeError(RuntimeError):
     pass
 

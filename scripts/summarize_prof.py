@@ -51,6 +51,14 @@ def main():
         if "k_plan_distros<false, false>" in k and "hbm_bytes_per_launch_corrected" in v:
             out["k_plan_distros_hbm_bytes_per_launch"] = v["hbm_bytes_per_launch_corrected"]
             out["k_plan_distros_hbm_bytes_per_launch_raw"] = v["hbm_bytes_per_launch_raw"]
+    # the build these counters describe: bench.py reports roofline.traffic_stale when the tree's kernel sources hash differently
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from evergreen_amd import native
+        out["kernel_sources_sha16"] = native.kernel_sources_hash()
+    except Exception as e:  # pragma: no cover
+        out["kernel_sources_sha16"] = "unknown (%s)" % e
+    out["source"] = tag + "_pmc.json"
     json.dump(out, open(os.path.join(d, tag + "-pmc.json"), "w"), indent=1)
 
 

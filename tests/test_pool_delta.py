@@ -113,3 +113,77 @@ def test_delta_contract_violations_are_refused(native_ctx):
     got = native_ctx.pool_plan(pool0, pool0.now_ns, breakdown=False, n_units=False)
     up = native_ctx.plan(pool0, breakdown=False, n_units=False)
     assert np.array_equal(got.order, up.order)
+
+
+@pytest.mark.gpu
+def test_violations_only_the_kernels_can_see_are_refused_and_leave_the_pool_intact(native_ctx):
+    """Round 5 moved the per-row / per-edge checks of a delta onto the device (they walk the arrays the kernels move anyway: ~0.3 ms of
+    host time per 5 % tick): every class of violation is reported with the reference to the offending entry, and -- the re-packed pool is
+    swapped in only behind a clean status block -- the resident pool plans exactly as before. Among them the two ADVICE r4 found
+    unchecked: an edge relinked to an added row of ANOTHER distro (it would put a row outside the distro's range into dep_idx) and a
+    relinked edge that already names a row of the queue."""
+    from evergreen_amd import native
+    full, pool0, delta, _, _ = _tick(gen.GenConfig(6_000, 6, gen.SEED_BASE + 63, tg_fraction=0.2, dag_depth=4))
+    assert delta.relinked_edges is not None and len(delta.relinked_edges) > 4 and len(delta.added_distro) > 8
+    native_ctx.pool_load(pool0)
+    before = native_ctx.pool_plan(pool0, pool0.now_ns, breakdown=False, n_units=False)
+
+    def refused(match, **change):
+        bad = dict(delta.kwargs())
+        bad.update(change)
+        with pytest.raises(native.NativeError, match=match):
+            native_ctx.pool_apply_delta(**bad)
+        again = native_ctx.pool_plan(pool0, pool0.now_ns, breakdown=False, n_units=False)
+        assert np.array_equal(again.order, before.order) and np.array_equal(again.wait_ns, before.wait_ns), match
+
+    rm = delta.removed_rows.copy(); rm[3] = pool0.n_tasks + 7
+    refused("outside the pool", removed_rows=rm)
+    st = delta.removed_dep_state.copy(); st[0] = 0xC0
+    refused("removed_dep_state", removed_dep_state=st)
+    cols = {k: v.copy() for k, v in delta.added_cols.items()}
+    cols["version_key"][2] = 10**6
+    refused("key outside", added_cols=cols)
+    edges = {k: (v.copy() if v is not None else None) for k, v in delta.added_edges.items()}
+    k = int(np.nonzero(edges["dep_idx"] >= 0)[0][0]) if (edges["dep_idx"] >= 0).any() else 0
+    d_of_edge_row = int(delta.added_distro[np.searchsorted(delta.added_dep_off, k, side="right") - 1])
+    other = (d_of_edge_row + 1) % pool0.n_distros
+    edges["dep_idx"][k] = int(pool0.task_off[other])  # a current row of ANOTHER distro
+    refused("added edge", added_edges=edges)
+    re = delta.relinked_edges.copy(); re[1] = re[0]
+    refused("relinked edge .* twice", relinked_edges=re)
+    re = delta.relinked_edges.copy(); re[2] = pool0.n_edges + 3
+    refused("relinked edge .* outside", relinked_edges=re)
+    to = delta.relinked_to.copy(); to[0] = len(delta.added_distro)
+    refused("not an added row", relinked_to=to)
+    # a relink across distros: point the first relinked edge at an added row of another distro
+    to = delta.relinked_to.copy()
+    kept_rl = np.nonzero(~np.isin(np.searchsorted(pool0.dep_off, delta.relinked_edges, side="right") - 1, delta.removed_rows))[0]
+    q = int(kept_rl[0])  # (an edge of a row that leaves in this delta is never copied: pick a kept row's)
+    elsewhere = np.nonzero(delta.added_distro != int(delta.added_distro[to[q]]))[0]
+    to[q] = int(elsewhere[0])
+    refused("another distro", relinked_to=to)
+    # a relinked edge that is an in-queue edge already
+    edge_row = np.searchsorted(pool0.dep_off, np.arange(pool0.n_edges), side="right") - 1
+    edge_distro = np.searchsorted(pool0.task_off, edge_row, side="right") - 1
+    ok = (pool0.edges["dep_idx"] >= 0) & ~np.isin(np.arange(pool0.n_edges), delta.relinked_edges) & ~np.isin(edge_row, delta.removed_rows) & (
+        edge_distro == int(delta.added_distro[delta.relinked_to[0]]))  # a KEPT row's in-queue edge, in the added row's own distro
+    re = delta.relinked_edges.copy(); re[0] = int(np.nonzero(ok)[0][0])
+    refused("already names a row", relinked_edges=re)
+    # and the untouched delta still applies
+    native_ctx.pool_apply_delta(**delta.kwargs())
+    pool1 = pool_delta.apply_delta(pool0, delta)
+    got = native_ctx.pool_plan(pool1, pool1.now_ns, breakdown=False, n_units=False)
+    up = native_ctx.plan(pool1, breakdown=False, n_units=False)
+    assert np.array_equal(got.order, up.order)
+
+
+@pytest.mark.gpu
+def test_an_empty_pool_loads_with_null_tables(native_ctx):
+    """evg_validate_plan_input accepts n_distros == 0 with NULL offset tables; evg_pool_load then dereferenced them."""
+    import ctypes as C
+    inp = abi.PlanInput()
+    assert native_ctx.lib.evg_pool_load(native_ctx.h, C.byref(inp)) == abi.EVG_OK
+    out = abi.PlanOutput()
+    dummy = np.zeros(4, np.int64)
+    out.order = out.deps_met = out.wait_ns = out.distro_info = out.group_info = dummy.ctypes.data
+    assert native_ctx.lib.evg_pool_plan(native_ctx.h, 0, C.byref(out)) == abi.EVG_OK
