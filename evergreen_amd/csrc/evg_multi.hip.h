@@ -130,6 +130,17 @@ struct Rank {
   evg_alloc_output aout{};
   int d0 = 0, d1 = 0;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // around move-in | plan | allocate | gather
+  // EVG_MULTI_RESIDENT_SHARDS: the rank's own distro range as a resident pool of its context (local numbering), its outputs in
+  // a local block, the allocator's settings and host columns of the range in `abuf`
+  unsigned char* outl = nullptr;
+  size_t outl_cap = 0;
+  unsigned char* abuf = nullptr;
+  size_t abuf_cap = 0;
+  struct { size_t order, met, wait, di, gi, uot, ubd, alloc, total; } ol{};
+  evg_plan_output poutl{};
+  evg_alloc_input ainl{};
+  evg_alloc_output aoutl{};
+  int32_t nh = 0;  // hosts of the range
 };
 
 // offsets of the output arrays inside a rank's output block
@@ -271,10 +282,295 @@ static void free_rank(Rank& r) {
   if (r.comm) (void)g_rccl.CommDestroy(r.comm);
   if (r.buf) (void)hipFree(r.buf);
   if (r.out) (void)hipFree(r.out);
+  if (r.outl) (void)hipFree(r.outl);
+  if (r.abuf) (void)hipFree(r.abuf);
   for (hipEvent_t& e : r.ev) if (e) (void)hipEventDestroy(e);
   if (r.stream) (void)hipStreamDestroy(r.stream);
   if (r.ctx) evg_destroy(r.ctx);
   r = Rank{};
+}
+
+
+// ---- EVG_MULTI_RESIDENT_SHARDS: every rank keeps ITS distro range resident ----------------------------------------------------------
+// The tick north_star describes starts from a pool on one rank, so its broadcast (84.6 MB for config 4, 927 MB for config 5)
+// outweighs the kernels at every N. With structural deltas (evg_pool_apply_delta) the production shape is the other way round: the
+// reference re-plans every distro every 15 s over a queue of which a few per cent changed
+// (units/crons_remote_fifteen_second.go:21,58-60), so every rank loads its range ONCE (evg_pool_load of the range, re-based to
+// local numbering), a tick routes each rank ITS part of the delta (evg_multi_apply_delta: host -> that rank's device, a few per cent
+// of the shard), every rank plans + allocates its resident pool, and the result slices are gathered into rank 0's full-size arrays
+// (the same grouped ncclSend / ncclRecv as the broadcast mode, from local offsets to global ones). A distro never moves between
+// ranks inside a load; the ranges are re-cut by the next evg_multi_load.
+__global__ void __launch_bounds__(256) k_add_base_i32(int32_t* v, int n, int32_t base) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] += base;
+}
+
+static size_t al256(size_t b) { return (b + kAlign - 1) / kAlign * kAlign; }
+
+// (Re)builds the output blocks from the CURRENT global tables (m->task_off / tg_off / ver_off / host_off): rank 0's full-size block in
+// the layout evg_multi_results reads, every rank's local block and the argument structs that point into it.
+static int resident_layout(evg_multi* m) {
+  Layout& L = m->lay;
+  const size_t D = L.D;
+  L.N = (size_t)m->task_off[D]; L.TG = (size_t)m->tg_off[D]; L.V = (size_t)m->ver_off[D];
+  const size_t N = L.N, G = D + L.TG;
+  m->n_slots = N + L.TG + L.V;
+  const bool units = (m->flags & EVG_MULTI_UNIT_ROWS) != 0;
+  Outs& o = m->o;
+  size_t pos = 0;
+  auto carve = [&](size_t bytes) { const size_t at = pos; pos = (pos + bytes + kAlign - 1) / kAlign * kAlign; return at; };
+  o.order = carve(4 * (N + 1)); o.met = carve(N + 1); o.wait = carve(8 * (N + 1)); o.di = carve(sizeof(evg_distro_info) * D);
+  o.gi = carve(sizeof(evg_group_info) * G);
+  o.uot = carve(units ? 4 * (N + 1) : 0); o.ubd = carve(units ? 8 * EVG_BREAKDOWN_FIELDS * (m->n_slots + 1) : 0);
+  o.alloc = carve(L.has_hosts ? 12 * D : 0);
+  o.total = pos + kAlign;
+  Rank& root = m->r[0];
+  EVGM_HIP(m, hipSetDevice(root.device));
+  if (o.total > m->out_cap || !root.out) {
+    if (root.out) EVGM_HIP(m, hipFree(root.out));
+    root.out = nullptr;
+    EVGM_HIP(m, hipMalloc((void**)&root.out, o.total + o.total / 8));
+    m->out_cap = o.total + o.total / 8;
+  }
+  for (int k = 0; k < m->n; k++) {
+    Rank& r = m->r[k];
+    const size_t nd = (size_t)(r.d1 - r.d0), n = (size_t)(m->task_off[r.d1] - m->task_off[r.d0]), ntg = (size_t)(m->tg_off[r.d1] - m->tg_off[r.d0]),
+                 nver = (size_t)(m->ver_off[r.d1] - m->ver_off[r.d0]), ns = n + ntg + nver;
+    size_t p2 = 0;
+    auto cv = [&](size_t bytes) { const size_t at = p2; p2 = al256(p2 + bytes); return at; };
+    r.ol.order = cv(4 * (n + 1)); r.ol.met = cv(n + 1); r.ol.wait = cv(8 * (n + 1)); r.ol.di = cv(sizeof(evg_distro_info) * nd);
+    r.ol.gi = cv(sizeof(evg_group_info) * (nd + ntg));
+    r.ol.uot = cv(units ? 4 * (n + 1) : 0); r.ol.ubd = cv(units ? 8 * EVG_BREAKDOWN_FIELDS * (ns + 1) : 0);
+    r.ol.alloc = cv(L.has_hosts ? 12 * nd : 0);
+    r.ol.total = p2 + kAlign;
+    EVGM_HIP(m, hipSetDevice(r.device));
+    if (r.ol.total > r.outl_cap || !r.outl) {
+      if (r.outl) EVGM_HIP(m, hipFree(r.outl));
+      r.outl = nullptr;
+      EVGM_HIP(m, hipMalloc((void**)&r.outl, r.ol.total + r.ol.total / 8));
+      r.outl_cap = r.ol.total + r.ol.total / 8;
+    }
+    evg_plan_output& po = r.poutl;
+    po = evg_plan_output{};
+    po.order = (int32_t*)(r.outl + r.ol.order); po.deps_met = r.outl + r.ol.met; po.wait_ns = (int64_t*)(r.outl + r.ol.wait);
+    po.distro_info = (evg_distro_info*)(r.outl + r.ol.di); po.group_info = (evg_group_info*)(r.outl + r.ol.gi);
+    if (units) { po.unit_of_task = (int32_t*)(r.outl + r.ol.uot); po.unit_breakdown = (int64_t*)(r.outl + r.ol.ubd); }
+    if (L.has_hosts) {
+      r.ainl.distro_info = po.distro_info; r.ainl.group_info = po.group_info;
+      r.aoutl.new_hosts = (int32_t*)(r.outl + r.ol.alloc); r.aoutl.free_hosts = r.aoutl.new_hosts + nd; r.aoutl.status = r.aoutl.new_hosts + 2 * nd;
+    }
+  }
+  return EVG_OK;
+}
+
+// The allocator's per-distro settings and host columns of every rank's range, re-based to the rank's numbering, up to its device.
+// (Hosts change every tick -- tasks start and finish on them -- and a host's tg_key is in the distro's CURRENT key numbering: a tick
+// that grows key ranges re-sends them: evg_multi_apply_delta takes the allocator input too.)
+static int resident_hosts(evg_multi* m, const evg_alloc_input* alloc) {
+  Layout& L = m->lay;
+  const size_t D = L.D;
+  if (alloc->n_distros != (int32_t)D || !alloc->params || !alloc->host_off || alloc->hosts.n_hosts < 0 || alloc->host_off[0] != 0 ||
+      alloc->host_off[D] != alloc->hosts.n_hosts)
+    return merr(m, EVG_E_INVALID, "the allocator input does not describe the same batch");
+  m->host_off.assign(alloc->host_off, alloc->host_off + D + 1);
+  L.H = (size_t)alloc->hosts.n_hosts;
+  std::vector<unsigned char> stage;
+  for (int k = 0; k < m->n; k++) {
+    Rank& r = m->r[k];
+    const size_t nd = (size_t)(r.d1 - r.d0), h0 = (size_t)alloc->host_off[r.d0], nh = (size_t)alloc->host_off[r.d1] - h0;
+    const int32_t g0 = m->tg_off[r.d0];
+    r.nh = (int32_t)nh;
+    const size_t o_par = 0, o_hoff = al256(nd * sizeof(evg_alloc_params)), o_fl = o_hoff + al256(4 * (nd + 1)), o_key = o_fl + al256(nh + 1),
+                 o_st = o_key + al256(4 * nh + 4), o_ex = o_st + al256(8 * nh + 8), o_sd = o_ex + al256(8 * nh + 8), total = o_sd + al256(8 * nh + 8);
+    stage.assign(total, 0);
+    if (nd) memcpy(stage.data() + o_par, alloc->params + r.d0, nd * sizeof(evg_alloc_params));
+    int32_t* ho = (int32_t*)(stage.data() + o_hoff);
+    for (size_t d = 0; d <= nd; d++) ho[d] = alloc->host_off[r.d0 + d] - (int32_t)h0;
+    if (nh) {
+      if (!alloc->hosts.flags || !alloc->hosts.tg_key || !alloc->hosts.start_ts_ns || !alloc->hosts.expected_duration_ns || !alloc->hosts.duration_stddev_ns)
+        return merr(m, EVG_E_INVALID, "null host column");
+      memcpy(stage.data() + o_fl, alloc->hosts.flags + h0, nh);
+      int32_t* key = (int32_t*)(stage.data() + o_key);
+      for (size_t i = 0; i < nh; i++) { const int32_t g = alloc->hosts.tg_key[h0 + i]; key[i] = g < 0 ? g : g - g0; }
+      memcpy(stage.data() + o_st, alloc->hosts.start_ts_ns + h0, 8 * nh);
+      memcpy(stage.data() + o_ex, alloc->hosts.expected_duration_ns + h0, 8 * nh);
+      memcpy(stage.data() + o_sd, alloc->hosts.duration_stddev_ns + h0, 8 * nh);
+    }
+    EVGM_HIP(m, hipSetDevice(r.device));
+    if (total > r.abuf_cap || !r.abuf) {
+      if (r.abuf) EVGM_HIP(m, hipFree(r.abuf));
+      r.abuf = nullptr;
+      EVGM_HIP(m, hipMalloc((void**)&r.abuf, total + total / 4 + 256));
+      r.abuf_cap = total + total / 4 + 256;
+    }
+    EVGM_HIP(m, hipMemcpyAsync(r.abuf, stage.data(), total, hipMemcpyHostToDevice, r.stream));
+    EVGM_HIP(m, hipStreamSynchronize(r.stream));  // `stage` is re-used for the next rank
+    evg_alloc_input& ai = r.ainl;
+    ai = evg_alloc_input{};
+    ai.n_distros = (int32_t)nd; ai.params = (const evg_alloc_params*)(r.abuf + o_par); ai.host_off = (const int32_t*)(r.abuf + o_hoff);
+    ai.hosts.n_hosts = (int32_t)nh; ai.hosts.flags = r.abuf + o_fl; ai.hosts.tg_key = (const int32_t*)(r.abuf + o_key);
+    ai.hosts.start_ts_ns = (const int64_t*)(r.abuf + o_st); ai.hosts.expected_duration_ns = (const int64_t*)(r.abuf + o_ex);
+    ai.hosts.duration_stddev_ns = (const int64_t*)(r.abuf + o_sd);
+    ai.max_concurrent_large_parser_project_tasks = alloc->max_concurrent_large_parser_project_tasks;
+    ai.running_large_parser_project_tasks = alloc->running_large_parser_project_tasks;
+  }
+  return EVG_OK;
+}
+
+static int resident_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input* alloc) {
+  Layout& L = m->lay;
+  L = Layout{};
+  const size_t D = (size_t)in->n_distros;
+  L.D = D; L.has_hosts = alloc != nullptr;
+  if (alloc && alloc->n_task_groups != in->n_task_groups) return merr(m, EVG_E_INVALID, "evg_multi_load: the allocator input does not describe the same batch");
+  const evg_task_soa& t = in->tasks;
+  if (t.n_tasks && !t.dep_off) return merr(m, EVG_E_INVALID, "dep_off is required");
+  m->task_off.assign(in->task_off, in->task_off + D + 1); m->tg_off.assign(in->tg_off, in->tg_off + D + 1); m->ver_off.assign(in->ver_off, in->ver_off + D + 1);
+  m->host_off.assign(D + 1, 0);
+  std::vector<int> cuts;
+  balanced_cuts(in->task_off, (int)D, m->n, cuts);
+  std::vector<int32_t> tgk, verk, doff, didx, toff, goff, voff;
+  for (int k = 0; k < m->n; k++) {
+    Rank& r = m->r[k];
+    r.d0 = cuts[k]; r.d1 = cuts[k + 1];
+    const int nd = r.d1 - r.d0;
+    const int32_t r0 = in->task_off[r.d0], r1 = in->task_off[r.d1], g0 = in->tg_off[r.d0], v0 = in->ver_off[r.d0];
+    const int32_t e0 = t.n_tasks ? t.dep_off[r0] : 0, e1 = t.n_tasks ? t.dep_off[r1] : 0;
+    const int n = r1 - r0, e = e1 - e0;
+    evg_plan_input sub{};
+    sub.n_distros = nd; sub.n_task_groups = in->tg_off[r.d1] - g0; sub.n_versions = in->ver_off[r.d1] - v0; sub.now_ns = in->now_ns;
+    tgk.resize((size_t)n + 1); verk.resize((size_t)n + 1); doff.resize((size_t)n + 1); didx.resize((size_t)e + 1);
+    toff.resize((size_t)nd + 1); goff.resize((size_t)nd + 1); voff.resize((size_t)nd + 1);
+    for (int i = 0; i < n; i++) { const int32_t g = t.tg_key[r0 + i]; tgk[i] = g < 0 ? g : g - g0; verk[i] = t.version_key[r0 + i] - v0; }
+    for (int i = 0; i <= n; i++) doff[i] = (t.n_tasks ? t.dep_off[r0 + i] : 0) - e0;
+    for (int x = 0; x < e; x++) { const int32_t j = t.dep_idx[e0 + x]; didx[x] = j < 0 ? -1 : j - r0; }
+    for (int d = 0; d <= nd; d++) { toff[d] = in->task_off[r.d0 + d] - r0; goff[d] = in->tg_off[r.d0 + d] - g0; voff[d] = in->ver_off[r.d0 + d] - v0; }
+    evg_task_soa& st = sub.tasks;
+    st.n_tasks = n; st.n_edges = e;
+    st.priority = t.priority + r0; st.expected_duration_ns = t.expected_duration_ns + r0; st.queue_ts_ns = t.queue_ts_ns + r0;
+    st.scheduled_ts_ns = t.scheduled_ts_ns + r0; st.deps_met_ts_ns = t.deps_met_ts_ns + r0; st.num_dependents = t.num_dependents + r0;
+    st.task_group_order = t.task_group_order + r0; st.task_group_max_hosts = t.task_group_max_hosts + r0; st.flags = t.flags + r0;
+    st.tg_key = tgk.data(); st.version_key = verk.data(); st.dep_off = doff.data(); st.dep_idx = didx.data();
+    st.dep_info = t.dep_info ? t.dep_info + e0 : nullptr; st.dep_finished_ts_ns = t.dep_finished_ts_ns ? t.dep_finished_ts_ns + e0 : nullptr;
+    sub.distros = in->distros + r.d0; sub.task_off = toff.data(); sub.tg_off = goff.data(); sub.ver_off = voff.data();
+    const int rc = evg_pool_load(r.ctx, &sub);
+    if (rc) return merr(m, rc, "rank %d: evg_pool_load of distros [%d, %d): %s", k, r.d0, r.d1, evg_last_error(r.ctx));
+  }
+  if (alloc)
+    if (int rc = resident_hosts(m, alloc)) return rc;
+  return resident_layout(m);
+}
+
+// One slice of a rank's local block and where it lands in rank 0's full-size block.
+struct Move { size_t src, dst, bytes; };
+static void resident_moves(const evg_multi* m, int k, std::vector<Move>& mv) {
+  const Layout& L = m->lay;
+  const Rank& r = m->r[k];
+  const Outs& o = m->o;
+  const size_t nd = (size_t)(r.d1 - r.d0), R0 = (size_t)m->task_off[r.d0], n = (size_t)m->task_off[r.d1] - R0, G0 = (size_t)m->tg_off[r.d0],
+               ntg = (size_t)m->tg_off[r.d1] - G0, V0 = (size_t)m->ver_off[r.d0], nver = (size_t)m->ver_off[r.d1] - V0, ns = n + ntg + nver, U0 = R0 + G0 + V0;
+  mv.clear();
+  auto add = [&](size_t src, size_t dst, size_t bytes) { if (bytes) mv.push_back(Move{src, dst, bytes}); };
+  add(r.ol.order, o.order + 4 * R0, 4 * n); add(r.ol.met, o.met + R0, n); add(r.ol.wait, o.wait + 8 * R0, 8 * n);
+  add(r.ol.di, o.di + sizeof(evg_distro_info) * r.d0, sizeof(evg_distro_info) * nd);
+  add(r.ol.gi, o.gi + sizeof(evg_group_info) * r.d0, sizeof(evg_group_info) * nd);                               // the stand-alone rows
+  add(r.ol.gi + sizeof(evg_group_info) * nd, o.gi + sizeof(evg_group_info) * (L.D + G0), sizeof(evg_group_info) * ntg);  // the task-group rows
+  if (m->flags & EVG_MULTI_UNIT_ROWS) {
+    add(r.ol.uot, o.uot + 4 * R0, 4 * n);
+    for (int f = 0; f < EVG_BREAKDOWN_FIELDS; f++) add(r.ol.ubd + 8 * ((size_t)f * ns), o.ubd + 8 * ((size_t)f * m->n_slots + U0), 8 * ns);  // field-major
+  }
+  if (L.has_hosts)
+    for (int q = 0; q < 3; q++) add(r.ol.alloc + 4 * (size_t)q * nd, o.alloc + 4 * ((size_t)q * L.D + r.d0), 4 * nd);
+}
+
+static int resident_tick_body(evg_multi* m, int64_t now_ns, bool& group_open, bool& group_whole) {
+  const Layout& L = m->lay;
+  const int n = m->n;
+  const bool units = (m->flags & EVG_MULTI_UNIT_ROWS) != 0;
+  auto inject = [&](int k, int phase) -> int {
+    if (m->inject_rank != k || m->inject_phase != phase) return EVG_OK;
+    m->inject_rank = m->inject_phase = -1;
+    return merr(m, EVG_E_HIP, "injected failure on rank %d in phase %d (evg_multi_inject_failure)", k, phase);
+  };
+  auto mark = [&](int k, int e) -> int {
+    if (!m->timed) return EVG_OK;
+    EVGM_HIP(m, hipSetDevice(m->r[k].device));
+    EVGM_HIP(m, hipEventRecord(m->r[k].ev[e], m->r[k].stream));
+    return EVG_OK;
+  };
+  for (int k = 0; k < n; k++) { if (int rc = mark(k, 0)) return rc; if (int rc = mark(k, 1)) return rc; }  // no move-in: the shards are resident
+  for (int k = 0; k < n; k++) if (int rc = inject(k, 0)) return rc;
+  // ---- plan + allocate: every rank its own resident pool ----
+  for (int k = 0; k < n; k++) {
+    Rank& r = m->r[k];
+    evg_ctx* c = r.ctx;
+    const int nd = r.d1 - r.d0, nrows = m->task_off[r.d1] - m->task_off[r.d0];
+    if (nd > 0) {
+      std::lock_guard<std::mutex> ck(c->mu);
+      if (!c->pool_loaded) return merr(m, EVG_E_INVALID, "rank %d holds no pool", k);
+      evg_plan_input di = c->pool_in;
+      di.now_ns = now_ns;
+      int rc = launch_plan(c, &di, &r.poutl, r.stream);
+      if (rc) return merr(m, rc, "rank %d: %s", k, evg_last_error(c));
+      if (int rci = inject(k, 1)) return rci;
+      if (int rc2 = mark(k, 2)) return rc2;
+      if (L.has_hosts) {
+        r.ainl.n_task_groups = di.n_task_groups; r.ainl.tg_off = di.tg_off; r.ainl.now_ns = now_ns;
+        rc = launch_alloc(c, &r.ainl, &r.aoutl, r.stream);
+        if (rc) return merr(m, rc, "rank %d: %s", k, evg_last_error(c));
+        if (int rci = inject(k, 2)) return rci;
+      }
+      // local numbering -> the full batch's: queue entries are rows, unit_of_task entries are unit slots
+      EVGM_HIP(m, hipSetDevice(r.device));
+      const int32_t R0 = m->task_off[r.d0], U0 = R0 + m->tg_off[r.d0] + m->ver_off[r.d0];
+      if (nrows > 0 && R0) hipLaunchKernelGGL(k_add_base_i32, dim3((nrows + 255) / 256), dim3(256), 0, r.stream, r.poutl.order, nrows, R0);
+      if (nrows > 0 && units && U0) hipLaunchKernelGGL(k_add_base_i32, dim3((nrows + 255) / 256), dim3(256), 0, r.stream, r.poutl.unit_of_task, nrows, U0);
+      EVGM_HIP(m, hipGetLastError());
+    } else {
+      if (int rci = inject(k, 1)) return rci;
+      if (int rc2 = mark(k, 2)) return rc2;
+      if (L.has_hosts) if (int rci = inject(k, 2)) return rci;
+    }
+    if (int rc2 = mark(k, 3)) return rc2;
+  }
+  // ---- gather: every rank's slices to their place in rank 0's arrays ----
+  std::vector<Move> mv;
+  Rank& root = m->r[0];
+  // rank 0's own slices wait for nothing but its own stream; the other ranks' slices must not land before poison / earlier reads of
+  // rank 0's block finished: they are ordered by the tick's epilogue (every stream is drained before the call returns)
+  resident_moves(m, 0, mv);
+  EVGM_HIP(m, hipSetDevice(root.device));
+  for (const Move& x : mv) EVGM_HIP(m, hipMemcpyAsync(root.out + x.dst, root.outl + x.src, x.bytes, hipMemcpyDeviceToDevice, root.stream));
+  if (m->loopback) {
+    for (int k = 1; k < n; k++) {
+      Rank& r = m->r[k];
+      EVGM_HIP(m, hipSetDevice(r.device));
+      resident_moves(m, k, mv);
+      for (const Move& x : mv) EVGM_HIP(m, hipMemcpyAsync(root.out + x.dst, r.outl + x.src, x.bytes, hipMemcpyDeviceToDevice, r.stream));
+      if (int rc = inject(k, 3)) return rc;
+    }
+    if (int rc = inject(0, 3)) return rc;
+  } else if (n > 1) {
+    EVGM_NCCL(m, g_rccl.GroupStart());
+    group_open = true;
+    for (int k = 1; k < n; k++) {
+      resident_moves(m, k, mv);
+      for (const Move& x : mv) {
+        group_whole = false;
+        EVGM_NCCL(m, g_rccl.Send(m->r[k].outl + x.src, x.bytes, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
+        EVGM_NCCL(m, g_rccl.Recv(root.out + x.dst, x.bytes, ncclUint8, k, root.comm, root.stream));
+        group_whole = true;
+      }
+      if (int rc = inject(k, 3)) return rc;
+    }
+    if (int rc = inject(0, 3)) return rc;
+    group_open = false;
+    EVGM_NCCL(m, g_rccl.GroupEnd());
+  } else if (int rc = inject(0, 3)) {
+    return rc;
+  }
+  for (int k = 0; k < n; k++) if (int rc = mark(k, 4)) return rc;
+  return EVG_OK;
 }
 
 }  // namespace evgm
@@ -356,6 +652,11 @@ int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input
   if (alloc && (alloc->n_distros != in->n_distros || alloc->n_task_groups != in->n_task_groups || !alloc->params || !alloc->host_off ||
                 alloc->hosts.n_hosts < 0 || alloc->host_off[0] != 0 || alloc->host_off[in->n_distros] != alloc->hosts.n_hosts))
     return merr(m, EVG_E_INVALID, "evg_multi_load: the allocator input does not describe the same batch");
+  if ((m->flags & EVG_MULTI_RESIDENT_SHARDS) && in->n_distros > 0) {
+    rc = resident_load(m, in, alloc);
+    m->loaded = rc == EVG_OK;
+    return rc;
+  }
   if (in->n_distros == 0) {  // nothing to plan: a tick is a no-op, the results are empty (the offset tables may be NULL)
     m->lay = Layout{};
     m->o = Outs{};
@@ -607,7 +908,7 @@ extern "C" int evg_multi_tick(evg_multi* m, int64_t now_ns) {
   if (!m->loaded) return merr(m, EVG_E_INVALID, "evg_multi_tick: no pool is loaded");
   if (m->lay.D == 0) return EVG_OK;
   bool group_open = false, group_whole = true;
-  int first = tick_body(m, now_ns, group_open, group_whole);  // its message is in m->err; the epilogue reports its own failures only when the body had none
+  int first = (m->flags & EVG_MULTI_RESIDENT_SHARDS) ? resident_tick_body(m, now_ns, group_open, group_whole) : tick_body(m, now_ns, group_open, group_whole);  // its message is in m->err; the epilogue reports its own failures only when the body had none
   // ---- epilogue, on every path ----
   if (group_open) {  // an error inside ncclGroupStart .. ncclGroupEnd: an open group would swallow every later RCCL call of this thread
     const ncclResult_t e = g_rccl.GroupEnd();
@@ -865,6 +1166,138 @@ int evg_multi_results(evg_multi* m, const evg_plan_output* out, const evg_alloc_
   return rc;
 }
 
+// A tick's structural change for resident shards (EVG_MULTI_RESIDENT_SHARDS): `delta` is written against the WHOLE batch -- current
+// global row / edge numbers, global added_distro, the new global key tables -- exactly what evg_pool_apply_delta takes for one pool;
+// here every rank gets the part that concerns its distro range, re-based to its numbering, and applies it to its resident pool
+// (evg_pool_apply_delta on its context: only that rank's share of the delta crosses the link to that device). `alloc` (or NULL)
+// brings the tick's allocator input for the whole batch: hosts change every tick, and their tg_key is in the distro's CURRENT key
+// numbering, so a delta that grows key ranges must bring them. A rank's failure leaves the ranks before it changed: the object then
+// needs evg_multi_load again (the message says so).
+int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_alloc_input* alloc) {
+  using namespace evgm;
+  if (!m || !dl) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (!(m->flags & EVG_MULTI_RESIDENT_SHARDS)) return merr(m, EVG_E_INVALID, "evg_multi_apply_delta: created without EVG_MULTI_RESIDENT_SHARDS");
+  if (!m->loaded || m->lay.D == 0) return merr(m, EVG_E_INVALID, "evg_multi_apply_delta: no pool is loaded");
+  Layout& L = m->lay;
+  const int D = (int)L.D, nr = dl->n_removed, na = dl->n_added, nl = dl->n_relinked;
+  if (nr < 0 || na < 0 || nl < 0 || (nr > 0 && (!dl->removed_rows || !dl->removed_dep_state)) || (na > 0 && !dl->added_distro) ||
+      (nl > 0 && (!dl->relinked_edges || !dl->relinked_to)))
+    return merr(m, EVG_E_INVALID, "evg_multi_apply_delta: null or negative");
+  const evg_task_soa& ad = dl->added;
+  if (na > 0 && (ad.n_tasks != na || !ad.dep_off || !ad.tg_key || !ad.version_key || (ad.n_edges > 0 && !ad.dep_idx)))
+    return merr(m, EVG_E_INVALID, "evg_multi_apply_delta: the added rows' columns are incomplete");
+  if (L.has_hosts && dl->tg_off && !alloc)
+    return merr(m, EVG_E_INVALID, "evg_multi_apply_delta: the key ranges change and the resident hosts' tg_key with them: pass the tick's allocator input");
+  const int32_t* n_tg = dl->tg_off ? dl->tg_off : m->tg_off.data();
+  const int32_t* n_ver = dl->ver_off ? dl->ver_off : m->ver_off.data();
+  const int n = m->n;
+  // where every rank's rows / edges start in the CURRENT global numbering
+  std::vector<int64_t> eoff(n + 1, 0);
+  for (int k = 0; k < n; k++) eoff[k + 1] = eoff[k] + (m->r[k].d1 > m->r[k].d0 ? m->r[k].ctx->pool_in.tasks.n_edges : 0);
+  auto rank_of_row = [&](int32_t r) { int k = 0; while (k + 1 < n && r >= m->task_off[m->r[k].d1]) k++; return k; };
+  // ---- cut the delta by rank ----
+  struct Part {
+    std::vector<int32_t> removed, rl_edges, rl_to, tgk, verk, doff, didx, distro, tg_off, ver_off;
+    std::vector<uint8_t> state;
+    std::vector<int64_t> fin;
+    int a0 = 0, a1 = 0;
+  };
+  std::vector<Part> part(n);
+  for (int i = 0; i < nr; i++) {
+    const int32_t r = dl->removed_rows[i];
+    if (r < 0 || r >= m->task_off[D]) return merr(m, EVG_E_CONTRACT, "evg_multi_apply_delta: removed row %d is outside the pool", r);
+    Part& p = part[rank_of_row(r)];
+    p.removed.push_back(r); p.state.push_back(dl->removed_dep_state[i]);
+    if (dl->removed_finished_ts_ns) p.fin.push_back(dl->removed_finished_ts_ns[i]);
+  }
+  {
+    int i = 0;
+    for (int k = 0; k < n; k++) {
+      part[k].a0 = i;
+      while (i < na && dl->added_distro[i] < m->r[k].d1) {
+        if (dl->added_distro[i] < m->r[k].d0 || (i > 0 && dl->added_distro[i] < dl->added_distro[i - 1]))
+          return merr(m, EVG_E_CONTRACT, "evg_multi_apply_delta: added_distro must be non-decreasing in [0, D) (row %d)", i);
+        i++;
+      }
+      part[k].a1 = i;
+    }
+    if (i != na) return merr(m, EVG_E_CONTRACT, "evg_multi_apply_delta: added_distro must be non-decreasing in [0, D) (row %d)", i);
+  }
+  for (int i = 0; i < nl; i++) {
+    const int64_t e = dl->relinked_edges[i];
+    if (e < 0 || e >= eoff[n]) return merr(m, EVG_E_CONTRACT, "evg_multi_apply_delta: relinked edge %d is outside the pool", (int)e);
+    int k = 0;
+    while (k + 1 < n && e >= eoff[k + 1]) k++;
+    const int32_t to = dl->relinked_to[i];
+    if (to < part[k].a0 || to >= part[k].a1) return merr(m, EVG_E_CONTRACT, "evg_multi_apply_delta: relinked edge %d belongs to a row of another distro than the added row it is pointed at", (int)e);
+    part[k].rl_edges.push_back((int32_t)(e - eoff[k])); part[k].rl_to.push_back(to - part[k].a0);
+  }
+  // ---- every rank applies its part ----
+  for (int k = 0; k < n; k++) {
+    Rank& r = m->r[k];
+    Part& p = part[k];
+    const int nd = r.d1 - r.d0, a0 = p.a0, nak = p.a1 - p.a0;
+    if (nd == 0) continue;
+    const int32_t R0 = m->task_off[r.d0];
+    for (int32_t& x : p.removed) x -= R0;
+    evg_pool_delta sub{};
+    sub.n_removed = (int32_t)p.removed.size(); sub.removed_rows = p.removed.data(); sub.removed_dep_state = p.state.data();
+    sub.removed_finished_ts_ns = dl->removed_finished_ts_ns ? p.fin.data() : nullptr;
+    p.tg_off.resize((size_t)nd + 1); p.ver_off.resize((size_t)nd + 1);
+    for (int d = 0; d <= nd; d++) { p.tg_off[d] = n_tg[r.d0 + d] - n_tg[r.d0]; p.ver_off[d] = n_ver[r.d0 + d] - n_ver[r.d0]; }
+    if (dl->tg_off) sub.tg_off = p.tg_off.data();
+    if (dl->ver_off) sub.ver_off = p.ver_off.data();
+    sub.n_added = nak;
+    if (nak > 0) {
+      const int32_t e0 = ad.dep_off[a0], e1 = ad.dep_off[a0 + nak];
+      p.distro.resize((size_t)nak); p.tgk.resize((size_t)nak); p.verk.resize((size_t)nak); p.doff.resize((size_t)nak + 1); p.didx.resize((size_t)(e1 - e0) + 1);
+      for (int i = 0; i < nak; i++) {
+        const int32_t d = dl->added_distro[a0 + i], g = ad.tg_key[a0 + i];
+        p.distro[i] = d - r.d0;
+        p.tgk[i] = g < 0 ? g : g - n_tg[r.d0];
+        p.verk[i] = ad.version_key[a0 + i] - n_ver[r.d0];
+      }
+      for (int i = 0; i <= nak; i++) p.doff[i] = ad.dep_off[a0 + i] - e0;
+      for (int x = 0; x < e1 - e0; x++) {
+        const int32_t j = ad.dep_idx[e0 + x];
+        if (j >= 0) p.didx[x] = j - R0;  // a current row: of this rank's range, or the device refuses it (not a row of the same distro)
+        else if (j <= -2) { const int32_t kk = -(j + 2); p.didx[x] = kk >= a0 && kk < p.a1 ? -((kk - a0) + 2) : (int32_t)0x40000000; }  // another rank's added row: refused
+        else p.didx[x] = -1;
+      }
+      sub.added_distro = p.distro.data();
+      evg_task_soa& st = sub.added;
+      st = ad;
+      st.n_tasks = nak; st.n_edges = e1 - e0;
+      st.priority = ad.priority + a0; st.expected_duration_ns = ad.expected_duration_ns + a0; st.queue_ts_ns = ad.queue_ts_ns + a0;
+      st.scheduled_ts_ns = ad.scheduled_ts_ns + a0; st.deps_met_ts_ns = ad.deps_met_ts_ns + a0; st.num_dependents = ad.num_dependents + a0;
+      st.task_group_order = ad.task_group_order + a0; st.task_group_max_hosts = ad.task_group_max_hosts + a0; st.flags = ad.flags + a0;
+      st.tg_key = p.tgk.data(); st.version_key = p.verk.data(); st.dep_off = p.doff.data(); st.dep_idx = p.didx.data();
+      st.dep_info = ad.dep_info ? ad.dep_info + e0 : nullptr; st.dep_finished_ts_ns = ad.dep_finished_ts_ns ? ad.dep_finished_ts_ns + e0 : nullptr;
+    }
+    sub.n_relinked = (int32_t)p.rl_edges.size(); sub.relinked_edges = p.rl_edges.data(); sub.relinked_to = p.rl_to.data();
+    const int rc = evg_pool_apply_delta(r.ctx, &sub);
+    if (rc) {
+      if (k > 0) m->loaded = false;
+      return merr(m, rc, "rank %d: %s%s", k, evg_last_error(r.ctx), k > 0 ? " -- the ranks before it have applied their part: load the pool again (evg_multi_load)" : "");
+    }
+  }
+  // ---- the global tables after the delta; output blocks for the new sizes; this tick's hosts ----
+  {
+    std::vector<int32_t> toff(D + 1, 0);
+    for (int k = 0; k < n; k++) {
+      const Rank& r = m->r[k];
+      for (int d = r.d0; d < r.d1; d++) toff[d + 1] = toff[d] + (r.ctx->pool_task_off[d - r.d0 + 1] - r.ctx->pool_task_off[d - r.d0]);
+    }
+    std::vector<int32_t> tgv(n_tg, n_tg + D + 1), verv(n_ver, n_ver + D + 1);
+    m->task_off = toff; m->tg_off = tgv; m->ver_off = verv;
+  }
+  if (alloc)
+    if (int rc = resident_hosts(m, alloc)) { m->loaded = false; return rc; }
+  if (int rc = resident_layout(m)) { m->loaded = false; return rc; }
+  return EVG_OK;
+}
+
 // Test hook: fills rank 0's output block with a byte pattern (a rank that wrote outside its slices, or a slice that never
 // arrived, shows in the gathered result).
 int evg_multi_poison_outputs(evg_multi* m, int32_t byte) {
@@ -875,6 +1308,12 @@ int evg_multi_poison_outputs(evg_multi* m, int32_t byte) {
     if (!r.out || !m->o.total) continue;  // an empty batch has no outputs
     EVGM_HIP(m, hipSetDevice(r.device));
     EVGM_HIP(m, hipMemsetAsync(r.out, byte, m->o.total, r.stream));
+    EVGM_HIP(m, hipStreamSynchronize(r.stream));
+  }
+  for (evgm::Rank& r : m->r) {  // resident shards: every rank's local block
+    if (!r.outl || !r.ol.total) continue;
+    EVGM_HIP(m, hipSetDevice(r.device));
+    EVGM_HIP(m, hipMemsetAsync(r.outl, byte, r.ol.total, r.stream));
     EVGM_HIP(m, hipStreamSynchronize(r.stream));
   }
   return EVG_OK;

@@ -27,7 +27,7 @@ EXPORTS = [
     "evg_check_abi", "evg_take_device_status", "evg_pool_load", "evg_pool_update", "evg_pool_plan", "evg_pool_apply_delta",
     "evg_multi_create", "evg_multi_destroy", "evg_multi_last_error", "evg_multi_load", "evg_multi_tick", "evg_multi_results",
     "evg_multi_ranges", "evg_multi_profile", "evg_multi_last_tick_ms", "evg_multi_poison_outputs", "evg_balanced_ranges",
-    "evg_multi_inject_failure", "evg_multi_abort", "evg_multi_selftest",
+    "evg_multi_inject_failure", "evg_multi_abort", "evg_multi_selftest", "evg_multi_apply_delta",
     "evg_batcher_create", "evg_batcher_destroy", "evg_batcher_plan", "evg_batcher_allocate", "evg_batcher_get_stats",
 ]
 
@@ -138,6 +138,7 @@ def load_library() -> C.CDLL:
             lib.evg_multi_inject_failure.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
             lib.evg_multi_abort.argtypes = [C.c_void_p]
             lib.evg_multi_selftest.argtypes = [C.c_void_p]
+            lib.evg_multi_apply_delta.argtypes = [C.c_void_p, C.POINTER(abi.PoolDelta), C.POINTER(abi.AllocInput)]
         lib.evg_balanced_ranges.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     if hasattr(lib, "evg_batcher_create"):  # ABI 3.2
         lib.evg_batcher_create.restype = C.c_void_p
@@ -176,18 +177,19 @@ def balanced_ranges(task_off, world: int):
     return [(int(b[k]), int(e[k])) for k in range(world)]
 
 
-MULTI_SCATTER, MULTI_UNIT_ROWS, MULTI_LOOPBACK = 0x1, 0x2, 0x100
+MULTI_SCATTER, MULTI_UNIT_ROWS, MULTI_RESIDENT_SHARDS, MULTI_LOOPBACK = 0x1, 0x2, 0x4, 0x100
 
 
 class MultiContext:
     """evg_multi wrapper: several devices driven from THIS process through the C ABI (include/evg_sched.h, ABI 3.1) -- what
     shim/gpu_multi.go calls. rank k = devices[k]; rank 0 holds the pool and receives the gathered results."""
 
-    def __init__(self, devices, scatter: bool = False, units: bool = False, loopback: bool = False):
+    def __init__(self, devices, scatter: bool = False, units: bool = False, loopback: bool = False, resident: bool = False):
         self.lib = load_library()
         self.devices = list(devices)
         self.units = units
-        flags = (MULTI_SCATTER if scatter else 0) | (MULTI_UNIT_ROWS if units else 0) | (MULTI_LOOPBACK if loopback else 0)
+        flags = (MULTI_SCATTER if scatter else 0) | (MULTI_UNIT_ROWS if units else 0) | (MULTI_LOOPBACK if loopback else 0) | (
+            MULTI_RESIDENT_SHARDS if resident else 0)
         arr = (C.c_int32 * len(self.devices))(*self.devices)
         self.h = self.lib.evg_multi_create(arr, len(self.devices), flags)
         if not self.h:
@@ -238,6 +240,18 @@ class MultiContext:
 
     def poison_outputs(self, byte: int = 0xA5) -> None:
         self._check(self.lib.evg_multi_poison_outputs(self.h, byte), "evg_multi_poison_outputs")
+
+    def apply_delta(self, new_batch: abi.PlanBatch, **delta_kw) -> None:
+        """evg_multi_apply_delta (resident shards): the delta in the WHOLE batch's numbering (Context.make_pool_delta's keyword arguments);
+        `new_batch` = the pool after it (its hosts, in the new key numbering, are this tick's allocator input; the results are sized by it)."""
+        blk, keep = Context.make_pool_delta(**delta_kw)
+        ainp = None
+        if new_batch.alloc_params is not None:
+            ainp = abi.make_alloc_input(new_batch, np.zeros(new_batch.n_distros + 1, abi.DISTRO_INFO_DTYPE),
+                                        np.zeros(new_batch.n_distros + new_batch.n_task_groups + 1, abi.GROUP_INFO_DTYPE))
+        self._check(self.lib.evg_multi_apply_delta(self.h, C.byref(blk), C.byref(ainp) if ainp is not None else None), "evg_multi_apply_delta")
+        del keep
+        self.batch = new_batch
 
     def inject_failure(self, rank: int, phase: int) -> None:
         """Test hook: the next tick fails on `rank` in `phase` (0 move-in, 1 plan, 2 allocate, 3 gather)."""

@@ -667,6 +667,12 @@ int evg_allocator_report(evg_ctx* ctx, int32_t n_distros, const int32_t* tg_off,
 typedef struct evg_multi evg_multi;
 #define EVG_MULTI_SCATTER 0x1
 #define EVG_MULTI_UNIT_ROWS 0x2
+/* Every rank keeps ITS distro range resident (ABI 3.2): evg_multi_load cuts the ranges and loads each one as the resident pool of its
+ * rank's context (evg_pool_load of the range, re-based) -- nothing is broadcast at tick time; a tick's structural change goes through
+ * evg_multi_apply_delta, which hands every rank its part of the delta; evg_multi_tick plans + allocates every rank's pool and gathers the
+ * result slices into rank 0's full-size arrays as before. The shape the 15 s cadence of the reference calls for
+ * (units/crons_remote_fifteen_second.go:21,58-60): per tick a few per cent of a shard cross the link instead of the whole pool. */
+#define EVG_MULTI_RESIDENT_SHARDS 0x4
 #define EVG_MULTI_LOOPBACK 0x100
 evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t flags);
 void evg_multi_destroy(evg_multi* m);
@@ -693,6 +699,11 @@ int evg_multi_poison_outputs(evg_multi* m, int32_t byte);
  *   evg_multi_selftest        start-up check before a scheduler routes its planning through several devices: a generated pool of mixed
  *                             shape planned + allocated on rank 0's device alone and over all the ranks must give identical outputs.
  *                             EVG_OK, EVG_E_CONTRACT (first difference in the message) or the failing call's code. Replaces the loaded pool */
+/* EVG_MULTI_RESIDENT_SHARDS only: a tick's structural change, written against the WHOLE batch exactly like evg_pool_apply_delta's (current
+ * global row and edge numbers, global added_distro, the new global key tables); every rank applies the part that concerns its range. `alloc`
+ * (or NULL) is the tick's allocator input for the whole batch -- required when the delta grows key ranges (the resident hosts' tg_key is in the
+ * distro's current key numbering). After a failure on a rank other than the first the pool must be loaded again. */
+int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* delta, const evg_alloc_input* alloc);
 int evg_multi_inject_failure(evg_multi* m, int32_t rank, int32_t phase);
 int evg_multi_abort(evg_multi* m);
 int evg_multi_selftest(evg_multi* m);

@@ -166,3 +166,71 @@ def test_abort_refuses_further_ticks():
             m.tick()
     finally:
         m.close()  # destroying an aborted object is fine
+
+
+@pytest.mark.parametrize("cfg,world,loopback", [(gen.GenConfig(40_000, 21, gen.SEED_BASE + 91, skew=True, tg_fraction=0.2, dag_depth=5), 3, True),
+                                                (gen.config(5, n_tasks=120_000, n_distros=10), 4, True),
+                                                (gen.GenConfig(30_000, 40, gen.SEED_BASE + 92, tg_fraction=0.15), 8, True),
+                                                (gen.config(2), 1, False)],
+                         ids=["skewed-x3", "config5-shape-x4", "small-distros-x8", "rccl-x1"])
+def test_resident_shards_tick_by_delta(oracle, cfg, world, loopback):
+    """EVG_MULTI_RESIDENT_SHARDS: every rank loads ITS distro range once; a tick's structural delta -- written against
+    the whole batch -- is routed to the owning ranks (evg_multi_apply_delta); the gathered plan + host counts equal the oracle on the
+    pool a caller would have re-uploaded in full (tests/pool_delta.py). Two deltas in a row, poisoned outputs, unit rows."""
+    from tests import pool_delta
+    full = gen.generate(cfg)
+    pool0, delta, _, _ = pool_delta.split_tick(full, 0.03, 0.03, seed=5, grow_keys=True)
+    m = native.MultiContext([0] * world, units=True, loopback=loopback, resident=True)
+    try:
+        m.load(pool0)
+        assert m.ranges() == multi.balanced_ranges(pool0.task_off, world)
+        m.poison_outputs()
+        m.tick()
+        want, want_alloc = _want(oracle, pool0)
+        _check(m, pool0, want, want_alloc, "resident shards x%d, loaded" % world)
+        pool1 = pool_delta.apply_delta(pool0, delta)
+        m.apply_delta(pool1, **delta.kwargs())
+        m.poison_outputs()
+        m.tick(pool1.now_ns + 15 * 10**9)
+        pool1.now_ns += 15 * 10**9
+        want, want_alloc = _want(oracle, pool1)
+        _check(m, pool1, want, want_alloc, "resident shards x%d, after a delta" % world)
+        # a second delta on top: remove a slice of what is there now, add nothing, keys unchanged
+        rng = np.random.default_rng(9)
+        gone = np.sort(rng.choice(pool1.n_tasks, pool1.n_tasks // 50, replace=False)).astype(np.int32)
+        d2 = pool_delta.Delta(removed_rows=gone, removed_dep_state=np.full(len(gone), 1 << 2, np.uint8), removed_finished_ts_ns=None,
+                              added_distro=np.zeros(0, np.int32), added_cols=pool_delta.empty_added()[1], added_dep_off=np.zeros(1, np.int32),
+                              added_edges=pool_delta.empty_added()[3])
+        pool2 = pool_delta.apply_delta(pool1, d2)
+        m.apply_delta(pool2, **d2.kwargs())
+        m.poison_outputs()
+        m.tick()
+        want, want_alloc = _want(oracle, pool2)
+        _check(m, pool2, want, want_alloc, "resident shards x%d, second delta" % world)
+    finally:
+        m.close()
+
+
+def test_resident_shards_refuse_what_one_pool_refuses():
+    from tests import pool_delta
+    full = gen.generate(gen.GenConfig(12_000, 9, gen.SEED_BASE + 93, tg_fraction=0.2))
+    pool0, delta, _, _ = pool_delta.split_tick(full, 0.03, 0.03, seed=5, grow_keys=True)
+    m = native.MultiContext([0] * 3, units=True, loopback=True, resident=True)
+    try:
+        m.load(pool0)
+        bad = dict(delta.kwargs())
+        bad["removed_rows"] = np.concatenate([delta.removed_rows[:1], delta.removed_rows])  # a row twice: rank 0's pool refuses it
+        bad["removed_dep_state"] = np.concatenate([delta.removed_dep_state[:1], delta.removed_dep_state])
+        bad["removed_finished_ts_ns"] = None
+        with pytest.raises(native.NativeError, match="twice"):
+            m.apply_delta(pool0, **bad)
+        m.tick()  # rank 0 refused before anything changed: the pool still plans
+        with pytest.raises(native.NativeError, match="EVG_MULTI_RESIDENT_SHARDS"):
+            m2 = native.MultiContext([0, 0], loopback=True)
+            try:
+                m2.load(pool0)
+                m2.apply_delta(pool0, **delta.kwargs())
+            finally:
+                m2.close()
+    finally:
+        m.close()
