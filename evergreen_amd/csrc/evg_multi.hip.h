@@ -196,7 +196,7 @@ static int merr(evg_multi* m, int code, const char* fmt, ...) {
 
 // Cost of a distro in quarter-tasks of the two-per-CU tier of the one-workgroup kernel (evergreen_amd/multi.py:distro_costs --
 // the same integers, so that a Go caller and the Python driver cut the same ranges): a distro of the one-per-CU tier holds a whole
-// CU for as long as two small ones share it (x2 per task), one on the large-distro pipeline costs x4.
+// CU for as long as two small ones share it (x2 per task), one on the large-distro pipeline costs x4 (LAB_NOTES.md, rounds 1-4, section 4).
 static inline int64_t distro_cost4(int64_t n) { return n > 4096 ? 16 * n : n > 2048 ? 8 * n : 4 * n; }
 
 // Contiguous distro ranges that minimise the largest rank cost: the smallest bound L such that a left-to-right fill with ranges

@@ -710,7 +710,7 @@ int evg_multi_selftest(evg_multi* m);
 
 /* Host only: the contiguous distro ranges `world` ranks plan, minimising the largest rank COST (a distro is never split: a rank's
  * results must be contiguous slices of the full-size outputs). Cost of a distro = tasks on the two-per-CU tier of the one-workgroup
- * kernel, x2 on its one-per-CU tier (2049..4096 tasks), x4 on the large-distro pipeline (measured); the
+ * kernel, x2 on its one-per-CU tier (2049..4096 tasks), x4 on the large-distro pipeline (measured, LAB_NOTES.md, rounds 1-4, section 4); the
  * same integers as evergreen_amd/multi.py:balanced_ranges, so every driver cuts the same ranges. Ranks past the last range get
  * empty ranges. */
 int evg_balanced_ranges(const int32_t* task_off, int32_t n_distros, int32_t world, int32_t* d_begin, int32_t* d_end);

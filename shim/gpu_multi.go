@@ -37,7 +37,7 @@ var (
 )
 
 // minTasksPerDevice: below this a batch stays on one device -- the broadcast of the pool costs more than the kernels it
-// spreads (DESIGN.md section 4: 84.6 MB over xGMI against ~60 us of kernels for 1 M tasks on ONE MI355X; BASELINE config 5's
+// spreads (LAB_NOTES.md, rounds 1-4, section 4: 84.6 MB over xGMI against ~60 us of kernels for 1 M tasks on ONE MI355X; BASELINE config 5's
 // 10 M tasks are where eight devices pay).
 const minTasksPerDevice = 1 << 20
 

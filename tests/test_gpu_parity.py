@@ -659,7 +659,7 @@ def test_big_tier_beside_the_small_tier(native_ctx, oracle):
 
 
 def test_big_tier_switched_off(oracle, monkeypatch):
-    """EVG_BIG_TIER=0 (the A/B knob of scripts/bench_cliff.py): a context that never launches the 4096-task tier plans the same pool
+    """EVG_BIG_TIER=0 (an A/B knob): a context that never launches the 4096-task tier plans the same pool
     through the small tier + the large-distro pipeline, whatever the hints promise."""
     import torch
     from evergreen_amd import native, resident
