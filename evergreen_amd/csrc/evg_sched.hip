@@ -413,7 +413,7 @@ struct evg_ctx {
   // the one-per-CU tier (k_plan_distros_big), EVG_BIG_TIER: 3 (default) = beside the small tier when the launch's workgroups leave CUs
   // free, behind it when they fill the chip (launch_plan); 1 = always behind the small tier's launch on the caller's stream; 2 = always
   // on the context's high-priority side stream, forked before that launch and joined after it; 0 = off (tier-12 distros take the
-  // large-distro pipeline). Measured (scripts/bench_cliff.py, config 3 = 512 distros with 1 / 8 / 64 of them grown to 4096 tasks):
+  // large-distro pipeline). Measured (bench.py object `cliff`, config 3 = 512 distros with 1 / 8 / 64 of them grown to 4096 tasks):
   // 0.118 / 0.117 / 0.153 ms per tick behind, 0.130 / 0.132 / 0.165 beside, 0.158 / 0.164 / 0.170 off: the 512 workgroups of the
   // small tier fill every CU the moment they are dispatched, so the big tier's workgroups -- which need a CU to themselves -- start
   // when the small tier ends either way, and the two event hand-overs cost ~15 us on top.
