@@ -19,6 +19,8 @@ for f in $(find $OUT/prof/${TAG}_c5-stats -name '*kernel_stats.csv' | head -1); 
 bash scripts/pmc_sq.sh $TAG > $OUT/${TAG}_sq_counters.txt 2>&1
 bash scripts/pmc_sq.sh ${TAG}_c5 python $R/scripts/bench_config5.py 1250000 64 --steps 5 > $OUT/${TAG}_c5_sq_counters.txt 2>&1
 bash scripts/pmc_mem.sh ${TAG}_c5 > $OUT/${TAG}_c5_mem_counters.txt 2>&1
+# the same L1 counters for round 4's final build (libevg_base.so, kept beside the library): requests per kernel before / after on one box
+[ -f $R/evergreen_amd/csrc/libevg_base.so ] && EVG_SCHED_LIB=$R/evergreen_amd/csrc/libevg_base.so bash scripts/pmc_mem.sh ${TAG}_c5_base > $OUT/${TAG}_c5_base_mem_counters.txt 2>&1
 timeout 300 python scripts/soak_random.py ${SOAK:-100} 51 2>&1 | tail -3 | tee $OUT/${TAG}_soak.log
 timeout 300 python scripts/soak_random.py ${SOAK:-100} 52 large 2>&1 | tail -3 | tee -a $OUT/${TAG}_soak.log
 timeout 300 python scripts/soak_delta.py ${SOAK_DELTA:-80} 7 2>&1 | tail -1 | tee -a $OUT/${TAG}_soak.log
