@@ -35,15 +35,16 @@ _lib = None
 
 
 def kernel_sources_hash() -> str:
-    """sha256 (first 16 hex digits) over the device sources of the library, in name order: what a committed rocprofv3 counter summary
-    (profiles/pmc_latest.json) is stamped with, so that bench.py can tell when the kernels changed after the counters were taken."""
+    """sha256 (first 16 hex digits) over the sources the PLANNER kernels are compiled from, in name order: what a committed rocprofv3
+    counter summary (profiles/pmc_latest.json) is stamped with, so that bench.py can tell when the kernels changed after the counters
+    were taken. (The entry-point file and the host-side fronts -- evg_sched.hip, evg_multi, evg_batcher, evg_pool_delta, evg_dispatch --
+    do not change what k_plan_distros moves.)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(_HERE, "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hip.h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("evg_alloc.hip.h", "evg_kernels.hip.h", "evg_plan_lds.hip.h", "evg_sort.hip.h", "evg_tiled.hip.h"):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
