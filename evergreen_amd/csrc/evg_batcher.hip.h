@@ -156,7 +156,7 @@ static Slot* join_slot(evg_batcher* b, std::unique_lock<std::mutex>& lk, int kin
     }
     if (open) {
       if ((int)open->members.size() < b->max_requests && open->in_used + bytes <= b->max_batch_bytes) { *leader = false; return open; }
-      // full: its leader closes it (it polls the count / the bytes); wait for a free slot
+      // full: its leader closes it (every join wakes it); wait for a free slot
     } else if (free_slot) {
       Slot& s = *free_slot;
       s.state = Slot::OPEN; s.kind = kind; s.members.clear(); s.in_used = 0;

@@ -721,7 +721,8 @@ int evg_balanced_ranges(const int32_t* task_off, int32_t n_distros, int32_t worl
  * allocator likewise (units/host_allocator.go:183-188). Through that call shape the host-pointer entry points above serve ONE distro
  * per call and the device's command path saturates at ~25 ms for 512 of them, whatever the number of threads. A batcher keeps the
  * call shape and issues batches: concurrent evg_batcher_plan (evg_batcher_allocate) calls are collected -- until `max_requests`
- * joined, nobody new has joined for a quarter of `max_wait_us`, or `max_wait_us` passed since the first -- and planned (allocated) by
+ * joined, every caller the batcher currently expects has joined (the recent peak of threads inside it, less those blocked in other
+ * batches: a lone caller's batch leaves at once), or `max_wait_us` passed since the first -- and planned (allocated) by
  * ONE launch sequence over all of them; every caller packs its own columns and cuts out its own results on its own thread. Each
  * request keeps its own now_ns (and the allocator's large-parser-project figures), so its results are bit for bit those of
  * evg_plan_distros / evg_allocate_hosts on the request alone; inputs, outputs and return codes are theirs too. Errors stay per

@@ -234,3 +234,33 @@ def test_resident_shards_refuse_what_one_pool_refuses():
                 m2.close()
     finally:
         m.close()
+
+
+def test_resident_shards_selftest_and_failed_ticks(oracle):
+    """The start-up self-check and the fail-safe tick hold for resident shards too: a failure injected on any rank in any phase is
+    reported, the next tick gives the whole plan, and a delta applied afterwards still lands on the right ranks."""
+    from tests import pool_delta
+    m = native.MultiContext([0] * 4, units=True, loopback=True, resident=True)
+    try:
+        m.selftest()
+        full = gen.generate(gen.GenConfig(24_000, 13, gen.SEED_BASE + 94, skew=True, tg_fraction=0.2))
+        pool0, delta, _, _ = pool_delta.split_tick(full, 0.03, 0.03, seed=6, grow_keys=True)
+        m.load(pool0)
+        want, want_alloc = _want(oracle, pool0)
+        for phase in (1, 2, 3):
+            for rank in (0, 3):
+                m.inject_failure(rank, phase)
+                m.poison_outputs()
+                with pytest.raises(native.NativeError, match="injected failure on rank %d in phase %d" % (rank, phase)):
+                    m.tick()
+                m.poison_outputs()
+                m.tick()
+                _check(m, pool0, want, want_alloc, "resident shards after a failure on rank %d in phase %d" % (rank, phase))
+        pool1 = pool_delta.apply_delta(pool0, delta)
+        m.apply_delta(pool1, **delta.kwargs())
+        m.poison_outputs()
+        m.tick()
+        want, want_alloc = _want(oracle, pool1)
+        _check(m, pool1, want, want_alloc, "resident shards, a delta after failed ticks")
+    finally:
+        m.close()
