@@ -24,4 +24,6 @@ bash scripts/pmc_mem.sh ${TAG}_c5 > $OUT/${TAG}_c5_mem_counters.txt 2>&1
 timeout 300 python scripts/soak_random.py ${SOAK:-100} 51 2>&1 | tail -3 | tee $OUT/${TAG}_soak.log
 timeout 300 python scripts/soak_random.py ${SOAK:-100} 52 large 2>&1 | tail -3 | tee -a $OUT/${TAG}_soak.log
 timeout 300 python scripts/soak_delta.py ${SOAK_DELTA:-80} 7 2>&1 | tail -1 | tee -a $OUT/${TAG}_soak.log
+timeout 300 python scripts/soak_multi_delta.py ${SOAK_DELTA:-80} 3 2>&1 | tail -1 | tee -a $OUT/${TAG}_soak.log   # resident shards over emulated ranks
+timeout 200 python scripts/soak_batcher.py ${SOAK_BATCHER:-60} 13 48 2>&1 | tail -1 | tee -a $OUT/${TAG}_soak.log    # the micro-batching front
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $OUT/${TAG}_soak.log
