@@ -703,9 +703,10 @@ def main():
                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                                 "algorithmic_bytes_per_launch": abytes, "kernel_ms": kernel_ms, "kernel_ms_min": kms[0], "kernel_ms_mean": sum(kms) / len(kms),
                                 "plan_entry_point_ms": plan_ms[0], "allocator_ms": alloc_ms[0],
-                                "kernel_ms_scope": "median HIP-event interval around the dominant kernel of the timed tick alone, events recorded by the library on "
-                                                   "the launch stream (evg_profile_plan_kernel), one call at a time; plan_entry_point_ms / allocator_ms = the intervals "
-                                                   "around the two separate calls in the phases pass",
+                                "kernel_ms_scope": "median duration of the dominant kernel of the timed tick alone: start / stop HIP events attached to the kernel's own "
+                                                   "dispatch by the library on its launch stream (evg_profile_plan_kernel -> hipExtLaunchKernelGGL: the interval "
+                                                   "rocprofv3's kernel trace reports), one call at a time; plan_entry_point_ms / allocator_ms = the intervals around "
+                                                   "the two separate calls in the phases pass (events recorded on the stream: they include the dispatch gaps)",
                                 "bytes_per_task": abytes / max(int(batch.task_off[d1] - batch.task_off[d0]), 1)}
             got, got_alloc = pool.plan_result(), pool.alloc_result()
         except Exception as e:

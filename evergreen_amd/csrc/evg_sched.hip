@@ -6,6 +6,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared evg_sched.hip -o libevg_sched.so
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -1194,13 +1195,18 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
     }
   }
   hipStream_t st_small = big_beside ? c->side : st;
-  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_start, st_small));
+  // evg_profile_plan_kernel: the two events ride ON the kernel's dispatch (hipExtLaunchKernelGGL: its start and end timestamps, what
+  // rocprofv3's kernel trace reports). Events recorded on the stream before and after the launch -- rounds 1-4 -- read 3 us longer than
+  // the kernel (55.7 against 52.5 us): the gap between a marker and the dispatch behind it is the command processor's, not the kernel's.
   // TaskPlan.Len() needs 18 KiB more LDS per workgroup (one workgroup per CU instead of two); the breakdown rows do not
-  if (out->n_units) hipLaunchKernelGGL((k_plan_distros<true, true>), dim3(D), dim3(kBlock), kLdsRich, st_small, a);
+  if (c->profile) {
+    if (out->n_units) hipExtLaunchKernelGGL((k_plan_distros<true, true>), dim3(D), dim3(kBlock), kLdsRich, st_small, c->ev_start, c->ev_stop, 0, a);
+    else if (a.out.unit_breakdown) hipExtLaunchKernelGGL((k_plan_distros<false, true>), dim3(D), dim3(kBlock), kLdsLean, st_small, c->ev_start, c->ev_stop, 0, a);
+    else hipExtLaunchKernelGGL((k_plan_distros<false, false>), dim3(D), dim3(kBlock), kLdsLean, st_small, c->ev_start, c->ev_stop, 0, a);
+  } else if (out->n_units) hipLaunchKernelGGL((k_plan_distros<true, true>), dim3(D), dim3(kBlock), kLdsRich, st_small, a);
   else if (a.out.unit_breakdown) hipLaunchKernelGGL((k_plan_distros<false, true>), dim3(D), dim3(kBlock), kLdsLean, st_small, a);
   else hipLaunchKernelGGL((k_plan_distros<false, false>), dim3(D), dim3(kBlock), kLdsLean, st_small, a);
   HIP_TRY(c, hipGetLastError());
-  if (c->profile) HIP_TRY(c, hipEventRecord(c->ev_stop, st_small));
   if (n_big > 0) {
     if (big_beside) {
       HIP_TRY(c, hipEventRecord(c->ev_join, c->side));

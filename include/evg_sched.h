@@ -352,10 +352,12 @@ void evg_destroy(evg_ctx* ctx);
 void* evg_host_alloc(evg_ctx* ctx, size_t bytes);
 void evg_host_free(evg_ctx* ctx, void* p);
 
-/* Measurement hook (ABI 1.2): when enabled, every plan call on `ctx` records a HIP event right before and right after the
- * planner kernel (k_plan_distros) on the stream it is launched on; evg_last_plan_kernel_ms waits for the last call's stop
- * event and returns the interval -- that kernel alone, without the large-distro kernels enqueued behind it. bench.py's
- * roofline block is measured with it. */
+/* Measurement hook (ABI 1.2): when enabled, every plan call on `ctx` attaches a start and a stop HIP event to the dispatch of the
+ * planner kernel (k_plan_distros; hipExtLaunchKernelGGL on the stream it is launched on -- the kernel's own begin and end
+ * timestamps, what rocprofv3's kernel trace reports; until round 5 the events were recorded on the stream before and after
+ * the launch and read ~3 us more than the kernel); evg_last_plan_kernel_ms waits for the last call's stop event and returns
+ * the interval -- that kernel alone, without the large-distro kernels enqueued behind it. bench.py's roofline block is
+ * measured with it. */
 int evg_profile_plan_kernel(evg_ctx* ctx, int enable);
 int evg_last_plan_kernel_ms(evg_ctx* ctx, float* ms);
 
