@@ -446,6 +446,8 @@ void evg_batcher_destroy(evg_batcher* b) {
     // batches in flight finish; nobody new joins
     b->cv_free.wait(lk, [&] { for (const evgb::Slot& s : b->slot) if (s.state != evgb::Slot::FREE) return false; return true; });
   }
+  // callers that were refused (or are returning their results) are still inside the functions: let them out before the object goes
+  while (b->inside.load(std::memory_order_acquire) != 0) std::this_thread::yield();
   for (evgb::Slot& s : b->slot) {
     if (s.ctx) {
       (void)hipSetDevice(s.ctx->device);
