@@ -367,7 +367,11 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const int d, 
     if (t1 >= 0) join(t1, ufe);
     const int x0 = doff[e], x1 = doff[e + 1];
     uint64_t recent = ~0ull;
+#ifdef EVG_EXP_NO_EDGES_B  // upper-bound experiment (results are garbage): what ANY re-organisation of phase B's edge walk could save
+    for (int x = x0; x < x0; x++) {
+#else
     for (int x = x0; x < x1; x++) {
+#endif
       // branch-free: an out-of-queue edge reads pslot[0] and ignores it
       const uint32_t raw = m.edge[x];
       const bool out = (raw & ED_OUT) != 0;
@@ -499,10 +503,12 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const int d, 
       best = better ? u : best; bvv = better ? v : bvv; bmm = better ? mr : bmm;
     };
     if (tv[e] >= 0) consider(tv[e]);
+#ifndef EVG_EXP_NO_EDGES_D  // upper-bound experiment (results are garbage): phase D without its candidate walk
     for (int x = doff[e]; x < doff[e + 1]; x++) {
       const uint32_t er = m.edge[x];
       if (!(er & (ED_OUT | ER_SKIP))) consider((int)(er & ER_SLOT));
     }
+#endif
     bv[e] = bvv; bm[e] = bmm; bs[e] = best;
     const uint64_t uv = ub(bvv), ud = ub(dur[e]);
     const uint32_t ut = ub(tgo[e]), un = ub(nd[e]), up = ub((int32_t)pri[e]);
@@ -940,11 +946,13 @@ __device__ __forceinline__ bool plan_distro_lds(const PlanArgs& a, const int d, 
       s_first = qp < s_first ? qp : s_first;
       s_pk += pk; s_dur += du_c; s_dover += du_o;
     } else {
+#ifndef EVG_EXP_NO_TG_G  // upper-bound experiment (results are garbage): phase G without its task-group branch
       const int g = 1 + (tgk[e] - c.tg_lo);
       atomicMin(&g_first[g], qp);
       atomicAdd((unsigned long long*)&g_pk[g], (unsigned long long)pk);
       atomicAdd((unsigned long long*)&g_dur[g], (unsigned long long)du_c);
       atomicAdd((unsigned long long*)&g_dover[g], (unsigned long long)du_o);
+#endif
     }
   }
   storev(EVG_LATE_ARG(int64_t*, out.wait_ns, late3) + lo, i0, n, wait4);
