@@ -1,6 +1,6 @@
 //go:build cgo && evg_mi355x
 
-// gpu_multi.go -- several MI355X behind the BATCHED planner of gpu_planner.go (include/evg_sched.h, ABI 3.1: evg_multi_*).
+// gpu_multi.go -- several MI355X behind the BATCHED planner of gpu_planner.go (include/evg_sched.h, ABI 3.1: evg_multi_*; 3.2: evg_multi_selftest).
 //
 // north_star / SURVEY.md 8e: "Distros shard naturally across the 8 GPUs of one node with a single RCCL broadcast of the shared
 // runnable-task pool over xGMI and a gather of the per-distro TaskQueue back to rank 0." The scheduler is ONE Go process that
@@ -9,7 +9,8 @@
 // decides WHEN a batch is worth spreading and hands the library the same two structs planBatch fills for one device.
 //
 // NEVER COMPILED HERE (no Go toolchain in the build image), like the rest of shim/. The library side is exercised by
-// tests/test_gpu_multi_abi.py: a world of one through RCCL, and 3 / 4 / 5 / 8 emulated ranks on one device.
+// tests/test_gpu_multi_abi.py: a world of one through RCCL, 3 / 4 / 5 / 8 emulated ranks on one device, a failure injected at
+// every (rank, phase) of a tick, evg_multi_abort, and the start-up self-check SetGPUDevices runs.
 package scheduler
 
 /*
