@@ -1092,7 +1092,14 @@ static int launch_generic(evg_ctx* c, evg::PlanArgs& a, const evg_plan_input* in
   hipLaunchKernelGGL(k_tiled_scatter, rt, tb, 0, t, a);
   hipLaunchKernelGGL(k_tiled_reduce, stl, tb, kTiledReduceLds, t, a);
   hipLaunchKernelGGL(k_tiled_elect, rt, tb, kTiledSortLds, t, a);
-  for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, t, a, p);
+  // the merge passes: with their splits from a launch of their own when a pass is several waves of workgroups (k_tiled_splits)
+  const bool hoist = !(a.tiled_mode & TM_NO_HSPLIT) && ((a.tiled_mode & TM_HSPLIT) || (int)rt.x > kTiledHoistTiles);
+  PlanArgs am = a;
+  am.tiled_mode = hoist ? (a.tiled_mode | TM_HSPLIT) : (a.tiled_mode & ~TM_HSPLIT);
+  for (int p = 0; p < passes; p++) {
+    if (hoist) hipLaunchKernelGGL(k_tiled_splits, dim3((rt.x + 3) / 4), dim3(256), 0, t, am, p);
+    hipLaunchKernelGGL(k_tiled_merge, rt, tb, kTiledSortLds, t, am, p);
+  }
   HIP_TRY(c, hipGetLastError());
   if (t != st) {
     HIP_TRY(c, hipEventRecord(c->ev_join2, t));

@@ -56,6 +56,8 @@ constexpr int kTileEdges = 6144;      // dependency edges of one row tile resolv
 // round 2; 32 = every thread stores its own keys
 constexpr int TM_ROW_SCATTER = 1, TM_ROW_ELECT = 2;  // 16: linear tile mapping (xcd_tile)
 constexpr int TM_KEY192 = 64;                        // keys always travel as 24 bytes (the 20-byte form off)
+constexpr int TM_HSPLIT = 128, TM_NO_HSPLIT = 256;   // merge-path splits from k_tiled_splits' launch: forced on / forced off (default: by size)
+constexpr int kTiledHoistTiles = 2048;               // row tiles from which the launch hoists the splits: more than ~2.5 waves of merge workgroups
 
 // blockIdx -> tile, XCD-aware: workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; tile
 // (b % 8) * ceil(T / 8) + b / 8 gives every XCD a contiguous eighth of the tile list, i.e. whole distros. -1: no tile.
@@ -1162,7 +1164,7 @@ __device__ __forceinline__ int merge_split20(const ulonglong2* hmA, const uint32
 }
 
 // One window of one pass over a distro whose keys are in the 20-byte form. Same steps as the 24-byte body of k_tiled_merge below.
-__device__ __forceinline__ void tiled_merge20(const PlanArgs& a, TState* ts, int d, int tile, int pass, unsigned char* smem, int* s_split) {
+__device__ __forceinline__ void tiled_merge20(const PlanArgs& a, TState* ts, int d, int tile, int pass, unsigned char* smem, int* s_split, int w) {
   const int tid = threadIdx.x, lane = tid & 63;
   const Keys20 src = keys20_of((pass & 1) ? a.w_keyB : a.w_keyA, ts), dst = keys20_of((pass & 1) ? a.w_keyA : a.w_keyB, ts);
   const long long P = (long long)ts->n_rt * kRT, L = (long long)kRT << pass;
@@ -1183,12 +1185,18 @@ __device__ __forceinline__ void tiled_merge20(const PlanArgs& a, TState* ts, int
     const ulonglong2 *hmA = src.hm + pair_lo, *hmB = src.hm + a_hi;
     const uint32_t *rowA = src.row + pair_lo, *rowB = src.row + a_hi;
     const int diag0 = (int)(pos0 - pair_lo);
-    if (tid < 128) {
-      const int s = merge_split20(hmA, rowA, hmB, rowB, na, nb, diag0 + (tid >> 6) * kRT, lane);
-      if (lane == 0) s_split[tid >> 6] = s;
+    int a0, a1;
+    if (a.tiled_mode & TM_HSPLIT) {  // from k_tiled_splits' launch in front of this pass (uniform over the launch)
+      a0 = (int)a.w_pslot[w];
+      a1 = diag0 + kRT >= na + nb ? na : (int)a.w_pslot[w + 1];
+    } else {
+      if (tid < 128) {
+        const int s = merge_split20(hmA, rowA, hmB, rowB, na, nb, diag0 + (tid >> 6) * kRT, lane);
+        if (lane == 0) s_split[tid >> 6] = s;
+      }
+      __syncthreads();
+      a0 = s_split[0]; a1 = s_split[1];
     }
-    __syncthreads();
-    const int a0 = s_split[0], a1 = s_split[1];
     const int b1 = diag0 + kRT - a1, cnt_a = a1 - a0;
     const int bs = b1 - (kRT - cnt_a);  // the window's first key of run B
     // the window's two key ranges into LDS by position: a wave's load is 1 KB of consecutive pairs / 256 B of consecutive rows
@@ -1221,6 +1229,36 @@ __device__ __forceinline__ void tiled_merge20(const PlanArgs& a, TState* ts, int
   store_tile_keys20(k, dst, pos0, tid, smem);
 }
 
+// The splits of one pass in a launch of their own (TM_HSPLIT): every window's first split (merge_split at the window's own diagonal) by
+// one wave per window; the merge workgroups then start from two loads instead of two wave-wide searches in global memory -- three
+// dependent round trips off the chain of every workgroup. Pays when a pass is several waves of workgroups (BASELINE config 5 at full size,
+// 5,120 windows on 768 slots: k_tiled_merge 113.2 -> 89.2 us per pass, this kernel 12.5 us; step 1.536 -> 1.483 ms); a pass that is ONE
+// wave only gets the extra launch (config-5 share: 18.7 -> 16.3 + 4.9 us), so the launch decides by the tile count (kTiledHoistTiles;
+// profiles/r05r_hsplit.log). The row keys in w_pslot are dead after k_tiled_elect: the splits go there, by directory index.
+__global__ void __launch_bounds__(256) k_tiled_splits(const PlanArgs a, int pass) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= a.w_ntile[0]) return;
+  const int d = a.w_rtile[2 * w], tile = a.w_rtile[2 * w + 1];
+  TState* ts = &a.w_ts[d];
+  if (!tiled_live(ts) || pass >= ts->passes) return;
+  const long long P = (long long)ts->n_rt * kRT, L = (long long)kRT << pass;
+  const long long pos0 = (long long)tile * kRT;
+  const long long pair_lo = pos0 / (2 * L) * (2 * L);
+  const long long a_hi = pair_lo + L < P ? pair_lo + L : P, b_hi = pair_lo + 2 * L < P ? pair_lo + 2 * L : P;
+  const int na = (int)(a_hi - pair_lo), nb = (int)(b_hi - a_hi);
+  if (nb <= 0) return;
+  const int diag0 = (int)(pos0 - pair_lo);
+  int s;
+  if (ts->key20) {
+    const Keys20 src = keys20_of((pass & 1) ? a.w_keyB : a.w_keyA, ts);
+    s = merge_split20(src.hm + pair_lo, src.row + pair_lo, src.hm + a_hi, src.row + a_hi, na, nb, diag0, lane);
+  } else {
+    const K192* src = (const K192*)((pass & 1) ? a.w_keyB : a.w_keyA) + (size_t)ts->rt_base * kRT;
+    s = merge_split(src + pair_lo, src + a_hi, na, nb, diag0, lane);
+  }
+  if (lane == 0) a.w_pslot[w] = (uint32_t)s;
+}
+
 __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a, int pass) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_split[2];
@@ -1230,7 +1268,7 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a
   TState* ts = &a.w_ts[d];
   if (!tiled_live(ts) || pass >= ts->passes) return;
   if (ts->key20) {
-    tiled_merge20(a, ts, d, tile, pass, smem, s_split);
+    tiled_merge20(a, ts, d, tile, pass, smem, s_split, w);
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1249,13 +1287,19 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_merge(const PlanArgs a
     const K192 *A = src + pair_lo, *B = src + a_hi;
     const int diag0 = (int)(pos0 - pair_lo);
     TT_BEGIN();
-    if (tid < 128) {
-      const int s = merge_split(A, B, na, nb, diag0 + (tid >> 6) * kRT, lane);
-      if (lane == 0) s_split[tid >> 6] = s;
+    int a0, a1;
+    if (a.tiled_mode & TM_HSPLIT) {
+      a0 = (int)a.w_pslot[w];
+      a1 = diag0 + kRT >= na + nb ? na : (int)a.w_pslot[w + 1];
+    } else {
+      if (tid < 128) {
+        const int s = merge_split(A, B, na, nb, diag0 + (tid >> 6) * kRT, lane);
+        if (lane == 0) s_split[tid >> 6] = s;
+      }
+      __syncthreads();
+      a0 = s_split[0]; a1 = s_split[1];
     }
-    __syncthreads();
     TT_MARK(22);
-    const int a0 = s_split[0], a1 = s_split[1];
     const int b1 = diag0 + kRT - a1, cnt_a = a1 - a0;
     {
       // Both ranges ascending into LDS, one merge-path round. The two ranges are contiguous 24-byte keys: they come in as 6144

@@ -680,13 +680,14 @@ def test_big_tier_switched_off(oracle, monkeypatch):
         ctx.close()
 
 
-@pytest.mark.parametrize("mode", [64, 1, 2, 3, 16, 32 | 64], ids=["keys-24-bytes", "per-row-scatter", "per-row-elect", "per-row-both", "linear-tiles",
-                                                                  "own-key-stores"])
+@pytest.mark.parametrize("mode", [64, 1, 2, 3, 16, 32 | 64, 128, 128 | 64], ids=["keys-24-bytes", "per-row-scatter", "per-row-elect", "per-row-both", "linear-tiles",
+                                                                                 "own-key-stores", "hoisted-splits", "hoisted-splits-24-bytes"])
 def test_large_distro_pipeline_forms(oracle, monkeypatch, mode):
     """EVG_TILED_MODE (the A/B knob of scripts/ab_tiled.py) selects forms of the large-distro pipeline that are otherwise taken only by
     distros of unusual shape: sort keys travelling as 24 bytes instead of 20 (the form of a distro whose unit values do not pack into
     one word), dependency edges resolved per row instead of staged edge-parallel in LDS (the form of a row tile with more than 6,144
-    edges). Every one plans the same pools bit for bit: a config-5 shape with ragged tile counts, and a grouped-versions Zipf pool."""
+    edges), the merge passes' splits from a launch of their own (the form of a plan with more than 2,048 row tiles: BASELINE config 5
+    at full size). Every one plans the same pools bit for bit: a config-5 shape with ragged tile counts, and a grouped-versions Zipf pool."""
     import torch
     from evergreen_amd import native, resident
     monkeypatch.setenv("EVG_TILED_MODE", str(mode))
