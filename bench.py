@@ -6,6 +6,8 @@ GetDistroQueueInfo and UtilizationBasedHostAllocator -- the BASELINE.json metric
 distros". Inputs are resident in HBM when the timed region starts (rank 0's HBM for N > 1).
 
   python bench.py --gpus 1 --steps 50 --warmup 5
+  python bench.py --gpus N ...          (N > 1 without a launcher: re-executes itself under torch.distributed.run, one rank per device;
+                                         refuses -- exit code != 0 -- when the box shows fewer than N devices)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -483,6 +485,91 @@ def single_process(args, gen, native, np, torch):
     print(json.dumps(line), flush=True)
 
 
+def env_world():
+    """WORLD_SIZE of the launcher that started this process, or None when there is none (unset or empty: `WORLD_SIZE= python bench.py`)."""
+    w = os.environ.get("WORLD_SIZE", "").strip()
+    return int(w) if w else None
+
+
+def launch_plan(gpus, world, device_count, single_process=False, rendezvous_only=False):
+    """What `bench.py --gpus N` does about its world BEFORE anything is measured (`--gpus 8` without a launcher used
+    to run config 3 on one device and print `n_gpus: 1`). Returns ("run", None) -- go on in this process; ("refuse", message) -- exit
+    non-zero; ("launch", argv) -- re-execute under torch.distributed.run with one rank per device. The reference's shape for N > 1 is
+    one job per distro fanned out by a cron (units/crons.go:303-332); here one rank per GPU takes a contiguous range of distros."""
+    if gpus < 1:
+        return "refuse", "--gpus %d: at least one device" % gpus
+    if world is not None and world != gpus:
+        return "refuse", "--gpus %d but the launcher's WORLD_SIZE is %d: refusing to print a line for another world" % (gpus, world)
+    if not rendezvous_only and device_count < gpus:
+        return "refuse", "bench.py --gpus %d needs %d devices, this box shows %d: refusing to measure a smaller world under that name" % (
+            gpus, gpus, device_count)
+    if gpus == 1 or single_process or world is not None:
+        return "run", None
+    import socket
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return "launch", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+                      "--master-port", str(port), os.path.abspath(__file__)]
+
+
+def rendezvous_only():
+    """`--rendezvous-only`: join the world the launcher made (RCCL on a GPU box, gloo without one), count the ranks with one all-reduce
+    and print it -- the launcher path of `--gpus N` without any device work (tests/test_bench_launch.py runs it on the CPU)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), env_world() or 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    cuda = torch.cuda.is_available()
+    if cuda:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl" if cuda else "gloo", rank=rank, world_size=world)
+    one = torch.ones(1, dtype=torch.int64, device="cuda" if cuda else "cpu")
+    dist.all_reduce(one)
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks_seen": int(one.item()), "backend": "nccl" if cuda else "gloo"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def multi_selftest_child(n):
+    """`--multi-selftest N` (a child of rank 0, under a timeout): evg_multi_selftest over devices 0..N-1 from ONE process -- what
+    shim/gpu_multi.go's SetGPUDevices runs before it trusts N > 1: a generated pool of mixed shape planned on the first device alone and
+    over all N through ncclBroadcast + the grouped ncclSend/ncclRecv gather, results compared. Prints one JSON object."""
+    from evergreen_amd import native
+    out = {"devices": n}
+    t0 = time.perf_counter()
+    try:
+        m = native.MultiContext(list(range(n)))
+        try:
+            m.selftest()
+            out["result"] = "ok"
+        finally:
+            m.close()
+    except Exception as e:
+        out["result"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    out["seconds"] = time.perf_counter() - t0
+    flush_c_stdio()
+    print(json.dumps(out), flush=True)
+
+
+def run_multi_selftest(n, timeout_s=240):
+    """Rank 0, before the process group exists: the library's own N-device self-check in a child process under a timeout, so that a
+    collective that never returns costs the run `timeout_s` and a line that says so -- not the run."""
+    import subprocess
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--multi-selftest", str(n)], capture_output=True, text=True, timeout=timeout_s, env=env)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"devices": n, "result": "no result line (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+    except subprocess.TimeoutExpired:
+        return {"devices": n, "result": "timeout after %d s" % timeout_s}
+    except Exception as e:
+        return {"devices": n, "result": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -501,28 +588,52 @@ def main():
     ap.add_argument("--scatter", action="store_true", help="with --single-process: the pool moves in as per-rank slices (EVG_MULTI_SCATTER)")
     ap.add_argument("--in-flight", type=int, default=3, help="also report the sustained rate with this many independent pools in flight "
                                                              "on their own streams (the `pipelined` object; 1 = skip)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="join the launcher's world, count the ranks, print that (no device work)")
+    ap.add_argument("--multi-selftest", type=int, default=0, help="(internal) evg_multi_selftest over this many devices from one process")
+    ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the library's N-device self-check in front of the run")
     args = ap.parse_args()
 
-    import numpy as np
+    if args.multi_selftest:
+        return multi_selftest_child(args.multi_selftest)
     import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    what, how = launch_plan(args.gpus, env_world(), have, args.single_process, args.rendezvous_only)
+    if what == "refuse":
+        raise SystemExit("bench.py: " + how)
+    if what == "launch":  # --gpus N > 1 from a bare `python bench.py`: the same command line, one rank per device
+        import subprocess
+        sys.stderr.write("bench.py: --gpus %d without a launcher: re-executing under torch.distributed.run\n" % args.gpus)
+        raise SystemExit(subprocess.call(how + sys.argv[1:]))
+    if args.rendezvous_only:
+        return rendezvous_only()
+
+    import numpy as np
     from evergreen_amd import gen, multi, native, resident
 
     if args.single_process:
         return single_process(args, gen, native, np, torch)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    world = env_world() or 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if local_rank >= have:
+        raise SystemExit("bench.py: LOCAL_RANK %d but this box shows %d devices" % (local_rank, have))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    selftest, ranks_seen = None, 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rank == 0 and not args.no_selftest:   # the other ranks wait in the rendezvous meanwhile
+            selftest = run_multi_selftest(world)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)                       # every rank really is there, over RCCL
+        ranks_seen = int(one.item())
+        if ranks_seen != world:
+            raise SystemExit("bench.py: %d ranks answered the all-reduce, the world is %d" % (ranks_seen, world))
 
     cfg_num = args.config or (3 if world == 1 else 4)
     over = {}
@@ -829,6 +940,20 @@ def main():
         for k, v in extra_objs.items():
             if v is not None:
                 line[k] = v
+        if world > 1:
+            # The driver's record keeps `config`, `roofline`, `cpu_baseline` whole and only the NAMES of other objects (BENCH_r05.parsed):
+            # what the first N > 1 run has to say goes into `config` as plain numbers -- who was there, whether the library's own
+            # N-device check passed, and the two shapes that matter beside the north_star broadcast tick.
+            def rate(o):
+                return o.get("value") if isinstance(o, dict) else None
+            c5 = line.get("config5")
+            line["config"]["multi"] = {
+                "rccl_ranks_seen": ranks_seen, "selftest": selftest if selftest is not None else "skipped",
+                "broadcast_tick_tasks_per_s": value, "kernel_only_tasks_per_s": rate(line.get("kernel_only")),
+                "resident_shards_tasks_per_s": rate(line.get("resident_shards")), "scatter_tasks_per_s": rate(line.get("scatter")),
+                "config5_tasks_per_s": rate(c5), "config5_parity_vs_oracle": c5.get("parity_vs_oracle") if isinstance(c5, dict) else None,
+                "config5_error": c5.get("error") if isinstance(c5, dict) else None,
+                "queue_order_match": line.get("queue_order_match")}
         flush_c_stdio()
         print(json.dumps(line), flush=True)
     if dist is not None:
