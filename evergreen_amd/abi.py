@@ -14,7 +14,7 @@ import numpy as np
 EVG_TIME_GO_ZERO = -(2**63)
 
 EVG_OK = 0
-EVG_E_INVALID, EVG_E_HIP, EVG_E_NOMEM, EVG_E_CONTRACT, EVG_E_NODEVICE = -1, -2, -3, -4, -5
+EVG_E_INVALID, EVG_E_HIP, EVG_E_NOMEM, EVG_E_CONTRACT, EVG_E_NODEVICE, EVG_E_TIMEOUT = -1, -2, -3, -4, -5, -6
 EVG_ALLOC_OK, EVG_ALLOC_E_FUTURE_FRACTION, EVG_ALLOC_E_POOL_SIZE = 0, 1, 2
 
 TF_REQ_MASK = 0x3
@@ -77,7 +77,7 @@ class PoolDelta(C.Structure):  # evg_pool_delta
 
 EVG_HINT_NO_TIER_DISTROS = 0x200
 EVG_HINT_MIXED_POOL = 0x100  # travels in evg_plan_input.promises; never changes a plan (include/evg_sched.h)
-EVG_ABI_MAJOR, EVG_ABI_MINOR = 3, 2
+EVG_ABI_MAJOR, EVG_ABI_MINOR = 3, 3
 
 
 class HostSoa(C.Structure):

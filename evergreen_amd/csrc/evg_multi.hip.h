@@ -23,6 +23,7 @@
 // Included by evg_sched.hip (it needs launch_plan / launch_alloc and the context internals).
 #pragma once
 
+#include <atomic>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -166,7 +167,8 @@ struct evg_multi {
   std::vector<int64_t> edge_cut;
   size_t n_slots = 0;
   bool timed = false;
-  bool aborted = false;          // evg_multi_abort: the communicators are gone; only evg_multi_destroy is left
+  std::atomic<bool> aborted{false};  // evg_multi_abort / an expired deadline: the communicators are gone; only evg_multi_destroy is left
+  int64_t deadline_ms = 30000;   // evg_multi_set_deadline_ms: every device wait of the object polls against it
   int inject_rank = -1, inject_phase = -1;  // evg_multi_inject_failure: the next tick fails there (test hook, one shot)
 };
 
@@ -193,6 +195,54 @@ static int merr(evg_multi* m, int code, const char* fmt, ...) {
     ncclResult_t e_ = (expr);                                                                                         \
     if (e_ != ncclSuccess) return evgm::merr((m), EVG_E_HIP, "%s: %s", #expr, evgm::g_rccl.GetErrorString(e_));       \
   } while (0)
+
+// A rank's communicator is taken out of the rank by whoever ends it (the tick's epilogue, an expired deadline, evg_multi_abort from
+// another thread, evg_multi_destroy): exchange, then abort / destroy what came out -- never twice, never one that is gone.
+static inline ncclComm_t comm_of(Rank& r) { return __atomic_load_n(&r.comm, __ATOMIC_ACQUIRE); }
+static void abort_comms(evg_multi* m) {
+  m->aborted.store(true, std::memory_order_release);
+  for (Rank& r : m->r) {
+    ncclComm_t c = __atomic_exchange_n(&r.comm, (ncclComm_t) nullptr, __ATOMIC_ACQ_REL);
+    if (!c) continue;
+    (void)hipSetDevice(r.device);
+    if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c); else (void)g_rccl.CommDestroy(c);
+  }
+}
+// The bounded wait on rank k's stream (evg_multi_set_deadline_ms; see evg_set_deadline_ms): `until` = the moment the wait gives up.
+// On expiry the communicators are aborted -- collectives other ranks are blocked in return -- and the object refuses further work.
+static int mwait_until(evg_multi* m, int k, const char* what, std::chrono::steady_clock::time_point until) {
+  Rank& r = m->r[k];
+  hipError_t e = hipSetDevice(r.device);
+  if (e != hipSuccess) return merr(m, EVG_E_HIP, "rank %d: hipSetDevice: %s", k, hipGetErrorString(e));
+  if (m->deadline_ms <= 0) {
+    e = hipStreamSynchronize(r.stream);
+    return e == hipSuccess ? EVG_OK : merr(m, EVG_E_HIP, "rank %d: %s: hipStreamSynchronize: %s", k, what, hipGetErrorString(e));
+  }
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  for (unsigned spin = 0;; spin++) {
+    e = hipStreamQuery(r.stream);
+    if (e == hipSuccess) return EVG_OK;
+    if (e != hipErrorNotReady) return merr(m, EVG_E_HIP, "rank %d: %s: hipStreamQuery: %s", k, what, hipGetErrorString(e));
+    if (spin < 64) continue;
+    const auto now = clk::now();
+    if (now >= until) {
+      abort_comms(m);
+      return merr(m, EVG_E_TIMEOUT, "rank %d: %s: the device did not finish within %lld ms (evg_multi_set_deadline_ms); the communicators were aborted and "
+                                    "this evg_multi refuses further work: destroy it and create a new one", k, what, (long long)m->deadline_ms);
+    }
+    const auto el = std::chrono::duration_cast<std::chrono::microseconds>(now - t0).count();
+    if (el > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    else if (el > 100) std::this_thread::yield();
+  }
+}
+static int mwait(evg_multi* m, int k, const char* what) {
+  return mwait_until(m, k, what, std::chrono::steady_clock::now() + std::chrono::milliseconds(m->deadline_ms));
+}
+static int refuse_aborted(evg_multi* m, const char* who) {
+  return merr(m, m->err.find("did not finish within") != std::string::npos ? EVG_E_TIMEOUT : EVG_E_INVALID,
+              "%s: the communicators were aborted (evg_multi_abort, or a device wait that outlived the deadline): destroy this evg_multi and create a new one", who);
+}
 
 // Cost of a distro in quarter-tasks of the two-per-CU tier of the one-workgroup kernel (evergreen_amd/multi.py:distro_costs --
 // the same integers, so that a Go caller and the Python driver cut the same ranges): a distro of the one-per-CU tier holds a whole
@@ -279,7 +329,7 @@ static void free_rank(Rank& r) {
     return;
   }
   (void)hipSetDevice(r.device);
-  if (r.comm) (void)g_rccl.CommDestroy(r.comm);
+  if (ncclComm_t c = __atomic_exchange_n(&r.comm, (ncclComm_t) nullptr, __ATOMIC_ACQ_REL)) (void)g_rccl.CommDestroy(c);
   if (r.buf) (void)hipFree(r.buf);
   if (r.out) (void)hipFree(r.out);
   if (r.outl) (void)hipFree(r.outl);
@@ -404,7 +454,7 @@ static int resident_hosts(evg_multi* m, const evg_alloc_input* alloc) {
       r.abuf_cap = total + total / 4 + 256;
     }
     EVGM_HIP(m, hipMemcpyAsync(r.abuf, stage.data(), total, hipMemcpyHostToDevice, r.stream));
-    EVGM_HIP(m, hipStreamSynchronize(r.stream));  // `stage` is re-used for the next rank
+    if (int rcw = mwait(m, k, "hosts in")) return rcw;  // `stage` is re-used for the next rank
     evg_alloc_input& ai = r.ainl;
     ai = evg_alloc_input{};
     ai.n_distros = (int32_t)nd; ai.params = (const evg_alloc_params*)(r.abuf + o_par); ai.host_off = (const int32_t*)(r.abuf + o_hoff);
@@ -557,8 +607,8 @@ static int resident_tick_body(evg_multi* m, int64_t now_ns, bool& group_open, bo
       resident_moves(m, k, mv);
       for (const Move& x : mv) {
         group_whole = false;
-        EVGM_NCCL(m, g_rccl.Send(m->r[k].outl + x.src, x.bytes, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
-        EVGM_NCCL(m, g_rccl.Recv(root.out + x.dst, x.bytes, ncclUint8, k, root.comm, root.stream));
+        EVGM_NCCL(m, g_rccl.Send(m->r[k].outl + x.src, x.bytes, ncclUint8, 0, comm_of(m->r[k]), m->r[k].stream));
+        EVGM_NCCL(m, g_rccl.Recv(root.out + x.dst, x.bytes, ncclUint8, k, comm_of(root), root.stream));
         group_whole = true;
       }
       if (int rc = inject(k, 3)) return rc;
@@ -597,6 +647,7 @@ evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t f
         if (devices[i] == devices[j]) { merr(nullptr, EVG_E_INVALID, "evg_multi_create: device %d listed twice (RCCL wants distinct devices; EVG_MULTI_LOOPBACK emulates ranks on one)", devices[i]); return nullptr; }
   evg_multi* m = new evg_multi();
   m->n = n_devices; m->flags = flags; m->loopback = loopback;
+  if (const char* e = getenv("EVG_DEADLINE_MS")) { const long long v = atoll(e); if (v >= 0) m->deadline_ms = v; }
   m->r.resize(n_devices);
   auto fail = [&]() -> evg_multi* {
     g_multi_err = m->err;
@@ -777,7 +828,7 @@ int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input
   evgm::Rank& root = m->r[0];
   EVGM_HIP(m, hipSetDevice(root.device));
   EVGM_HIP(m, hipMemcpyAsync(root.buf, m->packed_h, L.total, hipMemcpyHostToDevice, root.stream));
-  EVGM_HIP(m, hipStreamSynchronize(root.stream));
+  if (int rcw = mwait(m, 0, "pool in")) return rcw;
   m->loaded = true;
   return EVG_OK;
 }
@@ -831,8 +882,8 @@ static int tick_body(evg_multi* m, int64_t now_ns, bool& group_open, bool& group
       in_slices(m, k, sl);
       for (const Slice& s : sl) {
         group_whole = false;
-        EVGM_NCCL(m, g_rccl.Send(m->r[0].buf + s.off, s.bytes, ncclUint8, k, m->r[0].comm, m->r[0].stream));
-        EVGM_NCCL(m, g_rccl.Recv(m->r[k].buf + s.off, s.bytes, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
+        EVGM_NCCL(m, g_rccl.Send(m->r[0].buf + s.off, s.bytes, ncclUint8, k, comm_of(m->r[0]), m->r[0].stream));
+        EVGM_NCCL(m, g_rccl.Recv(m->r[k].buf + s.off, s.bytes, ncclUint8, 0, comm_of(m->r[k]), m->r[k].stream));
         group_whole = true;
       }
       if (int rc = inject(k, 0)) return rc;
@@ -844,7 +895,7 @@ static int tick_body(evg_multi* m, int64_t now_ns, bool& group_open, bool& group
     EVGM_NCCL(m, g_rccl.GroupStart());
     group_open = true;
     group_whole = false;
-    for (int k = 0; k < n; k++) EVGM_NCCL(m, g_rccl.Broadcast(m->r[k].buf, m->r[k].buf, L.total, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
+    for (int k = 0; k < n; k++) EVGM_NCCL(m, g_rccl.Broadcast(m->r[k].buf, m->r[k].buf, L.total, ncclUint8, 0, comm_of(m->r[k]), m->r[k].stream));
     group_whole = true;
     for (int k = 0; k < n; k++) if (int rc = inject(k, 0)) return rc;
     group_open = false;
@@ -884,8 +935,8 @@ static int tick_body(evg_multi* m, int64_t now_ns, bool& group_open, bool& group
       out_slices(m, k, sl);
       for (const Slice& s : sl) {
         group_whole = false;
-        EVGM_NCCL(m, g_rccl.Send(m->r[k].out + s.off, s.bytes, ncclUint8, 0, m->r[k].comm, m->r[k].stream));
-        EVGM_NCCL(m, g_rccl.Recv(m->r[0].out + s.off, s.bytes, ncclUint8, k, m->r[0].comm, m->r[0].stream));
+        EVGM_NCCL(m, g_rccl.Send(m->r[k].out + s.off, s.bytes, ncclUint8, 0, comm_of(m->r[k]), m->r[k].stream));
+        EVGM_NCCL(m, g_rccl.Recv(m->r[0].out + s.off, s.bytes, ncclUint8, k, comm_of(m->r[0]), m->r[0].stream));
         group_whole = true;
       }
       if (int rc = inject(k, 3)) return rc;  // pairs are matched rank by rank: what was enqueued so far completes
@@ -904,7 +955,7 @@ extern "C" int evg_multi_tick(evg_multi* m, int64_t now_ns) {
   using namespace evgm;
   if (!m) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
-  if (m->aborted) return merr(m, EVG_E_INVALID, "evg_multi_tick: the communicators were aborted (evg_multi_abort): destroy this evg_multi and create a new one");
+  if (m->aborted.load(std::memory_order_acquire)) return refuse_aborted(m, "evg_multi_tick");
   if (!m->loaded) return merr(m, EVG_E_INVALID, "evg_multi_tick: no pool is loaded");
   if (m->lay.D == 0) return EVG_OK;
   bool group_open = false, group_whole = true;
@@ -915,21 +966,20 @@ extern "C" int evg_multi_tick(evg_multi* m, int64_t now_ns) {
     if (e != ncclSuccess && !first) first = merr(m, EVG_E_HIP, "ncclGroupEnd: %s", g_rccl.GetErrorString(e));
     if (!group_whole) {  // a send without its receive, a broadcast without all its ranks: it never completes -- the communicators go
       const std::string why = m->err;
-      m->aborted = true;
-      for (Rank& r : m->r)
-        if (r.comm) {
-          (void)hipSetDevice(r.device);
-          if (g_rccl.CommAbort) (void)g_rccl.CommAbort(r.comm); else (void)g_rccl.CommDestroy(r.comm);
-          r.comm = nullptr;
-        }
+      abort_comms(m);
       merr(m, first ? first : EVG_E_HIP, "%s; the RCCL group was left half-issued, the communicators were aborted: destroy this evg_multi and create a new one", why.c_str());
       if (!first) first = EVG_E_HIP;
     }
   }
-  for (int k = 0; k < m->n; k++) {  // nothing of this tick is in flight after the return, error or not
-    hipError_t e = hipSetDevice(m->r[k].device);
-    if (e == hipSuccess) e = hipStreamSynchronize(m->r[k].stream);
-    if (e != hipSuccess && !first) first = merr(m, EVG_E_HIP, "rank %d: hipStreamSynchronize: %s", k, hipGetErrorString(e));
+  {  // nothing of this tick is in flight after the return, error or not -- within ONE deadline for all the ranks; once it has passed
+     // (the communicators are then gone and blocked collectives return) every further rank gets two more seconds to drain
+    auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(m->deadline_ms);
+    for (int k = 0; k < m->n; k++) {
+      const std::string keep = m->err;
+      const int rcw = mwait_until(m, k, "tick", until);
+      if (rcw == EVG_E_TIMEOUT) until = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+      if (rcw && !first) first = rcw; else if (rcw) m->err = keep;
+    }
   }
   for (int k = 0; k < m->n; k++) {  // ALL ranks: a status word left set would fail every later tick with a stale EVG_E_CONTRACT
     const int rc = evg_take_device_status(m->r[k].ctx);
@@ -954,13 +1004,26 @@ int evg_multi_inject_failure(evg_multi* m, int32_t rank, int32_t phase) {
 // holds it.
 int evg_multi_abort(evg_multi* m) {
   if (!m) return EVG_E_INVALID;
-  m->aborted = true;
-  for (evgm::Rank& r : m->r)
-    if (r.comm) {
-      (void)hipSetDevice(r.device);
-      if (evgm::g_rccl.CommAbort) (void)evgm::g_rccl.CommAbort(r.comm); else (void)evgm::g_rccl.CommDestroy(r.comm);
-      r.comm = nullptr;
-    }
+  evgm::abort_comms(m);
+  return EVG_OK;
+}
+
+// The deadline of every device wait of the object and of its ranks' contexts (default 30,000 ms, EVG_DEADLINE_MS; 0 = no limit).
+int evg_multi_set_deadline_ms(evg_multi* m, int64_t ms) {
+  if (!m || ms < 0) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  m->deadline_ms = ms;
+  for (evgm::Rank& r : m->r) if (r.ctx) (void)evg_set_deadline_ms(r.ctx, ms);
+  return EVG_OK;
+}
+
+// Test hook of the deadline: a kernel that spins for `ms` milliseconds on rank `rank`'s stream (see evg_debug_stall).
+int evg_multi_debug_stall(evg_multi* m, int32_t rank, int32_t ms) {
+  if (!m || rank < 0 || rank >= m->n || ms < 0 || ms > 20000) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(m->mu);
+  EVGM_HIP(m, hipSetDevice(m->r[rank].device));
+  hipLaunchKernelGGL(evg::k_debug_stall, dim3(1), dim3(64), 0, m->r[rank].stream, (long long)ms * 100000LL);
+  EVGM_HIP(m, hipGetLastError());
   return EVG_OK;
 }
 
@@ -1162,8 +1225,8 @@ int evg_multi_results(evg_multi* m, const evg_plan_output* out, const evg_alloc_
     if (!rc) rc = down(aout->free_hosts, o.alloc + 4 * L.D, 4 * L.D);
     if (!rc) rc = down(aout->status, o.alloc + 8 * L.D, 4 * L.D);
   }
-  (void)hipStreamSynchronize(root.stream);  // nothing of the caller's is touched after the return, error or not
-  return rc;
+  const int rcw = mwait(m, 0, "results");  // nothing of the caller's is touched after the return, error or not
+  return rc ? rc : rcw;
 }
 
 // A tick's structural change for resident shards (EVG_MULTI_RESIDENT_SHARDS): `delta` is written against the WHOLE batch -- current
@@ -1187,6 +1250,13 @@ int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_allo
   const evg_task_soa& ad = dl->added;
   if (na > 0 && (ad.n_tasks != na || !ad.dep_off || !ad.tg_key || !ad.version_key || (ad.n_edges > 0 && !ad.dep_idx)))
     return merr(m, EVG_E_INVALID, "evg_multi_apply_delta: the added rows' columns are incomplete");
+  if (na > 0) {  // the added rows' CSR, once for the whole delta and before anything is sized from it
+    if (ad.n_edges < 0 || ad.dep_off[0] != 0 || ad.dep_off[na] != ad.n_edges)
+      return merr(m, EVG_E_CONTRACT, "evg_multi_apply_delta: added.dep_off must run from 0 to added.n_edges (%d .. %d, n_edges %d)", ad.dep_off[0], ad.dep_off[na], ad.n_edges);
+    for (int i = 0; i < na; i++)
+      if (ad.dep_off[i + 1] < ad.dep_off[i])
+        return merr(m, EVG_E_CONTRACT, "evg_multi_apply_delta: added.dep_off decreases at added row %d", i);
+  }
   if (L.has_hosts && dl->tg_off && !alloc)
     return merr(m, EVG_E_INVALID, "evg_multi_apply_delta: the key ranges change and the resident hosts' tg_key with them: pass the tick's allocator input");
   const int32_t* n_tg = dl->tg_off ? dl->tg_off : m->tg_off.data();
@@ -1239,7 +1309,7 @@ int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_allo
     Part& p = part[k];
     const int nd = r.d1 - r.d0, a0 = p.a0, nak = p.a1 - p.a0;
     if (nd == 0) continue;
-    const int32_t R0 = m->task_off[r.d0];
+    const int32_t R0 = m->task_off[r.d0], R1 = m->task_off[r.d1];
     for (int32_t& x : p.removed) x -= R0;
     evg_pool_delta sub{};
     sub.n_removed = (int32_t)p.removed.size(); sub.removed_rows = p.removed.data(); sub.removed_dep_state = p.state.data();
@@ -1261,7 +1331,10 @@ int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_allo
       for (int i = 0; i <= nak; i++) p.doff[i] = ad.dep_off[a0 + i] - e0;
       for (int x = 0; x < e1 - e0; x++) {
         const int32_t j = ad.dep_idx[e0 + x];
-        if (j >= 0) p.didx[x] = j - R0;  // a current row: of this rank's range, or the device refuses it (not a row of the same distro)
+        // a current row: of this rank's range (re-based; the device then checks that it is a row of the same distro), or of another
+        // rank's -- below R0 or beyond the range: the sentinel the device refuses (DS_ADDED_EDGE), like evg_pool_apply_delta on one
+        // pool refuses an edge across distros. (j - R0 for a row below R0 would read as "not in the queue" or as an added row.)
+        if (j >= 0) p.didx[x] = j >= R0 && j < R1 ? j - R0 : (int32_t)0x40000000;
         else if (j <= -2) { const int32_t kk = -(j + 2); p.didx[x] = kk >= a0 && kk < p.a1 ? -((kk - a0) + 2) : (int32_t)0x40000000; }  // another rank's added row: refused
         else p.didx[x] = -1;
       }
@@ -1308,13 +1381,13 @@ int evg_multi_poison_outputs(evg_multi* m, int32_t byte) {
     if (!r.out || !m->o.total) continue;  // an empty batch has no outputs
     EVGM_HIP(m, hipSetDevice(r.device));
     EVGM_HIP(m, hipMemsetAsync(r.out, byte, m->o.total, r.stream));
-    EVGM_HIP(m, hipStreamSynchronize(r.stream));
+    if (int rcw = evgm::mwait(m, (int)(&r - m->r.data()), "poison")) return rcw;
   }
   for (evgm::Rank& r : m->r) {  // resident shards: every rank's local block
     if (!r.outl || !r.ol.total) continue;
     EVGM_HIP(m, hipSetDevice(r.device));
     EVGM_HIP(m, hipMemsetAsync(r.outl, byte, r.ol.total, r.stream));
-    EVGM_HIP(m, hipStreamSynchronize(r.stream));
+    if (int rcw = evgm::mwait(m, (int)(&r - m->r.data()), "poison")) return rcw;
   }
   return EVG_OK;
 }

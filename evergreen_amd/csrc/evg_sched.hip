@@ -23,6 +23,7 @@
 #include "evg_plan_lds.hip.h"
 #include "evg_dispatch.hip.h"
 #include "evg_pool_delta.hip.h"
+#include "evg_validate.hpp"
 
 namespace evg {
 
@@ -332,6 +333,12 @@ __global__ void __launch_bounds__(256) k_update_edges(int n, const int32_t* edge
 //   class 1  random X below 2^b, b in [1, 53], random n below 2^nb, nb in [1, 24];
 //   class 2  mainline boundaries: X = n * (week - h * hour + e) + delta around every whole hour h in [0, 168];
 //   class 3  negative / beyond-2^53 sums (the Go-shaped code must take over).
+// evg_debug_stall (test hook of the bounded waits): one wave spins for `ticks` of the 100 MHz device wall clock.
+__global__ void k_debug_stall(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+
 __global__ void k_selftest_unit_value(uint64_t seed, uint64_t n_cases, unsigned long long* out) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   unsigned long long bad = 0, first = ~0ull;
@@ -447,6 +454,9 @@ struct evg_ctx {
   // set by the micro-batching front around its own launches (evg_batcher.hip.h): per-distro clock readings / allocator tick rows
   const int64_t* now_d = nullptr;
   const void* tick_d = nullptr;
+  // bounded calls (evg_set_deadline_ms): every device wait polls against this; once one expired the context refuses work
+  int64_t deadline_ms = 30000;
+  bool timed_out = false;
   int tiled_mode = 0;  // EVG_TILED_MODE: TM_* bits (evg_tiled.hip.h), A/B runs of the large-distro pipeline's per-row / pairwise forms
 #ifdef EVG_PHASE_TIMING
   unsigned long long* dbg_ts = nullptr;
@@ -488,9 +498,46 @@ static int ensure(evg_ctx* c, DevBuf& b, size_t bytes) {
 
 // The host-pointer entry points are synchronous and retain nothing: whatever way they leave (an error after some copies
 // were enqueued included), the context's stream is drained first, so no copy touches caller memory after the return.
+//
+// Every wait is bounded (evg_set_deadline_ms): hipStreamQuery against a monotonic clock -- a tight poll for the first ~100 us (the
+// one-distro calls of the reference's own shape finish inside it: no latency added), then yields, then 50 us sleeps. On expiry the
+// context is poisoned: whatever hangs on the device may still read and write the context's buffers.
+template <class Query, class Block>
+static int wait_ready(evg_ctx* c, const char* what, Query query, Block block) {
+  if (c->deadline_ms <= 0) {
+    hipError_t e = block();
+    return e == hipSuccess ? EVG_OK : set_err(c, EVG_E_HIP, "%s: %s", what, hipGetErrorString(e));
+  }
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  for (unsigned spin = 0;; spin++) {
+    const hipError_t e = query();
+    if (e == hipSuccess) return EVG_OK;
+    if (e != hipErrorNotReady) return set_err(c, EVG_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    if (spin < 64) continue;
+    const auto el = std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count();
+    if (el > c->deadline_ms * 1000) {
+      c->timed_out = true;
+      return set_err(c, EVG_E_TIMEOUT, "%s: the device did not finish within %lld ms (evg_set_deadline_ms); this context refuses further work -- "
+                                       "destroy it and create another", what, (long long)c->deadline_ms);
+    }
+    if (el > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    else if (el > 100) std::this_thread::yield();
+  }
+}
+static int wait_stream(evg_ctx* c, hipStream_t st, const char* what) {
+  return wait_ready(c, what, [&] { return hipStreamQuery(st); }, [&] { return hipStreamSynchronize(st); });
+}
+static int wait_event(evg_ctx* c, hipEvent_t ev, const char* what) {
+  return wait_ready(c, what, [&] { return hipEventQuery(ev); }, [&] { return hipEventSynchronize(ev); });
+}
+static int refuse_timed_out(evg_ctx* c) {
+  return set_err(c, EVG_E_TIMEOUT, "an earlier call on this context outlived its deadline of %lld ms: the context refuses further work -- destroy it and "
+                                   "create another", (long long)c->deadline_ms);
+}
 struct StreamDrain {
   evg_ctx* c;
-  ~StreamDrain() { (void)hipStreamSynchronize(c->stream); }
+  ~StreamDrain() { if (!c->timed_out) { const std::string keep = c->err; if (wait_stream(c, c->stream, "drain") == EVG_OK) c->err = keep; } }
 };
 
 // Batches up to this many bytes (inputs + outputs) travel packed: the calls of the reference's own shape -- one distro per
@@ -583,7 +630,7 @@ struct Stager {
       if (hipMemcpyAsync(c->pack_h + in_cap, c->pack_d + in_cap, out_off, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
         return rc = set_err(c, EVG_E_HIP, "D2H copy failed");
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return rc = set_err(c, EVG_E_HIP, "hipStreamSynchronize failed");
+    if ((rc = wait_stream(c, c->stream, "results"))) return rc;
     for (const Down& x : downs) memcpy(x.host, c->pack_h + x.off, x.bytes);
     return EVG_OK;
   }
@@ -640,6 +687,7 @@ int evg_check_abi(int32_t major, int32_t minor, size_t sizeof_plan_input, size_t
 
 // The sticky device-side status (a false EVG_PROMISE_ALL_ON_LDS_PATH seen by the planner kernel): every entry point checks it first.
 static int pending_status(evg_ctx* c) {
+  if (c->timed_out) return refuse_timed_out(c);
   if (c->status_word && *(volatile uint32_t*)c->status_word)
     return set_err(c, EVG_E_CONTRACT, "a batch passed with EVG_PROMISE_ALL_ON_LDS_PATH held a distro the one-workgroup kernel cannot plan: "
                                       "its plan was not computed (evg_take_device_status clears this)");
@@ -691,6 +739,7 @@ evg_ctx* evg_create(int device_ordinal) {
   if (const char* m = getenv("EVG_BIG_TIER")) c->big_mode = atoi(m);
   if (const char* m = getenv("EVG_TILED_MODE")) c->tiled_mode = atoi(m);
   if (const char* m = getenv("EVG_OVERLAP")) c->overlap = atoi(m);
+  if (const char* m = getenv("EVG_DEADLINE_MS")) { const long long v = atoll(m); if (v >= 0) c->deadline_ms = v; }
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void**)&c->status_word, 64, hipHostMallocDefault) != hipSuccess) {
     set_err(nullptr, EVG_E_HIP, "cannot create a stream / the status word on device %d", device_ordinal);
@@ -705,6 +754,15 @@ evg_ctx* evg_create(int device_ordinal) {
 void evg_destroy(evg_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->timed_out) {
+    // One more bounded wait; a device that still has not come back keeps the buffers (hipFree would wait for it without a limit):
+    // the memory is leaked, the caller's thread is not.
+    c->timed_out = false;
+    bool idle = wait_stream(c, c->stream, "evg_destroy") == EVG_OK;
+    if (idle && c->side) idle = wait_stream(c, c->side, "evg_destroy") == EVG_OK;
+    if (idle && c->side2) idle = wait_stream(c, c->side2, "evg_destroy") == EVG_OK;
+    if (!idle) { delete c; return; }
+  }
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->stage) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->pool) if (b.p) (void)hipFree(b.p);
@@ -724,6 +782,24 @@ void evg_destroy(evg_ctx* c) {
   delete c;
 }
 
+int evg_set_deadline_ms(evg_ctx* c, int64_t ms) {
+  if (!c || ms < 0) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->deadline_ms = ms;
+  return EVG_OK;
+}
+int64_t evg_get_deadline_ms(const evg_ctx* c) { return c ? c->deadline_ms : -1; }
+
+int evg_debug_stall(evg_ctx* c, int32_t ms) {
+  if (!c || ms < 0 || ms > 20000) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->timed_out) return refuse_timed_out(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(evg::k_debug_stall, dim3(1), dim3(64), 0, c->stream, (long long)ms * 100000LL);
+  HIP_TRY(c, hipGetLastError());
+  return EVG_OK;
+}
+
 int evg_selftest_unit_value(evg_ctx* c, uint64_t seed, uint64_t n_cases, uint64_t* mismatches, uint64_t* first_bad_case) {
   if (!c || !mismatches) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
@@ -735,7 +811,7 @@ int evg_selftest_unit_value(evg_ctx* c, uint64_t seed, uint64_t n_cases, uint64_
   hipLaunchKernelGGL(evg::k_selftest_unit_value, dim3(4096), dim3(256), 0, c->stream, seed, n_cases, (unsigned long long*)c->scratch[29].p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(h, c->scratch[29].p, 16, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   *mismatches = h[0];
   if (first_bad_case) *first_bad_case = h[1];
   return EVG_OK;
@@ -757,7 +833,8 @@ int evg_last_plan_kernel_ms(evg_ctx* c, float* ms) {
   if (!c || !ms) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   if (!c->ev_start) return set_err(c, EVG_E_INVALID, "evg_profile_plan_kernel was never enabled on this context");
-  HIP_TRY(c, hipEventSynchronize(c->ev_stop));
+  if (c->timed_out) return refuse_timed_out(c);
+  if (int rcw_ = wait_event(c, c->ev_stop, __func__)) return rcw_;
   HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
   return EVG_OK;
 }
@@ -796,37 +873,6 @@ static int distro_lds_tier(const evg_plan_input* in, int d) {
   return tier;
 }
 
-// One distro's share of the layout contract; 0 or EVG_E_CONTRACT with the message in `err`.
-static int validate_distro(const evg_plan_input* in, int d, char* err, size_t err_len) {
-  const evg_task_soa& t = in->tasks;
-  auto fail = [&](const char* fmt, long a, long b) {
-    snprintf(err, err_len, fmt, a, b);
-    return EVG_E_CONTRACT;
-  };
-  const int lo = in->task_off[d], hi = in->task_off[d + 1];
-  if (hi < lo) return fail("task_off not monotone at distro %ld (%ld)", d, hi);
-  if (hi - lo >= (1 << 24)) return fail("distro %ld has %ld tasks; the limit is 2^24-1", d, hi - lo);
-  const int tg_lo = in->tg_off[d], tg_hi = in->tg_off[d + 1], ver_lo = in->ver_off[d], ver_hi = in->ver_off[d + 1];
-  if (tg_hi < tg_lo || ver_hi < ver_lo) return fail("key offsets not monotone at distro %ld (%ld)", d, tg_hi);
-  for (int r = lo; r < hi; r++) {
-    // keys: any one-to-one interning of the strings into the distro's range (ABI 3.1: neither first-appearance order nor
-    // density is required -- a resident pool that lost the last task of a group keeps the key, with no row behind it)
-    const int g = t.tg_key[r], v = t.version_key[r];
-    if (g != -1 && (g < tg_lo || g >= tg_hi)) return fail("row %ld: tg_key %ld is neither -1 nor in the distro's key range", r, g);
-    if (v < ver_lo || v >= ver_hi) return fail("row %ld: version_key %ld is outside the distro's key range", r, v);
-    const int e0 = t.dep_off[r], e1 = t.dep_off[r + 1];
-    if (e1 < e0) return fail("dep_off not monotone at row %ld (%ld)", r, e1);
-    if (e0 < 0 || e1 > t.n_edges) return fail("row %ld: dep_off %ld outside [0, n_edges]", r, e1);
-    // a dependency is a row of the SAME distro's queue or -1 (not in this queue: its state rides in dep_info); a row of
-    // another distro would be read as "not in the queue" with status bits nobody filled
-    for (int e = e0; e < e1; e++) {
-      const int j = t.dep_idx[e];
-      if (j != -1 && (j < lo || j >= hi)) return fail("edge %ld: dep_idx %ld is neither -1 nor a row of the same distro", e, j);
-    }
-  }
-  return EVG_OK;
-}
-
 int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, int32_t* promises, int32_t* n_big_tier_distros) {
   if (!in || !max_distro_tasks || !promises || !n_big_tier_distros) return EVG_E_INVALID;
   *max_distro_tasks = 0;
@@ -855,49 +901,6 @@ int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, i
   if (!any_none) *promises |= EVG_PROMISE_ALL_ON_LDS_TIERS;
   if (std::min(nt, np) * 8 >= (long long)in->tasks.n_tasks && in->tasks.n_tasks > 0) *promises |= EVG_HINT_MIXED_POOL;
   if (nt == 0 && np > 0 && np == (long long)in->tasks.n_tasks) *promises |= EVG_HINT_NO_TIER_DISTROS;
-  return EVG_OK;
-}
-
-int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len) {
-  auto fail = [&](const char* fmt, long a, long b) {
-    if (msg && msg_len > 0) snprintf(msg, msg_len, fmt, a, b);
-    return EVG_E_CONTRACT;
-  };
-  if (!in) return EVG_E_INVALID;
-  const int D = in->n_distros;
-  const evg_task_soa& t = in->tasks;
-  if (D < 0 || t.n_tasks < 0 || t.n_edges < 0) return fail("negative size (%ld, %ld)", D, t.n_tasks);
-  if (D == 0) return EVG_OK;
-  if (!in->task_off || !in->tg_off || !in->ver_off || !in->distros) return EVG_E_INVALID;
-  if (t.n_tasks > 0 && (!t.tg_key || !t.version_key || !t.dep_off || (t.n_edges > 0 && !t.dep_idx))) return EVG_E_INVALID;
-  if (in->task_off[0] != 0 || in->task_off[D] != t.n_tasks) return fail("task_off must span [0, n_tasks] (%ld..%ld)", in->task_off[0], in->task_off[D]);
-  if (in->tg_off[0] != 0 || in->tg_off[D] != in->n_task_groups) return fail("tg_off must span [0, n_task_groups] (%ld..%ld)", in->tg_off[0], in->tg_off[D]);
-  if (in->ver_off[0] != 0 || in->ver_off[D] != in->n_versions) return fail("ver_off must span [0, n_versions] (%ld..%ld)", in->ver_off[0], in->ver_off[D]);
-  if (t.n_tasks && t.dep_off[0] != 0) return fail("dep_off[0]=%ld must be 0 (n_edges=%ld)", t.dep_off[0], t.n_edges);
-  if (t.n_tasks && t.dep_off[t.n_tasks] != t.n_edges) return fail("dep_off[N]=%ld != n_edges=%ld", t.dep_off[t.n_tasks], t.n_edges);
-  if (in->max_distro_tasks < 0) return fail("max_distro_tasks %ld is negative (0 = unknown) (%ld)", in->max_distro_tasks, 0);
-  // The per-row checks are independent per distro: a large batch is checked by a few threads (this runs inside every
-  // host-pointer call; one thread needs ~1.5 ms for 1M rows + 1.3M edges). The FIRST failing distro's message is reported.
-  const int nt = t.n_tasks + t.n_edges < (1 << 18) ? 1 : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-  std::vector<int> first_bad(nt, D);
-  std::vector<std::string> errs(nt);
-  auto work = [&](int w) {
-    char buf[256];
-    for (int d = (int)((long long)D * w / nt), d1 = (int)((long long)D * (w + 1) / nt); d < d1; d++)
-      if (validate_distro(in, d, buf, sizeof buf) != EVG_OK) { first_bad[w] = d; errs[w] = buf; return; }
-  };
-  if (nt == 1) work(0);
-  else {
-    std::vector<std::thread> th;
-    for (int w = 1; w < nt; w++) th.emplace_back(work, w);
-    work(0);
-    for (auto& x : th) x.join();
-  }
-  for (int w = 0; w < nt; w++)
-    if (first_bad[w] < D) {
-      if (msg && msg_len > 0) snprintf(msg, msg_len, "%s", errs[w].c_str());
-      return EVG_E_CONTRACT;
-    }
   return EVG_OK;
 }
 
@@ -1588,13 +1591,13 @@ int evg_rebuild_dispatchers(evg_ctx* c, int32_t n_distros, const int32_t* item_o
   od.sorted = s.out<int32_t>(N, true); od.n_sorted = s.out<int32_t>(D, true); od.n_cycles = s.out<int32_t>(D, true);
   od.group_items = s.out<int32_t>(N, true); od.group_start = s.out<int32_t>(TG, true); od.group_count = s.out<int32_t>(TG, true);
   if (s.rc) return s.rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // iota is a local: its copy must have left before it goes away
+  if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;  // iota is a local: its copy must have left before it goes away
   int rc = do_dispatch_order_device(c, &di, di.task_off, d_row, &od, c->stream);
   if (rc) return rc;
   s.down(out->sorted, od.sorted, N); s.down(out->n_sorted, od.n_sorted, D); s.down(out->n_cycles, od.n_cycles, D);
   s.down(out->group_items, od.group_items, N); s.down(out->group_start, od.group_start, TG); s.down(out->group_count, od.group_count, TG);
   if (s.rc) return s.rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   return EVG_OK;
 }
 
@@ -1636,7 +1639,7 @@ int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
     c->pool_task_off.assign(1, 0); c->pool_tg_off.assign(1, 0); c->pool_ver_off.assign(1, 0);
     c->pool_gv.clear();
     c->pool_pri_wide = false;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
     c->pool_in = di;
     c->pool_loaded = true;
     return EVG_OK;
@@ -1648,7 +1651,7 @@ int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
   for (size_t d = 0; d < D; d++) c->pool_gv[d] = in->distros[d].group_versions != 0;
   c->pool_pri_wide = false;
   for (size_t r = 0; r < N && !c->pool_pri_wide; r++) c->pool_pri_wide = t.priority[r] != (int64_t)(int32_t)t.priority[r];
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   c->pool_in = di;
   c->pool_loaded = true;
   return EVG_OK;
@@ -1710,7 +1713,7 @@ int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update*
                      (int64_t*)t.deps_met_ts_ns, (int32_t*)t.num_dependents, (uint16_t*)t.flags};
     hipLaunchKernelGGL(evg::k_update_rows, dim3((nr + 255) / 256), dim3(256), 0, c->stream, nr, d_rows, dst, src);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the packed block is re-used below
+    if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;  // the packed block is re-used below
   }
   if (ne > 0) {
     Stager s2{c};
@@ -1725,7 +1728,7 @@ int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update*
                        (int64_t*)p.tasks.dep_finished_ts_ns, d_info, d_fin);
     HIP_TRY(c, hipGetLastError());
   }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   return EVG_OK;
 }
 
@@ -1953,7 +1956,7 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   HIP_TRY(c, hipMemcpyAsync(nw[18].p, d_nver, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
   std::vector<int32_t> back(8 + 2 * ((size_t)D + 1), 0);
   HIP_TRY(c, hipMemcpyAsync(back.data(), d_back, 4 * back.size(), hipMemcpyDeviceToHost, st));
-  HIP_TRY(c, hipStreamSynchronize(st));
+  if (int rcw_ = wait_stream(c, st, __func__)) return rcw_;
   lap("tables up, cuts back, synced");
   {  // the kernels' verdict: the first violation in the order the host used to look for them
     const unsigned long long first = ((unsigned long long)(uint32_t)back[5] << 32) | (uint32_t)back[4];
@@ -2048,7 +2051,7 @@ int evg_filter_runnable(evg_ctx* c, const evg_plan_input* in, const uint8_t* dis
   if (rc) return rc;
   s.down(deps_met, d_met, N); s.down(keep, d_keep, N); s.down(runnable_row, d_row, N); s.down(runnable_count, d_cnt, D);
   if (s.rc) return s.rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   return EVG_OK;
 }
 
@@ -2076,7 +2079,7 @@ int evg_allocator_report(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, c
   if (rc) return rc;
   s.down(report, d_rep, D);
   if (s.rc) return s.rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   return EVG_OK;
 }
 

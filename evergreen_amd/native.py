@@ -29,6 +29,10 @@ EXPORTS = [
     "evg_multi_ranges", "evg_multi_profile", "evg_multi_last_tick_ms", "evg_multi_poison_outputs", "evg_balanced_ranges",
     "evg_multi_inject_failure", "evg_multi_abort", "evg_multi_selftest", "evg_multi_apply_delta",
     "evg_batcher_create", "evg_batcher_destroy", "evg_batcher_plan", "evg_batcher_allocate", "evg_batcher_get_stats",
+    # ABI 3.3
+    "evg_set_deadline_ms", "evg_get_deadline_ms", "evg_debug_stall", "evg_multi_set_deadline_ms", "evg_multi_debug_stall",
+    "evg_batcher_schedule", "evg_batcher_plan_queue", "evg_batcher_set_deadline_ms", "evg_batcher_close", "evg_batcher_get_cache_stats",
+    "evg_batcher_debug_stall",
 ]
 
 _lib = None
@@ -148,6 +152,21 @@ def load_library() -> C.CDLL:
         lib.evg_batcher_plan.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_char_p, C.c_int32]
         lib.evg_batcher_allocate.argtypes = [C.c_void_p, C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_char_p, C.c_int32]
         lib.evg_batcher_get_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 4)]
+        if hasattr(lib, "evg_batcher_schedule"):  # ABI 3.3
+            lib.evg_batcher_schedule.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput),
+                                                 C.POINTER(abi.AllocInput), C.POINTER(abi.AllocOutput), C.c_char_p, C.c_int32]
+            lib.evg_batcher_plan_queue.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(abi.PlanInput), C.POINTER(abi.PlanOutput), C.c_char_p, C.c_int32]
+            lib.evg_batcher_set_deadline_ms.argtypes = [C.c_void_p, C.c_int64]
+            lib.evg_batcher_close.argtypes = [C.c_void_p]
+            lib.evg_batcher_debug_stall.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+            lib.evg_batcher_get_cache_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4
+    if hasattr(lib, "evg_set_deadline_ms"):  # ABI 3.3: bounded device waits
+        lib.evg_set_deadline_ms.argtypes = [C.c_void_p, C.c_int64]
+        lib.evg_get_deadline_ms.restype = C.c_int64
+        lib.evg_get_deadline_ms.argtypes = [C.c_void_p]
+        lib.evg_debug_stall.argtypes = [C.c_void_p, C.c_int32]
+        lib.evg_multi_set_deadline_ms.argtypes = [C.c_void_p, C.c_int64]
+        lib.evg_multi_debug_stall.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     if hasattr(lib, "evg_selftest_unit_value"):  # absent from older builds loaded through EVG_SCHED_LIB (A/B runs)
         lib.evg_selftest_unit_value.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
@@ -261,6 +280,13 @@ class MultiContext:
     def abort(self) -> None:
         self._check(self.lib.evg_multi_abort(self.h), "evg_multi_abort")
 
+    def set_deadline_ms(self, ms: int) -> None:
+        self._check(self.lib.evg_multi_set_deadline_ms(self.h, ms), "evg_multi_set_deadline_ms")
+
+    def debug_stall(self, rank: int, ms: int) -> None:
+        """Test hook: a kernel that spins for `ms` milliseconds on the rank's stream (the next tick finds that device busy)."""
+        self._check(self.lib.evg_multi_debug_stall(self.h, rank, ms), "evg_multi_debug_stall")
+
     def selftest(self) -> None:
         """A generated mixed pool planned on rank 0's device alone and over all the ranks: raises unless the outputs are identical."""
         self._check(self.lib.evg_multi_selftest(self.h), "evg_multi_selftest")
@@ -321,10 +347,48 @@ class Batcher:
             raise NativeError("evg_batcher_allocate failed (%d): %s" % (rc, err.value.decode()))
         return res
 
+    def plan_queue(self, queue_id: int, generation: int, batch: abi.PlanBatch, breakdown: bool = True, n_units: bool = True, units: bool = False,
+                   into: Optional[abi.PlanResult] = None) -> abi.PlanResult:
+        """evg_batcher_plan_queue: the queue's packed columns stay on the device under (queue_id, generation)."""
+        res = into if into is not None else abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=n_units, units=units)
+        inp, out, err = abi.make_plan_input(batch), res.c_output(), C.create_string_buffer(256)
+        rc = self.lib.evg_batcher_plan_queue(self.h, queue_id, generation, C.byref(inp), C.byref(out), err, 256)
+        if rc != abi.EVG_OK:
+            raise NativeError("evg_batcher_plan_queue failed (%d): %s" % (rc, err.value.decode()))
+        return res
+
+    def schedule(self, batch: abi.PlanBatch, queue_id: int = 0, generation: int = 0, breakdown: bool = True, n_units: bool = True, units: bool = False):
+        """evg_batcher_schedule: the distro's plan and its host allocation as ONE request. Returns (PlanResult, AllocResult); the plan's
+        group_info rows come back with CountFree / CountRequired filled in."""
+        res = abi.PlanResult.alloc_host(batch, breakdown=breakdown, n_units=n_units, units=units)
+        ares = abi.AllocResult.alloc_host(batch.n_distros)
+        inp, out, err = abi.make_plan_input(batch), res.c_output(), C.create_string_buffer(256)
+        ainp, aout = abi.make_alloc_input(batch, None, None), ares.c_output()
+        rc = self.lib.evg_batcher_schedule(self.h, queue_id, generation, C.byref(inp), C.byref(out), C.byref(ainp), C.byref(aout), err, 256)
+        if rc != abi.EVG_OK:
+            raise NativeError("evg_batcher_schedule failed (%d): %s" % (rc, err.value.decode()))
+        return res, ares
+
+    def debug_stall(self, slot: int, ms: int) -> None:
+        """Test hook: batch slot `slot`'s (0..3) device stream spins for `ms` milliseconds."""
+        rc = self.lib.evg_batcher_debug_stall(self.h, slot, ms)
+        if rc != abi.EVG_OK:
+            raise NativeError("evg_batcher_debug_stall failed (%d)" % rc)
+
+    def set_deadline_ms(self, ms: int) -> None:
+        rc = self.lib.evg_batcher_set_deadline_ms(self.h, ms)
+        if rc != abi.EVG_OK:
+            raise NativeError("evg_batcher_set_deadline_ms(%d) failed (%d)" % (ms, rc))
+
     def stats(self) -> dict:
         v = (C.c_uint64 * 4)()
         self.lib.evg_batcher_get_stats(self.h, C.byref(v))
-        return {"batches": int(v[0]), "requests": int(v[1]), "direct_requests": int(v[2]), "largest_batch": int(v[3])}
+        out = {"batches": int(v[0]), "requests": int(v[1]), "direct_requests": int(v[2]), "largest_batch": int(v[3])}
+        if hasattr(self.lib, "evg_batcher_get_cache_stats"):
+            c = [C.c_uint64(0) for _ in range(4)]
+            self.lib.evg_batcher_get_cache_stats(self.h, *[C.byref(x) for x in c])
+            out.update({"cache_hits": int(c[0].value), "cache_fills": int(c[1].value), "resident_queues": int(c[2].value), "resident_bytes": int(c[3].value)})
+        return out
 
 
 class Context:
@@ -352,6 +416,17 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_deadline_ms(self, ms: int) -> None:
+        """evg_set_deadline_ms: every device wait of this context gives up after `ms` milliseconds (EVG_E_TIMEOUT, the context is poisoned)."""
+        self._check(self.lib.evg_set_deadline_ms(self.h, ms), "evg_set_deadline_ms")
+
+    def deadline_ms(self) -> int:
+        return int(self.lib.evg_get_deadline_ms(self.h))
+
+    def debug_stall(self, ms: int) -> None:
+        """Test hook: a kernel that spins for `ms` milliseconds on the context's stream."""
+        self._check(self.lib.evg_debug_stall(self.h, ms), "evg_debug_stall")
 
     def _check(self, rc: int, what: str) -> None:
         if rc != abi.EVG_OK:

@@ -55,6 +55,8 @@ extern "C" {
 #define EVG_E_NOMEM (-3)    /* device or host allocation failed                                  */
 #define EVG_E_CONTRACT (-4) /* input violates the layout contract above                          */
 #define EVG_E_NODEVICE (-5) /* no gfx950 device / HIP runtime unavailable: there is NO CPU fallback */
+#define EVG_E_TIMEOUT (-6)  /* a device wait outlived the object's deadline (ABI 3.3): the object is poisoned and refuses
+                               further work -- destroy it and create another; see evg_set_deadline_ms            */
 
 /* ---- per-distro allocator status (out_status[d]); mirrors the reference's error returns ----- */
 #define EVG_ALLOC_OK 0
@@ -370,8 +372,11 @@ const char* evg_last_error(const evg_ctx* ctx);
  * and the one-launch evg_plan_allocate[_range]_device entry points are gone -- measured no faster than the two calls for three
  * rounds); MINOR adds entry points only. */
 #define EVG_ABI_MAJOR 3
-#define EVG_ABI_MINOR 2 /* 3.1: the evg_multi_* entry points (several devices from one process) and evg_balanced_ranges;
-                           3.2: the evg_batcher_* entry points (micro-batching front for per-distro callers) */
+#define EVG_ABI_MINOR 3 /* 3.1: the evg_multi_* entry points (several devices from one process) and evg_balanced_ranges;
+                           3.2: the evg_batcher_* entry points (micro-batching front for per-distro callers);
+                           3.3: bounded device waits (EVG_E_TIMEOUT, evg_set_deadline_ms, evg_multi_set_deadline_ms,
+                                evg_batcher_set_deadline_ms), evg_batcher_schedule / _plan_queue / _close (pair requests, resident
+                                queues), evg_pool_tick (the fused resident tick) */
 int32_t evg_abi_version(void);
 /* What a binding calls once at start-up with ITS compile-time view of the header: EVG_OK iff the library's major equals
  * `major`, its minor is at least `minor`, and the four struct sizes are the library's. A binding must refuse the library
@@ -386,6 +391,21 @@ int evg_check_abi(int32_t major, int32_t minor, size_t sizeof_plan_input, size_t
  * recorded one, and clears it; EVG_OK otherwise. Every later entry point on the context fails with EVG_E_CONTRACT too until
  * the status is taken. A caller that passes promises calls this after it synchronised the stream, before it uses the plan. */
 int evg_take_device_status(evg_ctx* ctx);
+
+/* Bounded calls (ABI 3.3). A cgo call pins its OS thread until it returns, and the reference bounds its own jobs (the distro
+ * scheduler job: 5 min, units/scheduler.go:18; the host allocator job: 10 min, units/host_allocator.go:32). Every wait of the
+ * library on the device -- each synchronous entry point ends in one -- polls the stream against a monotonic clock: when the
+ * device has not finished after `ms` milliseconds the call returns EVG_E_TIMEOUT, the context is POISONED (its buffers may still
+ * be in use by whatever hangs) and every later entry point on it fails with EVG_E_TIMEOUT at once; evg_destroy then waits once
+ * more and, if the device still has not come back, leaks the context's device memory instead of blocking. A caller's job fails
+ * and runs again on the next 15 s tick on a fresh context instead of holding a thread for ever.
+ * Default: 30,000 ms (EVG_DEADLINE_MS in the environment overrides it at evg_create); 0 = wait without a limit. The *_device
+ * entry points only enqueue: their caller owns the wait. */
+int evg_set_deadline_ms(evg_ctx* ctx, int64_t ms);
+int64_t evg_get_deadline_ms(const evg_ctx* ctx);
+/* Test hook for the deadline: enqueues, on the context's own stream, a kernel that spins for `ms` milliseconds of device wall
+ * clock (at most 20,000) -- the next synchronous call on the context finds the device busy for that long. */
+int evg_debug_stall(evg_ctx* ctx, int32_t ms);
 
 /* Host-side check of the layout contract; no GPU work. */
 int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len);
@@ -709,6 +729,12 @@ int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* delta, const evg_a
 int evg_multi_inject_failure(evg_multi* m, int32_t rank, int32_t phase);
 int evg_multi_abort(evg_multi* m);
 int evg_multi_selftest(evg_multi* m);
+/* ABI 3.3: the deadline of every device wait of the object and of its ranks' contexts (default 30,000 ms / EVG_DEADLINE_MS; 0 = no
+ * limit; see evg_set_deadline_ms). A wait that outlives it -- a hung collective, a lost peer -- aborts the communicators (what
+ * evg_multi_abort does from another thread), returns EVG_E_TIMEOUT, and the object refuses further work: destroy it and create
+ * another (shim/gpu_multi.go then goes on with one device). evg_multi_debug_stall is the test hook (evg_debug_stall on one rank). */
+int evg_multi_set_deadline_ms(evg_multi* m, int64_t ms);
+int evg_multi_debug_stall(evg_multi* m, int32_t rank, int32_t ms);
 
 /* Host only: the contiguous distro ranges `world` ranks plan, minimising the largest rank COST (a distro is never split: a rank's
  * results must be contiguous slices of the full-size outputs). Cost of a distro = tasks on the two-per-CU tier of the one-workgroup
@@ -744,6 +770,39 @@ void evg_batcher_destroy(evg_batcher* b);
 int evg_batcher_plan(evg_batcher* b, const evg_plan_input* in, const evg_plan_output* out, char* err, int32_t err_len);
 int evg_batcher_allocate(evg_batcher* b, const evg_alloc_input* in, const evg_alloc_output* out, char* err, int32_t err_len);
 int evg_batcher_get_stats(evg_batcher* b, evg_batcher_stats* stats);
+
+/* ---- ABI 3.3 ----
+ * evg_batcher_schedule: a distro's plan AND its host allocation as ONE request (scheduler.PlanDistro's planning phase,
+ * scheduler/scheduler.go:28-52, and the allocator job's call for the same distro, units/host_allocator.go:183-188): the allocator
+ * reads the plan's DistroQueueInfo rows where the planner left them on the device -- one round trip where evg_batcher_plan +
+ * evg_batcher_allocate make two. `alloc_in` covers the same distros and task-group keys as `in` (same tg_off); its distro_info /
+ * group_info are ignored (may be NULL). Results are those of the two calls in sequence; out->group_info comes back as
+ * evg_batcher_allocate would leave the caller's copy (CountFree / CountRequired filled in).
+ *
+ * Resident queues: `queue_id` != 0 names the caller's queue (any stable 64-bit name of the distro) and `generation` its content
+ * (anything that changes whenever ANY field of `in` other than now_ns changes: a counter the caller bumps on every change of the
+ * queue, or a hash). The first request of a (queue_id, generation) travels whole and leaves its packed columns in a device-side
+ * cache (EVG_BATCHER_CACHE_BYTES, default 1 GiB, least-recently-used queues evicted); a later request with the same pair --
+ * the same queue 15 s later, a new clock (units/crons_remote_fifteen_second.go:21) -- skips the host-side contract check and
+ * uploads its clock reading only. A request whose sizes differ from the resident generation's is refused (EVG_E_CONTRACT); a
+ * caller that changes the queue without changing the generation gets the plan of the resident content. queue_id 0 = no cache
+ * (evg_batcher_plan). evg_batcher_plan_queue is evg_batcher_plan with the two words.
+ *
+ * evg_batcher_set_deadline_ms: the deadline of every batch's device wait (default 30,000 ms / EVG_DEADLINE_MS; see
+ * evg_set_deadline_ms). A batch that outlives it fails its members with EVG_E_TIMEOUT and RETIRES its slot (of four); with no slot
+ * left every request fails with EVG_E_TIMEOUT: destroy the batcher and create another. Only between batches (EVG_E_INVALID
+ * otherwise).
+ * evg_batcher_close: refuses new requests, lets the batches in flight finish and returns when the last caller has left; the object
+ * stays valid (and refusing) until evg_batcher_destroy, which a caller that cannot rule out concurrent callers calls after it has
+ * joined them. (evg_batcher_destroy closes first; no call may START once it has returned.) */
+int evg_batcher_schedule(evg_batcher* b, uint64_t queue_id, uint64_t generation, const evg_plan_input* in, const evg_plan_output* out,
+                         const evg_alloc_input* alloc_in, const evg_alloc_output* alloc_out, char* err, int32_t err_len);
+int evg_batcher_plan_queue(evg_batcher* b, uint64_t queue_id, uint64_t generation, const evg_plan_input* in, const evg_plan_output* out,
+                           char* err, int32_t err_len);
+int evg_batcher_set_deadline_ms(evg_batcher* b, int64_t ms);
+void evg_batcher_close(evg_batcher* b);
+int evg_batcher_debug_stall(evg_batcher* b, int32_t slot, int32_t ms); /* test hook: evg_debug_stall on batch slot 0..3's context */
+int evg_batcher_get_cache_stats(evg_batcher* b, uint64_t* hits, uint64_t* fills, uint64_t* resident_queues, uint64_t* resident_bytes);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,132 @@
+"""Bounded calls (ABI 3.3): a cgo call pins its OS thread, and the reference bounds its own jobs (the distro scheduler
+job 5 min, units/scheduler.go:18; the host allocator job 10 min, units/host_allocator.go:32). Every device wait of the library polls
+against a deadline; on expiry the call returns EVG_E_TIMEOUT, the object is poisoned and refuses further work, and destroying it does not
+block either. Test hook: evg_debug_stall -- a kernel that spins for a given time on the object's own stream."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from evergreen_amd import abi, gen
+from tests import compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from evergreen_amd import native as n
+    return n
+
+
+def test_single_device_call_gives_up_and_the_context_is_poisoned(native, oracle):
+    batch = gen.generate(gen.config(1))
+    ctx = native.Context(0)
+    assert ctx.deadline_ms() == 30000
+    ctx.set_deadline_ms(300)
+    ctx.debug_stall(1500)
+    t0 = time.perf_counter()
+    with pytest.raises(native.NativeError, match=r"\(%d\).*did not finish within 300 ms" % abi.EVG_E_TIMEOUT):
+        ctx.plan(batch)
+    dt = time.perf_counter() - t0
+    assert 0.25 < dt < 1.2, dt  # the deadline, not the stall
+    with pytest.raises(native.NativeError, match=r"\(%d\).*refuses further work" % abi.EVG_E_TIMEOUT):
+        ctx.plan(batch)
+    with pytest.raises(native.NativeError, match="refuses further work"):
+        ctx.allocate(batch, np.zeros(batch.n_distros, abi.DISTRO_INFO_DTYPE), np.zeros(batch.n_distros + batch.n_task_groups, abi.GROUP_INFO_DTYPE))
+    t1 = time.perf_counter()
+    ctx.close()  # one more bounded wait (the stall ends inside it), then everything is freed
+    assert time.perf_counter() - t1 < 2.0
+    fresh = native.Context(0)  # what the caller does next: a new context; the device is fine
+    try:
+        got, want = fresh.plan(batch), oracle.plan(batch)
+        compare.assert_plan_equal(got, want, batch, "a fresh context after a timed-out one")
+    finally:
+        fresh.close()
+
+
+def test_a_stall_inside_the_deadline_is_just_slow(native, oracle):
+    batch = gen.generate(gen.config(1))
+    ctx = native.Context(0)
+    try:
+        ctx.set_deadline_ms(5000)
+        ctx.debug_stall(400)
+        t0 = time.perf_counter()
+        got = ctx.plan(batch)
+        assert time.perf_counter() - t0 > 0.35
+        compare.assert_plan_equal(got, oracle.plan(batch), batch, "behind a stall")
+        ctx.set_deadline_ms(0)  # no limit: plain hipStreamSynchronize
+        ctx.debug_stall(200)
+        compare.assert_plan_equal(ctx.plan(batch), oracle.plan(batch), batch, "no deadline")
+    finally:
+        ctx.close()
+
+
+def test_destroy_of_a_context_whose_device_never_came_back_does_not_block(native):
+    batch = gen.generate(gen.config(1))
+    ctx = native.Context(0)
+    ctx.set_deadline_ms(200)
+    ctx.debug_stall(6000)
+    with pytest.raises(native.NativeError, match="did not finish"):
+        ctx.plan(batch)
+    t0 = time.perf_counter()
+    ctx.close()  # waits its 200 ms once more, then leaks the context's device memory instead of waiting for the 6 s
+    assert time.perf_counter() - t0 < 1.5
+    time.sleep(6.0)  # let the stall end before the next test uses the device
+
+
+def test_batcher_slot_that_times_out_fails_its_members_and_is_retired(native, oracle):
+    batch = gen.generate(gen.config(2))
+    subs = [batch.one_distro(d) for d in range(16)]
+    b = native.Batcher(0, max_wait_us=500, max_requests=4)
+    try:
+        b.set_deadline_ms(300)
+        b.debug_stall(0, 1500)  # whichever batch lands on slot 0 outlives the deadline
+        res = [None] * len(subs)
+
+        def work(i):
+            try:
+                res[i] = b.plan(subs[i], breakdown=False, n_units=False)
+            except native.NativeError as e:
+                res[i] = e
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(subs))]
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert time.perf_counter() - t0 < 3.0
+        timed_out = [r for r in res if isinstance(r, native.NativeError)]
+        assert 1 <= len(timed_out) <= 4, res  # the members of ONE batch (at most max_requests)
+        assert all("(%d)" % abi.EVG_E_TIMEOUT in str(e) and "did not finish" in str(e) for e in timed_out), timed_out
+        for s, r in zip(subs, res):
+            if not isinstance(r, native.NativeError):
+                want = oracle.plan(s, breakdown=False, n_units=False)
+                want.breakdown = None; want.n_units = None
+                compare.assert_plan_equal(r, want, s, "a batch beside the one that timed out")
+        # the batcher goes on with three slots
+        for s in subs[:6]:
+            want = oracle.plan(s, breakdown=False, n_units=False)
+            want.breakdown = None; want.n_units = None
+            compare.assert_plan_equal(b.plan(s, breakdown=False, n_units=False), want, s, "after a slot was retired")
+        time.sleep(1.3)  # the stall ends before the batcher is destroyed: nothing is leaked
+    finally:
+        b.close()
+
+
+def test_multi_device_tick_that_times_out_aborts_and_refuses(native):
+    batch = gen.generate(gen.config(1))
+    m = native.MultiContext([0, 0, 0], loopback=True)
+    try:
+        m.load(batch)
+        m.tick()
+        m.set_deadline_ms(300)
+        m.debug_stall(1, 1500)
+        t0 = time.perf_counter()
+        with pytest.raises(native.NativeError, match=r"\(%d\).*rank 1.*did not finish within 300 ms" % abi.EVG_E_TIMEOUT):
+            m.tick()
+        assert time.perf_counter() - t0 < 3.5
+        with pytest.raises(native.NativeError, match="destroy this evg_multi"):
+            m.tick()
+        time.sleep(1.3)
+    finally:
+        m.close()

@@ -264,3 +264,36 @@ def test_resident_shards_selftest_and_failed_ticks(oracle):
         _check(m, pool1, want, want_alloc, "resident shards, a delta after failed ticks")
     finally:
         m.close()
+
+
+def test_resident_shards_refuse_a_dependency_on_another_ranks_row_and_a_broken_dep_off():
+    """an added row's dependency on a CURRENT row of a lower rank's range used to be re-based to a negative number and read as
+    "not in the queue" / as an added row; a non-monotone added.dep_off sized a vector from a negative difference. Both are refused now, the
+    first by the device (what evg_pool_apply_delta on one pool says about an edge across distros), the second before anything is sized."""
+    from tests import pool_delta
+    full = gen.generate(gen.GenConfig(12_000, 9, gen.SEED_BASE + 95, tg_fraction=0.2, dag_depth=4))
+    pool0, delta, _, _ = pool_delta.split_tick(full, 0.03, 0.03, seed=7, grow_keys=True)
+    m = native.MultiContext([0] * 3, units=True, loopback=True, resident=True)
+    try:
+        m.load(pool0)
+        ranges = m.ranges()
+        # an added row of the LAST rank's range with an edge: point it at row 0 (rank 0's range)
+        ad_distro = np.asarray(delta.added_distro)
+        last_lo = ranges[-1][0]
+        rows = np.nonzero((ad_distro >= last_lo) & (np.diff(delta.added_dep_off) > 0))[0]
+        assert len(rows), "the delta holds no added row with a dependency on the last rank"
+        bad = dict(delta.kwargs())
+        edges = {k: (None if v is None else v.copy()) for k, v in delta.added_edges.items()}
+        edges["dep_idx"][delta.added_dep_off[rows[0]]] = 0
+        bad["added_edges"] = edges
+        with pytest.raises(native.NativeError, match="added edge"):
+            m.apply_delta(pool0, **bad)
+        bad = dict(delta.kwargs())
+        off = delta.added_dep_off.copy()
+        if len(off) > 3:
+            off[1], off[2] = off[2] + 5, off[1]  # decreases
+        bad["added_dep_off"] = off
+        with pytest.raises(native.NativeError, match="dep_off"):
+            m.apply_delta(pool0, **bad)
+    finally:
+        m.close()
