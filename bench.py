@@ -182,6 +182,54 @@ def per_distro_calls(batch, native, got, got_alloc, dev_index):
             out["batcher_threads_%d_no_unit_rows" % nt] = {"wall_ms": wall * 1e3, "tasks_per_s": batch.n_tasks / wall,
                                                             "us_per_call_pair_p50": float(xs[len(xs) // 2]) * 1e6, "us_per_call_pair_p99": float(xs[int(len(xs) * 0.99)]) * 1e6,
                                                             "errors": int(errs), "requests_per_batch": st["requests"] / max(1, st["batches"])}
+        # ---- ABI 3.3: the pair as ONE request (evg_batcher_schedule), and RESIDENT QUEUES: the same 512 queues a tick later travel as
+        # clock readings. cold = every queue uploaded (and left on the device); warm = the same generation again; 90 % warm = every
+        # tenth queue changed (a new generation). With and without SortingValueBreakdown rows in the results.
+        if hasattr(lib, "evg_batcher_schedule"):
+            drv.pdc_run_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64] + [C.c_void_p, C.c_size_t] * 4 + [C.c_void_p, C.c_void_p]
+            f_sched = C.cast(lib.evg_batcher_schedule, C.c_void_p)
+            a_ain_pair = (abi.AllocInput * D)(*[abi.make_alloc_input(b, None, None) for b in subs])
+
+            def pairs(pout_arr, nt, queue_base, gens):
+                lat = np.zeros(D, np.float64)
+                wall = C.c_double(0)
+                errs = drv.pdc_run_pairs(f_sched, bt.h, nt, D, queue_base, gens, C.addressof(a_pin), C.sizeof(abi.PlanInput), C.addressof(pout_arr),
+                                         C.sizeof(abi.PlanOutput), C.addressof(a_ain_pair), C.sizeof(abi.AllocInput), C.addressof(a_aout), C.sizeof(abi.AllocOutput),
+                                         lat.ctypes.data, C.byref(wall))
+                return wall.value, int(errs)
+            for tag, pout_arr, rr in (("pairs_threads_64", a_pout, res), ("pairs_threads_64_no_unit_rows", a_pout_lean, res_lean)):
+                for r in rr:
+                    r.order[:] = -1
+                bt = native.Batcher(dev_index, max_wait_us=200, max_requests=64)
+                try:
+                    for _ in range(3):
+                        pairs(pout_arr, 64, 0, 0)  # warm-up: the slots' page-locked blocks and arenas reach their size
+                    plain = sorted(pairs(pout_arr, 64, 0, 0) for _ in range(3))[1]
+                    cold = []
+                    for k in range(3):  # a cold tick = a generation nobody has seen
+                        cold.append(pairs(pout_arr, 64, 1 << 20, 100 + k))
+                    warm = sorted(pairs(pout_arr, 64, 1 << 20, 102) for _ in range(3))[1]
+                    # ... and with as many callers as the reference has distro jobs in flight when its worker pool allows it
+                    more = {}
+                    for nt in (256, 512):
+                        pairs(pout_arr, nt, 1 << 20, 102)
+                        more["resident_queues_threads_%d_wall_ms" % nt] = sorted(pairs(pout_arr, nt, 1 << 20, 102) for _ in range(3))[1][0]
+                    st = bt.stats()
+                    same = True
+                    for d in range(D):
+                        lo, hi = int(batch.task_off[d]), int(batch.task_off[d + 1])
+                        same &= bool(np.array_equal(rr[d].order + lo, got.order[lo:hi]) and np.array_equal(rr[d].wait_ns, got.wait_ns[lo:hi]))
+                        if got_alloc is not None:
+                            same &= bool(ares[d].new_hosts[0] == got_alloc.new_hosts[d] and ares[d].free_hosts[0] == got_alloc.free_hosts[d])
+                finally:
+                    bt.close()
+                out[tag] = {"wall_ms": plain[0], "errors": plain[1], "cold_queues_wall_ms": sorted(cold)[1][0], "resident_queues_wall_ms": warm[0],
+                            "cache_hits": st.get("cache_hits"), "cache_fills": st.get("cache_fills"), "resident_bytes": st.get("resident_bytes"),
+                            "requests_per_batch": st["requests"] / max(1, st["batches"]), "identical_to_the_batched_tick": same}
+                out[tag].update(more)
+            out["pairs"] = ("evg_batcher_schedule from 64 native threads, one request per distro (plan + allocate): wall_ms = no queue ids; cold_queues = every "
+                            "queue named and uploaded (left resident on the device); resident_queues = the same generation again: the requests upload "
+                            "their clock readings only. Median of 3 runs each")
         out["batcher"] = ("evg_batcher_plan + evg_batcher_allocate on one shared batcher (max_wait_us 200, max_requests 64), median wall of 3 runs; what bounds "
                           "it: 1 M tasks are 84.6 MB in and 14.7 MB (+ 111 MB of unit rows) out over the host link, ~45 GB/s")
     try:
@@ -240,11 +288,38 @@ def delta_tick(batch, native, dev_index, got):
                                  np.array_equal(full.distro_info, res.distro_info) and np.array_equal(full.group_info, res.group_info))
             bytes_in = delta.bytes_in() + k * (4 + 8 + 8)
             rows_info = {"removed": int(len(gone)), "added": int(len(late)), "values_changed": int(k), "relinked_edges": int(len(delta.relinked_edges))}
+        # ---- the same ticks as ONE call (evg_pool_tick, ABI 3.3): delta + updates + plan + download behind one synchronisation ----
+        t_fused, same_fused = [], None
+        if hasattr(ctx.lib, "evg_pool_tick"):
+            same_fused = True
+            for tick in range(3):
+                pool0, delta, late, gone = pool_delta.split_tick(batch, 0.025, 0.025, seed=100 + tick)
+                pool1 = pool_delta.apply_delta(pool0, delta)
+                n1 = pool1.n_tasks
+                k = n1 // 20
+                rows = np.sort(rng.choice(n1, k, replace=False)).astype(np.int32)
+                pri = rng.integers(0, 100, k).astype(np.int64)
+                dur = (rng.integers(10, 14_000, k) * 10**9).astype(np.int64)
+                now = batch.now_ns + 15 * 10**9
+                ctx.pool_load(ctx.pinned_batch(pool0))
+                res = ctx.pinned_result(abi.PlanResult.alloc_host(pool1, breakdown=False, n_units=False))
+                blk, keep = ctx.make_pool_delta(**delta.kwargs())
+                upd = ctx.make_pool_update(rows, {"priority": pri, "expected_duration_ns": dur})
+                t0 = time.perf_counter()
+                ctx.pool_tick(pool1, now, delta=blk, update=upd, into=res)
+                t_fused.append(time.perf_counter() - t0)
+                pool1.cols["priority"][rows], pool1.cols["expected_duration_ns"][rows] = pri, dur
+                pool1.now_ns = now
+                full = ctx.plan(pool1, breakdown=False, n_units=False)
+                same_fused = same_fused and bool(np.array_equal(full.order, res.order) and np.array_equal(full.wait_ns, res.wait_ns) and
+                                                 np.array_equal(full.distro_info, res.distro_info) and np.array_equal(full.group_info, res.group_info))
         med = lambda xs: sorted(xs)[len(xs) // 2]  # noqa: E731
         ms = (med(t_delta) + med(t_upd) + med(t_plan)) * 1e3
         return {"value": batch.n_tasks / (ms * 1e-3), "unit": "tasks/s", "ms_per_tick": ms, "apply_delta_ms": med(t_delta) * 1e3, "update_ms": med(t_upd) * 1e3,
                 "plan_and_download_ms": med(t_plan) * 1e3, "rows_per_tick": rows_info, "bytes_in_per_tick": int(bytes_in),
                 "identical_to_full_upload": same,
+                "fused": None if not t_fused else {"ms_per_tick": med(t_fused) * 1e3, "value": batch.n_tasks / med(t_fused), "unit": "tasks/s", "identical_to_full_upload": same_fused,
+                                                   "what": "the same tick as ONE call: evg_pool_tick (delta + updates + plan + download, one synchronisation)"},
                 "what": "per tick: evg_pool_apply_delta (2.5 % of the rows removed, 2.5 % added, the dependents' edges relinked: re-packed on the "
                         "device) + evg_pool_update (5 % of the rows: new priority + expected duration) + evg_pool_plan (new now_ns; order / "
                         "deps_met / wait / info rows downloaded into page-locked buffers); host wall clock, median of three ticks"}

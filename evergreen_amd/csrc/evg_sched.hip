@@ -448,6 +448,8 @@ struct evg_ctx {
   // evg_pool_apply_delta re-packs into the second set and swaps; what the host must remember of the pool to cut a delta
   std::vector<DevBuf> pool_alt = std::vector<DevBuf>(20);
   std::vector<int32_t> pool_task_off, pool_tg_off, pool_ver_off;
+  std::vector<int32_t> pool_ecut;  // edge offset at every distro boundary (D + 1): the shape test of the launch hints needs the edges per distro
+  std::vector<DevBuf> tick_out = std::vector<DevBuf>(8);  // evg_pool_tick's output blocks
   std::vector<uint8_t> pool_gv;   // PlannerSettings.ShouldGroupVersions() per distro (the shape test of the launch hints)
   bool pool_pri_wide = false;     // some priority does not fit int32: no distro-shape promise holds
   std::vector<uint64_t> seen_bits;  // evg_pool_update's duplicate check: one bit per row / edge
@@ -1638,6 +1640,7 @@ int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
   if (D == 0) {  // an empty pool: evg_validate_plan_input accepts NULL offset tables for it (so does evg_multi_load); nothing to remember
     c->pool_task_off.assign(1, 0); c->pool_tg_off.assign(1, 0); c->pool_ver_off.assign(1, 0);
     c->pool_gv.clear();
+    c->pool_ecut.assign(1, 0);
     c->pool_pri_wide = false;
     if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
     c->pool_in = di;
@@ -1649,11 +1652,82 @@ int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
   c->pool_ver_off.assign(in->ver_off, in->ver_off + D + 1);
   c->pool_gv.resize(D);
   for (size_t d = 0; d < D; d++) c->pool_gv[d] = in->distros[d].group_versions != 0;
+  c->pool_ecut.assign(D + 1, 0);
+  for (size_t d = 0; d <= D; d++) c->pool_ecut[d] = N ? t.dep_off[in->task_off[d]] : 0;
   c->pool_pri_wide = false;
   for (size_t r = 0; r < N && !c->pool_pri_wide; r++) c->pool_pri_wide = t.priority[r] != (int64_t)(int32_t)t.priority[r];
   if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   c->pool_in = di;
   c->pool_loaded = true;
+  return EVG_OK;
+}
+
+// ---- evg_pool_update, in pieces (evg_pool_tick enqueues them between a delta and a plan) -----------------------------------------
+// The host's share of the contract: ranges against (n_tasks, n_edges_bound), distinct rows / edges. *wide: a priority beyond int32.
+static int update_check(evg_ctx* c, const evg_row_update* ru, const evg_edge_update* eu, int n_tasks, long long n_edges_bound, bool has_fin, bool has_info, bool* wide) {
+  const int nr = ru ? ru->n_rows : 0, ne = eu ? eu->n_edges : 0;
+  if (nr < 0 || ne < 0 || (nr > 0 && !ru->rows) || (ne > 0 && !eu->edges)) return set_err(c, EVG_E_INVALID, "evg_pool_update: null or negative");
+  for (int i = 0; i < nr; i++) {
+    if (ru->rows[i] < 0 || ru->rows[i] >= n_tasks) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: row %d is outside the pool", ru->rows[i]);
+    // a priority beyond int32 takes the distro off the one-workgroup path: the promise made at load time no longer holds
+    if (ru->priority && ru->priority[i] != (int64_t)(int32_t)ru->priority[i]) *wide = true;  // (n_big_tier_distros is a hint: it may overstate)
+  }
+  for (int i = 0; i < ne; i++)
+    if (eu->edges[i] < 0 || eu->edges[i] >= n_edges_bound) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: edge %d is outside the pool", eu->edges[i]);
+  if (ne > 0 && eu->dep_finished_ts_ns && !has_fin) return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_finished_ts_ns");
+  if (ne > 0 && eu->dep_info && !has_info)  // (k_update_edges would write through a null device pointer)
+    return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_info");
+  // `distinct`: a row / edge listed twice would take whichever of its two values the device wrote last. One bit per row / edge
+  // of the pool (125 KB for a million rows; sorting the 50,000 rows of a 5 % update cost 0.2 ms of the tick's 0.7)
+  auto dup = [&](const int32_t* v, int n, long long range) {
+    c->seen_bits.assign((size_t)range / 64 + 1, 0ull);
+    for (int i = 0; i < n; i++) {
+      uint64_t& w = c->seen_bits[(size_t)v[i] >> 6];
+      const uint64_t bit = 1ull << (v[i] & 63);
+      if (w & bit) return true;
+      w |= bit;
+    }
+    return false;
+  };
+  if (nr > 1 && dup(ru->rows, nr, n_tasks)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: a row is listed twice");
+  if (ne > 1 && dup(eu->edges, ne, n_edges_bound)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: an edge is listed twice");
+  return EVG_OK;
+}
+static size_t update_in_bytes(const evg_row_update* ru, const evg_edge_update* eu) {
+  const size_t nr = ru ? (size_t)ru->n_rows : 0, ne = eu ? (size_t)eu->n_edges : 0;
+  return nr * (4 + 5 * 8 + 4 + 2) + ne * (4 + 1 + 8) + 16 * 256;
+}
+struct UpdateFlight {
+  int nr = 0, ne = 0;
+  const int32_t* d_rows = nullptr;
+  evg::RowCols src{};
+  const int32_t* d_edges = nullptr;
+  const uint8_t* d_info = nullptr;
+  const int64_t* d_fin = nullptr;
+};
+static void update_up(Stager& s, const evg_row_update* ru, const evg_edge_update* eu, UpdateFlight& u) {  // the new values into the staging block
+  u.nr = ru ? ru->n_rows : 0; u.ne = eu ? eu->n_edges : 0;
+  if (u.nr > 0) {
+    const size_t nr = (size_t)u.nr;
+    u.d_rows = s.up(ru->rows, nr);
+    u.src = evg::RowCols{(int64_t*)s.up(ru->priority, nr), (int64_t*)s.up(ru->expected_duration_ns, nr), (int64_t*)s.up(ru->queue_ts_ns, nr),
+                         (int64_t*)s.up(ru->scheduled_ts_ns, nr), (int64_t*)s.up(ru->deps_met_ts_ns, nr), (int32_t*)s.up(ru->num_dependents, nr),
+                         (uint16_t*)s.up(ru->flags, nr)};
+  }
+  if (u.ne > 0) {
+    const size_t ne = (size_t)u.ne;
+    u.d_edges = s.up(eu->edges, ne); u.d_info = s.up(eu->dep_info, ne); u.d_fin = s.up(eu->dep_finished_ts_ns, ne);
+  }
+}
+static int update_enqueue(evg_ctx* c, const evg_task_soa& t, const UpdateFlight& u, hipStream_t st) {  // onto the columns `t` points at
+  if (u.nr > 0) {
+    evg::RowCols dst{(int64_t*)t.priority, (int64_t*)t.expected_duration_ns, (int64_t*)t.queue_ts_ns, (int64_t*)t.scheduled_ts_ns,
+                     (int64_t*)t.deps_met_ts_ns, (int32_t*)t.num_dependents, (uint16_t*)t.flags};
+    hipLaunchKernelGGL(evg::k_update_rows, dim3((u.nr + 255) / 256), dim3(256), 0, st, u.nr, u.d_rows, dst, u.src);
+  }
+  if (u.ne > 0)
+    hipLaunchKernelGGL(evg::k_update_edges, dim3((u.ne + 255) / 256), dim3(256), 0, st, u.ne, u.d_edges, (uint8_t*)t.dep_info, (int64_t*)t.dep_finished_ts_ns, u.d_info, u.d_fin);
+  HIP_TRY(c, hipGetLastError());
   return EVG_OK;
 }
 
@@ -1664,72 +1738,24 @@ int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update*
   if (int rc = pending_status(c)) return rc;
   if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_update: no pool is loaded on this context");
   const evg_plan_input& p = c->pool_in;
-  const int nr = ru ? ru->n_rows : 0, ne = eu ? eu->n_edges : 0;
-  if (nr < 0 || ne < 0 || (nr > 0 && !ru->rows) || (ne > 0 && !eu->edges)) return set_err(c, EVG_E_INVALID, "evg_pool_update: null or negative");
-  for (int i = 0; i < nr; i++) {
-    if (ru->rows[i] < 0 || ru->rows[i] >= p.tasks.n_tasks) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: row %d is outside the pool", ru->rows[i]);
-    // a priority beyond int32 takes the distro off the one-workgroup path: the promise made at load time no longer holds
-    if (ru->priority && ru->priority[i] != (int64_t)(int32_t)ru->priority[i]) {  // (n_big_tier_distros is a hint: it may overstate)
-      c->pool_in.promises &= ~(EVG_PROMISE_ALL_ON_LDS_PATH | EVG_PROMISE_ALL_ON_LDS_TIERS);
-      c->pool_pri_wide = true;
-    }
+  bool wide = false;
+  if (int rc = update_check(c, ru, eu, p.tasks.n_tasks, p.tasks.n_edges, p.tasks.dep_finished_ts_ns != nullptr, p.tasks.dep_info != nullptr, &wide)) return rc;
+  if (wide) {
+    c->pool_in.promises &= ~(EVG_PROMISE_ALL_ON_LDS_PATH | EVG_PROMISE_ALL_ON_LDS_TIERS);
+    c->pool_pri_wide = true;
   }
-  for (int i = 0; i < ne; i++)
-    if (eu->edges[i] < 0 || eu->edges[i] >= p.tasks.n_edges) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: edge %d is outside the pool", eu->edges[i]);
-  if (ne > 0 && eu->dep_finished_ts_ns && !p.tasks.dep_finished_ts_ns)
-    return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_finished_ts_ns");
-  if (ne > 0 && eu->dep_info && !p.tasks.dep_info)  // (k_update_edges would write through a null device pointer)
-    return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_info");
-  {  // `distinct`: a row / edge listed twice would take whichever of its two values the device wrote last. One bit per row / edge
-     // of the pool (125 KB for a million rows; sorting the 50,000 rows of a 5 % update cost 0.2 ms of the tick's 0.7)
-    auto dup = [&](const int32_t* v, int n, int range) {
-      c->seen_bits.assign((size_t)range / 64 + 1, 0ull);
-      for (int i = 0; i < n; i++) {
-        uint64_t& w = c->seen_bits[(size_t)v[i] >> 6];
-        const uint64_t bit = 1ull << (v[i] & 63);
-        if (w & bit) return true;
-        w |= bit;
-      }
-      return false;
-    };
-    if (nr > 1 && dup(ru->rows, nr, p.tasks.n_tasks)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: a row is listed twice");
-    if (ne > 1 && dup(eu->edges, ne, p.tasks.n_edges)) return set_err(c, EVG_E_CONTRACT, "evg_pool_update: an edge is listed twice");
-  }
-  if (nr == 0 && ne == 0) return EVG_OK;
+  if ((!ru || ru->n_rows == 0) && (!eu || eu->n_edges == 0)) return EVG_OK;
   StreamDrain drain{c};
   Stager s{c};
-  const size_t in_bytes = (size_t)nr * (4 + 5 * 8 + 4 + 2) + (size_t)ne * (4 + 1 + 8) + 16 * 256;
+  const size_t in_bytes = update_in_bytes(ru, eu);
   if (in_bytes <= kPackLimit)
     if (int rc = s.begin_packed(in_bytes, 256)) return rc;
-  if (nr > 0) {
-    const int32_t* d_rows = s.up(ru->rows, nr);
-    evg::RowCols src{(int64_t*)s.up(ru->priority, nr), (int64_t*)s.up(ru->expected_duration_ns, nr), (int64_t*)s.up(ru->queue_ts_ns, nr),
-                     (int64_t*)s.up(ru->scheduled_ts_ns, nr), (int64_t*)s.up(ru->deps_met_ts_ns, nr), (int32_t*)s.up(ru->num_dependents, nr),
-                     (uint16_t*)s.up(ru->flags, nr)};
-    if (s.rc) return s.rc;
-    if (s.flush_in()) return s.rc;
-    const evg_task_soa& t = p.tasks;
-    evg::RowCols dst{(int64_t*)t.priority, (int64_t*)t.expected_duration_ns, (int64_t*)t.queue_ts_ns, (int64_t*)t.scheduled_ts_ns,
-                     (int64_t*)t.deps_met_ts_ns, (int32_t*)t.num_dependents, (uint16_t*)t.flags};
-    hipLaunchKernelGGL(evg::k_update_rows, dim3((nr + 255) / 256), dim3(256), 0, c->stream, nr, d_rows, dst, src);
-    HIP_TRY(c, hipGetLastError());
-    if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;  // the packed block is re-used below
-  }
-  if (ne > 0) {
-    Stager s2{c};
-    if (in_bytes <= kPackLimit)
-      if (int rc = s2.begin_packed(in_bytes, 256)) return rc;
-    const int32_t* d_edges = s2.up(eu->edges, ne);
-    const uint8_t* d_info = s2.up(eu->dep_info, ne);
-    const int64_t* d_fin = s2.up(eu->dep_finished_ts_ns, ne);
-    if (s2.rc) return s2.rc;
-    if (s2.flush_in()) return s2.rc;
-    hipLaunchKernelGGL(evg::k_update_edges, dim3((ne + 255) / 256), dim3(256), 0, c->stream, ne, d_edges, (uint8_t*)p.tasks.dep_info,
-                       (int64_t*)p.tasks.dep_finished_ts_ns, d_info, d_fin);
-    HIP_TRY(c, hipGetLastError());
-  }
-  if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
-  return EVG_OK;
+  UpdateFlight u;
+  update_up(s, ru, eu, u);  // rows and edges in ONE block, one copy (two blocks with a wait between them until round 6)
+  if (s.rc) return s.rc;
+  if (s.flush_in()) return s.rc;
+  if (int rc = update_enqueue(c, p.tasks, u, c->stream)) return rc;
+  return wait_stream(c, c->stream, __func__);
 }
 
 int evg_pool_plan(evg_ctx* c, int64_t now_ns, const evg_plan_output* out) {
@@ -1781,29 +1807,79 @@ int evg_pool_plan(evg_ctx* c, int64_t now_ns, const evg_plan_output* out) {
   return s.finish();
 }
 
-// A tick's structural change applied to the resident pool on the device (evg_pool_delta.hip.h): see include/evg_sched.h.
-int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
+// The launch hints of a resident pool from its shape (evg_plan_launch_hints's test without the columns): task_off / tg_off / ver_off are
+// HOST tables, ne[d] = the distro's dependency edges or an upper bound of them (the tiers' shape test only grows with it: hints and
+// promises computed from a bound hold for the pool itself).
+static void pool_hints(evg_ctx* c, evg_plan_input& q, const int32_t* toff, const int32_t* tgv, const int32_t* verv, const int32_t* ne, bool pri_wide) {
   using namespace evg;
-  if (!c || !dl) return EVG_E_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIP_TRY(c, hipSetDevice(c->device));
-  if (int rc = pending_status(c)) return rc;
-  if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: no pool is loaded on this context");
+  const int D = q.n_distros;
+  const int NN = toff[D];
+  q.max_distro_tasks = 0; q.promises = 0; q.n_big_tier_distros = 0;
+  bool all11 = !pri_wide, all_tiers = !pri_wide;
+  long long nt_tiers = 0, nt_pipe = 0;
+  for (int d = 0; d < D; d++) {
+    const int n = toff[d + 1] - toff[d], ntg = tgv[d + 1] - tgv[d], nver = verv[d + 1] - verv[d];
+    q.max_distro_tasks = std::max(q.max_distro_tasks, n);
+    const int S = c->pool_gv[d] ? ntg + nver : n + ntg;
+    const int tier = lds_tier_of_shape(n, S, ntg, ne[d]);
+    if (tier != 11) all11 = false;
+    if (tier == 0) all_tiers = false;
+    if (tier == 12 && !pri_wide) q.n_big_tier_distros++;
+    if (tier != 0 && !pri_wide) nt_tiers += n; else if (n > kRT) nt_pipe += n;
+  }
+  if (all11) q.promises |= EVG_PROMISE_ALL_ON_LDS_PATH;
+  if (all_tiers) q.promises |= EVG_PROMISE_ALL_ON_LDS_TIERS;
+  if (std::min(nt_tiers, nt_pipe) * 8 >= (long long)NN && NN > 0) q.promises |= EVG_HINT_MIXED_POOL;
+  if (nt_tiers == 0 && nt_pipe > 0 && nt_pipe == (long long)NN) q.promises |= EVG_HINT_NO_TIER_DISTROS;
+}
+
+// A tick's structural change applied to the resident pool on the device (evg_pool_delta.hip.h): see include/evg_sched.h. In three pieces --
+// delta_stage (the host's tables, the delta's arrays into the staging block), delta_enqueue (the re-pack kernels into the SECOND set of
+// pool buffers; the status block, the edge cuts and the new task_off on their way back) and, behind the caller's wait, delta_commit
+// (the kernels' verdict; the swap; the new pool's tables and launch hints) -- so that evg_pool_tick can put value updates and the plan
+// between the second and the third without a synchronisation of their own.
+struct DeltaFlight {
+  int D = 0, N = 0, E = 0, nr = 0, na = 0, nl = 0, EA = 0, NN = 0;
+  size_t EN_cap = 0;
+  const int32_t *n_tg = nullptr, *n_ver = nullptr;
+  std::vector<int32_t> tg_shift, ver_shift, add_before, back, new_toff_host, ne_bound;
+  bool added_wide = false;
+  // device pointers into the staging block
+  const int32_t *d_removed = nullptr, *d_added_distro = nullptr, *d_add_before = nullptr, *d_tg_shift = nullptr, *d_ver_shift = nullptr, *d_ntg = nullptr,
+                *d_nver = nullptr, *d_rl_edges = nullptr, *d_rl_to = nullptr, *d_add_dep_off = nullptr;
+  const uint8_t* d_rm_state = nullptr;
+  const int64_t* d_rm_fin = nullptr;
+  evg::TaskCols a_cols{};
+  evg::EdgeCols a_edges{};
+  int32_t* d_back = nullptr;
+  evg_plan_input view{};  // the re-packed pool (device pointers into pool_alt), hints that hold whatever the device finds
+};
+static size_t delta_in_bytes(const evg_pool_delta* dl, int D) {
+  const size_t nr = (size_t)dl->n_removed, na = (size_t)dl->n_added, nl = (size_t)dl->n_relinked, EA = na > 0 ? (size_t)dl->added.n_edges : 0;
+  return nr * (4 + 1 + 8) + na * (4 + 5 * 8 + 5 * 4 + 2 + 4) + 4 + EA * (4 + 1 + 8) + nl * 8 + 7 * 4 * ((size_t)D + 1) + 40 * 256;
+}
+// `empty` comes back true for a delta that changes nothing (the caller then skips the other two pieces).
+static int delta_stage(evg_ctx* c, const evg_pool_delta* dl, Stager& sg, DeltaFlight& f, bool* empty) {
+  using namespace evg;
+  *empty = false;
   const evg_plan_input& p = c->pool_in;
   const int D = p.n_distros, N = p.tasks.n_tasks, E = p.tasks.n_edges;
   const int nr = dl->n_removed, na = dl->n_added;
+  f.D = D; f.N = N; f.E = E; f.nr = nr; f.na = na;
   if (nr < 0 || na < 0 || (nr > 0 && (!dl->removed_rows || !dl->removed_dep_state)) || (na > 0 && !dl->added_distro))
     return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: null or negative");
   const int nl = dl->n_relinked;
   if (nl < 0 || (nl > 0 && (!dl->relinked_edges || !dl->relinked_to))) return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: null or negative");
-  if (nr == 0 && na == 0 && nl == 0 && !dl->tg_off && !dl->ver_off) return EVG_OK;
-  if (D == 0) return nr || na || nl ? set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: the pool has no distros") : EVG_OK;
+  f.nl = nl;
+  if (nr == 0 && na == 0 && nl == 0 && !dl->tg_off && !dl->ver_off) { *empty = true; return EVG_OK; }
+  if (D == 0) { *empty = true; return nr || na || nl ? set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: the pool has no distros") : EVG_OK; }
   const evg_task_soa& ad = dl->added;
   if (na > 0 && (ad.n_tasks != na || !ad.priority || !ad.expected_duration_ns || !ad.queue_ts_ns || !ad.scheduled_ts_ns || !ad.deps_met_ts_ns ||
                  !ad.num_dependents || !ad.task_group_order || !ad.task_group_max_hosts || !ad.tg_key || !ad.version_key || !ad.flags || !ad.dep_off ||
                  ad.dep_off[0] != 0 || ad.dep_off[na] != ad.n_edges || (ad.n_edges > 0 && (!ad.dep_idx || !ad.dep_info))))
     return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: the added rows' columns are incomplete");
   const int EA = na > 0 ? ad.n_edges : 0;
+  f.EA = EA;
 #ifdef EVG_DELTA_TIMING
   auto tt0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -1820,7 +1896,9 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   // targets, relinks -- is checked by the kernels while they move the data (evg_pool_delta.hip.h: the status block) ----
   const int32_t* n_tg = dl->tg_off ? dl->tg_off : c->pool_tg_off.data();
   const int32_t* n_ver = dl->ver_off ? dl->ver_off : c->pool_ver_off.data();
-  std::vector<int32_t> tg_shift(D + 1), ver_shift(D + 1);
+  f.n_tg = n_tg; f.n_ver = n_ver;
+  std::vector<int32_t>&tg_shift = f.tg_shift, &ver_shift = f.ver_shift;
+  tg_shift.assign(D + 1, 0); ver_shift.assign(D + 1, 0);
   if (n_tg[0] != 0 || n_ver[0] != 0) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: key offsets start at 0");
   for (int d = 0; d < D; d++) {  // a distro's key range may only grow, at its end: an existing key keeps its place in the range
     if (n_tg[d + 1] - n_tg[d] < c->pool_tg_off[d + 1] - c->pool_tg_off[d] || n_ver[d + 1] - n_ver[d] < c->pool_ver_off[d + 1] - c->pool_ver_off[d])
@@ -1828,29 +1906,78 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
     tg_shift[d] = n_tg[d] - c->pool_tg_off[d];
     ver_shift[d] = n_ver[d] - c->pool_ver_off[d];
   }
-  std::vector<int32_t> add_before(D + 1, 0);
+  std::vector<int32_t>& add_before = f.add_before;
+  add_before.assign(D + 1, 0);
+  // an upper bound of every distro's edges after the delta (removals only take edges away): the launch hints below must hold whatever
+  // the device finds, and the tiers' shape test grows with the edge count
+  f.ne_bound.assign(D, 0);
+  for (int d = 0; d < D; d++) f.ne_bound[d] = (int)c->pool_ecut.size() == D + 1 ? c->pool_ecut[d + 1] - c->pool_ecut[d] : (1 << 30);
   for (int i = 0; i < na; i++) {
     const int d = dl->added_distro[i];
     if (d < 0 || d >= D || (i > 0 && d < dl->added_distro[i - 1])) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added_distro must be non-decreasing in [0, D) (row %d)", i);
     add_before[d + 1]++;
+    if (f.ne_bound[d] < (1 << 30)) f.ne_bound[d] += ad.dep_off[i + 1] - ad.dep_off[i];
+    if (ad.priority[i] != (int64_t)(int32_t)ad.priority[i]) f.added_wide = true;
     if (ad.dep_off[i + 1] < ad.dep_off[i]) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: added dep_off not monotone at row %d", i);
   }
   for (int d = 0; d < D; d++) add_before[d + 1] += add_before[d];
   if (nr > N) return set_err(c, EVG_E_CONTRACT, "evg_pool_apply_delta: %d removed rows in a pool of %d", nr, N);
   const int NN = N - nr + na;  // when the removed rows are distinct rows of the pool (the kernels check; the guards below hold otherwise)
   const size_t EN_cap = (size_t)E + (size_t)EA;  // edges only go (with their rows) or come (with the added rows)
-  lap("tables cut");
-  StreamDrain drain{c};
-  hipStream_t st = c->stream;
-  // ---- the delta's arrays up: ONE page-locked block, ONE copy (a 5 % tick is ~4 MB in ~30 arrays: from pageable memory every
-  // array is a staged copy of its own and the call was 1.5 ms, most of it those); scratch in the staging slots behind ----
-  Stager sg{c};
+  f.NN = NN; f.EN_cap = EN_cap;
+  // the new task_off as the host can know it (exact for a delta the device accepts): rows per distro = old - removed + added
   {
-    const size_t in_bytes = (size_t)nr * (4 + 1 + 8) + (size_t)na * (4 + 5 * 8 + 5 * 4 + 2 + 4) + 4 + (size_t)EA * (4 + 1 + 8) + (size_t)nl * 8 +
-                            7 * 4 * ((size_t)D + 1) + 40 * 256;
-    if (in_bytes <= kPackLimit)
-      if (int rc0 = sg.begin_packed(in_bytes, 256)) return rc0;
+    std::vector<int32_t> rem(D, 0);
+    const std::vector<int32_t>& to = c->pool_task_off;
+    int d_cur = 0;  // callers list the rows in ascending order as a rule: the distro then only moves forward (a search per row otherwise)
+    for (int i = 0; i < nr; i++) {
+      const int r = dl->removed_rows[i];
+      if (r < 0 || r >= N) continue;  // the device reports it
+      if (r < to[d_cur]) d_cur = (int)(std::upper_bound(to.begin(), to.end(), r) - to.begin()) - 1;
+      else while (r >= to[d_cur + 1]) d_cur++;
+      rem[d_cur]++;
+    }
+    f.new_toff_host.assign(D + 1, 0);
+    for (int d = 0; d < D; d++) f.new_toff_host[d + 1] = f.new_toff_host[d] + std::max(0, (to[d + 1] - to[d]) - rem[d]) + (add_before[d + 1] - add_before[d]);
   }
+  lap("tables cut");
+  // ---- the delta's arrays into the staging block (the caller opened it: ONE page-locked block, ONE copy -- a 5 % tick is ~4 MB in
+  // ~30 arrays: from pageable memory every array is a staged copy of its own and the call was 1.5 ms, most of it those) ----
+  int rc = EVG_OK;
+  f.d_removed = sg.up(dl->removed_rows, (size_t)nr);
+  f.d_rm_state = sg.up(dl->removed_dep_state, (size_t)nr);
+  f.d_rm_fin = sg.up(dl->removed_finished_ts_ns, (size_t)nr);
+  f.d_added_distro = sg.up(dl->added_distro, (size_t)na);
+  f.d_add_before = sg.up((const int32_t*)add_before.data(), (size_t)(D + 1));
+  f.d_tg_shift = sg.up((const int32_t*)tg_shift.data(), (size_t)(D + 1));
+  f.d_ver_shift = sg.up((const int32_t*)ver_shift.data(), (size_t)(D + 1));
+  f.d_ntg = sg.up(n_tg, (size_t)(D + 1));
+  f.d_nver = sg.up(n_ver, (size_t)(D + 1));
+  f.d_rl_edges = sg.up(dl->relinked_edges, (size_t)nl);
+  f.d_rl_to = sg.up(dl->relinked_to, (size_t)nl);
+  f.a_cols = TaskCols{(int64_t*)sg.up(ad.priority, (size_t)na), (int64_t*)sg.up(ad.expected_duration_ns, (size_t)na), (int64_t*)sg.up(ad.queue_ts_ns, (size_t)na),
+                  (int64_t*)sg.up(ad.scheduled_ts_ns, (size_t)na), (int64_t*)sg.up(ad.deps_met_ts_ns, (size_t)na), (int32_t*)sg.up(ad.num_dependents, (size_t)na),
+                  (int32_t*)sg.up(ad.task_group_order, (size_t)na), (int32_t*)sg.up(ad.task_group_max_hosts, (size_t)na), (int32_t*)sg.up(ad.tg_key, (size_t)na),
+                  (int32_t*)sg.up(ad.version_key, (size_t)na), (uint16_t*)sg.up(ad.flags, (size_t)na)};
+  f.d_add_dep_off = sg.up(na > 0 ? ad.dep_off : (const int32_t*)nullptr, (size_t)na + 1);
+  f.a_edges = EdgeCols{(int32_t*)sg.up(ad.dep_idx, (size_t)EA), (uint8_t*)sg.up(ad.dep_info, (size_t)EA), (int64_t*)sg.up(ad.dep_finished_ts_ns, (size_t)EA)};
+  (void)rc;
+  return sg.rc;
+}
+
+// The re-pack kernels (the staging block must have been flushed). Nothing is waited for.
+static int delta_enqueue(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f, hipStream_t st) {
+  using namespace evg;
+  const evg_plan_input& p = c->pool_in;
+  const int D = f.D, N = f.N, E = f.E, nr = f.nr, na = f.na, nl = f.nl, NN = f.NN;
+  const size_t EN_cap = f.EN_cap;
+  const int32_t *d_removed = f.d_removed, *d_added_distro = f.d_added_distro, *d_add_before = f.d_add_before, *d_tg_shift = f.d_tg_shift, *d_ver_shift = f.d_ver_shift,
+                *d_ntg = f.d_ntg, *d_nver = f.d_nver, *d_rl_edges = f.d_rl_edges, *d_rl_to = f.d_rl_to, *d_add_dep_off = f.d_add_dep_off;
+  const uint8_t* d_rm_state = f.d_rm_state;
+  const int64_t* d_rm_fin = f.d_rm_fin;
+  const TaskCols a_cols = f.a_cols;
+  const EdgeCols a_edges = f.a_edges;
+  auto lap = [](const char*) {};
   int rc = EVG_OK;
   int slot = 32;  // the scratch arrays' staging slots (the Stager's unpacked path uses 0..31)
   auto dev = [&](size_t bytes) -> void* {
@@ -1872,26 +1999,6 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   int32_t* d_back = (int32_t*)dev(4 * (8 + 2 * ((size_t)D + 1)));
   if (rc) return rc;
   int32_t *d_st = d_back, *d_ecut = d_back + 8, *d_ntoff = d_ecut + (D + 1);
-  const int32_t* d_removed = sg.up(dl->removed_rows, (size_t)nr);
-  const uint8_t* d_rm_state = sg.up(dl->removed_dep_state, (size_t)nr);
-  const int64_t* d_rm_fin = sg.up(dl->removed_finished_ts_ns, (size_t)nr);
-  const int32_t* d_added_distro = sg.up(dl->added_distro, (size_t)na);
-  const int32_t* d_add_before = sg.up((const int32_t*)add_before.data(), (size_t)(D + 1));
-  const int32_t* d_tg_shift = sg.up((const int32_t*)tg_shift.data(), (size_t)(D + 1));
-  const int32_t* d_ver_shift = sg.up((const int32_t*)ver_shift.data(), (size_t)(D + 1));
-  const int32_t* d_ntg = sg.up(n_tg, (size_t)(D + 1));
-  const int32_t* d_nver = sg.up(n_ver, (size_t)(D + 1));
-  const int32_t* d_rl_edges = sg.up(dl->relinked_edges, (size_t)nl);
-  const int32_t* d_rl_to = sg.up(dl->relinked_to, (size_t)nl);
-  TaskCols a_cols{(int64_t*)sg.up(ad.priority, (size_t)na), (int64_t*)sg.up(ad.expected_duration_ns, (size_t)na), (int64_t*)sg.up(ad.queue_ts_ns, (size_t)na),
-                  (int64_t*)sg.up(ad.scheduled_ts_ns, (size_t)na), (int64_t*)sg.up(ad.deps_met_ts_ns, (size_t)na), (int32_t*)sg.up(ad.num_dependents, (size_t)na),
-                  (int32_t*)sg.up(ad.task_group_order, (size_t)na), (int32_t*)sg.up(ad.task_group_max_hosts, (size_t)na), (int32_t*)sg.up(ad.tg_key, (size_t)na),
-                  (int32_t*)sg.up(ad.version_key, (size_t)na), (uint16_t*)sg.up(ad.flags, (size_t)na)};
-  const int32_t* d_add_dep_off = sg.up(na > 0 ? ad.dep_off : (const int32_t*)nullptr, (size_t)na + 1);
-  EdgeCols a_edges{(int32_t*)sg.up(ad.dep_idx, (size_t)EA), (uint8_t*)sg.up(ad.dep_info, (size_t)EA), (int64_t*)sg.up(ad.dep_finished_ts_ns, (size_t)EA)};
-  if (sg.rc) return sg.rc;
-  lap("delta packed (page-locked)");
-  if (sg.flush_in()) return sg.rc;
   // ---- the second set of pool buffers ----
   std::vector<DevBuf>& nw = c->pool_alt;
   const size_t n1 = (size_t)NN + 1;
@@ -1954,10 +2061,33 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   HIP_TRY(c, hipMemcpyAsync(nw[16].p, d_ntoff, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
   HIP_TRY(c, hipMemcpyAsync(nw[17].p, d_ntg, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
   HIP_TRY(c, hipMemcpyAsync(nw[18].p, d_nver, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
-  std::vector<int32_t> back(8 + 2 * ((size_t)D + 1), 0);
-  HIP_TRY(c, hipMemcpyAsync(back.data(), d_back, 4 * back.size(), hipMemcpyDeviceToHost, st));
-  if (int rcw_ = wait_stream(c, st, __func__)) return rcw_;
-  lap("tables up, cuts back, synced");
+  f.d_back = d_back;
+  f.back.assign(8 + 2 * ((size_t)D + 1), 0);
+  HIP_TRY(c, hipMemcpyAsync(f.back.data(), d_back, 4 * f.back.size(), hipMemcpyDeviceToHost, st));
+  // ---- the re-packed pool as the planner sees it, with launch hints that hold whatever the device finds: the host knows every
+  // distro's new size exactly (for a delta the device accepts) and an upper bound of its edges ----
+  evg_plan_input& q = f.view;
+  q = c->pool_in;
+  q.tasks.n_tasks = NN; q.tasks.n_edges = (int32_t)std::min<size_t>(EN_cap, 0x7FFFFFFF);
+  q.tasks.priority = (const int64_t*)nw[0].p; q.tasks.expected_duration_ns = (const int64_t*)nw[1].p; q.tasks.queue_ts_ns = (const int64_t*)nw[2].p;
+  q.tasks.scheduled_ts_ns = (const int64_t*)nw[3].p; q.tasks.deps_met_ts_ns = (const int64_t*)nw[4].p; q.tasks.num_dependents = (const int32_t*)nw[5].p;
+  q.tasks.task_group_order = (const int32_t*)nw[6].p; q.tasks.task_group_max_hosts = (const int32_t*)nw[7].p; q.tasks.tg_key = (const int32_t*)nw[8].p;
+  q.tasks.version_key = (const int32_t*)nw[9].p; q.tasks.flags = (const uint16_t*)nw[10].p; q.tasks.dep_off = (const int32_t*)nw[11].p;
+  q.tasks.dep_idx = (const int32_t*)nw[12].p; q.tasks.dep_info = (const uint8_t*)nw[13].p; q.tasks.dep_finished_ts_ns = (const int64_t*)nw[14].p;
+  q.distros = (const evg_distro_params*)c->pool[15].p; q.task_off = (const int32_t*)nw[16].p; q.tg_off = (const int32_t*)nw[17].p; q.ver_off = (const int32_t*)nw[18].p;
+  q.n_task_groups = f.n_tg[D]; q.n_versions = f.n_ver[D];
+  pool_hints(c, q, f.new_toff_host.data(), f.n_tg, f.n_ver, f.ne_bound.data(), c->pool_pri_wide || f.added_wide);
+  return EVG_OK;
+}
+
+// Behind the wait: the kernels' verdict; a clean delta's buffers become the pool.
+static int delta_commit(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f) {
+  using namespace evg;
+  const int D = f.D, NN = f.NN;
+  const int32_t *n_tg = f.n_tg, *n_ver = f.n_ver;
+  const evg_task_soa& ad = dl->added;
+  std::vector<int32_t>& back = f.back;
+  std::vector<DevBuf>& nw = c->pool_alt;
   {  // the kernels' verdict: the first violation in the order the host used to look for them
     const unsigned long long first = ((unsigned long long)(uint32_t)back[5] << 32) | (uint32_t)back[4];
     if (first != ~0ull) {
@@ -2000,25 +2130,136 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   std::vector<int32_t> tgv(n_tg, n_tg + D + 1), verv(n_ver, n_ver + D + 1);
   c->pool_task_off = new_toff; c->pool_tg_off = tgv; c->pool_ver_off = verv;
   c->pool_pri_wide = pri_wide;
-  // ---- the launch hints of the new pool, from its shape (evg_plan_launch_hints's test without the columns) ----
-  q.max_distro_tasks = 0; q.promises = 0; q.n_big_tier_distros = 0;
-  bool all11 = !pri_wide, all_tiers = !pri_wide;
-  long long nt_tiers = 0, nt_pipe = 0;
-  for (int d = 0; d < D; d++) {
-    const int n = new_toff[d + 1] - new_toff[d], ntg = tgv[d + 1] - tgv[d], nver = verv[d + 1] - verv[d];
-    q.max_distro_tasks = std::max(q.max_distro_tasks, n);
-    const int S = c->pool_gv[d] ? ntg + nver : n + ntg;
-    const int tier = lds_tier_of_shape(n, S, ntg, ecut[d + 1] - ecut[d]);
-    if (tier != 11) all11 = false;
-    if (tier == 0) all_tiers = false;
-    if (tier == 12 && !pri_wide) q.n_big_tier_distros++;
-    if (tier != 0 && !pri_wide) nt_tiers += n; else if (n > kRT) nt_pipe += n;
-  }
-  if (all11) q.promises |= EVG_PROMISE_ALL_ON_LDS_PATH;
-  if (all_tiers) q.promises |= EVG_PROMISE_ALL_ON_LDS_TIERS;
-  if (std::min(nt_tiers, nt_pipe) * 8 >= (long long)NN && NN > 0) q.promises |= EVG_HINT_MIXED_POOL;
-  if (nt_tiers == 0 && nt_pipe > 0 && nt_pipe == (long long)NN) q.promises |= EVG_HINT_NO_TIER_DISTROS;
+  std::vector<int32_t> ne_exact(D);
+  for (int d = 0; d < D; d++) ne_exact[d] = ecut[d + 1] - ecut[d];
+  c->pool_ecut.assign(ecut, ecut + D + 1);
+  pool_hints(c, q, c->pool_task_off.data(), c->pool_tg_off.data(), c->pool_ver_off.data(), ne_exact.data(), pri_wide);  // exact now
   return EVG_OK;
+}
+
+int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
+  if (!c || !dl) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = pending_status(c)) return rc;
+  if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: no pool is loaded on this context");
+  if (dl->n_removed < 0 || dl->n_added < 0 || dl->n_relinked < 0) return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: null or negative");
+  StreamDrain drain{c};
+  Stager sg{c};
+  const size_t in_bytes = delta_in_bytes(dl, c->pool_in.n_distros);
+  if (in_bytes <= kPackLimit)
+    if (int rc0 = sg.begin_packed(in_bytes, 256)) return rc0;
+  DeltaFlight f;
+  bool empty = false;
+  if (int rc = delta_stage(c, dl, sg, f, &empty)) return rc;
+  if (empty) return EVG_OK;
+  if (sg.flush_in()) return sg.rc;
+  if (int rc = delta_enqueue(c, dl, f, c->stream)) return rc;
+  if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
+  return delta_commit(c, dl, f);
+}
+
+// The fused resident tick (ABI 3.3): structural delta + value updates + plan + download behind ONE synchronisation -- what
+// evg_pool_apply_delta, evg_pool_update and evg_pool_plan do in three calls with a wait each (and evg_pool_update with two, until
+// round 6). The delta and the updates travel in one page-locked block; the re-pack kernels fill the second set of pool buffers, the
+// updates and the plan run on THAT set with launch hints the host can vouch for without the device's answer (every distro's new size,
+// an upper bound of its edges); the status block and the outputs come back together. A refused delta (or update) leaves the pool as
+// it was -- the second set is simply not swapped in -- and the outputs undefined.
+int evg_pool_tick(evg_ctx* c, const evg_pool_delta* dl, const evg_row_update* ru, const evg_edge_update* eu, int64_t now_ns, const evg_plan_output* out) {
+  if (!c || !out) return EVG_E_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = pending_status(c)) return rc;
+  if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_tick: no pool is loaded on this context");
+  if (!out->order || !out->deps_met || !out->wait_ns || !out->distro_info || !out->group_info)
+    return set_err(c, EVG_E_INVALID, "order, deps_met, wait_ns, distro_info and group_info outputs are required");
+  if (out->breakdown && !out->unit_breakdown) return set_err(c, EVG_E_INVALID, "evg_pool_tick: rows by task are not produced here (ask for unit_of_task + unit_breakdown)");
+  if (dl && (dl->n_removed < 0 || dl->n_added < 0 || dl->n_relinked < 0)) return set_err(c, EVG_E_INVALID, "evg_pool_tick: null or negative");
+  const int D = c->pool_in.n_distros;
+  if (D == 0) return EVG_OK;
+  static const bool timing = getenv("EVG_TICK_TIMING") != nullptr;  // host-side laps of the fused tick on stderr
+  auto tt0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tick] %-34s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - tt0).count());
+    tt0 = t;
+  };
+  StreamDrain drain{c};
+  hipStream_t st = c->stream;
+  Stager sg{c};
+  const size_t in_bytes = (dl ? delta_in_bytes(dl, D) : 0) + update_in_bytes(ru, eu);
+  if (in_bytes > kPackLimit) return set_err(c, EVG_E_INVALID, "evg_pool_tick: a tick of %zu bytes does not travel in one block: use evg_pool_apply_delta / _update / _plan", in_bytes);
+  if (int rc0 = sg.begin_packed(in_bytes, 256)) return rc0;
+  DeltaFlight f;
+  bool empty = true;
+  if (dl)
+    if (int rc = delta_stage(c, dl, sg, f, &empty)) return rc;
+  lap("delta: tables + staged");
+  // the updates name rows / edges of the pool AFTER the delta
+  const evg_plan_input& cur = c->pool_in;
+  bool wide = false;
+  if (int rc = update_check(c, ru, eu, empty ? cur.tasks.n_tasks : f.NN, empty ? (long long)cur.tasks.n_edges : (long long)f.EN_cap,
+                            cur.tasks.dep_finished_ts_ns != nullptr || !empty, cur.tasks.dep_info != nullptr || !empty, &wide)) return rc;
+  lap("updates checked");
+  UpdateFlight u;
+  update_up(sg, ru, eu, u);
+  if (sg.rc) return sg.rc;
+  if (sg.flush_in()) return sg.rc;
+  lap("updates staged, block on its way");
+  if (!empty)
+    if (int rc = delta_enqueue(c, dl, f, st)) return rc;
+  lap("delta kernels enqueued");
+  evg_plan_input view = empty ? c->pool_in : f.view;
+  if (wide) view.promises &= ~(EVG_PROMISE_ALL_ON_LDS_PATH | EVG_PROMISE_ALL_ON_LDS_TIERS);
+  if (int rc = update_enqueue(c, view.tasks, u, st)) return rc;
+  // ---- the plan, on the set of buffers the delta filled; outputs in the context's own blocks, down in place ----
+  view.now_ns = now_ns;
+  const size_t N = view.tasks.n_tasks, G = (size_t)D + view.n_task_groups, Stot = N + (size_t)view.n_task_groups + (size_t)view.n_versions;
+  evg_plan_output dout{};
+  {
+    int rc = EVG_OK;
+    auto buf = [&](int k, size_t bytes, bool wanted) -> void* {
+      if (rc || !wanted) return nullptr;
+      rc = ensure(c, c->tick_out[k], std::max<size_t>(bytes, 64));
+      return rc ? nullptr : c->tick_out[k].p;
+    };
+    dout.order = (int32_t*)buf(0, 4 * N, true); dout.deps_met = (uint8_t*)buf(1, N, true); dout.wait_ns = (int64_t*)buf(2, 8 * N, true);
+    dout.distro_info = (evg_distro_info*)buf(3, sizeof(evg_distro_info) * D, true); dout.group_info = (evg_group_info*)buf(4, sizeof(evg_group_info) * G, true);
+    dout.n_units = (int32_t*)buf(5, 4 * (size_t)D, out->n_units != nullptr);
+    dout.unit_of_task = (int32_t*)buf(6, 4 * N, out->unit_of_task != nullptr);
+    dout.unit_breakdown = (int64_t*)buf(7, 8 * Stot * EVG_BREAKDOWN_FIELDS, out->unit_breakdown != nullptr);
+    if (rc) return rc;
+  }
+  if (int rc = launch_plan(c, &view, &dout, st)) return rc;
+  auto down = [&](void* h, const void* dptr, size_t bytes) -> int {
+    if (!h || !dptr || !bytes) return EVG_OK;
+    HIP_TRY(c, hipMemcpyAsync(h, dptr, bytes, hipMemcpyDeviceToHost, st));
+    return EVG_OK;
+  };
+  int rc = down(out->order, dout.order, 4 * N);
+  if (!rc) rc = down(out->deps_met, dout.deps_met, N);
+  if (!rc) rc = down(out->wait_ns, dout.wait_ns, 8 * N);
+  if (!rc) rc = down(out->distro_info, dout.distro_info, sizeof(evg_distro_info) * D);
+  if (!rc) rc = down(out->group_info, dout.group_info, sizeof(evg_group_info) * G);
+  if (!rc) rc = down(out->n_units, dout.n_units, 4 * (size_t)D);
+  if (!rc) rc = down(out->unit_of_task, dout.unit_of_task, 4 * N);
+  if (!rc) rc = down(out->unit_breakdown, dout.unit_breakdown, 8 * Stot * EVG_BREAKDOWN_FIELDS);
+  if (rc) return rc;
+  lap("updates + plan + downloads enqueued");
+  if (int rcw_ = wait_stream(c, st, __func__)) return rcw_;  // THE synchronisation of the tick
+  lap("waited");
+  if (!empty) {
+    if (int rc2 = delta_commit(c, dl, f)) return rc2;
+    if (eu && eu->n_edges > 0)  // checked against an upper bound before the device had counted the edges
+      for (int i = 0; i < eu->n_edges; i++)
+        if (eu->edges[i] >= c->pool_in.tasks.n_edges) return set_err(c, EVG_E_CONTRACT, "evg_pool_tick: edge %d is outside the pool after the delta (the pool now holds the delta, not the updates' stray write)", eu->edges[i]);
+  }
+  if (wide) {
+    c->pool_in.promises &= ~(EVG_PROMISE_ALL_ON_LDS_PATH | EVG_PROMISE_ALL_ON_LDS_TIERS);
+    c->pool_pri_wide = true;
+  }
+  return pending_status(c);
 }
 
 int evg_filter_runnable(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,

@@ -32,7 +32,7 @@ EXPORTS = [
     # ABI 3.3
     "evg_set_deadline_ms", "evg_get_deadline_ms", "evg_debug_stall", "evg_multi_set_deadline_ms", "evg_multi_debug_stall",
     "evg_batcher_schedule", "evg_batcher_plan_queue", "evg_batcher_set_deadline_ms", "evg_batcher_close", "evg_batcher_get_cache_stats",
-    "evg_batcher_debug_stall",
+    "evg_batcher_debug_stall", "evg_pool_tick",
 ]
 
 _lib = None
@@ -115,6 +115,8 @@ def load_library() -> C.CDLL:
         lib.evg_pool_load.argtypes = [C.c_void_p, C.POINTER(abi.PlanInput)]
         lib.evg_pool_update.argtypes = [C.c_void_p, C.POINTER(abi.RowUpdate), C.POINTER(abi.EdgeUpdate)]
         lib.evg_pool_plan.argtypes = [C.c_void_p, C.c_int64, C.POINTER(abi.PlanOutput)]
+        if hasattr(lib, "evg_pool_tick"):  # ABI 3.3
+            lib.evg_pool_tick.argtypes = [C.c_void_p, C.POINTER(abi.PoolDelta), C.POINTER(abi.RowUpdate), C.POINTER(abi.EdgeUpdate), C.c_int64, C.POINTER(abi.PlanOutput)]
         if hasattr(lib, "evg_pool_apply_delta"):
             lib.evg_pool_apply_delta.argtypes = [C.c_void_p, C.POINTER(abi.PoolDelta)]
         # what a binding does once at start-up: refuse a library whose structs are not the ones it was written against
@@ -504,6 +506,25 @@ class Context:
     def pool_update(self, rows: Optional[np.ndarray] = None, cols: Optional[dict] = None, edges: Optional[np.ndarray] = None,
                     dep_info: Optional[np.ndarray] = None, dep_finished_ts_ns: Optional[np.ndarray] = None) -> None:
         """cols: {column name of evg_row_update: new values in the order of `rows`}."""
+        ru, eu, keep = self.make_pool_update(rows, cols, edges, dep_info, dep_finished_ts_ns)
+        self._check(self.lib.evg_pool_update(self.h, C.byref(ru) if ru is not None else None, C.byref(eu) if eu is not None else None), "evg_pool_update")
+        del keep
+
+    def pool_tick(self, batch_after: abi.PlanBatch, now_ns: int, delta=None, update=None, into: Optional[abi.PlanResult] = None,
+                  n_units: bool = False, units: bool = False) -> abi.PlanResult:
+        """evg_pool_tick (ABI 3.3): structural delta + value updates + plan + download behind ONE synchronisation. `delta`: a block from
+        make_pool_delta (or None); `update`: the (ru, eu, keep) triple of make_pool_update (or None); `batch_after` only sizes the result."""
+        res = into if into is not None else abi.PlanResult.alloc_host(batch_after, breakdown=False, n_units=n_units, units=units)
+        out = res.c_output()
+        ru, eu = (update[0], update[1]) if update is not None else (None, None)
+        self._check(self.lib.evg_pool_tick(self.h, C.byref(delta) if delta is not None else None, C.byref(ru) if ru is not None else None,
+                                           C.byref(eu) if eu is not None else None, now_ns, C.byref(out)), "evg_pool_tick")
+        return res
+
+    @staticmethod
+    def make_pool_update(rows: Optional[np.ndarray] = None, cols: Optional[dict] = None, edges: Optional[np.ndarray] = None,
+                         dep_info: Optional[np.ndarray] = None, dep_finished_ts_ns: Optional[np.ndarray] = None):
+        """The (evg_row_update, evg_edge_update, arrays to keep alive) of a value update (either struct may be None)."""
         ru, eu, keep = None, None, []
         if rows is not None and len(rows):
             ru = abi.RowUpdate()
@@ -530,8 +551,7 @@ class Context:
                 a = np.ascontiguousarray(dep_finished_ts_ns, np.int64)
                 keep.append(a)
                 eu.dep_finished_ts_ns = a.ctypes.data
-        self._check(self.lib.evg_pool_update(self.h, C.byref(ru) if ru is not None else None, C.byref(eu) if eu is not None else None),
-                    "evg_pool_update")
+        return ru, eu, keep
 
     @staticmethod
     def make_pool_delta(removed_rows=None, removed_dep_state=None, removed_finished_ts_ns=None, added_distro=None, added_cols=None,

@@ -625,6 +625,14 @@ int evg_pool_load(evg_ctx* ctx, const evg_plan_input* in);
 int evg_pool_apply_delta(evg_ctx* ctx, const evg_pool_delta* delta);
 int evg_pool_update(evg_ctx* ctx, const evg_row_update* rows, const evg_edge_update* edges); /* either may be NULL */
 int evg_pool_plan(evg_ctx* ctx, int64_t now_ns, const evg_plan_output* out);
+/* The fused resident tick (ABI 3.3): evg_pool_apply_delta(delta) + evg_pool_update(rows, edges) + evg_pool_plan(now_ns, out) as ONE
+ * call behind ONE synchronisation -- the tick of the reference's 15 s cadence (units/crons_remote_fifteen_second.go:21,58-60) on a
+ * resident pool. `delta`, `rows`, `edges` may each be NULL. The updates name rows / edges of the pool AFTER the delta. The delta and
+ * the updates must fit one staging block (8 MB: a 5 % tick of a million tasks is 4.7 MB; EVG_E_INVALID otherwise -- use the three
+ * calls). out->breakdown (rows by task) is not produced here: ask for unit_of_task + unit_breakdown. A delta or an update the
+ * contract refuses leaves the pool as it was before the call and the outputs undefined. */
+int evg_pool_tick(evg_ctx* ctx, const evg_pool_delta* delta, const evg_row_update* rows, const evg_edge_update* edges, int64_t now_ns,
+                  const evg_plan_output* out);
 
 /* Host-pointer forms of evg_filter_runnable_device and evg_allocator_report_device (stage in, run, stage out). */
 int evg_filter_runnable(evg_ctx* ctx, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,

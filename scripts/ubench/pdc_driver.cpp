@@ -66,3 +66,34 @@ extern "C" int pdc_run_batcher(void* fn_plan, void* fn_alloc, void* batcher, int
   for (int b : bad) errors += b;
   return errors;
 }
+
+// ABI 3.3: one evg_batcher_schedule call per distro (plan + allocate as ONE request), the queue named by `queue_base + d` and the
+// generation given: a second run with the same generation finds every queue resident on the device and uploads clock readings only.
+// queue_base 0: no resident queues.
+typedef int (*sched_fn)(void* batcher, unsigned long long queue_id, unsigned long long generation, const void* in, const void* out, const void* ain,
+                        const void* aout, char* err, int err_len);
+extern "C" int pdc_run_pairs(void* fn_schedule, void* batcher, int n_threads, int n_distros, unsigned long long queue_base, unsigned long long generation,
+                             const char* pin, size_t pin_stride, const char* pout, size_t pout_stride, const char* ain, size_t ain_stride, const char* aout,
+                             size_t aout_stride, double* lat_us, double* wall_ms) {
+  const sched_fn schedule = (sched_fn)fn_schedule;
+  std::vector<int> bad(n_threads, 0);
+  auto work = [&](int w) {
+    char err[256];
+    for (int d = w; d < n_distros; d += n_threads) {
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rc = schedule(batcher, queue_base ? queue_base + (unsigned long long)d : 0ull, generation, pin + (size_t)d * pin_stride, pout + (size_t)d * pout_stride,
+                              ain + (size_t)d * ain_stride, aout + (size_t)d * aout_stride, err, (int)sizeof err);
+      lat_us[d] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      bad[w] += rc != 0;
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int w = 1; w < n_threads; w++) th.emplace_back(work, w);
+  work(0);
+  for (auto& t : th) t.join();
+  *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  int errors = 0;
+  for (int b : bad) errors += b;
+  return errors;
+}

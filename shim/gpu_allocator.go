@@ -195,6 +195,7 @@ func allocateBatch(ctx context.Context, datas []*HostAllocatorData) ([]allocResu
 			return nil, err
 		}
 	} else if rc := C.evg_allocate_hosts(g.c, &in, &out); rc != C.EVG_OK {
+		g.dead = rc == C.EVG_E_TIMEOUT // (units/host_allocator.go:32 bounds the job at 10 min; the library's default deadline is 30 s)
 		return nil, errors.Errorf("evg_allocate_hosts: %s (%d)", C.GoString(C.evg_last_error(g.c)), int(rc))
 	}
 

@@ -57,6 +57,7 @@ type gpuCtx struct {
 	arena unsafe.Pointer // evg_host_alloc memory, grown when a batch needs more, re-used tick after tick
 	size  uintptr
 	used  uintptr
+	dead  bool // a call on it came back EVG_E_TIMEOUT (ABI 3.3): the library refuses it from now on; put() destroys it
 }
 
 type gpuCtxPool struct {
@@ -91,10 +92,15 @@ func (p *gpuCtxPool) get() (*gpuCtx, error) {
 	if c == nil { // no gfx950 device: there is no CPU fallback inside the library
 		return nil, errors.Errorf("evg_create: %s", C.GoString(C.evg_last_error(nil)))
 	}
+	C.evg_set_deadline_ms(c, C.int64_t(gpuDeadlineMS)) // SetGPUDeadline (gpu_batcher.go); the library's default is 30 s
 	return &gpuCtx{c: c}, nil
 }
 
 func (p *gpuCtxPool) put(g *gpuCtx) {
+	if g.dead { // poisoned by an expired deadline: evg_destroy waits once more and then leaks rather than blocks -- off this goroutine
+		go C.evg_destroy(g.c)
+		return
+	}
 	g.used = 0
 	p.mu.Lock()
 	p.free = append(p.free, g)
@@ -495,6 +501,7 @@ func planBatch(ctx context.Context, ds []*distro.Distro, queues [][]task.Task) (
 		if err == errGPUShardClosed { // replaced while this batch was being packed: one device plans it, same result
 			err = nil
 			if rc := C.evg_plan_distros(g.c, &in, &out); rc != C.EVG_OK {
+				g.dead = rc == C.EVG_E_TIMEOUT
 				return nil, nil, errors.Errorf("evg_plan_distros: %s (%d)", C.GoString(C.evg_last_error(g.c)), int(rc))
 			}
 		}
@@ -502,10 +509,26 @@ func planBatch(ctx context.Context, ds []*distro.Distro, queues [][]task.Task) (
 			return nil, nil, err
 		}
 	} else if batcher != nil {
-		if err := batchedPlan(batcher, &in, &out); err != nil {
+		// the queue by name and content (gpu_batcher.go): the same queue as 15 s ago travels as a clock reading
+		gen := uint64(fnvOffset)
+		for _, c := range []struct {
+			p unsafe.Pointer
+			b int
+		}{{unsafe.Pointer(ptr(priority)), 8 * n}, {unsafe.Pointer(ptr(expDur)), 8 * n}, {unsafe.Pointer(ptr(queueTS)), 8 * n}, {unsafe.Pointer(ptr(schedTS)), 8 * n},
+			{unsafe.Pointer(ptr(metTS)), 8 * n}, {unsafe.Pointer(ptr(numDep)), 4 * n}, {unsafe.Pointer(ptr(tgOrder)), 4 * n}, {unsafe.Pointer(ptr(tgMaxHosts)), 4 * n},
+			{unsafe.Pointer(ptr(tgKey)), 4 * n}, {unsafe.Pointer(ptr(verKey)), 4 * n}, {unsafe.Pointer(ptr(flags)), 2 * n}, {unsafe.Pointer(ptr(depOff)), 4 * (n + 1)},
+			{unsafe.Pointer(ptr(depIdx)), 4 * e}, {unsafe.Pointer(ptr(depInfo)), e}, {unsafe.Pointer(ptr(depFin)), 8 * e},
+			{unsafe.Pointer(ptr(params)), int(unsafe.Sizeof(params[0])) * D}} {
+			if c.b > 0 {
+				gen = hashWords(gen, c.p, c.b)
+			}
+		}
+		gen = (gen ^ (uint64(nTG)<<32 | uint64(nVer))) * fnvPrime // the sizes of the two key ranges
+		if err := batchedPlan(batcher, fnv64(ds[0].Id)|1, gen, &in, &out); err != nil {
 			return nil, nil, err
 		}
 	} else if rc := C.evg_plan_distros(g.c, &in, &out); rc != C.EVG_OK {
+		g.dead = rc == C.EVG_E_TIMEOUT // the job fails and runs again on the next tick, on a fresh context (units/scheduler.go:18 bounds the job too)
 		return nil, nil, errors.Errorf("evg_plan_distros: %s (%d)", C.GoString(C.evg_last_error(g.c)), int(rc))
 	}
 

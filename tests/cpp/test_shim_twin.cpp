@@ -68,6 +68,10 @@ struct Lib {
   int (*batcher_plan)(evg_batcher*, const evg_plan_input*, const evg_plan_output*, char*, int32_t) = nullptr;
   int (*batcher_allocate)(evg_batcher*, const evg_alloc_input*, const evg_alloc_output*, char*, int32_t) = nullptr;
   int (*batcher_get_stats)(evg_batcher*, evg_batcher_stats*) = nullptr;
+  // ABI 3.3: resident queues, bounded waits
+  int (*batcher_plan_queue)(evg_batcher*, uint64_t, uint64_t, const evg_plan_input*, const evg_plan_output*, char*, int32_t) = nullptr;
+  int (*batcher_set_deadline_ms)(evg_batcher*, int64_t) = nullptr;
+  int (*batcher_get_cache_stats)(evg_batcher*, uint64_t*, uint64_t*, uint64_t*, uint64_t*) = nullptr;
   std::atomic<int> calls_batched{0};
   // oracle mode: the two batched calls without a context
   int (*o_plan)(const evg_plan_input*, const evg_plan_output*) = nullptr;
@@ -162,6 +166,7 @@ static evg_batcher* batcherFor(int n, int D) {
   if (!g_batcher) {
     g_batcher = L.batcher_create(0, 2000, 64);
     if (!g_batcher) throw std::runtime_error(std::string("evg_batcher_create: ") + L.last_error(nullptr));
+    L.batcher_set_deadline_ms(g_batcher, 30000);  // SetGPUDeadline's default
   }
   return g_batcher;
 }
@@ -238,6 +243,16 @@ static DistroQueueInfo queueInfoFromRows(const GoSlice<evg_distro_info>& di, con
   add(gi[d], "");
   for (int k = tgOff[d]; k < tgOff[d + 1]; k++) add(gi[D + k], tgNames[(size_t)k]);
   return info;
+}
+
+// fnv64 / hashWords (gpu_batcher.go): the two words that name a resident queue
+static const uint64_t fnvOffset = 14695981039346656037ull, fnvPrime = 1099511628211ull;
+static uint64_t fnv64(const std::string& s) { uint64_t h = fnvOffset; for (unsigned char c : s) h = (h ^ c) * fnvPrime; return h; }
+static uint64_t hashWords(uint64_t h, const void* p, size_t bytes) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i + 8 <= bytes; i += 8) { uint64_t x; memcpy(&x, b + i, 8); h = (h ^ x) * fnvPrime; }
+  for (size_t i = bytes & ~(size_t)7; i < bytes; i++) h = (h ^ b[i]) * fnvPrime;
+  return h;
 }
 
 // ---- planBatch (gpu_planner.go) -----------------------------------------------------------------------------------------
@@ -368,9 +383,17 @@ static PlanOut planBatch(const std::vector<const Distro*>& ds, const std::vector
   if (g_shard) g_shard->plan(&in, &out);  // shard.plan(&in, &out): the same two structs, spread over the devices by the library
   else if (batcher) {
     char msg[256];
-    rc = L.batcher_plan(batcher, &in, &out, msg, (int32_t)sizeof msg);
+    // the queue by name and content: the same queue as 15 s ago travels as a clock reading
+    uint64_t gen = fnvOffset;
+    const struct { const void* p; size_t b; } cols[] = {{ptr(priority), 8 * (size_t)n}, {ptr(expDur), 8 * (size_t)n}, {ptr(queueTS), 8 * (size_t)n}, {ptr(schedTS), 8 * (size_t)n},
+      {ptr(metTS), 8 * (size_t)n}, {ptr(numDep), 4 * (size_t)n}, {ptr(tgOrder), 4 * (size_t)n}, {ptr(tgMaxHosts), 4 * (size_t)n}, {ptr(tgKey), 4 * (size_t)n},
+      {ptr(verKey), 4 * (size_t)n}, {ptr(flags), 2 * (size_t)n}, {ptr(depOff), 4 * (size_t)(n + 1)}, {ptr(depIdx), 4 * (size_t)e}, {ptr(depInfo), (size_t)e},
+      {ptr(depFin), 8 * (size_t)e}, {ptr(params), sizeof(evg_distro_params) * (size_t)D}};
+    for (const auto& c : cols) if (c.b) gen = hashWords(gen, c.p, c.b);
+    gen = (gen ^ ((uint64_t)nTG << 32 | (uint64_t)nVer)) * fnvPrime;
+    rc = L.batcher_plan_queue(batcher, fnv64(ds[0]->Id) | 1, gen, &in, &out, msg, (int32_t)sizeof msg);
     L.calls_batched++;
-    if (rc != EVG_OK) throw std::runtime_error(std::string("evg_batcher_plan: ") + msg + " (" + std::to_string(rc) + ")");
+    if (rc != EVG_OK) throw std::runtime_error(std::string("evg_batcher_plan_queue: ") + msg + " (" + std::to_string(rc) + ")");
   } else rc = L.hip ? L.plan_distros(g->c, &in, &out) : L.o_plan(&in, &out);
   L.calls_plan++;
   if (rc != EVG_OK) throw std::runtime_error(std::string("evg_plan_distros: ") + (L.hip ? L.last_error(g->c) : "oracle") + " (" + std::to_string(rc) + ")");
@@ -659,13 +682,14 @@ static void run_batcher_cases() {
   std::vector<PlanOut> alone((size_t)K), together((size_t)K);
   std::vector<allocResult> a_alone((size_t)K), a_together((size_t)K);
   const std::map<std::string, Task> running;
+  Time tick_dt = 0;  // the second batched phase runs 15 s later
   auto one = [&](int k, PlanOut& po, allocResult& ar) {
-    po = planBatch({&ds[(size_t)k]}, {&qs[(size_t)k]}, NOW + k);  // every caller has its own clock reading
+    po = planBatch({&ds[(size_t)k]}, {&qs[(size_t)k]}, NOW + k + tick_dt);  // every caller has its own clock reading
     HostAllocatorData data;
     data.Distro = ds[(size_t)k];
     data.DistroQueueInfo = po.infos[0];
     std::vector<HostAllocatorData*> v{&data};
-    ar = allocateBatch(v, NOW + k, running)[0];
+    ar = allocateBatch(v, NOW + k + tick_dt, running)[0];
   };
   for (int k = 0; k < K; k++) one(k, alone[(size_t)k], a_alone[(size_t)k]);
   // together: K threads at once, batching on
@@ -699,6 +723,38 @@ static void run_batcher_cases() {
          "batcher: %d requests went out in fewer launch sequences (%llu requests, %llu batches)", 2 * K, (unsigned long long)st.requests,
          (unsigned long long)st.batches);
   EXPECT(L.calls_batched == 2 * K, "every one-distro call of the concurrent phase went through evg_batcher_* (%d)", (int)L.calls_batched);
+  // ---- the same queues 15 s later (units/crons_remote_fifteen_second.go:21): resident under (fnv64(distro id), hash of the columns) --
+  // the batcher uploads the clock readings only; results are those of the calls alone at the new time
+  tick_dt = 15LL * 1000000000LL;
+  std::vector<PlanOut> alone2((size_t)K), together2((size_t)K);
+  std::vector<allocResult> a_alone2((size_t)K), a_together2((size_t)K);
+  for (int k = 0; k < K; k++) one(k, alone2[(size_t)k], a_alone2[(size_t)k]);
+  uint64_t hits0 = 0, fills0 = 0, hits1 = 0, fills1 = 0;
+  L.batcher_get_cache_stats(g_batcher, &hits0, &fills0, nullptr, nullptr);
+  { std::lock_guard<std::mutex> lk(g_batcher_mu); g_batch_off = false; }
+  th.clear();
+  for (int k = 0; k < K; k++)
+    th.emplace_back([&, k] {
+      try { one(k, together2[(size_t)k], a_together2[(size_t)k]); } catch (const std::exception& e) { errs[(size_t)k] = e.what(); }
+    });
+  for (auto& t : th) t.join();
+  { std::lock_guard<std::mutex> lk(g_batcher_mu); g_batch_off = true; }
+  L.batcher_get_cache_stats(g_batcher, &hits1, &fills1, nullptr, nullptr);
+  EXPECT(fills0 == (uint64_t)K && hits1 - hits0 == (uint64_t)K && fills1 == fills0,
+         "batcher: the second tick found all %d queues resident (fills %llu -> %llu, hits %llu -> %llu)", K, (unsigned long long)fills0,
+         (unsigned long long)fills1, (unsigned long long)hits0, (unsigned long long)hits1);
+  for (int k = 0; k < K; k++) {
+    EXPECT(errs[(size_t)k].empty(), "batcher, second tick: request %d failed: %s", k, errs[(size_t)k].c_str());
+    if (!errs[(size_t)k].empty()) continue;
+    const auto &x = alone2[(size_t)k].plans[0], &y = together2[(size_t)k].plans[0];
+    bool same = x.size() == y.size();
+    for (size_t p = 0; same && p < x.size(); p++)
+      same = x[p].Id == y[p].Id && x[p].SortingValueBreakdown.TotalValue == y[p].SortingValueBreakdown.TotalValue &&
+             x[p].WaitSinceDependenciesMet == y[p].WaitSinceDependenciesMet;
+    EXPECT(same, "batcher, second tick: distro %d from its resident queue == planned alone at the new time", k);
+    EXPECT(a_alone2[(size_t)k].newHosts == a_together2[(size_t)k].newHosts && a_alone2[(size_t)k].freeHosts == a_together2[(size_t)k].freeHosts,
+           "batcher, second tick: host counts of distro %d", k);
+  }
 }
 
 static void run_twin_specifics() {
@@ -836,6 +892,9 @@ int main(int argc, char** argv) {
       L.batcher_create = sym<decltype(L.batcher_create)>(h, "evg_batcher_create"); L.batcher_destroy = sym<decltype(L.batcher_destroy)>(h, "evg_batcher_destroy");
       L.batcher_plan = sym<decltype(L.batcher_plan)>(h, "evg_batcher_plan"); L.batcher_allocate = sym<decltype(L.batcher_allocate)>(h, "evg_batcher_allocate");
       L.batcher_get_stats = sym<decltype(L.batcher_get_stats)>(h, "evg_batcher_get_stats");
+      L.batcher_plan_queue = sym<decltype(L.batcher_plan_queue)>(h, "evg_batcher_plan_queue");
+      L.batcher_set_deadline_ms = sym<decltype(L.batcher_set_deadline_ms)>(h, "evg_batcher_set_deadline_ms");
+      L.batcher_get_cache_stats = sym<decltype(L.batcher_get_cache_stats)>(h, "evg_batcher_get_cache_stats");
     } else {
       L.o_plan = sym<decltype(L.o_plan)>(h, "evg_oracle_plan_distros"); L.o_alloc = sym<decltype(L.o_alloc)>(h, "evg_oracle_allocate_hosts");
     }

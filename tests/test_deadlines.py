@@ -122,7 +122,9 @@ def test_multi_device_tick_that_times_out_aborts_and_refuses(native):
         m.set_deadline_ms(300)
         m.debug_stall(1, 1500)
         t0 = time.perf_counter()
-        with pytest.raises(native.NativeError, match=r"\(%d\).*rank 1.*did not finish within 300 ms" % abi.EVG_E_TIMEOUT):
+        # (which rank's wait gives up first is not the stalled one's privilege: loopback ranks share a device, and HIP maps more streams
+        # than it has hardware queues onto the same queues -- a stalled stream holds up its queue-mates)
+        with pytest.raises(native.NativeError, match=r"\(%d\).*rank \d.*did not finish within 300 ms" % abi.EVG_E_TIMEOUT):
             m.tick()
         assert time.perf_counter() - t0 < 3.5
         with pytest.raises(native.NativeError, match="destroy this evg_multi"):

@@ -187,3 +187,83 @@ def test_an_empty_pool_loads_with_null_tables(native_ctx):
     dummy = np.zeros(4, np.int64)
     out.order = out.deps_met = out.wait_ns = out.distro_info = out.group_info = dummy.ctypes.data
     assert native_ctx.lib.evg_pool_plan(native_ctx.h, 0, C.byref(out)) == abi.EVG_OK
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [gen.config(2), gen.GenConfig(60_000, 24, gen.SEED_BASE + 31, skew=True), gen.config(5, n_tasks=150_000, n_distros=12),
+                                 gen.GenConfig(3_000, 40, 321)], ids=["config2", "skewed", "config5-shape", "small"])
+def test_fused_tick_is_the_three_calls(native_ctx, oracle, cfg):
+    """evg_pool_tick (ABI 3.3) = evg_pool_apply_delta + evg_pool_update + evg_pool_plan behind ONE synchronisation: three ticks in a row --
+    delta + updates, updates only, delta only -- each equal to the oracle on the batch the host restatement builds; the pool it leaves
+    plans like that batch afterwards (evg_pool_plan), i.e. the second set of buffers really became the pool."""
+    full, pool0, delta, _, _ = _tick(cfg)
+    native_ctx.pool_load(pool0)
+    pool1 = pool_delta.apply_delta(pool0, delta)
+    rng = np.random.default_rng(11)
+    k = max(pool1.n_tasks // 20, 1)
+    rows = np.sort(rng.choice(pool1.n_tasks, size=k, replace=False)).astype(np.int32)
+    pri, dur = rng.integers(0, 100, k).astype(np.int64), (rng.integers(10, 9_000, k) * 10**9).astype(np.int64)
+    ke = max(pool1.n_edges // 50, 1) if pool1.n_edges else 0
+    edges = np.sort(rng.choice(pool1.n_edges, size=ke, replace=False)).astype(np.int32) if ke else None
+    info = (pool1.edges["dep_info"][edges] ^ np.where(pool1.edges["dep_idx"][edges] < 0, 1 << abi.DEP_STATE_SHIFT, 0)).astype(np.uint8) if ke else None
+    blk, keep = native_ctx.make_pool_delta(**delta.kwargs())
+    upd = native_ctx.make_pool_update(rows, {"priority": pri, "expected_duration_ns": dur}, edges, info)
+    now = pool1.now_ns + 15 * 10**9
+    got = native_ctx.pool_tick(pool1, now, delta=blk, update=upd, n_units=True, units=True)
+    pool1.cols["priority"][rows], pool1.cols["expected_duration_ns"][rows] = pri, dur
+    if ke:
+        pool1.edges["dep_info"][edges] = info
+    pool1.now_ns = now
+    want = oracle.plan(pool1, breakdown=True, n_units=True)
+    want.breakdown = None
+    compare.assert_plan_equal(got, want, pool1, "fused tick: delta + updates")
+    assert np.array_equal(got.expand_breakdown(), oracle.plan(pool1, breakdown=True, n_units=True).breakdown), "unit rows of the fused tick"
+    again = native_ctx.pool_plan(pool1, now, n_units=True)
+    compare.assert_plan_equal(again, want, pool1, "the pool the fused tick left")
+    # updates only
+    pri2 = rng.integers(0, 100, k).astype(np.int64)
+    got = native_ctx.pool_tick(pool1, now + 15 * 10**9, update=native_ctx.make_pool_update(rows, {"priority": pri2}), n_units=True)
+    pool1.cols["priority"][rows] = pri2
+    pool1.now_ns = now + 15 * 10**9
+    want = oracle.plan(pool1, breakdown=False, n_units=True)
+    want.breakdown = None
+    compare.assert_plan_equal(got, want, pool1, "fused tick: updates only")
+    # a second structural delta on top (the buffers swap back), no updates
+    gone = np.sort(rng.choice(pool1.n_tasks, max(pool1.n_tasks // 40, 1), replace=False)).astype(np.int32)
+    d2 = pool_delta.Delta(removed_rows=gone, removed_dep_state=np.full(len(gone), 1 << 2, np.uint8), removed_finished_ts_ns=None,
+                          added_distro=np.zeros(0, np.int32), added_cols=pool_delta.empty_added()[1], added_dep_off=np.zeros(1, np.int32),
+                          added_edges=pool_delta.empty_added()[3])
+    pool2 = pool_delta.apply_delta(pool1, d2)
+    blk2, keep2 = native_ctx.make_pool_delta(**d2.kwargs())
+    got = native_ctx.pool_tick(pool2, pool2.now_ns, delta=blk2, n_units=True)
+    want = oracle.plan(pool2, breakdown=False, n_units=True)
+    want.breakdown = None
+    compare.assert_plan_equal(got, want, pool2, "fused tick: delta only")
+    del keep, keep2
+
+
+@pytest.mark.gpu
+def test_fused_tick_refuses_what_the_three_calls_refuse_and_leaves_the_pool(native_ctx, oracle):
+    from evergreen_amd import native
+    full, pool0, delta, _, _ = _tick(gen.GenConfig(20_000, 9, gen.SEED_BASE + 61, tg_fraction=0.3))
+    native_ctx.pool_load(pool0)
+    base = native_ctx.pool_plan(pool0, pool0.now_ns, n_units=True)
+    pool1 = pool_delta.apply_delta(pool0, delta)
+    bad = dict(delta.kwargs())
+    bad["removed_rows"] = np.concatenate([delta.removed_rows[:1], delta.removed_rows])  # a row twice: only the kernels can see it
+    bad["removed_dep_state"] = np.concatenate([delta.removed_dep_state[:1], delta.removed_dep_state])
+    bad["removed_finished_ts_ns"] = None
+    blk, keep = native_ctx.make_pool_delta(**bad)
+    with pytest.raises(native.NativeError, match="twice"):
+        native_ctx.pool_tick(pool1, pool1.now_ns, delta=blk)
+    compare.assert_plan_equal(native_ctx.pool_plan(pool0, pool0.now_ns, n_units=True), base, pool0, "the pool after a refused fused tick")
+    blk, keep = native_ctx.make_pool_delta(**delta.kwargs())
+    rows = np.array([3, 3], np.int32)  # an update the host refuses: before anything is enqueued
+    with pytest.raises(native.NativeError, match="listed twice"):
+        native_ctx.pool_tick(pool1, pool1.now_ns, delta=blk, update=native_ctx.make_pool_update(rows, {"priority": np.array([1, 2], np.int64)}))
+    compare.assert_plan_equal(native_ctx.pool_plan(pool0, pool0.now_ns, n_units=True), base, pool0, "the pool after a refused update")
+    got = native_ctx.pool_tick(pool1, pool1.now_ns, delta=blk, n_units=True)  # and the good delta still applies
+    want = oracle.plan(pool1, breakdown=False, n_units=True)
+    want.breakdown = None
+    compare.assert_plan_equal(got, want, pool1, "a good fused tick after refused ones")
+    del keep
