@@ -1234,8 +1234,8 @@ int evg_multi_results(evg_multi* m, const evg_plan_output* out, const evg_alloc_
 // here every rank gets the part that concerns its distro range, re-based to its numbering, and applies it to its resident pool
 // (evg_pool_apply_delta on its context: only that rank's share of the delta crosses the link to that device). `alloc` (or NULL)
 // brings the tick's allocator input for the whole batch: hosts change every tick, and their tg_key is in the distro's CURRENT key
-// numbering, so a delta that grows key ranges must bring them. A rank's failure leaves the ranks before it changed: the object then
-// needs evg_multi_load again (the message says so).
+// numbering, so a delta that grows key ranges must bring them. All or nothing (round 6): every rank's re-pack is enqueued on its device
+// before any is waited for, every rank's verdict is read, and only a delta that every rank accepts becomes the pools.
 int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_alloc_input* alloc) {
   using namespace evgm;
   if (!m || !dl) return EVG_E_INVALID;
@@ -1303,7 +1303,11 @@ int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_allo
     if (to < part[k].a0 || to >= part[k].a1) return merr(m, EVG_E_CONTRACT, "evg_multi_apply_delta: relinked edge %d belongs to a row of another distro than the added row it is pointed at", (int)e);
     part[k].rl_edges.push_back((int32_t)(e - eoff[k])); part[k].rl_to.push_back(to - part[k].a0);
   }
-  // ---- every rank applies its part ----
+  // ---- every rank's part: built, then ENQUEUED on its device before any is waited for (the ranks re-pack side by side), then all
+  // verdicts read, and only if every rank's is clean do the re-packed buffers become the pools: a delta one rank refuses leaves every
+  // rank as it was (until round 6 the ranks applied one after the other, a wait each, and a refusal on rank k left ranks 0..k-1 changed) ----
+  std::vector<evg_pool_delta> subs((size_t)n);
+  std::vector<PoolDeltaTxn> txn((size_t)n);
   for (int k = 0; k < n; k++) {
     Rank& r = m->r[k];
     Part& p = part[k];
@@ -1311,7 +1315,8 @@ int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_allo
     if (nd == 0) continue;
     const int32_t R0 = m->task_off[r.d0], R1 = m->task_off[r.d1];
     for (int32_t& x : p.removed) x -= R0;
-    evg_pool_delta sub{};
+    evg_pool_delta& sub = subs[(size_t)k];
+    sub = evg_pool_delta{};
     sub.n_removed = (int32_t)p.removed.size(); sub.removed_rows = p.removed.data(); sub.removed_dep_state = p.state.data();
     sub.removed_finished_ts_ns = dl->removed_finished_ts_ns ? p.fin.data() : nullptr;
     p.tg_off.resize((size_t)nd + 1); p.ver_off.resize((size_t)nd + 1);
@@ -1349,11 +1354,27 @@ int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_allo
       st.dep_info = ad.dep_info ? ad.dep_info + e0 : nullptr; st.dep_finished_ts_ns = ad.dep_finished_ts_ns ? ad.dep_finished_ts_ns + e0 : nullptr;
     }
     sub.n_relinked = (int32_t)p.rl_edges.size(); sub.relinked_edges = p.rl_edges.data(); sub.relinked_to = p.rl_to.data();
-    const int rc = evg_pool_apply_delta(r.ctx, &sub);
-    if (rc) {
-      if (k > 0) m->loaded = false;
-      return merr(m, rc, "rank %d: %s%s", k, evg_last_error(r.ctx), k > 0 ? " -- the ranks before it have applied their part: load the pool again (evg_multi_load)" : "");
-    }
+  }
+  int first = EVG_OK, first_rank = -1;
+  for (int k = 0; k < n && !first; k++) {
+    if (m->r[k].d1 == m->r[k].d0) continue;
+    first = pool_delta_begin(m->r[k].ctx, &subs[(size_t)k], txn[(size_t)k]);
+    if (first) first_rank = k;
+  }
+  for (int k = 0; k < n; k++) {  // every rank that began is waited for, whatever another rank said
+    const int rc = pool_delta_wait_verdict(&subs[(size_t)k], txn[(size_t)k]);
+    if (rc && !first) { first = rc; first_rank = k; }
+  }
+  std::string why;
+  if (first) why = evg_last_error(m->r[first_rank].ctx);
+  bool poisoned = false;
+  for (int k = 0; k < n; k++) {
+    pool_delta_end(txn[(size_t)k], first == EVG_OK);
+    poisoned = poisoned || (m->r[k].ctx && m->r[k].ctx->timed_out);
+  }
+  if (first) {
+    if (poisoned) m->loaded = false;  // a rank's context outlived its deadline: the object needs re-creating
+    return merr(m, first, "rank %d: %s -- no rank's pool was changed", first_rank, why.c_str());
   }
   // ---- the global tables after the delta; output blocks for the new sizes; this tick's hosts ----
   {

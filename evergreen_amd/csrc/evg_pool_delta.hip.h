@@ -100,6 +100,52 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int32_t* v, int
   if (blockIdx.x == 0 && tid == 0) out[n] = bsum[nb];
 }
 
+// A scan that is ONE block (n <= kScanTile: the per-distro tables): block sums, their prefix and the apply step in one launch.
+template <bool FLAG>
+__global__ void __launch_bounds__(kScanBlock) k_scan_single(const int32_t* v, int n, int32_t* out) {
+  __shared__ int s_w[kScanBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, base = tid * kScanPer;
+  int x[kScanPer], s = 0;
+#pragma unroll
+  for (int q = 0; q < kScanPer; q++) { x[q] = scan_in<FLAG>(v, base + q, n); s += x[q]; }
+  int incl = s;
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+  const int r0 = __builtin_amdgcn_readlane(incl, 15), r1 = __builtin_amdgcn_readlane(incl, 31), r2 = __builtin_amdgcn_readlane(incl, 47);
+  const int row = lane >> 4;
+  incl += (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+  if (lane == 63) s_w[tid >> 6] = incl;
+  __syncthreads();
+  int pre = 0, total = 0;
+  for (int w = 0; w < kScanBlock / 64; w++) { pre += w < (tid >> 6) ? s_w[w] : 0; total += s_w[w]; }
+  pre += incl - s;
+#pragma unroll
+  for (int q = 0; q < kScanPer; q++) {
+    if (base + q < n) out[base + q] = pre;
+    pre += x[q];
+  }
+  if (tid == 0) out[n] = total;
+}
+
+// The re-pack's initial state in one launch (six memsets before: ~9 us of launch train each): the status block, the removed-row
+// counters, the source table, the removed-row index and the relink table.
+__global__ void __launch_bounds__(256) k_delta_init(int32_t* st, int32_t* rem, int D, int32_t* src, int NN, int32_t* rmi, int N, int32_t* relink, int E) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 4) st[i] = 0;
+  else if (i < 6) st[i] = -1;  // packed (code, index) of the first violation: ~0 = clean
+  if (i <= D) rem[i] = 0;
+  if (i <= NN) src[i] = 0;     // a refused delta leaves entries unset: they must still be rows of the pool
+  if (i < N) rmi[i] = -1;
+  if (relink && i < E) relink[i] = -1;
+}
+// The three per-distro tables of the re-packed pool (D + 1 words each) in one launch.
+__global__ void __launch_bounds__(256) k_copy3_i32(int n, const int32_t* a, int32_t* a_out, const int32_t* b, int32_t* b_out, const int32_t* c, int32_t* c_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { a_out[i] = a[i]; b_out[i] = b[i]; c_out[i] = c[i]; }
+}
+
 // ---- the delta's contract, checked where the data is ---------------------------------------------------------------------------
 // Round 4 validated a delta on the HOST before anything was enqueued: a bitmap pass over the removed rows, a popcount per distro,
 // a loop over every added row and edge, a bitmap pass over the relinked edges -- ~0.3 ms of the call's 0.7 for a 5 % tick of a 1 M

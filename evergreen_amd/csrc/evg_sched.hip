@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -2020,34 +2021,33 @@ static int delta_enqueue(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f, h
   EdgeCols n_edges{(int32_t*)nw[12].p, (uint8_t*)nw[13].p, (int64_t*)nw[14].p}, o_edges{(int32_t*)t.dep_idx, (uint8_t*)t.dep_info, (int64_t*)t.dep_finished_ts_ns};
   auto grid = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
   // ---- status block; removed rows; rows per distro; the new task_off ----
-  HIP_TRY(c, hipMemsetAsync(d_st, 0, 16, st));
-  HIP_TRY(c, hipMemsetAsync(d_st + 4, 0xFF, 8, st));  // packed (code, index) of the first violation: ~0 = clean
-  HIP_TRY(c, hipMemsetAsync(d_rem, 0, 4 * ((size_t)D + 1), st));
-  HIP_TRY(c, hipMemsetAsync(d_src, 0, 4 * ((size_t)NN + 1), st));  // a refused delta leaves entries unset: they must still be rows of the pool
-  if (N > 0) HIP_TRY(c, hipMemsetAsync(d_rmi, 0xFF, 4 * (size_t)N, st));
+  // (one launch for what were six memsets; a scan of one block in one launch: the host's launch rate, ~9 us a call, is what the re-pack
+  // of a 5 % tick waits for -- LAB_NOTES 6.1)
+  hipLaunchKernelGGL(k_delta_init, grid(std::max<size_t>(std::max<size_t>((size_t)N, (size_t)NN + 1), std::max<size_t>((size_t)D + 1, nl > 0 ? (size_t)E : 8))), dim3(256), 0, st,
+                     d_st, d_rem, D, d_src, NN, d_rmi, N, nl > 0 ? d_relink : (int32_t*)nullptr, E);
   if (nr > 0) hipLaunchKernelGGL(k_delta_mark, grid(nr), dim3(256), 0, st, nr, d_removed, d_rm_state, N, D, p.task_off, d_rmi, d_rem, d_st);
   hipLaunchKernelGGL(k_delta_counts, grid(D), dim3(256), 0, st, D, p.task_off, d_rem, d_add_before, d_ntoff, d_st);
-  hipLaunchKernelGGL(k_scan_block_sums<false>, dim3(nb_d), dim3(kScanBlock), 0, st, d_ntoff, D, d_bsum);
-  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb_d);
-  hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb_d), dim3(kScanBlock), 0, st, d_ntoff, D, d_bsum, nb_d, d_ntoff);
+  auto scan = [&](auto flag, const int32_t* v, int n_, int nb, int32_t* out) {  // exclusive prefix sums of v[0, n_) (+ the total at out[n_])
+    constexpr bool F = decltype(flag)::value;
+    if (nb <= 1) { hipLaunchKernelGGL(k_scan_single<F>, dim3(1), dim3(kScanBlock), 0, st, v, n_, out); return; }
+    hipLaunchKernelGGL(k_scan_block_sums<F>, dim3(nb), dim3(kScanBlock), 0, st, v, n_, d_bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb);
+    hipLaunchKernelGGL(k_scan_apply<F>, dim3(nb), dim3(kScanBlock), 0, st, v, n_, d_bsum, nb, out);
+  };
+  scan(std::false_type{}, d_ntoff, D, nb_d, d_ntoff);
   // ---- kept rows, their new numbers ----
   if (N > 0) {
-    hipLaunchKernelGGL(k_scan_block_sums<true>, dim3(nb_old), dim3(kScanBlock), 0, st, d_rmi, N, d_bsum);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb_old);
-    hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb_old), dim3(kScanBlock), 0, st, d_rmi, N, d_bsum, nb_old, d_kept);
+    scan(std::true_type{}, d_rmi, N, nb_old, d_kept);
     hipLaunchKernelGGL(k_delta_place, grid(N), dim3(256), 0, st, N, D, d_rmi, d_kept, p.task_off, d_add_before, d_newrow, d_src, NN);
   }
   if (na > 0) hipLaunchKernelGGL(k_delta_src_added, grid(na), dim3(256), 0, st, na, d_added_distro, d_add_before, d_ntoff, d_added_dst, d_src, NN);
   if (nl > 0) {
-    HIP_TRY(c, hipMemsetAsync(d_relink, 0xFF, 4 * (size_t)E, st));
     hipLaunchKernelGGL(k_delta_relink, grid(nl), dim3(256), 0, st, nl, d_rl_edges, d_rl_to, d_relink, E, na, d_st);
   }
   if (NN > 0) {
     hipLaunchKernelGGL(k_delta_rows, grid(NN), dim3(256), 0, st, NN, D, d_src, n_cols, o_cols, a_cols, t.dep_off, d_add_dep_off, d_ntoff, d_tg_shift,
                        d_ver_shift, n_dep_off, d_added_distro, d_ntg, d_nver, d_st);
-    hipLaunchKernelGGL(k_scan_block_sums<false>, dim3(nb_new), dim3(kScanBlock), 0, st, n_dep_off, NN, d_bsum);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb_new);
-    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb_new), dim3(kScanBlock), 0, st, n_dep_off, NN, d_bsum, nb_new, n_dep_off);
+    scan(std::false_type{}, n_dep_off, NN, nb_new, n_dep_off);
     hipLaunchKernelGGL(k_delta_edges, grid(NN), dim3(256), 0, st, NN, d_src, n_dep_off, n_edges, o_edges, a_edges, t.dep_off, d_add_dep_off, d_newrow, d_rmi,
                        d_rm_state, d_rm_fin, d_added_dst, d_relink, na, d_added_distro, p.task_off, d_ntoff, D, d_st, (int)EN_cap);
     hipLaunchKernelGGL(k_gather_i32, grid(D + 1), dim3(256), 0, st, D + 1, d_ntoff, n_dep_off, d_ecut, NN);
@@ -2058,9 +2058,8 @@ static int delta_enqueue(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f, h
   HIP_TRY(c, hipGetLastError());
   lap("buffers + kernels enqueued");
   // the small tables of the new pool; status, edge cuts and the new task_off come back in one copy
-  HIP_TRY(c, hipMemcpyAsync(nw[16].p, d_ntoff, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(nw[17].p, d_ntg, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(nw[18].p, d_nver, 4 * (size_t)(D + 1), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_copy3_i32, grid(D + 1), dim3(256), 0, st, D + 1, d_ntoff, (int32_t*)nw[16].p, d_ntg, (int32_t*)nw[17].p, d_nver, (int32_t*)nw[18].p);
+  HIP_TRY(c, hipGetLastError());
   f.d_back = d_back;
   f.back.assign(8 + 2 * ((size_t)D + 1), 0);
   HIP_TRY(c, hipMemcpyAsync(f.back.data(), d_back, 4 * f.back.size(), hipMemcpyDeviceToHost, st));
@@ -2081,13 +2080,11 @@ static int delta_enqueue(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f, h
 }
 
 // Behind the wait: the kernels' verdict; a clean delta's buffers become the pool.
-static int delta_commit(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f) {
+static int delta_verdict(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f) {
   using namespace evg;
   const int D = f.D, NN = f.NN;
-  const int32_t *n_tg = f.n_tg, *n_ver = f.n_ver;
   const evg_task_soa& ad = dl->added;
   std::vector<int32_t>& back = f.back;
-  std::vector<DevBuf>& nw = c->pool_alt;
   {  // the kernels' verdict: the first violation in the order the host used to look for them
     const unsigned long long first = ((unsigned long long)(uint32_t)back[5] << 32) | (uint32_t)back[4];
     if (first != ~0ull) {
@@ -2109,9 +2106,18 @@ static int delta_commit(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f) {
       }
     }
   }
+  if (back[8 + (D + 1) + D] != NN) return set_err(c, EVG_E_HIP, "evg_pool_apply_delta: internal: the re-packed pool has %d rows, %d expected", back[8 + (D + 1) + D], NN);
+  return EVG_OK;
+}
+// A delta with a clean verdict: its buffers become the pool. Cannot fail.
+static void delta_swap(evg_ctx* c, DeltaFlight& f) {
+  using namespace evg;
+  const int D = f.D, NN = f.NN;
+  const int32_t *n_tg = f.n_tg, *n_ver = f.n_ver;
+  std::vector<int32_t>& back = f.back;
+  std::vector<DevBuf>& nw = c->pool_alt;
   const int32_t* ecut = back.data() + 8;
   std::vector<int32_t> new_toff(back.begin() + 8 + (D + 1), back.begin() + 8 + 2 * (D + 1));
-  if (new_toff[D] != NN) return set_err(c, EVG_E_HIP, "evg_pool_apply_delta: internal: the re-packed pool has %d rows, %d expected", new_toff[D], NN);
   const bool pri_wide = c->pool_pri_wide || back[2] != 0;
   // ---- swap: the new buffers ARE the pool (the distro settings are not re-packed: their buffer moves over) ----
   std::swap(nw[15], c->pool[15]);
@@ -2134,7 +2140,53 @@ static int delta_commit(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f) {
   for (int d = 0; d < D; d++) ne_exact[d] = ecut[d + 1] - ecut[d];
   c->pool_ecut.assign(ecut, ecut + D + 1);
   pool_hints(c, q, c->pool_task_off.data(), c->pool_tg_off.data(), c->pool_ver_off.data(), ne_exact.data(), pri_wide);  // exact now
+}
+static int delta_commit(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f) {
+  if (int rc = delta_verdict(c, dl, f)) return rc;
+  delta_swap(c, f);
   return EVG_OK;
+}
+
+// A delta on ONE context in two steps, for a caller that applies deltas to several contexts at once (evg_multi_apply_delta: every
+// rank's re-pack is enqueued before any is waited for, and no rank's pool changes unless every rank's delta is clean):
+// pool_delta_begin stages + enqueues and keeps the context locked; pool_delta_wait_verdict waits and reads the kernels' verdict;
+// pool_delta_end swaps (commit) or leaves the pool as it was, and unlocks.
+struct PoolDeltaTxn {
+  evg_ctx* c = nullptr;
+  std::unique_lock<std::mutex> lk;
+  std::unique_ptr<Stager> sg;
+  DeltaFlight f;
+  bool empty = true, open = false;
+};
+static int pool_delta_begin(evg_ctx* c, const evg_pool_delta* dl, PoolDeltaTxn& t) {
+  t.c = c;
+  t.lk = std::unique_lock<std::mutex>(c->mu);
+  t.open = true;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = pending_status(c)) return rc;
+  if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: no pool is loaded on this context");
+  if (dl->n_removed < 0 || dl->n_added < 0 || dl->n_relinked < 0) return set_err(c, EVG_E_INVALID, "evg_pool_apply_delta: null or negative");
+  t.sg.reset(new Stager{c});
+  const size_t in_bytes = delta_in_bytes(dl, c->pool_in.n_distros);
+  if (in_bytes <= kPackLimit)
+    if (int rc0 = t.sg->begin_packed(in_bytes, 256)) return rc0;
+  if (int rc = delta_stage(c, dl, *t.sg, t.f, &t.empty)) return rc;
+  if (t.empty) return EVG_OK;
+  if (t.sg->flush_in()) return t.sg->rc;
+  return delta_enqueue(c, dl, t.f, c->stream);
+}
+static int pool_delta_wait_verdict(const evg_pool_delta* dl, PoolDeltaTxn& t) {
+  if (!t.open) return EVG_OK;
+  (void)hipSetDevice(t.c->device);
+  if (int rc = wait_stream(t.c, t.c->stream, "evg_pool_apply_delta")) return rc;
+  return t.empty ? EVG_OK : delta_verdict(t.c, dl, t.f);
+}
+static void pool_delta_end(PoolDeltaTxn& t, bool commit) {
+  if (!t.open) return;
+  if (commit && !t.empty) delta_swap(t.c, t.f);
+  else if (!t.c->timed_out) { (void)hipSetDevice(t.c->device); const std::string keep = t.c->err; if (wait_stream(t.c, t.c->stream, "drain") == EVG_OK) t.c->err = keep; }
+  t.open = false;
+  t.lk.unlock();
 }
 
 int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {

@@ -732,7 +732,8 @@ int evg_multi_poison_outputs(evg_multi* m, int32_t byte);
 /* EVG_MULTI_RESIDENT_SHARDS only: a tick's structural change, written against the WHOLE batch exactly like evg_pool_apply_delta's (current
  * global row and edge numbers, global added_distro, the new global key tables); every rank applies the part that concerns its range. `alloc`
  * (or NULL) is the tick's allocator input for the whole batch -- required when the delta grows key ranges (the resident hosts' tg_key is in the
- * distro's current key numbering). After a failure on a rank other than the first the pool must be loaded again. */
+ * distro's current key numbering). All or nothing since ABI 3.3: the ranks re-pack side by side, and a delta that any rank refuses
+ * leaves EVERY rank's pool as it was (until then a refusal on rank k left ranks 0..k-1 changed and the pool had to be loaded again). */
 int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* delta, const evg_alloc_input* alloc);
 int evg_multi_inject_failure(evg_multi* m, int32_t rank, int32_t phase);
 int evg_multi_abort(evg_multi* m);

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Soak of the micro-batching front (evg_batcher_*): pools of random shape (tests/random_shapes.py's shapes, capped at 120 k tasks) cut
 into random requests of one to four distros, every request with its own now_ns and its own choice of outputs, planned + allocated from
-many threads at once through ONE batcher -- each result against the oracle on the request alone. GPU box only.
+many threads at once through ONE batcher -- each result against the oracle on the request alone. A third of the requests go as PAIRS
+(evg_batcher_schedule), half of all requests name a resident queue (ABI 3.3), and every pool is planned TWICE, 15 s apart: the second
+time the named queues are on the device already. GPU box only.
 usage: scripts/soak_batcher.py [seconds] [seed] [threads]"""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,34 +32,46 @@ try:
             if rng.random() < 0.3:
                 s.edges["dep_finished_ts_ns"] = None
             jobs.append((s, bool(rng.random() < 0.5), bool(rng.random() < 0.15), bool(rng.random() < 0.5)))
-        res, errs = [None] * len(jobs), []
+        kinds = [(bool(rng.random() < 0.33), int(pools * 100_000 + i + 1) if rng.random() < 0.5 else 0) for i in range(len(jobs))]  # (pair?, queue id)
+        for tick in range(2):
+            res, errs = [None] * len(jobs), []
+            for s, _, _, _ in jobs:
+                s.now_ns += tick * 15 * 10**9
 
-        def work(w):
-            for i in range(w, len(jobs), n_threads):
-                s, bd, nu, un = jobs[i]
-                try:
-                    p = b.plan(s, breakdown=bd, n_units=nu, units=un)
-                    a = b.allocate(s, p.distro_info, p.group_info.copy())
-                    res[i] = (p, a)
-                except Exception as e:  # noqa: BLE001
-                    errs.append((i, e))
-        th = [threading.Thread(target=work, args=(w,)) for w in range(n_threads)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        assert not errs, errs[:3]
-        for (s, bd, nu, un), (p, a) in zip(jobs, res):
-            want = oracle.plan(s, breakdown=bd, n_units=nu)
-            if not bd:
-                want.breakdown = None
-            if not nu:
-                want.n_units = None
-            compare.assert_plan_equal(p, want, s, "request of %d distros, %d tasks" % (s.n_distros, s.n_tasks))
-            compare.assert_alloc_equal(a, oracle.allocate(s, want.distro_info, want.group_info.copy()), "request")
-            reqs += 1
-            tasks += s.n_tasks
+            def work(w):
+                for i in range(w, len(jobs), n_threads):
+                    s, bd, nu, un = jobs[i]
+                    pair, qid = kinds[i]
+                    try:
+                        if pair:
+                            res[i] = b.schedule(s, queue_id=qid, generation=pools + 1, breakdown=bd, n_units=nu, units=un)
+                        else:
+                            p = b.plan_queue(qid, pools + 1, s, breakdown=bd, n_units=nu, units=un) if qid else b.plan(s, breakdown=bd, n_units=nu, units=un)
+                            gi = p.group_info.copy()
+                            a = b.allocate(s, p.distro_info, gi)
+                            res[i] = (p, a)
+                    except Exception as e:  # noqa: BLE001
+                        errs.append((i, e))
+            th = [threading.Thread(target=work, args=(w,)) for w in range(n_threads)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not errs, errs[:3]
+            for (s, bd, nu, un), (pair, qid), (p, a) in zip(jobs, kinds, res):
+                want = oracle.plan(s, breakdown=bd, n_units=nu)
+                if not bd:
+                    want.breakdown = None
+                if not nu:
+                    want.n_units = None
+                gi = want.group_info if pair else want.group_info.copy()  # a pair's rows come back as the allocator leaves them
+                wa = oracle.allocate(s, want.distro_info, gi)
+                compare.assert_plan_equal(p, want, s, "%s of %d distros, %d tasks, queue %d, tick %d" % ("pair" if pair else "request", s.n_distros, s.n_tasks, qid, tick))
+                compare.assert_alloc_equal(a, wa, "request")
+                reqs += 1
+                tasks += s.n_tasks
         pools += 1
     st = b.stats()
 finally:
     b.close()
-print("soak_batcher: %d pools cut into %d requests (%d tasks) from %d threads, %d plan/allocate requests in %d batches (largest %d, %d direct): "
-      "every one equal to the oracle on the request alone" % (pools, reqs, tasks, n_threads, st["requests"], st["batches"], st["largest_batch"], st["direct_requests"]))
+print("soak_batcher: %d pools cut into %d requests (%d tasks; plan + allocate, pairs, resident queues; two ticks each) from %d threads, %d batcher requests in %d "
+      "batches (largest %d, %d direct; queue cache: %d fills, %d hits): every one equal to the oracle on the request alone" % (
+          pools, reqs, tasks, n_threads, st["requests"], st["batches"], st["largest_batch"], st["direct_requests"], st.get("cache_fills", 0), st.get("cache_hits", 0)))

@@ -2,8 +2,9 @@
 """Randomised soak of the resident pool's structural deltas: pools of random shape (tests/random_shapes.py), optionally with sparse,
 unordered keys (gen.sparsify_keys); each is cut into (pool0, delta) with random late / gone fractions (tests/pool_delta.py), loaded,
 brought forward by evg_pool_apply_delta -- then by a value update and a SECOND structural delta (the buffers swap back) -- and
-planned; every plan against the oracle on the host restatement's batch. GPU box only.
-usage: scripts/soak_delta.py [seconds] [seed]"""
+planned; every plan against the oracle on the host restatement's batch. GPU box only. With `fused` every other pool goes through
+evg_pool_tick (delta + updates + plan in ONE call, ABI 3.3) instead of the three calls.
+usage: scripts/soak_delta.py [seconds] [seed] [fused]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +13,8 @@ from evergreen_amd import gen, native
 from tests import compare, oracle_lib, pool_delta, random_shapes
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260923
+fused_mode = len(sys.argv) > 3 and sys.argv[3] == "fused"
+n_fused = 0
 rng = np.random.default_rng(seed)
 ctx, oracle = native.Context(0), oracle_lib.OracleBackend()
 t_end, k, tasks = time.time() + budget, 0, 0
@@ -24,9 +27,15 @@ while time.time() < t_end:
     pool0, d1, _, _ = pool_delta.split_tick(full, late, gone, seed=int(rng.integers(1, 1 << 30)), grow_keys=bool(rng.random() < 0.5))
     tag = "%r late %.2f gone %.2f" % (cfg, late, gone)
     ctx.pool_load(pool0)
-    ctx.pool_apply_delta(**d1.kwargs())
     pool1 = pool_delta.apply_delta(pool0, d1)
-    got = ctx.pool_plan(pool1, pool1.now_ns, breakdown=False, n_units=False, units=True)
+    fused = fused_mode and k % 2 == 0
+    if fused:
+        blk, keep = ctx.make_pool_delta(**d1.kwargs())
+        got = ctx.pool_tick(pool1, pool1.now_ns, delta=blk, units=True)
+        n_fused += 1
+    else:
+        ctx.pool_apply_delta(**d1.kwargs())
+        got = ctx.pool_plan(pool1, pool1.now_ns, breakdown=False, n_units=False, units=True)
     want = oracle.plan(pool1, breakdown=True, n_units=False)
     want.n_units = None
     got.breakdown = got.expand_breakdown()
@@ -35,16 +44,23 @@ while time.time() < t_end:
     if pool1.n_tasks > 20:
         rows = rng.choice(pool1.n_tasks, size=max(pool1.n_tasks // 10, 1), replace=False).astype(np.int32)
         pri = rng.integers(0, 100, len(rows)).astype(np.int64)
-        ctx.pool_update(rows=rows, cols={"priority": pri})
-        pool1.cols["priority"][rows] = pri
         _, d2, _, _ = pool_delta.split_tick(pool1, 0.0, float(rng.choice([0.02, 0.2])), seed=int(rng.integers(1, 1 << 30)), grow_keys=False)
-        ctx.pool_apply_delta(**d2.kwargs())
-        pool2 = pool_delta.apply_delta(pool1, d2)
-        got2 = ctx.pool_plan(pool2, pool2.now_ns + 15 * 10**9, breakdown=False, n_units=False)
+        if fused:  # the update first (a tick of its own), then delta + plan in one call
+            ctx.pool_tick(pool1, pool1.now_ns, update=ctx.make_pool_update(rows, {"priority": pri}))
+            pool1.cols["priority"][rows] = pri
+            pool2 = pool_delta.apply_delta(pool1, d2)
+            blk2, keep2 = ctx.make_pool_delta(**d2.kwargs())
+            got2 = ctx.pool_tick(pool2, pool2.now_ns + 15 * 10**9, delta=blk2)
+        else:
+            ctx.pool_update(rows=rows, cols={"priority": pri})
+            pool1.cols["priority"][rows] = pri
+            ctx.pool_apply_delta(**d2.kwargs())
+            pool2 = pool_delta.apply_delta(pool1, d2)
+            got2 = ctx.pool_plan(pool2, pool2.now_ns + 15 * 10**9, breakdown=False, n_units=False)
         import dataclasses
         want2 = oracle.plan(dataclasses.replace(pool2, now_ns=pool2.now_ns + 15 * 10**9), breakdown=False, n_units=False)
         want2.breakdown, want2.n_units = None, None
         compare.assert_plan_equal(got2, want2, pool2, tag + " (second delta)")
     k += 1
     tasks += full.n_tasks
-print("soak_delta: %d pools, %d tasks, every plan after a structural delta equal to the oracle on the restated batch" % (k, tasks))
+print("soak_delta: %d pools (%d through evg_pool_tick), %d tasks, every plan after a structural delta equal to the oracle on the restated batch" % (k, n_fused, tasks))

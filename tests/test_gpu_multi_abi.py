@@ -266,7 +266,7 @@ def test_resident_shards_selftest_and_failed_ticks(oracle):
         m.close()
 
 
-def test_resident_shards_refuse_a_dependency_on_another_ranks_row_and_a_broken_dep_off():
+def test_resident_shards_refuse_a_dependency_on_another_ranks_row_and_a_broken_dep_off(oracle):
     """an added row's dependency on a CURRENT row of a lower rank's range used to be re-based to a negative number and read as
     "not in the queue" / as an added row; a non-monotone added.dep_off sized a vector from a negative difference. Both are refused now, the
     first by the device (what evg_pool_apply_delta on one pool says about an edge across distros), the second before anything is sized."""
@@ -286,9 +286,14 @@ def test_resident_shards_refuse_a_dependency_on_another_ranks_row_and_a_broken_d
         edges = {k: (None if v is None else v.copy()) for k, v in delta.added_edges.items()}
         edges["dep_idx"][delta.added_dep_off[rows[0]]] = 0
         bad["added_edges"] = edges
-        with pytest.raises(native.NativeError, match="added edge"):
+        with pytest.raises(native.NativeError, match="added edge.*no rank's pool was changed"):
             m.apply_delta(pool0, **bad)
-        m.load(pool0)  # (the last rank refused: the ranks before it had applied their part)
+        # the LAST rank refused -- and the ranks before it did not apply their part either (round 6: every rank's verdict is read before
+        # any rank's buffers are swapped in): the object still plans the pool it had
+        m.poison_outputs()
+        m.tick()
+        want, want_alloc = _want(oracle, pool0)
+        _check(m, pool0, want, want_alloc, "resident shards after a delta the last rank refused")
         bad = dict(delta.kwargs())
         off = delta.added_dep_off.copy()
         if len(off) > 3:
@@ -296,5 +301,12 @@ def test_resident_shards_refuse_a_dependency_on_another_ranks_row_and_a_broken_d
         bad["added_dep_off"] = off
         with pytest.raises(native.NativeError, match="dep_off"):
             m.apply_delta(pool0, **bad)
+        # and the good delta still lands on every rank
+        pool1 = pool_delta.apply_delta(pool0, delta)
+        m.apply_delta(pool1, **delta.kwargs())
+        m.poison_outputs()
+        m.tick()
+        want, want_alloc = _want(oracle, pool1)
+        _check(m, pool1, want, want_alloc, "resident shards: the good delta after two refused ones")
     finally:
         m.close()

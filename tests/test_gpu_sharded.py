@@ -77,13 +77,19 @@ def test_config4_tick_through_rccl_one_rank(native_ctx, oracle):
     (== RCCL) with a world of one: the same device-resident code bench.py --gpus N runs, equal to config 3's plan."""
     import torch
     import torch.distributed as dist
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dev = torch.device("cuda:0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    for attempt in range(4):  # (a port that was free a moment ago can be taken when the store binds it: 1 in 40 back-to-back runs, profiles/r06e_hang_hunt.log)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            break
+        except Exception as e:  # noqa: BLE001
+            if "EADDRINUSE" not in str(e) or attempt == 3:
+                raise
     try:
         b = gen.generate(gen.config(4))
         pool = multi.ShardedPool(native_ctx, dev, breakdown=True)
