@@ -177,8 +177,9 @@ struct Slot {
   int32_t N = 0, E = 0, D = 0, TG = 0, V = 0, H = 0;
   uint32_t want = 0;
   bool any_fin = false;
-  std::chrono::steady_clock::time_point opened;
+  std::chrono::steady_clock::time_point opened, last_join;
   std::atomic<int> packed{0};
+  std::atomic<int> final_members{0};  // set when the batch closes (0: still open): the member whose packing completes it wakes the leader
   int unpacked = 0;
   std::condition_variable cv_lead;  // the leader's: a join, the last member's packing
   std::condition_variable cv_done;  // the members': the batch's results are in h_out
@@ -194,6 +195,7 @@ template <class BE>
 struct Batcher {
   int device = 0;
   int32_t max_wait_us = 200, max_requests = 64;
+  int32_t idle_us = 40;  // EVG_BATCHER_IDLE_US: a batch that has members closes when nobody joined for this long (arrivals have stopped)
   size_t max_batch_bytes = 32u << 20;  // of packed inputs per batch (EVG_BATCHER_MAX_BYTES); a request above half of it goes straight through
   int64_t deadline_ms = 30000;
   std::mutex mu;
@@ -332,8 +334,8 @@ static Slot<BE>* join_slot(Batcher<BE>* b, std::unique_lock<std::mutex>& lk, int
       }
       s.state = Slot<BE>::OPEN; s.kind = kind; s.members.clear(); s.in_used = 0;
       s.N = s.E = s.D = s.TG = s.V = s.H = 0; s.want = 0; s.any_fin = false;
-      s.packed.store(0); s.unpacked = 0; s.rc = EVG_OK; s.err.clear();
-      s.opened = std::chrono::steady_clock::now();
+      s.packed.store(0); s.final_members.store(0); s.unpacked = 0; s.rc = EVG_OK; s.err.clear();
+      s.opened = s.last_join = std::chrono::steady_clock::now();
       *leader = true;
       return &s;
     }
@@ -533,6 +535,10 @@ static inline void wait_until_steady(std::condition_variable& cv, std::unique_lo
 template <class BE>
 static void lead(Batcher<BE>* b, Slot<BE>& s) {
   using clk = std::chrono::steady_clock;
+  static const bool timing = getenv("EVG_BATCHER_TIMING") != nullptr;  // one line per batch on stderr: where its life went
+  const auto t_lead = clk::now();
+  auto us = [](clk::time_point a, clk::time_point b_) { return std::chrono::duration<double, std::micro>(b_ - a).count(); };
+  clk::time_point t_closed, t_packed;
   int members;
   {
     std::unique_lock<std::mutex> lk(b->mu);
@@ -543,18 +549,30 @@ static void lead(Batcher<BE>* b, Slot<BE>& s) {
         if (&o != &s && o.kind == s.kind && (o.state == Slot<BE>::OPEN || o.state == Slot<BE>::CLOSED)) elsewhere += (int)o.members.size();
       const int target = std::max(1, std::min<int>(b->max_requests, b->expect[s.kind] - elsewhere));
       members = (int)s.members.size();
-      const bool timed_out = clk::now() >= deadline;
-      if (members >= b->max_requests || members >= target || s.in_used >= b->max_batch_bytes / 2 || b->closing || timed_out) {
+      const auto now = clk::now();
+      const bool timed_out = now >= deadline;
+      // Arrivals have stopped: callers in lockstep -- the members of a batch that has just come back -- join within microseconds of
+      // each other; when nobody joined for idle_us the rest of the window would only add latency (round 6: the leader used to wait out
+      // max_wait_us whenever fewer callers than `expect` showed up -- 200 of a batch's ~400 us with 64 closed-loop callers).
+      const auto idle_at = s.last_join + std::chrono::microseconds(b->idle_us);
+      const bool idle = now >= idle_at;
+      if (members >= b->max_requests || members >= target || s.in_used >= b->max_batch_bytes / 2 || b->closing || timed_out || idle) {
         if (timed_out && members < target) b->expect[s.kind] = std::max(members + elsewhere, b->expect[s.kind] / 2);  // fewer callers than it thought
         break;
       }
-      wait_until_steady(s.cv_lead, lk, deadline);
+      wait_until_steady(s.cv_lead, lk, std::min(deadline, idle_at));
     }
     s.state = Slot<BE>::CLOSED;  // membership is final
+    s.final_members.store(members);
     b->cv_free.notify_all();     // whoever waits for an open slot may open another one now
-    s.cv_lead.wait(lk, [&] { return s.packed.load(std::memory_order_acquire) >= members; });
+    t_closed = clk::now();
+    s.cv_lead.wait(lk, [&] { return s.packed.load() >= members; });
+    t_packed = clk::now();
   }
   int rc = run_batch(b, s);
+  if (timing)
+    fprintf(stderr, "[batch] kind %d members %3d rows %7d: opened->leader %6.0f  window %6.0f  packing %6.0f  device %6.0f us\n", s.kind, members, (int)s.N,
+            us(s.opened, t_lead), us(t_lead, t_closed), us(t_closed, t_packed), us(t_packed, clk::now()));
   {
     std::lock_guard<std::mutex> lk(b->mu);
     s.rc = rc;
@@ -578,8 +596,13 @@ static void lead(Batcher<BE>* b, Slot<BE>& s) {
 // A member has packed its columns.
 template <class BE>
 static void packed_one(Batcher<BE>* b, Slot<BE>& s) {
-  s.packed.fetch_add(1, std::memory_order_release);
-  std::lock_guard<std::mutex> lk(b->mu);  // (the leader checks the counter under the mutex: no lost wake-up)
+  // Only the member whose packing completes a CLOSED batch has somebody to wake; the others do not touch the mutex. final_members is 0
+  // while the batch is open. Sequentially consistent on both sides (this increment / that load here; the leader's store of
+  // final_members / its load of `packed` under the mutex): either this member sees the batch closed, or the leader sees its increment.
+  const int done = s.packed.fetch_add(1) + 1;
+  const int fin = s.final_members.load();
+  if (fin == 0 || done < fin) return;
+  std::lock_guard<std::mutex> lk(b->mu);
   if (s.state == Slot<BE>::CLOSED) s.cv_lead.notify_one();
 }
 
@@ -626,6 +649,8 @@ static B* batcher_create(int device_ordinal, int32_t max_wait_us, int32_t max_re
     if (!b->cache_cap) b->cache_failed = true;  // 0: no queue cache
   }
   if (const char* m = getenv("EVG_DEADLINE_MS")) { const long long v = atoll(m); if (v >= 0) b->deadline_ms = v; }
+  if (const char* m = getenv("EVG_BATCHER_IDLE_US")) { const long long v = atoll(m); if (v >= 0) b->idle_us = (int32_t)std::min<long long>(v, 1000000); }
+  b->idle_us = std::min(b->idle_us, b->max_wait_us);
   b->direct = BE::dev_create(device_ordinal);
   bool ok = b->direct != nullptr;
   for (Slot<BE>& s : b->slot) {
@@ -724,6 +749,7 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
   }
   if (m.nd == 0) return EVG_OK;
   CacheEntry* hit = nullptr;
+  std::unique_lock<std::mutex> jl(b->mu, std::defer_lock);  // the join's lock
   if (plan) {
     if (!pout->order || !pout->deps_met || !pout->wait_ns || !pout->distro_info || !pout->group_info)
       return fail(err, err_len, EVG_E_INVALID, "order, deps_met, wait_ns, distro_info and group_info outputs are required");
@@ -731,7 +757,7 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
       return fail(err, err_len, EVG_E_INVALID, "unit_of_task and unit_breakdown come together (both or neither)");
     m.want = (pout->breakdown ? W_BREAKDOWN : 0) | (pout->n_units ? W_NUNITS : 0) | (pout->unit_of_task ? W_UNITS : 0);
     if (queue_id) {  // the same queue as last time? Then its columns are on the device already, checked when they went there
-      std::lock_guard<std::mutex> lk(b->mu);
+      jl.lock();     // (a hit keeps the mutex until it has joined its batch: one acquisition per request instead of two)
       auto it = b->cache.find(queue_id);
       if (it != b->cache.end() && it->second->ready && it->second->generation == generation) {
         CacheEntry* en = it->second;
@@ -742,6 +768,7 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
         hit->pins++;  // released below if the request never joins a batch, by the batch's leader otherwise
         m.hint_max = en->hint_max; m.hint_promises = en->hint_promises; m.hint_big = en->hint_big;
       }
+      if (!hit) jl.unlock();
     }
     if (!hit) {
       char msg[256];
@@ -751,7 +778,7 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
       if (rc) return fail(err, err_len, rc, "invalid plan input");
     }
   }
-  auto unpin = [&] { if (hit) { std::lock_guard<std::mutex> lk(b->mu); hit->pins--; } };
+  auto unpin = [&] { if (hit) { if (!jl.owns_lock()) jl.lock(); hit->pins--; jl.unlock(); } };
   const size_t n = m.n, e = m.e, nd = m.nd, nh = m.nh, ntg = m.ntg;
   size_t bytes = plan ? al16(nd * 8) : 0;  // the clock readings
   m.cols_off = bytes;
@@ -789,7 +816,8 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
   bool leader = false;
   Slot<BE>* sp;
   {
-    std::unique_lock<std::mutex> lk(b->mu);
+    if (!jl.owns_lock()) jl.lock();
+    std::unique_lock<std::mutex>& lk = jl;
     b->inside_kind[kind]++;
     in_call.batching(kind);
     int why = 0;
@@ -816,8 +844,10 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
       }
     }
     s.members.push_back(m);
+    s.last_join = std::chrono::steady_clock::now();
     b->expect[kind] = std::max(b->expect[kind], b->inside_kind[kind]);
     if (!leader) s.cv_lead.notify_one();
+    jl.unlock();
   }
   Slot<BE>& s = *sp;
   // ---- pack: the request's columns as they are (the segment kernel re-bases them into the batch's numbering) ----
