@@ -9,6 +9,9 @@
 # Everything lands in gpurun_out/<tag>_*; what is worth keeping is copied to profiles/ by hand.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT/prof; cd $R; export PYTHONPATH=$R
 TAG=${1:-r06z}
+# 0 the driver's own sequence first: the whole GPU suite in ONE process, smoke(), then (2) its bench command
+timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/${TAG}_driver_suite.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $OUT/${TAG}_driver_suite.log
 bash scripts/gpu_suite.sh $TAG 200
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>$OUT/${TAG}_bench.err | tail -n 1 > $OUT/${TAG}_bench.log; tail -c 300 $OUT/${TAG}_bench.log
 PROFILE_ONLY=1 C5=1 bash scripts/gpu_round.sh $TAG 2>&1 | tail -60 > $OUT/${TAG}_round.log
