@@ -169,6 +169,7 @@ struct Slot {
   typename BE::Dev* dev = nullptr;
   unsigned char *h_in = nullptr, *h_out = nullptr;  // page-locked
   size_t h_in_cap = 0, h_out_cap = 0;
+  std::vector<void*> parked;       // outgrown page-locked blocks (grow_host)
   enum State { FREE, OPEN, CLOSED, DONE } state = FREE;
   bool dead = false;               // its device wait outlived the deadline: never opened again
   int kind = K_PLAN;
@@ -230,12 +231,14 @@ static inline int fail(char* err, int32_t err_len, int code, const char* fmt, ..
   return code;
 }
 
+// (An outgrown block is parked in `parked` until the batcher is destroyed: freeing page-locked memory synchronises the whole device,
+// i.e. waits -- without a limit -- for whatever hangs on any stream of the process.)
 template <class BE>
-static bool grow_host(unsigned char*& p, size_t& cap, size_t need) {
+static bool grow_host(unsigned char*& p, size_t& cap, size_t need, std::vector<void*>& parked) {
   if (need <= cap) return true;
-  if (p) BE::host_free(p);
+  if (p) parked.push_back(p);
   p = nullptr; cap = 0;
-  const size_t want = need + need / 4 + 4096;
+  const size_t want = need + need / 2 + 4096;
   p = (unsigned char*)BE::host_alloc(want);
   if (!p) return false;
   cap = want;
@@ -328,7 +331,7 @@ static Slot<BE>* join_slot(Batcher<BE>* b, std::unique_lock<std::mutex>& lk, int
       Slot<BE>& s = *free_slot;
       // the page-locked input block, whole, when the slot is first opened: members pack into it while others still join, so it
       // must never move afterwards
-      if (!s.h_in && !grow_host<BE>(s.h_in, s.h_in_cap, b->max_batch_bytes + (1u << 20) + (size_t)b->max_requests * (PC_COUNT + AC_COUNT + 2) * sizeof(Seg))) {
+      if (!s.h_in && !grow_host<BE>(s.h_in, s.h_in_cap, b->max_batch_bytes + (1u << 20) + (size_t)b->max_requests * (PC_COUNT + AC_COUNT + 2) * sizeof(Seg), s.parked)) {
         *why = 3;
         return nullptr;
       }
@@ -387,7 +390,7 @@ static int run_batch(Batcher<BE>* b, Slot<BE>& s) {
   const size_t out_bytes = off - out_base;
   unsigned char* A = nullptr;
   if (int rc = BE::arena(s.dev, off, &A)) { s.err = BE::dev_error(s.dev); return rc; }
-  if (!grow_host<BE>(s.h_out, s.h_out_cap, out_bytes)) { s.err = "cannot grow the batch's page-locked output block"; return EVG_E_NOMEM; }
+  if (!grow_host<BE>(s.h_out, s.h_out_cap, out_bytes, s.parked)) { s.err = "cannot grow the batch's page-locked output block"; return EVG_E_NOMEM; }
   // ---- the segment table ----
   Seg* segs = at<Seg>(s.h_in, seg_off);
   size_t ns = 0, max_seg = 0;
@@ -685,6 +688,7 @@ static void batcher_destroy(B* b) {
     if (s.dev) BE::dev_destroy(s.dev);
     if (s.h_in) BE::host_free(s.h_in);
     if (s.h_out) BE::host_free(s.h_out);
+    for (void* q : s.parked) BE::host_free(q);
   }
   if (b->direct) BE::dev_destroy(b->direct);
   for (auto& kv : b->cache) delete kv.second;

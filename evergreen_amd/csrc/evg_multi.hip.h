@@ -377,7 +377,7 @@ static int resident_layout(evg_multi* m) {
   Rank& root = m->r[0];
   EVGM_HIP(m, hipSetDevice(root.device));
   if (o.total > m->out_cap || !root.out) {
-    if (root.out) EVGM_HIP(m, hipFree(root.out));
+    if (root.out) root.ctx->dead_dev.push_back(root.out);  // (not hipFree on the way into a tick: evg_ctx::dead_dev)
     root.out = nullptr;
     EVGM_HIP(m, hipMalloc((void**)&root.out, o.total + o.total / 8));
     m->out_cap = o.total + o.total / 8;
@@ -395,7 +395,7 @@ static int resident_layout(evg_multi* m) {
     r.ol.total = p2 + kAlign;
     EVGM_HIP(m, hipSetDevice(r.device));
     if (r.ol.total > r.outl_cap || !r.outl) {
-      if (r.outl) EVGM_HIP(m, hipFree(r.outl));
+      if (r.outl) r.ctx->dead_dev.push_back(r.outl);
       r.outl = nullptr;
       EVGM_HIP(m, hipMalloc((void**)&r.outl, r.ol.total + r.ol.total / 8));
       r.outl_cap = r.ol.total + r.ol.total / 8;
@@ -448,7 +448,7 @@ static int resident_hosts(evg_multi* m, const evg_alloc_input* alloc) {
     }
     EVGM_HIP(m, hipSetDevice(r.device));
     if (total > r.abuf_cap || !r.abuf) {
-      if (r.abuf) EVGM_HIP(m, hipFree(r.abuf));
+      if (r.abuf) r.ctx->dead_dev.push_back(r.abuf);
       r.abuf = nullptr;
       EVGM_HIP(m, hipMalloc((void**)&r.abuf, total + total / 4 + 256));
       r.abuf_cap = total + total / 4 + 256;
@@ -725,7 +725,7 @@ int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input
   const size_t D = L.D, N = L.N, G = D + L.TG;
   // ---- the packed pool on the host ----
   if (L.total > m->packed_cap) {
-    if (m->packed_h) (void)hipHostFree(m->packed_h);
+    if (m->packed_h) m->r[0].ctx->dead_host.push_back(m->packed_h);  // (freed with rank 0's context: evg_ctx::dead_dev)
     m->packed_h = nullptr; m->packed_cap = 0;
     EVGM_HIP(m, hipSetDevice(m->r[0].device));
     EVGM_HIP(m, hipHostMalloc((void**)&m->packed_h, L.total + L.total / 8, hipHostMallocDefault));
@@ -779,12 +779,12 @@ int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input
     r.d0 = cuts[k]; r.d1 = cuts[k + 1];
     EVGM_HIP(m, hipSetDevice(r.device));
     if (L.total > m->buf_cap || !r.buf) {
-      if (r.buf) EVGM_HIP(m, hipFree(r.buf));
+      if (r.buf) r.ctx->dead_dev.push_back(r.buf);
       r.buf = nullptr;
       EVGM_HIP(m, hipMalloc((void**)&r.buf, L.total + L.total / 8));
     }
     if (o.total > m->out_cap || !r.out) {
-      if (r.out) EVGM_HIP(m, hipFree(r.out));
+      if (r.out) r.ctx->dead_dev.push_back(r.out);
       r.out = nullptr;
       EVGM_HIP(m, hipMalloc((void**)&r.out, o.total + o.total / 8));
     }

@@ -457,6 +457,11 @@ struct evg_ctx {
   // set by the micro-batching front around its own launches (evg_batcher.hip.h): per-distro clock readings / allocator tick rows
   const int64_t* now_d = nullptr;
   const void* tick_d = nullptr;
+  // Buffers a growing batch has outgrown. hipFree / hipHostFree synchronise the WHOLE device -- every stream of every context of the
+  // process -- so a buffer freed on the way into a call would make that call wait, without a limit, for whatever hangs on any other
+  // stream (round 6: a batch on one slot of the batcher sat 1.5 s inside ensure() behind a stall on ANOTHER slot's stream, past its 300 ms
+  // deadline). They are parked here and freed by evg_destroy; buffers grow by half, so at most ~3x the largest size is ever parked.
+  std::vector<void*> dead_dev, dead_host;
   // bounded calls (evg_set_deadline_ms): every device wait polls against this; once one expired the context refuses work
   int64_t deadline_ms = 30000;
   bool timed_out = false;
@@ -490,10 +495,10 @@ static int set_err(evg_ctx* c, int code, const char* fmt, ...) {
 
 static int ensure(evg_ctx* c, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return EVG_OK;
-  if (b.p) HIP_TRY(c, hipFree(b.p));
+  if (b.p) c->dead_dev.push_back(b.p);  // not hipFree: it would wait for every stream of the process (evg_ctx::dead_dev)
   b.p = nullptr;
   b.cap = 0;
-  size_t want = bytes + bytes / 8 + 256;
+  size_t want = bytes + bytes / 2 + 256;
   HIP_TRY(c, hipMalloc(&b.p, want));
   b.cap = want;
   return EVG_OK;
@@ -553,7 +558,7 @@ struct Stager {
   int rc = EVG_OK;
   // packed mode: inputs are memcpy'd into the context's page-locked block and leave in ONE H2D copy (flush_in); outputs are
   // carved out of the same device block behind them and come back in ONE D2H copy (flush_out), then to the caller's buffers
-  bool packed = false;
+  bool packed = false, waited = false;
   size_t in_off = 0, in_cap = 0, out_off = 0;
   struct Down { void* host; size_t off, bytes; };
   std::vector<Down> downs;
@@ -564,11 +569,11 @@ struct Stager {
     in_bytes = al(in_bytes);  // the outputs start behind the inputs: aligned like everything else (scalar loads ignore low address bits)
     const size_t need = in_bytes + out_bytes;
     if (need > c->pack_cap) {
-      if (c->pack_h) (void)hipHostFree(c->pack_h);
-      if (c->pack_d) (void)hipFree(c->pack_d);
+      if (c->pack_h) c->dead_host.push_back(c->pack_h);  // (freed by evg_destroy: see evg_ctx::dead_dev)
+      if (c->pack_d) c->dead_dev.push_back(c->pack_d);
       c->pack_h = c->pack_d = nullptr;
       c->pack_cap = 0;
-      const size_t want = need + need / 4 + 4096;
+      const size_t want = need + need / 2 + 4096;
       if (hipHostMalloc((void**)&c->pack_h, want, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&c->pack_d, want) != hipSuccess)
         return rc = set_err(c, EVG_E_NOMEM, "cannot allocate the %zu-byte staging blocks", want);
       c->pack_cap = want;
@@ -623,6 +628,9 @@ struct Stager {
   void down(T* h, const T* dptr, size_t count) {
     if (rc || !h || !dptr || count == 0) return;
     if (packed) { downs.push_back({(void*)h, (size_t)((const unsigned char*)dptr - c->pack_d), count * sizeof(T)}); return; }
+    // Into the caller's own memory: when that is pageable, hipMemcpyAsync only returns once the data has arrived -- behind everything
+    // the stream still has to do, without a limit. So the stream is waited for first, within the deadline: the copies then only move bytes.
+    if (!waited) { waited = true; if ((rc = wait_stream(c, c->stream, "results"))) return; }
     if (hipMemcpyAsync(h, dptr, count * sizeof(T), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
       rc = set_err(c, EVG_E_HIP, "D2H copy failed");
   }
@@ -766,6 +774,9 @@ void evg_destroy(evg_ctx* c) {
     if (idle && c->side2) idle = wait_stream(c, c->side2, "evg_destroy") == EVG_OK;
     if (!idle) { delete c; return; }
   }
+  for (void* q : c->dead_dev) (void)hipFree(q);
+  for (void* q : c->dead_host) (void)hipHostFree(q);
+  for (auto& b : c->tick_out) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->stage) if (b.p) (void)hipFree(b.p);
   for (auto& b : c->pool) if (b.p) (void)hipFree(b.p);
