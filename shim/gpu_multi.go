@@ -22,6 +22,7 @@ import "C"
 import (
 	"context"
 	"sync"
+	"sync/atomic"
 
 	"github.com/evergreen-ci/evergreen/model"
 	"github.com/evergreen-ci/evergreen/model/distro"
@@ -47,6 +48,7 @@ type gpuMulti struct {
 	m      *C.evg_multi
 	n      int
 	closed bool // SetGPUDevices replaced this object: a planBatch that still holds it falls back to one device
+	dead   atomic.Bool // a tick outlived its deadline (EVG_E_TIMEOUT): the library refuses the object; shardFor skips it
 }
 
 // SetGPUDevices is the EXPLICIT opt-in to multi-device planning, called once at start-up (one device is the default and needs no
@@ -83,6 +85,7 @@ func SetGPUDevices(devs []int) error {
 	if m == nil {
 		return errors.Errorf("evg_multi_create: %s; planning stays on device %d", C.GoString(C.evg_multi_last_error(nil)), gpuDevices[0])
 	}
+	C.evg_multi_set_deadline_ms(m, C.int64_t(gpuDeadlineMS)) // ABI 3.3: a tick that does not come back aborts the communicators by itself
 	if rc := C.evg_multi_selftest(m); rc != C.EVG_OK {
 		err := errors.Errorf("evg_multi_selftest over %d devices: %s (%d); planning stays on device %d", len(devs),
 			C.GoString(C.evg_multi_last_error(m)), int(rc), gpuDevices[0])
@@ -99,7 +102,7 @@ func shardFor(n, D int) (*gpuMulti, error) {
 	gpuDevicesMu.Lock()
 	defer gpuDevicesMu.Unlock()
 	k := len(gpuDevices)
-	if gpuShard == nil || k < 2 || D < k || n < k*minTasksPerDevice {
+	if gpuShard == nil || gpuShard.dead.Load() || k < 2 || D < k || n < k*minTasksPerDevice {
 		return nil, nil
 	}
 	return gpuShard, nil
@@ -117,7 +120,14 @@ func (s *gpuMulti) plan(in *C.evg_plan_input, out *C.evg_plan_output) error {
 		return errors.Errorf("evg_multi_load: %s (%d)", C.GoString(C.evg_multi_last_error(s.m)), int(rc))
 	}
 	if rc := C.evg_multi_tick(s.m, in.now_ns); rc != C.EVG_OK {
-		return errors.Errorf("evg_multi_tick: %s (%d)", C.GoString(C.evg_multi_last_error(s.m)), int(rc))
+		err := errors.Errorf("evg_multi_tick: %s (%d)", C.GoString(C.evg_multi_last_error(s.m)), int(rc))
+		if rc == C.EVG_E_TIMEOUT { // a device wait outlived the deadline: the object refuses further ticks -- planning goes on on one device
+			s.closed = true // (planBatch falls back to evg_plan_distros on errGPUShardClosed; SetGPUDevices may build a new one)
+			go func(m *C.evg_multi) { C.evg_multi_destroy(m) }(s.m)
+			s.m = nil           // (SetGPUDevices destroys old.m under this lock: evg_multi_destroy(NULL) is a no-op)
+			s.dead.Store(true)  // shardFor skips it from now on (no gpuDevicesMu here: SetGPUDevices takes the two locks in the other order)
+		}
+		return err
 	}
 	if rc := C.evg_multi_results(s.m, out, nil); rc != C.EVG_OK {
 		return errors.Errorf("evg_multi_results: %s (%d)", C.GoString(C.evg_multi_last_error(s.m)), int(rc))
