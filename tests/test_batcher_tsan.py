@@ -43,3 +43,16 @@ def test_queue_cache_eviction_under_tsan(exe):
     import re
     m = re.search(r"cache (\d+) fills / (\d+) hits / (\d+) queues / (\d+) bytes", out)
     assert m and int(m.group(4)) <= (1 << 20) and int(m.group(3)) < 100, out[-2000:]  # ~5 MB of queues through a 1 MiB cache
+
+
+def test_state_machine_clean_under_asan_ubsan():
+    """The same driver under AddressSanitizer + UndefinedBehaviorSanitizer (leak check on): the segment table, the queue cache's blocks, the
+    members' stretches of the batch block and the slots' parked buffers are all carved by hand."""
+    exe = EXE + "_asan"
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in DEPS):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-pthread", "-I",
+                               os.path.join(ROOT, "include")] + SRC + ["-o", exe])
+    for env in ({}, {"EVG_BATCHER_CACHE_BYTES": str(1 << 20), "TSAN_QUEUE_TASKS": "700"}):
+        r = subprocess.run([exe, "24", "8", "5"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", **env), timeout=900)
+        out = r.stdout + r.stderr
+        assert r.returncode == 0 and " 0 failures" in out and "Sanitizer" not in out and "runtime error" not in out, out[-4000:]
