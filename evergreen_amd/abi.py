@@ -310,7 +310,7 @@ class PlanResult:
     order: np.ndarray
     breakdown: Optional[np.ndarray]
     deps_met: np.ndarray
-    wait_ns: np.ndarray
+    wait_ns: Optional[np.ndarray]
     distro_info: np.ndarray
     group_info: np.ndarray
     n_units: Optional[np.ndarray]
@@ -323,7 +323,7 @@ class PlanResult:
         return np.ascontiguousarray(self.unit_breakdown[:, self.unit_of_task].T)
 
     @staticmethod
-    def alloc_host(batch: PlanBatch, breakdown=True, n_units=True, units=False) -> "PlanResult":
+    def alloc_host(batch: PlanBatch, breakdown=True, n_units=True, units=False, wait=True) -> "PlanResult":
         n, d, g = batch.n_tasks, batch.n_distros, batch.n_task_groups
         nslots = n + g + int(batch.ver_off[-1])
         return PlanResult(
@@ -331,7 +331,7 @@ class PlanResult:
             unit_breakdown=np.zeros((BREAKDOWN_FIELDS, nslots), np.int64) if units else None,
             order=np.full(n, -1, np.int32),
             breakdown=np.zeros((n, BREAKDOWN_FIELDS), np.int64) if breakdown else None,
-            deps_met=np.zeros(n, np.uint8), wait_ns=np.zeros(n, np.int64),
+            deps_met=np.zeros(n, np.uint8), wait_ns=np.zeros(n, np.int64) if wait else None,  # None: resident entry points only
             distro_info=np.zeros(d, DISTRO_INFO_DTYPE), group_info=np.zeros(d + g, GROUP_INFO_DTYPE),
             n_units=np.zeros(d, np.int32) if n_units else None)
 

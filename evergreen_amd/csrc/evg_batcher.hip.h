@@ -58,7 +58,8 @@ struct HipBackend {
       idle = wait_stream(d->ctx, d->ctx->stream, "evg_batcher_destroy") == EVG_OK;
       d->ctx->timed_out = !idle;
     }
-    if (idle && d->arena.p) (void)hipFree(d->arena.p);
+    // (hipFree waits for the whole device: not behind a hang on another object's stream either -- evgreg; leaked otherwise)
+    if (idle && d->arena.p && evgreg::quiesced_within(d->ctx->device, d->ctx->deadline_ms)) (void)hipFree(d->arena.p);
     evg_destroy(d->ctx);
     delete d;
   }
@@ -69,13 +70,27 @@ struct HipBackend {
     void* p = nullptr;
     return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
   }
-  static void host_free(void* p) { (void)hipHostFree(p); }
+  // hipHostFree / hipFree wait for the whole device, without a limit: only behind evgreg's bounded look at the device's streams (the
+  // batcher's own contexts have been destroyed -- or leaked -- by then); a block behind a hang is leaked with it
+  static int64_t free_deadline_ms() {
+    static const int64_t v = [] { const char* e = getenv("EVG_DEADLINE_MS"); const long long x = e ? atoll(e) : 30000; return (int64_t)(x >= 0 ? x : 30000); }();
+    return v;
+  }
+  static void host_free(void* p) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || !evgreg::quiesced_within(dev, free_deadline_ms())) return;
+    (void)hipHostFree(p);
+  }
   static void* cache_alloc(int device, size_t bytes) {
     void* p = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
   }
-  static void cache_free(int device, void* p) { (void)hipSetDevice(device); (void)hipFree(p); }
+  static void cache_free(int device, void* p) {
+    (void)hipSetDevice(device);
+    if (!evgreg::quiesced_within(device, free_deadline_ms())) return;
+    (void)hipFree(p);
+  }
   static int launch_hints(const evg_plan_input* in, int32_t* a, int32_t* b, int32_t* c) { return evg_plan_launch_hints(in, a, b, c); }
   static int direct_plan(Dev* d, const evg_plan_input* in, const evg_plan_output* out) { return evg_plan_distros(d->ctx, in, out); }
   static int direct_alloc(Dev* d, const evg_alloc_input* in, const evg_alloc_output* out) { return evg_allocate_hosts(d->ctx, in, out); }

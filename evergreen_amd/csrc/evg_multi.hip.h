@@ -323,23 +323,53 @@ static void out_slices(const evg_multi* m, int k, std::vector<Slice>& out) {
     for (int q = 0; q < 3; q++) add(o.alloc, 4, q * L.D + r.d0, q * L.D + r.d1);
 }
 
-static void free_rank(Rank& r) {
+// Round 6: destruction is bounded like every other call. hipFree / hipStreamDestroy / hipEventDestroy / ncclCommDestroy wait without a
+// limit -- hipFree for the WHOLE device, every rank's streams on it -- so they are only reached when a bounded wait has found every rank
+// of that device idle (free_ranks); otherwise the device's ranks keep their buffers, streams and events (leaked), their communicators
+// are aborted instead of destroyed, and their contexts are destroyed as timed-out ones (which leak too). Seen on one box of the pool
+// (LAB_NOTES 6.7): a multi-device test whose tick had timed out sat in evg_multi_destroy's first hipFree until pytest's own timeout
+// ended the run. Returns false when the rank was leaked.
+static bool free_rank(Rank& r, bool leak) {
   if (!r.ctx) {  // evg_create refused the device (a bad ordinal): nothing was allocated on it, and hipSetDevice on it would leave a
     r = Rank{};  // sticky "invalid device ordinal" behind for the next hipGetLastError of this thread
-    return;
+    return true;
   }
   (void)hipSetDevice(r.device);
-  if (ncclComm_t c = __atomic_exchange_n(&r.comm, (ncclComm_t) nullptr, __ATOMIC_ACQ_REL)) (void)g_rccl.CommDestroy(c);
+  if (ncclComm_t c = __atomic_exchange_n(&r.comm, (ncclComm_t) nullptr, __ATOMIC_ACQ_REL)) {
+    if (!leak || !g_rccl.CommAbort) (void)g_rccl.CommDestroy(c);
+    else (void)g_rccl.CommAbort(c);
+  }
+  if (leak) {
+    r.ctx->timed_out = true;
+    r.ctx->deadline_ms = 1;  // evg_destroy looks once more, briefly, and leaks
+    evg_destroy(r.ctx);
+    r = Rank{};
+    return false;
+  }
   if (r.buf) (void)hipFree(r.buf);
   if (r.out) (void)hipFree(r.out);
   if (r.outl) (void)hipFree(r.outl);
   if (r.abuf) (void)hipFree(r.abuf);
   for (hipEvent_t& e : r.ev) if (e) (void)hipEventDestroy(e);
-  if (r.stream) (void)hipStreamDestroy(r.stream);
+  if (r.stream) { evgreg::remove(r.stream); (void)hipStreamDestroy(r.stream); }
   if (r.ctx) evg_destroy(r.ctx);
   r = Rank{};
+  return true;
 }
-
+// Every rank of the object. A device that has not finished what its streams -- this object's or anyone's (evgreg) -- hold within the
+// deadline keeps what this object has on it. Returns true when nothing was leaked.
+static bool free_ranks(std::vector<Rank>& rs, int64_t deadline_ms) {
+  std::vector<int> seen, busy_dev;
+  for (Rank& r : rs) {
+    if (!r.ctx || std::find(seen.begin(), seen.end(), r.device) != seen.end()) continue;
+    seen.push_back(r.device);
+    (void)hipSetDevice(r.device);
+    if (!evgreg::quiesced_within(r.device, deadline_ms)) busy_dev.push_back(r.device);
+  }
+  bool clean = true;
+  for (Rank& r : rs) clean = free_rank(r, std::find(busy_dev.begin(), busy_dev.end(), r.device) != busy_dev.end()) && clean;
+  return clean;
+}
 
 // ---- EVG_MULTI_RESIDENT_SHARDS: every rank keeps ITS distro range resident ----------------------------------------------------------
 // The tick north_star describes starts from a pool on one rank, so its broadcast (84.6 MB for config 4, 927 MB for config 5)
@@ -651,7 +681,7 @@ evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t f
   m->r.resize(n_devices);
   auto fail = [&]() -> evg_multi* {
     g_multi_err = m->err;
-    for (Rank& r : m->r) free_rank(r);
+    (void)free_ranks(m->r, m->deadline_ms);
     delete m;
     return nullptr;
   };
@@ -661,6 +691,7 @@ evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t f
     r.ctx = evg_create(devices[k]);
     if (!r.ctx) { m->err = evg_last_error(nullptr); return fail(); }
     if (hipSetDevice(r.device) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess) { m->err = "cannot create a stream"; return fail(); }
+    evgreg::add(r.device, r.stream);
     for (hipEvent_t& e : r.ev)
       if (hipEventCreate(&e) != hipSuccess) { m->err = "cannot create an event"; return fail(); }
   }
@@ -678,8 +709,9 @@ evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t f
 
 void evg_multi_destroy(evg_multi* m) {
   if (!m) return;
-  for (evgm::Rank& r : m->r) evgm::free_rank(r);
-  if (m->packed_h) (void)hipHostFree(m->packed_h);
+  // a rank that has not come back within the deadline is leaked, and so is the page-locked block (hipHostFree waits for the device)
+  const bool all_idle = evgm::free_ranks(m->r, m->deadline_ms);
+  if (m->packed_h && all_idle) (void)hipHostFree(m->packed_h);
   delete m;
 }
 

@@ -13,7 +13,7 @@
 //   k_scan_*         exclusive scan of the edge counts = the new dep_off
 //   k_delta_edges    every row's edges copied; an edge that pointed at a removed row becomes an out-of-queue edge carrying the
 //                    removed task's state (the REQUIRED status of the edge is the dependent's and stays); an out-of-queue edge
-//                    whose dependency enters the queue with this delta is pointed at that added row (k_delta_relink)
+//                    whose dependency enters the queue with this delta is pointed at that added row (k_delta_added_relink)
 //
 // Survivors keep their relative order inside their distro; added rows follow them in the order given. The result is bit for bit the
 // batch a caller would have uploaded for the same rows in that order (tests/test_gpu_pool_delta.py).
@@ -45,36 +45,18 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_block_sums(const int32_t* v
     bsum[blockIdx.x] = t;
   }
 }
-// One workgroup: bsum[0..nb) -> its exclusive prefix sums in place, bsum[nb] = the total.
-__global__ void __launch_bounds__(kScanBlock) k_scan_bsums(int32_t* bsum, int nb) {
-  __shared__ int s_v[kScanBlock];
-  __shared__ int s_carry;
-  const int tid = threadIdx.x;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int b0 = 0; b0 < nb; b0 += kScanBlock) {
-    const int x = b0 + tid < nb ? bsum[b0 + tid] : 0;
-    s_v[tid] = x;
-    __syncthreads();
-    for (int off = 1; off < kScanBlock; off <<= 1) {  // Hillis-Steele: ten steps, once per 4 M rows
-      const int y = tid >= off ? s_v[tid - off] : 0;
-      __syncthreads();
-      s_v[tid] += y;
-      __syncthreads();
-    }
-    const int carry = s_carry;
-    if (b0 + tid < nb) bsum[b0 + tid] = carry + s_v[tid] - x;
-    __syncthreads();
-    if (tid == kScanBlock - 1) s_carry = carry + s_v[tid];
-    __syncthreads();
-  }
-  if (tid == 0) bsum[nb] = s_carry;
-}
-// out[i] = exclusive prefix of the scanned values, i < n; out[n] = the total. out may alias v only when !FLAG.
+// out[i] = exclusive prefix of the scanned values, i < n; out[n] = the total. out may alias v only when !FLAG. bsum: the RAW block sums
+// of k_scan_block_sums -- every block adds up the ones before it itself (a few loads per thread: a million rows are 245 blocks), which
+// took a one-workgroup launch between the two (round 6: the host's launch train is what a tick's re-pack waits for).
 template <bool FLAG>
 __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int32_t* v, int n, const int32_t* bsum, int nb, int32_t* out) {
   __shared__ int s_w[kScanBlock / 64];
+  __shared__ int s_b[kScanBlock / 64];
   const int tid = threadIdx.x, lane = tid & 63, base = blockIdx.x * kScanTile + tid * kScanPer;
+  int before = 0;
+  for (int b = tid; b < (int)blockIdx.x; b += kScanBlock) before += bsum[b];
+  before = (int)wave_sum((uint32_t)before);
+  if (lane == 0) s_b[tid >> 6] = before;
   int x[kScanPer], s = 0;
 #pragma unroll
   for (int q = 0; q < kScanPer; q++) { x[q] = scan_in<FLAG>(v, base + q, n); s += x[q]; }
@@ -89,7 +71,9 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int32_t* v, int
   incl += (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
   if (lane == 63) s_w[tid >> 6] = incl;
   __syncthreads();
-  int pre = bsum[blockIdx.x];
+  int pre = 0;
+#pragma unroll
+  for (int w = 0; w < kScanBlock / 64; w++) pre += s_b[w];
   for (int w = 0; w < (tid >> 6); w++) pre += s_w[w];
   pre += incl - s;
 #pragma unroll
@@ -97,7 +81,7 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int32_t* v, int
     if (base + q < n) out[base + q] = pre;
     pre += x[q];
   }
-  if (blockIdx.x == 0 && tid == 0) out[n] = bsum[nb];
+  if ((int)blockIdx.x == nb - 1 && tid == kScanBlock - 1) out[n] = pre;  // the last thread of the last block has walked past everything
 }
 
 // A scan that is ONE block (n <= kScanTile: the per-distro tables): block sums, their prefix and the apply step in one launch.
@@ -190,6 +174,44 @@ __global__ void __launch_bounds__(256) k_delta_counts(int D, const int32_t* old_
   cnt[d] = n;
 }
 
+// k_delta_counts and the one-block scan behind it in ONE launch (D <= kScanTile: always, in practice): cnt[0, D) = the new task_off,
+// cnt[D] = the new row count.
+__global__ void __launch_bounds__(kScanBlock) k_delta_counts_scan(int D, const int32_t* old_task_off, const int32_t* rem_cnt, const int32_t* add_before, int32_t* cnt,
+                                                                  int32_t* st) {
+  __shared__ int s_w[kScanBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, base = tid * kScanPer;
+  int x[kScanPer], s = 0;
+#pragma unroll
+  for (int q = 0; q < kScanPer; q++) {
+    const int d = base + q;
+    int n = 0;
+    if (d < D) {
+      n = (old_task_off[d + 1] - old_task_off[d]) - rem_cnt[d] + (add_before[d + 1] - add_before[d]);
+      if (n >= (1 << 24)) delta_fail(st, DS_DISTRO_SIZE, d);
+    }
+    x[q] = n; s += n;
+  }
+  int incl = s;
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+  const int r0 = __builtin_amdgcn_readlane(incl, 15), r1 = __builtin_amdgcn_readlane(incl, 31), r2 = __builtin_amdgcn_readlane(incl, 47);
+  const int row = lane >> 4;
+  incl += (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+  if (lane == 63) s_w[tid >> 6] = incl;
+  __syncthreads();
+  int pre = 0, total = 0;
+  for (int w = 0; w < kScanBlock / 64; w++) { pre += w < (tid >> 6) ? s_w[w] : 0; total += s_w[w]; }
+  pre += incl - s;
+#pragma unroll
+  for (int q = 0; q < kScanPer; q++) {
+    if (base + q < D) cnt[base + q] = pre;
+    pre += x[q];
+  }
+  if (tid == 0) cnt[D] = total;
+}
+
 struct TaskCols {  // the eleven per-task columns of evg_task_soa, mutable
   int64_t *priority, *expected_duration_ns, *queue_ts_ns, *scheduled_ts_ns, *deps_met_ts_ns;
   int32_t *num_dependents, *task_group_order, *task_group_max_hosts, *tg_key, *version_key;
@@ -247,17 +269,6 @@ __global__ void __launch_bounds__(256) k_delta_rows(int n_new, int D, const int3
     cnt[q] = c < 0 ? 0 : c;
   }
 }
-// Where every added row goes: behind the kept rows of its distro, in the order given. added_dst[i] for the edge kernel, src[] for the rows.
-__global__ void __launch_bounds__(256) k_delta_src_added(int n_added, const int32_t* added_distro, const int32_t* add_before, const int32_t* new_task_off,
-                                                         int32_t* added_dst, int32_t* src, int n_new) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_added) return;
-  const int d = added_distro[i];
-  const int q = new_task_off[d + 1] - (add_before[d + 1] - add_before[d]) + (i - add_before[d]);
-  added_dst[i] = q < n_new ? q : 0;
-  if (q < n_new) src[q] = -(i + 1);
-}
-
 struct EdgeCols {
   int32_t* dep_idx;
   uint8_t* dep_info;            // may be null on the OLD side (a pool loaded without it: all zero), like the next one
@@ -328,18 +339,35 @@ __global__ void __launch_bounds__(256) k_delta_edges(int n_new, const int32_t* s
   }
 }
 
-// relink[edge] = the added row a kept row's edge points at from now on (-1 elsewhere: memset before)
-__global__ void __launch_bounds__(256) k_delta_relink(int n, const int32_t* edges, const int32_t* to, int32_t* relink, int E, int n_added, int32_t* st) {
+// Two independent flat steps in ONE launch (they were two until round 6): thread i takes added row i and relink i.
+//   added row i goes behind the kept rows of its distro, in the order given: added_dst[i] for the edge kernel, src[] for the rows;
+//   relink[edge] = the added row a kept row's edge points at from now on (-1 elsewhere: k_delta_init).
+__global__ void __launch_bounds__(256) k_delta_added_relink(int n_added, const int32_t* added_distro, const int32_t* add_before, const int32_t* new_task_off,
+                                                            int32_t* added_dst, int32_t* src, int n_new, int n_rl, const int32_t* edges, const int32_t* to,
+                                                            int32_t* relink, int E, int32_t* st) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_added) {
+    const int d = added_distro[i];
+    const int q = new_task_off[d + 1] - (add_before[d + 1] - add_before[d]) + (i - add_before[d]);
+    added_dst[i] = q < n_new ? q : 0;
+    if (q < n_new) src[q] = -(i + 1);
+  }
+  if (i < n_rl) {
+    const int e = edges[i], k = to[i];
+    if ((unsigned)e >= (unsigned)E) delta_fail(st, DS_RELINK_RANGE, i);
+    else if ((unsigned)k >= (unsigned)n_added) delta_fail(st, DS_RELINK_TO, i);
+    else if (atomicExch(&relink[e], k) >= 0) delta_fail(st, DS_RELINK_TWICE, i);
+  }
+}
+// The tail of the re-pack in ONE launch: the edge offset at every distro boundary (a gather through the new task_off) and the three
+// per-distro tables of the re-packed pool.
+__global__ void __launch_bounds__(256) k_delta_tables(int n, const int32_t* new_task_off, const int32_t* new_dep_off, int32_t* ecut, int n_new, int32_t* toff_out,
+                                                      const int32_t* tg, int32_t* tg_out, const int32_t* ver, int32_t* ver_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int e = edges[i], k = to[i];
-  if ((unsigned)e >= (unsigned)E) { delta_fail(st, DS_RELINK_RANGE, i); return; }
-  if ((unsigned)k >= (unsigned)n_added) { delta_fail(st, DS_RELINK_TO, i); return; }
-  if (atomicExch(&relink[e], k) >= 0) delta_fail(st, DS_RELINK_TWICE, i);
-}
-__global__ void __launch_bounds__(256) k_gather_i32(int n, const int32_t* idx, const int32_t* v, int32_t* out, int idx_max) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = (unsigned)idx[i] <= (unsigned)idx_max ? v[idx[i]] : 0;
+  const int r = new_task_off[i];
+  ecut[i] = (unsigned)r <= (unsigned)n_new ? new_dep_off[r] : 0;
+  toff_out[i] = r; tg_out[i] = tg[i]; ver_out[i] = ver[i];
 }
 
 }  // namespace evg

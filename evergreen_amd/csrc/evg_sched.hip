@@ -451,6 +451,11 @@ struct evg_ctx {
   std::vector<int32_t> pool_task_off, pool_tg_off, pool_ver_off;
   std::vector<int32_t> pool_ecut;  // edge offset at every distro boundary (D + 1): the shape test of the launch hints needs the edges per distro
   std::vector<DevBuf> tick_out = std::vector<DevBuf>(8);  // evg_pool_tick's output blocks
+  // where a delta's status block + tables come back: page-locked, so that the copy is only ENQUEUED (into pageable memory hipMemcpyAsync
+  // returns when the data has arrived -- behind the whole re-pack: the fused tick's host then sat out the device's work in the middle of
+  // its own, round 6)
+  int32_t* back_h = nullptr;
+  size_t back_cap = 0;
   std::vector<uint8_t> pool_gv;   // PlannerSettings.ShouldGroupVersions() per distro (the shape test of the launch hints)
   bool pool_pri_wide = false;     // some priority does not fit int32: no distro-shape promise holds
   std::vector<uint64_t> seen_bits;  // evg_pool_update's duplicate check: one bit per row / edge
@@ -503,6 +508,72 @@ static int ensure(evg_ctx* c, DevBuf& b, size_t bytes) {
   b.cap = want;
   return EVG_OK;
 }
+
+// ---- every stream the library has created, by device (round 6) --------------------------------------------------------------------
+// hipFree / hipHostFree / hipStreamDestroy wait for the WHOLE device -- every stream of every context of the process -- inside the
+// runtime, where no deadline reaches. Before an object frees anything it asks whether everything that was enqueued on the device's
+// streams SO FAR is done (an event on each, polled against the object's deadline: what hipFree itself would wait for, not "all streams
+// idle at one moment", which concurrent callers could starve); if not, it leaks what it holds instead of blocking its caller's thread.
+// Streams of leaked objects stay in the table: whatever hangs on them keeps hanging for the frees of everyone else.
+namespace evgreg {
+struct Entry { int dev; hipStream_t st; bool hung; };
+struct Table { std::mutex mu; std::vector<Entry> v; };
+static Table& table() { static Table* t = new Table; return *t; }  // never destroyed: objects may be torn down during exit
+static void add(int dev, hipStream_t st) {
+  if (!st) return;
+  std::lock_guard<std::mutex> lk(table().mu);
+  table().v.push_back(Entry{dev, st, false});
+}
+static void remove(hipStream_t st) {
+  if (!st) return;
+  Table& t = table();
+  std::lock_guard<std::mutex> lk(t.mu);
+  for (size_t i = 0; i < t.v.size(); i++)
+    if (t.v[i].st == st) { t.v[i] = t.v.back(); t.v.pop_back(); return; }
+}
+// Is everything enqueued so far on the library's streams of device `dev` done within deadline_ms? (<= 0: no limit asked for -- true
+// without looking: the caller's frees wait as long as it takes.) The current device must be `dev`. A stream that has let one caller wait
+// out a deadline is remembered as hung: while it stays busy the next callers are told so at once instead of waiting a deadline each.
+static bool quiesced_within(int dev, int64_t deadline_ms) {
+  if (deadline_ms <= 0) return true;
+  std::vector<std::pair<hipEvent_t, hipStream_t>> evs;
+  bool hung = false;
+  {
+    Table& t = table();
+    std::lock_guard<std::mutex> lk(t.mu);  // (streams are destroyed only after remove(): none of these is gone while the lock is held)
+    for (Entry& x : t.v) {
+      if (x.dev != dev) continue;
+      if (hipStreamQuery(x.st) == hipSuccess) { x.hung = false; continue; }
+      if (x.hung) { hung = true; break; }
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) continue;
+      if (hipEventRecord(e, x.st) != hipSuccess) { (void)hipEventDestroy(e); continue; }
+      evs.emplace_back(e, x.st);
+    }
+  }
+  (void)hipGetLastError();  // hipErrorNotReady of the queries is not an error of the caller's
+  using clk = std::chrono::steady_clock;
+  const auto until = clk::now() + std::chrono::milliseconds(deadline_ms);
+  hipStream_t late = nullptr;
+  for (size_t i = 0; i < evs.size() && !hung && !late; i++) {
+    for (unsigned spin = 0;; spin++) {
+      const hipError_t e = hipEventQuery(evs[i].first);
+      if (e != hipErrorNotReady) break;  // done (or an error of the stream's: nothing to wait for)
+      if (spin < 64) continue;
+      if (clk::now() >= until) { late = evs[i].second; break; }
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+  (void)hipGetLastError();
+  if (late) {
+    Table& t = table();
+    std::lock_guard<std::mutex> lk(t.mu);
+    for (Entry& x : t.v) if (x.st == late) x.hung = true;
+  }
+  if (!hung && !late) for (auto& e : evs) (void)hipEventDestroy(e.first);  // (events behind a hang are leaked with it)
+  return !hung && !late;
+}
+}  // namespace evgreg
 
 // The host-pointer entry points are synchronous and retain nothing: whatever way they leave (an error after some copies
 // were enqueued included), the context's stream is drained first, so no copy touches caller memory after the return.
@@ -559,7 +630,7 @@ struct Stager {
   // packed mode: inputs are memcpy'd into the context's page-locked block and leave in ONE H2D copy (flush_in); outputs are
   // carved out of the same device block behind them and come back in ONE D2H copy (flush_out), then to the caller's buffers
   bool packed = false, waited = false;
-  size_t in_off = 0, in_cap = 0, out_off = 0;
+  size_t in_off = 0, in_cap = 0, out_off = 0, in_flushed = 0;
   struct Down { void* host; size_t off, bytes; };
   std::vector<Down> downs;
   static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -619,9 +690,11 @@ struct Stager {
     rc = ensure(c, b, count * sizeof(T));
     return rc ? nullptr : (T*)b.p;
   }
+  // what has been packed since the last flush goes up (evg_pool_tick flushes twice: the delta's arrays, then the updates')
   int flush_in() {
-    if (rc || !packed || in_off == 0) return rc;
-    if (hipMemcpyAsync(c->pack_d, c->pack_h, in_off, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = set_err(c, EVG_E_HIP, "H2D copy failed");
+    if (rc || !packed || in_off == in_flushed) return rc;
+    if (hipMemcpyAsync(c->pack_d + in_flushed, c->pack_h + in_flushed, in_off - in_flushed, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = set_err(c, EVG_E_HIP, "H2D copy failed");
+    in_flushed = in_off;
     return rc;
   }
   template <class T>
@@ -759,6 +832,7 @@ evg_ctx* evg_create(int device_ordinal) {
     return nullptr;
   }
   *c->status_word = 0;
+  evgreg::add(c->device, c->stream);
   return c;
 }
 
@@ -772,8 +846,11 @@ void evg_destroy(evg_ctx* c) {
     bool idle = wait_stream(c, c->stream, "evg_destroy") == EVG_OK;
     if (idle && c->side) idle = wait_stream(c, c->side, "evg_destroy") == EVG_OK;
     if (idle && c->side2) idle = wait_stream(c, c->side2, "evg_destroy") == EVG_OK;
-    if (!idle) { delete c; return; }
+    if (!idle) { delete c; return; }  // (its streams stay in evgreg's table: they are still busy)
   }
+  // the frees below wait for the whole device: not behind a hang on ANOTHER object's stream either (evgreg)
+  if (!evgreg::quiesced_within(c->device, c->deadline_ms)) { delete c; return; }
+  evgreg::remove(c->stream); evgreg::remove(c->side); evgreg::remove(c->side2);
   for (void* q : c->dead_dev) (void)hipFree(q);
   for (void* q : c->dead_host) (void)hipHostFree(q);
   for (auto& b : c->tick_out) if (b.p) (void)hipFree(b.p);
@@ -793,6 +870,7 @@ void evg_destroy(evg_ctx* c) {
   if (c->status_word) (void)hipHostFree(c->status_word);
   if (c->pack_h) (void)hipHostFree(c->pack_h);
   if (c->pack_d) (void)hipFree(c->pack_d);
+  if (c->back_h) (void)hipHostFree(c->back_h);
   delete c;
 }
 
@@ -868,6 +946,7 @@ void evg_host_free(evg_ctx* c, void* p) {
   if (!c || !p) return;
   std::lock_guard<std::mutex> lk(c->mu);
   (void)hipSetDevice(c->device);
+  if (!evgreg::quiesced_within(c->device, c->deadline_ms)) { c->dead_host.push_back(p); return; }  // hipHostFree waits for the whole device: parked until evg_destroy
   (void)hipHostFree(p);
 }
 
@@ -1159,6 +1238,7 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
     if (c->overlap == 2 || (c->overlap == 1 && (in->promises & EVG_HINT_MIXED_POOL))) {
       if (!c->side2) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+        evgreg::add(c->device, c->side2);
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
       }
@@ -1202,6 +1282,7 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
       int lo_pri = 0, hi_pri = 0;
       HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
       HIP_TRY(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi_pri));
+      evgreg::add(c->device, c->side);
       HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
       HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
@@ -1676,7 +1757,15 @@ int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
 
 // ---- evg_pool_update, in pieces (evg_pool_tick enqueues them between a delta and a plan) -----------------------------------------
 // The host's share of the contract: ranges against (n_tasks, n_edges_bound), distinct rows / edges. *wide: a priority beyond int32.
+// In two pieces: what keeps the device's writes inside the pool (and shapes the launch) comes before anything is enqueued; `distinct` may
+// come behind the enqueue when the updates land in buffers that are not the pool yet (evg_pool_tick behind a delta).
+static int update_check_distinct(evg_ctx* c, const evg_row_update* ru, const evg_edge_update* eu, int n_tasks, long long n_edges_bound);
+static int update_check_ranges(evg_ctx* c, const evg_row_update* ru, const evg_edge_update* eu, int n_tasks, long long n_edges_bound, bool has_fin, bool has_info, bool* wide);
 static int update_check(evg_ctx* c, const evg_row_update* ru, const evg_edge_update* eu, int n_tasks, long long n_edges_bound, bool has_fin, bool has_info, bool* wide) {
+  if (int rc = update_check_ranges(c, ru, eu, n_tasks, n_edges_bound, has_fin, has_info, wide)) return rc;
+  return update_check_distinct(c, ru, eu, n_tasks, n_edges_bound);
+}
+static int update_check_ranges(evg_ctx* c, const evg_row_update* ru, const evg_edge_update* eu, int n_tasks, long long n_edges_bound, bool has_fin, bool has_info, bool* wide) {
   const int nr = ru ? ru->n_rows : 0, ne = eu ? eu->n_edges : 0;
   if (nr < 0 || ne < 0 || (nr > 0 && !ru->rows) || (ne > 0 && !eu->edges)) return set_err(c, EVG_E_INVALID, "evg_pool_update: null or negative");
   for (int i = 0; i < nr; i++) {
@@ -1689,6 +1778,10 @@ static int update_check(evg_ctx* c, const evg_row_update* ru, const evg_edge_upd
   if (ne > 0 && eu->dep_finished_ts_ns && !has_fin) return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_finished_ts_ns");
   if (ne > 0 && eu->dep_info && !has_info)  // (k_update_edges would write through a null device pointer)
     return set_err(c, EVG_E_INVALID, "evg_pool_update: the pool was loaded without dep_info");
+  return EVG_OK;
+}
+static int update_check_distinct(evg_ctx* c, const evg_row_update* ru, const evg_edge_update* eu, int n_tasks, long long n_edges_bound) {
+  const int nr = ru ? ru->n_rows : 0, ne = eu ? eu->n_edges : 0;
   // `distinct`: a row / edge listed twice would take whichever of its two values the device wrote last. One bit per row / edge
   // of the pool (125 KB for a million rows; sorting the 50,000 rows of a 5 % update cost 0.2 ms of the tick's 0.7)
   auto dup = [&](const int32_t* v, int n, long long range) {
@@ -1776,8 +1869,10 @@ int evg_pool_plan(evg_ctx* c, int64_t now_ns, const evg_plan_output* out) {
   HIP_TRY(c, hipSetDevice(c->device));
   if (int rc = pending_status(c)) return rc;
   if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_plan: no pool is loaded on this context");
-  if (!out->order || !out->deps_met || !out->wait_ns || !out->distro_info || !out->group_info)
-    return set_err(c, EVG_E_INVALID, "order, deps_met, wait_ns, distro_info and group_info outputs are required");
+  // wait_ns may be NULL on the resident entry points (evg_pool_plan, evg_pool_tick): Task.WaitSinceDependenciesMet is 8 of a tick's 14.7 bytes per task over the
+  // link and nothing in the reference reads it back (scheduler.go:141 sets it; the queue-info rows carry what it decides)
+  if (!out->order || !out->deps_met || !out->distro_info || !out->group_info)
+    return set_err(c, EVG_E_INVALID, "order, deps_met, distro_info and group_info outputs are required");
   evg_plan_input di = c->pool_in;
   di.now_ns = now_ns;
   const size_t N = di.tasks.n_tasks, D = di.n_distros, G = D + di.n_task_groups, Stot = N + (size_t)di.n_task_groups + (size_t)di.n_versions;
@@ -1854,7 +1949,8 @@ struct DeltaFlight {
   int D = 0, N = 0, E = 0, nr = 0, na = 0, nl = 0, EA = 0, NN = 0;
   size_t EN_cap = 0;
   const int32_t *n_tg = nullptr, *n_ver = nullptr;
-  std::vector<int32_t> tg_shift, ver_shift, add_before, back, new_toff_host, ne_bound;
+  std::vector<int32_t> tg_shift, ver_shift, add_before, new_toff_host, ne_bound;
+  const int32_t* back = nullptr;  // the context's page-locked block: [status: 8 words][edge offset at every distro boundary][the new task_off]
   bool added_wide = false;
   // device pointers into the staging block
   const int32_t *d_removed = nullptr, *d_added_distro = nullptr, *d_add_before = nullptr, *d_tg_shift = nullptr, *d_ver_shift = nullptr, *d_ntg = nullptr,
@@ -2037,43 +2133,52 @@ static int delta_enqueue(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f, h
   hipLaunchKernelGGL(k_delta_init, grid(std::max<size_t>(std::max<size_t>((size_t)N, (size_t)NN + 1), std::max<size_t>((size_t)D + 1, nl > 0 ? (size_t)E : 8))), dim3(256), 0, st,
                      d_st, d_rem, D, d_src, NN, d_rmi, N, nl > 0 ? d_relink : (int32_t*)nullptr, E);
   if (nr > 0) hipLaunchKernelGGL(k_delta_mark, grid(nr), dim3(256), 0, st, nr, d_removed, d_rm_state, N, D, p.task_off, d_rmi, d_rem, d_st);
-  hipLaunchKernelGGL(k_delta_counts, grid(D), dim3(256), 0, st, D, p.task_off, d_rem, d_add_before, d_ntoff, d_st);
   auto scan = [&](auto flag, const int32_t* v, int n_, int nb, int32_t* out) {  // exclusive prefix sums of v[0, n_) (+ the total at out[n_])
     constexpr bool F = decltype(flag)::value;
     if (nb <= 1) { hipLaunchKernelGGL(k_scan_single<F>, dim3(1), dim3(kScanBlock), 0, st, v, n_, out); return; }
     hipLaunchKernelGGL(k_scan_block_sums<F>, dim3(nb), dim3(kScanBlock), 0, st, v, n_, d_bsum);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(kScanBlock), 0, st, d_bsum, nb);
     hipLaunchKernelGGL(k_scan_apply<F>, dim3(nb), dim3(kScanBlock), 0, st, v, n_, d_bsum, nb, out);
   };
-  scan(std::false_type{}, d_ntoff, D, nb_d, d_ntoff);
+  if (nb_d <= 1) hipLaunchKernelGGL(k_delta_counts_scan, dim3(1), dim3(kScanBlock), 0, st, D, p.task_off, d_rem, d_add_before, d_ntoff, d_st);
+  else {
+    hipLaunchKernelGGL(k_delta_counts, grid(D), dim3(256), 0, st, D, p.task_off, d_rem, d_add_before, d_ntoff, d_st);
+    scan(std::false_type{}, d_ntoff, D, nb_d, d_ntoff);
+  }
   // ---- kept rows, their new numbers ----
   if (N > 0) {
     scan(std::true_type{}, d_rmi, N, nb_old, d_kept);
     hipLaunchKernelGGL(k_delta_place, grid(N), dim3(256), 0, st, N, D, d_rmi, d_kept, p.task_off, d_add_before, d_newrow, d_src, NN);
   }
-  if (na > 0) hipLaunchKernelGGL(k_delta_src_added, grid(na), dim3(256), 0, st, na, d_added_distro, d_add_before, d_ntoff, d_added_dst, d_src, NN);
-  if (nl > 0) {
-    hipLaunchKernelGGL(k_delta_relink, grid(nl), dim3(256), 0, st, nl, d_rl_edges, d_rl_to, d_relink, E, na, d_st);
-  }
+  if (na > 0 || nl > 0)
+    hipLaunchKernelGGL(k_delta_added_relink, grid(std::max(na, nl)), dim3(256), 0, st, na, d_added_distro, d_add_before, d_ntoff, d_added_dst, d_src, NN, nl, d_rl_edges,
+                       d_rl_to, d_relink, E, d_st);
   if (NN > 0) {
     hipLaunchKernelGGL(k_delta_rows, grid(NN), dim3(256), 0, st, NN, D, d_src, n_cols, o_cols, a_cols, t.dep_off, d_add_dep_off, d_ntoff, d_tg_shift,
                        d_ver_shift, n_dep_off, d_added_distro, d_ntg, d_nver, d_st);
     scan(std::false_type{}, n_dep_off, NN, nb_new, n_dep_off);
     hipLaunchKernelGGL(k_delta_edges, grid(NN), dim3(256), 0, st, NN, d_src, n_dep_off, n_edges, o_edges, a_edges, t.dep_off, d_add_dep_off, d_newrow, d_rmi,
                        d_rm_state, d_rm_fin, d_added_dst, d_relink, na, d_added_distro, p.task_off, d_ntoff, D, d_st, (int)EN_cap);
-    hipLaunchKernelGGL(k_gather_i32, grid(D + 1), dim3(256), 0, st, D + 1, d_ntoff, n_dep_off, d_ecut, NN);
+    // the edge offset at every distro boundary and the small tables of the new pool, one launch
+    hipLaunchKernelGGL(k_delta_tables, grid(D + 1), dim3(256), 0, st, D + 1, d_ntoff, n_dep_off, d_ecut, NN, (int32_t*)nw[16].p, d_ntg, (int32_t*)nw[17].p, d_nver,
+                       (int32_t*)nw[18].p);
   } else {
     HIP_TRY(c, hipMemsetAsync(n_dep_off, 0, 8, st));
     HIP_TRY(c, hipMemsetAsync(d_ecut, 0, 4 * (size_t)(D + 1), st));
+    hipLaunchKernelGGL(k_copy3_i32, grid(D + 1), dim3(256), 0, st, D + 1, d_ntoff, (int32_t*)nw[16].p, d_ntg, (int32_t*)nw[17].p, d_nver, (int32_t*)nw[18].p);
   }
   HIP_TRY(c, hipGetLastError());
   lap("buffers + kernels enqueued");
-  // the small tables of the new pool; status, edge cuts and the new task_off come back in one copy
-  hipLaunchKernelGGL(k_copy3_i32, grid(D + 1), dim3(256), 0, st, D + 1, d_ntoff, (int32_t*)nw[16].p, d_ntg, (int32_t*)nw[17].p, d_nver, (int32_t*)nw[18].p);
-  HIP_TRY(c, hipGetLastError());
+  // status, edge cuts and the new task_off come back in one copy
   f.d_back = d_back;
-  f.back.assign(8 + 2 * ((size_t)D + 1), 0);
-  HIP_TRY(c, hipMemcpyAsync(f.back.data(), d_back, 4 * f.back.size(), hipMemcpyDeviceToHost, st));
+  const size_t back_n = 8 + 2 * ((size_t)D + 1);
+  if (back_n > c->back_cap) {
+    if (c->back_h) c->dead_host.push_back(c->back_h);  // (freed by evg_destroy: see evg_ctx::dead_dev)
+    c->back_h = nullptr; c->back_cap = 0;
+    if (hipHostMalloc((void**)&c->back_h, 4 * (back_n + back_n / 2), hipHostMallocDefault) != hipSuccess) return set_err(c, EVG_E_NOMEM, "cannot allocate the delta's page-locked status block");
+    c->back_cap = back_n + back_n / 2;
+  }
+  f.back = c->back_h;
+  HIP_TRY(c, hipMemcpyAsync(c->back_h, d_back, 4 * back_n, hipMemcpyDeviceToHost, st));
   // ---- the re-packed pool as the planner sees it, with launch hints that hold whatever the device finds: the host knows every
   // distro's new size exactly (for a delta the device accepts) and an upper bound of its edges ----
   evg_plan_input& q = f.view;
@@ -2095,7 +2200,7 @@ static int delta_verdict(evg_ctx* c, const evg_pool_delta* dl, DeltaFlight& f) {
   using namespace evg;
   const int D = f.D, NN = f.NN;
   const evg_task_soa& ad = dl->added;
-  std::vector<int32_t>& back = f.back;
+  const int32_t* back = f.back;
   {  // the kernels' verdict: the first violation in the order the host used to look for them
     const unsigned long long first = ((unsigned long long)(uint32_t)back[5] << 32) | (uint32_t)back[4];
     if (first != ~0ull) {
@@ -2125,10 +2230,10 @@ static void delta_swap(evg_ctx* c, DeltaFlight& f) {
   using namespace evg;
   const int D = f.D, NN = f.NN;
   const int32_t *n_tg = f.n_tg, *n_ver = f.n_ver;
-  std::vector<int32_t>& back = f.back;
+  const int32_t* back = f.back;
   std::vector<DevBuf>& nw = c->pool_alt;
-  const int32_t* ecut = back.data() + 8;
-  std::vector<int32_t> new_toff(back.begin() + 8 + (D + 1), back.begin() + 8 + 2 * (D + 1));
+  const int32_t* ecut = back + 8;
+  std::vector<int32_t> new_toff(back + 8 + (D + 1), back + 8 + 2 * (D + 1));
   const bool pri_wide = c->pool_pri_wide || back[2] != 0;
   // ---- swap: the new buffers ARE the pool (the distro settings are not re-packed: their buffer moves over) ----
   std::swap(nw[15], c->pool[15]);
@@ -2234,9 +2339,10 @@ int evg_pool_tick(evg_ctx* c, const evg_pool_delta* dl, const evg_row_update* ru
   HIP_TRY(c, hipSetDevice(c->device));
   if (int rc = pending_status(c)) return rc;
   if (!c->pool_loaded) return set_err(c, EVG_E_INVALID, "evg_pool_tick: no pool is loaded on this context");
-  if (!out->order || !out->deps_met || !out->wait_ns || !out->distro_info || !out->group_info)
-    return set_err(c, EVG_E_INVALID, "order, deps_met, wait_ns, distro_info and group_info outputs are required");
-  if (out->breakdown && !out->unit_breakdown) return set_err(c, EVG_E_INVALID, "evg_pool_tick: rows by task are not produced here (ask for unit_of_task + unit_breakdown)");
+  if (!out->order || !out->deps_met || !out->distro_info || !out->group_info)  // wait_ns may be NULL: see evg_pool_plan
+    return set_err(c, EVG_E_INVALID, "order, deps_met, distro_info and group_info outputs are required");
+  if (out->breakdown) return set_err(c, EVG_E_INVALID, "evg_pool_tick: rows by task are not produced here (ask for unit_of_task + unit_breakdown)");
+  if ((out->unit_of_task != nullptr) != (out->unit_breakdown != nullptr)) return set_err(c, EVG_E_INVALID, "unit_of_task and unit_breakdown come together (both or neither)");
   if (dl && (dl->n_removed < 0 || dl->n_added < 0 || dl->n_relinked < 0)) return set_err(c, EVG_E_INVALID, "evg_pool_tick: null or negative");
   const int D = c->pool_in.n_distros;
   if (D == 0) return EVG_OK;
@@ -2259,20 +2365,30 @@ int evg_pool_tick(evg_ctx* c, const evg_pool_delta* dl, const evg_row_update* ru
   if (dl)
     if (int rc = delta_stage(c, dl, sg, f, &empty)) return rc;
   lap("delta: tables + staged");
+  // the delta's arrays go up and its re-pack starts while the host checks and stages the updates (nothing here waits: the status block
+  // comes back into page-locked memory). An update the contract refuses below leaves the second set of buffers half-written -- they
+  // are not the pool until delta_commit
+  if (!empty) {
+    if (sg.flush_in()) return sg.rc;
+    if (int rc = delta_enqueue(c, dl, f, st)) return rc;
+  }
+  lap("delta: block on its way, kernels enqueued");
   // the updates name rows / edges of the pool AFTER the delta
   const evg_plan_input& cur = c->pool_in;
   bool wide = false;
-  if (int rc = update_check(c, ru, eu, empty ? cur.tasks.n_tasks : f.NN, empty ? (long long)cur.tasks.n_edges : (long long)f.EN_cap,
-                            cur.tasks.dep_finished_ts_ns != nullptr || !empty, cur.tasks.dep_info != nullptr || !empty, &wide)) return rc;
+  const int u_tasks = empty ? cur.tasks.n_tasks : f.NN;
+  const long long u_edges = empty ? (long long)cur.tasks.n_edges : (long long)f.EN_cap;
+  if (int rc = update_check_ranges(c, ru, eu, u_tasks, u_edges, cur.tasks.dep_finished_ts_ns != nullptr || !empty, cur.tasks.dep_info != nullptr || !empty, &wide)) return rc;
+  // `distinct` (a bitmap pass: ~45 us for a 5 % tick): before anything is enqueued when the updates land in the pool itself; behind a
+  // delta they land in the second set of buffers -- not the pool until delta_commit -- and the host checks while the device works
+  if (empty)
+    if (int rc = update_check_distinct(c, ru, eu, u_tasks, u_edges)) return rc;
   lap("updates checked");
   UpdateFlight u;
   update_up(sg, ru, eu, u);
   if (sg.rc) return sg.rc;
   if (sg.flush_in()) return sg.rc;
   lap("updates staged, block on its way");
-  if (!empty)
-    if (int rc = delta_enqueue(c, dl, f, st)) return rc;
-  lap("delta kernels enqueued");
   evg_plan_input view = empty ? c->pool_in : f.view;
   if (wide) view.promises &= ~(EVG_PROMISE_ALL_ON_LDS_PATH | EVG_PROMISE_ALL_ON_LDS_TIERS);
   if (int rc = update_enqueue(c, view.tasks, u, st)) return rc;
@@ -2310,6 +2426,9 @@ int evg_pool_tick(evg_ctx* c, const evg_pool_delta* dl, const evg_row_update* ru
   if (!rc) rc = down(out->unit_breakdown, dout.unit_breakdown, 8 * Stot * EVG_BREAKDOWN_FIELDS);
   if (rc) return rc;
   lap("updates + plan + downloads enqueued");
+  if (!empty)
+    if (int rc = update_check_distinct(c, ru, eu, u_tasks, u_edges)) return rc;  // (the drain waits the stream out; nothing is committed)
+  lap("updates: distinct (behind the enqueue)");
   if (int rcw_ = wait_stream(c, st, __func__)) return rcw_;  // THE synchronisation of the tick
   lap("waited");
   if (!empty) {

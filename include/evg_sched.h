@@ -252,7 +252,10 @@ typedef struct evg_plan_output {
   uint8_t* deps_met;       /* N by row: checkDependenciesMet result (scheduler.go:70-76); this is
                               also Task.HasDependenciesMet() after the call (persister :47)      */
   int64_t* wait_ns;        /* N by row: Task.WaitSinceDependenciesMet (scheduler.go:141), 0 when
-                              the reference leaves it untouched                                  */
+                              the reference leaves it untouched. evg_pool_plan / evg_pool_tick take
+                              NULL here (not downloaded: it is 8 of a resident tick's 14.7 bytes per
+                              task over the link, and nothing in the reference reads the field
+                              back -- the queue-info rows carry what it decides)                  */
   evg_distro_info* distro_info; /* D */
   evg_group_info* group_info;   /* D + n_task_groups */
   int32_t* n_units;        /* D: TaskPlan.Len() after UnitCache.Export dedup (planner.go:73-89),

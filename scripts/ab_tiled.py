@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Plan-only timing of the large-distro pipeline on one box (config-5 share or the skewed config 3); EVG_TILED_MODE selects
-the variant. usage: ab_tiled.py c5|skew|c5full   (EVG_GEN_NOSHUFFLE=1: generator rows left in canonical order)"""
+the variant. usage: ab_tiled.py c5|skew|c5full|cliff<size>[x<count>]   (EVG_GEN_NOSHUFFLE=1: generator rows left in canonical order)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -12,6 +12,9 @@ if which == "skew":
     cfg = gen.config(3, skew=True, shuffle=shuf)
 elif which == "c5full":
     cfg = gen.config(5, shuffle=shuf)
+elif which.startswith("cliff"):  # cliff10000 / cliff6000x8: config 3 with 1 (or xK) distros grown to that many tasks
+    sz, _, k = which[5:].partition("x")
+    cfg = gen.cliff_config(int(k or 1) if int(sz) else 0, int(sz))
 else:
     cfg = gen.config(5, n_tasks=1_250_000, n_distros=64, shuffle=shuf)
 b = gen.generate(cfg)

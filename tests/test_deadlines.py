@@ -152,6 +152,56 @@ def test_multi_device_tick_that_times_out_aborts_and_refuses(native):
         m.close()
 
 
+def test_destroy_next_to_a_stalled_context_does_not_block(native, oracle):
+    """evg_destroy / evg_host_free call hipFree / hipHostFree, which wait for the WHOLE device inside the runtime: a context that is idle
+    itself used to sit out whatever hung on another context's stream. Every stream the library creates is in a table now (evgreg); an
+    object frees only when what those streams held at that moment is done within its deadline, and leaks what it holds otherwise."""
+    small = gen.generate(gen.config(1))
+    a, b = native.Context(0), native.Context(0)
+    try:
+        compare.assert_plan_equal(b.plan(small), oracle.plan(small), small, "warm-up")
+        keep = b.pinned_copy(np.arange(1 << 16, dtype=np.int64))
+        assert keep[123] == 123
+        b.set_deadline_ms(300)
+        a.debug_stall(2500)
+        t0 = time.perf_counter()
+        b.close()  # evg_host_free of the page-locked block + evg_destroy: 300 ms each at most, then b's memory is leaked
+        dt = time.perf_counter() - t0
+        assert dt < 1.5, "destroying an idle context waited %.2f s for a stall on another context" % dt
+        time.sleep(2.5 - dt if dt < 2.5 else 0)
+        c = native.Context(0)  # the device serves the next context; its destruction frees normally (the stall is over)
+        compare.assert_plan_equal(c.plan(small), oracle.plan(small), small, "after the stall")
+        t0 = time.perf_counter()
+        c.close()
+        assert time.perf_counter() - t0 < 1.0
+    finally:
+        a.close()
+        b.close()
+
+
+def test_multi_device_destroy_while_a_rank_is_stalled_does_not_block(native):
+    """evg_multi_destroy is bounded like every other call (round 6): hipFree / hipStreamDestroy / ncclCommDestroy wait for the device
+    without a limit, so they are only reached behind a bounded wait that found the rank idle; a rank that is still busy at the deadline
+    is leaked. (On one box of the pool a multi-device test whose tick had timed out sat in evg_multi_destroy's first hipFree until
+    pytest's own timeout ended the whole run.)"""
+    batch = gen.generate(gen.config(1))
+    m = native.MultiContext([0, 0, 0], loopback=True)
+    m.load(batch)
+    m.tick()
+    m.set_deadline_ms(300)
+    m.debug_stall(1, 2500)
+    t0 = time.perf_counter()
+    m.close()
+    assert time.perf_counter() - t0 < 1.5, "evg_multi_destroy waited out a stall beyond its deadline"
+    time.sleep(2.5)  # the stall ends; what was leaked stays leaked
+    m2 = native.MultiContext([0, 0], loopback=True)  # and the device serves the next object
+    try:
+        m2.load(batch)
+        m2.tick()
+    finally:
+        m2.close()
+
+
 def test_a_hang_on_one_context_never_costs_another_more_than_its_deadline(native, oracle):
     """hipFree / hipHostFree synchronise the whole device: a context that freed an outgrown buffer on the way into a call used to wait --
     inside the HIP runtime, where no deadline reaches -- for a stall on ANOTHER context's stream (found in round 6 by the driver's

@@ -243,6 +243,34 @@ def test_fused_tick_is_the_three_calls(native_ctx, oracle, cfg):
 
 
 @pytest.mark.gpu
+def test_resident_entry_points_take_no_wait_ns(native_ctx, oracle):
+    """evg_pool_plan / evg_pool_tick with wait_ns == NULL: Task.WaitSinceDependenciesMet (scheduler.go:141) is not downloaded -- it is 8 of
+    a resident tick's 14.7 bytes per task over the link -- and everything else is what the call with it returns."""
+    full, pool0, delta, _, _ = _tick(gen.GenConfig(40_000, 16, gen.SEED_BASE + 77, tg_fraction=0.3))
+    native_ctx.pool_load(pool0)
+    lean = abi.PlanResult.alloc_host(pool0, breakdown=False, n_units=False, wait=False)
+    assert lean.wait_ns is None
+    got = native_ctx.pool_plan(pool0, pool0.now_ns, into=lean)
+    want = oracle.plan(pool0, breakdown=False, n_units=False)
+    for f in ("order", "deps_met", "distro_info", "group_info"):
+        assert np.array_equal(getattr(got, f), getattr(want, f)), "evg_pool_plan without wait_ns: " + f
+    pool1 = pool_delta.apply_delta(pool0, delta)
+    blk, keep = native_ctx.make_pool_delta(**delta.kwargs())
+    rows = np.arange(0, pool1.n_tasks, 7, dtype=np.int32)
+    pri = (rows.astype(np.int64) * 13) % 101
+    lean1 = abi.PlanResult.alloc_host(pool1, breakdown=False, n_units=False, wait=False)
+    got = native_ctx.pool_tick(pool1, pool1.now_ns + 15 * 10**9, delta=blk, update=native_ctx.make_pool_update(rows, {"priority": pri}), into=lean1)
+    pool1.cols["priority"][rows] = pri
+    pool1.now_ns += 15 * 10**9
+    want = oracle.plan(pool1, breakdown=False, n_units=False)
+    for f in ("order", "deps_met", "distro_info", "group_info"):
+        assert np.array_equal(getattr(got, f), getattr(want, f)), "evg_pool_tick without wait_ns: " + f
+    full_again = native_ctx.pool_plan(pool1, pool1.now_ns)  # and the pool it left is the pool
+    compare.assert_plan_equal(full_again, want, pool1, "the pool a lean fused tick left")
+    del keep
+
+
+@pytest.mark.gpu
 def test_fused_tick_refuses_what_the_three_calls_refuse_and_leaves_the_pool(native_ctx, oracle):
     from evergreen_amd import native
     full, pool0, delta, _, _ = _tick(gen.GenConfig(20_000, 9, gen.SEED_BASE + 61, tg_fraction=0.3))
@@ -258,7 +286,7 @@ def test_fused_tick_refuses_what_the_three_calls_refuse_and_leaves_the_pool(nati
         native_ctx.pool_tick(pool1, pool1.now_ns, delta=blk)
     compare.assert_plan_equal(native_ctx.pool_plan(pool0, pool0.now_ns, n_units=True), base, pool0, "the pool after a refused fused tick")
     blk, keep = native_ctx.make_pool_delta(**delta.kwargs())
-    rows = np.array([3, 3], np.int32)  # an update the host refuses: before anything is enqueued
+    rows = np.array([3, 3], np.int32)  # an update the host refuses (the delta's re-pack is already on its way into the second set of buffers: not the pool)
     with pytest.raises(native.NativeError, match="listed twice"):
         native_ctx.pool_tick(pool1, pool1.now_ns, delta=blk, update=native_ctx.make_pool_update(rows, {"priority": np.array([1, 2], np.int64)}))
     compare.assert_plan_equal(native_ctx.pool_plan(pool0, pool0.now_ns, n_units=True), base, pool0, "the pool after a refused update")
