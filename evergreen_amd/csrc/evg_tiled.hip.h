@@ -59,14 +59,6 @@ constexpr int TM_KEY192 = 64;                        // keys always travel as 24
 constexpr int TM_HSPLIT = 128, TM_NO_HSPLIT = 256;   // merge-path splits from k_tiled_splits' launch: forced on / forced off (default: by size)
 constexpr int kTiledHoistTiles = 2048;               // row tiles from which the launch hoists the splits: more than ~2.5 waves of merge workgroups
 
-// Experiment switch (round 6, LAB_NOTES 6.6): the headline kernel's falling wave priority (EVG_PRIO: the workgroup that is behind on its CU gets
-// the issue slots) at the phase boundaries of the pipeline's kernels, where three workgroups share a CU.
-#ifdef EVG_TILED_PRIO
-#define TP(step) EVG_PRIO(step)
-#else
-#define TP(step) do {} while (0)
-#endif
-
 // blockIdx -> tile, XCD-aware: workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; tile
 // (b % 8) * ceil(T / 8) + b / 8 gives every XCD a contiguous eighth of the tile list, i.e. whole distros. -1: no tile.
 __device__ __forceinline__ int xcd_tile(int b, int T, int mode = 0) {
@@ -389,7 +381,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
   const int i_end = (tile + 1) * kRT < n ? (tile + 1) * kRT : n;
   const int E0 = t.dep_off[lo + tile * kRT], E1 = t.dep_off[lo + i_end];
   TT_BEGIN();
-  TP(0);
   const bool eL = E1 - E0 <= kTileEdges && !(a.tiled_mode & TM_ROW_SCATTER);
   if (eL) {
     // six edges per thread at a time: their index loads together, then the gathers of the dependencies' rows together (edge
@@ -417,7 +408,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
   if (tid < 20) s_u32[tid] = (tid == 0 || tid == 2 || tid == 4) ? ~0u : 0u;
   __syncthreads();
   TT_MARK(12);
-  TP(1);
   const bool incl = p.includes_dependencies != 0;
   const int64_t Thi = target_hi(p), Tlo = target_lo(p);
 
@@ -527,7 +517,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
     if (m.t1 >= 0) atomicAdd(&s_cnt[m.t1 / kST], 1);
   }
   TT_MARK(13);
-  TP(2);
   if (eL) {  // every row's FINAL slots are in LDS after the barrier below; k_tiled_elect reads them back edge-parallel
     __syncthreads();
     for (int x = tid; x < E1 - E0; x += kTiledBlock) a.w_eslot[E0 + x] = (int32_t)s_edge[x];
@@ -603,7 +592,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_scatter(const PlanArgs
   }
   __syncthreads();
   TT_MARK(14);
-  TP(3);
   // ---- pass 2: the records ----
   TRec* rec = (TRec*)a.w_rec + rec_region(a, c, tile);
 #pragma unroll
@@ -660,7 +648,6 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
   const int64_t T = has_mq ? target_lo(p) : target_hi(p);
   const uint32_t wait_bit = has_mq ? RW_WAIT_LO : RW_WAIT_HI;
   TT_BEGIN();
-  TP(0);
   // where this tile's records are (one bucket per source row tile): a chain of dependent loads, issued ahead of the init loop
   // whose own loads it does not depend on
   const int n_rt = ts->n_rt;
@@ -711,13 +698,11 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
     }
   }
   TT_MARK(16);
-  TP(1);
   if (tid < n_rt) s_base[tid] = my_base;
   if (tid == 0) { s_pref[0] = 0; s_t64[0] = 0; s_t64[1] = 0; s_t64[2] = ~0ull; s_t64[3] = 0; s_t32[0] = 0; s_t32[1] = 0; s_t32[2] = 0; }
   s_pref[tid + 1] = block_scan_sum(mine, tid, s_w8);
   __syncthreads();
   TT_MARK(17);
-  TP(2);
   const int total = s_pref[n_rt];
   const TRec* recs = (const TRec*)a.w_rec;
   constexpr int kRB = 3;  // records per thread in flight: their loads are issued together, then their rows' gathers
@@ -774,7 +759,6 @@ __global__ void __launch_bounds__(kTiledBlock) k_tiled_reduce(const PlanArgs a) 
   }
   __syncthreads();
   TT_MARK(18);
-  TP(3);
   // ---- score; rows out ----
   const size_t sb = (size_t)c.lo + c.tg_lo + c.ver_lo;  // the distro's slot range in the global slot arrays
   uint64_t t_dur = 0, t_dover = 0, r_vmin = ~0ull, r_vmax = 0;
@@ -982,7 +966,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
     return un.value == INT64_MIN ? ~0ull : (shl64(vmaxu - ub(un.value), bmr + bsl) | ((uint64_t)un.minrow << bsl) | (uint64_t)u);
   };
   TT_BEGIN();
-  TP(0);
   // The units the tile's dependency edges name, edge-parallel into LDS (the slots come coalesced, one gather per edge).
   // (Fetching the four rows' columns ahead of this loop was measured: 85 VGPRs, one workgroup less per CU, slower.)
   uint64_t* s_uk = (uint64_t*)smem;
@@ -1008,7 +991,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
     __syncthreads();
   }
   TT_MARK(8);
-  TP(1);
   K192 k[4];
 #pragma unroll
   for (int e4 = 0; e4 < 4; e4++) {
@@ -1057,7 +1039,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
     if (a.out.unit_of_task) a.out.unit_of_task[r] = (int32_t)(sb + best);
   }
   TT_MARK(9);
-  TP(2);
   __syncthreads();  // the staged candidates are dead: the sort works in the same bytes
   // The tile sort: thread t holds the keys of positions 4t..4t+3. (Measured and dropped: sorting ONE 64-bit word per row --
   // [unit word | row in the tile], when the unit word fits 53 bits -- on the planner's 64-bit network and ranking the rows
@@ -1066,7 +1047,6 @@ __global__ void __launch_bounds__(kTiledBlock, 6) k_tiled_elect(const PlanArgs a
   K192* const tile_out = (K192*)a.w_keyA + ((size_t)ts->rt_base + tile) * kRT;
   tile_sort_merge_path(k, tid, smem);
   TT_MARK(10);
-  TP(3);
   if (key20) {
     store_tile_keys20(k, keys20_of(a.w_keyA, ts), (long long)tile * kRT, tid, smem);
   } else if (a.tiled_mode & 32) {  // A/B: every thread stores its own four keys
