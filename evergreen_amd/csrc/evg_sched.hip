@@ -1998,6 +1998,24 @@ static int delta_stage(evg_ctx* c, const evg_pool_delta* dl, Stager& sg, DeltaFl
 #else
   auto lap = [](const char*) {};
 #endif
+  // ---- the delta's arrays into the staging block (the caller opened it: ONE page-locked block, ONE copy -- a 5 % tick is ~4 MB in
+  // ~30 arrays: from pageable memory every array is a staged copy of its own and the call was 1.5 ms, most of it those) ----
+  f.d_removed = sg.up(dl->removed_rows, (size_t)nr);
+  f.d_rm_state = sg.up(dl->removed_dep_state, (size_t)nr);
+  f.d_rm_fin = sg.up(dl->removed_finished_ts_ns, (size_t)nr);
+  if (sg.flush_in()) return sg.rc;  // (in pieces: the link moves one piece while the host packs the next -- and cuts its tables, below)
+  f.d_added_distro = sg.up(dl->added_distro, (size_t)na);
+  f.d_rl_edges = sg.up(dl->relinked_edges, (size_t)nl);
+  f.d_rl_to = sg.up(dl->relinked_to, (size_t)nl);
+  f.a_cols = TaskCols{(int64_t*)sg.up(ad.priority, (size_t)na), (int64_t*)sg.up(ad.expected_duration_ns, (size_t)na), (int64_t*)sg.up(ad.queue_ts_ns, (size_t)na),
+                  (int64_t*)sg.up(ad.scheduled_ts_ns, (size_t)na), (int64_t*)sg.up(ad.deps_met_ts_ns, (size_t)na), (int32_t*)sg.up(ad.num_dependents, (size_t)na),
+                  (int32_t*)sg.up(ad.task_group_order, (size_t)na), (int32_t*)sg.up(ad.task_group_max_hosts, (size_t)na), (int32_t*)sg.up(ad.tg_key, (size_t)na),
+                  (int32_t*)sg.up(ad.version_key, (size_t)na), (uint16_t*)sg.up(ad.flags, (size_t)na)};
+  if (sg.flush_in()) return sg.rc;
+  f.d_add_dep_off = sg.up(na > 0 ? ad.dep_off : (const int32_t*)nullptr, (size_t)na + 1);
+  f.a_edges = EdgeCols{(int32_t*)sg.up(ad.dep_idx, (size_t)EA), (uint8_t*)sg.up(ad.dep_info, (size_t)EA), (int64_t*)sg.up(ad.dep_finished_ts_ns, (size_t)EA)};
+  if (sg.flush_in()) return sg.rc;
+  lap("arrays staged, on their way");
   const std::vector<int32_t>& toff = c->pool_task_off;
   // ---- what the HOST still checks: O(D) tables and one pass over the added rows' distro numbers and edge offsets (they size the
   // launches and bound every index the kernels form). Everything per row / per edge -- ranges, duplicates, keys, dependency
@@ -2049,27 +2067,12 @@ static int delta_stage(evg_ctx* c, const evg_pool_delta* dl, Stager& sg, DeltaFl
     for (int d = 0; d < D; d++) f.new_toff_host[d + 1] = f.new_toff_host[d] + std::max(0, (to[d + 1] - to[d]) - rem[d]) + (add_before[d + 1] - add_before[d]);
   }
   lap("tables cut");
-  // ---- the delta's arrays into the staging block (the caller opened it: ONE page-locked block, ONE copy -- a 5 % tick is ~4 MB in
-  // ~30 arrays: from pageable memory every array is a staged copy of its own and the call was 1.5 ms, most of it those) ----
-  int rc = EVG_OK;
-  f.d_removed = sg.up(dl->removed_rows, (size_t)nr);
-  f.d_rm_state = sg.up(dl->removed_dep_state, (size_t)nr);
-  f.d_rm_fin = sg.up(dl->removed_finished_ts_ns, (size_t)nr);
-  f.d_added_distro = sg.up(dl->added_distro, (size_t)na);
+  // the small tables go last (the caller flushes them)
   f.d_add_before = sg.up((const int32_t*)add_before.data(), (size_t)(D + 1));
   f.d_tg_shift = sg.up((const int32_t*)tg_shift.data(), (size_t)(D + 1));
   f.d_ver_shift = sg.up((const int32_t*)ver_shift.data(), (size_t)(D + 1));
   f.d_ntg = sg.up(n_tg, (size_t)(D + 1));
   f.d_nver = sg.up(n_ver, (size_t)(D + 1));
-  f.d_rl_edges = sg.up(dl->relinked_edges, (size_t)nl);
-  f.d_rl_to = sg.up(dl->relinked_to, (size_t)nl);
-  f.a_cols = TaskCols{(int64_t*)sg.up(ad.priority, (size_t)na), (int64_t*)sg.up(ad.expected_duration_ns, (size_t)na), (int64_t*)sg.up(ad.queue_ts_ns, (size_t)na),
-                  (int64_t*)sg.up(ad.scheduled_ts_ns, (size_t)na), (int64_t*)sg.up(ad.deps_met_ts_ns, (size_t)na), (int32_t*)sg.up(ad.num_dependents, (size_t)na),
-                  (int32_t*)sg.up(ad.task_group_order, (size_t)na), (int32_t*)sg.up(ad.task_group_max_hosts, (size_t)na), (int32_t*)sg.up(ad.tg_key, (size_t)na),
-                  (int32_t*)sg.up(ad.version_key, (size_t)na), (uint16_t*)sg.up(ad.flags, (size_t)na)};
-  f.d_add_dep_off = sg.up(na > 0 ? ad.dep_off : (const int32_t*)nullptr, (size_t)na + 1);
-  f.a_edges = EdgeCols{(int32_t*)sg.up(ad.dep_idx, (size_t)EA), (uint8_t*)sg.up(ad.dep_info, (size_t)EA), (int64_t*)sg.up(ad.dep_finished_ts_ns, (size_t)EA)};
-  (void)rc;
   return sg.rc;
 }
 
