@@ -289,11 +289,12 @@ def delta_tick(batch, native, dev_index, got):
             bytes_in = delta.bytes_in() + k * (4 + 8 + 8)
             rows_info = {"removed": int(len(gone)), "added": int(len(late)), "values_changed": int(k), "relinked_edges": int(len(delta.relinked_edges))}
         # ---- the same ticks as ONE call (evg_pool_tick, ABI 3.3): delta + updates + plan + download behind one synchronisation ----
-        t_fused, t_lean, same_fused = [], [], None
+        t_fused, t_lean, t_place, same_fused = [], [], [], None
         if hasattr(ctx.lib, "evg_pool_tick"):
             same_fused = True
-            for tick in range(6):  # ticks 3..5: the same ticks without wait_ns (8 of the 14.7 bytes per task that come back)
-                lean, tick = tick >= 3, tick % 3
+            for tick in range(9):  # ticks 3..5: the same ticks without wait_ns (8 of the 14.7 bytes per task that come back);
+                # 6..8: without wait_ns AND with the delta + updates built in ONE evg_host_alloc block (read by DMA where they are: no packing)
+                lean, in_place, tick = tick >= 3, tick >= 6, tick % 3
                 pool0, delta, late, gone = pool_delta.split_tick(batch, 0.025, 0.025, seed=100 + tick)
                 pool1 = pool_delta.apply_delta(pool0, delta)
                 n1 = pool1.n_tasks
@@ -304,8 +305,13 @@ def delta_tick(batch, native, dev_index, got):
                 now = batch.now_ns + 15 * 10**9
                 ctx.pool_load(ctx.pinned_batch(pool0))
                 res = ctx.pinned_result(abi.PlanResult.alloc_host(pool1, breakdown=False, n_units=False, wait=not lean))
-                blk, keep = ctx.make_pool_delta(**delta.kwargs())
-                upd = ctx.make_pool_update(rows, {"priority": pri, "expected_duration_ns": dur})
+                if in_place:
+                    kw, urows, ucols = ctx.pinned_pack((delta.kwargs(), rows, {"priority": pri, "expected_duration_ns": dur}))
+                    blk, keep = ctx.make_pool_delta(**kw)
+                    upd = ctx.make_pool_update(urows, ucols)
+                else:
+                    blk, keep = ctx.make_pool_delta(**delta.kwargs())
+                    upd = ctx.make_pool_update(rows, {"priority": pri, "expected_duration_ns": dur})
                 t0 = time.perf_counter()
                 try:
                     ctx.pool_tick(pool1, now, delta=blk, update=upd, into=res)
@@ -313,7 +319,7 @@ def delta_tick(batch, native, dev_index, got):
                     if not lean:
                         raise
                     continue  # (an A/B library from before wait_ns became optional)
-                (t_lean if lean else t_fused).append(time.perf_counter() - t0)
+                (t_place if in_place else t_lean if lean else t_fused).append(time.perf_counter() - t0)
                 pool1.cols["priority"][rows], pool1.cols["expected_duration_ns"][rows] = pri, dur
                 pool1.now_ns = now
                 full = ctx.plan(pool1, breakdown=False, n_units=False)
@@ -324,6 +330,7 @@ def delta_tick(batch, native, dev_index, got):
         ms3 = (med(t_delta) + med(t_upd) + med(t_plan)) * 1e3
         ms = med(t_fused) * 1e3 if t_fused else ms3  # the tick IS evg_pool_tick since ABI 3.3; the three calls are reported beside it
         return {"value": batch.n_tasks / (ms * 1e-3), "unit": "tasks/s", "ms_per_tick": ms, "ms_per_tick_without_wait_ns": med(t_lean) * 1e3 if t_lean else None,
+                "ms_per_tick_without_wait_ns_in_place": med(t_place) * 1e3 if t_fused and t_place else None,
                 "three_calls_ms_per_tick": ms3, "apply_delta_ms": med(t_delta) * 1e3, "update_ms": med(t_upd) * 1e3,
                 "plan_and_download_ms": med(t_plan) * 1e3, "rows_per_tick": rows_info, "bytes_in_per_tick": int(bytes_in),
                 "identical_to_full_upload": same,
@@ -334,7 +341,8 @@ def delta_tick(batch, native, dev_index, got):
                 "what": "per tick: 2.5 % of the rows removed, 2.5 % added, the dependents' edges relinked (re-packed on the device), 5 % of the rows with a "
                         "new priority + expected duration, a new now_ns; order / deps_met / wait / info rows downloaded into page-locked buffers; host wall "
                         "clock, median of three ticks. ms_per_tick = ONE call, evg_pool_tick (without_wait_ns: out->wait_ns NULL, 6.7 instead of 14.7 MB "
-                        "back); three_calls_ms_per_tick = evg_pool_apply_delta + evg_pool_update + evg_pool_plan (apply_delta_ms + update_ms + "
+                        "back; in_place: the caller built the delta and the updates in one evg_host_alloc block, which the library reads by DMA "
+                        "where it is instead of packing 3.7 MB into its own); three_calls_ms_per_tick = evg_pool_apply_delta + evg_pool_update + evg_pool_plan (apply_delta_ms + update_ms + "
                         "plan_and_download_ms)"}
     finally:
         ctx.close()

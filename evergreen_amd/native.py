@@ -461,6 +461,47 @@ class Context:
         out[...] = a
         return out
 
+    def pinned_pack(self, tree, block=None):
+        """`tree` (arrays, None, nested dicts / lists / tuples of them) with every array copied into ONE evg_host_alloc block, each at a
+        256-byte offset: what a shim does that builds a tick's delta and updates in a block of its own. The library does not re-pack arrays
+        it finds in such a block (>= 1 MiB): it mirrors the block on the device and moves the stretch a call names in one copy.
+        `block`: a uint8 array from pinned_empty to pack into (from its start) instead of a new one."""
+        arrays = []
+
+        def walk(x):
+            if isinstance(x, np.ndarray):
+                arrays.append(x)
+            elif isinstance(x, dict):
+                for v in x.values():
+                    walk(v)
+            elif isinstance(x, (list, tuple)):
+                for v in x:
+                    walk(v)
+        walk(tree)
+        total = sum((a.nbytes + 255) & ~255 for a in arrays) + 256
+        if block is None:
+            block = self.pinned_empty(max(total, 1 << 20), np.uint8)
+        assert block.nbytes >= total and block.ctypes.data % 256 == 0, "the block is too small for the arrays"
+        off, done = 0, {}
+
+        def place(x):
+            nonlocal off
+            if isinstance(x, np.ndarray):
+                if id(x) in done:
+                    return done[id(x)]
+                src = np.ascontiguousarray(x)
+                out = block[off:off + src.nbytes].view(src.dtype).reshape(src.shape)
+                out[...] = src
+                off += (src.nbytes + 255) & ~255
+                done[id(x)] = out
+                return out
+            if isinstance(x, dict):
+                return {k: place(v) for k, v in x.items()}
+            if isinstance(x, (list, tuple)):
+                return type(x)(place(v) for v in x)
+            return x
+        return place(tree)
+
     def pinned_batch(self, batch: abi.PlanBatch) -> abi.PlanBatch:
         """The batch with every column in page-locked memory: what a shim that builds its columns in evg_host_alloc
         buffers hands to evg_plan_distros / evg_allocate_hosts."""

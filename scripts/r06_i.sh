@@ -12,7 +12,7 @@ for l in sys.stdin:
     try: o = json.loads(l)
     except Exception: print(l.rstrip()); continue
     f = o.get('fused') or {}
-    print('three calls %.3f ms (delta %.3f update %.3f plan %.3f)  fused %.3f  fused lean %s  same %s %s' % (o.get('three_calls_ms_per_tick', o['ms_per_tick']), o['apply_delta_ms'], o['update_ms'], o['plan_and_download_ms'], f.get('ms_per_tick', 0), f.get('ms_per_tick_without_wait_ns'), o['identical_to_full_upload'], f.get('identical_to_full_upload')))
+    print('three calls %.3f ms (delta %.3f update %.3f plan %.3f)  fused %.3f  fused lean %s  in place %s  same %s %s' % (o.get('three_calls_ms_per_tick', o['ms_per_tick']), o['apply_delta_ms'], o['update_ms'], o['plan_and_download_ms'], f.get('ms_per_tick', 0), f.get('ms_per_tick_without_wait_ns'), o.get('ms_per_tick_without_wait_ns_in_place'), o['identical_to_full_upload'], f.get('identical_to_full_upload')))
 "
 done; done
 echo "=== laps (sched)"; EVG_TICK_TIMING=1 timeout -k 5 300 python scripts/bench_delta.py 1 2>&1 | grep "^\[tick\]" | tail -14

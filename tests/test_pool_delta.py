@@ -271,6 +271,60 @@ def test_resident_entry_points_take_no_wait_ns(native_ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [gen.GenConfig(60_000, 24, gen.SEED_BASE + 31, skew=True), gen.GenConfig(3_000, 40, 321)], ids=["skewed", "small"])
+def test_a_tick_built_in_one_page_locked_block_is_read_where_it_is(native_ctx, oracle, cfg):
+    """Arrays a caller hands over inside ONE large evg_host_alloc block (>= 1 MiB, 256-byte offsets) are not packed into the library's
+    staging block: the block is mirrored on the device and the stretch a call names goes up in one copy per flush. Same results as the
+    packed path -- through evg_pool_apply_delta + evg_pool_update, through evg_pool_tick, twice in a row out of the SAME block (the second
+    tick re-uses it with other contents), and with one array at an offset that is not a multiple of 256 (that one is packed)."""
+    full, pool0, delta, _, _ = _tick(cfg)
+    native_ctx.pool_load(pool0)
+    pool1 = pool_delta.apply_delta(pool0, delta)
+    rng = np.random.default_rng(13)
+    k = max(pool1.n_tasks // 20, 1)
+    rows = np.sort(rng.choice(pool1.n_tasks, size=k, replace=False)).astype(np.int32)
+    pri = rng.integers(0, 100, k).astype(np.int64)
+    raw = native_ctx.pinned_empty(16 << 20, np.uint8)
+    kw, urows, ucols = native_ctx.pinned_pack((delta.kwargs(), rows, {"priority": pri}), block=raw)
+    assert kw["removed_rows"].ctypes.data % 256 == 0 and raw.ctypes.data <= kw["removed_rows"].ctypes.data < raw.ctypes.data + raw.nbytes
+    blk, keep = native_ctx.make_pool_delta(**kw)
+    now = pool1.now_ns + 15 * 10**9
+    got = native_ctx.pool_tick(pool1, now, delta=blk, update=native_ctx.make_pool_update(urows, ucols), n_units=True)
+    pool1.cols["priority"][rows] = pri
+    pool1.now_ns = now
+    want = oracle.plan(pool1, breakdown=False, n_units=True)
+    want.breakdown = None
+    compare.assert_plan_equal(got, want, pool1, "a tick out of one page-locked block")
+    # the three calls, out of the same block with other contents; the row list sits one int32 off a 256-byte offset: packed, not mirrored
+    gone = np.sort(rng.choice(pool1.n_tasks, max(pool1.n_tasks // 40, 1), replace=False)).astype(np.int32)
+    d2 = pool_delta.Delta(removed_rows=gone, removed_dep_state=np.full(len(gone), 1 << 2, np.uint8), removed_finished_ts_ns=None,
+                          added_distro=np.zeros(0, np.int32), added_cols=pool_delta.empty_added()[1], added_dep_off=np.zeros(1, np.int32),
+                          added_edges=pool_delta.empty_added()[3])
+    pool2 = pool_delta.apply_delta(pool1, d2)
+    g2 = raw[4:4 + gone.nbytes].view(np.int32)
+    g2[...] = gone
+    st2 = raw[1 << 19:(1 << 19) + len(gone)]
+    st2[...] = 1 << 2
+    kw2 = dict(d2.kwargs())
+    kw2["removed_rows"], kw2["removed_dep_state"] = g2, st2
+    native_ctx.pool_apply_delta(**kw2)
+    k2 = max(pool2.n_tasks // 30, 1)
+    rows2 = np.sort(rng.choice(pool2.n_tasks, size=k2, replace=False)).astype(np.int32)
+    dur2 = (rng.integers(10, 9_000, k2) * 10**9).astype(np.int64)
+    r2 = raw[1 << 18:(1 << 18) + rows2.nbytes].view(np.int32)
+    r2[...] = rows2
+    v2 = raw[3 << 18:(3 << 18) + dur2.nbytes].view(np.int64)
+    v2[...] = dur2
+    native_ctx.pool_update(r2, {"expected_duration_ns": v2})
+    pool2.cols["expected_duration_ns"][rows2] = dur2
+    got = native_ctx.pool_plan(pool2, pool2.now_ns, n_units=True)
+    want = oracle.plan(pool2, breakdown=False, n_units=True)
+    want.breakdown = None
+    compare.assert_plan_equal(got, want, pool2, "the three calls out of the same block")
+    del keep
+
+
+@pytest.mark.gpu
 def test_fused_tick_refuses_what_the_three_calls_refuse_and_leaves_the_pool(native_ctx, oracle):
     from evergreen_amd import native
     full, pool0, delta, _, _ = _tick(gen.GenConfig(20_000, 9, gen.SEED_BASE + 61, tg_fraction=0.3))
