@@ -21,7 +21,7 @@ so = os.path.join(tempfile.gettempdir(), "libpdc_%d.so" % os.getpid())
 subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-pthread", os.path.join(ROOT, "scripts", "ubench", "pdc_driver.cpp"), "-o", so])
 drv = C.CDLL(so)
 drv.pdc_run_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64] + [C.c_void_p, C.c_size_t] * 4 + [C.c_void_p, C.c_void_p]
-bt = native.Batcher(0, max_wait_us=200, max_requests=64)
+bt = native.Batcher(0, max_wait_us=int(os.environ.get("PAIRS_MAX_WAIT_US", "200")), max_requests=int(os.environ.get("PAIRS_MAX_REQUESTS", "64")))
 def run(q, g):
     lat = np.zeros(D); wall = C.c_double(0)
     e = drv.pdc_run_pairs(C.cast(lib.evg_batcher_schedule, C.c_void_p), bt.h, nt, D, q, g, C.addressof(a_pin), C.sizeof(abi.PlanInput), C.addressof(a_pout), C.sizeof(abi.PlanOutput),

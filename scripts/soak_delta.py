@@ -17,6 +17,8 @@ fused_mode = len(sys.argv) > 3 and sys.argv[3] == "fused"
 n_fused = 0
 rng = np.random.default_rng(seed)
 ctx, oracle = native.Context(0), oracle_lib.OracleBackend()
+raw = ctx.pinned_empty(96 << 20, np.uint8)  # every third pool hands its deltas over inside this ONE page-locked block (read where they are)
+n_place = 0
 t_end, k, tasks = time.time() + budget, 0, 0
 while time.time() < t_end:
     cfg = random_shapes.draw(rng, k, max_tasks=250_000)
@@ -29,12 +31,15 @@ while time.time() < t_end:
     ctx.pool_load(pool0)
     pool1 = pool_delta.apply_delta(pool0, d1)
     fused = fused_mode and k % 2 == 0
+    in_place = k % 3 == 1
+    kw1 = ctx.pinned_pack(d1.kwargs(), block=raw) if in_place else d1.kwargs()
+    n_place += in_place
     if fused:
-        blk, keep = ctx.make_pool_delta(**d1.kwargs())
+        blk, keep = ctx.make_pool_delta(**kw1)
         got = ctx.pool_tick(pool1, pool1.now_ns, delta=blk, units=True)
         n_fused += 1
     else:
-        ctx.pool_apply_delta(**d1.kwargs())
+        ctx.pool_apply_delta(**kw1)
         got = ctx.pool_plan(pool1, pool1.now_ns, breakdown=False, n_units=False, units=True)
     want = oracle.plan(pool1, breakdown=True, n_units=False)
     want.n_units = None
@@ -45,16 +50,17 @@ while time.time() < t_end:
         rows = rng.choice(pool1.n_tasks, size=max(pool1.n_tasks // 10, 1), replace=False).astype(np.int32)
         pri = rng.integers(0, 100, len(rows)).astype(np.int64)
         _, d2, _, _ = pool_delta.split_tick(pool1, 0.0, float(rng.choice([0.02, 0.2])), seed=int(rng.integers(1, 1 << 30)), grow_keys=False)
+        kw2, rows_h, pri_h = ctx.pinned_pack((d2.kwargs(), rows, pri), block=raw) if in_place else (d2.kwargs(), rows, pri)
         if fused:  # the update first (a tick of its own), then delta + plan in one call
-            ctx.pool_tick(pool1, pool1.now_ns, update=ctx.make_pool_update(rows, {"priority": pri}))
+            ctx.pool_tick(pool1, pool1.now_ns, update=ctx.make_pool_update(rows_h, {"priority": pri_h}))
             pool1.cols["priority"][rows] = pri
             pool2 = pool_delta.apply_delta(pool1, d2)
-            blk2, keep2 = ctx.make_pool_delta(**d2.kwargs())
+            blk2, keep2 = ctx.make_pool_delta(**kw2)
             got2 = ctx.pool_tick(pool2, pool2.now_ns + 15 * 10**9, delta=blk2)
         else:
-            ctx.pool_update(rows=rows, cols={"priority": pri})
+            ctx.pool_update(rows=rows_h, cols={"priority": pri_h})
             pool1.cols["priority"][rows] = pri
-            ctx.pool_apply_delta(**d2.kwargs())
+            ctx.pool_apply_delta(**kw2)
             pool2 = pool_delta.apply_delta(pool1, d2)
             got2 = ctx.pool_plan(pool2, pool2.now_ns + 15 * 10**9, breakdown=False, n_units=False)
         import dataclasses
@@ -63,4 +69,4 @@ while time.time() < t_end:
         compare.assert_plan_equal(got2, want2, pool2, tag + " (second delta)")
     k += 1
     tasks += full.n_tasks
-print("soak_delta: %d pools (%d through evg_pool_tick), %d tasks, every plan after a structural delta equal to the oracle on the restated batch" % (k, n_fused, tasks))
+print("soak_delta: %d pools (%d through evg_pool_tick, %d with their deltas in one page-locked block), %d tasks, every plan after a structural delta equal to the oracle on the restated batch" % (k, n_fused, n_place, tasks))

@@ -64,7 +64,10 @@ def test_pair_requests_from_sixty_four_threads(native, oracle):
         compare.assert_alloc_equal(r[1], wa, "pair %d" % d)
     # one request per distro where the two calls make two; how many launch sequences they leave in depends on how the 64 Python threads
     # trickle in behind the GIL (a batch closes when arrivals stop): fewer than requests, not a fixed number
-    assert st["requests"] == 64 and st["batches"] < st["requests"], st
+    # (19 runs of 20 in a row on one box saw fewer batches than requests, one saw 64 batches of one -- profiles/r06m_hang_hunt.log: not a
+    # promise. That requests DO share launch sequences is pinned where callers are native threads: tests/cpp/test_batcher_tsan.cpp,
+    # bench.py's per_distro_calls.)
+    assert st["requests"] == 64 and st["batches"] <= st["requests"], st
 
 
 def test_pair_of_several_distros_large_shapes_and_a_direct_one(native, oracle, monkeypatch):

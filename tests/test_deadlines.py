@@ -2,6 +2,7 @@
 job 5 min, units/scheduler.go:18; the host allocator job 10 min, units/host_allocator.go:32). Every device wait of the library polls
 against a deadline; on expiry the call returns EVG_E_TIMEOUT, the object is poisoned and refuses further work, and destroying it does not
 block either. Test hook: evg_debug_stall -- a kernel that spins for a given time on the object's own stream."""
+import os
 import threading
 import time
 
@@ -23,7 +24,7 @@ def native():
 def test_single_device_call_gives_up_and_the_context_is_poisoned(native, oracle):
     batch = gen.generate(gen.config(1))
     ctx = native.Context(0)
-    assert ctx.deadline_ms() == 30000
+    assert ctx.deadline_ms() == int(os.environ.get("EVG_DEADLINE_MS", "30000"))  # (the hang hunt runs the suites under a shorter default)
     ctx.set_deadline_ms(300)
     ctx.debug_stall(1500)
     t0 = time.perf_counter()
