@@ -181,9 +181,22 @@ struct Slot {
   std::chrono::steady_clock::time_point opened, last_join;
   std::atomic<int> packed{0};
   std::atomic<int> final_members{0};  // set when the batch closes (0: still open): the member whose packing completes it wakes the leader
-  int unpacked = 0;
+  std::atomic<int> unpacked{0};     // members that have cut their results out: the last one frees the slot (only it takes the mutex)
   std::condition_variable cv_lead;  // the leader's: a join, the last member's packing
-  std::condition_variable cv_done;  // the members': the batch's results are in h_out
+  // The members' wait for the results has a mutex of the SLOT's own (late round 6). With the batcher's one mutex under it, the 64
+  // members a batch wakes queued for that mutex one hand-over at a time -- in the way of the callers joining the next batch; a request
+  // took the batcher's mutex four times (join, wake-up, leave, return) and ~130-180 k requests/s was all any number of callers got
+  // (512 pairs: ~5 ms from 64, 128, 256 or 512 callers). It takes it once now (the join); the last member to leave takes it again.
+  // ... and the members wait in kDoneShards groups (by the order they joined in), each with a mutex of its own: the 64 threads one
+  // notify_all wakes re-acquire the mutex they waited with one after the other.
+  static constexpr int kDoneShards = 8;
+  struct DoneShard {
+    std::mutex mu;
+    std::condition_variable cv;  // (with mu) the batch's results are in h_out
+    uint64_t seq = 0;            // (mu) == open_seq of the batch whose results are there
+  };
+  DoneShard done[kDoneShards];
+  uint64_t open_seq = 0;            // (the batcher's mutex) counts the batches this slot has held
   // results of the batch (valid in DONE)
   int rc = EVG_OK;
   std::string err;
@@ -204,7 +217,7 @@ struct Batcher {
   std::condition_variable cv_idle;  // evg_batcher_close: the last caller left
   Slot<BE> slot[4];
   std::atomic<int> inside{0};       // threads between entry and return of an entry point
-  int inside_kind[K_KINDS] = {0, 0, 0};  // ... of them, callers that are on their way into (or inside) a batch of that kind
+  std::atomic<int> inside_kind[K_KINDS] = {{0}, {0}, {0}};  // ... of them, callers that are on their way into (or inside) a batch of that kind
   int expect[K_KINDS] = {1, 1, 1};  // how many callers a batch of a kind waits for before its window ends: the recent peak of
                                     // inside_kind, halved whenever a window ran out short of it
   typename BE::Dev* direct = nullptr;  // requests too large for a batch go straight through (serialised by the context's mutex)
@@ -218,7 +231,7 @@ struct Batcher {
   uint64_t use_clock = 0;
   // counters
   uint64_t n_batches = 0, n_requests = 0, n_direct = 0, max_batch = 0, n_hits = 0, n_fills = 0;
-  bool closing = false;
+  std::atomic<bool> closing{false};  // (stored under the mutex; a returning caller looks at it without)
 };
 
 static inline int fail(char* err, int32_t err_len, int code, const char* fmt, ...) {
@@ -337,7 +350,8 @@ static Slot<BE>* join_slot(Batcher<BE>* b, std::unique_lock<std::mutex>& lk, int
       }
       s.state = Slot<BE>::OPEN; s.kind = kind; s.members.clear(); s.in_used = 0;
       s.N = s.E = s.D = s.TG = s.V = s.H = 0; s.want = 0; s.any_fin = false;
-      s.packed.store(0); s.final_members.store(0); s.unpacked = 0; s.rc = EVG_OK; s.err.clear();
+      s.packed.store(0); s.final_members.store(0); s.unpacked.store(0); s.rc = EVG_OK; s.err.clear();
+      s.open_seq++;
       s.opened = s.last_join = std::chrono::steady_clock::now();
       *leader = true;
       return &s;
@@ -593,7 +607,13 @@ static void lead(Batcher<BE>* b, Slot<BE>& s) {
     b->n_requests += (uint64_t)members;
     b->max_batch = std::max<uint64_t>(b->max_batch, (uint64_t)members);
   }
-  s.cv_done.notify_all();
+  for (auto& sh : s.done) {  // (open_seq cannot move: the slot is not FREE before every member has left)
+    {
+      std::lock_guard<std::mutex> dl(sh.mu);
+      sh.seq = s.open_seq;
+    }
+    sh.cv.notify_all();
+  }
 }
 
 // A member has packed its columns.
@@ -612,12 +632,15 @@ static void packed_one(Batcher<BE>* b, Slot<BE>& s) {
 // Every member after it has cut its results out: the last one frees the slot.
 template <class BE>
 static void leave(Batcher<BE>* b, Slot<BE>& s) {
-  std::unique_lock<std::mutex> lk(b->mu);
-  if (++s.unpacked == (int)s.members.size()) {
+  // (the membership has been final since the batch closed; the increment orders every member's reads of the slot before the last
+  // member's release of it)
+  const int fin = (int)s.members.size();  // read BEFORE this member counts itself out: afterwards the slot may be re-opened under it
+  if (s.unpacked.fetch_add(1, std::memory_order_acq_rel) + 1 != fin) return;
+  {
+    std::lock_guard<std::mutex> lk(b->mu);
     s.state = Slot<BE>::FREE;
-    lk.unlock();
-    b->cv_free.notify_all();
   }
+  b->cv_free.notify_all();
 }
 
 template <class BE>
@@ -627,9 +650,14 @@ struct Inside {  // counts the calling thread as inside the batcher for the leng
   explicit Inside(Batcher<BE>* b_) : b(b_) { b->inside.fetch_add(1, std::memory_order_acq_rel); }
   void batching(int k) { kind = k; }  // (with b->mu held) the caller is on its way into a batch of kind k
   ~Inside() {
-    std::lock_guard<std::mutex> lk(b->mu);
-    if (kind >= 0) b->inside_kind[kind]--;
-    if (b->inside.fetch_sub(1, std::memory_order_acq_rel) == 1 && b->closing) b->cv_idle.notify_all();
+    // No mutex on the way out unless somebody is closing the batcher. Sequentially consistent on both sides (this decrement, then the
+    // load of `closing`; evg_batcher_close's store of `closing`, then its load of `inside` under the mutex): either this caller sees
+    // the close and wakes it under the mutex, or the close sees the caller gone.
+    if (kind >= 0) b->inside_kind[kind].fetch_sub(1);
+    if (b->inside.fetch_sub(1) == 1 && b->closing.load()) {
+      std::lock_guard<std::mutex> lk(b->mu);
+      b->cv_idle.notify_all();
+    }
   }
 };
 
@@ -674,7 +702,7 @@ static void batcher_close(Batcher<BE>* b) {
   b->cv_free.notify_all();
   for (Slot<BE>& s : b->slot) s.cv_lead.notify_all();
   b->cv_idle.wait(lk, [&] {
-    if (b->inside.load(std::memory_order_acquire) != 0) return false;
+    if (b->inside.load() != 0) return false;
     for (const Slot<BE>& s : b->slot) if (s.state != Slot<BE>::FREE) return false;
     return true;
   });
@@ -819,6 +847,8 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
   // ---- join ----
   bool leader = false;
   Slot<BE>* sp;
+  uint64_t my_seq = 0;
+  int my_shard = 0;
   {
     if (!jl.owns_lock()) jl.lock();
     std::unique_lock<std::mutex>& lk = jl;
@@ -833,6 +863,8 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
                       : fail(err, err_len, EVG_E_NOMEM, "cannot allocate the batch's page-locked block");
     }
     Slot<BE>& s = *sp;
+    my_seq = s.open_seq;
+    my_shard = (int)(s.members.size() % Slot<BE>::kDoneShards);
     m.src = s.in_used; s.in_used += al256(bytes);
     m.r0 = s.N; m.e0 = s.E; m.d0 = s.D; m.g0 = s.TG; m.v0 = s.V; m.h0 = s.H;
     s.N += m.n; s.E += m.e; s.D += m.nd; s.TG += m.ntg; s.V += m.nver; s.H += m.nh;
@@ -849,7 +881,7 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
     }
     s.members.push_back(m);
     s.last_join = std::chrono::steady_clock::now();
-    b->expect[kind] = std::max(b->expect[kind], b->inside_kind[kind]);
+    b->expect[kind] = std::max(b->expect[kind], b->inside_kind[kind].load());
     if (!leader) s.cv_lead.notify_one();
     jl.unlock();
   }
@@ -900,8 +932,9 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
   // ---- run / wait ----
   if (leader) lead(b, s);
   else {
-    std::unique_lock<std::mutex> lk(b->mu);
-    s.cv_done.wait(lk, [&] { return s.state == Slot<BE>::DONE; });
+    auto& sh = s.done[my_shard];
+    std::unique_lock<std::mutex> dl(sh.mu);
+    sh.cv.wait(dl, [&] { return sh.seq == my_seq; });
   }
   // ---- cut the results out (the slot stays DONE until every member left) ----
   const int rc = s.rc;
