@@ -210,6 +210,7 @@ struct Batcher {
   int device = 0;
   int32_t max_wait_us = 200, max_requests = 64;
   int32_t idle_us = 40;  // EVG_BATCHER_IDLE_US: a batch that has members closes when nobody joined for this long (arrivals have stopped)
+  int32_t split_from = 16;  // EVG_BATCHER_SPLIT: from this many expected callers on, a batch with nothing else in flight leaves at half of them (0: never)
   size_t max_batch_bytes = 32u << 20;  // of packed inputs per batch (EVG_BATCHER_MAX_BYTES); a request above half of it goes straight through
   int64_t deadline_ms = 30000;
   std::mutex mu;
@@ -564,7 +565,13 @@ static void lead(Batcher<BE>* b, Slot<BE>& s) {
       int elsewhere = 0;  // callers of this kind blocked in other batches that are still filling or on the device: they cannot join this one
       for (const Slot<BE>& o : b->slot)  // (the members of a batch that is DONE are about to return and call again: they are expected here)
         if (&o != &s && o.kind == s.kind && (o.state == Slot<BE>::OPEN || o.state == Slot<BE>::CLOSED)) elsewhere += (int)o.members.size();
-      const int target = std::max(1, std::min<int>(b->max_requests, b->expect[s.kind] - elsewhere));
+      int target = std::max(1, std::min<int>(b->max_requests, b->expect[s.kind] - elsewhere));
+      // Two batches in flight beat one (late round 6): callers in a closed loop that all sit in ONE batch leave the device idle while
+      // they wake, cut their results out, return and join again (~110 us of a ~330 us round with 64 callers), and the link idle while
+      // the kernels run. When nothing of this kind is in flight and many callers are expected, the batch leaves at HALF of them; the
+      // other half forms the next batch while this one is on the device, and from then on each group is what `expect - elsewhere` waits
+      // for (512 resident pair requests from 64 callers: 3.5-4.7 -> 2.7-3.2 ms with batches capped at 32, 5.7 -> 4.3-5.3 with unit rows).
+      if (elsewhere == 0 && b->split_from > 0 && b->expect[s.kind] >= b->split_from) target = std::min(target, (b->expect[s.kind] + 1) / 2);
       members = (int)s.members.size();
       const auto now = clk::now();
       const bool timed_out = now >= deadline;
@@ -682,6 +689,7 @@ static B* batcher_create(int device_ordinal, int32_t max_wait_us, int32_t max_re
   if (const char* m = getenv("EVG_DEADLINE_MS")) { const long long v = atoll(m); if (v >= 0) b->deadline_ms = v; }
   if (const char* m = getenv("EVG_BATCHER_IDLE_US")) { const long long v = atoll(m); if (v >= 0) b->idle_us = (int32_t)std::min<long long>(v, 1000000); }
   b->idle_us = std::min(b->idle_us, b->max_wait_us);
+  if (const char* m = getenv("EVG_BATCHER_SPLIT")) { const long long v = atoll(m); if (v >= 0) b->split_from = (int32_t)std::min<long long>(v, 1 << 20); }
   b->direct = BE::dev_create(device_ordinal);
   bool ok = b->direct != nullptr;
   for (Slot<BE>& s : b->slot) {
