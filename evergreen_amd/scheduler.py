@@ -301,15 +301,19 @@ class PackedQueues:
     tasks: List[List[Task]]            # per distro, input order (row = task_off[d] + i)
     tg_names: List[str]                # tg key -> group string
     tg_key_of: List[Dict[str, int]]    # per distro: group string -> key
+    ver_key_of: List[Dict[str, int]] = field(default_factory=list)  # per distro: version id -> key
 
 
 def pack_queues(queues: Sequence[Tuple[Distro, Sequence[Task]]], now_ns: int,
                 dep_lookup: Optional[DepLookup] = None,
-                includes_dependencies: Optional[Sequence[bool]] = None) -> PackedQueues:
+                includes_dependencies: Optional[Sequence[bool]] = None,
+                seed_keys: Optional[Sequence[Tuple[Sequence[str], Sequence[str]]]] = None) -> PackedQueues:
     """Interns strings and lays the D (distro, tasks) queues out as the ABI's struct-of-arrays.
 
     Does what PopulateCaches (setup_funcs.go:18-67) leaves behind -- resolved durations -- plus the
-    string->key interning of SURVEY.md 8b'. Keys are numbered in order of first appearance per distro."""
+    string->key interning of SURVEY.md 8b'. Keys are numbered in order of first appearance per distro.
+    `seed_keys[d]` = (task-group strings, version ids) that already HAVE keys in distro d, in key order: they keep them whether or not a
+    task still names them, new strings follow (a resident pool's key ranges only grow, at a distro's end: evg_pool_delta)."""
     D = len(queues)
     n = sum(len(ts) for _, ts in queues)
     cols = {k: np.zeros(n, dt) for k, dt in abi.TASK_COLUMNS.items()}
@@ -324,6 +328,7 @@ def pack_queues(queues: Sequence[Tuple[Distro, Sequence[Task]]], now_ns: int,
     dep_fin: List[int] = []
     tg_names: List[str] = []
     tg_key_of: List[Dict[str, int]] = []
+    ver_key_of: List[Dict[str, int]] = []
     bare_names: Dict[str, int] = {}
     r = 0
     n_tg = n_ver = 0
@@ -345,6 +350,12 @@ def pack_queues(queues: Sequence[Tuple[Distro, Sequence[Task]]], now_ns: int,
         row_of = {t.Id: r + i for i, t in enumerate(tasks)}
         tgk: Dict[str, int] = {}
         verk: Dict[str, int] = {}
+        if seed_keys is not None:
+            for s_ in seed_keys[d][0]:
+                tgk[s_] = n_tg + len(tgk)
+                tg_names.append(s_)
+            for v_ in seed_keys[d][1]:
+                verk[v_] = n_ver + len(verk)
         for i, t in enumerate(tasks):
             x = r + i
             cols["priority"][x] = t.Priority
@@ -393,6 +404,7 @@ def pack_queues(queues: Sequence[Tuple[Distro, Sequence[Task]]], now_ns: int,
                 dep_fin.append(0 if dep.FinishedAt is None else dep.FinishedAt)
             dep_off.append(len(dep_idx))
         tg_key_of.append(tgk)
+        ver_key_of.append(verk)
         r += len(tasks)
         n_tg += len(tgk)
         n_ver += len(verk)
@@ -403,7 +415,7 @@ def pack_queues(queues: Sequence[Tuple[Distro, Sequence[Task]]], now_ns: int,
                           edges=edges, distros=distros, task_off=task_off, tg_off=tg_off, ver_off=ver_off,
                           tg_name_key=tg_name_key)
     batch.check()
-    return PackedQueues(batch, [list(ts) for _, ts in queues], tg_names, tg_key_of)
+    return PackedQueues(batch, [list(ts) for _, ts in queues], tg_names, tg_key_of, ver_key_of)
 
 
 def _info_from_rows(packed: PackedQueues, res: abi.PlanResult, d: int) -> DistroQueueInfo:
@@ -443,6 +455,12 @@ def PlanDistros(backend: Backend, queues: Sequence[Tuple[Distro, Sequence[Task]]
     `includes_dependencies` overrides it (for callers of GetDistroQueueInfo itself)."""
     packed = pack_queues(queues, now_ns, dep_lookup, includes_dependencies)
     res = backend.plan(packed.batch, breakdown=True)
+    return _plans_from_result(packed, res, now_ns, opts)
+
+
+def _plans_from_result(packed: PackedQueues, res: abi.PlanResult, now_ns: int,
+                       opts: Optional[Sequence[TaskPlannerOptions]] = None) -> List[Tuple[List[Task], DistroQueueInfo]]:
+    """(plan, DistroQueueInfo) per distro from the rows a backend returned: the Task objects of `packed` re-ordered and stamped."""
     out = []
     b = packed.batch
     names = list(abi.BD)
@@ -604,3 +622,229 @@ def UtilizationBasedHostAllocator(backend: Backend, data: HostAllocatorData, now
 
 def GetHostAllocator(name: str):                   # scheduler/host_allocator.go:23-30
     return UtilizationBasedHostAllocator
+
+
+# ---- the resident pool driven from the reference's own data model (evg_pool_load / evg_pool_tick) --------------------------------------
+# The reference re-plans every distro every 15 s (units/crons_remote_fifteen_second.go:21,58-60) from the task lists the finder returns;
+# between two ticks a few per cent of a queue change. ResidentPlanner takes those lists tick after tick -- the arguments of PlanDistros --
+# and keeps the pool on the device: it works out what left, what arrived, which values and which dependency states changed, hands
+# evg_pool_tick a structural delta + value updates, and keeps the id -> row map the way the device re-packs (kept rows of a distro in
+# their order, then its added rows). Results are those of PlanDistros on the same lists (tests/test_resident_planner.py).
+
+_UPDATABLE = ("priority", "expected_duration_ns", "queue_ts_ns", "scheduled_ts_ns", "deps_met_ts_ns", "num_dependents", "flags")
+
+
+class ResidentContext:
+    """The resident entry points of a native.Context (duck-typed: make_pool_delta / make_pool_update / pool_load / pool_tick) behind the
+    two calls ResidentPlanner makes."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def pool_load(self, batch: abi.PlanBatch) -> None:
+        self.ctx.pool_load(batch)
+
+    def pool_tick(self, batch_after: abi.PlanBatch, now_ns: int, delta: Optional[dict] = None, rows=None, cols=None, edges=None,
+                  dep_info=None, dep_finished_ts_ns=None) -> abi.PlanResult:
+        blk, keep = self.ctx.make_pool_delta(**delta) if delta is not None else (None, None)
+        upd = None
+        if (rows is not None and len(rows)) or (edges is not None and len(edges)):
+            upd = self.ctx.make_pool_update(rows, cols, edges, dep_info, dep_finished_ts_ns)
+        res = self.ctx.pool_tick(batch_after, now_ns, delta=blk, update=upd, units=True)
+        res.breakdown = res.expand_breakdown()
+        del keep
+        return res
+
+
+class ResidentPlanner:
+    """PlanDistros for a caller that comes back every tick with the same distros: the pool stays on the device between calls.
+
+    plan(queues, now_ns, ...) takes PlanDistros' arguments and returns what it returns. The first call -- and any call after the set of
+    distros, a distro's planner settings or a task list with duplicate ids changed the ground under the pool -- uploads everything
+    (evg_pool_load); every other call is ONE evg_pool_tick with the tick's delta. `last` says which it was and how large the delta."""
+
+    MAX_TICK_BYTES = 6 << 20  # evg_pool_tick's staging block holds 8 MB
+
+    def __init__(self, backend):
+        self.backend = backend
+        self.packed: Optional[PackedQueues] = None
+        self.ids: List[List[str]] = []
+        self.dep_ids: List[List[Tuple[str, ...]]] = []
+        self.sig: List[tuple] = []
+        self.last: Dict[str, object] = {}
+
+    # what must not change under a resident pool (the device's evg_distro_params rows are loaded once)
+    @staticmethod
+    def _signature(distro: Distro, inc: Optional[bool]) -> tuple:
+        ps = distro.PlannerSettings
+        return (distro.Id, ps.PatchFactor, ps.PatchTimeInQueueFactor, ps.CommitQueueFactor, ps.MainlineTimeInQueueFactor, ps.ExpectedRuntimeFactor,
+                ps.GenerateTaskFactor, ps.StepbackTaskFactor, ps.NumDependentsFactor, ps.TargetTime, ps.MergeQueueTargetTime, ps.ShouldGroupVersions(),
+                distro.DispatcherSettings.Version if inc is None else bool(inc))
+
+    def _load(self, queues, now_ns, dep_lookup, includes_dependencies, opts, why: str):
+        packed = pack_queues(queues, now_ns, dep_lookup, includes_dependencies)
+        self.backend.pool_load(packed.batch)
+        res = self.backend.pool_tick(packed.batch, now_ns)
+        self._remember(packed, queues, includes_dependencies)
+        self.last = {"mode": "load", "why": why, "tasks": packed.batch.n_tasks}
+        return _plans_from_result(packed, res, now_ns, opts)
+
+    def _remember(self, packed: PackedQueues, queues, includes_dependencies) -> None:
+        self.packed = packed
+        self.ids = [[t.Id for t in ts] for ts in packed.tasks]
+        self.dep_ids = [[tuple(x.TaskId for x in t.DependsOn) for t in ts] for ts in packed.tasks]
+        self.sig = [self._signature(d, None if includes_dependencies is None else includes_dependencies[i]) for i, (d, _) in enumerate(queues)]
+
+    def plan(self, queues: Sequence[Tuple[Distro, Sequence[Task]]], now_ns: int, opts: Optional[Sequence[TaskPlannerOptions]] = None,
+             dep_lookup: Optional[DepLookup] = None, includes_dependencies: Optional[Sequence[bool]] = None):
+        D = len(queues)
+        sig = [self._signature(d, None if includes_dependencies is None else includes_dependencies[i]) for i, (d, _) in enumerate(queues)]
+        if self.packed is None or sig != self.sig:
+            return self._load(queues, now_ns, dep_lookup, includes_dependencies, opts, "first tick" if self.packed is None else "the distros changed")
+        prev, pb = self.packed, self.packed.batch
+        # ---- who stays (same id, same place in its groups, same dependency list), who leaves, who arrives ----
+        resident_q, kept_old_rows, removed_rows, n_kept = [], [], [], []
+        for d, (distro, tasks) in enumerate(queues):
+            by_id = {t.Id: t for t in tasks}
+            if len(by_id) != len(tasks):
+                return self._load(queues, now_ns, dep_lookup, includes_dependencies, opts, "duplicate task ids in distro %s" % distro.Id)
+            lo = int(pb.task_off[d])
+            tgk, verk = prev.tg_key_of[d], prev.ver_key_of[d]
+            # a task that is still there but changed its place (group, version, dependency list) leaves its row and comes back as an added
+            # row; so does every task that depends on such a task through an in-queue edge, and so on: an edge of a KEPT row can be
+            # pointed at an added row only if it was an out-of-queue edge (evg_pool_delta: relinked_edges)
+            moved = set()
+            for i, tid in enumerate(self.ids[d]):
+                t = by_id.get(tid)
+                if t is None:
+                    continue
+                r = lo + i
+                if not (tuple(x.TaskId for x in t.DependsOn) == self.dep_ids[d][i]
+                        and int(pb.cols["task_group_order"][r]) == t.TaskGroupOrder and int(pb.cols["task_group_max_hosts"][r]) == t.TaskGroupMaxHosts
+                        and int(pb.cols["tg_key"][r]) == (tgk.get(t.GetTaskGroupString(), -2) if t.TaskGroup != "" else -1)
+                        and int(pb.cols["version_key"][r]) == verk.get(t.Version, -2)):
+                    moved.add(tid)
+            if moved:
+                dependents: Dict[str, List[str]] = {}
+                for i, tid in enumerate(self.ids[d]):
+                    for dep in self.dep_ids[d][i]:
+                        dependents.setdefault(dep, []).append(tid)
+                work = list(moved)
+                while work:
+                    for tid in dependents.get(work.pop(), ()):
+                        if tid in by_id and tid not in moved:
+                            moved.add(tid)
+                            work.append(tid)
+            kept, kept_ids = [], set()
+            for i, tid in enumerate(self.ids[d]):
+                t = by_id.get(tid)
+                if t is not None and tid not in moved:
+                    kept.append(t)
+                    kept_ids.add(tid)
+                    kept_old_rows.append(lo + i)
+                else:
+                    removed_rows.append(lo + i)
+            added = [t for t in tasks if t.Id not in kept_ids]
+            resident_q.append((distro, kept + added))
+            n_kept.append(len(kept))
+        seed = [(sorted(prev.tg_key_of[d], key=prev.tg_key_of[d].get), sorted(prev.ver_key_of[d], key=prev.ver_key_of[d].get)) for d in range(D)]
+        target = pack_queues(resident_q, now_ns, dep_lookup, includes_dependencies, seed_keys=seed)
+        tb = target.batch
+        NN, N = tb.n_tasks, pb.n_tasks
+        # target row -> the old row it was (-1: added) / its index among the added rows (-1: kept)
+        t2old = np.full(NN, -1, np.int64)
+        t2added = np.full(NN, -1, np.int64)
+        added_rows, added_distro, ko = [], [], 0
+        for d in range(D):
+            lo = int(tb.task_off[d])
+            for i in range(n_kept[d]):
+                t2old[lo + i] = kept_old_rows[ko]
+                ko += 1
+            for x in range(lo + n_kept[d], int(tb.task_off[d + 1])):
+                t2added[x] = len(added_rows)
+                added_rows.append(x)
+                added_distro.append(d)
+        removed_rows = np.asarray(removed_rows, np.int32)
+        removed_index = {int(r): k for k, r in enumerate(removed_rows)}
+        rm_state = np.full(len(removed_rows), abi.DEP_MISSING, np.uint8)   # what a dependent sees of a task that left: set from the first edge that says
+        rm_fin = np.zeros(len(removed_rows), np.int64)
+        rm_seen = np.zeros(len(removed_rows), bool)
+        # ---- the kept rows: value updates; their edges: what the delta makes of them against what they must be ----
+        upd_rows, e_idx, e_info, e_fin, rl_edges, rl_to = [], [], [], [], [], []
+        p_idx, p_info, p_fin = pb.edges["dep_idx"], pb.edges["dep_info"], pb.edges["dep_finished_ts_ns"]
+        t_idx, t_info, t_fin = tb.edges["dep_idx"], tb.edges["dep_info"], tb.edges["dep_finished_ts_ns"]
+        REQ = abi.DEP_REQ_MASK
+        pending = []  # (target edge, old edge, removed row index): compared once every removed row's state is known
+        for x in range(NN):
+            r = int(t2old[x])
+            if r < 0:
+                continue
+            if any(pb.cols[k][r] != tb.cols[k][x] for k in _UPDATABLE):
+                upd_rows.append(x)
+            eo, et = int(pb.dep_off[r]), int(tb.dep_off[x])
+            for i in range(int(pb.dep_off[r + 1]) - eo):
+                jo, jt = int(p_idx[eo + i]), int(t_idx[et + i])
+                if jo >= 0:
+                    if jt >= 0 and t2old[jt] == jo:        # the dependency stays where it is: the edge keeps its record
+                        after = (int(p_info[eo + i]), int(p_fin[eo + i]))
+                    elif jt < 0:                            # it left: the device writes the removed task's state into the edge
+                        k = removed_index[jo]
+                        if not rm_seen[k]:
+                            rm_seen[k] = True
+                            rm_state[k] = int(t_info[et + i]) & ~REQ
+                            rm_fin[k] = int(t_fin[et + i])
+                        pending.append((et + i, eo + i, k))
+                        continue
+                    else:                                   # it left its row and came back in the same tick: no delta says that
+                        return self._load(queues, now_ns, dep_lookup, includes_dependencies, opts, "a dependency was re-added in the tick it left")
+                else:
+                    if jt >= 0:                             # an out-of-queue dependency entered the queue: the edge is pointed at its added row
+                        if t2added[jt] < 0:
+                            return self._load(queues, now_ns, dep_lookup, includes_dependencies, opts, "an out-of-queue edge names a row that was there")
+                        rl_edges.append(eo + i)
+                        rl_to.append(int(t2added[jt]))
+                        after = (int(p_info[eo + i]) & REQ, 0)
+                    else:
+                        after = (int(p_info[eo + i]), int(p_fin[eo + i]))
+                if after != (int(t_info[et + i]), int(t_fin[et + i])):
+                    e_idx.append(et + i); e_info.append(int(t_info[et + i])); e_fin.append(int(t_fin[et + i]))
+        for et_i, eo_i, k in pending:
+            after = ((int(p_info[eo_i]) & REQ) | int(rm_state[k]), int(rm_fin[k]))
+            if after != (int(t_info[et_i]), int(t_fin[et_i])):
+                e_idx.append(et_i); e_info.append(int(t_info[et_i])); e_fin.append(int(t_fin[et_i]))
+        # ---- the added rows: their columns as packed; their edges in the delta's numbering ----
+        delta = None
+        na = len(added_rows)
+        keys_grew = not (np.array_equal(tb.tg_off, pb.tg_off) and np.array_equal(tb.ver_off, pb.ver_off))
+        if na or len(removed_rows) or rl_edges or keys_grew:
+            ar = np.asarray(added_rows, np.int64)
+            a_off, a_idx, a_info, a_fin = [0], [], [], []
+            for x in added_rows:
+                for e in range(int(tb.dep_off[x]), int(tb.dep_off[x + 1])):
+                    j = int(t_idx[e])
+                    a_idx.append(-1 if j < 0 else int(t2old[j]) if t2old[j] >= 0 else -(int(t2added[j]) + 2))
+                    a_info.append(int(t_info[e])); a_fin.append(int(t_fin[e]))
+                a_off.append(len(a_idx))
+            delta = dict(removed_rows=removed_rows, removed_dep_state=rm_state, removed_finished_ts_ns=rm_fin,
+                         added_distro=np.asarray(added_distro, np.int32), added_cols={k: tb.cols[k][ar] for k in abi.TASK_COLUMNS},
+                         added_dep_off=np.asarray(a_off, np.int32),
+                         added_edges={"dep_idx": np.asarray(a_idx, np.int32), "dep_info": np.asarray(a_info, np.uint8),
+                                      "dep_finished_ts_ns": np.asarray(a_fin, np.int64)},
+                         tg_off=tb.tg_off.copy(), ver_off=tb.ver_off.copy(),
+                         relinked_edges=np.asarray(rl_edges, np.int32), relinked_to=np.asarray(rl_to, np.int32))
+        rows = np.asarray(upd_rows, np.int32)
+        cols = {k: tb.cols[k][rows] for k in _UPDATABLE} if len(rows) else None
+        edges = np.asarray(e_idx, np.int32)
+        order = np.argsort(edges, kind="stable")
+        edges, einfo, efin = edges[order], np.asarray(e_info, np.uint8)[order], np.asarray(e_fin, np.int64)[order]
+        tick_bytes = (len(removed_rows) * 13 + na * 70 + (len(delta["added_edges"]["dep_idx"]) * 13 if delta else 0) + len(rl_edges) * 8 + len(rows) * 46
+                      + len(edges) * 13 + 28 * (D + 1))
+        if tick_bytes > self.MAX_TICK_BYTES:
+            return self._load(queues, now_ns, dep_lookup, includes_dependencies, opts, "a tick of %d bytes does not travel in one block" % tick_bytes)
+        res = self.backend.pool_tick(tb, now_ns, delta=delta, rows=rows if len(rows) else None, cols=cols,
+                                     edges=edges if len(edges) else None, dep_info=einfo if len(edges) else None,
+                                     dep_finished_ts_ns=efin if len(edges) else None)
+        self._remember(target, queues, includes_dependencies)
+        self.last = {"mode": "tick", "removed": int(len(removed_rows)), "added": na, "relinked": len(rl_edges), "rows_updated": int(len(rows)),
+                     "edges_updated": int(len(edges)), "tasks": NN}
+        return _plans_from_result(target, res, now_ns, opts)

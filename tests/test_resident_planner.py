@@ -1,0 +1,228 @@
+"""scheduler.ResidentPlanner: PlanDistros for a caller that comes back every tick (the reference's 15 s cadence,
+units/crons_remote_fifteen_second.go:21,58-60) -- the pool stays on the device and every later call is ONE evg_pool_tick with the tick's
+structural delta + value updates, worked out from the task lists themselves (what left, what arrived, which values and dependency states
+changed). Queues of random shape evolve for several ticks: tasks are dispatched / finish (their dependents see a finished dependency),
+new tasks arrive (in old and new versions and task groups, depending on tasks that are there, that arrive with them, that have finished or
+that nobody knows), values change, a task moves to another group, a dependency list changes.
+
+CPU: the resident entry points are played by the checker's restatement of the device re-pack (tests/pool_delta.py) + the oracle; the
+delta and the updates the planner hands over must reproduce -- array for array -- the batch it says the pool now is, and the plans must be
+those of PlanDistros on the same lists. GPU: the same ticks through evg_pool_load / evg_pool_tick."""
+import copy
+import dataclasses
+
+import numpy as np
+import pytest
+
+from evergreen_amd import abi, gen
+from evergreen_amd import scheduler as S
+from tests import pool_delta
+
+
+class CheckerResident:
+    """pool_load / pool_tick over tests/pool_delta.apply_delta + the oracle (test infrastructure: the product's are evg_pool_*)."""
+
+    def __init__(self, oracle):
+        self.oracle, self.b, self.ticks = oracle, None, 0
+
+    def pool_load(self, batch):
+        self.b = copy.deepcopy(batch)
+
+    def pool_tick(self, batch_after, now_ns, delta=None, rows=None, cols=None, edges=None, dep_info=None, dep_finished_ts_ns=None):
+        b = self.b
+        if delta is not None:
+            b = pool_delta.apply_delta(b, pool_delta.Delta(**{k: v for k, v in delta.items()}))
+        b = dataclasses.replace(b, cols={k: v.copy() for k, v in b.cols.items()}, edges={k: v.copy() for k, v in b.edges.items()}, now_ns=now_ns)
+        if rows is not None:
+            assert len(set(rows.tolist())) == len(rows)
+            for k, v in cols.items():
+                b.cols[k][rows] = v
+        if edges is not None:
+            assert len(set(edges.tolist())) == len(edges)
+            b.edges["dep_info"][edges] = dep_info
+            b.edges["dep_finished_ts_ns"][edges] = dep_finished_ts_ns
+        # the delta + the updates ARE the batch the planner says the pool now is
+        for k in abi.TASK_COLUMNS:
+            assert np.array_equal(b.cols[k], batch_after.cols[k]), "column %s after the tick" % k
+        assert np.array_equal(b.dep_off, batch_after.dep_off) and np.array_equal(b.task_off, batch_after.task_off)
+        for k in ("dep_idx", "dep_info", "dep_finished_ts_ns"):
+            assert np.array_equal(b.edges[k], batch_after.edges[k]), "edge column %s after the tick" % k
+        assert np.array_equal(b.tg_off, batch_after.tg_off) and np.array_equal(b.ver_off, batch_after.ver_off)
+        self.b = b
+        self.ticks += 1
+        bb = dataclasses.replace(batch_after, now_ns=now_ns)
+        return self.oracle.plan(bb, breakdown=True, n_units=False)
+
+
+class World:
+    """Queues of Task objects that live through ticks."""
+
+    def __init__(self, seed, n_distros, n_tasks):
+        self.rng = np.random.default_rng(seed)
+        self.now = 1_700_000_000 * S.SECOND
+        self.distros = []
+        for d in range(n_distros):
+            ps = S.PlannerSettings(TargetTime=int(self.rng.integers(0, 3)) * 30 * S.MINUTE, GroupVersions=bool(self.rng.random() < 0.4),
+                                   PatchFactor=int(self.rng.integers(0, 40)), PatchTimeInQueueFactor=int(self.rng.integers(0, 30)),
+                                   CommitQueueFactor=int(self.rng.integers(0, 50)), MainlineTimeInQueueFactor=int(self.rng.integers(0, 30)),
+                                   ExpectedRuntimeFactor=int(self.rng.integers(0, 20)), GenerateTaskFactor=int(self.rng.integers(0, 60)),
+                                   NumDependentsFactor=float(self.rng.integers(0, 8)) / 2, StepbackTaskFactor=int(self.rng.integers(0, 20)))
+            ds = S.DispatcherSettings(Version=S.DispatcherVersionRevisedWithDependencies if self.rng.random() < 0.5 else "revised")
+            self.distros.append(S.Distro(Id="distro%d" % d, PlannerSettings=ps, DispatcherSettings=ds))
+        self.tasks = [dict() for _ in range(n_distros)]  # id -> Task, insertion-ordered
+        self.done = {}                                   # id -> (status, blocked) of tasks that left
+        self.serial = 0
+        self.versions = [["v%d_%d" % (d, k) for k in range(4)] for d in range(n_distros)]
+        self.groups = [["tg%d_%d" % (d, k) for k in range(3)] for d in range(n_distros)]
+        for d in range(n_distros):
+            for _ in range(int(n_tasks * (0.5 + self.rng.random()))):
+                self.add(d, [])
+
+    def lookup(self, tid):
+        return self.done.get(tid)
+
+    def add(self, d, arriving):
+        rng = self.rng
+        self.serial += 1
+        tid = "t%d_%d" % (d, self.serial)
+        if rng.random() < 0.15:
+            self.versions[d].append("v%d_n%d" % (d, self.serial))
+        if rng.random() < 0.08:
+            self.groups[d].append("tg%d_n%d" % (d, self.serial))
+        grp = str(rng.choice(self.groups[d])) if rng.random() < 0.3 else ""
+        ver = str(rng.choice(self.versions[d]))
+        t = S.Task(Id=tid, DistroId=self.distros[d].Id if rng.random() < 0.9 else "elsewhere", Version=ver, TaskGroup=grp,
+                   BuildVariant="bv%d" % int(rng.integers(0, 2)), Project="p", TaskGroupOrder=int(rng.integers(0, 5)) if grp else 0,
+                   TaskGroupMaxHosts=int(rng.integers(1, 4)) if grp else 0,
+                   Requester=str(rng.choice([S.RepotrackerVersionRequester, S.PatchVersionRequester, S.GithubMergeRequester, S.GithubPRRequester])),
+                   Priority=int(rng.integers(0, 100)), NumDependents=int(rng.integers(0, 6)), GenerateTask=bool(rng.random() < 0.1),
+                   ActivatedBy=S.StepbackTaskActivator if rng.random() < 0.05 else "",
+                   ActivatedTime=self.now - int(rng.integers(0, 10 * 3600)) * S.SECOND if rng.random() < 0.9 else None,
+                   IngestTime=self.now - int(rng.integers(0, 20 * 3600)) * S.SECOND,
+                   ScheduledTime=self.now - int(rng.integers(0, 3600)) * S.SECOND if rng.random() < 0.8 else None,
+                   DependenciesMetTime=self.now - int(rng.integers(0, 3600)) * S.SECOND if rng.random() < 0.4 else None,
+                   ExpectedDuration=int(rng.integers(1, 200)) * S.MINUTE, Status=S.TaskUndispatched,
+                   CachedProjectStorageMethod=S.ProjectStorageMethodS3 if rng.random() < 0.1 else "")
+        pool = list(self.tasks[d]) + [x.Id for x in arriving]
+        for _ in range(int(rng.integers(0, 4))):
+            r = rng.random()
+            if r < 0.6 and pool:
+                dep = str(rng.choice(pool))
+            elif r < 0.8 and self.done:
+                dep = str(rng.choice(list(self.done)))
+            else:
+                dep = "nobody%d" % int(rng.integers(0, 50))
+            if any(x.TaskId == dep for x in t.DependsOn):
+                continue
+            t.DependsOn.append(S.Dependency(TaskId=dep, Status=str(rng.choice(["", S.TaskSucceeded, S.TaskFailed, S.AllStatuses, "odd"])),
+                                            Unattainable=bool(rng.random() < 0.05),
+                                            FinishedAt=self.now - 60 * S.SECOND if dep in self.done and rng.random() < 0.7 else None))
+        self.tasks[d][tid] = t
+        arriving.append(t)
+        return t
+
+    def tick(self, churn=0.06, structural=True):
+        rng = self.rng
+        self.now += 15 * S.SECOND
+        for d in range(len(self.tasks)):
+            ids = list(self.tasks[d])
+            for tid in ids:                                   # some tasks are dispatched / finish
+                if rng.random() < churn:
+                    del self.tasks[d][tid]
+                    self.done[tid] = (str(rng.choice([S.TaskSucceeded, S.TaskFailed, "started"])), bool(rng.random() < 0.1))
+            for t in self.tasks[d].values():                  # the DB stamps a finished dependency on its dependents -- on most of them
+                for dep in t.DependsOn:
+                    if dep.TaskId in self.done and dep.FinishedAt is None and rng.random() < 0.8:
+                        dep.FinishedAt = self.now - int(rng.integers(0, 15)) * S.SECOND
+                    if rng.random() < 0.01:
+                        dep.Unattainable = not dep.Unattainable
+                if rng.random() < 0.1:
+                    t.Priority = int(rng.integers(0, 100))
+                if rng.random() < 0.05:
+                    t.ScheduledTime = self.now - int(rng.integers(0, 600)) * S.SECOND
+                if rng.random() < 0.05:
+                    t.NumDependents += 1
+                if rng.random() < 0.03:
+                    t.DependenciesMetTime = self.now
+                if structural and rng.random() < 0.01:       # into another group / out of its group
+                    t.TaskGroup = str(rng.choice(self.groups[d])) if rng.random() < 0.7 else ""
+                    t.TaskGroupOrder, t.TaskGroupMaxHosts = (int(rng.integers(0, 5)), int(rng.integers(1, 4))) if t.TaskGroup else (0, 0)
+                if structural and rng.random() < 0.01 and t.DependsOn:
+                    t.DependsOn = t.DependsOn[:-1]
+            arriving = []
+            for _ in range(int(len(ids) * churn * (0.5 + rng.random())) + 1):
+                self.add(d, arriving)
+            if rng.random() < 0.3:                            # the finder returns its rows in whatever order (setup_funcs.go:55-64)
+                items = list(self.tasks[d].items())
+                rng.shuffle(items)
+                self.tasks[d] = dict(items)
+
+    def queues(self):
+        return [(self.distros[d], [copy.deepcopy(t) for t in self.tasks[d].values()]) for d in range(len(self.tasks))]
+
+
+def _same_plans(got, want, tag):
+    assert len(got) == len(want)
+    for d, ((gp, gi), (wp, wi)) in enumerate(zip(got, want)):
+        assert [t.Id for t in gp] == [t.Id for t in wp], "%s: queue order of distro %d" % (tag, d)
+        for a, b in zip(gp, wp):
+            assert a.SortingValueBreakdown == b.SortingValueBreakdown, "%s: breakdown of %s" % (tag, a.Id)
+            assert (a.ExpectedDuration, a.WaitSinceDependenciesMet, a.DependenciesMetTime) == (b.ExpectedDuration, b.WaitSinceDependenciesMet, b.DependenciesMetTime), \
+                "%s: stamps of %s" % (tag, a.Id)
+        gi2 = dataclasses.replace(gi, TaskGroupInfos=sorted(gi.TaskGroupInfos, key=lambda g: g.Name))
+        wi2 = dataclasses.replace(wi, TaskGroupInfos=sorted(wi.TaskGroupInfos, key=lambda g: g.Name))
+        assert gi2 == wi2, "%s: DistroQueueInfo of distro %d" % (tag, d)
+
+
+def _run(world, planner, fresh_backend, ticks, tag, structural=True):
+    modes = []
+    for k in range(ticks):
+        q = world.queues()
+        got = planner.plan(q, world.now, dep_lookup=world.lookup)
+        modes.append(planner.last["mode"])
+        # the same lists in the pool's row order (ties between equal keys fall to the lower row: planner.go's unstable sort leaves them open)
+        by_id = [{t.Id: t for t in ts} for _, ts in world.queues()]
+        resident = [(world.distros[d], [by_id[d][tid] for tid in planner.ids[d]]) for d in range(len(by_id))]
+        want = S.PlanDistros(fresh_backend, resident, world.now, dep_lookup=world.lookup)
+        _same_plans(got, want, "%s tick %d (%s)" % (tag, k, planner.last))
+        world.tick(structural=structural)
+    return modes
+
+
+@pytest.mark.parametrize("seed,D,n", [(1, 3, 40), (2, 6, 120), (3, 1, 300), (4, 10, 15)])
+def test_ticks_by_delta_are_plan_distros(oracle, seed, D, n):
+    world = World(seed, D, n)
+    be = CheckerResident(oracle)
+    planner = S.ResidentPlanner(be)
+    modes = _run(world, planner, oracle, 8, "seed %d" % seed)
+    assert modes[0] == "load" and modes.count("tick") >= 4, modes   # (a dependency that leaves its row and comes back in one tick reloads)
+
+
+def test_quiet_ticks_and_reload_conditions(oracle):
+    world = World(7, 3, 50)
+    be = CheckerResident(oracle)
+    planner = S.ResidentPlanner(be)
+    q = world.queues()
+    planner.plan(q, world.now, dep_lookup=world.lookup)
+    assert planner.last["mode"] == "load"
+    world.now += 15 * S.SECOND                      # nothing changed but the clock: a tick without a delta
+    got = planner.plan(world.queues(), world.now, dep_lookup=world.lookup)
+    assert planner.last["mode"] == "tick" and planner.last["removed"] == 0 and planner.last["added"] == 0 and planner.last["relinked"] == 0
+    want = S.PlanDistros(oracle, world.queues(), world.now, dep_lookup=world.lookup)
+    _same_plans(got, want, "clock only")
+    world.distros[1].PlannerSettings.PatchFactor += 1   # the device's settings rows are loaded once: a changed distro reloads
+    planner.plan(world.queues(), world.now, dep_lookup=world.lookup)
+    assert planner.last["mode"] == "load" and "distros changed" in planner.last["why"]
+    q = world.queues()
+    q[0][1].append(copy.deepcopy(q[0][1][0]))       # the same id twice: no delta is attempted
+    planner.plan(q, world.now, dep_lookup=world.lookup)
+    assert planner.last["mode"] == "load" and "duplicate" in planner.last["why"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,D,n", [(11, 4, 200), (12, 12, 60), (13, 2, 1500)])
+def test_ticks_by_delta_on_the_device(native_ctx, oracle, seed, D, n):
+    world = World(seed, D, n)
+    planner = S.ResidentPlanner(S.ResidentContext(native_ctx))
+    modes = _run(world, planner, oracle, 6, "gpu seed %d" % seed)
+    assert modes[0] == "load" and modes.count("tick") >= 3, modes
