@@ -32,6 +32,7 @@
 #include <string>
 #include <tuple>
 #include <unordered_map>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -253,6 +254,7 @@ struct PackedQueues {
   std::vector<evg_distro_params> distros;
   std::vector<std::string> tg_names;                              // tg key -> group string
   std::vector<std::unordered_map<std::string, int32_t>> tg_key_of;  // per distro
+  std::vector<std::unordered_map<std::string, int32_t>> ver_key_of;  // per distro: version id -> key
   Time now = 0;
 
   evg_plan_input input() const {
@@ -278,8 +280,12 @@ struct PackedQueues {
 
 // Interns strings and lays the D (distro, tasks) queues out as the ABI's struct-of-arrays: what PopulateCaches
 // (setup_funcs.go:18-67) leaves behind -- resolved durations -- plus the string -> key interning of SURVEY.md 8b'.
+// seed_keys[d] = (task-group strings, version ids) that already HAVE keys in distro d, in key order: they keep them whether or not a task
+// still names them, new strings follow (a resident pool's key ranges only grow, at a distro's end: evg_pool_delta).
+using SeedKeys = std::vector<std::pair<std::vector<std::string>, std::vector<std::string>>>;
 inline PackedQueues pack_queues(const std::vector<std::pair<const Distro*, const std::vector<Task>*>>& queues, Time now,
-                                const DepLookup& lookup = nullptr, const std::vector<bool>* includes_dependencies = nullptr) {
+                                const DepLookup& lookup = nullptr, const std::vector<bool>* includes_dependencies = nullptr,
+                                const SeedKeys* seed_keys = nullptr) {
   PackedQueues p;
   p.now = now;
   p.dep_off.push_back(0);
@@ -300,6 +306,10 @@ inline PackedQueues pack_queues(const std::vector<std::pair<const Distro*, const
                                                      : (d.DispatcherSettings.Version == DispatcherVersionRevisedWithDependencies ? 1 : 0);  // scheduler.go:29
     p.distros.push_back(dp);
     std::unordered_map<std::string, int32_t> row_of, tgk, verk;
+    if (seed_keys) {
+      for (const std::string& s : (*seed_keys)[di].first) { tgk.emplace(s, n_tg + (int32_t)tgk.size()); p.tg_names.push_back(s); }
+      for (const std::string& v : (*seed_keys)[di].second) verk.emplace(v, n_ver + (int32_t)verk.size());
+    }
     for (size_t i = 0; i < tasks.size(); i++) row_of[tasks[i].Id] = row + (int32_t)i;  // later duplicates win, like a Go map
     for (const Task& t : tasks) {
       p.priority.push_back(t.Priority);
@@ -349,6 +359,7 @@ inline PackedQueues pack_queues(const std::vector<std::pair<const Distro*, const
       p.dep_off.push_back((int32_t)p.dep_idx.size());
     }
     p.tg_key_of.push_back(tgk);
+    p.ver_key_of.push_back(verk);
     row += (int32_t)tasks.size();
     n_tg += (int32_t)tgk.size();
     n_ver += (int32_t)verk.size();
@@ -366,24 +377,35 @@ struct PlannedQueue {
   DistroQueueInfo info;
   int n_units = 0;
 };
-inline std::vector<PlannedQueue> PlanDistros(const Backend& be, const std::vector<std::pair<const Distro*, const std::vector<Task>*>>& queues,
-                                             Time now, const std::vector<TaskPlannerOptions>* opts = nullptr, const DepLookup& lookup = nullptr,
-                                             const std::vector<bool>* includes_dependencies = nullptr) {
-  const PackedQueues p = pack_queues(queues, now, lookup, includes_dependencies);
-  const size_t n = p.priority.size(), D = queues.size(), G = D + (size_t)p.tg_off.back();
-  // SortingValueBreakdown: one row per UNIT + the emitting unit of every task (evg_plan_output.unit_of_task); the stamp on
-  // each task (planner.go:475) is a copy of its unit's row
-  const size_t n_slots = n + (size_t)p.tg_off.back() + (size_t)p.ver_off.back();
-  std::vector<int32_t> order(n + 1), n_units(D + 1), unit_of_task(n + 1);
-  std::vector<int64_t> unit_breakdown((n_slots + 1) * EVG_BREAKDOWN_FIELDS), wait(n + 1);
-  std::vector<uint8_t> met(n + 1);
-  std::vector<evg_distro_info> di(D + 1);
-  std::vector<evg_group_info> gi(G + 1);
-  const evg_plan_input in = p.input();
-  evg_plan_output out{order.data(), nullptr, met.data(), wait.data(), di.data(), gi.data(), n_units.data(), unit_of_task.data(),
-                      unit_breakdown.data()};
-  const int rc = be.plan(&in, &out);
-  if (rc != EVG_OK) throw PlanError("evg_plan_distros failed (" + std::to_string(rc) + "): " + (be.last_error ? be.last_error() : ""));
+namespace detail {
+// The output arrays of one plan over the batch `p`, and the evg_plan_output that points into them.
+struct PlanBuffers {
+  size_t n, D, G, n_slots;
+  std::vector<int32_t> order, n_units, unit_of_task;
+  std::vector<int64_t> unit_breakdown, wait;
+  std::vector<uint8_t> met;
+  std::vector<evg_distro_info> di;
+  std::vector<evg_group_info> gi;
+  explicit PlanBuffers(const PackedQueues& p)
+      : n(p.priority.size()), D(p.distros.size()), G(D + (size_t)p.tg_off.back()),
+        // SortingValueBreakdown: one row per UNIT + the emitting unit of every task (evg_plan_output.unit_of_task); the stamp on
+        // each task (planner.go:475) is a copy of its unit's row
+        n_slots(n + (size_t)p.tg_off.back() + (size_t)p.ver_off.back()),
+        order(n + 1), n_units(D + 1), unit_of_task(n + 1), unit_breakdown((n_slots + 1) * EVG_BREAKDOWN_FIELDS), wait(n + 1), met(n + 1), di(D + 1),
+        gi(G + 1) {}
+  evg_plan_output out() {
+    return evg_plan_output{order.data(), nullptr, met.data(), wait.data(), di.data(), gi.data(), n_units.data(), unit_of_task.data(), unit_breakdown.data()};
+  }
+};
+// (plan, DistroQueueInfo) per distro from the rows a backend returned: the task values of `queues` re-ordered and stamped.
+inline std::vector<PlannedQueue> planned_from(const PackedQueues& p, const std::vector<std::pair<const Distro*, const std::vector<Task>*>>& queues,
+                                              const PlanBuffers& b, Time now, const std::vector<TaskPlannerOptions>* opts) {
+  const size_t D = b.D, n_slots = b.n_slots;
+  const std::vector<int32_t>&order = b.order, &n_units = b.n_units, &unit_of_task = b.unit_of_task;
+  const std::vector<int64_t>&unit_breakdown = b.unit_breakdown, &wait = b.wait;
+  const std::vector<uint8_t>& met = b.met;
+  const std::vector<evg_distro_info>& di = b.di;
+  const std::vector<evg_group_info>& gi = b.gi;
   std::vector<PlannedQueue> res(D);
   for (size_t d = 0; d < D; d++) {
     const int lo = p.task_off[d], hi = p.task_off[d + 1];
@@ -437,6 +459,19 @@ inline std::vector<PlannedQueue> PlanDistros(const Backend& be, const std::vecto
     }
   }
   return res;
+}
+}  // namespace detail
+
+inline std::vector<PlannedQueue> PlanDistros(const Backend& be, const std::vector<std::pair<const Distro*, const std::vector<Task>*>>& queues,
+                                             Time now, const std::vector<TaskPlannerOptions>* opts = nullptr, const DepLookup& lookup = nullptr,
+                                             const std::vector<bool>* includes_dependencies = nullptr) {
+  const PackedQueues p = pack_queues(queues, now, lookup, includes_dependencies);
+  detail::PlanBuffers b(p);
+  const evg_plan_input in = p.input();
+  evg_plan_output out = b.out();
+  const int rc = be.plan(&in, &out);
+  if (rc != EVG_OK) throw PlanError("evg_plan_distros failed (" + std::to_string(rc) + "): " + (be.last_error ? be.last_error() : ""));
+  return detail::planned_from(p, queues, b, now, opts);
 }
 
 // scheduler.PrioritizeTasks (scheduler.go:28-33) for one distro: a batch of one.
@@ -738,5 +773,321 @@ inline std::pair<int, int> UtilizationBasedHostAllocator(const Backend& be, Host
 }
 using HostAllocator = std::function<std::pair<int, int>(const Backend&, HostAllocatorData&, Time, const RunningTaskLookup&)>;
 inline HostAllocator GetHostAllocator(const std::string& /*name*/) { return UtilizationBasedHostAllocator; }  // host_allocator.go:23-30
+
+// ---- the resident pool driven from the reference's own data model (evg_pool_load / evg_pool_tick; late round 6) ---------------------
+// The reference re-plans every distro every 15 s (units/crons_remote_fifteen_second.go:21,58-60) from the task lists the finder returns;
+// between two ticks a few per cent of a queue change. ResidentPlanner takes those lists tick after tick -- PlanDistros' arguments --
+// and keeps the pool on the device: it works out what left, what arrived, which values and which dependency states changed, hands
+// evg_pool_tick a structural delta + value updates, and keeps the id -> row map the way the device re-packs (kept rows of a distro in
+// their order, then its added rows). Results are those of PlanDistros on the same lists. (evergreen_amd/scheduler.py holds the same
+// class; tests/test_resident_planner.py holds both to the checker's re-pack and to each other.)
+struct ResidentBackend {
+  std::function<int(const evg_plan_input*)> pool_load;
+  std::function<int(const evg_pool_delta*, const evg_row_update*, const evg_edge_update*, int64_t, const evg_plan_output*)> pool_tick;
+  std::function<std::string()> last_error;
+  std::shared_ptr<void> keep;
+};
+inline ResidentBackend HipResidentBackend(const std::string& lib_path, int device = 0) {
+  void* h = dlopen(lib_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!h) throw std::runtime_error(std::string("cannot load the HIP library: ") + dlerror());
+  auto create = reinterpret_cast<evg_ctx* (*)(int)>(dlsym(h, "evg_create"));
+  auto destroy = reinterpret_cast<void (*)(evg_ctx*)>(dlsym(h, "evg_destroy"));
+  auto lasterr = reinterpret_cast<const char* (*)(const evg_ctx*)>(dlsym(h, "evg_last_error"));
+  auto load = reinterpret_cast<int (*)(evg_ctx*, const evg_plan_input*)>(dlsym(h, "evg_pool_load"));
+  auto tick = reinterpret_cast<int (*)(evg_ctx*, const evg_pool_delta*, const evg_row_update*, const evg_edge_update*, int64_t, const evg_plan_output*)>(
+      dlsym(h, "evg_pool_tick"));
+  if (!create || !destroy || !lasterr || !load || !tick) throw std::runtime_error("libevg_sched.so lacks evg_pool_load / evg_pool_tick");
+  evg_ctx* ctx = create(device);
+  if (!ctx) throw std::runtime_error(std::string("evg_create failed: ") + lasterr(nullptr));
+  ResidentBackend b;
+  b.keep = std::shared_ptr<void>(ctx, [destroy](void* p) { destroy(static_cast<evg_ctx*>(p)); });
+  b.pool_load = [ctx, load](const evg_plan_input* in) { return load(ctx, in); };
+  b.pool_tick = [ctx, tick](const evg_pool_delta* dl, const evg_row_update* ru, const evg_edge_update* eu, int64_t now, const evg_plan_output* out) {
+    return tick(ctx, dl, ru, eu, now, out);
+  };
+  b.last_error = [ctx, lasterr]() { return std::string(lasterr(ctx)); };
+  return b;
+}
+
+class ResidentPlanner {
+ public:
+  using Queues = std::vector<std::pair<const Distro*, const std::vector<Task>*>>;
+  struct Last {  // what the last call was
+    std::string mode, why;  // "load" (and why) or "tick"
+    int removed = 0, added = 0, relinked = 0, rows_updated = 0, edges_updated = 0;
+  } last;
+  static constexpr size_t kMaxTickBytes = 6u << 20;  // evg_pool_tick's staging block holds 8 MB
+
+  explicit ResidentPlanner(ResidentBackend be) : be_(std::move(be)) {}
+  const std::vector<std::vector<std::string>>& ids() const { return ids_; }  // per distro, in the pool's row order
+
+  // PlanDistros' arguments, PlanDistros' result. The first call -- and any call after the set of distros, a distro's planner settings
+  // or a task list with duplicate ids changed the ground under the pool -- uploads everything (evg_pool_load); every other call is ONE
+  // evg_pool_tick with the tick's delta.
+  std::vector<PlannedQueue> Plan(const Queues& queues, Time now, const std::vector<TaskPlannerOptions>* opts = nullptr, const DepLookup& lookup = nullptr,
+                                 const std::vector<bool>* includes_dependencies = nullptr) {
+    const size_t D = queues.size();
+    std::vector<std::string> sig;
+    for (size_t d = 0; d < D; d++) sig.push_back(signature(*queues[d].first, includes_dependencies ? (int)(*includes_dependencies)[d] : -1));
+    if (!loaded_ || sig != sig_) return load(queues, now, opts, lookup, includes_dependencies, loaded_ ? "the distros changed" : "first tick");
+    const PackedQueues& pb = packed_;
+    // ---- who stays (same id, same place in its groups, same dependency list), who leaves, who arrives ----
+    std::vector<std::vector<Task>> resident(D);
+    std::vector<int32_t> kept_old_rows, removed_rows;
+    std::vector<size_t> n_kept(D);
+    for (size_t d = 0; d < D; d++) {
+      const std::vector<Task>& tasks = *queues[d].second;
+      std::unordered_map<std::string, const Task*> by_id;
+      for (const Task& t : tasks) by_id[t.Id] = &t;
+      if (by_id.size() != tasks.size()) return load(queues, now, opts, lookup, includes_dependencies, "duplicate task ids in distro " + queues[d].first->Id);
+      const int lo = pb.task_off[d];
+      const auto &tgk = pb.tg_key_of[d], &verk = pb.ver_key_of[d];
+      // a task that is still there but changed its place (group, version, dependency list) leaves its row and comes back as an added
+      // row; so does every task that depends on such a task through an in-queue edge, and so on: an edge of a KEPT row can be pointed at
+      // an added row only if it was an out-of-queue edge (evg_pool_delta: relinked_edges)
+      std::unordered_set<std::string> moved;
+      for (size_t i = 0; i < ids_[d].size(); i++) {
+        auto it = by_id.find(ids_[d][i]);
+        if (it == by_id.end()) continue;
+        const Task& t = *it->second;
+        const size_t r = (size_t)lo + i;
+        bool same = t.DependsOn.size() == dep_ids_[d][i].size();
+        for (size_t k = 0; same && k < t.DependsOn.size(); k++) same = t.DependsOn[k].TaskId == dep_ids_[d][i][k];
+        int32_t want_tg = -1;
+        if (!t.TaskGroup.empty()) { auto f = tgk.find(t.GetTaskGroupString()); want_tg = f == tgk.end() ? -2 : f->second; }
+        auto fv = verk.find(t.Version);
+        same = same && pb.tg_order[r] == t.TaskGroupOrder && pb.tg_max_hosts[r] == t.TaskGroupMaxHosts && pb.tg_key[r] == want_tg &&
+               pb.version_key[r] == (fv == verk.end() ? -2 : fv->second);
+        if (!same) moved.insert(t.Id);
+      }
+      if (!moved.empty()) {
+        std::unordered_map<std::string, std::vector<const std::string*>> dependents;
+        for (size_t i = 0; i < ids_[d].size(); i++)
+          for (const std::string& dep : dep_ids_[d][i]) dependents[dep].push_back(&ids_[d][i]);
+        std::vector<std::string> work(moved.begin(), moved.end());
+        while (!work.empty()) {
+          const std::string cur = work.back();
+          work.pop_back();
+          auto f = dependents.find(cur);
+          if (f == dependents.end()) continue;
+          for (const std::string* tid : f->second)
+            if (by_id.count(*tid) && !moved.count(*tid)) { moved.insert(*tid); work.push_back(*tid); }
+        }
+      }
+      std::unordered_set<std::string> kept_ids;
+      for (size_t i = 0; i < ids_[d].size(); i++) {
+        auto it = by_id.find(ids_[d][i]);
+        if (it != by_id.end() && !moved.count(ids_[d][i])) {
+          resident[d].push_back(*it->second);
+          kept_ids.insert(ids_[d][i]);
+          kept_old_rows.push_back(lo + (int32_t)i);
+        } else {
+          removed_rows.push_back(lo + (int32_t)i);
+        }
+      }
+      n_kept[d] = resident[d].size();
+      for (const Task& t : tasks)
+        if (!kept_ids.count(t.Id)) resident[d].push_back(t);
+    }
+    SeedKeys seed(D);
+    for (size_t d = 0; d < D; d++) {
+      seed[d].first.resize(pb.tg_key_of[d].size());
+      for (const auto& kv : pb.tg_key_of[d]) seed[d].first[(size_t)(kv.second - pb.tg_off[d])] = kv.first;
+      seed[d].second.resize(pb.ver_key_of[d].size());
+      for (const auto& kv : pb.ver_key_of[d]) seed[d].second[(size_t)(kv.second - pb.ver_off[d])] = kv.first;
+    }
+    Queues rq;
+    for (size_t d = 0; d < D; d++) rq.push_back({queues[d].first, &resident[d]});
+    PackedQueues tb = pack_queues(rq, now, lookup, includes_dependencies, &seed);
+    const size_t NN = tb.priority.size();
+    // target row -> the old row it was (-1: added) / its index among the added rows (-1: kept)
+    std::vector<int64_t> t2old(NN, -1), t2added(NN, -1);
+    std::vector<int32_t> added_rows, added_distro;
+    {
+      size_t ko = 0;
+      for (size_t d = 0; d < D; d++) {
+        const int lo = tb.task_off[d];
+        for (size_t i = 0; i < n_kept[d]; i++) t2old[(size_t)lo + i] = kept_old_rows[ko++];
+        for (int x = lo + (int)n_kept[d]; x < tb.task_off[d + 1]; x++) {
+          t2added[(size_t)x] = (int64_t)added_rows.size();
+          added_rows.push_back(x);
+          added_distro.push_back((int32_t)d);
+        }
+      }
+    }
+    std::unordered_map<int32_t, size_t> removed_index;
+    for (size_t k = 0; k < removed_rows.size(); k++) removed_index[removed_rows[k]] = k;
+    std::vector<uint8_t> rm_state(removed_rows.size(), (uint8_t)EVG_DEP_MISSING);  // what a dependent sees of a task that left: from the first edge that says
+    std::vector<int64_t> rm_fin(removed_rows.size(), 0);
+    std::vector<char> rm_seen(removed_rows.size(), 0);
+    // ---- the kept rows: value updates; their edges: what the delta makes of them against what they must be ----
+    std::vector<int32_t> upd_rows, rl_edges, rl_to;
+    struct EdgeFix { int32_t e; uint8_t info; int64_t fin; };
+    std::vector<EdgeFix> fixes;
+    struct Pending { size_t et, eo, k; };
+    std::vector<Pending> pending;
+    const uint8_t REQ = (uint8_t)EVG_DEP_REQ_MASK;
+    for (size_t x = 0; x < NN; x++) {
+      const int64_t r = t2old[x];
+      if (r < 0) continue;
+      const size_t ro = (size_t)r;
+      if (pb.priority[ro] != tb.priority[x] || pb.expected_duration[ro] != tb.expected_duration[x] || pb.queue_ts[ro] != tb.queue_ts[x] ||
+          pb.scheduled_ts[ro] != tb.scheduled_ts[x] || pb.deps_met_ts[ro] != tb.deps_met_ts[x] || pb.num_dependents[ro] != tb.num_dependents[x] ||
+          pb.flags[ro] != tb.flags[x])
+        upd_rows.push_back((int32_t)x);
+      const size_t eo = (size_t)pb.dep_off[ro], et = (size_t)tb.dep_off[x], ne = (size_t)pb.dep_off[ro + 1] - eo;
+      for (size_t i = 0; i < ne; i++) {
+        const int32_t jo = pb.dep_idx[eo + i], jt = tb.dep_idx[et + i];
+        uint8_t a_info;
+        int64_t a_fin;
+        if (jo >= 0) {
+          if (jt >= 0 && t2old[(size_t)jt] == jo) {  // the dependency stays where it is: the edge keeps its record
+            a_info = pb.dep_info[eo + i]; a_fin = pb.dep_finished[eo + i];
+          } else if (jt < 0) {                        // it left: the device writes the removed task's state into the edge
+            const size_t k = removed_index.at(jo);
+            if (!rm_seen[k]) { rm_seen[k] = 1; rm_state[k] = (uint8_t)(tb.dep_info[et + i] & ~REQ); rm_fin[k] = tb.dep_finished[et + i]; }
+            pending.push_back({et + i, eo + i, k});
+            continue;
+          } else {                                    // it left its row and came back in the same tick: no delta says that
+            return load(queues, now, opts, lookup, includes_dependencies, "a dependency was re-added in the tick it left");
+          }
+        } else if (jt >= 0) {                         // an out-of-queue dependency entered the queue: the edge is pointed at its added row
+          if (t2added[(size_t)jt] < 0) return load(queues, now, opts, lookup, includes_dependencies, "an out-of-queue edge names a row that was there");
+          rl_edges.push_back((int32_t)(eo + i));
+          rl_to.push_back((int32_t)t2added[(size_t)jt]);
+          a_info = (uint8_t)(pb.dep_info[eo + i] & REQ); a_fin = 0;
+        } else {
+          a_info = pb.dep_info[eo + i]; a_fin = pb.dep_finished[eo + i];
+        }
+        if (a_info != tb.dep_info[et + i] || a_fin != tb.dep_finished[et + i]) fixes.push_back({(int32_t)(et + i), tb.dep_info[et + i], tb.dep_finished[et + i]});
+      }
+    }
+    for (const Pending& q : pending) {
+      const uint8_t a_info = (uint8_t)((pb.dep_info[q.eo] & REQ) | rm_state[q.k]);
+      if (a_info != tb.dep_info[q.et] || rm_fin[q.k] != tb.dep_finished[q.et]) fixes.push_back({(int32_t)q.et, tb.dep_info[q.et], tb.dep_finished[q.et]});
+    }
+    std::stable_sort(fixes.begin(), fixes.end(), [](const EdgeFix& a, const EdgeFix& b) { return a.e < b.e; });
+    // ---- the added rows: their columns as packed; their edges in the delta's numbering ----
+    const size_t na = added_rows.size();
+    const bool keys_grew = tb.tg_off != pb.tg_off || tb.ver_off != pb.ver_off;
+    const bool have_delta = na || !removed_rows.empty() || !rl_edges.empty() || keys_grew;
+    struct AddedCols {
+      std::vector<int64_t> priority, expected_duration, queue_ts, scheduled_ts, deps_met_ts, dep_finished;
+      std::vector<int32_t> num_dependents, tg_order, tg_max_hosts, tg_key, version_key, dep_off, dep_idx;
+      std::vector<uint16_t> flags;
+      std::vector<uint8_t> dep_info;
+    } a;
+    a.dep_off.push_back(0);
+    for (const int32_t xr : added_rows) {
+      const size_t x = (size_t)xr;
+      a.priority.push_back(tb.priority[x]); a.expected_duration.push_back(tb.expected_duration[x]); a.queue_ts.push_back(tb.queue_ts[x]);
+      a.scheduled_ts.push_back(tb.scheduled_ts[x]); a.deps_met_ts.push_back(tb.deps_met_ts[x]); a.num_dependents.push_back(tb.num_dependents[x]);
+      a.tg_order.push_back(tb.tg_order[x]); a.tg_max_hosts.push_back(tb.tg_max_hosts[x]); a.tg_key.push_back(tb.tg_key[x]);
+      a.version_key.push_back(tb.version_key[x]); a.flags.push_back(tb.flags[x]);
+      for (int32_t e = tb.dep_off[x]; e < tb.dep_off[x + 1]; e++) {
+        const int32_t j = tb.dep_idx[(size_t)e];
+        a.dep_idx.push_back(j < 0 ? -1 : t2old[(size_t)j] >= 0 ? (int32_t)t2old[(size_t)j] : -(int32_t)(t2added[(size_t)j] + 2));
+        a.dep_info.push_back(tb.dep_info[(size_t)e]);
+        a.dep_finished.push_back(tb.dep_finished[(size_t)e]);
+      }
+      a.dep_off.push_back((int32_t)a.dep_idx.size());
+    }
+    const size_t tick_bytes = removed_rows.size() * 13 + na * 70 + a.dep_idx.size() * 13 + rl_edges.size() * 8 + upd_rows.size() * 46 + fixes.size() * 13 + 28 * (D + 1);
+    if (tick_bytes > kMaxTickBytes) return load(queues, now, opts, lookup, includes_dependencies, "a tick of " + std::to_string(tick_bytes) + " bytes does not travel in one block");
+    evg_pool_delta dl{};
+    if (have_delta) {
+      dl.n_removed = (int32_t)removed_rows.size(); dl.n_added = (int32_t)na;
+      dl.removed_rows = removed_rows.data(); dl.removed_dep_state = rm_state.data(); dl.removed_finished_ts_ns = rm_fin.data();
+      dl.added_distro = added_distro.data();
+      evg_task_soa& t = dl.added;
+      t.n_tasks = (int32_t)na; t.n_edges = (int32_t)a.dep_idx.size();
+      t.priority = a.priority.data(); t.expected_duration_ns = a.expected_duration.data(); t.queue_ts_ns = a.queue_ts.data();
+      t.scheduled_ts_ns = a.scheduled_ts.data(); t.deps_met_ts_ns = a.deps_met_ts.data(); t.num_dependents = a.num_dependents.data();
+      t.task_group_order = a.tg_order.data(); t.task_group_max_hosts = a.tg_max_hosts.data(); t.tg_key = a.tg_key.data();
+      t.version_key = a.version_key.data(); t.flags = a.flags.data(); t.dep_off = a.dep_off.data(); t.dep_idx = a.dep_idx.data();
+      t.dep_info = a.dep_info.data(); t.dep_finished_ts_ns = a.dep_finished.data();
+      dl.tg_off = tb.tg_off.data(); dl.ver_off = tb.ver_off.data();
+      dl.n_relinked = (int32_t)rl_edges.size(); dl.relinked_edges = rl_edges.data(); dl.relinked_to = rl_to.data();
+    }
+    std::vector<int64_t> u_pri, u_dur, u_q, u_s, u_m, e_fin;
+    std::vector<int32_t> u_nd, e_idx;
+    std::vector<uint16_t> u_fl;
+    std::vector<uint8_t> e_info;
+    for (const int32_t xr : upd_rows) {
+      const size_t x = (size_t)xr;
+      u_pri.push_back(tb.priority[x]); u_dur.push_back(tb.expected_duration[x]); u_q.push_back(tb.queue_ts[x]); u_s.push_back(tb.scheduled_ts[x]);
+      u_m.push_back(tb.deps_met_ts[x]); u_nd.push_back(tb.num_dependents[x]); u_fl.push_back(tb.flags[x]);
+    }
+    for (const EdgeFix& f : fixes) { e_idx.push_back(f.e); e_info.push_back(f.info); e_fin.push_back(f.fin); }
+    evg_row_update ru{};
+    ru.n_rows = (int32_t)upd_rows.size(); ru.rows = upd_rows.data(); ru.priority = u_pri.data(); ru.expected_duration_ns = u_dur.data();
+    ru.queue_ts_ns = u_q.data(); ru.scheduled_ts_ns = u_s.data(); ru.deps_met_ts_ns = u_m.data(); ru.num_dependents = u_nd.data(); ru.flags = u_fl.data();
+    evg_edge_update eu{};
+    eu.n_edges = (int32_t)e_idx.size(); eu.edges = e_idx.data(); eu.dep_info = e_info.data(); eu.dep_finished_ts_ns = e_fin.data();
+    detail::PlanBuffers b(tb);
+    evg_plan_output out = b.out();
+    const int rc = be_.pool_tick(have_delta ? &dl : nullptr, upd_rows.empty() ? nullptr : &ru, e_idx.empty() ? nullptr : &eu, now, &out);
+    if (rc != EVG_OK) throw PlanError("evg_pool_tick failed (" + std::to_string(rc) + "): " + (be_.last_error ? be_.last_error() : ""));
+    last = Last{};
+    last.mode = "tick";
+    last.removed = (int)removed_rows.size(); last.added = (int)na; last.relinked = (int)rl_edges.size(); last.rows_updated = (int)upd_rows.size();
+    last.edges_updated = (int)e_idx.size();
+    std::vector<PlannedQueue> res = detail::planned_from(tb, rq, b, now, opts);
+    remember(std::move(tb), rq, sig);
+    return res;
+  }
+
+ private:
+  // what must not change under a resident pool (the device's evg_distro_params rows are loaded once)
+  static std::string signature(const Distro& d, int inc) {
+    const auto& ps = d.PlannerSettings;
+    std::string s = d.Id;
+    for (int64_t v : {(int64_t)ps.PatchFactor, (int64_t)ps.PatchTimeInQueueFactor, (int64_t)ps.CommitQueueFactor, (int64_t)ps.MainlineTimeInQueueFactor,
+                      (int64_t)ps.ExpectedRuntimeFactor, (int64_t)ps.GenerateTaskFactor, (int64_t)ps.StepbackTaskFactor, (int64_t)ps.TargetTime,
+                      (int64_t)ps.MergeQueueTargetTime, (int64_t)ps.ShouldGroupVersions()})
+      s += "|" + std::to_string(v);
+    s += "|" + std::to_string(ps.NumDependentsFactor) + "|" + (inc < 0 ? d.DispatcherSettings.Version : std::to_string(inc));
+    return s;
+  }
+  std::vector<PlannedQueue> load(const Queues& queues, Time now, const std::vector<TaskPlannerOptions>* opts, const DepLookup& lookup,
+                                 const std::vector<bool>* includes_dependencies, const std::string& why) {
+    PackedQueues p = pack_queues(queues, now, lookup, includes_dependencies);
+    const evg_plan_input in = p.input();
+    int rc = be_.pool_load(&in);
+    if (rc != EVG_OK) throw PlanError("evg_pool_load failed (" + std::to_string(rc) + "): " + (be_.last_error ? be_.last_error() : ""));
+    detail::PlanBuffers b(p);
+    evg_plan_output out = b.out();
+    rc = be_.pool_tick(nullptr, nullptr, nullptr, now, &out);
+    if (rc != EVG_OK) throw PlanError("evg_pool_tick failed (" + std::to_string(rc) + "): " + (be_.last_error ? be_.last_error() : ""));
+    std::vector<PlannedQueue> res = detail::planned_from(p, queues, b, now, opts);
+    std::vector<std::string> sig;
+    for (size_t d = 0; d < queues.size(); d++) sig.push_back(signature(*queues[d].first, includes_dependencies ? (int)(*includes_dependencies)[d] : -1));
+    remember(std::move(p), queues, sig);
+    last = Last{};
+    last.mode = "load"; last.why = why;
+    return res;
+  }
+  void remember(PackedQueues&& p, const Queues& resident_queues, const std::vector<std::string>& sig) {
+    ids_.assign(resident_queues.size(), {});
+    dep_ids_.assign(resident_queues.size(), {});
+    for (size_t d = 0; d < resident_queues.size(); d++)
+      for (const Task& t : *resident_queues[d].second) {
+        ids_[d].push_back(t.Id);
+        std::vector<std::string> deps;
+        for (const auto& x : t.DependsOn) deps.push_back(x.TaskId);
+        dep_ids_[d].push_back(std::move(deps));
+      }
+    packed_ = std::move(p);
+    sig_ = sig;
+    loaded_ = true;
+  }
+
+  ResidentBackend be_;
+  PackedQueues packed_;
+  bool loaded_ = false;
+  std::vector<std::vector<std::string>> ids_;
+  std::vector<std::vector<std::vector<std::string>>> dep_ids_;
+  std::vector<std::string> sig_;
+};
 
 }  // namespace evergreen

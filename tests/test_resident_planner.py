@@ -10,6 +10,8 @@ delta and the updates the planner hands over must reproduce -- array for array -
 those of PlanDistros on the same lists. GPU: the same ticks through evg_pool_load / evg_pool_tick."""
 import copy
 import dataclasses
+import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -226,3 +228,121 @@ def test_ticks_by_delta_on_the_device(native_ctx, oracle, seed, D, n):
     planner = S.ResidentPlanner(S.ResidentContext(native_ctx))
     modes = _run(world, planner, oracle, 6, "gpu seed %d" % seed)
     assert modes[0] == "load" and modes.count("tick") >= 3, modes
+
+
+# ---- the C++ planner (include/evg_host.hpp: evergreen::ResidentPlanner) against the Python one --------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_resident_planner")
+
+
+def _exe():
+    src = [os.path.join(ROOT, "tests", "cpp", "test_resident_planner.cpp"), os.path.join(ROOT, "include", "evg_host.hpp"), os.path.join(ROOT, "include", "evg_sched.h")]
+    if not os.path.exists(EXE) or any(os.path.getmtime(f) > os.path.getmtime(EXE) for f in src):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), src[0], "-o", EXE, "-ldl"])
+    return EXE
+
+
+def _t(x):
+    return "Z" if x is None else str(int(x))
+
+
+def _s(x):
+    return x if x != "" else "-"
+
+
+def write_world_tick(f, world):
+    """One tick of `world` in the text format tests/cpp/test_resident_planner.cpp reads."""
+    q = world.queues()
+    f.write("TICK %d %d\n" % (world.now, len(q)))
+    for d, ts in q:
+        ps = d.PlannerSettings
+        f.write("DISTRO %s %d %d %d %d %d %d %d %d %d %r %d %s\n" % (d.Id, ps.TargetTime, ps.MergeQueueTargetTime, int(bool(ps.GroupVersions)), ps.PatchFactor,
+                ps.PatchTimeInQueueFactor, ps.CommitQueueFactor, ps.MainlineTimeInQueueFactor, ps.ExpectedRuntimeFactor, ps.GenerateTaskFactor,
+                float(ps.NumDependentsFactor), ps.StepbackTaskFactor, _s(d.DispatcherSettings.Version)))
+        for t in ts:
+            f.write("TASK %s %s %s %s %s %s %d %d %s %d %d %d %s %s %s %s %s %d %d %s %s\n" % (
+                t.Id, t.DistroId, t.Version, _s(t.TaskGroup), t.BuildVariant, t.Project, t.TaskGroupOrder, t.TaskGroupMaxHosts, t.Requester, t.Priority,
+                t.NumDependents, int(t.GenerateTask), _s(t.ActivatedBy), _t(t.ActivatedTime), _t(t.IngestTime), _t(t.ScheduledTime), _t(t.DependenciesMetTime),
+                int(t.OverrideDependencies), t.ExpectedDuration, t.Status, _s(t.CachedProjectStorageMethod)))
+            for dep in t.DependsOn:
+                f.write("DEP %s %s %d %s\n" % (dep.TaskId, _s(dep.Status), int(dep.Unattainable), _t(dep.FinishedAt)))
+    for tid, (status, blocked) in world.done.items():
+        f.write("D %s %s %d\n" % (tid, status, int(blocked)))
+    return q
+
+
+class Recorder:
+    """What a planner hands to pool_load / pool_tick, as the text the C++ driver's `record` mode writes."""
+
+    def __init__(self):
+        self.lines = []
+
+    def _dump(self, name, v):
+        v = [] if v is None else np.asarray(v).tolist()
+        self.lines.append(" ".join([name, str(len(v))] + [str(int(x)) for x in v]))
+
+    def pool_load(self, b):
+        self.lines.append("LOAD %d %d %d" % (b.n_distros, b.n_tasks, b.n_edges))
+        self._dump("task_off", b.task_off); self._dump("tg_key", b.cols["tg_key"]); self._dump("dep_idx", b.edges["dep_idx"])
+
+    def pool_tick(self, batch_after, now_ns, delta=None, rows=None, cols=None, edges=None, dep_info=None, dep_finished_ts_ns=None):
+        self.lines.append("TICKCALL %d %d %d %d" % (now_ns, int(delta is not None), 0 if rows is None else len(rows), 0 if edges is None else len(edges)))
+        if delta is not None:
+            for k in ("removed_rows", "removed_dep_state", "removed_finished_ts_ns", "added_distro"):
+                self._dump(k, delta[k])
+            for k in abi.TASK_COLUMNS:
+                self._dump(k, delta["added_cols"][k])
+            self._dump("added_dep_off", delta["added_dep_off"])
+            for k in ("dep_idx", "dep_info", "dep_finished_ts_ns"):
+                self._dump("a_" + k, delta["added_edges"][k])
+            for k in ("tg_off", "ver_off", "relinked_edges", "relinked_to"):
+                self._dump(k, delta[k])
+        if rows is not None:
+            self._dump("u_rows", rows)
+            for k in S._UPDATABLE:
+                self._dump("u_" + k, cols[k])
+        if edges is not None:
+            self._dump("e_edges", edges); self._dump("e_dep_info", dep_info); self._dump("e_dep_finished_ts_ns", dep_finished_ts_ns)
+        res = abi.PlanResult.alloc_host(batch_after, breakdown=True, n_units=False)
+        res.order[:] = np.arange(batch_after.n_tasks)
+        return res
+
+
+@pytest.mark.parametrize("seed,D,n", [(21, 3, 40), (22, 6, 120), (23, 1, 300), (24, 9, 20)])
+def test_the_cpp_planner_hands_over_what_the_python_planner_does(tmp_path, seed, D, n):
+    """include/evg_host.hpp's ResidentPlanner and scheduler.ResidentPlanner are one algorithm twice: for the same task lists, tick after
+    tick, they must hand the resident entry points the same delta, the same updates -- array for array (the Python one is held to the
+    checker's re-pack and to PlanDistros above)."""
+    world = World(seed, D, n)
+    rec = Recorder()
+    planner = S.ResidentPlanner(rec)
+    wf = tmp_path / "world.txt"
+    with open(wf, "w") as f:
+        for k in range(7):
+            q = write_world_tick(f, world)
+            planner.plan(q, world.now, dep_lookup=world.lookup)
+            rec.lines.append("MODE %s" % planner.last["mode"])
+            world.tick()
+    out = tmp_path / "cpp.txt"
+    r = subprocess.run([_exe(), "record", str(wf), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = open(out).read().splitlines()
+    assert len(got) == len(rec.lines), (len(got), len(rec.lines))
+    for i, (a, b) in enumerate(zip(got, rec.lines)):
+        assert a == b, "line %d (%s): the C++ planner %s... / the Python planner %s..." % (i, b.split()[0], a[:200], b[:200])
+    assert sum(1 for x in rec.lines if x == "MODE tick") >= 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,D,n", [(31, 4, 200), (32, 10, 50)])
+def test_the_cpp_planner_on_the_device(tmp_path, seed, D, n):
+    world = World(seed, D, n)
+    wf = tmp_path / "world.txt"
+    with open(wf, "w") as f:
+        for k in range(6):
+            write_world_tick(f, world)
+            world.tick()
+    lib = os.path.join(ROOT, "evergreen_amd", "csrc", "libevg_sched.so")
+    r = subprocess.run([_exe(), "hip", lib, str(wf)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "(5 by delta)" in r.stdout or "(4 by delta)" in r.stdout, r.stdout
