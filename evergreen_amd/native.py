@@ -53,7 +53,11 @@ def kernel_sources_hash() -> str:
 
 
 class NativeError(RuntimeError):
-    pass
+    """A call into the library failed. `rc` is the library's code (abi.EVG_E_*) where the failing call returned one, else None."""
+
+    def __init__(self, msg: str, rc: Optional[int] = None):
+        super().__init__(msg)
+        self.rc = rc
 
 
 def load_library() -> C.CDLL:
@@ -231,7 +235,7 @@ class MultiContext:
 
     def _check(self, rc: int, what: str) -> None:
         if rc != abi.EVG_OK:
-            raise NativeError("%s failed (%d): %s" % (what, rc, (self.lib.evg_multi_last_error(self.h) or b"?").decode()))
+            raise NativeError("%s failed (%d): %s" % (what, rc, (self.lib.evg_multi_last_error(self.h) or b"?").decode()), rc)
 
     def load(self, batch: abi.PlanBatch) -> None:
         inp = abi.make_plan_input(batch)
@@ -337,7 +341,7 @@ class Batcher:
         inp, out, err = abi.make_plan_input(batch), res.c_output(), C.create_string_buffer(256)
         rc = self.lib.evg_batcher_plan(self.h, C.byref(inp), C.byref(out), err, 256)
         if rc != abi.EVG_OK:
-            raise NativeError("evg_batcher_plan failed (%d): %s" % (rc, err.value.decode()))
+            raise NativeError("evg_batcher_plan failed (%d): %s" % (rc, err.value.decode()), rc)
         return res
 
     def allocate(self, batch: abi.PlanBatch, distro_info: np.ndarray, group_info: np.ndarray,
@@ -346,7 +350,7 @@ class Batcher:
         inp, out, err = abi.make_alloc_input(batch, distro_info, group_info), res.c_output(), C.create_string_buffer(256)
         rc = self.lib.evg_batcher_allocate(self.h, C.byref(inp), C.byref(out), err, 256)
         if rc != abi.EVG_OK:
-            raise NativeError("evg_batcher_allocate failed (%d): %s" % (rc, err.value.decode()))
+            raise NativeError("evg_batcher_allocate failed (%d): %s" % (rc, err.value.decode()), rc)
         return res
 
     def plan_queue(self, queue_id: int, generation: int, batch: abi.PlanBatch, breakdown: bool = True, n_units: bool = True, units: bool = False,
@@ -356,7 +360,7 @@ class Batcher:
         inp, out, err = abi.make_plan_input(batch), res.c_output(), C.create_string_buffer(256)
         rc = self.lib.evg_batcher_plan_queue(self.h, queue_id, generation, C.byref(inp), C.byref(out), err, 256)
         if rc != abi.EVG_OK:
-            raise NativeError("evg_batcher_plan_queue failed (%d): %s" % (rc, err.value.decode()))
+            raise NativeError("evg_batcher_plan_queue failed (%d): %s" % (rc, err.value.decode()), rc)
         return res
 
     def schedule(self, batch: abi.PlanBatch, queue_id: int = 0, generation: int = 0, breakdown: bool = True, n_units: bool = True, units: bool = False):
@@ -368,7 +372,7 @@ class Batcher:
         ainp, aout = abi.make_alloc_input(batch, None, None), ares.c_output()
         rc = self.lib.evg_batcher_schedule(self.h, queue_id, generation, C.byref(inp), C.byref(out), C.byref(ainp), C.byref(aout), err, 256)
         if rc != abi.EVG_OK:
-            raise NativeError("evg_batcher_schedule failed (%d): %s" % (rc, err.value.decode()))
+            raise NativeError("evg_batcher_schedule failed (%d): %s" % (rc, err.value.decode()), rc)
         return res, ares
 
     def debug_stall(self, slot: int, ms: int) -> None:
@@ -433,7 +437,7 @@ class Context:
     def _check(self, rc: int, what: str) -> None:
         if rc != abi.EVG_OK:
             msg = self.lib.evg_last_error(self.h)
-            raise NativeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+            raise NativeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"), rc)
 
     # ---- page-locked host buffers (evg_host_alloc): numpy views for the host-pointer entry points ---------------------
     def pinned_empty(self, shape, dtype) -> np.ndarray:

@@ -683,6 +683,7 @@ class ResidentPlanner:
 
     def _load(self, queues, now_ns, dep_lookup, includes_dependencies, opts, why: str):
         packed = pack_queues(queues, now_ns, dep_lookup, includes_dependencies)
+        self.packed = None  # until the plan of the new pool is back: a call that fails in between leaves the next one to load again
         self.backend.pool_load(packed.batch)
         res = self.backend.pool_tick(packed.batch, now_ns)
         self._remember(packed, queues, includes_dependencies)
@@ -841,9 +842,19 @@ class ResidentPlanner:
                       + len(edges) * 13 + 28 * (D + 1))
         if tick_bytes > self.MAX_TICK_BYTES:
             return self._load(queues, now_ns, dep_lookup, includes_dependencies, opts, "a tick of %d bytes does not travel in one block" % tick_bytes)
-        res = self.backend.pool_tick(tb, now_ns, delta=delta, rows=rows if len(rows) else None, cols=cols,
-                                     edges=edges if len(edges) else None, dep_info=einfo if len(edges) else None,
-                                     dep_finished_ts_ns=efin if len(edges) else None)
+        try:
+            res = self.backend.pool_tick(tb, now_ns, delta=delta, rows=rows if len(rows) else None, cols=cols,
+                                         edges=edges if len(edges) else None, dep_info=einfo if len(edges) else None,
+                                         dep_finished_ts_ns=efin if len(edges) else None)
+        except Exception as e:
+            # a delta or an update the contract refuses leaves the pool as it was (include/evg_sched.h, evg_pool_tick): the tick's lists
+            # go up whole, the way the reference plans every tick, and `last["why"]` keeps what the device said. Anything else (a HIP
+            # failure, an expired deadline: the context is poisoned) is the caller's to see -- and says nothing about which pool the
+            # device holds: the next call loads.
+            if getattr(e, "rc", None) not in (abi.EVG_E_CONTRACT, abi.EVG_E_INVALID):
+                self.packed = None
+                raise
+            return self._load(queues, now_ns, dep_lookup, includes_dependencies, opts, "the device refused the tick: %s" % e)
         self._remember(target, queues, includes_dependencies)
         self.last = {"mode": "tick", "removed": int(len(removed_rows)), "added": na, "relinked": len(rl_edges), "rows_updated": int(len(rows)),
                      "edges_updated": int(len(edges)), "tasks": NN}

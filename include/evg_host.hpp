@@ -1027,7 +1027,16 @@ class ResidentPlanner {
     detail::PlanBuffers b(tb);
     evg_plan_output out = b.out();
     const int rc = be_.pool_tick(have_delta ? &dl : nullptr, upd_rows.empty() ? nullptr : &ru, e_idx.empty() ? nullptr : &eu, now, &out);
-    if (rc != EVG_OK) throw PlanError("evg_pool_tick failed (" + std::to_string(rc) + "): " + (be_.last_error ? be_.last_error() : ""));
+    // a delta or an update the contract refuses leaves the pool as it was (evg_sched.h, evg_pool_tick): the tick's lists go up whole, the
+    // way the reference plans every tick, and `last.why` keeps what the device said. Anything else (a HIP failure, an expired deadline:
+    // the context is poisoned) is the caller's to see -- and says nothing about which pool the device holds: the next call loads.
+    if (rc == EVG_E_CONTRACT || rc == EVG_E_INVALID)
+      return load(queues, now, opts, lookup, includes_dependencies,
+                  "the device refused the tick (" + std::to_string(rc) + "): " + (be_.last_error ? be_.last_error() : ""));
+    if (rc != EVG_OK) {
+      loaded_ = false;
+      throw PlanError("evg_pool_tick failed (" + std::to_string(rc) + "): " + (be_.last_error ? be_.last_error() : ""));
+    }
     last = Last{};
     last.mode = "tick";
     last.removed = (int)removed_rows.size(); last.added = (int)na; last.relinked = (int)rl_edges.size(); last.rows_updated = (int)upd_rows.size();
@@ -1053,6 +1062,7 @@ class ResidentPlanner {
                                  const std::vector<bool>* includes_dependencies, const std::string& why) {
     PackedQueues p = pack_queues(queues, now, lookup, includes_dependencies);
     const evg_plan_input in = p.input();
+    loaded_ = false;  // until the plan of the new pool is back: a call that fails in between leaves the next one to load again
     int rc = be_.pool_load(&in);
     if (rc != EVG_OK) throw PlanError("evg_pool_load failed (" + std::to_string(rc) + "): " + (be_.last_error ? be_.last_error() : ""));
     detail::PlanBuffers b(p);

@@ -6,6 +6,7 @@
 //   hip <lib> <world>      on the device: every tick's plans == PlanDistros (evg_plan_distros) on the same lists in the pool's row order
 #include <cinttypes>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -99,6 +100,8 @@ int main(int argc, char** argv) {
   Backend fresh;
   size_t cur_D = 0;
   long long cur_N = 0;  // (record: the rows of the pool, for an identity `order` -- the plans themselves are not looked at)
+  int delta_ticks = 0;
+  const int refuse_at = getenv("EVG_TEST_REFUSE_TICK") ? atoi(getenv("EVG_TEST_REFUSE_TICK")) : 0;
   if (record) {
     rb.pool_load = [&](const evg_plan_input* in) {
       fprintf(o, "LOAD %d %d %d\n", in->n_distros, in->tasks.n_tasks, in->tasks.n_edges);
@@ -109,6 +112,8 @@ int main(int argc, char** argv) {
       return EVG_OK;
     };
     rb.pool_tick = [&](const evg_pool_delta* dl, const evg_row_update* ru, const evg_edge_update* eu, int64_t now, const evg_plan_output* out) {
+      // EVG_TEST_REFUSE_TICK=k: the k-th tick that carries a delta is refused the way the device refuses one (the pool stays as it was)
+      if (dl && ++delta_ticks == refuse_at) { fprintf(o, "REFUSED\n"); return EVG_E_CONTRACT; }
       if (dl) cur_N += dl->n_added - dl->n_removed;
       for (long long i = 0; i < cur_N; i++) out->order[i] = (int32_t)i;
       fprintf(o, "TICKCALL %lld %d %d %d\n", (long long)now, dl ? 1 : 0, ru ? ru->n_rows : 0, eu ? eu->n_edges : 0);
@@ -154,7 +159,7 @@ int main(int argc, char** argv) {
     const auto q = queues_of(t);
     std::vector<PlannedQueue> got = planner.Plan(q, t.now, nullptr, lookup);
     by_delta += planner.last.mode == "tick";
-    if (record) { fprintf(o, "MODE %s\n", planner.last.mode.c_str()); continue; }
+    if (record) { fprintf(o, "MODE %s%s\n", planner.last.mode.c_str(), planner.last.why.rfind("the device refused", 0) == 0 ? " refused" : ""); continue; }
     // the same lists in the pool's row order (ties between equal keys fall to the lower row)
     std::vector<std::vector<Task>> res(t.distros.size());
     for (size_t d = 0; d < t.distros.size(); d++) {

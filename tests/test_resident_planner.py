@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from evergreen_amd import abi, gen
+from evergreen_amd import abi, gen, native
 from evergreen_amd import scheduler as S
 from tests import pool_delta
 
@@ -221,6 +221,56 @@ def test_quiet_ticks_and_reload_conditions(oracle):
     assert planner.last["mode"] == "load" and "duplicate" in planner.last["why"]
 
 
+class Failing:
+    """A resident backend whose next pool_tick fails with `rc` (once)."""
+
+    def __init__(self, inner):
+        self.inner, self.fail_rc = inner, None
+
+    def pool_load(self, batch):
+        return self.inner.pool_load(batch)
+
+    def pool_tick(self, *a, **kw):
+        if self.fail_rc is not None:
+            rc, self.fail_rc = self.fail_rc, None
+            raise native.NativeError("evg_pool_tick failed (%d): injected" % rc, rc)
+        return self.inner.pool_tick(*a, **kw)
+
+
+def test_a_refused_tick_loads_and_a_failed_call_leaves_the_next_one_to_load(oracle):
+    """evg_pool_tick leaves the pool as it was when it refuses a delta (EVG_E_CONTRACT / EVG_E_INVALID): the planner uploads the tick's
+    lists whole and says why -- the caller gets PlanDistros' answer either way, as the reference's job does every 15 s. Any other failure
+    is raised, and since it says nothing about which pool the device holds the next call loads instead of sending a delta."""
+    world = World(41, 4, 60)
+    be = Failing(CheckerResident(oracle))
+    planner = S.ResidentPlanner(be)
+    planner.plan(world.queues(), world.now, dep_lookup=world.lookup)
+    world.tick()
+    be.fail_rc = abi.EVG_E_CONTRACT
+    got = planner.plan(world.queues(), world.now, dep_lookup=world.lookup)
+    assert planner.last["mode"] == "load" and planner.last["why"].startswith("the device refused the tick")
+    by_id = [{t.Id: t for t in ts} for _, ts in world.queues()]
+    resident = [(world.distros[d], [by_id[d][tid] for tid in planner.ids[d]]) for d in range(len(by_id))]
+    _same_plans(got, S.PlanDistros(oracle, resident, world.now, dep_lookup=world.lookup), "refused tick")
+    world.tick()
+    planner.plan(world.queues(), world.now, dep_lookup=world.lookup)
+    assert planner.last["mode"] == "tick"
+    world.tick()
+    be.fail_rc = abi.EVG_E_HIP
+    with pytest.raises(native.NativeError):
+        planner.plan(world.queues(), world.now, dep_lookup=world.lookup)
+    planner.plan(world.queues(), world.now, dep_lookup=world.lookup)
+    assert planner.last["mode"] == "load" and planner.last["why"] == "first tick"
+    world.tick()
+    be.fail_rc = abi.EVG_E_TIMEOUT                   # ... and one that fails between a load's upload and its plan
+    world.distros[0].PlannerSettings.PatchFactor += 1
+    with pytest.raises(native.NativeError):
+        planner.plan(world.queues(), world.now, dep_lookup=world.lookup)
+    assert planner.packed is None
+    planner.plan(world.queues(), world.now, dep_lookup=world.lookup)
+    assert planner.last["mode"] == "load"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,D,n", [(11, 4, 200), (12, 12, 60), (13, 2, 1500)])
 def test_ticks_by_delta_on_the_device(native_ctx, oracle, seed, D, n):
@@ -274,8 +324,8 @@ def write_world_tick(f, world):
 class Recorder:
     """What a planner hands to pool_load / pool_tick, as the text the C++ driver's `record` mode writes."""
 
-    def __init__(self):
-        self.lines = []
+    def __init__(self, refuse_at=0):
+        self.lines, self.refuse_at, self.delta_ticks = [], refuse_at, 0
 
     def _dump(self, name, v):
         v = [] if v is None else np.asarray(v).tolist()
@@ -286,6 +336,11 @@ class Recorder:
         self._dump("task_off", b.task_off); self._dump("tg_key", b.cols["tg_key"]); self._dump("dep_idx", b.edges["dep_idx"])
 
     def pool_tick(self, batch_after, now_ns, delta=None, rows=None, cols=None, edges=None, dep_info=None, dep_finished_ts_ns=None):
+        if delta is not None:
+            self.delta_ticks += 1
+            if self.delta_ticks == self.refuse_at:  # the way the device refuses a delta: the pool stays as it was
+                self.lines.append("REFUSED")
+                raise native.NativeError("evg_pool_tick failed (-4): refused by the test", abi.EVG_E_CONTRACT)
         self.lines.append("TICKCALL %d %d %d %d" % (now_ns, int(delta is not None), 0 if rows is None else len(rows), 0 if edges is None else len(edges)))
         if delta is not None:
             for k in ("removed_rows", "removed_dep_state", "removed_finished_ts_ns", "added_distro"):
@@ -308,29 +363,33 @@ class Recorder:
         return res
 
 
-@pytest.mark.parametrize("seed,D,n", [(21, 3, 40), (22, 6, 120), (23, 1, 300), (24, 9, 20)])
-def test_the_cpp_planner_hands_over_what_the_python_planner_does(tmp_path, seed, D, n):
+@pytest.mark.parametrize("seed,D,n,refuse_at", [(21, 3, 40, 0), (22, 6, 120, 0), (23, 1, 300, 0), (24, 9, 20, 0), (25, 4, 60, 2)])
+def test_the_cpp_planner_hands_over_what_the_python_planner_does(tmp_path, seed, D, n, refuse_at):
     """include/evg_host.hpp's ResidentPlanner and scheduler.ResidentPlanner are one algorithm twice: for the same task lists, tick after
     tick, they must hand the resident entry points the same delta, the same updates -- array for array (the Python one is held to the
     checker's re-pack and to PlanDistros above)."""
     world = World(seed, D, n)
-    rec = Recorder()
+    rec = Recorder(refuse_at)
     planner = S.ResidentPlanner(rec)
     wf = tmp_path / "world.txt"
     with open(wf, "w") as f:
         for k in range(7):
             q = write_world_tick(f, world)
             planner.plan(q, world.now, dep_lookup=world.lookup)
-            rec.lines.append("MODE %s" % planner.last["mode"])
+            rec.lines.append("MODE %s%s" % (planner.last["mode"], " refused" if str(planner.last.get("why", "")).startswith("the device refused") else ""))
             world.tick()
     out = tmp_path / "cpp.txt"
-    r = subprocess.run([_exe(), "record", str(wf), str(out)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([_exe(), "record", str(wf), str(out)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, EVG_TEST_REFUSE_TICK=str(refuse_at)))
     assert r.returncode == 0, r.stdout + r.stderr
     got = open(out).read().splitlines()
     assert len(got) == len(rec.lines), (len(got), len(rec.lines))
     for i, (a, b) in enumerate(zip(got, rec.lines)):
         assert a == b, "line %d (%s): the C++ planner %s... / the Python planner %s..." % (i, b.split()[0], a[:200], b[:200])
     assert sum(1 for x in rec.lines if x == "MODE tick") >= 4
+    if refuse_at:  # a refused tick (both planners: REFUSED, then the same lists as a LOAD) does not end the resident pool
+        i = rec.lines.index("REFUSED")
+        assert rec.lines[i + 1].startswith("LOAD ") and "MODE load refused" in rec.lines[i:] and "MODE tick" in rec.lines[rec.lines.index("MODE load refused"):]
 
 
 @pytest.mark.gpu
