@@ -20,6 +20,10 @@ it, the phases under the reference's names (scheduler/wrapper.go:121-123 "planni
 the Go algorithm -- the Go reference cannot be built here), the PCIe-inclusive host-pointer rate (`end_to_end`), the
 skewed config-3 variant (`skewed`), BASELINE config 5's per-GPU share (`config5_share`) and the rate with several
 batches in flight (`pipelined`). `--weak` keeps round 1's mode (an independent pool per rank, no collective).
+
+An N > 1 run cannot end without a line: rank 0 builds the headline before the collective extras run, the extras stand under
+`--extras-deadline-s` (the line goes out without them) and the headline part under `--tick-deadline-s` (a line with value null and the
+reason; exit code 3) -- see Deadline below.
 """
 import argparse
 import json
@@ -609,9 +613,11 @@ def launch_plan(gpus, world, device_count, single_process=False, rendezvous_only
                       "--master-port", str(port), os.path.abspath(__file__)]
 
 
-def rendezvous_only():
+def rendezvous_only(args):
     """`--rendezvous-only`: join the world the launcher made (RCCL on a GPU box, gloo without one), count the ranks with one all-reduce
-    and print it -- the launcher path of `--gpus N` without any device work (tests/test_bench_launch.py runs it on the CPU)."""
+    and print it -- the launcher path of `--gpus N` without any device work (tests/test_bench_launch.py runs it on the CPU).
+    `--stall-rank R` (tests): rank R then stays away from a second all-reduce, the others sit in it -- the shape of a collective that
+    never returns -- and the run's Deadline has to end it: rank 0 prints the unmeasured line, every rank leaves with code 3."""
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), env_world() or 1
@@ -622,6 +628,14 @@ def rendezvous_only():
     dist.init_process_group("nccl" if cuda else "gloo", rank=rank, world_size=world)
     one = torch.ones(1, dtype=torch.int64, device="cuda" if cuda else "cpu")
     dist.all_reduce(one)
+    if args.stall_rank >= 0:
+        Deadline().arm(args.tick_deadline_s, lambda: give_up(rank, unmeasured_line(args, world, int(one.item()), None)))
+        if rank == args.stall_rank:
+            time.sleep(3600)
+        dist.all_reduce(one)
+        if cuda:
+            torch.cuda.synchronize()
+        time.sleep(3600)
     if rank == 0:
         print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks_seen": int(one.item()), "backend": "nccl" if cuda else "gloo"}), flush=True)
     dist.barrier()
@@ -647,6 +661,52 @@ def multi_selftest_child(n):
     out["seconds"] = time.perf_counter() - t0
     flush_c_stdio()
     print(json.dumps(out), flush=True)
+
+
+class Deadline:
+    """A bound on the parts of an N > 1 run that no library deadline covers (torch.distributed's collectives; PyTorch's own RCCL watchdog
+    ends the PROCESS after 10 minutes, and the line with it). arm(seconds, fn): fn runs on a timer thread when the time is up -- unless
+    the line has been claimed by then; claim() is true for exactly one caller, so the line is printed once whoever gets there first."""
+
+    def __init__(self):
+        self._lock, self._claimed, self._timer = threading.Lock(), False, None
+
+    def claim(self):
+        with self._lock:
+            first, self._claimed = not self._claimed, True
+            return first
+
+    def arm(self, seconds, on_expiry):
+        self.cancel()
+
+        def fire():
+            if self.claim():
+                on_expiry()
+        self._timer = threading.Timer(seconds, fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def cancel(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+
+def unmeasured_line(args, world, ranks_seen, selftest):
+    """What rank 0 prints when an N > 1 run does not get as far as its line: the contract's keys with value null, why, and what is known."""
+    return {"metric": METRIC, "value": None, "unit": "tasks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "error": "the %d-rank run did not reach its line within %.0f s (--tick-deadline-s): a collective that never returned?" % (world, args.tick_deadline_s),
+            "config": {"workload": "BASELINE config 4 over %d ranks: NOT measured" % world,
+                       "multi": {"rccl_ranks_seen": ranks_seen, "selftest": selftest if selftest is not None else "skipped"}}}
+
+
+def give_up(rank, line):
+    """On a Deadline's timer thread: rank 0 prints `line`, every rank leaves with code 3 (the main thread sits in a collective)."""
+    if rank == 0:
+        flush_c_stdio()
+        print(json.dumps(line), flush=True)
+    os._exit(3)
 
 
 def run_multi_selftest(n, timeout_s=240):
@@ -687,6 +747,12 @@ def main():
     ap.add_argument("--rendezvous-only", action="store_true", help="join the launcher's world, count the ranks, print that (no device work)")
     ap.add_argument("--multi-selftest", type=int, default=0, help="(internal) evg_multi_selftest over this many devices from one process")
     ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the library's N-device self-check in front of the run")
+    ap.add_argument("--stall-rank", type=int, default=-1, help="(tests, with --rendezvous-only) this rank stays away from a collective the others enter")
+    ap.add_argument("--tick-deadline-s", type=float, default=420.0, help="N > 1: when the headline part of the run (pool in, the timed ticks, rank 0's "
+                                                                          "roofline / CPU baseline) is not over by then, rank 0 prints a line that says so "
+                                                                          "(value null) and every rank exits 3")
+    ap.add_argument("--extras-deadline-s", type=float, default=420.0, help="N > 1: when the collective extras (scatter, config 5) are not over by then, rank 0 "
+                                                                            "prints the headline line without them and every rank exits 0")
     args = ap.parse_args()
 
     if args.multi_selftest:
@@ -701,7 +767,7 @@ def main():
         sys.stderr.write("bench.py: --gpus %d without a launcher: re-executing under torch.distributed.run\n" % args.gpus)
         raise SystemExit(subprocess.call(how + sys.argv[1:]))
     if args.rendezvous_only:
-        return rendezvous_only()
+        return rendezvous_only(args)
 
     import numpy as np
     from evergreen_amd import gen, multi, native, resident
@@ -730,6 +796,9 @@ def main():
         ranks_seen = int(one.item())
         if ranks_seen != world:
             raise SystemExit("bench.py: %d ranks answered the all-reduce, the world is %d" % (ranks_seen, world))
+    deadline = Deadline()
+    if world > 1:
+        deadline.arm(args.tick_deadline_s, lambda: give_up(rank, unmeasured_line(args, world, ranks_seen, selftest)))
 
     cfg_num = args.config or (3 if world == 1 else 4)
     over = {}
@@ -813,9 +882,15 @@ def main():
         sum_tasks = my_tasks
     total_tasks = sum_tasks if args.weak else float(pool.layout.N)
 
-    # ---- collective extras (every rank takes part; rank 0 keeps the objects) -------------------------------------------
+    # ---- collective extras (every rank takes part; rank 0 keeps the objects). Run AFTER rank 0 has built its line (below): code that
+    # has never met N > 1 hardware must not be able to cost the headline -- the other ranks wait in the extras' first collective
+    # while rank 0 takes its roofline and CPU baseline (seconds), and a deadline stands behind the extras themselves. ----------------
     extra_objs = {}
-    if not args.weak and not args.no_extras:
+
+    def run_collective_extras():
+        if args.weak or args.no_extras:
+            return
+
         def collective(key, fn):
             try:
                 extra_objs[key] = fn()
@@ -831,6 +906,7 @@ def main():
                 + (" on one MI355X" if world == 1 else ", distros sharded over %d ranks (one broadcast of the packed pool + one grouped gather per tick)" % world),
                 native.Context(local_rank), dev, dist, rank, world, "broadcast", max(3, min(args.steps, 10)), 2, multi, torch, check=True))
 
+    line = None
     if rank == 0:
         def med(i, j):
             xs = sorted(e[i].elapsed_time(e[j]) for e in ev)
@@ -1033,7 +1109,12 @@ def main():
             guarded("single_process_abi", lambda: multi_abi_tick(batch, native, [dev.index or 0], 20, 3, want=got, want_alloc=got_alloc)[0])
             if args.in_flight > 1:
                 guarded("pipelined", lambda: pipelined_rate(batch, dev, args.in_flight, min(args.steps, 60), native, resident, torch))
-        for k, v in extra_objs.items():
+
+    def emit(extras_note=None):
+        """Rank 0: the ONE line -- the headline with whatever the collective extras have produced by now."""
+        if rank != 0:
+            return
+        for k, v in list(extra_objs.items()):
             if v is not None:
                 line[k] = v
         if world > 1:
@@ -1045,13 +1126,25 @@ def main():
             c5 = line.get("config5")
             line["config"]["multi"] = {
                 "rccl_ranks_seen": ranks_seen, "selftest": selftest if selftest is not None else "skipped",
-                "broadcast_tick_tasks_per_s": value, "kernel_only_tasks_per_s": rate(line.get("kernel_only")),
+                "broadcast_tick_tasks_per_s": line["value"], "kernel_only_tasks_per_s": rate(line.get("kernel_only")),
                 "resident_shards_tasks_per_s": rate(line.get("resident_shards")), "scatter_tasks_per_s": rate(line.get("scatter")),
                 "config5_tasks_per_s": rate(c5), "config5_parity_vs_oracle": c5.get("parity_vs_oracle") if isinstance(c5, dict) else None,
                 "config5_error": c5.get("error") if isinstance(c5, dict) else None,
-                "queue_order_match": line.get("queue_order_match")}
+                "queue_order_match": line.get("queue_order_match"), "extras": extras_note or "complete"}
         flush_c_stdio()
         print(json.dumps(line), flush=True)
+
+    if world > 1:
+        def extras_expired():  # the headline is measured and checked: it goes out, the run counts
+            emit("NOT complete: the collective extras did not finish within %.0f s (--extras-deadline-s); what is missing was not measured" % args.extras_deadline_s)
+            os._exit(0)
+        deadline.arm(args.extras_deadline_s, extras_expired)  # (replaces the headline's deadline: every rank is past its ticks here)
+    run_collective_extras()
+    deadline.cancel()
+    if not deadline.claim():   # the timer got there first: it prints (rank 0) and ends the process
+        time.sleep(30)
+        os._exit(0)
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -67,3 +67,39 @@ def test_gpus_2_relaunches_itself_and_both_ranks_answer():
     obj = json.loads(lines[0])
     assert obj["n_gpus"] == 2 and obj["ranks_seen"] == 2
     assert "re-executing under torch.distributed.run" in r.stderr
+
+
+def test_deadline_fires_once_and_a_claimed_line_is_not_printed_twice():
+    import time
+    d, fired = bench.Deadline(), []
+    d.arm(0.05, lambda: fired.append("a"))
+    time.sleep(0.3)
+    assert fired == ["a"] and not d.claim()          # the timer took the line: the main thread must not print another
+    d2, fired2 = bench.Deadline(), []
+    d2.arm(0.05, lambda: fired2.append("a"))
+    d2.cancel()
+    time.sleep(0.2)
+    assert fired2 == [] and d2.claim() and not d2.claim()
+    d3, fired3 = bench.Deadline(), []
+    d3.arm(5.0, lambda: fired3.append("first"))      # re-armed for the next part of the run: only the later timer is alive
+    d3.arm(0.05, lambda: fired3.append("second"))
+    time.sleep(0.3)
+    assert fired3 == ["second"]
+    d4, fired4 = bench.Deadline(), []
+    assert d4.claim()                                # the line went out before the time was up: the timer has nothing to do
+    d4.arm(0.05, lambda: fired4.append("late"))
+    time.sleep(0.2)
+    assert fired4 == []
+
+
+def test_a_collective_that_never_returns_costs_the_deadline_not_the_line():
+    """Two gloo ranks, rank 1 stays away from the second all-reduce: torch.distributed would sit there (and PyTorch's watchdog would end
+    the process without a line); the run's Deadline prints the unmeasured line from rank 0 and ends every rank with code 3."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only", "--stall-rank", "1", "--tick-deadline-s", "3"],
+                       capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    obj = json.loads(lines[0])
+    assert obj["value"] is None and obj["n_gpus"] == 2 and "did not reach its line" in obj["error"]
+    assert obj["config"]["multi"]["rccl_ranks_seen"] == 2
