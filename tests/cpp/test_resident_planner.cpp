@@ -100,7 +100,7 @@ int main(int argc, char** argv) {
   Backend fresh;
   size_t cur_D = 0;
   long long cur_N = 0;  // (record: the rows of the pool, for an identity `order` -- the plans themselves are not looked at)
-  int delta_ticks = 0;
+  int delta_ticks = 0, refused = 0, loads_after_refusal = 0;
   const int refuse_at = getenv("EVG_TEST_REFUSE_TICK") ? atoi(getenv("EVG_TEST_REFUSE_TICK")) : 0;
   if (record) {
     rb.pool_load = [&](const evg_plan_input* in) {
@@ -145,6 +145,19 @@ int main(int argc, char** argv) {
   } else {
     rb = HipResidentBackend(argv[2]);
     fresh = HipBackend(argv[2]);
+    if (refuse_at > 0) {  // the k-th tick that carries a delta goes to the device spoiled (a relinked edge far outside the pool): the library refuses it
+      auto real = rb.pool_tick;
+      rb.pool_tick = [&, real](const evg_pool_delta* dl, const evg_row_update* ru, const evg_edge_update* eu, int64_t now, const evg_plan_output* out) {
+        if (!dl || ++delta_ticks != refuse_at) return real(dl, ru, eu, now, out);
+        static const int32_t bad_edge = 1 << 30, bad_to = 0;
+        evg_pool_delta spoiled = *dl;
+        spoiled.n_relinked = 1; spoiled.relinked_edges = &bad_edge; spoiled.relinked_to = &bad_to;
+        const int rc = real(&spoiled, ru, eu, now, out);
+        printf("spoiled tick: rc %d (%s)\n", rc, rb.last_error().c_str());
+        refused += rc == EVG_E_CONTRACT || rc == EVG_E_INVALID;
+        return rc;
+      };
+    }
   }
   ResidentPlanner planner(rb);
   int by_delta = 0, fails = 0;
@@ -159,6 +172,7 @@ int main(int argc, char** argv) {
     const auto q = queues_of(t);
     std::vector<PlannedQueue> got = planner.Plan(q, t.now, nullptr, lookup);
     by_delta += planner.last.mode == "tick";
+    loads_after_refusal += planner.last.mode == "load" && planner.last.why.rfind("the device refused", 0) == 0;
     if (record) { fprintf(o, "MODE %s%s\n", planner.last.mode.c_str(), planner.last.why.rfind("the device refused", 0) == 0 ? " refused" : ""); continue; }
     // the same lists in the pool's row order (ties between equal keys fall to the lower row)
     std::vector<std::vector<Task>> res(t.distros.size());
@@ -196,5 +210,9 @@ int main(int argc, char** argv) {
   }
   if (o) fclose(o);
   printf("resident planner: %zu ticks (%d by delta), %d mismatches\n", ticks.size(), by_delta, fails);
+  if (refuse_at > 0 && !record) {
+    printf("refused by the device: %d, answered by a load: %d\n", refused, loads_after_refusal);
+    if (refused != 1 || loads_after_refusal != 1) return 1;
+  }
   return fails ? 1 : 0;
 }

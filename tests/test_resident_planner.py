@@ -280,6 +280,41 @@ def test_ticks_by_delta_on_the_device(native_ctx, oracle, seed, D, n):
     assert modes[0] == "load" and modes.count("tick") >= 3, modes
 
 
+class Spoiling(S.ResidentContext):
+    """The product's resident entry points, with ONE tick's delta spoiled on its way in (a relinked edge far outside the pool)."""
+
+    def __init__(self, ctx):
+        super().__init__(ctx)
+        self.spoil_next, self.refusals = False, []
+
+    def pool_tick(self, batch_after, now_ns, delta=None, **kw):
+        if self.spoil_next and delta is not None:
+            self.spoil_next = False
+            delta = dict(delta, relinked_edges=np.array([1 << 30], np.int32), relinked_to=np.array([0], np.int32))
+            try:
+                return super().pool_tick(batch_after, now_ns, delta=delta, **kw)
+            except native.NativeError as e:
+                self.refusals.append((e.rc, str(e)))
+                raise
+        return super().pool_tick(batch_after, now_ns, delta=delta, **kw)
+
+
+@pytest.mark.gpu
+def test_a_tick_the_device_refuses_is_answered_by_a_load_on_the_device(native_ctx, oracle):
+    """The library's own refusal (EVG_E_CONTRACT through NativeError.rc) and its promise that a refused tick leaves the pool as it was: the
+    planner uploads the lists whole, the plans are PlanDistros', and the ticks after it travel as deltas again."""
+    world = World(51, 5, 120)
+    be = Spoiling(native_ctx)
+    planner = S.ResidentPlanner(be)
+    modes = _run(world, planner, oracle, 2, "before the refusal")
+    be.spoil_next = True
+    modes += _run(world, planner, oracle, 1, "the refused tick")
+    assert len(be.refusals) == 1 and be.refusals[0][0] in (abi.EVG_E_CONTRACT, abi.EVG_E_INVALID), be.refusals
+    assert planner.last["mode"] == "load" and planner.last["why"].startswith("the device refused the tick")
+    modes += _run(world, planner, oracle, 3, "after the refusal")
+    assert modes[-3:].count("tick") >= 2, modes
+
+
 # ---- the C++ planner (include/evg_host.hpp: evergreen::ResidentPlanner) against the Python one --------------------------------------
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "test_resident_planner")
@@ -393,8 +428,8 @@ def test_the_cpp_planner_hands_over_what_the_python_planner_does(tmp_path, seed,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,D,n", [(31, 4, 200), (32, 10, 50)])
-def test_the_cpp_planner_on_the_device(tmp_path, seed, D, n):
+@pytest.mark.parametrize("seed,D,n,refuse_at", [(31, 4, 200, 0), (32, 10, 50, 0), (33, 5, 80, 2)])
+def test_the_cpp_planner_on_the_device(tmp_path, seed, D, n, refuse_at):
     world = World(seed, D, n)
     wf = tmp_path / "world.txt"
     with open(wf, "w") as f:
@@ -402,6 +437,8 @@ def test_the_cpp_planner_on_the_device(tmp_path, seed, D, n):
             write_world_tick(f, world)
             world.tick()
     lib = os.path.join(ROOT, "evergreen_amd", "csrc", "libevg_sched.so")
-    r = subprocess.run([_exe(), "hip", lib, str(wf)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([_exe(), "hip", lib, str(wf)], capture_output=True, text=True, timeout=600, env=dict(os.environ, EVG_TEST_REFUSE_TICK=str(refuse_at)))
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "(5 by delta)" in r.stdout or "(4 by delta)" in r.stdout, r.stdout
+    assert any("(%d by delta)" % k in r.stdout for k in ((5, 4) if not refuse_at else (4, 3))), r.stdout
+    if refuse_at:  # the library's own refusal reached the planner, which answered with a load (the plans above include that tick's)
+        assert "refused by the device: 1, answered by a load: 1" in r.stdout, r.stdout
