@@ -185,6 +185,15 @@ static int merr(evg_multi* m, int code, const char* fmt, ...) {
   if (m) m->err = buf; else g_multi_err = buf;
   return code;
 }
+static int mcaught(evg_multi* m) noexcept {  // evg_sched.hip's caught() for the multi-device entry points
+  try {
+    try { throw; }
+    catch (const std::bad_alloc&) { return merr(m, EVG_E_NOMEM, "out of host memory"); }
+    catch (const std::length_error& e) { return merr(m, EVG_E_NOMEM, "out of host memory (%s)", e.what()); }
+    catch (const std::exception& e) { return merr(m, EVG_E_HIP, "internal failure: %s", e.what()); }
+    catch (...) { return merr(m, EVG_E_HIP, "internal failure: unknown exception"); }
+  } catch (...) { return EVG_E_NOMEM; }
+}
 #define EVGM_HIP(m, expr)                                                                                             \
   do {                                                                                                                \
     hipError_t e_ = (expr);                                                                                           \
@@ -659,15 +668,15 @@ extern "C" {
 
 const char* evg_multi_last_error(const evg_multi* m) { return m ? m->err.c_str() : evgm::g_multi_err.c_str(); }
 
-int evg_balanced_ranges(const int32_t* task_off, int32_t n_distros, int32_t world, int32_t* d_begin, int32_t* d_end) {
+int evg_balanced_ranges(const int32_t* task_off, int32_t n_distros, int32_t world, int32_t* d_begin, int32_t* d_end) try {
   if (!task_off || n_distros < 0 || world <= 0 || !d_begin || !d_end) return EVG_E_INVALID;
   std::vector<int> cuts;
   evgm::balanced_cuts(task_off, n_distros, world, cuts);
   for (int k = 0; k < world; k++) { d_begin[k] = cuts[k]; d_end[k] = cuts[k + 1]; }
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)nullptr); }
 
-evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t flags) {
+evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t flags) try {
   using namespace evgm;
   if (!devices || n_devices <= 0 || n_devices > 64) { merr(nullptr, EVG_E_INVALID, "evg_multi_create: 1..64 devices"); return nullptr; }
   const bool loopback = (flags & EVG_MULTI_LOOPBACK) != 0;
@@ -705,7 +714,7 @@ evg_multi* evg_multi_create(const int32_t* devices, int32_t n_devices, int32_t f
     for (int k = 0; k < n_devices; k++) m->r[k].comm = comms[k];
   }
   return m;
-}
+} catch (...) { evgm::mcaught(nullptr); return nullptr; }
 
 void evg_multi_destroy(evg_multi* m) {
   if (!m) return;
@@ -715,16 +724,16 @@ void evg_multi_destroy(evg_multi* m) {
   delete m;
 }
 
-int evg_multi_ranges(const evg_multi* m, int32_t* d_begin, int32_t* d_end) {
+int evg_multi_ranges(const evg_multi* m, int32_t* d_begin, int32_t* d_end) try {
   if (!m || !m->loaded || !d_begin || !d_end) return EVG_E_INVALID;
   for (int k = 0; k < m->n; k++) { d_begin[k] = m->r[k].d0; d_end[k] = m->r[k].d1; }
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // Validates the batch, packs it ONCE into a page-locked block in the pool layout, uploads it to rank 0's device and cuts the
 // distro ranges. `alloc` (or NULL: plan only) brings the allocator's per-distro settings and host columns; its distro_info /
 // group_info pointers are ignored -- every rank's allocator reads the rows its own planner left on the device.
-int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input* alloc) {
+int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input* alloc) try {
   using namespace evgm;
   if (!m || !in) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
@@ -863,7 +872,7 @@ int evg_multi_load(evg_multi* m, const evg_plan_input* in, const evg_alloc_input
   if (int rcw = mwait(m, 0, "pool in")) return rcw;
   m->loaded = true;
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // One tick over the loaded pool: move-in (broadcast or scatter from rank 0) -> every rank plans + allocates its range -> gather to
 // rank 0; returns when every device is done. Results stay on rank 0's device (evg_multi_results downloads them).
@@ -983,7 +992,7 @@ static int tick_body(evg_multi* m, int64_t now_ns, bool& group_open, bool& group
   return EVG_OK;
 }
 
-extern "C" int evg_multi_tick(evg_multi* m, int64_t now_ns) {
+extern "C" int evg_multi_tick(evg_multi* m, int64_t now_ns) try {
   using namespace evgm;
   if (!m) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
@@ -1018,46 +1027,46 @@ extern "C" int evg_multi_tick(evg_multi* m, int64_t now_ns) {
     if (rc && !first) first = merr(m, rc, "rank %d: %s", k, evg_last_error(m->r[k].ctx));
   }
   return first;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // Test hook: the NEXT evg_multi_tick fails on `rank` in `phase` (0 move-in, 1 plan, 2 allocate, 3 gather) after that rank's share of
 // the phase was enqueued -- inside the open RCCL group for the move-in and the gather. One shot. rank < 0 clears it.
-int evg_multi_inject_failure(evg_multi* m, int32_t rank, int32_t phase) {
+int evg_multi_inject_failure(evg_multi* m, int32_t rank, int32_t phase) try {
   if (!m || rank >= m->n || phase > 3) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
   m->inject_rank = rank < 0 ? -1 : rank;
   m->inject_phase = rank < 0 ? -1 : phase;
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // After a tick that did not come back (a peer device lost, a hung collective -- called from another thread) or an RCCL error the
 // caller does not trust: ncclCommAbort on every communicator, so that blocked collectives return, and the object refuses further
 // ticks. The caller destroys it and creates a new one (or goes on with one device). Takes no lock: the thread inside evg_multi_tick
 // holds it.
-int evg_multi_abort(evg_multi* m) {
+int evg_multi_abort(evg_multi* m) try {
   if (!m) return EVG_E_INVALID;
   evgm::abort_comms(m);
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // The deadline of every device wait of the object and of its ranks' contexts (default 30,000 ms, EVG_DEADLINE_MS; 0 = no limit).
-int evg_multi_set_deadline_ms(evg_multi* m, int64_t ms) {
+int evg_multi_set_deadline_ms(evg_multi* m, int64_t ms) try {
   if (!m || ms < 0) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
   m->deadline_ms = ms;
   for (evgm::Rank& r : m->r) if (r.ctx) (void)evg_set_deadline_ms(r.ctx, ms);
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // Test hook of the deadline: a kernel that spins for `ms` milliseconds on rank `rank`'s stream (see evg_debug_stall).
-int evg_multi_debug_stall(evg_multi* m, int32_t rank, int32_t ms) {
+int evg_multi_debug_stall(evg_multi* m, int32_t rank, int32_t ms) try {
   if (!m || rank < 0 || rank >= m->n || ms < 0 || ms > 20000) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
   EVGM_HIP(m, hipSetDevice(m->r[rank].device));
   hipLaunchKernelGGL(evg::k_debug_stall, dim3(1), dim3(64), 0, m->r[rank].stream, (long long)ms * 100000LL);
   EVGM_HIP(m, hipGetLastError());
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // Start-up self-check (the N > 1 path has never met hardware, and a Go scheduler that routes its only planning path
 // through it should know before the first tick): a small generated pool of mixed shape -- small distros, one for the 4096-task
@@ -1065,7 +1074,7 @@ int evg_multi_debug_stall(evg_multi* m, int32_t rank, int32_t ms) {
 // device alone (evg_plan_distros / evg_allocate_hosts) and once through evg_multi_load / _tick / _results over all the ranks: every
 // output array must be the same, byte for byte. EVG_OK, or EVG_E_CONTRACT with the first difference in the message (any other code:
 // that call failed). Replaces the loaded pool. shim/gpu_multi.go calls it from SetGPUDevices and stays on one device unless it passes.
-int evg_multi_selftest(evg_multi* m) {
+int evg_multi_selftest(evg_multi* m) try {
   using namespace evgm;
   if (!m) return EVG_E_INVALID;
   const int n_small = 3 * m->n + 2;
@@ -1199,17 +1208,17 @@ int evg_multi_selftest(evg_multi* m) {
         if (a.ub[(size_t)f * slots + a.uot[r]] != b.ub[(size_t)f * slots + b.uot[r]])
           return merr(m, EVG_E_CONTRACT, "evg_multi_selftest: the SortingValueBreakdown of row %d (field %d) differs between %d ranks and one device", r, f, m->n);
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // Per-phase HIP-event times of the last tick, the maximum over the ranks (ms): move-in | plan | allocate | gather. Enable first
 // (the events cost stream time at these step lengths, like bench.py's).
-int evg_multi_profile(evg_multi* m, int enable) {
+int evg_multi_profile(evg_multi* m, int enable) try {
   if (!m) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
   m->timed = enable != 0;
   return EVG_OK;
-}
-int evg_multi_last_tick_ms(evg_multi* m, float* ms4) {
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
+int evg_multi_last_tick_ms(evg_multi* m, float* ms4) try {
   if (!m || !ms4) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
   if (!m->timed) return evgm::merr(m, EVG_E_INVALID, "evg_multi_last_tick_ms: evg_multi_profile was not enabled");
@@ -1222,11 +1231,11 @@ int evg_multi_last_tick_ms(evg_multi* m, float* ms4) {
       ms4[q] = std::max(ms4[q], t);
     }
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // Downloads rank 0's full-size results into the caller's host buffers (NULL pointers / structs are skipped); `breakdown` by task
 // is not produced here (ask for EVG_MULTI_UNIT_ROWS: unit_of_task + unit_breakdown).
-int evg_multi_results(evg_multi* m, const evg_plan_output* out, const evg_alloc_output* aout) {
+int evg_multi_results(evg_multi* m, const evg_plan_output* out, const evg_alloc_output* aout) try {
   using namespace evgm;
   if (!m) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
@@ -1259,7 +1268,7 @@ int evg_multi_results(evg_multi* m, const evg_plan_output* out, const evg_alloc_
   }
   const int rcw = mwait(m, 0, "results");  // nothing of the caller's is touched after the return, error or not
   return rc ? rc : rcw;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // A tick's structural change for resident shards (EVG_MULTI_RESIDENT_SHARDS): `delta` is written against the WHOLE batch -- current
 // global row / edge numbers, global added_distro, the new global key tables -- exactly what evg_pool_apply_delta takes for one pool;
@@ -1268,7 +1277,7 @@ int evg_multi_results(evg_multi* m, const evg_plan_output* out, const evg_alloc_
 // brings the tick's allocator input for the whole batch: hosts change every tick, and their tg_key is in the distro's CURRENT key
 // numbering, so a delta that grows key ranges must bring them. All or nothing (round 6): every rank's re-pack is enqueued on its device
 // before any is waited for, every rank's verdict is read, and only a delta that every rank accepts becomes the pools.
-int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_alloc_input* alloc) {
+int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_alloc_input* alloc) try {
   using namespace evgm;
   if (!m || !dl) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
@@ -1422,11 +1431,11 @@ int evg_multi_apply_delta(evg_multi* m, const evg_pool_delta* dl, const evg_allo
     if (int rc = resident_hosts(m, alloc)) { m->loaded = false; return rc; }
   if (int rc = resident_layout(m)) { m->loaded = false; return rc; }
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 // Test hook: fills rank 0's output block with a byte pattern (a rank that wrote outside its slices, or a slice that never
 // arrived, shows in the gathered result).
-int evg_multi_poison_outputs(evg_multi* m, int32_t byte) {
+int evg_multi_poison_outputs(evg_multi* m, int32_t byte) try {
   if (!m) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(m->mu);
   if (!m->loaded) return EVG_E_INVALID;
@@ -1443,6 +1452,6 @@ int evg_multi_poison_outputs(evg_multi* m, int32_t byte) {
     if (int rcw = evgm::mwait(m, (int)(&r - m->r.data()), "poison")) return rcw;
   }
   return EVG_OK;
-}
+} catch (...) { return evgm::mcaught((evg_multi*)m); }
 
 }  // extern "C"

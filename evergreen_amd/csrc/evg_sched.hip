@@ -16,6 +16,8 @@
 #include <chrono>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -503,6 +505,21 @@ static int set_err(evg_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
+// No exception leaves the library through the C boundary (cgo or ctypes above it would end the process: the reference's jobs fail and are
+// retried, units/scheduler.go:18). Every int-returning entry point is a function-try-block whose handler calls this (a Lippincott
+// function: it re-throws inside to tell the kinds apart): host memory that ran out -> EVG_E_NOMEM, anything else -> EVG_E_HIP, the
+// message in evg_last_error. Locks and StreamDrain guards have unwound by then. (The batcher's entry points are not covered: a batch
+// leader that left its state machine half way would strand its members until their deadline; it allocates before it takes members.)
+static int caught(evg_ctx* c) noexcept {
+  try {
+    try { throw; }
+    catch (const std::bad_alloc&) { return set_err(c, EVG_E_NOMEM, "out of host memory"); }
+    catch (const std::length_error& e) { return set_err(c, EVG_E_NOMEM, "out of host memory (%s)", e.what()); }
+    catch (const std::exception& e) { return set_err(c, EVG_E_HIP, "internal failure: %s", e.what()); }
+    catch (...) { return set_err(c, EVG_E_HIP, "internal failure: unknown exception"); }
+  } catch (...) { return EVG_E_NOMEM; }  // (set_err's own std::string could not be assigned)
+}
+
 #define HIP_TRY(c, expr)                                                                        \
   do {                                                                                          \
     hipError_t e_ = (expr);                                                                     \
@@ -782,8 +799,13 @@ static void for_distros_parallel(const evg_plan_input* in, F f) {
   };
   if (nt == 1) { work(0); return; }
   std::vector<std::thread> th;
-  for (int w = 1; w < nt; w++) th.emplace_back(work, w);
+  th.reserve(nt);
+  int started = 1;
+  for (; started < nt; started++) {
+    try { th.emplace_back(work, started); } catch (...) { break; }  // no more threads to be had: the other ranges run here
+  }
   work(0);
+  for (int w = started; w < nt; w++) work(w);
   for (auto& x : th) x.join();
 }
 
@@ -792,13 +814,13 @@ extern "C" {
 int32_t evg_abi_version(void) { return (EVG_ABI_MAJOR << 16) | EVG_ABI_MINOR; }
 
 int evg_check_abi(int32_t major, int32_t minor, size_t sizeof_plan_input, size_t sizeof_plan_output, size_t sizeof_alloc_input,
-                  size_t sizeof_group_info) {
+                  size_t sizeof_group_info) try {
   if (major != EVG_ABI_MAJOR || minor > EVG_ABI_MINOR) return EVG_E_INVALID;
   if (sizeof_plan_input != sizeof(evg_plan_input) || sizeof_plan_output != sizeof(evg_plan_output) ||
       sizeof_alloc_input != sizeof(evg_alloc_input) || sizeof_group_info != sizeof(evg_group_info))
     return EVG_E_INVALID;
   return EVG_OK;
-}
+} catch (...) { return caught(nullptr); }
 
 // The sticky device-side status (a false EVG_PROMISE_ALL_ON_LDS_PATH seen by the planner kernel): every entry point checks it first.
 static int pending_status(evg_ctx* c) {
@@ -809,13 +831,13 @@ static int pending_status(evg_ctx* c) {
   return EVG_OK;
 }
 
-int evg_take_device_status(evg_ctx* c) {
+int evg_take_device_status(evg_ctx* c) try {
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   const int rc = pending_status(c);
   if (c->status_word) *(volatile uint32_t*)c->status_word = 0;
   return rc;
-}
+} catch (...) { return caught(c); }
 
 #ifdef EVG_PHASE_TIMING
 // diagnostics build only (scripts/phase_timing.py): device buffer of D x 16 s_memtime stamps
@@ -826,7 +848,7 @@ void evg_dbg_tiled_buffer(evg_ctx* c, void* dev_ptr) { c->dbg_tiled = (unsigned 
 
 const char* evg_last_error(const evg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
-evg_ctx* evg_create(int device_ordinal) {
+evg_ctx* evg_create(int device_ordinal) try {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -865,7 +887,7 @@ evg_ctx* evg_create(int device_ordinal) {
   *c->status_word = 0;
   evgreg::add(c->device, c->stream);
   return c;
-}
+} catch (...) { caught(nullptr); return nullptr; }
 
 void evg_destroy(evg_ctx* c) {
   if (!c) return;
@@ -906,15 +928,15 @@ void evg_destroy(evg_ctx* c) {
   delete c;
 }
 
-int evg_set_deadline_ms(evg_ctx* c, int64_t ms) {
+int evg_set_deadline_ms(evg_ctx* c, int64_t ms) try {
   if (!c || ms < 0) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   c->deadline_ms = ms;
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 int64_t evg_get_deadline_ms(const evg_ctx* c) { return c ? c->deadline_ms : -1; }
 
-int evg_debug_stall(evg_ctx* c, int32_t ms) {
+int evg_debug_stall(evg_ctx* c, int32_t ms) try {
   if (!c || ms < 0 || ms > 20000) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   if (c->timed_out) return refuse_timed_out(c);
@@ -922,9 +944,21 @@ int evg_debug_stall(evg_ctx* c, int32_t ms) {
   hipLaunchKernelGGL(evg::k_debug_stall, dim3(1), dim3(64), 0, c->stream, (long long)ms * 100000LL);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 
-int evg_selftest_unit_value(evg_ctx* c, uint64_t seed, uint64_t n_cases, uint64_t* mismatches, uint64_t* first_bad_case) {
+int evg_debug_throw(evg_ctx* c, int32_t kind) try {  // test hook: what an exception inside an entry point turns into (c may be NULL)
+  std::unique_lock<std::mutex> lk;
+  if (c) lk = std::unique_lock<std::mutex>(c->mu);  // (unwound before the handler runs: the next call on the context must not block)
+  switch (kind) {
+    case 0: throw std::bad_alloc();
+    case 1: throw std::runtime_error("thrown by evg_debug_throw");
+    case 2: throw 42;
+    case 3: { std::vector<int64_t> v; v.resize(v.max_size() + 1); return (int)v.size(); }
+    default: return EVG_OK;
+  }
+} catch (...) { return caught(c); }
+
+int evg_selftest_unit_value(evg_ctx* c, uint64_t seed, uint64_t n_cases, uint64_t* mismatches, uint64_t* first_bad_case) try {
   if (!c || !mismatches) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -939,9 +973,9 @@ int evg_selftest_unit_value(evg_ctx* c, uint64_t seed, uint64_t n_cases, uint64_
   *mismatches = h[0];
   if (first_bad_case) *first_bad_case = h[1];
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 
-int evg_profile_plan_kernel(evg_ctx* c, int enable) {
+int evg_profile_plan_kernel(evg_ctx* c, int enable) try {
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -951,9 +985,9 @@ int evg_profile_plan_kernel(evg_ctx* c, int enable) {
   }
   c->profile = enable != 0;
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 
-int evg_last_plan_kernel_ms(evg_ctx* c, float* ms) {
+int evg_last_plan_kernel_ms(evg_ctx* c, float* ms) try {
   if (!c || !ms) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   if (!c->ev_start) return set_err(c, EVG_E_INVALID, "evg_profile_plan_kernel was never enabled on this context");
@@ -961,7 +995,7 @@ int evg_last_plan_kernel_ms(evg_ctx* c, float* ms) {
   if (int rcw_ = wait_event(c, c->ev_stop, __func__)) return rcw_;
   HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 
 void* evg_host_alloc(evg_ctx* c, size_t bytes) {
   if (!c || bytes == 0) return nullptr;
@@ -1005,7 +1039,7 @@ static int distro_lds_tier(const evg_plan_input* in, int d) {
   return tier;
 }
 
-int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, int32_t* promises, int32_t* n_big_tier_distros) {
+int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, int32_t* promises, int32_t* n_big_tier_distros) try {
   if (!in || !max_distro_tasks || !promises || !n_big_tier_distros) return EVG_E_INVALID;
   *max_distro_tasks = 0;
   *promises = 0;
@@ -1034,7 +1068,7 @@ int evg_plan_launch_hints(const evg_plan_input* in, int32_t* max_distro_tasks, i
   if (std::min(nt, np) * 8 >= (long long)in->tasks.n_tasks && in->tasks.n_tasks > 0) *promises |= EVG_HINT_MIXED_POOL;
   if (nt == 0 && np > 0 && np == (long long)in->tasks.n_tasks) *promises |= EVG_HINT_NO_TIER_DISTROS;
   return EVG_OK;
-}
+} catch (...) { return caught(nullptr); }
 
 // Fills the kernel argument block of the planner (scratch of the generic path included).
 static int prepare_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, evg::PlanArgs* pa) {
@@ -1371,11 +1405,11 @@ static int launch_plan(evg_ctx* c, const evg_plan_input* in, const evg_plan_outp
   return finish_breakdown(c, a, out, st, d_end < 0 || (d_begin == 0 && d_end == in->n_distros));
 }
 
-int evg_plan_distros_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, void* hip_stream) {
+int evg_plan_distros_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, void* hip_stream) try {
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return launch_plan(c, in, out, (hipStream_t)hip_stream);
-}
+} catch (...) { return caught(c); }
 
 static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, hipStream_t st, int d_begin = 0, int d_end = -1) {
   using namespace evg;
@@ -1396,28 +1430,28 @@ static int launch_alloc(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_o
   return EVG_OK;
 }
 
-int evg_allocate_hosts_device(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, void* hip_stream) {
+int evg_allocate_hosts_device(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, void* hip_stream) try {
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return launch_alloc(c, in, out, (hipStream_t)hip_stream);
-}
+} catch (...) { return caught(c); }
 
 int evg_plan_distro_range_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, int32_t d_begin, int32_t d_end,
-                                 void* hip_stream) {
+                                 void* hip_stream) try {
   if (!c || d_end < 0) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return launch_plan(c, in, out, (hipStream_t)hip_stream, d_begin, d_end);
-}
+} catch (...) { return caught(c); }
 
 int evg_allocate_host_range_device(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out, int32_t d_begin, int32_t d_end,
-                                   void* hip_stream) {
+                                   void* hip_stream) try {
   if (!c || d_end < 0) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return launch_alloc(c, in, out, (hipStream_t)hip_stream, d_begin, d_end);
-}
+} catch (...) { return caught(c); }
 
 int evg_cap_queue_device(evg_ctx* c, int32_t n_distros, const int32_t* task_off, const int32_t* order,
-                         const int32_t* tg_name_key, int32_t max_scheduled, int32_t* cut, void* hip_stream) {
+                         const int32_t* tg_name_key, int32_t max_scheduled, int32_t* cut, void* hip_stream) try {
   if (!c || n_distros < 0) return EVG_E_INVALID;
   if (n_distros == 0) return EVG_OK;
   std::lock_guard<std::mutex> lk(c->mu);
@@ -1426,7 +1460,7 @@ int evg_cap_queue_device(evg_ctx* c, int32_t n_distros, const int32_t* task_off,
                      task_off, order, tg_name_key, max_scheduled, cut);
   HIP_TRY(c, hipGetLastError());
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 
 static int do_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* plan, const int32_t* tg_name_key,
                                  int32_t max_scheduled, const evg_queue_items* items, void* hip_stream) {
@@ -1518,33 +1552,33 @@ static int do_allocator_report_device(evg_ctx* c, int32_t n_distros, const int32
 // ---- the device-pointer entry points of the SURVEY 8f rows: lock, then the bodies above ----------------------
 
 int evg_materialize_queue_device(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* plan, const int32_t* tg_name_key,
-                                 int32_t max_scheduled, const evg_queue_items* items, void* hip_stream) {
+                                 int32_t max_scheduled, const evg_queue_items* items, void* hip_stream) try {
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return do_materialize_queue_device(c, in, plan, tg_name_key, max_scheduled, items, hip_stream);
-}
+} catch (...) { return caught(c); }
 
 int evg_filter_runnable_device(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
-                               int32_t* runnable_row, int32_t* runnable_count, void* hip_stream) {
+                               int32_t* runnable_row, int32_t* runnable_count, void* hip_stream) try {
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return do_filter_runnable_device(c, in, dispatchable, deps_met, keep, runnable_row, runnable_count, hip_stream);
-}
+} catch (...) { return caught(c); }
 
 int evg_dispatch_order_device(evg_ctx* c, const evg_plan_input* in, const int32_t* item_off, const int32_t* item_row,
-                              const evg_dispatch_order* out, void* hip_stream) {
+                              const evg_dispatch_order* out, void* hip_stream) try {
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return do_dispatch_order_device(c, in, item_off, item_row, out, hip_stream);
-}
+} catch (...) { return caught(c); }
 
 int evg_allocator_report_device(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
                                 const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
-                                const evg_report_params* params, evg_alloc_report* report, void* hip_stream) {
+                                const evg_report_params* params, evg_alloc_report* report, void* hip_stream) try {
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return do_allocator_report_device(c, n_distros, tg_off, distro_info, group_info, hosts_spawned, free_hosts, params, report, hip_stream);
-}
+} catch (...) { return caught(c); }
 
 // ---- host-pointer entry points: stage in, run, stage out, synchronously ---------------------------------
 
@@ -1669,14 +1703,14 @@ static int schedule_host(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
   return s.finish();
 }
 
-int evg_plan_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out) {
+int evg_plan_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out) try {
   if (!c || !in || !out) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   return schedule_host(c, in, out, nullptr, 0, nullptr, nullptr);
-}
+} catch (...) { return caught(c); }
 
 int evg_schedule_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_output* out, const int32_t* tg_name_key,
-                         int32_t max_scheduled, const evg_queue_items* items, const evg_dispatch_order* dispatch) {
+                         int32_t max_scheduled, const evg_queue_items* items, const evg_dispatch_order* dispatch) try {
   if (!c || !in || !out) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   if (items && (!items->cut || !items->item_off || (in->tasks.n_tasks > 0 && (!items->row || !items->expected_duration_ns ||
@@ -1686,10 +1720,10 @@ int evg_schedule_distros(evg_ctx* c, const evg_plan_input* in, const evg_plan_ou
                    (in->tasks.n_tasks > 0 && (!dispatch->sorted || !dispatch->group_items))))
     return set_err(c, EVG_E_INVALID, "null dispatch-order output");
   return schedule_host(c, in, out, tg_name_key, max_scheduled, items, dispatch);
-}
+} catch (...) { return caught(c); }
 
 int evg_rebuild_dispatchers(evg_ctx* c, int32_t n_distros, const int32_t* item_off, const int32_t* dep_off, const int32_t* dep_idx,
-                       const int32_t* group_key, const int32_t* tg_off, const int32_t* group_index, const evg_dispatch_order* out) {
+                       const int32_t* group_key, const int32_t* tg_off, const int32_t* group_index, const evg_dispatch_order* out) try {
   if (!c || !out || n_distros < 0) return EVG_E_INVALID;
   if (n_distros == 0) return EVG_OK;
   std::lock_guard<std::mutex> lk(c->mu);
@@ -1733,9 +1767,9 @@ int evg_rebuild_dispatchers(evg_ctx* c, int32_t n_distros, const int32_t* item_o
   if (s.rc) return s.rc;
   if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 
-int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
+int evg_pool_load(evg_ctx* c, const evg_plan_input* in) try {
   if (!c || !in) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1792,7 +1826,7 @@ int evg_pool_load(evg_ctx* c, const evg_plan_input* in) {
   c->pool_in = di;
   c->pool_loaded = true;
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 
 // ---- evg_pool_update, in pieces (evg_pool_tick enqueues them between a delta and a plan) -----------------------------------------
 // The host's share of the contract: ranges against (n_tasks, n_edges_bound), distinct rows / edges. *wide: a priority beyond int32.
@@ -1875,7 +1909,7 @@ static int update_enqueue(evg_ctx* c, const evg_task_soa& t, const UpdateFlight&
   return EVG_OK;
 }
 
-int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update* eu) {
+int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update* eu) try {
   if (!c) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1900,9 +1934,9 @@ int evg_pool_update(evg_ctx* c, const evg_row_update* ru, const evg_edge_update*
   if (s.flush_in()) return s.rc;
   if (int rc = update_enqueue(c, p.tasks, u, c->stream)) return rc;
   return wait_stream(c, c->stream, __func__);
-}
+} catch (...) { return caught(c); }
 
-int evg_pool_plan(evg_ctx* c, int64_t now_ns, const evg_plan_output* out) {
+int evg_pool_plan(evg_ctx* c, int64_t now_ns, const evg_plan_output* out) try {
   if (!c || !out) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1951,7 +1985,7 @@ int evg_pool_plan(evg_ctx* c, int64_t now_ns, const evg_plan_output* out) {
   s.down(out->unit_of_task, dout.unit_of_task, N);
   s.down(out->unit_breakdown, dout.unit_breakdown, Stot * EVG_BREAKDOWN_FIELDS);
   return s.finish();
-}
+} catch (...) { return caught(c); }
 
 // The launch hints of a resident pool from its shape (evg_plan_launch_hints's test without the columns): task_off / tg_off / ver_off are
 // HOST tables, ne[d] = the distro's dependency edges or an upper bound of them (the tiers' shape test only grows with it: hints and
@@ -2347,7 +2381,7 @@ static void pool_delta_end(PoolDeltaTxn& t, bool commit) {
   t.lk.unlock();
 }
 
-int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
+int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) try {
   if (!c || !dl) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2367,7 +2401,7 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
   if (int rc = delta_enqueue(c, dl, f, c->stream)) return rc;
   if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   return delta_commit(c, dl, f);
-}
+} catch (...) { return caught(c); }
 
 // The fused resident tick (ABI 3.3): structural delta + value updates + plan + download behind ONE synchronisation -- what
 // evg_pool_apply_delta, evg_pool_update and evg_pool_plan do in three calls with a wait each (and evg_pool_update with two, until
@@ -2375,7 +2409,7 @@ int evg_pool_apply_delta(evg_ctx* c, const evg_pool_delta* dl) {
 // updates and the plan run on THAT set with launch hints the host can vouch for without the device's answer (every distro's new size,
 // an upper bound of its edges); the status block and the outputs come back together. A refused delta (or update) leaves the pool as
 // it was -- the second set is simply not swapped in -- and the outputs undefined.
-int evg_pool_tick(evg_ctx* c, const evg_pool_delta* dl, const evg_row_update* ru, const evg_edge_update* eu, int64_t now_ns, const evg_plan_output* out) {
+int evg_pool_tick(evg_ctx* c, const evg_pool_delta* dl, const evg_row_update* ru, const evg_edge_update* eu, int64_t now_ns, const evg_plan_output* out) try {
   if (!c || !out) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2484,10 +2518,10 @@ int evg_pool_tick(evg_ctx* c, const evg_pool_delta* dl, const evg_row_update* ru
     c->pool_pri_wide = true;
   }
   return pending_status(c);
-}
+} catch (...) { return caught(c); }
 
 int evg_filter_runnable(evg_ctx* c, const evg_plan_input* in, const uint8_t* dispatchable, uint8_t* deps_met, uint8_t* keep,
-                        int32_t* runnable_row, int32_t* runnable_count) {
+                        int32_t* runnable_row, int32_t* runnable_count) try {
   if (!c || !in) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2518,11 +2552,11 @@ int evg_filter_runnable(evg_ctx* c, const evg_plan_input* in, const uint8_t* dis
   if (s.rc) return s.rc;
   if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 
 int evg_allocator_report(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, const evg_distro_info* distro_info,
                          const evg_group_info* group_info, const int32_t* hosts_spawned, const int32_t* free_hosts,
-                         const evg_report_params* params, evg_alloc_report* report) {
+                         const evg_report_params* params, evg_alloc_report* report) try {
   if (!c || n_distros < 0) return EVG_E_INVALID;
   if (n_distros == 0) return EVG_OK;
   std::lock_guard<std::mutex> lk(c->mu);
@@ -2546,9 +2580,9 @@ int evg_allocator_report(evg_ctx* c, int32_t n_distros, const int32_t* tg_off, c
   if (s.rc) return s.rc;
   if (int rcw_ = wait_stream(c, c->stream, __func__)) return rcw_;
   return EVG_OK;
-}
+} catch (...) { return caught(c); }
 
-int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out) {
+int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_output* out) try {
   if (!c || !in || !out) return EVG_E_INVALID;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2589,7 +2623,7 @@ int evg_allocate_hosts(evg_ctx* c, const evg_alloc_input* in, const evg_alloc_ou
     s.down(in->group_info, (const evg_group_info*)di.group_info, G);
   }
   return s.finish();
-}
+} catch (...) { return caught(c); }
 
 }  // extern "C"
 

@@ -41,7 +41,7 @@ static int validate_distro(const evg_plan_input* in, int d, char* err, size_t er
   return EVG_OK;
 }
 
-extern "C" int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len) {
+extern "C" int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len) try {
   auto fail = [&](const char* fmt, long a, long b) {
     if (msg && msg_len > 0) snprintf(msg, msg_len, fmt, a, b);
     return EVG_E_CONTRACT;
@@ -63,25 +63,33 @@ extern "C" int evg_validate_plan_input(const evg_plan_input* in, char* msg, int3
   // The per-row checks are independent per distro: a large batch is checked by a few threads (this runs inside every
   // host-pointer call; one thread needs ~1.5 ms for 1M rows + 1.3M edges). The FIRST failing distro's message is reported.
   const int nt = t.n_tasks + t.n_edges < (1 << 18) ? 1 : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  struct Text { char s[256]; };
   std::vector<int> first_bad(nt, D);
-  std::vector<std::string> errs(nt);
-  auto work = [&](int w) {
-    char buf[256];
+  std::vector<Text> errs(nt);
+  auto work = [&](int w) noexcept {  // (nothing in here allocates: an exception on a worker thread would end the process)
     for (int d = (int)((long long)D * w / nt), d1 = (int)((long long)D * (w + 1) / nt); d < d1; d++)
-      if (validate_distro(in, d, buf, sizeof buf) != EVG_OK) { first_bad[w] = d; errs[w] = buf; return; }
+      if (validate_distro(in, d, errs[w].s, sizeof errs[w].s) != EVG_OK) { first_bad[w] = d; return; }
   };
   if (nt == 1) work(0);
   else {
     std::vector<std::thread> th;
-    for (int w = 1; w < nt; w++) th.emplace_back(work, w);
+    th.reserve(nt);
+    int started = 1;
+    for (; started < nt; started++) {
+      try { th.emplace_back(work, started); } catch (...) { break; }  // no more threads to be had: the other ranges are checked here
+    }
     work(0);
+    for (int w = started; w < nt; w++) work(w);
     for (auto& x : th) x.join();
   }
   for (int w = 0; w < nt; w++)
     if (first_bad[w] < D) {
-      if (msg && msg_len > 0) snprintf(msg, msg_len, "%s", errs[w].c_str());
+      if (msg && msg_len > 0) snprintf(msg, msg_len, "%s", errs[w].s);
       return EVG_E_CONTRACT;
     }
   return EVG_OK;
+} catch (...) {  // the checker threads or their tables could not be had: nothing leaves through the C boundary
+  if (msg && msg_len > 0) snprintf(msg, msg_len, "out of host resources while checking the batch");
+  return EVG_E_NOMEM;
 }
 

@@ -30,7 +30,7 @@ EXPORTS = [
     "evg_multi_inject_failure", "evg_multi_abort", "evg_multi_selftest", "evg_multi_apply_delta",
     "evg_batcher_create", "evg_batcher_destroy", "evg_batcher_plan", "evg_batcher_allocate", "evg_batcher_get_stats",
     # ABI 3.3
-    "evg_set_deadline_ms", "evg_get_deadline_ms", "evg_debug_stall", "evg_multi_set_deadline_ms", "evg_multi_debug_stall",
+    "evg_set_deadline_ms", "evg_get_deadline_ms", "evg_debug_stall", "evg_debug_throw", "evg_multi_set_deadline_ms", "evg_multi_debug_stall",
     "evg_batcher_schedule", "evg_batcher_plan_queue", "evg_batcher_set_deadline_ms", "evg_batcher_close", "evg_batcher_get_cache_stats",
     "evg_batcher_debug_stall", "evg_pool_tick",
 ]
@@ -171,6 +171,8 @@ def load_library() -> C.CDLL:
         lib.evg_get_deadline_ms.restype = C.c_int64
         lib.evg_get_deadline_ms.argtypes = [C.c_void_p]
         lib.evg_debug_stall.argtypes = [C.c_void_p, C.c_int32]
+        if hasattr(lib, "evg_debug_throw"):
+            lib.evg_debug_throw.argtypes = [C.c_void_p, C.c_int32]
         lib.evg_multi_set_deadline_ms.argtypes = [C.c_void_p, C.c_int64]
         lib.evg_multi_debug_stall.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     if hasattr(lib, "evg_selftest_unit_value"):  # absent from older builds loaded through EVG_SCHED_LIB (A/B runs)

@@ -415,6 +415,17 @@ int64_t evg_get_deadline_ms(const evg_ctx* ctx);
  * clock (at most 20,000) -- the next synchronous call on the context finds the device busy for that long. */
 int evg_debug_stall(evg_ctx* ctx, int32_t ms);
 
+/* No exception leaves the library through this boundary (late round 6): a C++ exception unwinding into cgo or ctypes ends the process,
+ * where the reference's jobs fail and are retried (units/scheduler.go:18, units/host_allocator.go:32). Every int-returning entry point
+ * of the single-context and multi-device families catches what its body throws: host memory that ran out (std::bad_alloc,
+ * std::length_error) is EVG_E_NOMEM, anything else EVG_E_HIP, the text in evg_last_error / evg_multi_last_error; evg_create and
+ * evg_multi_create return NULL. Locks and stream guards have unwound by then: the context takes the next call. Threads the library
+ * starts for host-side checks run code that cannot throw, and a thread that cannot be had costs parallelism, not the call.
+ * (The evg_batcher_* entry points are not covered: see evg_sched.hip, caught().)
+ * evg_debug_throw is the test hook: throws inside such an entry point while holding the context's mutex -- kind 0 std::bad_alloc,
+ * 1 std::runtime_error, 2 a non-std object, 3 a vector grown past max_size; `ctx` may be NULL (no GPU is touched). */
+int evg_debug_throw(evg_ctx* ctx, int32_t kind);
+
 /* Host-side check of the layout contract; no GPU work. */
 int evg_validate_plan_input(const evg_plan_input* in, char* msg, int32_t msg_len);
 

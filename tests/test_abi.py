@@ -197,3 +197,29 @@ def test_library_cuts_the_same_ranges_as_the_python_driver():
     for off in tables:
         for world in (1, 2, 3, 4, 8, 13):
             assert native.balanced_ranges(off.astype(np.int32), world) == multi.balanced_ranges(off, world), (off[:8], world)
+
+
+def test_no_exception_leaves_through_the_c_boundary(lib):
+    """A C++ exception unwinding into cgo / ctypes ends the process; the reference's jobs fail and are retried (units/scheduler.go:18).
+    evg_debug_throw throws inside a guarded entry point (no GPU is touched with a NULL context): each kind comes back as a code with its
+    text in evg_last_error -- host memory that ran out is EVG_E_NOMEM, anything else EVG_E_HIP."""
+    want = {0: (abi.EVG_E_NOMEM, b"out of host memory"), 1: (abi.EVG_E_HIP, b"thrown by evg_debug_throw"),
+            2: (abi.EVG_E_HIP, b"unknown exception"), 3: (abi.EVG_E_NOMEM, b"out of host memory")}
+    for kind, (rc, text) in want.items():
+        assert lib.evg_debug_throw(None, kind) == rc, kind
+        assert text in lib.evg_last_error(None), (kind, lib.evg_last_error(None))
+    assert lib.evg_debug_throw(None, 99) == abi.EVG_OK
+
+
+@pytest.mark.gpu
+def test_a_context_takes_the_next_call_after_an_exception(native_ctx, oracle):
+    """The same on a live context: the throw happens under the context's mutex, which has unwound when the code comes back -- the next
+    call neither blocks nor sees a stale error."""
+    from tests import compare
+    lib = native_ctx.lib
+    batch = gen.generate(gen.GenConfig(n_tasks=3000, n_distros=6, seed=77))
+    want = oracle.plan(batch, breakdown=True, n_units=False)
+    for kind, rc in ((0, abi.EVG_E_NOMEM), (1, abi.EVG_E_HIP), (2, abi.EVG_E_HIP), (3, abi.EVG_E_NOMEM)):
+        assert lib.evg_debug_throw(native_ctx.h, kind) == rc
+        assert lib.evg_last_error(native_ctx.h)
+        compare.assert_plan_equal(native_ctx.plan(batch, breakdown=True), want, batch, "after a thrown kind %d" % kind)
