@@ -49,6 +49,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -593,7 +595,17 @@ static void lead(Batcher<BE>* b, Slot<BE>& s) {
     s.cv_lead.wait(lk, [&] { return s.packed.load() >= members; });
     t_packed = clk::now();
   }
-  int rc = run_batch(b, s);
+  int rc;
+  try { rc = run_batch(b, s); }  // (the backend's own guard has drained the stream by the time an exception arrives here)
+  catch (...) {
+    rc = EVG_E_NOMEM;
+    try {
+      try { throw; }
+      catch (const std::bad_alloc&) { s.err = "out of host memory while the batch was run"; }
+      catch (const std::exception& e) { rc = EVG_E_HIP; s.err = std::string("internal failure while the batch was run: ") + e.what(); }
+      catch (...) { rc = EVG_E_HIP; s.err = "internal failure while the batch was run"; }
+    } catch (...) { s.err.clear(); }
+  }
   if (timing)
     fprintf(stderr, "[batch] kind %d members %3d rows %7d: opened->leader %6.0f  window %6.0f  packing %6.0f  device %6.0f us\n", s.kind, members, (int)s.N,
             us(s.opened, t_lead), us(t_lead, t_closed), us(t_closed, t_packed), us(t_packed, clk::now()));
@@ -696,6 +708,10 @@ static B* batcher_create(int device_ordinal, int32_t max_wait_us, int32_t max_re
     s.dev = ok ? BE::dev_create(device_ordinal) : nullptr;
     ok = ok && s.dev;
     if (s.dev) BE::dev_set_deadline(s.dev, b->deadline_ms);
+    // nothing between a request's join and its batch's results may throw (a leader that unwound out of the state machine would strand
+    // its members until their deadline): a slot's member list never grows past max_requests, its parked blocks are a handful
+    s.members.reserve((size_t)b->max_requests);
+    s.parked.reserve(16);
   }
   if (ok) BE::dev_set_deadline(b->direct, b->deadline_ms);
   return ok ? b : (batcher_destroy<B, BE>(b), nullptr);
@@ -863,7 +879,8 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
     b->inside_kind[kind]++;
     in_call.batching(kind);
     int why = 0;
-    sp = join_slot(b, lk, kind, bytes, &leader, &why);
+    try { sp = join_slot(b, lk, kind, bytes, &leader, &why); }
+    catch (...) { sp = nullptr; why = 3; }  // (growing a slot's blocks: out of host memory -- the request has not joined anything)
     if (!sp) {
       if (hit) hit->pins--;
       return why == 1 ? fail(err, err_len, EVG_E_INVALID, "the batcher is being destroyed")
@@ -879,7 +896,8 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
     s.want |= m.want; s.any_fin |= m.has_fin;
     if (hit) { m.hit = hit; hit->last_use = ++b->use_clock; b->n_hits++; }
     else if (plan && queue_id) {
-      m.fill = cache_reserve(b, queue_id, generation, m.cols_bytes);
+      try { m.fill = cache_reserve(b, queue_id, generation, m.cols_bytes); }
+      catch (...) { m.fill = nullptr; b->cache_failed = true; }  // the cache's own tables could not grow: no cache from here on, the request travels whole
       if (m.fill) {
         CacheEntry* en = m.fill;
         en->pins++; en->last_use = ++b->use_clock;
@@ -981,6 +999,17 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
   return rc;
 }
 
+// What the C entry points call: nothing leaves through the boundary. By the time a request has joined a batch nothing in its path
+// throws (see batcher_create, lead); this is for the part in front of the join.
+template <class BE>
+static int batcher_request_nothrow(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t generation, const evg_plan_input* pin, const evg_plan_output* pout,
+                                   const evg_alloc_input* ain, const evg_alloc_output* aout, char* err, int32_t err_len) {
+  try { return batcher_request<BE>(b, kind, queue_id, generation, pin, pout, ain, aout, err, err_len); }
+  catch (const std::bad_alloc&) { return fail(err, err_len, EVG_E_NOMEM, "out of host memory"); }
+  catch (const std::exception& e) { return fail(err, err_len, EVG_E_HIP, "internal failure: %s", e.what()); }
+  catch (...) { return fail(err, err_len, EVG_E_HIP, "internal failure: unknown exception"); }
+}
+
 }  // namespace evgb
 
 // The C entry points over a backend, for the translation unit that names it (the HIP library; the CPU build of the race tests).
@@ -1023,17 +1052,17 @@ static int batcher_request(Batcher<BE>* b, int kind, uint64_t queue_id, uint64_t
     return EVG_OK;                                                                                                                              \
   }                                                                                                                                             \
   int evg_batcher_plan(evg_batcher* b, const evg_plan_input* in, const evg_plan_output* out, char* err, int32_t err_len) {                      \
-    return evgb::batcher_request<BE>(b, evgb::K_PLAN, 0, 0, in, out, nullptr, nullptr, err, err_len);                                           \
+    return evgb::batcher_request_nothrow<BE>(b, evgb::K_PLAN, 0, 0, in, out, nullptr, nullptr, err, err_len);                                           \
   }                                                                                                                                             \
   int evg_batcher_plan_queue(evg_batcher* b, uint64_t queue_id, uint64_t generation, const evg_plan_input* in, const evg_plan_output* out,      \
                              char* err, int32_t err_len) {                                                                                      \
-    return evgb::batcher_request<BE>(b, evgb::K_PLAN, queue_id, generation, in, out, nullptr, nullptr, err, err_len);                           \
+    return evgb::batcher_request_nothrow<BE>(b, evgb::K_PLAN, queue_id, generation, in, out, nullptr, nullptr, err, err_len);                           \
   }                                                                                                                                             \
   int evg_batcher_allocate(evg_batcher* b, const evg_alloc_input* in, const evg_alloc_output* out, char* err, int32_t err_len) {                \
-    return evgb::batcher_request<BE>(b, evgb::K_ALLOC, 0, 0, nullptr, nullptr, in, out, err, err_len);                                          \
+    return evgb::batcher_request_nothrow<BE>(b, evgb::K_ALLOC, 0, 0, nullptr, nullptr, in, out, err, err_len);                                          \
   }                                                                                                                                             \
   int evg_batcher_schedule(evg_batcher* b, uint64_t queue_id, uint64_t generation, const evg_plan_input* in, const evg_plan_output* out,        \
                            const evg_alloc_input* alloc_in, const evg_alloc_output* alloc_out, char* err, int32_t err_len) {                    \
-    return evgb::batcher_request<BE>(b, evgb::K_PAIR, queue_id, generation, in, out, alloc_in, alloc_out, err, err_len);                        \
+    return evgb::batcher_request_nothrow<BE>(b, evgb::K_PAIR, queue_id, generation, in, out, alloc_in, alloc_out, err, err_len);                        \
   }                                                                                                                                             \
   }

@@ -508,8 +508,9 @@ static int set_err(evg_ctx* c, int code, const char* fmt, ...) {
 // No exception leaves the library through the C boundary (cgo or ctypes above it would end the process: the reference's jobs fail and are
 // retried, units/scheduler.go:18). Every int-returning entry point is a function-try-block whose handler calls this (a Lippincott
 // function: it re-throws inside to tell the kinds apart): host memory that ran out -> EVG_E_NOMEM, anything else -> EVG_E_HIP, the
-// message in evg_last_error. Locks and StreamDrain guards have unwound by then. (The batcher's entry points are not covered: a batch
-// leader that left its state machine half way would strand its members until their deadline; it allocates before it takes members.)
+// message in evg_last_error. Locks and StreamDrain guards have unwound by then. (The batcher has its own arrangement: a batch leader
+// that left its state machine half way would strand its members until their deadline -- evg_batcher_core.hpp, lead() and
+// batcher_request_nothrow().)
 static int caught(evg_ctx* c) noexcept {
   try {
     try { throw; }

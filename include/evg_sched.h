@@ -421,7 +421,9 @@ int evg_debug_stall(evg_ctx* ctx, int32_t ms);
  * std::length_error) is EVG_E_NOMEM, anything else EVG_E_HIP, the text in evg_last_error / evg_multi_last_error; evg_create and
  * evg_multi_create return NULL. Locks and stream guards have unwound by then: the context takes the next call. Threads the library
  * starts for host-side checks run code that cannot throw, and a thread that cannot be had costs parallelism, not the call.
- * (The evg_batcher_* entry points are not covered: see evg_sched.hip, caught().)
+ * The evg_batcher_* request entry points: nothing throws between a request's join and its batch's results (a slot's member list is
+ * reserved up front; an exception inside the leader's run of the batch becomes the batch's code, every member gets it, the slot goes
+ * on), and what is in front of the join is caught at the entry point (the code + text in `err`).
  * evg_debug_throw is the test hook: throws inside such an entry point while holding the context's mutex -- kind 0 std::bad_alloc,
  * 1 std::runtime_error, 2 a non-std object, 3 a vector grown past max_size; `ctx` may be NULL (no GPU is touched). */
 int evg_debug_throw(evg_ctx* ctx, int32_t kind);

@@ -15,6 +15,7 @@
 #include <cinttypes>
 #include <cstdio>
 #include <random>
+#include <stdexcept>
 #include <thread>
 
 #include "../../evergreen_amd/csrc/evg_batcher_core.hpp"
@@ -28,6 +29,7 @@ int evg_oracle_allocate_host_range(const evg_alloc_input* in, const evg_alloc_ou
 
 static std::atomic<int> g_fail_next{0};     // the next N batches fail on the "device" (EVG_E_HIP)
 static std::atomic<int> g_timeout_next{0};  // the next N batches outlive the deadline (EVG_E_TIMEOUT)
+static std::atomic<int> g_throw_next{0};    // the next N batches meet std::bad_alloc / a std::runtime_error on their leader's thread, in turn
 static std::atomic<bool> g_close_returned{false};  // scenario 3: evg_batcher_close has returned -- no request that STARTS now may be served
 
 struct CpuBackend {
@@ -67,6 +69,9 @@ struct CpuBackend {
     f = g_fail_next.load();
     while (f > 0 && !g_fail_next.compare_exchange_weak(f, f - 1)) {}
     if (f > 0) { d->err = "injected device failure"; return EVG_E_HIP; }
+    f = g_throw_next.load();
+    while (f > 0 && !g_throw_next.compare_exchange_weak(f, f - 1)) {}
+    if (f > 0) { if (f & 1) throw std::bad_alloc(); throw std::runtime_error("injected exception"); }  // (the lock_guard unwinds, as the HIP backend's drain does)
     memcpy(L.A, L.h_in, L.up_bytes);
     if (L.zero_bytes) memset(L.A + L.zero_off, 0, L.zero_bytes);
     const evgb::Seg* segs = (const evgb::Seg*)(L.A + L.seg_off);
@@ -287,7 +292,7 @@ static void caller(evg_batcher* b, int id, int rounds, uint64_t seed, std::atomi
       rc = qid ? evg_batcher_plan_queue(b, qid, gen[(size_t)qi], &in, &out, err, sizeof err) : evg_batcher_plan(b, &in, &out, err, sizeof err);
     }
     if (rc == EVG_E_INVALID && strstr(err, "destroyed")) { EXPECT(closing->load(), "caller %d refused although nobody closes the batcher", id); return; }
-    if (rc != EVG_OK && tolerate_device_errors && (rc == EVG_E_HIP || rc == EVG_E_TIMEOUT)) continue;  // injected: every member of that batch got it
+    if (rc != EVG_OK && tolerate_device_errors && (rc == EVG_E_HIP || rc == EVG_E_TIMEOUT || rc == EVG_E_NOMEM)) continue;  // injected: every member of that batch got it
     EXPECT(rc == EVG_OK, "caller %d round %d: request failed (%d) %s", id, r, rc, err);
     if (rc != EVG_OK) continue;
     EXPECT(!started_after_close, "caller %d: a request that started after evg_batcher_close had returned was served", id);
@@ -306,7 +311,7 @@ static void caller(evg_batcher* b, int id, int rounds, uint64_t seed, std::atomi
       evg_alloc_output aout = g2.aout();
       rc = evg_batcher_allocate(b, &ain, &aout, err, sizeof err);
       if (rc == EVG_E_INVALID && strstr(err, "destroyed")) return;
-      if (rc != EVG_OK && tolerate_device_errors && (rc == EVG_E_HIP || rc == EVG_E_TIMEOUT)) continue;
+      if (rc != EVG_OK && tolerate_device_errors && (rc == EVG_E_HIP || rc == EVG_E_TIMEOUT || rc == EVG_E_NOMEM)) continue;
       EXPECT(rc == EVG_OK, "caller %d: allocate failed (%d) %s", id, rc, err);
       evg_alloc_input win = q.alloc_in(want.di.data(), want.gi.data());
       evg_alloc_output waout = want.aout();
@@ -349,11 +354,13 @@ int main(int argc, char** argv) {
     evg_batcher* b = b2;
     EXPECT(evg_batcher_set_deadline_ms(b, 50) == EVG_OK, "set_deadline");
     g_fail_next = 5; g_timeout_next = 2;  // two of the four slots are retired
+    g_throw_next = 4;                     // ... and four leaders meet an exception inside run_batch: their members get a code, the slot goes on
     served = 0;
     std::vector<std::thread> th;
     for (int i = 0; i < std::min(T, 24); i++) th.emplace_back(caller, b, 100 + i, rounds / 2 + 4, seed + 1, &closing, &served, true);
     for (auto& t : th) t.join();
-    EXPECT(g_fail_next.load() == 0 && g_timeout_next.load() == 0 && served.load() > 0, "the injected failures were consumed, the rest was served (%ld)", served.load());
+    EXPECT(g_fail_next.load() == 0 && g_timeout_next.load() == 0 && g_throw_next.load() == 0 && served.load() > 0,
+           "the injected failures and exceptions were consumed, the rest was served (%ld)", served.load());
     g_timeout_next = 2;  // the last two slots go: then every request is refused with EVG_E_TIMEOUT
     std::mt19937_64 g(seed + 99);
     char err[256];
