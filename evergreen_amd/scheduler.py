@@ -859,3 +859,109 @@ class ResidentPlanner:
         self.last = {"mode": "tick", "removed": int(len(removed_rows)), "added": na, "relinked": len(rl_edges), "rows_updated": int(len(rows)),
                      "edges_updated": int(len(edges)), "tasks": NN}
         return _plans_from_result(target, res, now_ns, opts)
+
+
+# ---- the resident planner with one process per GPU --------------------------------------------------------------------------
+# The path shards by distro with nothing to exchange: no term of scoring, sorting, queue info or allocation crosses a distro, and the
+# reference itself runs one job per distro (units/crons.go:303-332), each reading its own distro's tasks and persisting its own queue.
+# ShardedResidentPlanner is that with one rank per device: every rank OWNS some distros, keeps their queues resident on its device
+# (ResidentPlanner) and plans them from the task lists it is handed -- no data-path collective. Ownership is worked out by every rank
+# from the same (distro id, task count) table, so nothing travels for it either; it is sticky (a distro stays where its queue is resident)
+# and only re-dealt -- greedy longest-processing-time on the task counts, SURVEY 8e's partitioning -- when the heaviest rank carries more
+# than `rebalance_over` times the mean. gather() is for a caller that wants every plan in one place (task ids + DistroQueueInfo per
+# distro through torch.distributed's gather_object): the reference's jobs have no such step.
+
+def lpt_owners(ids: Sequence[str], counts: Sequence[int], world: int) -> Dict[str, int]:
+    """Greedy longest-processing-time: distros by task count (ties by id), each to the rank that carries least so far (ties by rank)."""
+    load = [0] * world
+    owner: Dict[str, int] = {}
+    for i in sorted(range(len(ids)), key=lambda i: (-int(counts[i]), ids[i])):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[ids[i]] = r
+        load[r] += int(counts[i]) + 1   # (+1: an empty distro still costs a workgroup)
+    return owner
+
+
+class ShardedResidentPlanner:
+    def __init__(self, backend, rank: int = 0, world: int = 1, group=None, rebalance_over: float = 1.5):
+        if not (0 <= rank < world):
+            raise ValueError("rank %d of a world of %d" % (rank, world))
+        self.planner = ResidentPlanner(backend)
+        self.rank, self.world, self.group, self.rebalance_over = rank, world, group, float(rebalance_over)
+        self.owner: Dict[str, int] = {}
+        self.mine: List[int] = []          # indices into the last call's `queues`
+        self.deals = 0                     # how often the distros were dealt out (1 = never re-dealt)
+
+    def assign(self, ids: Sequence[str], counts: Sequence[int]) -> List[int]:
+        """Updates the ownership table from this tick's (distro id, task count) rows -- the same on every rank -- and returns the indices
+        this rank owns. A distro that is new goes to the rank that carries least; distros that left are forgotten."""
+        if len(set(ids)) != len(ids):
+            raise ValueError("duplicate distro ids")
+        known = set(ids)
+        self.owner = {k: r for k, r in self.owner.items() if k in known}
+        load = [0] * self.world
+        for i, k in enumerate(ids):
+            if k in self.owner:
+                load[self.owner[k]] += int(counts[i]) + 1
+        for i in sorted((i for i, k in enumerate(ids) if k not in self.owner), key=lambda i: (-int(counts[i]), ids[i])):
+            r = min(range(self.world), key=lambda r: (load[r], r))
+            self.owner[ids[i]] = r
+            load[r] += int(counts[i]) + 1
+        total = sum(load)
+        if self.deals == 0 or (total and max(load) * self.world > self.rebalance_over * total and
+                               max(lpt_load(ids, counts, self.world)) < max(load)):
+            self.owner = lpt_owners(ids, counts, self.world)
+            self.deals += 1
+        self.mine = [i for i, k in enumerate(ids) if self.owner[k] == self.rank]
+        return self.mine
+
+    def plan(self, queues: Sequence[Tuple[Distro, Optional[Sequence[Task]]]], now_ns: int, opts: Optional[Sequence[TaskPlannerOptions]] = None,
+             dep_lookup: Optional[DepLookup] = None, includes_dependencies: Optional[Sequence[bool]] = None,
+             counts: Optional[Sequence[int]] = None) -> Dict[int, Tuple[List[Task], DistroQueueInfo]]:
+        """PlanDistros' arguments on every rank; {index into `queues`: (plan, DistroQueueInfo)} for the distros this rank owns. A caller
+        that fetches only its own distros' tasks passes `counts` (every distro's task count, the same on every rank) and may leave the
+        task lists of the others None."""
+        ids = [d.Id for d, _ in queues]
+        if counts is None:
+            counts = [len(ts) for _, ts in queues]
+        mine = self.assign(ids, counts)
+        if not mine:
+            return {}
+        sub = [queues[i] for i in mine]
+        if any(ts is None for _, ts in sub):
+            raise ValueError("rank %d owns distro %s but was handed no task list for it" % (self.rank, next(d.Id for d, ts in sub if ts is None)))
+        res = self.planner.plan(sub, now_ns, None if opts is None else [opts[i] for i in mine], dep_lookup,
+                                None if includes_dependencies is None else [includes_dependencies[i] for i in mine])
+        return dict(zip(mine, res))
+
+    def gather(self, n_distros: int, mine: Dict[int, Tuple[List[Task], DistroQueueInfo]], dst: int = 0):
+        """Every rank's plans in one place: on rank `dst` a list over the distros of (task ids in queue order, DistroQueueInfo), elsewhere
+        None. Collective over the group (torch.distributed.gather_object); a world of one needs no process group."""
+        part = {i: ([t.Id for t in plan], info) for i, (plan, info) in mine.items()}
+        if self.world == 1:
+            parts = [part]
+        else:
+            import torch.distributed as dist
+            parts = [None] * self.world if self.rank == dst else None
+            dist.gather_object(part, parts, dst=dst, group=self.group)
+            if self.rank != dst:
+                return None
+        out: List[Optional[Tuple[List[str], DistroQueueInfo]]] = [None] * n_distros
+        for p in parts:
+            for i, v in p.items():
+                if out[i] is not None:
+                    raise RuntimeError("distro %d was planned by two ranks" % i)
+                out[i] = v
+        missing = [i for i, v in enumerate(out) if v is None]
+        if missing:
+            raise RuntimeError("no rank planned distros %s" % missing[:8])
+        return out
+
+
+def lpt_load(ids: Sequence[str], counts: Sequence[int], world: int) -> List[int]:
+    """The per-rank load lpt_owners' deal would give."""
+    own = lpt_owners(ids, counts, world)
+    load = [0] * world
+    for i, k in enumerate(ids):
+        load[own[k]] += int(counts[i]) + 1
+    return load
