@@ -1100,4 +1100,103 @@ class ResidentPlanner {
   std::vector<std::string> sig_;
 };
 
+// ---- the resident planner with one process per GPU (evergreen_amd/scheduler.py holds the same class) ---------------------
+// The path shards by distro with nothing to exchange -- the reference runs one job per distro, each reading its own distro's tasks and
+// persisting its own queue (units/crons.go:303-332) -- so a rank that is handed the task lists of the distros it OWNS needs nothing from
+// the others: it keeps their queues resident on its device (ResidentPlanner) and plans them; no data-path collective. Ownership is worked
+// out by every rank from the same (distro id, task count) table, so nothing travels for it either: greedy longest-processing-time on the
+// task counts (SURVEY 8e's partitioning), sticky afterwards (a distro stays where its queue is resident, a new one goes to the rank that
+// carries least), re-dealt only when the heaviest rank carries more than `rebalance_over` times the mean and a deal would help.
+inline std::unordered_map<std::string, int> LptOwners(const std::vector<std::string>& ids, const std::vector<int64_t>& counts, int world) {
+  std::vector<size_t> by(ids.size());
+  for (size_t i = 0; i < by.size(); i++) by[i] = i;
+  std::sort(by.begin(), by.end(), [&](size_t a, size_t b) { return counts[a] != counts[b] ? counts[a] > counts[b] : ids[a] < ids[b]; });
+  std::vector<int64_t> load((size_t)world, 0);
+  std::unordered_map<std::string, int> owner;
+  for (size_t i : by) {
+    const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());  // (the first of equals: the lowest rank)
+    owner[ids[i]] = r;
+    load[(size_t)r] += counts[i] + 1;  // (+1: an empty distro still costs a workgroup)
+  }
+  return owner;
+}
+
+class ShardedResidentPlanner {
+ public:
+  ShardedResidentPlanner(ResidentBackend be, int rank = 0, int world = 1, double rebalance_over = 1.5)
+      : planner(std::move(be)), rank_(rank), world_(world), rebalance_over_(rebalance_over) {
+    if (rank < 0 || rank >= world) throw std::invalid_argument("rank " + std::to_string(rank) + " of a world of " + std::to_string(world));
+  }
+  ResidentPlanner planner;
+  int deals = 0;  // how often the distros were dealt out (1 = never re-dealt)
+  const std::unordered_map<std::string, int>& owner() const { return owner_; }
+  const std::vector<size_t>& mine() const { return mine_; }  // indices into the last call's queues
+
+  // Updates the ownership table from this tick's (distro id, task count) rows -- the same on every rank -- and returns the indices this
+  // rank owns.
+  const std::vector<size_t>& Assign(const std::vector<std::string>& ids, const std::vector<int64_t>& counts) {
+    if (std::unordered_set<std::string>(ids.begin(), ids.end()).size() != ids.size()) throw std::invalid_argument("duplicate distro ids");
+    const std::unordered_set<std::string> known(ids.begin(), ids.end());
+    for (auto it = owner_.begin(); it != owner_.end();) it = known.count(it->first) ? std::next(it) : owner_.erase(it);
+    std::vector<int64_t> load((size_t)world_, 0);
+    std::vector<size_t> fresh;
+    for (size_t i = 0; i < ids.size(); i++) {
+      auto f = owner_.find(ids[i]);
+      if (f != owner_.end()) load[(size_t)f->second] += counts[i] + 1; else fresh.push_back(i);
+    }
+    std::sort(fresh.begin(), fresh.end(), [&](size_t a, size_t b) { return counts[a] != counts[b] ? counts[a] > counts[b] : ids[a] < ids[b]; });
+    for (size_t i : fresh) {
+      const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+      owner_[ids[i]] = r;
+      load[(size_t)r] += counts[i] + 1;
+    }
+    int64_t total = 0, heaviest = 0;
+    for (int64_t l : load) { total += l; heaviest = std::max(heaviest, l); }
+    bool deal = deals == 0;
+    if (!deal && total && (double)heaviest * world_ > rebalance_over_ * (double)total) {
+      const auto dealt = LptOwners(ids, counts, world_);
+      std::vector<int64_t> l2((size_t)world_, 0);
+      for (size_t i = 0; i < ids.size(); i++) l2[(size_t)dealt.at(ids[i])] += counts[i] + 1;
+      deal = *std::max_element(l2.begin(), l2.end()) < heaviest;
+    }
+    if (deal) { owner_ = LptOwners(ids, counts, world_); deals++; }
+    mine_.clear();
+    for (size_t i = 0; i < ids.size(); i++)
+      if (owner_.at(ids[i]) == rank_) mine_.push_back(i);
+    return mine_;
+  }
+
+  // PlanDistros' arguments on every rank (a caller that fetches only its own distros' tasks passes every distro's task count in `counts`
+  // and may leave the others' lists null); the plans of the distros this rank owns, in mine()'s order.
+  std::vector<PlannedQueue> Plan(const ResidentPlanner::Queues& queues, Time now, const std::vector<TaskPlannerOptions>* opts = nullptr,
+                                 const DepLookup& lookup = nullptr, const std::vector<bool>* includes_dependencies = nullptr,
+                                 const std::vector<int64_t>* counts = nullptr) {
+    std::vector<std::string> ids;
+    std::vector<int64_t> cnt;
+    for (size_t d = 0; d < queues.size(); d++) {
+      ids.push_back(queues[d].first->Id);
+      if (!counts && !queues[d].second) throw std::invalid_argument("distro " + ids.back() + ": neither a task list nor a task count");
+      cnt.push_back(counts ? (*counts)[d] : (int64_t)queues[d].second->size());
+    }
+    Assign(ids, cnt);
+    if (mine_.empty()) return {};
+    ResidentPlanner::Queues sub;
+    std::vector<TaskPlannerOptions> sub_opts;
+    std::vector<bool> sub_inc;
+    for (size_t i : mine_) {
+      if (!queues[i].second) throw std::invalid_argument("rank " + std::to_string(rank_) + " owns distro " + queues[i].first->Id + " but was handed no task list for it");
+      sub.push_back(queues[i]);
+      if (opts) sub_opts.push_back((*opts)[i]);
+      if (includes_dependencies) sub_inc.push_back((*includes_dependencies)[i]);
+    }
+    return planner.Plan(sub, now, opts ? &sub_opts : nullptr, lookup, includes_dependencies ? &sub_inc : nullptr);
+  }
+
+ private:
+  int rank_, world_;
+  double rebalance_over_;
+  std::unordered_map<std::string, int> owner_;
+  std::vector<size_t> mine_;
+};
+
 }  // namespace evergreen

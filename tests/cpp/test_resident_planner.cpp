@@ -91,14 +91,45 @@ static ResidentPlanner::Queues queues_of(const Tick& t) {
   return q;
 }
 
+// owners <steps> <out>: ShardedResidentPlanner::Assign over a sequence of (distro id, task count) tables, for every rank of the world --
+// the Python test compares the ownership tables, the deal counts and every rank's share with scheduler.ShardedResidentPlanner's.
+static int owners_mode(const char* steps, const char* out_path) {
+  std::ifstream f(steps);
+  if (!f) { fprintf(stderr, "cannot open %s\n", steps); return 2; }
+  FILE* o = fopen(out_path, "w");
+  int world = 0;
+  f >> world;
+  std::vector<ShardedResidentPlanner> ranks;
+  for (int r = 0; r < world; r++) ranks.emplace_back(ResidentBackend{}, r, world);
+  size_t n;
+  while (f >> n) {
+    std::vector<std::string> ids(n);
+    std::vector<int64_t> counts(n);
+    for (size_t i = 0; i < n; i++) f >> ids[i] >> counts[i];
+    for (int r = 0; r < world; r++) {
+      const auto& mine = ranks[(size_t)r].Assign(ids, counts);
+      std::map<std::string, int> sorted(ranks[(size_t)r].owner().begin(), ranks[(size_t)r].owner().end());
+      fprintf(o, "rank %d deals %d owner", r, ranks[(size_t)r].deals);
+      for (const auto& kv : sorted) fprintf(o, " %s=%d", kv.first.c_str(), kv.second);
+      fprintf(o, " mine");
+      for (size_t i : mine) fprintf(o, " %zu", i);
+      fprintf(o, "\n");
+    }
+  }
+  fclose(o);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 4) { fprintf(stderr, "usage: %s record <world> <out> | hip <lib> <world>\n", argv[0]); return 2; }
+  if (argc >= 4 && !strcmp(argv[1], "owners")) return owners_mode(argv[2], argv[3]);
+  if (argc < 4) { fprintf(stderr, "usage: %s record <world> <out> | hip <lib> <world> | owners <steps> <out>\n", argv[0]); return 2; }
   const bool record = !strcmp(argv[1], "record");
   const std::vector<Tick> ticks = read_world(record ? argv[2] : argv[3]);
   FILE* o = record ? fopen(argv[3], "w") : nullptr;
   ResidentBackend rb;
   Backend fresh;
   size_t cur_D = 0;
+  std::function<size_t()> pool_D = [&] { return cur_D; };  // the distros of the pool the planner keeps (a rank's share under EVG_TEST_WORLD)
   long long cur_N = 0;  // (record: the rows of the pool, for an identity `order` -- the plans themselves are not looked at)
   int delta_ticks = 0, refused = 0, loads_after_refusal = 0;
   const int refuse_at = getenv("EVG_TEST_REFUSE_TICK") ? atoi(getenv("EVG_TEST_REFUSE_TICK")) : 0;
@@ -127,7 +158,7 @@ int main(int argc, char** argv) {
         dump(o, "task_group_order", t.task_group_order, na); dump(o, "task_group_max_hosts", t.task_group_max_hosts, na); dump(o, "tg_key", t.tg_key, na);
         dump(o, "version_key", t.version_key, na); dump(o, "flags", t.flags, na); dump(o, "added_dep_off", t.dep_off, na + 1);
         dump(o, "a_dep_idx", t.dep_idx, ea); dump(o, "a_dep_info", t.dep_info, ea); dump(o, "a_dep_finished_ts_ns", t.dep_finished_ts_ns, ea);
-        dump(o, "tg_off", dl->tg_off, cur_D + 1); dump(o, "ver_off", dl->ver_off, cur_D + 1);
+        dump(o, "tg_off", dl->tg_off, pool_D() + 1); dump(o, "ver_off", dl->ver_off, pool_D() + 1);
         dump(o, "relinked_edges", dl->relinked_edges, nl); dump(o, "relinked_to", dl->relinked_to, nl);
       }
       if (ru) {
@@ -159,7 +190,12 @@ int main(int argc, char** argv) {
       };
     }
   }
-  ResidentPlanner planner(rb);
+  // EVG_TEST_WORLD / EVG_TEST_RANK: the same ticks through ShardedResidentPlanner -- this rank's share of the distros only
+  const int sh_world = getenv("EVG_TEST_WORLD") ? atoi(getenv("EVG_TEST_WORLD")) : 0, sh_rank = getenv("EVG_TEST_RANK") ? atoi(getenv("EVG_TEST_RANK")) : 0;
+  ShardedResidentPlanner sharded(rb, sh_world ? sh_rank : 0, sh_world ? sh_world : 1);
+  ResidentPlanner plain(rb);
+  ResidentPlanner& planner = sh_world ? sharded.planner : plain;
+  if (sh_world) pool_D = [&] { return sharded.mine().size(); };
   int by_delta = 0, fails = 0;
   for (size_t k = 0; k < ticks.size(); k++) {
     const Tick& t = ticks[k];
@@ -170,6 +206,15 @@ int main(int argc, char** argv) {
       return it->second;
     };
     const auto q = queues_of(t);
+    if (sh_world) {
+      std::vector<PlannedQueue> part = sharded.Plan(q, t.now, nullptr, lookup);
+      if (!record) { fprintf(stderr, "EVG_TEST_WORLD is for record mode\n"); return 2; }
+      fprintf(o, "SHARE deals %d mine", sharded.deals);
+      for (size_t i : sharded.mine()) fprintf(o, " %zu", i);
+      fprintf(o, " plans %zu\n", part.size());
+      if (!sharded.mine().empty()) { fprintf(o, "MODE %s\n", planner.last.mode.c_str()); by_delta += planner.last.mode == "tick"; }
+      continue;
+    }
     std::vector<PlannedQueue> got = planner.Plan(q, t.now, nullptr, lookup);
     by_delta += planner.last.mode == "tick";
     loads_after_refusal += planner.last.mode == "load" && planner.last.why.rfind("the device refused", 0) == 0;

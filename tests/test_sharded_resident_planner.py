@@ -144,3 +144,75 @@ def test_a_world_of_one_on_the_device(native_ctx, oracle):
     sp = S.ShardedResidentPlanner(S.ResidentContext(native_ctx))
     modes = _ticks(sp, w, oracle, 5, "gpu world of one", True)
     assert modes[0] == "load" and modes.count("tick") >= 3, modes
+
+
+# ---- the C++ class (include/evg_host.hpp: evergreen::ShardedResidentPlanner) against the Python one -------------------------------------
+def test_the_cpp_ownership_table_is_the_python_one(tmp_path):
+    """Every rank of a deployment may run either host layer: the two must deal the same distros to the same ranks, step after step
+    (first deal, drift, arrivals, departures, a queue that grows past the imbalance bound)."""
+    import subprocess
+
+    import numpy as np
+    from tests.test_resident_planner import _exe
+    rng = np.random.default_rng(5)
+    for world in (2, 3, 8):
+        ids = ["distro%d" % i for i in range(14)]
+        counts = [int(c) for c in rng.integers(0, 900, len(ids))]
+        steps = []
+        for k in range(12):
+            steps.append((list(ids), list(counts)))
+            counts = [max(0, c + int(rng.integers(-30, 31))) for c in counts]          # drift
+            if k % 3 == 1:
+                ids.append("late%d_%d" % (world, k)); counts.append(int(rng.integers(0, 500)))
+            if k % 4 == 2:
+                j = int(rng.integers(0, len(ids))); ids.pop(j); counts.pop(j)
+            if k == 7:
+                counts[0] = counts[0] * 40 + 20_000                                     # one queue explodes: re-dealt
+        sf, of = tmp_path / ("steps%d.txt" % world), tmp_path / ("owners%d.txt" % world)
+        with open(sf, "w") as f:
+            f.write("%d\n" % world)
+            for sids, scounts in steps:
+                f.write("%d\n" % len(sids) + "".join("%s %d\n" % (a, b) for a, b in zip(sids, scounts)))
+        r = subprocess.run([_exe(), "owners", str(sf), str(of)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = open(of).read().splitlines()
+        planners = [S.ShardedResidentPlanner(None, rank, world) for rank in range(world)]
+        want = []
+        for sids, scounts in steps:
+            for rank, sp in enumerate(planners):
+                mine = sp.assign(sids, scounts)
+                want.append("rank %d deals %d owner%s mine%s" % (rank, sp.deals, "".join(" %s=%d" % kv for kv in sorted(sp.owner.items())),
+                                                                "".join(" %d" % i for i in mine)))
+        assert got == want, next((a, b) for a, b in zip(got, want) if a != b)
+        assert planners[0].deals >= 2, "the exploding queue was re-dealt"
+
+
+@pytest.mark.parametrize("world_size,seed,D,n", [(2, 71, 6, 40), (3, 72, 9, 25)])
+def test_the_cpp_sharded_planner_hands_over_what_the_python_one_does(tmp_path, world_size, seed, D, n):
+    """Rank by rank: the share of the distros, and every array handed to evg_pool_load / evg_pool_tick for it, line for line."""
+    import subprocess
+
+    from tests.test_resident_planner import Recorder, _exe, write_world_tick
+    w = World(seed, D, n)
+    wf = tmp_path / "world.txt"
+    recs = [Recorder() for _ in range(world_size)]
+    sps = [S.ShardedResidentPlanner(recs[r], r, world_size) for r in range(world_size)]
+    with open(wf, "w") as f:
+        for k in range(6):
+            q = write_world_tick(f, w)
+            for r, sp in enumerate(sps):
+                got = sp.plan(q, w.now, dep_lookup=w.lookup)
+                recs[r].lines.append("SHARE deals %d mine%s plans %d" % (sp.deals, "".join(" %d" % i for i in sp.mine), len(got)))
+                if sp.mine:
+                    recs[r].lines.append("MODE %s" % sp.planner.last["mode"])
+            w.tick()
+    for r in range(world_size):
+        out = tmp_path / ("cpp%d.txt" % r)
+        p = subprocess.run([_exe(), "record", str(wf), str(out)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, EVG_TEST_WORLD=str(world_size), EVG_TEST_RANK=str(r), EVG_TEST_REFUSE_TICK="0"))
+        assert p.returncode == 0, p.stdout + p.stderr
+        got = open(out).read().splitlines()
+        assert len(got) == len(recs[r].lines), (r, len(got), len(recs[r].lines))
+        for i, (a, b) in enumerate(zip(got, recs[r].lines)):
+            assert a == b, "rank %d line %d (%s): the C++ planner %s... / the Python planner %s..." % (r, i, b.split()[0], a[:200], b[:200])
+        assert sum(1 for x in recs[r].lines if x == "MODE tick") >= 3
