@@ -785,20 +785,22 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     selftest, ranks_seen = None, 1
+    deadline = Deadline()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rank == 0 and not args.no_selftest:   # the other ranks wait in the rendezvous meanwhile
+        if rank == 0 and not args.no_selftest:   # the other ranks wait in the rendezvous meanwhile (their deadline covers its 240 s)
             selftest = run_multi_selftest(world)
+        ranks_seen = 0                             # until the all-reduce below has counted them
+        # (the lambda reads ranks_seen / selftest when it fires) the rendezvous and RCCL's own start-up stand under the deadline too
+        deadline.arm(args.tick_deadline_s + (0 if rank == 0 else 240), lambda: give_up(rank, unmeasured_line(args, world, ranks_seen, selftest)))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         one = torch.ones(1, dtype=torch.int64, device=dev)
         dist.all_reduce(one)                       # every rank really is there, over RCCL
         ranks_seen = int(one.item())
         if ranks_seen != world:
             raise SystemExit("bench.py: %d ranks answered the all-reduce, the world is %d" % (ranks_seen, world))
-    deadline = Deadline()
-    if world > 1:
-        deadline.arm(args.tick_deadline_s, lambda: give_up(rank, unmeasured_line(args, world, ranks_seen, selftest)))
+        deadline.arm(args.tick_deadline_s, lambda: give_up(rank, unmeasured_line(args, world, ranks_seen, selftest)))  # the clock starts again
 
     cfg_num = args.config or (3 if world == 1 else 4)
     over = {}
