@@ -216,3 +216,17 @@ def test_the_cpp_sharded_planner_hands_over_what_the_python_one_does(tmp_path, w
         for i, (a, b) in enumerate(zip(got, recs[r].lines)):
             assert a == b, "rank %d line %d (%s): the C++ planner %s... / the Python planner %s..." % (r, i, b.split()[0], a[:200], b[:200])
         assert sum(1 for x in recs[r].lines if x == "MODE tick") >= 3
+
+
+def test_more_ranks_than_distros(oracle):
+    """A rank that owns nothing plans nothing (and touches no device); the others carry one distro each."""
+    w = World(66, 2, 30)
+    q = w.queues()
+    shares = []
+    for rank in range(4):
+        be = CheckerResident(oracle)
+        sp = S.ShardedResidentPlanner(be, rank, 4)
+        got = sp.plan(q, w.now, dep_lookup=w.lookup)
+        shares.append(sorted(got))
+        assert (be.b is None) == (not got)
+    assert sorted(i for s_ in shares for i in s_) == [0, 1] and shares.count([]) == 2
