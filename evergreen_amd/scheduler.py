@@ -183,6 +183,7 @@ class Distro:
     PlannerSettings: PlannerSettings = field(default_factory=PlannerSettings)
     HostAllocatorSettings: HostAllocatorSettings = field(default_factory=HostAllocatorSettings)
     DispatcherSettings: DispatcherSettings = field(default_factory=DispatcherSettings)
+    SingleTaskDistro: bool = False                 # distro.go: one host per task; the allocator JOB bypasses the HostAllocator (below)
 
     def IsEphemeral(self) -> bool:                 # distro.go:513-515
         return self.Provider in ProviderSpawnable
@@ -622,6 +623,56 @@ def UtilizationBasedHostAllocator(backend: Backend, data: HostAllocatorData, now
 
 def GetHostAllocator(name: str):                   # scheduler/host_allocator.go:23-30
     return UtilizationBasedHostAllocator
+
+
+# ---- the caller of the HostAllocator: the allocator job's host counts (units/host_allocator.go:150-192) -----------------------------------
+# One step outside the HostAllocator value: the job first lowers the queue's LengthWithDependenciesMet when the large-parser-project limit
+# is saturated (:150), then EITHER bypasses the allocator for a single-task distro -- one host per task that can run, minus the hosts
+# already on their way, at least MinimumHosts (:174-182) -- OR calls the allocator (:183-192). A batched tick needs both branches on its
+# side of the boundary: the closed form stays on the host (three integers per distro), everything else goes through AllocateHosts.
+
+def adjust_for_large_parser_project_limit(info: DistroQueueInfo, limit: int, currently_running: int) -> DistroQueueInfo:
+    """adjustForLargeParserProjectLimit (units/host_allocator.go:478-520) without its log line and its two lookups (the caller passes
+    GetMaxConcurrentLargeParserProjTasks and CountLargeParserProjectTasks): a COPY of `info` like the Go value parameter."""
+    import dataclasses
+    if info.NumQueuedLargeParserProjectTasks == 0 or limit <= 0:
+        return info
+    remaining = max(0, limit - currently_running)
+    blocked = info.NumQueuedLargeParserProjectTasks - remaining
+    if blocked <= 0:
+        return info
+    return dataclasses.replace(info, LengthWithDependenciesMet=info.LengthWithDependenciesMet - blocked)
+
+
+@dataclass
+class HostAllocatorJobData:                        # what the job assembles for one distro (units/host_allocator.go:152-170)
+    Distro: Distro
+    UpHosts: List[Host]                            # existingHosts.Uphosts()
+    NumProvisioningHosts: int                      # len(existingHosts.ProvisioningHosts())
+    DistroQueueInfo: DistroQueueInfo               # the persisted queue's, NOT yet adjusted for the large-parser limit
+
+
+def HostAllocatorJobCounts(backend: Backend, jobs: Sequence[HostAllocatorJobData], now_ns: int, running: Optional[RunningTaskLookup] = None,
+                           large_parser: Tuple[int, int] = (0, 0)) -> List[Tuple[int, int, Optional[str]]]:
+    """(nHosts, nHostsFree, error-or-None) per distro as units/host_allocator.go:150-192 computes them: single-task distros by the job's
+    closed form (nHostsFree stays 0, the Go zero value), the others through ONE batched AllocateHosts."""
+    out: List[Optional[Tuple[int, int, Optional[str]]]] = [None] * len(jobs)
+    rest, datas = [], []
+    for i, j in enumerate(jobs):
+        if j.Distro.SingleTaskDistro:
+            info = adjust_for_large_parser_project_limit(j.DistroQueueInfo, large_parser[0], large_parser[1])   # :150
+            n = info.LengthWithDependenciesMet - j.NumProvisioningHosts                                            # :176
+            minimum = j.Distro.HostAllocatorSettings.MinimumHosts                                                 # :178-181
+            if n + len(j.UpHosts) < minimum:
+                n = minimum - len(j.UpHosts)
+            out[i] = (n, 0, None)
+        else:
+            rest.append(i)
+            datas.append(HostAllocatorData(Distro=j.Distro, ExistingHosts=j.UpHosts, DistroQueueInfo=j.DistroQueueInfo))
+    if rest:
+        for i, r in zip(rest, AllocateHosts(backend, datas, now_ns, running, large_parser)):   # (the library applies :150 to these itself)
+            out[i] = r
+    return out  # type: ignore[return-value]
 
 
 # ---- the resident pool driven from the reference's own data model (evg_pool_load / evg_pool_tick) --------------------------------------

@@ -131,6 +131,7 @@ struct Distro {
   evergreen::PlannerSettings PlannerSettings;
   evergreen::HostAllocatorSettings HostAllocatorSettings;
   struct { std::string Version; } DispatcherSettings;
+  bool SingleTaskDistro = false;  // one host per task; the allocator JOB bypasses the HostAllocator (HostAllocatorJobCounts below)
   bool IsEphemeral() const { return Provider == ProviderNameEc2Fleet || Provider == ProviderNameMock || Provider == ProviderNameDocker; }  // distro.go:513
 };
 struct Host {  // the model/host/host.go fields the allocator reads
@@ -773,6 +774,59 @@ inline std::pair<int, int> UtilizationBasedHostAllocator(const Backend& be, Host
 }
 using HostAllocator = std::function<std::pair<int, int>(const Backend&, HostAllocatorData&, Time, const RunningTaskLookup&)>;
 inline HostAllocator GetHostAllocator(const std::string& /*name*/) { return UtilizationBasedHostAllocator; }  // host_allocator.go:23-30
+
+// ---- the caller of the HostAllocator: the allocator job's host counts (units/host_allocator.go:150-192) ----------------------------
+// One step outside the HostAllocator value: the job first lowers the queue's LengthWithDependenciesMet when the large-parser-project
+// limit is saturated (:150), then EITHER bypasses the allocator for a single-task distro -- one host per task that can run, minus the
+// hosts already on their way, at least MinimumHosts (:174-182) -- OR calls the allocator (:183-192). A batched tick needs both branches
+// on its side of the boundary: the closed form stays on the host, everything else goes through ONE AllocateHosts.
+// adjustForLargeParserProjectLimit (:478-520) without its log line and its two lookups (the caller passes
+// GetMaxConcurrentLargeParserProjTasks and CountLargeParserProjectTasks); `info` by value, as in Go.
+inline DistroQueueInfo AdjustForLargeParserProjectLimit(DistroQueueInfo info, int limit, int currentlyRunning) {
+  if (info.NumQueuedLargeParserProjectTasks == 0 || limit <= 0) return info;
+  const int remainingCapacity = std::max(0, limit - currentlyRunning);
+  const int blocked = info.NumQueuedLargeParserProjectTasks - remainingCapacity;
+  if (blocked <= 0) return info;
+  info.LengthWithDependenciesMet -= blocked;
+  return info;
+}
+struct HostAllocatorJobData {  // what the job assembles for one distro (units/host_allocator.go:152-170)
+  evergreen::Distro Distro;
+  std::vector<Host> UpHosts;     // existingHosts.Uphosts()
+  int NumProvisioningHosts = 0;  // len(existingHosts.ProvisioningHosts())
+  evergreen::DistroQueueInfo DistroQueueInfo;  // the persisted queue's, NOT yet adjusted; comes back adjusted, CountFree / CountRequired filled
+};
+// (nHosts, nHostsFree, error) per distro as the job computes them; nHostsFree stays 0 on the single-task branch (the Go zero value).
+inline std::vector<AllocatorResult> HostAllocatorJobCounts(const Backend& be, std::vector<HostAllocatorJobData>& jobs, Time now,
+                                                           const RunningTaskLookup& running = nullptr, int largeParserLimit = 0,
+                                                           int largeParserRunning = 0) {
+  std::vector<AllocatorResult> out(jobs.size());
+  std::vector<size_t> rest;
+  std::vector<HostAllocatorData> datas;
+  for (size_t i = 0; i < jobs.size(); i++) {
+    HostAllocatorJobData& j = jobs[i];
+    j.DistroQueueInfo = AdjustForLargeParserProjectLimit(j.DistroQueueInfo, largeParserLimit, largeParserRunning);  // :150
+    if (j.Distro.SingleTaskDistro) {
+      int n = j.DistroQueueInfo.LengthWithDependenciesMet - j.NumProvisioningHosts;                                // :176
+      const int minimumHosts = j.Distro.HostAllocatorSettings.MinimumHosts, numExisting = (int)j.UpHosts.size();    // :178-181
+      if (n + numExisting < minimumHosts) n = minimumHosts - numExisting;
+      out[i].newHostsNeeded = n;
+    } else {
+      rest.push_back(i);
+      datas.push_back(HostAllocatorData{j.Distro, j.UpHosts, j.DistroQueueInfo});
+    }
+  }
+  if (!rest.empty()) {
+    std::vector<HostAllocatorData*> ptrs;
+    for (auto& d : datas) ptrs.push_back(&d);
+    const std::vector<AllocatorResult> got = AllocateHosts(be, ptrs, now, running);
+    for (size_t k = 0; k < rest.size(); k++) {
+      out[rest[k]] = got[k];
+      jobs[rest[k]].DistroQueueInfo.TaskGroupInfos = datas[k].DistroQueueInfo.TaskGroupInfos;  // CountFree / CountRequired (:106-109)
+    }
+  }
+  return out;
+}
 
 // ---- the resident pool driven from the reference's own data model (evg_pool_load / evg_pool_tick; late round 6) ---------------------
 // The reference re-plans every distro every 15 s (units/crons_remote_fifteen_second.go:21,58-60) from the task lists the finder returns;

@@ -276,6 +276,56 @@ static void run_finder_cases(const Backend& be) {
   EXPECT(FindRunnableTasks(be, dd, ts, [](const Task&) { return true; }, lookup).size() == 5, "FindRunnableTasks: revised-with-dependencies");
 }
 
+// The HostAllocator's caller (units/host_allocator.go:150-192): TestSingleTaskDistroHostAllocatorJob units/host_allocator_test.go:22-79
+// (queue 3 / 2 with dependencies met, one host provisioning -> 2 active hosts afterwards = ONE more) and
+// TestAdjustForLargeParserProjectLimit :245-300 (10 -> 10, 10 -> 7).
+static void run_allocator_job_cases(const Backend& be) {
+  HostAllocatorJobData job;
+  job.Distro.Id = "d"; job.Distro.SingleTaskDistro = true;
+  job.NumProvisioningHosts = 1;
+  job.DistroQueueInfo.Length = 3; job.DistroQueueInfo.LengthWithDependenciesMet = 2;
+  {
+    std::vector<HostAllocatorJobData> jobs{job};
+    const auto r = HostAllocatorJobCounts(be, jobs, NOW);
+    EXPECT(r[0].newHostsNeeded == 1 && r[0].estimatedFreeHosts == 0 && r[0].err.empty(), "single-task distro: %d new hosts, want 1 (2 active afterwards)", r[0].newHostsNeeded);
+  }
+  const int clamp[][4] = {{0, 0, 2, 5}, {3, 0, 1, 2}, {3, 2, 1, 2}, {4, 0, 3, 3}, {6, 0, 0, 0}, {0, 4, 1, 5}, {2, 9, 1, 3}};  // up, provisioning, met -> want (MinimumHosts 5)
+  for (const auto& c : clamp) {
+    HostAllocatorJobData j = job;
+    j.Distro.HostAllocatorSettings.MinimumHosts = 5;
+    j.UpHosts.assign((size_t)c[0], Host{});
+    j.NumProvisioningHosts = c[1];
+    j.DistroQueueInfo.Length = c[2] + 1; j.DistroQueueInfo.LengthWithDependenciesMet = c[2];
+    std::vector<HostAllocatorJobData> jobs{j};
+    const auto r = HostAllocatorJobCounts(be, jobs, NOW);
+    EXPECT(r[0].newHostsNeeded == c[3], "single-task distro, MinimumHosts 5: up %d provisioning %d met %d -> %d, want %d", c[0], c[1], c[2], r[0].newHostsNeeded, c[3]);
+  }
+  const int adjust[][5] = {{10, 5, 10, 2, 10}, {10, 5, 5, 3, 7}};  // length, queued large-parser tasks, limit, running -> adjusted
+  for (const auto& a : adjust) {
+    DistroQueueInfo q;
+    q.Length = a[0]; q.LengthWithDependenciesMet = a[0]; q.NumQueuedLargeParserProjectTasks = a[1];
+    EXPECT(AdjustForLargeParserProjectLimit(q, a[2], a[3]).LengthWithDependenciesMet == a[4] && q.LengthWithDependenciesMet == a[0], "adjustForLargeParserProjectLimit -> %d", a[4]);
+    HostAllocatorJobData j = job;
+    j.NumProvisioningHosts = 0; j.DistroQueueInfo = q;
+    std::vector<HostAllocatorJobData> jobs{j};
+    EXPECT(HostAllocatorJobCounts(be, jobs, NOW, nullptr, a[2], a[3])[0].newHostsNeeded == a[4], "single-task distro behind the large-parser limit -> %d", a[4]);
+  }
+  // a batched tick: a single-task distro next to NoExistingHosts (utilization_based_host_allocator_test.go:226-251: 2 new hosts, 0 free)
+  HostAllocatorJobData normal;
+  normal.Distro.Id = "testDistro"; normal.Distro.Provider = ProviderNameEc2Fleet; normal.Distro.HostAllocatorSettings.MaximumHosts = 50;
+  normal.DistroQueueInfo.Length = 5; normal.DistroQueueInfo.LengthWithDependenciesMet = 5; normal.DistroQueueInfo.ExpectedDuration = 2 * 30 * Minute + 3 * Minute;
+  normal.DistroQueueInfo.MaxDurationThreshold = 30 * Minute; normal.DistroQueueInfo.CountDurationOverThreshold = 0;
+  TaskGroupInfo g;
+  g.Count = 5; g.ExpectedDuration = normal.DistroQueueInfo.ExpectedDuration;
+  normal.DistroQueueInfo.TaskGroupInfos = {g};
+  std::vector<HostAllocatorJobData> jobs{job, normal, job};
+  const auto r = HostAllocatorJobCounts(be, jobs, NOW);
+  HostAllocatorData alone{normal.Distro, normal.UpHosts, normal.DistroQueueInfo};
+  const auto want = UtilizationBasedHostAllocator(be, alone, NOW);
+  EXPECT(r[0].newHostsNeeded == 1 && r[2].newHostsNeeded == 1 && r[1].newHostsNeeded == want.first && r[1].estimatedFreeHosts == want.second && want.first > 0,
+         "batched job counts: %d / (%d, %d) / %d, the allocator alone (%d, %d)", r[0].newHostsNeeded, r[1].newHostsNeeded, r[1].estimatedFreeHosts, r[2].newHostsNeeded, want.first, want.second);
+}
+
 static void run_planner_behaviour(const Backend& be) {
   // planner_test.go:406-432 TaskPlan: NoChange / ChangeOrder
   std::vector<Task> ts(2);
@@ -312,6 +362,7 @@ int main(int argc, char** argv) {
     run_queue_item_behaviour(be);
     run_finder_cases(be);
     run_report_cases(be);
+    run_allocator_job_cases(be);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 1;

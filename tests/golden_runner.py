@@ -174,6 +174,46 @@ def check_large_parser_limit(backend):
         assert [g[0] for g in S.AllocateHosts(backend, datas, G.NOW, None)] == [length] * 3  # no limit configured (:486)
 
 
+def check_allocator_job(backend):
+    """The HostAllocator's caller (units/host_allocator.go:150-192) -- HostAllocatorJobCounts. Pinned by the reference's
+    TestSingleTaskDistroHostAllocatorJob (units/host_allocator_test.go:22-79: a single-task distro whose persisted queue says Length 3,
+    LengthWithDependenciesMet 2, one host that is provisioning -> the job leaves 2 active hosts, i.e. asks for ONE more) and by
+    TestAdjustForLargeParserProjectLimit (:245-300: 10 -> 10 and 10 -> 7)."""
+    single = S.Distro(Id="d", SingleTaskDistro=True)
+    q = S.DistroQueueInfo(Length=3, LengthWithDependenciesMet=2)
+    job = S.HostAllocatorJobData(Distro=single, UpHosts=[], NumProvisioningHosts=1, DistroQueueInfo=q)
+    (n, free, err), = S.HostAllocatorJobCounts(backend, [job], G.NOW)
+    assert (n, free, err) == (1, 0, None) and 1 + n == 2                      # host_allocator_test.go:75-78: require.Len(hosts, 2)
+    # :178-181: at least MinimumHosts running -- counted against the hosts that are UP, whatever is provisioning
+    s5 = S.Distro(Id="d5", SingleTaskDistro=True, HostAllocatorSettings=S.HostAllocatorSettings(MinimumHosts=5))
+    for up, prov, met, want in [(0, 0, 2, 5), (3, 0, 1, 2), (3, 2, 1, 2), (4, 0, 3, 3), (6, 0, 0, 0), (0, 4, 1, 5), (2, 9, 1, 3)]:
+        j = S.HostAllocatorJobData(Distro=s5, UpHosts=[S.Host(Id="h%d" % i) for i in range(up)], NumProvisioningHosts=prov,
+                                   DistroQueueInfo=S.DistroQueueInfo(Length=met + 1, LengthWithDependenciesMet=met))
+        assert S.HostAllocatorJobCounts(backend, [j], G.NOW)[0] == (want, 0, None), (up, prov, met, want)
+    # :150 in front of the single-task branch: the reference's two vectors (length, queued large-parser tasks, limit, running, adjusted)
+    for length, queued, limit, running, want in G.ADJUST_LARGE_PARSER:
+        info = S.DistroQueueInfo(Length=length, LengthWithDependenciesMet=length, NumQueuedLargeParserProjectTasks=queued)
+        assert S.adjust_for_large_parser_project_limit(info, limit, running).LengthWithDependenciesMet == want
+        assert info.LengthWithDependenciesMet == length                        # a value parameter in Go: the caller's struct is untouched
+        j = S.HostAllocatorJobData(Distro=single, UpHosts=[], NumProvisioningHosts=0, DistroQueueInfo=info)
+        assert S.HostAllocatorJobCounts(backend, [j], G.NOW, large_parser=(limit, running))[0] == (want, 0, None)
+        assert S.HostAllocatorJobCounts(backend, [j], G.NOW)[0] == (length, 0, None)
+    # a batched tick: single-task distros between the reference's allocator scenarios -- those come back as AllocateHosts gives them
+    cases = G.allocator_cases()[:6]
+    jobs, allrun = [], {}
+    for i, (name, data, running, want, line) in enumerate(cases):
+        for h in data.ExistingHosts:
+            if h.RunningTask:
+                nid = "%d/%s" % (i, h.RunningTask)
+                if h.RunningTask in running:
+                    allrun[nid] = running[h.RunningTask]
+                h.RunningTask = nid
+        jobs.append(S.HostAllocatorJobData(Distro=data.Distro, UpHosts=data.ExistingHosts, NumProvisioningHosts=0, DistroQueueInfo=data.DistroQueueInfo))
+        jobs.append(job)
+    got = S.HostAllocatorJobCounts(backend, jobs, G.NOW, allrun.get)
+    assert [g[:2] for g in got[0::2]] == [c[3] for c in cases] and all(g == (1, 0, None) for g in got[1::2]), got
+
+
 def check_fuzz_invariants(backend, seed=1234, iters=200):
     # host_allocator_fuzzer_test.go:154-172: 0 <= newHosts <= queue length
     rng = np.random.default_rng(seed)

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("check", [
     R.check_unit_values, R.check_grouped_unit, R.check_dependency_first, R.check_task_plan_order, R.check_task_list,
     R.check_prepare, R.check_queue_info, R.check_distro_alias_order, R.check_allocator, R.check_calc_existing_free,
-    R.check_allocator_errors, R.check_in_place_group_counts, R.check_large_parser_limit], ids=lambda f: f.__name__)
+    R.check_allocator_errors, R.check_in_place_group_counts, R.check_large_parser_limit, R.check_allocator_job], ids=lambda f: f.__name__)
 def test_reference_golden_vectors(native_ctx, check):
     check(native_ctx)
 

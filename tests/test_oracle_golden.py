@@ -51,6 +51,10 @@ def test_allocator_end_to_end(oracle):
     R.check_allocator(oracle)
 
 
+def test_allocator_job_counts(oracle):
+    R.check_allocator_job(oracle)
+
+
 def test_calc_existing_free_hosts(oracle):
     R.check_calc_existing_free(oracle)
 
